@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- GDoF/s of the matrix-free 3-D DG stiffness apply (Au = K u), p = 7, fp64.
+
+Contract (see the task statement):  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; the volume
+stiffness apply is element-independent, so ranks own disjoint Morton shards and the data
+path has NO collective (weak scaling: every rank owns one config-2 brick's worth of
+elements).  A step = one stiffness apply over the rank's whole shard, inputs resident in HBM.
+
+Rank 0 prints ONE JSON line on stdout.  Everything else goes to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes_per_dof(N, NQ):
+    """read u (8) + write Au (8) + 6 symmetric metric entries per quadrature node."""
+    return 16.0 + 48.0 * (NQ / N) ** 3
+
+
+def cpu_baseline(mesh, J, rst, u, budget_s=12.0):
+    """Times the CPU restatement of the reference algorithm (oracle, kind "port") on the host
+    cores of this box, on a bounded sample of the same workload."""
+    from tests import oracle_lib
+    oracle = oracle_lib.load()
+    cores = min(os.cpu_count() or 1, 64)
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    # sample: leading elements of the same mesh (same p, same geometry layout); sized for ~budget_s
+    from disco4est_amd import mesh as M
+    probe = M.BrickMesh(mesh.level, int(mesh.deg[0]), quad_type=mesh.quad_type, first=0, count=min(mesh.n_elements, 8 * cores))
+    Jp, rstp = probe.geometry(None)
+    up = np.ascontiguousarray(u[:probe.local_nodes])
+    t0 = time.perf_counter()
+    oracle.apply_stiffness(probe, Jp, rstp, up, nthreads=cores)
+    t_probe = max(time.perf_counter() - t0, 1e-6)
+    per_elem = t_probe / probe.n_elements
+    n_sample = int(max(cores, min(mesh.n_elements, budget_s / 3.0 / per_elem)))
+    sample = M.BrickMesh(mesh.level, int(mesh.deg[0]), quad_type=mesh.quad_type, first=0, count=n_sample)
+    Js, rsts = sample.geometry(None)
+    us = np.ascontiguousarray(u[:sample.local_nodes])
+    oracle.apply_stiffness(sample, Js, rsts, us, nthreads=cores)  # warm-up
+    reps, t_acc = 0, 0.0
+    while reps < 2 or (t_acc < budget_s * 0.6 and reps < 50):
+        t0 = time.perf_counter()
+        oracle.apply_stiffness(sample, Js, rsts, us, nthreads=cores)
+        t_acc += time.perf_counter() - t0
+        reps += 1
+    gdofs = sample.local_nodes * reps / t_acc / 1e9
+    return {
+        "value": gdofs, "unit": "GDoF/s", "cores": cores, "kind": "port",
+        "sample": "%d of %d elements (p=%d) of the same brick, %d reps, %d OpenMP threads over elements; "
+                  "oracle/d4est_oracle.c (27-pass reference algorithm, naive row-major dgemm, gcc -O2)"
+                  % (sample.n_elements, mesh.n_elements, int(mesh.deg[0]), reps, cores),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--level", type=int, default=4)
+    ap.add_argument("--deg", type=int, default=7)
+    ap.add_argument("--deg-quad-inc", type=int, default=0)
+    ap.add_argument("--geometry", choices=["affine", "sine"], default="affine")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from disco4est_amd import Plan, build, mesh as M
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if build.needs_build():
+        if rank == 0:
+            build.build_library(verbose=False)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.barrier()
+
+    # ---- workload: config 2 of BASELINE.json, one brick per rank (weak scaling)
+    mesh = M.BrickMesh(args.level, args.deg, deg_quad_inc=args.deg_quad_inc)
+    mp = M.SineMap(0.05) if args.geometry == "sine" else None
+    J, rst = mesh.geometry(mp)
+    u = mesh.field(mp, seed=102321 + rank)
+    N, NQ = args.deg + 1, args.deg + args.deg_quad_inc + 1
+
+    stream = torch.cuda.current_stream()
+    plan = Plan(mesh.deg, mesh.deg_quad, mesh.nodal_stride, mesh.quad_stride, 0, stream=stream)
+    plan.set_geometry(J, rst)
+    du = torch.from_numpy(u).to(dev)
+    dAu = torch.empty_like(du)
+
+    # ---- parity gate on a sample before any timing is reported
+    if not args.no_check and rank == 0:
+        from tests import oracle_lib
+        oracle = oracle_lib.load()
+        plan.apply_stiffness_matrix(du, dAu)
+        got = dAu.cpu().numpy()
+        worst = 0.0
+        for e in range(0, mesh.n_elements, max(1, mesh.n_elements // 16)):
+            sub = M.BrickMesh(args.level, args.deg, deg_quad_inc=args.deg_quad_inc, first=e, count=1)
+            Je, rste = sub.geometry(mp)
+            s, n3 = mesh.nodal_stride[e], N ** 3
+            ref = oracle.apply_stiffness(sub, Je, rste, np.ascontiguousarray(u[s:s + n3]))
+            worst = max(worst, np.abs(got[s:s + n3] - ref).max() / np.abs(ref).max())
+        log("parity vs oracle on sampled elements: rel-inf = %.3e" % worst)
+        if not worst <= 1e-12:
+            raise SystemExit("parity gate failed: %.3e" % worst)
+
+    # ---- warm-up, then time exactly K steps
+    for _ in range(args.warmup):
+        plan.apply_stiffness_matrix(du, dAu)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        plan.apply_stiffness_matrix(du, dAu)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream: average launch duration
+
+    if dist is not None:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = t[0].item(), t[1].item()
+
+    dofs_per_rank = mesh.local_nodes
+    total_dofs = dofs_per_rank * world
+    value = total_dofs * args.steps / elapsed / 1e9
+    bpd = algorithmic_bytes_per_dof(N, NQ)
+    achieved = bpd * dofs_per_rank / (kernel_ms * 1e-3) / 1e9  # GB/s of the dominant kernel on one GPU
+
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            rec = json.load(open(tf))
+            key = "level%d_p%d_inc%d" % (args.level, args.deg, args.deg_quad_inc)
+            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "GDoF/s for matrix-free 3D DG stiffness apply (Ax), p=%d" % args.deg,
+        "value": value,
+        "unit": "GDoF/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "3D Poisson stiffness apply on a single-tree brick, uniform level=%d (%d elements/GPU), p=%d, "
+                        "deg_quad=deg+%d, Gauss-Legendre; general path (per-node symmetric metric streamed, %s values)"
+                        % (args.level, mesh.n_elements, args.deg, args.deg_quad_inc, args.geometry),
+            "dofs_per_gpu": dofs_per_rank,
+            "elements_per_gpu": mesh.n_elements,
+            "sharding": "one Morton-contiguous brick per rank, no data-path collective",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel": "d4est_hip::stiffness_kernel<%d,%d>" % (N, NQ),
+            "kernel_avg_ms": kernel_ms,
+            "algorithmic_bytes_per_dof": bpd,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(mesh, J, rst, u)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+"""ctypes binding of libd4est_hip.so (include/d4est_hip.h).
+
+Only plumbing lives here: argument marshalling and a ``Plan`` class whose methods
+take torch CUDA tensors and pass their ``data_ptr()`` through the C-ABI.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libd4est_hip.so")
+
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/d4est_hip.h one to one
+SIGNATURES = {
+    "d4est_hip_version": (ctypes.c_char_p, []),
+    "d4est_hip_device_count": (ctypes.c_int, []),
+    "d4est_hip_table": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p]),
+    "d4est_hip_malloc": (_vp, [ctypes.c_size_t]),
+    "d4est_hip_free": (None, [_vp]),
+    "d4est_hip_memcpy_h2d": (None, [_vp, _vp, ctypes.c_size_t]),
+    "d4est_hip_memcpy_d2h": (None, [_vp, _vp, ctypes.c_size_t]),
+    "d4est_hip_memset": (None, [_vp, ctypes.c_int, ctypes.c_size_t]),
+    "d4est_hip_device_synchronize": (None, []),
+    "d4est_hip_plan_create": (_vp, [ctypes.c_int, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int]),
+    "d4est_hip_plan_destroy": (None, [_vp]),
+    "d4est_hip_plan_set_stream": (None, [_vp, _vp]),
+    "d4est_hip_plan_local_nodes": (ctypes.c_int, [_vp]),
+    "d4est_hip_plan_local_nodes_quad": (ctypes.c_int, [_vp]),
+    "d4est_hip_plan_n_elements": (ctypes.c_int, [_vp]),
+    "d4est_hip_plan_set_geometry": (None, [_vp, _vp, _vp, ctypes.c_int]),
+    "d4est_hip_apply_stiffness_matrix": (None, [_vp, _vp, _vp]),
+    "d4est_hip_apply_mass_matrix": (None, [_vp, _vp, _vp]),
+    "d4est_hip_apply_galerkin_integral": (None, [_vp, _vp, _vp]),
+    "d4est_hip_interpolate": (None, [_vp, _vp, _vp]),
+    "d4est_hip_compute_dudr": (None, [_vp, _vp, _vp, _vp, _vp]),
+    "d4est_hip_apply_stiffness_matrix_host": (None, [_vp, _vp, _vp]),
+}
+
+TABLE = {
+    "lobatto_nodes": 0, "lobatto_weights": 1, "gauss_nodes": 2, "gauss_weights": 3,
+    "dij": 4, "mij": 5, "invmij": 6, "lobatto_to_gauss": 7,
+    "p_prolong": 8, "hp_prolong": 9, "p_restrict": 10, "hp_restrict": 11,
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libd4est_hip.so and attach the signatures.  Fails loudly when absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "libd4est_hip.so not found at %s -- build it with `python -m disco4est_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % p)
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def table(name, deg_a, deg_b=0):
+    """1-D operator table as a numpy array (host-side, no GPU needed)."""
+    lib = load_library()
+    tid = TABLE[name]
+    n = lib.d4est_hip_table(tid, int(deg_a), int(deg_b), None)
+    out = np.empty(n, dtype=np.float64)
+    lib.d4est_hip_table(tid, int(deg_a), int(deg_b), out.ctypes.data_as(_c_double_p))
+    return out
+
+
+def _ptr(t):
+    """Device pointer of a contiguous float64 torch CUDA tensor."""
+    import torch
+    assert isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), \
+        "expected a contiguous float64 CUDA tensor"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _iarr(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_c_int_p)
+
+
+class Plan:
+    """Host mirror of a d4est mesh level: element arrays + geometric factors on the device.
+
+    Argument meaning follows d4est_element_data_t (src/Mesh/d4est_element_data.h:13-48) and
+    d4est_mesh_data_t (src/Mesh/d4est_mesh.h:123-169) of the reference.
+    """
+
+    def __init__(self, deg, deg_quad, nodal_stride, quad_stride, quad_type=0, stream=None):
+        self.lib = load_library()
+        self._keep = [_iarr(deg), _iarr(deg_quad), _iarr(nodal_stride), _iarr(quad_stride)]
+        n = len(self._keep[0][0])
+        self.handle = self.lib.d4est_hip_plan_create(n, self._keep[0][1], self._keep[1][1], self._keep[2][1],
+                                                     self._keep[3][1], int(quad_type))
+        self.n_elements = n
+        self.local_nodes = self.lib.d4est_hip_plan_local_nodes(self.handle)
+        self.local_nodes_quad = self.lib.d4est_hip_plan_local_nodes_quad(self.handle)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        """stream: a torch.cuda.Stream (its raw hipStream_t is passed through) or an int handle."""
+        h = getattr(stream, "cuda_stream", stream)
+        self.lib.d4est_hip_plan_set_stream(self.handle, ctypes.c_void_p(int(h)))
+
+    def set_geometry(self, J_quad, rst_xyz_quad):
+        """J_quad[local_nodes_quad], rst_xyz_quad[9*local_nodes_quad] (reference SoA layout);
+        numpy arrays (host) or torch CUDA tensors (device)."""
+        if isinstance(J_quad, np.ndarray):
+            J = np.ascontiguousarray(J_quad, dtype=np.float64)
+            R = np.ascontiguousarray(rst_xyz_quad, dtype=np.float64).reshape(-1)
+            assert J.size == self.local_nodes_quad and R.size == 9 * self.local_nodes_quad
+            self.lib.d4est_hip_plan_set_geometry(self.handle, J.ctypes.data_as(_vp), R.ctypes.data_as(_vp), 0)
+        else:
+            assert J_quad.numel() == self.local_nodes_quad and rst_xyz_quad.numel() == 9 * self.local_nodes_quad
+            self.lib.d4est_hip_plan_set_geometry(self.handle, _ptr(J_quad), _ptr(rst_xyz_quad), 1)
+
+    def apply_stiffness_matrix(self, u, Au):
+        assert u.numel() == self.local_nodes and Au.numel() == self.local_nodes
+        self.lib.d4est_hip_apply_stiffness_matrix(self.handle, _ptr(u), _ptr(Au))
+
+    def apply_mass_matrix(self, u, Mu):
+        assert u.numel() == self.local_nodes and Mu.numel() == self.local_nodes
+        self.lib.d4est_hip_apply_mass_matrix(self.handle, _ptr(u), _ptr(Mu))
+
+    def apply_galerkin_integral(self, f_quad, out):
+        assert f_quad.numel() == self.local_nodes_quad and out.numel() == self.local_nodes
+        self.lib.d4est_hip_apply_galerkin_integral(self.handle, _ptr(f_quad), _ptr(out))
+
+    def interpolate(self, u, u_quad):
+        assert u.numel() == self.local_nodes and u_quad.numel() == self.local_nodes_quad
+        self.lib.d4est_hip_interpolate(self.handle, _ptr(u), _ptr(u_quad))
+
+    def compute_dudr(self, u, d0, d1, d2):
+        for t in (u, d0, d1, d2):
+            assert t.numel() == self.local_nodes
+        self.lib.d4est_hip_compute_dudr(self.handle, _ptr(u), _ptr(d0), _ptr(d1), _ptr(d2))
+
+    def apply_stiffness_matrix_host(self, u_host):
+        u = np.ascontiguousarray(u_host, dtype=np.float64)
+        assert u.size == self.local_nodes
+        out = np.empty_like(u)
+        self.lib.d4est_hip_apply_stiffness_matrix_host(self.handle, u.ctypes.data_as(_vp), out.ctypes.data_as(_vp))
+        return out
+
+    def destroy(self):
+        if self.handle:
+            self.lib.d4est_hip_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -1,0 +1,224 @@
+// extern "C" entry points of libd4est_hip.so (declared in include/d4est_hip.h):
+// tables, device-memory helpers, plan life cycle and the volume applies.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <utility>
+
+#include "d4est_hip_internal.h"
+#include "d4est_hip_tables.h"
+
+using d4est_hip::Bucket;
+using d4est_hip::Tables1D;
+
+namespace {
+
+double* upload(const std::vector<double>& v) {
+  double* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(double)));
+  if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+  return d;
+}
+
+int* upload_i(const std::vector<int>& v) {
+  int* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(int)));
+  if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+  return d;
+}
+
+void check_plan(const d4est_hip_plan_t* plan, const char* fn) {
+  if (!plan) D4EST_HIP_ABORT("%s: NULL plan", fn);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* d4est_hip_version(void) { return "d4est_hip 0.1 (gfx950)"; }
+
+int d4est_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int d4est_hip_table(int table_id, int deg_a, int deg_b, double* out_host) {
+  std::vector<double> t, tmp;
+  switch (table_id) {
+    case D4EST_HIP_TABLE_LOBATTO_NODES: Tables1D::lobatto(deg_a, t, tmp); break;
+    case D4EST_HIP_TABLE_LOBATTO_WEIGHTS: Tables1D::lobatto(deg_a, tmp, t); break;
+    case D4EST_HIP_TABLE_GAUSS_NODES: Tables1D::gauss(deg_a, t, tmp); break;
+    case D4EST_HIP_TABLE_GAUSS_WEIGHTS: Tables1D::gauss(deg_a, tmp, t); break;
+    case D4EST_HIP_TABLE_DIJ: t = Tables1D::dij(deg_a); break;
+    case D4EST_HIP_TABLE_MIJ: t = Tables1D::mij(deg_a); break;
+    case D4EST_HIP_TABLE_INVMIJ: t = Tables1D::invmij(deg_a); break;
+    case D4EST_HIP_TABLE_LOBATTO_TO_GAUSS: t = Tables1D::lobatto_to_gauss(deg_a, deg_b); break;
+    case D4EST_HIP_TABLE_P_PROLONG: t = Tables1D::p_prolong(deg_a, deg_b); break;
+    case D4EST_HIP_TABLE_HP_PROLONG: t = Tables1D::hp_prolong(deg_a, deg_b); break;
+    case D4EST_HIP_TABLE_P_RESTRICT: t = Tables1D::p_restrict(deg_a, deg_b); break;
+    case D4EST_HIP_TABLE_HP_RESTRICT: t = Tables1D::hp_restrict(deg_a, deg_b); break;
+    default: D4EST_HIP_ABORT("d4est_hip_table: unknown table id %d", table_id);
+  }
+  if (out_host) std::memcpy(out_host, t.data(), t.size() * sizeof(double));
+  return (int)t.size();
+}
+
+void* d4est_hip_malloc(size_t bytes) {
+  void* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+  return p;
+}
+void d4est_hip_free(void* p) {
+  if (p) HIP_CHECK(hipFree(p));
+}
+void d4est_hip_memcpy_h2d(void* dst, const void* src, size_t bytes) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
+void d4est_hip_memcpy_d2h(void* dst, const void* src, size_t bytes) { HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); }
+void d4est_hip_memset(void* dst, int value, size_t bytes) { HIP_CHECK(hipMemset(dst, value, bytes)); }
+void d4est_hip_device_synchronize(void) { HIP_CHECK(hipDeviceSynchronize()); }
+
+d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
+                                        const int* quad_stride, int quad_type) {
+  if (n_elements < 0) D4EST_HIP_ABORT("plan_create: n_elements = %d", n_elements);
+  if (n_elements > 0 && (!deg || !deg_quad || !nodal_stride || !quad_stride)) D4EST_HIP_ABORT("plan_create: NULL element array");
+  if (quad_type != D4EST_HIP_QUAD_LEGENDRE && quad_type != D4EST_HIP_QUAD_LOBATTO) D4EST_HIP_ABORT("plan_create: unknown quadrature type %d", quad_type);
+  d4est_hip_plan_t* plan = new d4est_hip_plan_t();
+  plan->n_elements = n_elements;
+  plan->quad_type = quad_type;
+  plan->deg.assign(deg, deg + n_elements);
+  plan->deg_quad.assign(deg_quad, deg_quad + n_elements);
+  plan->nodal_stride.assign(nodal_stride, nodal_stride + n_elements);
+  plan->quad_stride.assign(quad_stride, quad_stride + n_elements);
+
+  // bucket by (deg, deg_quad); keep element order inside a bucket (Morton order of the caller)
+  std::map<std::pair<int, int>, std::vector<int>> groups;
+  long long ln = 0, lq = 0;
+  for (int e = 0; e < n_elements; ++e) {
+    const int p = deg[e], pq = deg_quad[e];
+    if (p < 1 || p > Tables1D::kMaxDeg || pq < 1 || pq > Tables1D::kMaxDeg)
+      D4EST_HIP_ABORT("plan_create: element %d has deg %d / deg_quad %d outside [1,%d]", e, p, pq, Tables1D::kMaxDeg);
+    groups[{p, pq}].push_back(e);
+    const long long n3 = (long long)(p + 1) * (p + 1) * (p + 1), q3 = (long long)(pq + 1) * (pq + 1) * (pq + 1);
+    ln = std::max(ln, nodal_stride[e] + n3);
+    lq = std::max(lq, quad_stride[e] + q3);
+  }
+  if (ln > 0x7fffffffLL || lq > 0x7fffffffLL) D4EST_HIP_ABORT("plan_create: local_nodes exceeds 32-bit int (reference strides are int)");
+  plan->local_nodes = (int)ln;
+  plan->local_nodes_quad = (int)lq;
+
+  std::vector<int> ids;
+  ids.reserve(n_elements);
+  for (auto& kv : groups) {
+    Bucket bk;
+    bk.deg = kv.first.first;
+    bk.deg_quad = kv.first.second;
+    bk.N = bk.deg + 1;
+    bk.NQ = bk.deg_quad + 1;
+    bk.n_elem = (int)kv.second.size();
+    bk.elem_offset = (int)ids.size();
+    ids.insert(ids.end(), kv.second.begin(), kv.second.end());
+    std::vector<double> B = Tables1D::quad_interp(quad_type, bk.deg, bk.deg_quad);
+    std::vector<double> D = Tables1D::dij(bk.deg);
+    std::vector<double> G = Tables1D::matmul(B, D, bk.NQ, bk.N, bk.N);
+    bk.d_B = upload(B);
+    bk.d_G = upload(G);
+    bk.d_D = upload(D);
+    bk.d_w = upload(Tables1D::quad_weights(quad_type, bk.deg_quad));
+    plan->buckets.push_back(bk);
+  }
+  plan->d_elem_ids = upload_i(ids);
+  plan->d_nodal_stride = upload_i(plan->nodal_stride);
+  plan->d_quad_stride = upload_i(plan->quad_stride);
+  return plan;
+}
+
+void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
+  if (!plan) return;
+  for (Bucket& bk : plan->buckets) {
+    hipFree(bk.d_B);
+    hipFree(bk.d_G);
+    hipFree(bk.d_D);
+    hipFree(bk.d_w);
+  }
+  hipFree(plan->d_elem_ids);
+  hipFree(plan->d_nodal_stride);
+  hipFree(plan->d_quad_stride);
+  hipFree(plan->d_J);
+  hipFree(plan->d_metric);
+  hipFree(plan->d_scratch);
+  delete plan;
+}
+
+void d4est_hip_plan_set_stream(d4est_hip_plan_t* plan, void* hip_stream) {
+  check_plan(plan, "plan_set_stream");
+  plan->stream = reinterpret_cast<hipStream_t>(hip_stream);
+}
+
+int d4est_hip_plan_local_nodes(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes"); return plan->local_nodes; }
+int d4est_hip_plan_local_nodes_quad(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes_quad"); return plan->local_nodes_quad; }
+int d4est_hip_plan_n_elements(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_n_elements"); return plan->n_elements; }
+
+void d4est_hip_plan_set_geometry(d4est_hip_plan_t* plan, const double* J_quad, const double* rst_xyz_quad, int on_device) {
+  check_plan(plan, "plan_set_geometry");
+  if (!J_quad || !rst_xyz_quad) D4EST_HIP_ABORT("plan_set_geometry: NULL geometry array");
+  const size_t nq = (size_t)plan->local_nodes_quad;
+  if (!plan->d_J) HIP_CHECK(hipMalloc(&plan->d_J, std::max<size_t>(nq, 1) * sizeof(double)));
+  if (!plan->d_metric) HIP_CHECK(hipMalloc(&plan->d_metric, std::max<size_t>(6 * nq, 1) * sizeof(double)));
+  const double* d_rst = rst_xyz_quad;
+  double* tmp_rst = nullptr;
+  if (on_device) {
+    HIP_CHECK(hipMemcpyAsync(plan->d_J, J_quad, nq * sizeof(double), hipMemcpyDeviceToDevice, plan->stream));
+  } else {
+    HIP_CHECK(hipMemcpy(plan->d_J, J_quad, nq * sizeof(double), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc(&tmp_rst, std::max<size_t>(9 * nq, 1) * sizeof(double)));
+    HIP_CHECK(hipMemcpy(tmp_rst, rst_xyz_quad, 9 * nq * sizeof(double), hipMemcpyHostToDevice));
+    d_rst = tmp_rst;
+  }
+  d4est_hip::launch_metric_precombine(plan, plan->d_J, d_rst);
+  if (tmp_rst) {
+    HIP_CHECK(hipStreamSynchronize(plan->stream));
+    HIP_CHECK(hipFree(tmp_rst));
+  }
+  plan->has_geometry = true;
+}
+
+void d4est_hip_apply_stiffness_matrix(d4est_hip_plan_t* plan, const double* u_dev, double* Au_dev) {
+  check_plan(plan, "apply_stiffness_matrix");
+  d4est_hip::launch_stiffness(plan, u_dev, Au_dev);
+}
+
+void d4est_hip_apply_mass_matrix(d4est_hip_plan_t* plan, const double* u_dev, double* Mu_dev) {
+  check_plan(plan, "apply_mass_matrix");
+  d4est_hip::launch_mass_like(plan, 0, u_dev, Mu_dev);
+}
+
+void d4est_hip_apply_galerkin_integral(d4est_hip_plan_t* plan, const double* f_quad_dev, double* out_dev) {
+  check_plan(plan, "apply_galerkin_integral");
+  d4est_hip::launch_mass_like(plan, 1, f_quad_dev, out_dev);
+}
+
+void d4est_hip_interpolate(d4est_hip_plan_t* plan, const double* u_dev, double* u_quad_dev) {
+  check_plan(plan, "interpolate");
+  d4est_hip::launch_mass_like(plan, 2, u_dev, u_quad_dev);
+}
+
+void d4est_hip_compute_dudr(d4est_hip_plan_t* plan, const double* u_dev, double* dudr0_dev, double* dudr1_dev, double* dudr2_dev) {
+  check_plan(plan, "compute_dudr");
+  d4est_hip::launch_dudr(plan, u_dev, dudr0_dev, dudr1_dev, dudr2_dev);
+}
+
+void d4est_hip_apply_stiffness_matrix_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host) {
+  check_plan(plan, "apply_stiffness_matrix_host");
+  const size_t bytes = (size_t)plan->local_nodes * sizeof(double);
+  double *du = nullptr, *dAu = nullptr;
+  HIP_CHECK(hipMalloc(&du, std::max<size_t>(bytes, 8)));
+  HIP_CHECK(hipMalloc(&dAu, std::max<size_t>(bytes, 8)));
+  HIP_CHECK(hipMemcpyAsync(du, u_host, bytes, hipMemcpyHostToDevice, plan->stream));
+  d4est_hip::launch_stiffness(plan, du, dAu);
+  HIP_CHECK(hipMemcpyAsync(Au_host, dAu, bytes, hipMemcpyDeviceToHost, plan->stream));
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  HIP_CHECK(hipFree(du));
+  HIP_CHECK(hipFree(dAu));
+}
+
+}  // extern "C"

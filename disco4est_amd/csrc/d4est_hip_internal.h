@@ -1,0 +1,74 @@
+// Internal declarations shared by the HIP translation units of libd4est_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/d4est_hip.h"
+
+#define D4EST_HIP_ABORT(...)                                   \
+  do {                                                         \
+    std::fprintf(stderr, "[D4EST_HIP_ABORT] ");                \
+    std::fprintf(stderr, __VA_ARGS__);                         \
+    std::fprintf(stderr, " (%s:%d)\n", __FILE__, __LINE__);    \
+    std::abort();                                              \
+  } while (0)
+
+#define HIP_CHECK(expr)                                                              \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) D4EST_HIP_ABORT("%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+namespace d4est_hip {
+
+// One (deg, deg_quad) bucket of elements; launches are per bucket so N and NQ are
+// compile-time constants inside the kernels.
+struct Bucket {
+  int deg = 0, deg_quad = 0;
+  int N = 0, NQ = 0;
+  int n_elem = 0;
+  int elem_offset = 0;      // offset into Plan::d_elem_ids
+  // device 1-D tables (row-major)
+  double* d_B = nullptr;    // NQ x N  interpolation Lobatto -> quadrature nodes
+  double* d_G = nullptr;    // NQ x N  G = B * D  (derivative evaluated at quadrature nodes)
+  double* d_D = nullptr;    // N x N   collocation derivative
+  double* d_w = nullptr;    // NQ      quadrature weights
+};
+
+}  // namespace d4est_hip
+
+struct d4est_hip_plan {
+  int n_elements = 0;
+  int local_nodes = 0;
+  int local_nodes_quad = 0;
+  int quad_type = 0;
+  hipStream_t stream = nullptr;
+
+  std::vector<int> deg, deg_quad, nodal_stride, quad_stride;  // host copies
+  std::vector<d4est_hip::Bucket> buckets;
+
+  int* d_elem_ids = nullptr;      // element ids sorted by bucket
+  int* d_nodal_stride = nullptr;  // by element id
+  int* d_quad_stride = nullptr;   // by element id
+
+  bool has_geometry = false;
+  double* d_J = nullptr;          // local_nodes_quad  (reference layout)
+  double* d_metric = nullptr;     // 6 * local_nodes_quad, element-blocked: [e][c][n], c in (rr,rs,rt,ss,st,tt)
+
+  // generic-path scratch (allocated lazily)
+  double* d_scratch = nullptr;
+  size_t scratch_doubles = 0;
+};
+
+namespace d4est_hip {
+
+// d4est_hip_volume.hip
+void launch_metric_precombine(d4est_hip_plan* plan, const double* d_J, const double* d_rst);
+void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
+void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out);
+void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, double* d2);
+
+}  // namespace d4est_hip

@@ -1,0 +1,711 @@
+// Volume (element-local) kernels of the MI355X DG engine: stiffness, mass-like
+// applies, collocation derivatives and the geometry pre-combination.
+//
+// Replaces, for all local elements at once:
+//   d4est_quadrature_apply_stiffness_matrix  (src/Quadrature/d4est_quadrature.c:263-382)
+//   d4est_quadrature_apply_mass_matrix       (:385-477)
+//   d4est_quadrature_apply_galerkin_integral (:142-213)
+//   d4est_quadrature_interpolate             (:966-1016)
+//   d4est_laplacian_compute_dudr             (src/dGMath/d4est_laplacian.c:237-282)
+//
+// Design (gfx950): the 27-pass reference loop is fused into ONE sum-factorised
+// pass  out = sum_lp D_lp^T V^T [ W J G_{lp,l} (V D_l u) ].  One element is owned
+// by NQ*NQ threads (one 64-lane wavefront at p = 7); each thread keeps a whole
+// tensor COLUMN in registers and contracts it with the 1-D operator, whose entries
+// are wave-uniform and come from scalar loads.  Between the three tensor
+// directions the columns are transposed through LDS with an odd (padded) leading
+// dimension so that every column read is bank-conflict free.  HBM traffic per
+// element is the algorithmic minimum: u once, the 6-entry symmetric metric once,
+// Au once (64 B/DoF at Nq = N).
+#include "d4est_hip_internal.h"
+
+namespace d4est_hip {
+
+// ---------------------------------------------------------------------------
+// compile-time configuration per (N, NQ)
+// ---------------------------------------------------------------------------
+template <int N, int NQ>
+struct VolCfg {
+  static_assert(NQ >= N, "quadrature degree below polynomial degree is served by the generic path");
+  static constexpr int PL = NQ * NQ;                                   // threads per element
+  static constexpr int EPB = (PL <= 64) ? (64 / PL) : 1;               // elements per block
+  static constexpr int THREADS = (PL <= 64) ? 64 : ((PL + 63) / 64) * 64;
+  static constexpr int PN = N | 1;                                     // odd padded column lengths
+  static constexpr int PQ = NQ | 1;
+  static constexpr int FS = NQ * NQ * PQ;                              // doubles per LDS field
+  static constexpr int LDS_PER_ELEM = 3 * FS;
+  static constexpr size_t LDS_BYTES = (size_t)EPB * LDS_PER_ELEM * sizeof(double);
+};
+
+// The 1-D operator entries are wave-uniform: they are fetched with scalar loads
+// (s_load) and feed v_fma_f64 as SGPR operands.  `launder` hides the pointer's
+// provenance from the optimiser once per operator ROW, so identical loads are not
+// CSE'd across stages (which would keep 128+ doubles live in SGPRs and spill them
+// through v_readlane); each row (<= 16 doubles) lives only for its own FMAs.
+// The laundered pointer is re-typed to the constant address space (4) so the
+// backend keeps emitting s_load_dwordx* for it.
+typedef const double __attribute__((address_space(4))) * sdouble_ptr;
+__device__ __forceinline__ sdouble_ptr launder(const double* p) {
+  unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  asm volatile("" : "+s"(v));
+  return (sdouble_ptr)v;
+}
+
+// y = op x, op is NO x NI row-major
+template <int NI, int NO>
+__device__ __forceinline__ void contract_n(const double* __restrict__ op, const double* x, double* y) {
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    sdouble_ptr row = launder(op + o * NI);
+    double s = row[0] * x[0];
+#pragma unroll
+    for (int i = 1; i < NI; ++i) s = fma(row[i], x[i], s);
+    y[o] = s;
+  }
+}
+
+// y (+)= op^T x, op is NI x NO row-major.  Loop order i-outer so that each scalar
+// row op[i][0..NO) is consumed by NO independent FMA chains.
+template <int NI, int NO, bool ACC>
+__device__ __forceinline__ void contract_t(const double* __restrict__ op, const double* x, double* y) {
+  if (!ACC) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) y[o] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    sdouble_ptr row = launder(op + i * NO);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) y[o] = fma(row[o], x[i], y[o]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// stiffness:  Au_e = sum_{lp,l} D_lp^T V^T [ M_{lp,l} (V D_l u_e) ]
+// ---------------------------------------------------------------------------
+template <int N, int NQ>
+__global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
+    const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
+    const int* __restrict__ elem_ids, const int* __restrict__ nodal_stride, const int* __restrict__ quad_stride,
+    int n_bucket, const double* __restrict__ Bop, const double* __restrict__ Gop) {
+  using C = VolCfg<N, NQ>;
+  constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
+  constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const int tid = threadIdx.x;
+  const int slot = tid / PL;
+  const int te = tid - slot * PL;
+  const int a = te % NQ, b = te / NQ;
+  const int ei = blockIdx.x * C::EPB + slot;
+  const bool active = (slot < C::EPB) && (ei < n_bucket);
+  double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
+  double* R1 = R0 + FS;
+  double* R2 = R1 + FS;
+
+  int ns = 0, qs = 0;
+  if (active) {
+    const int e = elem_ids[ei];
+    ns = nodal_stride[e];
+    qs = quad_stride[e];
+  }
+
+  // ---- load u_e (coalesced) into R0[k][j][i], i fastest, padded PN
+  if (active) {
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      R0[i + PN * (j + N * k)] = u[ns + idx];
+    }
+  }
+  __syncthreads();
+
+  // ---- S1: r-contraction, thread (j=a, k=b): B u and G u along i -> R1,R2 [k][iq][j]
+  if (active && a < N && b < N) {
+    double x[N], br[NQ], gr[NQ];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+    contract_n<N, NQ>(Bop, x, br);
+    contract_n<N, NQ>(Gop, x, gr);
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+      R1[a + PN * (iq + NQ * b)] = br[iq];
+      R2[a + PN * (iq + NQ * b)] = gr[iq];
+    }
+  }
+  __syncthreads();
+
+  // ---- S2: s-contraction, thread (iq=a, k=b)
+  double t_bg[NQ], t_gb[NQ], t_bb[NQ];  // B_s G_r u | G_s B_r u | B_s B_r u
+  if (active && b < N) {
+    double x[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];
+    contract_n<N, NQ>(Bop, x, t_bb);
+    contract_n<N, NQ>(Gop, x, t_gb);
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] = R2[j + PN * (a + NQ * b)];
+    contract_n<N, NQ>(Bop, x, t_bg);
+  }
+  __syncthreads();
+  if (active && b < N) {
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq) {  // [jq][iq][k], k fastest
+      R0[b + PN * (a + NQ * jq)] = t_bg[jq];
+      R1[b + PN * (a + NQ * jq)] = t_gb[jq];
+      R2[b + PN * (a + NQ * jq)] = t_bb[jq];
+    }
+  }
+  __syncthreads();
+
+  // ---- S3: t-contraction, thread (iq=a, jq=b): reference-space gradient at quadrature nodes
+  double gr[NQ], gs[NQ], gt[NQ];
+  double ca[N], cb[N], cc[N];
+  if (active) {
+    double x[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
+    contract_n<N, NQ>(Bop, x, gr);
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] = R1[k + PN * (a + NQ * b)];
+    contract_n<N, NQ>(Bop, x, gs);
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] = R2[k + PN * (a + NQ * b)];
+    contract_n<N, NQ>(Gop, x, gt);
+
+    // ---- quadrature-point stage: symmetric metric (rr,rs,rt,ss,st,tt), coalesced along (iq,jq)
+    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) {
+      const int q = NQ * NQ * kq;
+      const double m0 = m[q], m1 = m[NQ3 + q], m2 = m[2 * NQ3 + q];
+      const double m3 = m[3 * NQ3 + q], m4 = m[4 * NQ3 + q], m5 = m[5 * NQ3 + q];
+      const double r = gr[kq], s = gs[kq], t = gt[kq];
+      gr[kq] = m0 * r + m1 * s + m2 * t;
+      gs[kq] = m1 * r + m3 * s + m4 * t;
+      gt[kq] = m2 * r + m4 * s + m5 * t;
+    }
+
+    // ---- S5: t-contraction transposed (registers)
+    contract_t<NQ, N, false>(Bop, gr, ca);
+    contract_t<NQ, N, false>(Bop, gs, cb);
+    contract_t<NQ, N, false>(Gop, gt, cc);
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {  // [k][iq][jq], jq fastest
+      R0[b + PQ * (a + NQ * k)] = ca[k];
+      R1[b + PQ * (a + NQ * k)] = cb[k];
+      R2[b + PQ * (a + NQ * k)] = cc[k];
+    }
+  }
+  __syncthreads();
+
+  // ---- S6: s-contraction transposed, thread (iq=a, k=b)
+  double ar[N], bs[N];
+  if (active && b < N) {
+    double x[NQ];
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+    contract_t<NQ, N, false>(Bop, x, ar);
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq) x[jq] = R1[jq + PQ * (a + NQ * b)];
+    contract_t<NQ, N, false>(Gop, x, bs);
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq) x[jq] = R2[jq + PQ * (a + NQ * b)];
+    contract_t<NQ, N, true>(Bop, x, bs);
+  }
+  __syncthreads();
+  if (active && b < N) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {  // [k][j][iq], iq fastest
+      R0[a + PQ * (j + N * b)] = ar[j];
+      R1[a + PQ * (j + N * b)] = bs[j];
+    }
+  }
+  __syncthreads();
+
+  // ---- S7: r-contraction transposed, thread (j=a, k=b)
+  if (active && a < N && b < N) {
+    double x[NQ], o[N];
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) x[iq] = R0[iq + PQ * (a + N * b)];
+    contract_t<NQ, N, false>(Gop, x, o);
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) x[iq] = R1[iq + PQ * (a + N * b)];
+    contract_t<NQ, N, true>(Bop, x, o);
+#pragma unroll
+    for (int i = 0; i < N; ++i) R2[i + PN * (a + N * b)] = o[i];
+  }
+  __syncthreads();
+
+  // ---- store Au_e (coalesced)
+  if (active) {
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      Au[ns + idx] = R2[i + PN * (j + N * k)];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// mass-like applies (one field):
+//   MODE 0: out = V^T (W J) V in          (mass)            in: nodal, out: nodal
+//   MODE 1: out = V^T (W J) in_quad       (galerkin)        in: quad,  out: nodal
+//   MODE 2: out_quad = V in               (interpolate)     in: nodal, out: quad
+// ---------------------------------------------------------------------------
+template <int N, int NQ, int MODE>
+__global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void mass_like_kernel(
+    const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ Jq,
+    const int* __restrict__ elem_ids, const int* __restrict__ nodal_stride, const int* __restrict__ quad_stride,
+    int n_bucket, const double* __restrict__ Bop, const double* __restrict__ wq) {
+  using C = VolCfg<N, NQ>;
+  constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ;
+  constexpr int N3 = N * N * N;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const int tid = threadIdx.x;
+  const int slot = tid / PL;
+  const int te = tid - slot * PL;
+  const int a = te % NQ, b = te / NQ;
+  const int ei = blockIdx.x * C::EPB + slot;
+  const bool active = (slot < C::EPB) && (ei < n_bucket);
+  double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
+  double* R1 = R0 + C::FS;
+
+  int ns = 0, qs = 0;
+  if (active) {
+    const int e = elem_ids[ei];
+    ns = nodal_stride[e];
+    qs = quad_stride[e];
+  }
+
+  double g[NQ];  // values at quadrature nodes along kq for thread (iq=a, jq=b)
+  if (MODE != 1) {
+    if (active) {
+#pragma unroll
+      for (int idx = te; idx < N3; idx += PL) {
+        const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+        R0[i + PN * (j + N * k)] = in[ns + idx];
+      }
+    }
+    __syncthreads();
+    if (active && a < N && b < N) {  // r
+      double x[N], y[NQ];
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+      contract_n<N, NQ>(Bop, x, y);
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) R1[a + PN * (iq + NQ * b)] = y[iq];
+    }
+    __syncthreads();
+    if (active && b < N) {  // s
+      double x[N], y[NQ];
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];
+      contract_n<N, NQ>(Bop, x, y);
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = y[jq];
+    }
+    __syncthreads();
+    if (active) {  // t
+      double x[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
+      contract_n<N, NQ>(Bop, x, g);
+    }
+  } else if (active) {
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) g[kq] = in[qs + a + NQ * (b + NQ * kq)];
+  }
+
+  if (MODE == 2) {
+    if (active) {
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) out[qs + a + NQ * (b + NQ * kq)] = g[kq];
+    }
+    return;
+  }
+
+  double c[N];
+  if (active) {
+    const double wab = wq[a] * wq[b];
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) g[kq] *= (wq[kq] * wab) * Jq[qs + a + NQ * (b + NQ * kq)];
+    contract_t<NQ, N, false>(Bop, g, c);
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = c[k];
+  }
+  __syncthreads();
+  if (active && b < N) {
+    double x[NQ], y[N];
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+    contract_t<NQ, N, false>(Bop, x, y);
+#pragma unroll
+    for (int j = 0; j < N; ++j) R1[a + PQ * (j + N * b)] = y[j];
+  }
+  __syncthreads();
+  if (active && a < N && b < N) {
+    double x[NQ], o[N];
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) x[iq] = R1[iq + PQ * (a + N * b)];
+    contract_t<NQ, N, false>(Bop, x, o);
+#pragma unroll
+    for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = o[i];
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      out[ns + idx] = R0[i + PN * (j + N * k)];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// generic path: any (N, NQ) with runtime sizes, one 256-thread block per element,
+// staged through a per-block global scratch (L2 resident).  Correctness fallback
+// for degree pairs without a compiled fast kernel.
+// ---------------------------------------------------------------------------
+struct GenDims { int n[3]; };
+
+// out = (op applied along `dir`) in; op(o,c) = op[o*so + c*sc]; in has dims d (x fastest)
+__device__ void gen_apply(const double* __restrict__ op, int rows, int so, int sc, int dir, const double* in, GenDims d,
+                          double* out, bool acc) {
+  GenDims od = d;
+  const int cols = d.n[dir];
+  od.n[dir] = rows;
+  const int total = od.n[0] * od.n[1] * od.n[2];
+  int in_stride = 1;
+  for (int q = 0; q < dir; ++q) in_stride *= d.n[q];
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    int c[3];
+    c[0] = idx % od.n[0];
+    c[1] = (idx / od.n[0]) % od.n[1];
+    c[2] = idx / (od.n[0] * od.n[1]);
+    const int o = c[dir];
+    c[dir] = 0;
+    const int base = c[0] + d.n[0] * (c[1] + d.n[1] * c[2]);
+    double s = 0.0;
+    for (int q = 0; q < cols; ++q) s = fma(op[o * so + q * sc], in[base + q * in_stride], s);
+    out[idx] = acc ? out[idx] + s : s;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void generic_volume_kernel(
+    int mode /* 0 mass, 1 galerkin, 2 interp, 3 stiffness */, const double* __restrict__ in, double* __restrict__ out,
+    const double* __restrict__ metric, const double* __restrict__ Jq, const int* __restrict__ elem_ids,
+    const int* __restrict__ nodal_stride, const int* __restrict__ quad_stride, int n_bucket, int N, int NQ,
+    const double* __restrict__ Bop, const double* __restrict__ Gop, const double* __restrict__ wq, double* scratch,
+    size_t scratch_per_block) {
+  const int NM = N > NQ ? N : NQ;
+  const size_t A = (size_t)NM * NM * NM;
+  double* s = scratch + (size_t)blockIdx.x * scratch_per_block;
+  double *t0 = s, *t1 = s + A, *t2 = s + 2 * A, *t3 = s + 3 * A, *t4 = s + 4 * A, *t5 = s + 5 * A, *t6 = s + 6 * A, *t7 = s + 7 * A;
+  const int NQ3 = NQ * NQ * NQ;
+  for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
+    const int e = elem_ids[ei];
+    const int ns = nodal_stride[e], qs = quad_stride[e];
+    const double* ue = in + ns;
+    GenDims dn = {{N, N, N}};
+    if (mode == 3) {
+      // forward: gr = (B,B,G) u, gs = (B,G,B) u, gt = (G,B,B) u   (order t,s,r | here listed as z,y,x operators)
+      gen_apply(Bop, NQ, N, 1, 0, ue, dn, t0, false);          // B_r u
+      gen_apply(Gop, NQ, N, 1, 0, ue, dn, t1, false);          // G_r u
+      GenDims d1 = {{NQ, N, N}};
+      gen_apply(Bop, NQ, N, 1, 1, t0, d1, t2, false);          // B_s B_r u
+      gen_apply(Gop, NQ, N, 1, 1, t0, d1, t3, false);          // G_s B_r u
+      gen_apply(Bop, NQ, N, 1, 1, t1, d1, t4, false);          // B_s G_r u
+      GenDims d2 = {{NQ, NQ, N}};
+      gen_apply(Bop, NQ, N, 1, 2, t4, d2, t5, false);          // gr
+      gen_apply(Bop, NQ, N, 1, 2, t3, d2, t6, false);          // gs
+      gen_apply(Gop, NQ, N, 1, 2, t2, d2, t7, false);          // gt
+      const double* m = metric + (size_t)6 * qs;
+      for (int q = threadIdx.x; q < NQ3; q += blockDim.x) {
+        const double r = t5[q], sv = t6[q], t = t7[q];
+        const double m0 = m[q], m1 = m[NQ3 + q], m2 = m[2 * NQ3 + q], m3 = m[3 * NQ3 + q], m4 = m[4 * NQ3 + q], m5 = m[5 * NQ3 + q];
+        t5[q] = m0 * r + m1 * sv + m2 * t;
+        t6[q] = m1 * r + m3 * sv + m4 * t;
+        t7[q] = m2 * r + m4 * sv + m5 * t;
+      }
+      __syncthreads();
+      GenDims dq = {{NQ, NQ, NQ}};
+      gen_apply(Bop, N, 1, N, 2, t5, dq, t0, false);           // B_t^T fr
+      gen_apply(Bop, N, 1, N, 2, t6, dq, t1, false);           // B_t^T fs
+      gen_apply(Gop, N, 1, N, 2, t7, dq, t2, false);           // G_t^T ft
+      GenDims d3 = {{NQ, NQ, N}};
+      gen_apply(Bop, N, 1, N, 1, t0, d3, t3, false);           // B_s^T .
+      gen_apply(Gop, N, 1, N, 1, t1, d3, t4, false);           // G_s^T .
+      gen_apply(Bop, N, 1, N, 1, t2, d3, t4, true);            // + B_s^T .
+      GenDims d4 = {{NQ, N, N}};
+      gen_apply(Gop, N, 1, N, 0, t3, d4, out + ns, false);
+      gen_apply(Bop, N, 1, N, 0, t4, d4, out + ns, true);
+    } else {
+      const double* gq;
+      if (mode != 1) {
+        gen_apply(Bop, NQ, N, 1, 0, ue, dn, t0, false);
+        GenDims d1 = {{NQ, N, N}};
+        gen_apply(Bop, NQ, N, 1, 1, t0, d1, t1, false);
+        GenDims d2 = {{NQ, NQ, N}};
+        if (mode == 2) {
+          gen_apply(Bop, NQ, N, 1, 2, t1, d2, out + qs, false);
+          continue;
+        }
+        gen_apply(Bop, NQ, N, 1, 2, t1, d2, t2, false);
+        gq = t2;
+      } else {
+        gq = in + qs;
+      }
+      for (int q = threadIdx.x; q < NQ3; q += blockDim.x) {
+        const int iq = q % NQ, jq = (q / NQ) % NQ, kq = q / (NQ * NQ);
+        t3[q] = gq[q] * (wq[kq] * (wq[iq] * wq[jq])) * Jq[qs + q];
+      }
+      __syncthreads();
+      GenDims dq = {{NQ, NQ, NQ}};
+      gen_apply(Bop, N, 1, N, 2, t3, dq, t0, false);
+      GenDims d3 = {{NQ, NQ, N}};
+      gen_apply(Bop, N, 1, N, 1, t0, d3, t1, false);
+      GenDims d4 = {{NQ, N, N}};
+      gen_apply(Bop, N, 1, N, 0, t1, d4, out + ns, false);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// collocation derivatives  dudr_i = D_i u   (3 outputs), one element per NxN threads
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__((VolCfg<N, N>::THREADS)) void dudr_kernel(
+    const double* __restrict__ u, double* __restrict__ d0, double* __restrict__ d1, double* __restrict__ d2,
+    const int* __restrict__ elem_ids, const int* __restrict__ nodal_stride, int n_bucket, const double* __restrict__ Dop) {
+  using C = VolCfg<N, N>;
+  constexpr int PL = C::PL, PN = C::PN, N3 = N * N * N;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int slot = tid / PL;
+  const int te = tid - slot * PL;
+  const int a = te % N, b = te / N;
+  const int ei = blockIdx.x * C::EPB + slot;
+  const bool active = (slot < C::EPB) && (ei < n_bucket);
+  double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
+  double* R1 = R0 + C::FS;
+  int ns = 0;
+  if (active) ns = nodal_stride[elem_ids[ei]];
+  if (active) {
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      R0[i + PN * (j + N * k)] = u[ns + idx];
+    }
+  }
+  __syncthreads();
+  // direction t (dir 2): thread (i=a, j=b), column along k; output coalesced directly
+  if (active) {
+    double x[N], y[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] = R0[a + PN * (b + N * k)];
+    contract_n<N, N>(Dop, x, y);
+#pragma unroll
+    for (int k = 0; k < N; ++k) d2[ns + a + N * (b + N * k)] = y[k];
+    // direction s (dir 1): thread (i=a, k=b), column along j
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] = R0[a + PN * (j + N * b)];
+    contract_n<N, N>(Dop, x, y);
+#pragma unroll
+    for (int j = 0; j < N; ++j) d1[ns + a + N * (j + N * b)] = y[j];
+    // direction r (dir 0): thread (j=a, k=b), column along i -> stage through LDS for a coalesced store
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+    contract_n<N, N>(Dop, x, y);
+#pragma unroll
+    for (int i = 0; i < N; ++i) R1[i + PN * (a + N * b)] = y[i];
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      d0[ns + idx] = R1[i + PN * (j + N * k)];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void generic_dudr_kernel(const double* __restrict__ u, double* __restrict__ d0,
+                                                           double* __restrict__ d1, double* __restrict__ d2,
+                                                           const int* __restrict__ elem_ids,
+                                                           const int* __restrict__ nodal_stride, int n_bucket, int N,
+                                                           const double* __restrict__ Dop) {
+  for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
+    const int ns = nodal_stride[elem_ids[ei]];
+    GenDims dn = {{N, N, N}};
+    gen_apply(Dop, N, N, 1, 0, u + ns, dn, d0 + ns, false);
+    gen_apply(Dop, N, N, 1, 1, u + ns, dn, d1 + ns, false);
+    gen_apply(Dop, N, N, 1, 2, u + ns, dn, d2 + ns, false);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// geometry pre-combination: symmetric metric  M_{ab} = w_i w_j w_k J sum_d r_{a,d} r_{b,d}
+// from the reference's SoA arrays (setup-time transform).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void metric_precombine_kernel(const double* __restrict__ J, const double* __restrict__ rst,
+                                                                size_t local_nodes_quad, const int* __restrict__ elem_ids,
+                                                                const int* __restrict__ quad_stride, int n_bucket, int NQ,
+                                                                const double* __restrict__ wq, double* __restrict__ metric) {
+  const int NQ3 = NQ * NQ * NQ;
+  for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
+    const int qs = quad_stride[elem_ids[ei]];
+    double* m = metric + (size_t)6 * qs;
+    for (int q = threadIdx.x; q < NQ3; q += blockDim.x) {
+      const int iq = q % NQ, jq = (q / NQ) % NQ, kq = q / (NQ * NQ);
+      const double wj = (wq[kq] * (wq[jq] * wq[iq])) * J[qs + q];
+      double r[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r[i][j] = rst[(size_t)(3 * i + j) * local_nodes_quad + qs + q];
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) {
+          m[(size_t)c * NQ3 + q] = wj * (r[i][0] * r[j][0] + r[i][1] * r[j][1] + r[i][2] * r[j][2]);
+          ++c;
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------
+#define D4EST_HIP_FAST_PAIRS(X) \
+  X(2, 2) X(3, 3) X(4, 4) X(5, 5) X(6, 6) X(7, 7) X(8, 8) X(9, 9) X(10, 10) X(11, 11) X(12, 12) \
+  X(13, 13) X(14, 14) X(15, 15) X(16, 16)                                                       \
+  X(2, 3) X(3, 4) X(4, 5) X(8, 9) X(3, 6) X(4, 6) X(8, 10)
+
+template <typename K>
+static void set_lds_limit(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+static void ensure_scratch(d4est_hip_plan* plan, size_t doubles) {
+  if (plan->scratch_doubles >= doubles) return;
+  if (plan->d_scratch) HIP_CHECK(hipFree(plan->d_scratch));
+  HIP_CHECK(hipMalloc(&plan->d_scratch, doubles * sizeof(double)));
+  plan->scratch_doubles = doubles;
+}
+
+static void launch_generic(d4est_hip_plan* plan, const Bucket& bk, int mode, const double* in, double* out) {
+  const int NM = bk.N > bk.NQ ? bk.N : bk.NQ;
+  const size_t per_block = (size_t)8 * NM * NM * NM;
+  const int grid = bk.n_elem < 1024 ? bk.n_elem : 1024;
+  ensure_scratch(plan, per_block * grid);
+  hipLaunchKernelGGL(generic_volume_kernel, dim3(grid), dim3(256), 0, plan->stream, mode, in, out, plan->d_metric, plan->d_J,
+                     plan->d_elem_ids + bk.elem_offset, plan->d_nodal_stride, plan->d_quad_stride, bk.n_elem, bk.N, bk.NQ,
+                     bk.d_B, bk.d_G, bk.d_w, plan->d_scratch, per_block);
+}
+
+void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
+  if (!plan->has_geometry) D4EST_HIP_ABORT("apply_stiffness_matrix: d4est_hip_plan_set_geometry was not called");
+  for (const Bucket& bk : plan->buckets) {
+    if (bk.n_elem == 0) continue;
+    bool done = false;
+#define X(N_, NQ_)                                                                                              \
+  if (!done && bk.N == N_ && bk.NQ == NQ_) {                                                                    \
+    using C = VolCfg<N_, NQ_>;                                                                                  \
+    if (C::LDS_BYTES <= 160 * 1024) {                                                                           \
+      set_lds_limit(stiffness_kernel<N_, NQ_>, C::LDS_BYTES);                                                   \
+      const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                       \
+      hipLaunchKernelGGL((stiffness_kernel<N_, NQ_>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, \
+                         u, Au, plan->d_metric, plan->d_elem_ids + bk.elem_offset, plan->d_nodal_stride,        \
+                         plan->d_quad_stride, bk.n_elem, bk.d_B, bk.d_G);                                       \
+      done = true;                                                                                              \
+    }                                                                                                           \
+  }
+    D4EST_HIP_FAST_PAIRS(X)
+#undef X
+    if (!done) launch_generic(plan, bk, 3, u, Au);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+template <int MODE>
+static void launch_mass_like_mode(d4est_hip_plan* plan, const double* in, double* out) {
+  for (const Bucket& bk : plan->buckets) {
+    if (bk.n_elem == 0) continue;
+    bool done = false;
+#define X(N_, NQ_)                                                                                                    \
+  if (!done && bk.N == N_ && bk.NQ == NQ_) {                                                                          \
+    using C = VolCfg<N_, NQ_>;                                                                                        \
+    if (C::LDS_BYTES <= 160 * 1024) {                                                                                 \
+      set_lds_limit(mass_like_kernel<N_, NQ_, MODE>, C::LDS_BYTES);                                                   \
+      const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                             \
+      hipLaunchKernelGGL((mass_like_kernel<N_, NQ_, MODE>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, \
+                         in, out, plan->d_J, plan->d_elem_ids + bk.elem_offset, plan->d_nodal_stride,                 \
+                         plan->d_quad_stride, bk.n_elem, bk.d_B, bk.d_w);                                             \
+      done = true;                                                                                                    \
+    }                                                                                                                 \
+  }
+    D4EST_HIP_FAST_PAIRS(X)
+#undef X
+    if (!done) launch_generic(plan, bk, MODE, in, out);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out) {
+  if (mode != 2 && !plan->has_geometry) D4EST_HIP_ABORT("mass/galerkin apply: d4est_hip_plan_set_geometry was not called");
+  if (mode == 0) launch_mass_like_mode<0>(plan, in, out);
+  else if (mode == 1) launch_mass_like_mode<1>(plan, in, out);
+  else if (mode == 2) launch_mass_like_mode<2>(plan, in, out);
+  else D4EST_HIP_ABORT("launch_mass_like: bad mode %d", mode);
+}
+
+void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, double* d2) {
+  for (const Bucket& bk : plan->buckets) {
+    if (bk.n_elem == 0) continue;
+    bool done = false;
+#define X(N_, NQ_)                                                                                         \
+  if (!done && N_ == NQ_ && bk.N == N_) {                                                                  \
+    using C = VolCfg<N_, N_>;                                                                              \
+    if (C::LDS_BYTES <= 160 * 1024) {                                                                      \
+      set_lds_limit(dudr_kernel<N_>, C::LDS_BYTES);                                                        \
+      const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                  \
+      hipLaunchKernelGGL((dudr_kernel<N_>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, u,   \
+                         d0, d1, d2, plan->d_elem_ids + bk.elem_offset, plan->d_nodal_stride, bk.n_elem,   \
+                         bk.d_D);                                                                          \
+      done = true;                                                                                         \
+    }                                                                                                      \
+  }
+    D4EST_HIP_FAST_PAIRS(X)
+#undef X
+    if (!done) {
+      const int grid = bk.n_elem < 2048 ? bk.n_elem : 2048;
+      hipLaunchKernelGGL(generic_dudr_kernel, dim3(grid), dim3(256), 0, plan->stream, u, d0, d1, d2,
+                         plan->d_elem_ids + bk.elem_offset, plan->d_nodal_stride, bk.n_elem, bk.N, bk.d_D);
+    }
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_metric_precombine(d4est_hip_plan* plan, const double* d_J, const double* d_rst) {
+  for (const Bucket& bk : plan->buckets) {
+    if (bk.n_elem == 0) continue;
+    const int grid = bk.n_elem < 4096 ? bk.n_elem : 4096;
+    hipLaunchKernelGGL(metric_precombine_kernel, dim3(grid), dim3(256), 0, plan->stream, d_J, d_rst,
+                       (size_t)plan->local_nodes_quad, plan->d_elem_ids + bk.elem_offset, plan->d_quad_stride, bk.n_elem,
+                       bk.NQ, bk.d_w, plan->d_metric);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace d4est_hip

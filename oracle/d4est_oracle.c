@@ -1,0 +1,791 @@
+/*
+ * oracle/d4est_oracle.c -- TEST INFRASTRUCTURE ONLY (see d4est_oracle.h).
+ *
+ * CPU restatement of the d4est element hot path: 1-D operator tables, Kronecker
+ * applies, operator applies and the quadrature-level stiffness / mass kernels.
+ * Function-by-function citations of the reference are in d4est_oracle.h and
+ * beside each body.  Operation ORDER follows the reference (e.g. the 27-term
+ * k,lp,l loop of the stiffness apply), so this file is also the "port" CPU
+ * baseline timed by bench.py.
+ */
+#include "d4est_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_MAX_DEG 24
+#define ORACLE_ABORT(msg) do { fprintf(stderr, "[ORACLE_ABORT] %s (%s:%d)\n", msg, __FILE__, __LINE__); abort(); } while (0)
+
+static double* dalloc(size_t n) {
+  double* p = (double*)malloc(sizeof(double) * (n ? n : 1));
+  if (!p) ORACLE_ABORT("out of memory");
+  return p;
+}
+
+/* ------------------------------------------------------------------------- */
+/* LinearAlgebra                                                              */
+/* ------------------------------------------------------------------------- */
+
+/* d4est_linalg.c:65-78: C(m x n) = A(m x l) B(l x n), row-major (dgemm there). */
+void oracle_linalg_mat_multiply(const double* A, const double* B, double* C, int m, int l, int n) {
+  for (int i = 0; i < m; i++) {
+    for (int j = 0; j < n; j++) C[i * n + j] = 0.;
+    for (int k = 0; k < l; k++) {
+      const double a = A[i * l + k];
+      const double* b = &B[k * n];
+      double* c = &C[i * n];
+      for (int j = 0; j < n; j++) c[j] += a * b[j];
+    }
+  }
+}
+
+/* d4est_linalg.c:92-116: b = alpha A v + beta b, A is m x n row-major (dgemv 'T' there). */
+void oracle_linalg_matvec_plus_vec(double alpha, const double* A, const double* v, double beta, double* b, int m, int n) {
+  for (int i = 0; i < m; i++) {
+    double s = 0.;
+    for (int j = 0; j < n; j++) s += A[i * n + j] * v[j];
+    b[i] = alpha * s + ((beta == 0.) ? 0. : beta * b[i]);
+  }
+}
+
+/* d4est_linalg.c:135-143 */
+void oracle_linalg_mat_transpose_nonsqr(const double* A, double* At, int rows, int cols) {
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) At[j * rows + i] = A[i * cols + j];
+}
+
+/* d4est_linalg.c:10-25 (dgetrf+dgetri there): in-place inverse, partial pivoting. */
+int oracle_linalg_invert(double* A, int n) {
+  double* M = dalloc((size_t)n * 2 * n);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      M[i * 2 * n + j] = A[i * n + j];
+      M[i * 2 * n + n + j] = (i == j) ? 1. : 0.;
+    }
+  for (int c = 0; c < n; c++) {
+    int piv = c;
+    double best = fabs(M[c * 2 * n + c]);
+    for (int r = c + 1; r < n; r++)
+      if (fabs(M[r * 2 * n + c]) > best) { best = fabs(M[r * 2 * n + c]); piv = r; }
+    if (best == 0.) { free(M); return 1; }
+    if (piv != c)
+      for (int j = 0; j < 2 * n; j++) { double t = M[c * 2 * n + j]; M[c * 2 * n + j] = M[piv * 2 * n + j]; M[piv * 2 * n + j] = t; }
+    const double d = 1. / M[c * 2 * n + c];
+    for (int j = 0; j < 2 * n; j++) M[c * 2 * n + j] *= d;
+    for (int r = 0; r < n; r++) {
+      if (r == c) continue;
+      const double f = M[r * 2 * n + c];
+      if (f == 0.) continue;
+      for (int j = 0; j < 2 * n; j++) M[r * 2 * n + j] -= f * M[c * 2 * n + j];
+    }
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) A[i * n + j] = M[i * 2 * n + n + j];
+  free(M);
+  return 0;
+}
+
+void oracle_linalg_vec_axpy(double alpha, const double* x, double* y, int n) { for (int i = 0; i < n; i++) y[i] += alpha * x[i]; }
+void oracle_linalg_vec_scale(double alpha, double* x, int n) { for (int i = 0; i < n; i++) x[i] *= alpha; }
+/* d4est_linalg.c:226-230: y = x + beta y */
+void oracle_linalg_vec_xpby(const double* x, double beta, double* y, int n) { for (int i = 0; i < n; i++) y[i] = beta * y[i] + x[i]; }
+double oracle_linalg_vec_dot(const double* x, const double* y, int n) { double s = 0.; for (int i = 0; i < n; i++) s += x[i] * y[i]; return s; }
+
+/* ------------------------------------------------------------------------- */
+/* d4est_lgl.c                                                                */
+/* ------------------------------------------------------------------------- */
+
+/* d4est_lgl.c:14-48: orthonormal Jacobi polynomial P_N^(alpha,beta)(r). */
+double oracle_lgl_jacobi(double r, double alpha, double beta, int N) {
+  double J0, J1, J2 = 0;
+  double gamma0 = (pow(2.0, alpha + beta + 1) / (alpha + beta + 1.0)) * tgamma(alpha + 1.0) * tgamma(beta + 1.0) / tgamma(alpha + beta + 1.0);
+  double gamma1 = (alpha + 1.0) * ((beta + 1.0) / (alpha + beta + 3.0)) * gamma0;
+  double aold = (2.0 / (2.0 + alpha + beta)) * sqrt((alpha + 1.0) * (beta + 1.0) / (alpha + beta + 3.0));
+  J0 = 1.0 / sqrt(gamma0);
+  if (N == 0) return J0;
+  J1 = ((alpha + beta + 2.0) * r / 2.0 + (alpha - beta) / 2) / sqrt(gamma1);
+  if (N == 1) return J1;
+  for (int i = 0; i < N - 1; i++) {
+    double h1 = 2.0 * (i + 1) + alpha + beta;
+    double anew = (2.0 / (h1 + 2.0)) * sqrt(((i + 1) + 1.0) * ((i + 1) + 1.0 + alpha + beta) * ((i + 1) + 1.0 + alpha) * (((i + 1) + 1.0 + beta) / (h1 + 1.0)) / (h1 + 3.0));
+    double bnew = -((alpha * alpha - beta * beta) / h1) / (h1 + 2.0);
+    J2 = (1.0 / anew) * (-aold * J0 + (r - bnew) * J1);
+    aold = anew;
+    J0 = J1;
+    J1 = J2;
+  }
+  return J2;
+}
+
+/* d4est_lgl.c:50-56 */
+double oracle_lgl_gradjacobi(double r, double alpha, double beta, int N) {
+  if (N == 0) return 0;
+  return sqrt(N * (N + alpha + beta + 1.0)) * oracle_lgl_jacobi(r, alpha + 1.0, beta + 1.0, N - 1);
+}
+
+/* ------------------------------------------------------------------------- */
+/* nodes & weights.  The reference tabulates these (GL_and_GLL_nodes_and_weights.h:6,
+ * :4082, n <= 20); the values are the roots of P_n (Gauss) and of (1-x^2)P'_{n-1}
+ * (Lobatto).  Computed here by Newton iteration from Chebyshev guesses.        */
+/* ------------------------------------------------------------------------- */
+
+static void legendre_pd(int n, double x, double* p, double* dp) {
+  /* P_n(x), P'_n(x) by the three-term recurrence (unnormalised Legendre) */
+  double p0 = 1., p1 = x;
+  if (n == 0) { *p = 1.; *dp = 0.; return; }
+  for (int k = 2; k <= n; k++) {
+    double pk = ((2. * k - 1.) * x * p1 - (k - 1.) * p0) / k;
+    p0 = p1;
+    p1 = pk;
+  }
+  *p = p1;
+  if (fabs(x) == 1.) *dp = 0.5 * n * (n + 1.) * ((x > 0 || (n % 2 == 1)) ? 1. : -1.); /* P'_n(+-1) = (+-1)^(n+1) n(n+1)/2 */
+  else *dp = n * (x * p1 - p0) / (x * x - 1.);
+}
+
+void oracle_gauss_nodes_and_weights(int n, double* x, double* w) {
+  for (int i = 0; i < n; i++) {
+    double xi = -cos(M_PI * (i + 0.75) / (n + 0.5));
+    for (int it = 0; it < 100; it++) {
+      double p, dp;
+      legendre_pd(n, xi, &p, &dp);
+      double dx = p / dp;
+      xi -= dx;
+      if (fabs(dx) < 1e-16) break;
+    }
+    double p, dp;
+    legendre_pd(n, xi, &p, &dp);
+    x[i] = xi;
+    w[i] = 2. / ((1. - xi * xi) * dp * dp);
+  }
+  /* symmetrise */
+  for (int i = 0; i < n / 2; i++) {
+    double a = 0.5 * (x[n - 1 - i] - x[i]);
+    x[i] = -a; x[n - 1 - i] = a;
+    double ww = 0.5 * (w[i] + w[n - 1 - i]);
+    w[i] = ww; w[n - 1 - i] = ww;
+  }
+  if (n % 2) x[n / 2] = 0.;
+}
+
+void oracle_lobatto_nodes_and_weights(int n, double* x, double* w) {
+  /* n points = degree n-1; interior nodes are the roots of P'_{n-1} */
+  const int N = n - 1;
+  x[0] = -1.; x[N] = 1.;
+  for (int i = 1; i < N; i++) {
+    double xi = -cos(M_PI * i / N);
+    for (int it = 0; it < 100; it++) {
+      /* f = P'_N ; f' = P''_N = (2x P'_N - N(N+1) P_N)/(1-x^2) */
+      double p, dp;
+      legendre_pd(N, xi, &p, &dp);
+      double ddp = (2. * xi * dp - N * (N + 1.) * p) / (1. - xi * xi);
+      double dx = dp / ddp;
+      xi -= dx;
+      if (fabs(dx) < 1e-16) break;
+    }
+    x[i] = xi;
+  }
+  for (int i = 0; i < n / 2; i++) {
+    double a = 0.5 * (x[n - 1 - i] - x[i]);
+    x[i] = -a; x[n - 1 - i] = a;
+  }
+  if (n % 2) x[n / 2] = 0.;
+  for (int i = 0; i < n; i++) {
+    double p, dp;
+    legendre_pd(N, x[i], &p, &dp);
+    w[i] = 2. / (N * (N + 1.) * p * p);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* 1-D operator tables                                                        */
+/* ------------------------------------------------------------------------- */
+
+static void lobatto_nodes(int deg, double* x) { double w[ORACLE_MAX_DEG + 1]; oracle_lobatto_nodes_and_weights(deg + 1, x, w); }
+
+/* d4est_operators.c:347-355 */
+void oracle_build_Vij_1d(double* V, int deg) {
+  double x[ORACLE_MAX_DEG + 1];
+  lobatto_nodes(deg, x);
+  int n = deg + 1;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) V[i * n + j] = oracle_lgl_jacobi(x[i], 0., 0., j);
+}
+
+/* d4est_operators.c:357-362 */
+void oracle_build_invvij_1d(double* invV, int deg) {
+  oracle_build_Vij_1d(invV, deg);
+  if (oracle_linalg_invert(invV, deg + 1)) ORACLE_ABORT("singular Vandermonde");
+}
+
+/* d4est_operators.c:712-724: M = (V V^T)^{-1} */
+void oracle_build_mij_1d(double* M, int deg) {
+  int n = deg + 1;
+  double* v = dalloc((size_t)n * n);
+  double* vt = dalloc((size_t)n * n);
+  oracle_build_Vij_1d(v, deg);
+  oracle_linalg_mat_transpose_nonsqr(v, vt, n, n);
+  oracle_linalg_mat_multiply(v, vt, M, n, n, n);
+  if (oracle_linalg_invert(M, n)) ORACLE_ABORT("singular V V^T");
+  free(v); free(vt);
+}
+
+/* d4est_operators.c:849-853 */
+void oracle_build_invmij_1d(double* invM, int deg) {
+  oracle_build_mij_1d(invM, deg);
+  if (oracle_linalg_invert(invM, deg + 1)) ORACLE_ABORT("singular mass");
+}
+
+/* d4est_operators.c:855-872 (+ :702-710): D = V_r V^{-1} */
+void oracle_build_dij_1d(double* D, int deg) {
+  int n = deg + 1;
+  double x[ORACLE_MAX_DEG + 1];
+  lobatto_nodes(deg, x);
+  double* invv = dalloc((size_t)n * n);
+  double* vr = dalloc((size_t)n * n);
+  oracle_build_invvij_1d(invv, deg);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) vr[i * n + j] = oracle_lgl_gradjacobi(x[i], 0., 0., j);
+  oracle_linalg_mat_multiply(vr, invv, D, n, n, n);
+  free(invv); free(vr);
+}
+
+/* d4est_operators.c:411-438: I = V(x^G) V^{-1}, (deg_gauss+1) x (deg_lobatto+1) */
+void oracle_build_lobatto_to_gauss_interp_1d(double* I, int deg_lobatto, int deg_gauss) {
+  int rows = deg_gauss + 1, cols = deg_lobatto + 1;
+  double xg[ORACLE_MAX_DEG + 1], wg[ORACLE_MAX_DEG + 1];
+  oracle_gauss_nodes_and_weights(rows, xg, wg);
+  double* gv = dalloc((size_t)rows * cols);
+  double* invv = dalloc((size_t)cols * cols);
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) gv[i * cols + j] = oracle_lgl_jacobi(xg[i], 0., 0., j);
+  oracle_build_invvij_1d(invv, deg_lobatto);
+  oracle_linalg_mat_multiply(gv, invv, I, rows, cols, cols);
+  free(gv); free(invv);
+}
+
+/* d4est_operators.c:995-1012: P = V_H(x_h) V_H^{-1}, (degh+1) x (degH+1) */
+void oracle_build_p_prolong_1d(double* P, int degH, int degh) {
+  int rows = degh + 1, cols = degH + 1;
+  double xh[ORACLE_MAX_DEG + 1];
+  lobatto_nodes(degh, xh);
+  double* vh = dalloc((size_t)rows * cols);
+  double* invv = dalloc((size_t)cols * cols);
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) vh[i * cols + j] = oracle_lgl_jacobi(xh[i], 0., 0., j);
+  oracle_build_invvij_1d(invv, degH);
+  oracle_linalg_mat_multiply(vh, invv, P, rows, cols, cols);
+  free(vh); free(invv);
+}
+
+/* d4est_operators.c:944-993: two (degh+1)x(degH+1) blocks, child c=0 on [-1,0], c=1 on [0,1]
+ * (d4est_reference.c:36-47: r -> r/2 -/+ 1/2). */
+void oracle_build_hp_prolong_1d(double* P2, int degH, int degh) {
+  int nH = degH + 1, nh = degh + 1;
+  double xh[ORACLE_MAX_DEG + 1];
+  lobatto_nodes(degh, xh);
+  double* invv = dalloc((size_t)nH * nH);
+  double* invvt = dalloc((size_t)nH * nH);
+  double* phi = dalloc((size_t)nH);
+  oracle_build_invvij_1d(invv, degH);
+  oracle_linalg_mat_transpose_nonsqr(invv, invvt, nH, nH);
+  for (int c = 0; c < 2; c++) {
+    for (int n = 0; n < nh; n++) {
+      double r = xh[n] * .5;
+      r += (c == 0) ? -.5 : .5;
+      for (int i = 0; i < nH; i++) phi[i] = oracle_lgl_jacobi(r, 0, 0, i);
+      oracle_linalg_matvec_plus_vec(1.0, invvt, phi, 0.0, &P2[c * nh * nH + n * nH], nH, nH);
+    }
+  }
+  free(invv); free(invvt); free(phi);
+}
+
+/* d4est_operators.c:1134-1163: R = M_H^{-1} (0.5 P)^T M_h */
+static void build_hp_restrict_1d_aux(int degh, int degH, const double* prolong, const double* Mh, const double* invMH, double* R) {
+  int nH = degH + 1, nh = degh + 1;
+  double* tmp = dalloc(nH);
+  double* cs = dalloc((size_t)nh * nH);
+  double* csM = dalloc((size_t)nh * nh);
+  for (int s = 0; s < nH; s++) tmp[s] = 0.;
+  for (int s = 0; s < nH; s++) {
+    tmp[s] = 1.0;
+    oracle_linalg_matvec_plus_vec(.5, prolong, tmp, 0.0, &cs[s * nh], nh, nH);
+    tmp[s] = 0.0;
+  }
+  oracle_linalg_mat_multiply(cs, Mh, csM, nH, nh, nh);
+  oracle_linalg_mat_multiply(invMH, csM, R, nH, nH, nh);
+  free(tmp); free(cs); free(csM);
+}
+
+/* d4est_operators.c:1165-1185 */
+void oracle_build_p_restrict_1d(double* R, int degH, int degh) {
+  int nH = degH + 1, nh = degh + 1;
+  double* P = dalloc((size_t)nh * nH);
+  double* MH = dalloc((size_t)nH * nH);
+  double* Mh = dalloc((size_t)nh * nh);
+  oracle_build_p_prolong_1d(P, degH, degh);
+  oracle_build_invmij_1d(MH, degH);
+  oracle_build_mij_1d(Mh, degh);
+  build_hp_restrict_1d_aux(degh, degH, P, Mh, MH, R);
+  oracle_linalg_vec_scale(2., R, nH * nh);
+  free(P); free(MH); free(Mh);
+}
+
+/* d4est_operators.c:1232-1259 */
+void oracle_build_hp_restrict_1d(double* R2, int degH, int degh) {
+  int nH = degH + 1, nh = degh + 1;
+  double* P2 = dalloc((size_t)2 * nh * nH);
+  double* MH = dalloc((size_t)nH * nH);
+  double* Mh = dalloc((size_t)nh * nh);
+  oracle_build_hp_prolong_1d(P2, degH, degh);
+  oracle_build_invmij_1d(MH, degH);
+  oracle_build_mij_1d(Mh, degh);
+  build_hp_restrict_1d_aux(degh, degH, &P2[0], Mh, MH, &R2[0]);
+  build_hp_restrict_1d_aux(degh, degH, &P2[nH * nh], Mh, MH, &R2[nH * nh]);
+  free(P2); free(MH); free(Mh);
+}
+
+/* Quadrature vtables: d4est_quadrature_legendre.c:22-93 / d4est_quadrature_lobatto.c:23-93 */
+void oracle_quad_weights(int quad_type, int deg_quad, double* w) {
+  double x[ORACLE_MAX_DEG + 1];
+  if (quad_type == 0) oracle_gauss_nodes_and_weights(deg_quad + 1, x, w);
+  else if (quad_type == 1) oracle_lobatto_nodes_and_weights(deg_quad + 1, x, w);
+  else ORACLE_ABORT("unknown quadrature type");
+}
+
+void oracle_quad_interp(int quad_type, int deg_lobatto, int deg_quad, double* I) {
+  if (quad_type == 0) oracle_build_lobatto_to_gauss_interp_1d(I, deg_lobatto, deg_quad);
+  else if (quad_type == 1) oracle_build_p_prolong_1d(I, deg_lobatto, deg_quad);
+  else ORACLE_ABORT("unknown quadrature type");
+}
+
+/* ------------------------------------------------------------------------- */
+/* Kron                                                                       */
+/* ------------------------------------------------------------------------- */
+
+/* d4est_kron.h:444-467: out = (A1 (x) A2) X with the reference's transpose/multiply sequence. */
+void oracle_kron_A1A2x_nonsqr(double* out, const double* A1, const double* A2, const double* X,
+                              int a1_rows, int a1_cols, int a2_rows, int a2_cols) {
+  int N = (a1_rows * a2_rows > a2_rows * a1_cols) ? a1_rows * a2_rows : a2_rows * a1_cols;
+  N = (a1_cols * a2_cols > N) ? a1_cols * a2_cols : N;
+  double* tmp = dalloc(N);
+  double* tmp1 = dalloc(N);
+  oracle_linalg_mat_transpose_nonsqr(X, tmp1, a1_cols, a2_cols);
+  oracle_linalg_mat_multiply(A2, tmp1, tmp, a2_rows, a2_cols, a1_cols);
+  oracle_linalg_mat_transpose_nonsqr(tmp, tmp1, a2_rows, a1_cols);
+  oracle_linalg_mat_multiply(A1, tmp1, out, a1_rows, a1_cols, a2_rows);
+  free(tmp); free(tmp1);
+}
+
+/* d4est_kron.h:532-548 */
+void oracle_kron_A1A2A3x_nonsqr(double* out, const double* A1, const double* A2, const double* A3, const double* X,
+                                int a1_rows, int a1_cols, int a2_rows, int a2_cols, int a3_rows, int a3_cols) {
+  double* tmp = dalloc((size_t)a2_rows * a3_rows * a1_cols);
+  for (int i = 0; i < a1_cols; i++)
+    oracle_kron_A1A2x_nonsqr(&tmp[i * a2_rows * a3_rows], A2, A3, &X[i * a2_cols * a3_cols], a2_rows, a2_cols, a3_rows, a3_cols);
+  oracle_linalg_mat_multiply(A1, tmp, out, a1_rows, a1_cols, a2_rows * a3_rows);
+  free(tmp);
+}
+
+static void kron_AoB(const double* A, const double* B, double* C, int a_rows, int a_cols, int b_rows, int b_cols) {
+  /* d4est_kron.h (AoB): dense Kronecker product, test helper */
+  int cc = a_cols * b_cols;
+  for (int i = 0; i < a_rows; i++)
+    for (int j = 0; j < a_cols; j++)
+      for (int k = 0; k < b_rows; k++)
+        for (int l = 0; l < b_cols; l++) C[(i * b_rows + k) * cc + (j * b_cols + l)] = A[i * a_cols + j] * B[k * b_cols + l];
+}
+
+/* d4est_kron.h:428-440 */
+void oracle_kron_AoBoC(const double* A, const double* B, const double* C, double* D,
+                       int a_rows, int a_cols, int b_rows, int b_cols, int c_rows, int c_cols) {
+  double* AoB = dalloc((size_t)a_rows * a_cols * b_rows * b_cols);
+  kron_AoB(A, B, AoB, a_rows, a_cols, b_rows, b_cols);
+  kron_AoB(AoB, C, D, a_rows * b_rows, a_cols * b_cols, c_rows, c_cols);
+  free(AoB);
+}
+
+/* d4est_kron.h:469-487, 550-575 : (MAT o I o I), (I o MAT o I), (I o I o MAT) */
+static void kron_MAToIx(double* out, const double* M, const double* X, int N) { oracle_linalg_mat_multiply(M, X, out, N, N, N); }
+static void kron_IoMATx(double* out, const double* M, const double* X, int N) {
+  double* tmp = dalloc((size_t)N * N);
+  double* tmp1 = dalloc((size_t)N * N);
+  oracle_linalg_mat_transpose_nonsqr(X, tmp1, N, N);
+  oracle_linalg_mat_multiply(M, tmp1, tmp, N, N, N);
+  oracle_linalg_mat_transpose_nonsqr(tmp, out, N, N);
+  free(tmp); free(tmp1);
+}
+static void kron_MAToIoIx(double* out, const double* M, const double* X, int N) { oracle_linalg_mat_multiply(M, X, out, N, N, N * N); }
+static void kron_IoMAToIx(double* out, const double* M, const double* X, int N) { for (int i = 0; i < N; i++) kron_MAToIx(&out[i * N * N], M, &X[i * N * N], N); }
+static void kron_IoIoMATx(double* out, const double* M, const double* X, int N) { for (int i = 0; i < N; i++) kron_IoMATx(&out[i * N * N], M, &X[i * N * N], N); }
+
+/* ------------------------------------------------------------------------- */
+/* tiny per-thread table cache (the reference caches lazily in d4est_operators_t,
+ * d4est_operators.c:196-304)                                                   */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int ready;
+  double* dij; double* dij_t; double* mij; double* invmij;
+} deg_tables_t;
+static deg_tables_t g_deg[ORACLE_MAX_DEG + 1];
+
+typedef struct {
+  int ready;
+  double* interp; double* interp_t; double* w;
+} quad_tables_t;
+static quad_tables_t g_quad[2][ORACLE_MAX_DEG + 1][ORACLE_MAX_DEG + 1];
+
+static deg_tables_t* get_deg(int deg) {
+  if (deg < 1 || deg > ORACLE_MAX_DEG) ORACLE_ABORT("degree out of range");
+  deg_tables_t* t = &g_deg[deg];
+  if (!t->ready) {
+#pragma omp critical(oracle_deg_cache)
+    {
+      if (!t->ready) {
+        int n = deg + 1;
+        t->dij = dalloc((size_t)n * n); t->dij_t = dalloc((size_t)n * n);
+        t->mij = dalloc((size_t)n * n); t->invmij = dalloc((size_t)n * n);
+        oracle_build_dij_1d(t->dij, deg);
+        oracle_linalg_mat_transpose_nonsqr(t->dij, t->dij_t, n, n); /* d4est_operators.c:2239-2245 */
+        oracle_build_mij_1d(t->mij, deg);
+        oracle_build_invmij_1d(t->invmij, deg);
+#pragma omp flush
+        t->ready = 1;
+      }
+    }
+  }
+  return t;
+}
+
+static quad_tables_t* get_quad(int quad_type, int deg_lobatto, int deg_quad) {
+  if (quad_type < 0 || quad_type > 1) ORACLE_ABORT("quad type");
+  if (deg_lobatto < 1 || deg_lobatto > ORACLE_MAX_DEG || deg_quad < 1 || deg_quad > ORACLE_MAX_DEG) ORACLE_ABORT("degree out of range");
+  quad_tables_t* t = &g_quad[quad_type][deg_lobatto][deg_quad];
+  if (!t->ready) {
+#pragma omp critical(oracle_quad_cache)
+    {
+      if (!t->ready) {
+        int nl = deg_lobatto + 1, nq = deg_quad + 1;
+        t->interp = dalloc((size_t)nq * nl); t->interp_t = dalloc((size_t)nq * nl); t->w = dalloc(nq);
+        oracle_quad_interp(quad_type, deg_lobatto, deg_quad, t->interp);
+        oracle_linalg_mat_transpose_nonsqr(t->interp, t->interp_t, nq, nl);
+        oracle_quad_weights(quad_type, deg_quad, t->w);
+#pragma omp flush
+        t->ready = 1;
+      }
+    }
+  }
+  return t;
+}
+
+/* ------------------------------------------------------------------------- */
+/* operator applies (3-D)                                                      */
+/* ------------------------------------------------------------------------- */
+
+/* d4est_operators.c:1385-1410 */
+void oracle_apply_dij(const double* in, int deg, int dir, double* out) {
+  const double* D = get_deg(deg)->dij;
+  int n = deg + 1;
+  if (dir == 0) kron_IoIoMATx(out, D, in, n);
+  else if (dir == 1) kron_IoMAToIx(out, D, in, n);
+  else if (dir == 2) kron_MAToIoIx(out, D, in, n);
+  else ORACLE_ABORT("apply_dij: dir");
+}
+
+/* d4est_operators.c:2259-2284 */
+void oracle_apply_dij_transpose(const double* in, int deg, int dir, double* out) {
+  const double* Dt = get_deg(deg)->dij_t;
+  int n = deg + 1;
+  if (dir == 0) kron_IoIoMATx(out, Dt, in, n);
+  else if (dir == 1) kron_IoMAToIx(out, Dt, in, n);
+  else if (dir == 2) kron_MAToIoIx(out, Dt, in, n);
+  else ORACLE_ABORT("apply_dij_transpose: dir");
+}
+
+/* d4est_operators.c:891-908 */
+void oracle_apply_mij(const double* in, int deg, double* out) {
+  const double* M = get_deg(deg)->mij;
+  int n = deg + 1;
+  oracle_kron_A1A2A3x_nonsqr(out, M, M, M, in, n, n, n, n, n, n);
+}
+
+/* d4est_operators.c:910-928 */
+void oracle_apply_invmij(const double* in, int deg, double* out) {
+  const double* M = get_deg(deg)->invmij;
+  int n = deg + 1;
+  oracle_kron_A1A2A3x_nonsqr(out, M, M, M, in, n, n, n, n, n, n);
+}
+
+/* d4est_operators.c:1521-1582 with the unit-vector "slicer" (lift_1d, :1434-1438):
+ * face 0,1 = -x,+x ; 2,3 = -y,+y ; 4,5 = -z,+z.  3-D: out[N*N]. */
+void oracle_apply_slicer(const double* in, int face, int deg, double* out) {
+  int n = deg + 1;
+  if (face < 0 || face > 5) ORACLE_ABORT("slicer: face");
+  int dir = face / 2, side = face % 2;
+  int fix = side ? deg : 0;
+  /* The reference multiplies by e_side^T through dgemm; with a unit vector the product is the gather below
+   * (times exactly 1.0, plus exact zeros), so values are reproduced bit-for-bit. */
+  for (int b = 0; b < n; b++)
+    for (int a = 0; a < n; a++) {
+      int idx;
+      if (dir == 0) idx = fix + a * n + b * n * n;        /* (I o I o e^T): a=y, b=z */
+      else if (dir == 1) idx = a + fix * n + b * n * n;   /* (I o e^T o I): a=x, b=z */
+      else idx = a + b * n + fix * n * n;                 /* (e^T o I o I): a=x, b=y */
+      out[a + b * n] = in[idx];
+    }
+}
+
+/* d4est_operators.c:1454-1519: out[N^3] = face data scattered to the face nodes, zero elsewhere. */
+void oracle_apply_lift(const double* in, int deg, int face, double* out) {
+  int n = deg + 1;
+  if (face < 0 || face > 5) ORACLE_ABORT("lift: face");
+  int dir = face / 2, side = face % 2;
+  int fix = side ? deg : 0;
+  for (int i = 0; i < n * n * n; i++) out[i] = 0.;
+  for (int b = 0; b < n; b++)
+    for (int a = 0; a < n; a++) {
+      int idx;
+      if (dir == 0) idx = fix + a * n + b * n * n;
+      else if (dir == 1) idx = a + fix * n + b * n * n;
+      else idx = a + b * n + fix * n * n;
+      out[idx] = in[a + b * n];
+    }
+}
+
+static int ipow(int b, int e) { int r = 1; for (int i = 0; i < e; i++) r *= b; return r; }
+
+static void apply_tensor(const double* op, int rows, int cols, int dim, const double* in, double* out) {
+  if (dim == 1) oracle_linalg_matvec_plus_vec(1.0, op, in, 0., out, rows, cols);
+  else if (dim == 2) oracle_kron_A1A2x_nonsqr(out, op, op, in, rows, cols, rows, cols);
+  else if (dim == 3) oracle_kron_A1A2A3x_nonsqr(out, op, op, op, in, rows, cols, rows, cols, rows, cols);
+  else ORACLE_ABORT("dim");
+}
+
+/* d4est_operators.c:1107-1132 */
+void oracle_apply_p_prolong(const double* in, int degH, int dim, int degh, double* out) {
+  if (degh == degH) { memcpy(out, in, sizeof(double) * ipow(degh + 1, dim)); return; }
+  double* P = dalloc((size_t)(degh + 1) * (degH + 1));
+  oracle_build_p_prolong_1d(P, degH, degh);
+  apply_tensor(P, degh + 1, degH + 1, dim, in, out);
+  free(P);
+}
+
+/* d4est_operators.c:1205-1230 */
+void oracle_apply_p_restrict(const double* in, int degh, int dim, int degH, double* out) {
+  if (degh == degH) { memcpy(out, in, sizeof(double) * ipow(degh + 1, dim)); return; }
+  double* R = dalloc((size_t)(degh + 1) * (degH + 1));
+  oracle_build_p_restrict_1d(R, degH, degh);
+  apply_tensor(R, degH + 1, degh + 1, dim, in, out);
+  free(R);
+}
+
+/* d4est_operators.c:1719-1749 */
+void oracle_apply_p_prolong_transpose(const double* in, int degh, int dim, int degH, double* out) {
+  if (degh == degH) { memcpy(out, in, sizeof(double) * ipow(degh + 1, dim)); return; }
+  double* P = dalloc((size_t)(degh + 1) * (degH + 1));
+  double* Pt = dalloc((size_t)(degh + 1) * (degH + 1));
+  oracle_build_p_prolong_1d(P, degH, degh);
+  oracle_linalg_mat_transpose_nonsqr(P, Pt, degh + 1, degH + 1);
+  apply_tensor(Pt, degH + 1, degh + 1, dim, in, out);
+  free(P); free(Pt);
+}
+
+/* d4est_reference.c:14-34 */
+static int child_lr(int c, int dir) { return (c >> dir) & 1; }
+
+static void hp_apply_child(const double* op2 /* two blocks rows x cols */, int rows, int cols, int dim, int c, const double* in, double* out) {
+  /* d4est_operators.c:376-404 / :663-700 / :1017-1055: A1 = z-block, A2 = y-block, A3 = x-block */
+  int blk = rows * cols;
+  if (dim == 1) oracle_linalg_matvec_plus_vec(1.0, &op2[c * blk], in, 0., out, rows, cols);
+  else if (dim == 2) oracle_kron_A1A2x_nonsqr(out, &op2[child_lr(c, 1) * blk], &op2[child_lr(c, 0) * blk], in, rows, cols, rows, cols);
+  else oracle_kron_A1A2A3x_nonsqr(out, &op2[child_lr(c, 2) * blk], &op2[child_lr(c, 1) * blk], &op2[child_lr(c, 0) * blk], in, rows, cols, rows, cols, rows, cols);
+}
+
+/* d4est_operators.c:1091-1105 */
+void oracle_apply_hp_prolong(const double* in, int degH, int dim, const int* degh, double* out) {
+  int children = 1 << dim, stride = 0;
+  for (int c = 0; c < children; c++) {
+    int nh = degh[c] + 1, nH = degH + 1;
+    double* P2 = dalloc((size_t)2 * nh * nH);
+    oracle_build_hp_prolong_1d(P2, degH, degh[c]);
+    hp_apply_child(P2, nh, nH, dim, c, in, &out[stride]);
+    stride += ipow(nh, dim);
+    free(P2);
+  }
+}
+
+/* d4est_operators.c:1275-1297 */
+void oracle_apply_hp_restrict(const double* in, const int* degh, int dim, int degH, double* out) {
+  int children = 1 << dim, stride = 0, nodesH = ipow(degH + 1, dim);
+  double* tmp = dalloc(nodesH);
+  for (int i = 0; i < nodesH; i++) out[i] = 0.;
+  for (int c = 0; c < children; c++) {
+    int nh = degh[c] + 1, nH = degH + 1;
+    double* R2 = dalloc((size_t)2 * nh * nH);
+    oracle_build_hp_restrict_1d(R2, degH, degh[c]);
+    hp_apply_child(R2, nH, nh, dim, c, &in[stride], tmp);
+    oracle_linalg_vec_axpy(1.0, tmp, out, nodesH);
+    stride += ipow(nh, dim);
+    free(R2);
+  }
+  free(tmp);
+}
+
+/* d4est_operators.c:1689-1717 (+ :1611-1621) */
+void oracle_apply_hp_prolong_transpose(const double* in, const int* degh, int dim, int degH, double* out) {
+  int children = 1 << dim, stride = 0, nodesH = ipow(degH + 1, dim);
+  double* tmp = dalloc(nodesH);
+  for (int i = 0; i < nodesH; i++) out[i] = 0.;
+  for (int c = 0; c < children; c++) {
+    int nh = degh[c] + 1, nH = degH + 1;
+    double* P2 = dalloc((size_t)2 * nh * nH);
+    double* P2t = dalloc((size_t)2 * nh * nH);
+    oracle_build_hp_prolong_1d(P2, degH, degh[c]);
+    oracle_linalg_mat_transpose_nonsqr(P2, P2t, nh, nH);
+    oracle_linalg_mat_transpose_nonsqr(&P2[nh * nH], &P2t[nh * nH], nh, nH);
+    hp_apply_child(P2t, nH, nh, dim, c, &in[stride], tmp);
+    oracle_linalg_vec_axpy(1.0, tmp, out, nodesH);
+    stride += ipow(nh, dim);
+    free(P2); free(P2t);
+  }
+  free(tmp);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Quadrature element kernels                                                 */
+/* ------------------------------------------------------------------------- */
+
+/* d4est_kron.h:259-283 */
+static void kron_vec1_o_vec2_o_vec3_dot_wxyz(const double* v1, const double* v2, const double* v3, const double* w, const double* x,
+                                             const double* y, const double* z, int n1, int n2, int n3, double* out) {
+  for (int i = 0; i < n1; i++)
+    for (int k = 0; k < n2; k++)
+      for (int m = 0; m < n3; m++) {
+        int s = m + (k + i * n2) * n3;
+        out[s] = v1[i] * v2[k] * v3[m] * w[s] * x[s] * y[s] * z[s];
+      }
+}
+
+/* d4est_kron.h:232-255 */
+static void kron_vec1_o_vec2_o_vec3_dot_xy(const double* v1, const double* v2, const double* v3, const double* x, const double* y,
+                                           int n1, int n2, int n3, double* out) {
+  for (int i = 0; i < n1; i++)
+    for (int k = 0; k < n2; k++)
+      for (int m = 0; m < n3; m++) {
+        int s = m + (k + i * n2) * n3;
+        out[s] = v1[i] * v2[k] * v3[m] * x[s] * y[s];
+      }
+}
+
+/* d4est_quadrature.c:263-382 -- THE metric kernel.  27 (k,lp,l) passes, each
+ * D_l -> V -> pointwise (w w w J r_lk r_lpk) -> V^T -> D_lp^T -> axpy into out. */
+void oracle_quadrature_apply_stiffness_matrix(int quad_type, const double* in, int deg_lobatto,
+        const double* jac_quad, const double* rst_xyz[3][3], int deg_quad, double* out) {
+  const int dim = 3;
+  int nl = deg_lobatto + 1, nq = deg_quad + 1;
+  int vq = nq * nq * nq, vl = nl * nl * nl;
+  quad_tables_t* qt = get_quad(quad_type, deg_lobatto, deg_quad);
+  const double* V = qt->interp;
+  const double* Vt = qt->interp_t;
+  const double* w = qt->w;
+
+  double* Dl_in = dalloc(vl);
+  double* V_Dl_in = dalloc(vq);
+  double* W_V_Dl_in = dalloc(vq);
+  double* VT_W_V_Dl_in = dalloc(vl);
+  double* DTlp_VT_W_V_Dl_in = dalloc(vl);
+
+  for (int i = 0; i < vl; i++) out[i] = 0.;
+
+  for (int k = 0; k < dim; k++) {
+    for (int lp = 0; lp < dim; lp++) {
+      for (int l = 0; l < dim; l++) {
+        oracle_apply_dij(in, deg_lobatto, l, Dl_in);
+        oracle_kron_A1A2A3x_nonsqr(V_Dl_in, V, V, V, Dl_in, nq, nl, nq, nl, nq, nl);
+        kron_vec1_o_vec2_o_vec3_dot_wxyz(w, w, w, jac_quad, rst_xyz[l][k], rst_xyz[lp][k], V_Dl_in, nq, nq, nq, W_V_Dl_in);
+        oracle_kron_A1A2A3x_nonsqr(VT_W_V_Dl_in, Vt, Vt, Vt, W_V_Dl_in, nl, nq, nl, nq, nl, nq);
+        oracle_apply_dij_transpose(VT_W_V_Dl_in, deg_lobatto, lp, DTlp_VT_W_V_Dl_in);
+        oracle_linalg_vec_axpy(1., DTlp_VT_W_V_Dl_in, out, vl);
+      }
+    }
+  }
+  free(DTlp_VT_W_V_Dl_in); free(VT_W_V_Dl_in); free(W_V_Dl_in); free(V_Dl_in); free(Dl_in);
+}
+
+/* d4est_quadrature.c:385-477 */
+void oracle_quadrature_apply_mass_matrix(int quad_type, const double* in, int deg_lobatto,
+        const double* jac_quad, int deg_quad, double* out) {
+  int nl = deg_lobatto + 1, nq = deg_quad + 1, vq = nq * nq * nq;
+  quad_tables_t* qt = get_quad(quad_type, deg_lobatto, deg_quad);
+  double* in_quad = dalloc(vq);
+  double* w_j_in_quad = dalloc(vq);
+  oracle_kron_A1A2A3x_nonsqr(in_quad, qt->interp, qt->interp, qt->interp, in, nq, nl, nq, nl, nq, nl);
+  kron_vec1_o_vec2_o_vec3_dot_xy(qt->w, qt->w, qt->w, jac_quad, in_quad, nq, nq, nq, w_j_in_quad);
+  oracle_kron_A1A2A3x_nonsqr(out, qt->interp_t, qt->interp_t, qt->interp_t, w_j_in_quad, nl, nq, nl, nq, nl, nq);
+  free(in_quad); free(w_j_in_quad);
+}
+
+/* d4est_quadrature.c:142-213 */
+void oracle_quadrature_apply_galerkin_integral(int quad_type, const double* in_quad, int deg_lobatto,
+        const double* jac_quad, int deg_quad, double* out) {
+  int nl = deg_lobatto + 1, nq = deg_quad + 1, vq = nq * nq * nq;
+  quad_tables_t* qt = get_quad(quad_type, deg_lobatto, deg_quad);
+  double* w_j_in_quad = dalloc(vq);
+  kron_vec1_o_vec2_o_vec3_dot_xy(qt->w, qt->w, qt->w, jac_quad, in_quad, nq, nq, nq, w_j_in_quad);
+  oracle_kron_A1A2A3x_nonsqr(out, qt->interp_t, qt->interp_t, qt->interp_t, w_j_in_quad, nl, nq, nl, nq, nl, nq);
+  free(w_j_in_quad);
+}
+
+/* d4est_quadrature.c:966-1016 */
+void oracle_quadrature_interpolate(int quad_type, const double* in, int deg_lobatto, double* out_quad, int deg_quad) {
+  int nl = deg_lobatto + 1, nq = deg_quad + 1;
+  quad_tables_t* qt = get_quad(quad_type, deg_lobatto, deg_quad);
+  oracle_kron_A1A2A3x_nonsqr(out_quad, qt->interp, qt->interp, qt->interp, in, nq, nl, nq, nl, nq, nl);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Laplacian element loops                                                    */
+/* ------------------------------------------------------------------------- */
+
+/* d4est_laplacian.c:198-234 (+ :143-195 and Mesh/d4est_mesh.c:2757-2776 for the geometry pointers).
+ * nthreads > 1 splits the element loop like d4est's one-MPI-rank-per-core usage. */
+void oracle_laplacian_apply_stiffness_matrix(int quad_type, int n_elements, const int* deg, const int* deg_quad,
+        const int* nodal_stride, const int* quad_stride, int local_nodes_quad,
+        const double* J_quad, const double* rst_xyz_quad, const double* u, double* Au, int nthreads) {
+  /* warm the caches serially */
+  for (int e = 0; e < n_elements; e++) { get_deg(deg[e]); get_quad(quad_type, deg[e], deg_quad[e]); }
+#ifdef _OPENMP
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+  for (int e = 0; e < n_elements; e++) {
+    const double* rst[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) rst[i][j] = &rst_xyz_quad[(size_t)(3 * i + j) * local_nodes_quad + quad_stride[e]];
+    oracle_quadrature_apply_stiffness_matrix(quad_type, &u[nodal_stride[e]], deg[e], &J_quad[quad_stride[e]], rst, deg_quad[e], &Au[nodal_stride[e]]);
+  }
+}
+
+void oracle_laplacian_apply_mass_matrix(int quad_type, int n_elements, const int* deg, const int* deg_quad,
+        const int* nodal_stride, const int* quad_stride,
+        const double* J_quad, const double* u, double* Mu, int nthreads) {
+  for (int e = 0; e < n_elements; e++) { get_deg(deg[e]); get_quad(quad_type, deg[e], deg_quad[e]); }
+#ifdef _OPENMP
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+  for (int e = 0; e < n_elements; e++)
+    oracle_quadrature_apply_mass_matrix(quad_type, &u[nodal_stride[e]], deg[e], &J_quad[quad_stride[e]], deg_quad[e], &Mu[nodal_stride[e]]);
+}
+
+/* d4est_laplacian.c:237-282 (local elements) */
+void oracle_laplacian_compute_dudr(int n_elements, const int* deg, const int* nodal_stride,
+        const double* u, double* dudr0, double* dudr1, double* dudr2) {
+  double* d[3] = {dudr0, dudr1, dudr2};
+  for (int e = 0; e < n_elements; e++)
+    for (int i = 0; i < 3; i++) oracle_apply_dij(&u[nodal_stride[e]], deg[e], i, &d[i][nodal_stride[e]]);
+}

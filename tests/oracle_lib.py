@@ -1,0 +1,182 @@
+"""ctypes wrapper of the CPU oracle (oracle/libd4est_oracle.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ODIR, "libd4est_oracle.so")
+
+dp = ctypes.POINTER(ctypes.c_double)
+ip = ctypes.POINTER(ctypes.c_int)
+
+
+def build():
+    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", ODIR, "-s", "-B"])
+    return LIB
+
+
+def P(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(dp)
+
+
+def I(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ip)
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.oracle_lgl_jacobi.restype = ctypes.c_double
+        lib.oracle_lgl_jacobi.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+        lib.oracle_linalg_matvec_plus_vec.argtypes = [ctypes.c_double, dp, dp, ctypes.c_double, dp, ctypes.c_int, ctypes.c_int]
+
+    # ---- tables
+    def lobatto(self, deg):
+        x = np.zeros(deg + 1); w = np.zeros(deg + 1)
+        self.lib.oracle_lobatto_nodes_and_weights(deg + 1, P(x), P(w))
+        return x, w
+
+    def gauss(self, deg):
+        x = np.zeros(deg + 1); w = np.zeros(deg + 1)
+        self.lib.oracle_gauss_nodes_and_weights(deg + 1, P(x), P(w))
+        return x, w
+
+    def _sq(self, fn, deg):
+        n = deg + 1
+        out = np.zeros((n, n))
+        getattr(self.lib, fn)(P(out), deg)
+        return out
+
+    def Vij(self, deg): return self._sq("oracle_build_Vij_1d", deg)
+    def mij(self, deg): return self._sq("oracle_build_mij_1d", deg)
+    def invmij(self, deg): return self._sq("oracle_build_invmij_1d", deg)
+    def dij(self, deg): return self._sq("oracle_build_dij_1d", deg)
+
+    def lobatto_to_gauss(self, deg, deg_gauss):
+        out = np.zeros((deg_gauss + 1, deg + 1))
+        self.lib.oracle_build_lobatto_to_gauss_interp_1d(P(out), deg, deg_gauss)
+        return out
+
+    def p_prolong(self, degH, degh):
+        out = np.zeros((degh + 1, degH + 1))
+        self.lib.oracle_build_p_prolong_1d(P(out), degH, degh)
+        return out
+
+    def hp_prolong(self, degH, degh):
+        out = np.zeros((2, degh + 1, degH + 1))
+        self.lib.oracle_build_hp_prolong_1d(P(out), degH, degh)
+        return out
+
+    def p_restrict(self, degH, degh):
+        out = np.zeros((degH + 1, degh + 1))
+        self.lib.oracle_build_p_restrict_1d(P(out), degH, degh)
+        return out
+
+    def hp_restrict(self, degH, degh):
+        out = np.zeros((2, degH + 1, degh + 1))
+        self.lib.oracle_build_hp_restrict_1d(P(out), degH, degh)
+        return out
+
+    # ---- kron
+    def kron_A1A2A3x(self, A1, A2, A3, x):
+        out = np.zeros(A1.shape[0] * A2.shape[0] * A3.shape[0])
+        self.lib.oracle_kron_A1A2A3x_nonsqr(P(out), P(A1), P(A2), P(A3), P(x), A1.shape[0], A1.shape[1], A2.shape[0],
+                                            A2.shape[1], A3.shape[0], A3.shape[1])
+        return out
+
+    def kron_A1A2x(self, A1, A2, x):
+        out = np.zeros(A1.shape[0] * A2.shape[0])
+        self.lib.oracle_kron_A1A2x_nonsqr(P(out), P(A1), P(A2), P(x), A1.shape[0], A1.shape[1], A2.shape[0], A2.shape[1])
+        return out
+
+    def kron_AoBoC(self, A, B, C):
+        out = np.zeros((A.shape[0] * B.shape[0] * C.shape[0], A.shape[1] * B.shape[1] * C.shape[1]))
+        self.lib.oracle_kron_AoBoC(P(A), P(B), P(C), P(out), A.shape[0], A.shape[1], B.shape[0], B.shape[1], C.shape[0], C.shape[1])
+        return out
+
+    # ---- element-level
+    def apply_dij(self, u, deg, d, transpose=False):
+        out = np.zeros_like(u)
+        (self.lib.oracle_apply_dij_transpose if transpose else self.lib.oracle_apply_dij)(P(u), deg, d, P(out))
+        return out
+
+    def apply_mij(self, u, deg):
+        out = np.zeros_like(u); self.lib.oracle_apply_mij(P(u), deg, P(out)); return out
+
+    def apply_invmij(self, u, deg):
+        out = np.zeros_like(u); self.lib.oracle_apply_invmij(P(u), deg, P(out)); return out
+
+    def apply_slicer(self, u, face, deg):
+        out = np.zeros((deg + 1) ** 2); self.lib.oracle_apply_slicer(P(u), face, deg, P(out)); return out
+
+    def apply_lift(self, f, deg, face):
+        out = np.zeros((deg + 1) ** 3); self.lib.oracle_apply_lift(P(f), deg, face, P(out)); return out
+
+    def stiffness_element(self, quad_type, u, deg, J, rst9, deg_quad):
+        """rst9: list of 9 arrays (3*i+j) of quad-node values"""
+        arr = (dp * 3 * 3)()
+        keep = [np.ascontiguousarray(r, dtype=np.float64) for r in rst9]
+        for i in range(3):
+            for j in range(3):
+                arr[i][j] = P(keep[3 * i + j])
+        out = np.zeros_like(u)
+        self.lib.oracle_quadrature_apply_stiffness_matrix(quad_type, P(u), deg, P(J), arr, deg_quad, P(out))
+        return out
+
+    # ---- mesh-level (flat element list)
+    def apply_stiffness(self, mesh, J, rst, u, nthreads=1):
+        Au = np.zeros(mesh.local_nodes)
+        self.lib.oracle_laplacian_apply_stiffness_matrix(
+            mesh.quad_type, mesh.n_elements, I(mesh.deg), I(mesh.deg_quad), I(mesh.nodal_stride), I(mesh.quad_stride),
+            mesh.local_nodes_quad, P(J), P(rst), P(u), P(Au), nthreads)
+        return Au
+
+    def apply_mass(self, mesh, J, u, nthreads=1):
+        Mu = np.zeros(mesh.local_nodes)
+        self.lib.oracle_laplacian_apply_mass_matrix(
+            mesh.quad_type, mesh.n_elements, I(mesh.deg), I(mesh.deg_quad), I(mesh.nodal_stride), I(mesh.quad_stride),
+            P(J), P(u), P(Mu), nthreads)
+        return Mu
+
+    def apply_galerkin(self, mesh, J, fq):
+        out = np.zeros(mesh.local_nodes)
+        for e in range(mesh.n_elements):
+            s, q = mesh.nodal_stride[e], mesh.quad_stride[e]
+            n3, q3 = (mesh.deg[e] + 1) ** 3, (mesh.deg_quad[e] + 1) ** 3
+            o = np.zeros(n3)
+            self.lib.oracle_quadrature_apply_galerkin_integral(mesh.quad_type, P(np.ascontiguousarray(fq[q:q + q3])), int(mesh.deg[e]),
+                                                               P(np.ascontiguousarray(J[q:q + q3])), int(mesh.deg_quad[e]), P(o))
+            out[s:s + n3] = o
+        return out
+
+    def interpolate(self, mesh, u):
+        out = np.zeros(mesh.local_nodes_quad)
+        for e in range(mesh.n_elements):
+            s, q = mesh.nodal_stride[e], mesh.quad_stride[e]
+            n3, q3 = (mesh.deg[e] + 1) ** 3, (mesh.deg_quad[e] + 1) ** 3
+            o = np.zeros(q3)
+            self.lib.oracle_quadrature_interpolate(mesh.quad_type, P(np.ascontiguousarray(u[s:s + n3])), int(mesh.deg[e]), P(o), int(mesh.deg_quad[e]))
+            out[q:q + q3] = o
+        return out
+
+    def compute_dudr(self, mesh, u):
+        d = [np.zeros(mesh.local_nodes) for _ in range(3)]
+        self.lib.oracle_laplacian_compute_dudr(mesh.n_elements, I(mesh.deg), I(mesh.nodal_stride), P(u), P(d[0]), P(d[1]), P(d[2]))
+        return d
+
+
+_oracle = None
+
+
+def load():
+    global _oracle
+    if _oracle is None:
+        _oracle = Oracle(ctypes.CDLL(build()))
+    return _oracle

@@ -1,0 +1,195 @@
+"""GPU parity tests (through the C-ABI) of the volume kernels against the CPU oracle,
+plus size-independent properties at BASELINE.json's full config-2 size.
+
+fp64 tolerance: the fused kernel re-associates the reference's 27 separately rounded
+passes, so parity is stated relative to ||Au||_inf: 1e-12 (the reference's own
+cross-implementation precedent is 1e-13 absolute per node, d4est_test_laplacian_speedup.c:485)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _plan(m, J, rst):
+    from disco4est_amd import Plan
+    p = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, m.quad_type)
+    p.set_geometry(J, rst)
+    return p
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+CASES = [
+    # (level, deg, inc, quad_type, curved)
+    (1, 1, 0, 0, True), (1, 2, 0, 0, True), (1, 3, 0, 0, False), (1, 3, 0, 0, True), (1, 4, 0, 0, True),
+    (1, 5, 0, 0, True), (1, 6, 0, 0, True), (1, 7, 0, 0, False), (1, 7, 0, 0, True), (1, 8, 0, 0, True),
+    (1, 9, 0, 0, True), (1, 11, 0, 0, True), (0, 15, 0, 0, True), (1, 12, 0, 0, True),
+    (1, 2, 3, 0, True), (1, 3, 1, 0, True), (1, 7, 1, 0, True), (1, 7, 2, 0, True), (1, 3, 2, 0, True),
+    (1, 3, 0, 1, True), (1, 7, 0, 1, True), (1, 2, 1, 1, True),
+    (0, 17, 0, 0, True), (0, 19, 0, 0, False), (1, 5, 2, 0, True), (1, 1, 1, 0, True),
+]
+
+
+@pytest.mark.parametrize("level,deg,inc,qt,curved", CASES)
+def test_stiffness_parity(gpu, hiplib, oracle, level, deg, inc, qt, curved):
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(level, deg, deg_quad_inc=inc, quad_type=qt)
+    mp = M.SineMap(0.06) if curved else None
+    J, rst = m.geometry(mp)
+    u = m.field(mp)
+    ref = oracle.apply_stiffness(m, J, rst, u, nthreads=8)
+    plan = _plan(m, J, rst)
+    du = _t(u, gpu)
+    dAu = torch.full_like(du, float("nan"))  # the apply must overwrite every entry
+    plan.apply_stiffness_matrix(du, dAu)
+    torch.cuda.synchronize()
+    got = dAu.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert _rel(got, ref) <= RTOL
+    # host-pointer convenience path gives the same bits
+    np.testing.assert_array_equal(plan.apply_stiffness_matrix_host(u), got)
+    plan.destroy()
+
+
+def test_stiffness_mixed_p_parity(gpu, hiplib, oracle):
+    """config-4 style: mixed p = 3..9 in one plan (degree-bucketed launches)."""
+    import torch
+    from disco4est_amd import mesh as M
+    deg = 3 + (np.arange(64) * 5) % 7
+    m = M.BrickMesh(2, deg)
+    mp = M.SineMap(0.05)
+    J, rst = m.geometry(mp)
+    u = m.field(mp)
+    ref = oracle.apply_stiffness(m, J, rst, u, nthreads=8)
+    plan = _plan(m, J, rst)
+    du = _t(u, gpu); dAu = torch.full_like(du, float("nan"))
+    plan.apply_stiffness_matrix(du, dAu)
+    got = dAu.cpu().numpy()
+    assert _rel(got, ref) <= RTOL
+    # per-element check so a small-p element cannot hide behind a large-p norm
+    for e in range(m.n_elements):
+        s = m.nodal_stride[e]; n3 = (deg[e] + 1) ** 3
+        assert _rel(got[s:s + n3], ref[s:s + n3]) <= 10 * RTOL
+
+
+def test_golden_probe_on_gpu(gpu, hiplib):
+    """The survey-time outputs of the real reference, reproduced by the HIP kernel."""
+    import json, os, torch
+    from disco4est_amd import Plan, table
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_probe.json")))
+    h = g["h"]
+    for case in g["cases"]:
+        p = case["p"]; n = p + 1
+        x = table("lobatto_nodes", p)
+        X = h * (x + 1) / 2
+        xx, yy, zz = X[None, None, :], X[None, :, None], X[:, None, None]
+        u = (xx ** 2 + 2 * yy ** 2 + 3 * zz ** 2 + xx * yy * zz).reshape(-1).copy()
+        J = np.full(n ** 3, h ** 3 / 8)
+        rst = np.zeros((9, n ** 3)); rst[0] = rst[4] = rst[8] = 2 / h
+        plan = Plan([p], [p], [0], [0], 0)
+        plan.set_geometry(J, rst.reshape(-1))
+        du = _t(u, gpu); dAu = torch.empty_like(du)
+        plan.apply_stiffness_matrix(du, dAu)
+        Au = dAu.cpu().numpy()
+        assert abs((Au ** 2).sum() - case["Au_sq"]) <= 1e-12 * case["Au_sq"]
+        assert abs(Au[0] - case["Au0"]) <= 1e-12 * np.abs(Au).max()
+
+
+@pytest.mark.parametrize("level,deg,inc,qt", [(1, 1, 0, 0), (1, 3, 0, 0), (1, 3, 1, 0), (1, 7, 0, 0), (1, 7, 2, 0), (1, 2, 3, 0),
+                                              (1, 4, 0, 1), (0, 11, 0, 0), (0, 15, 0, 0), (0, 18, 1, 0)])
+def test_mass_galerkin_interp_dudr_parity(gpu, hiplib, oracle, level, deg, inc, qt):
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(level, deg, deg_quad_inc=inc, quad_type=qt)
+    mp = M.SineMap(0.06)
+    J, rst = m.geometry(mp)
+    u = m.field(mp)
+    plan = _plan(m, J, rst)
+    du = _t(u, gpu)
+    out = torch.full_like(du, float("nan"))
+    plan.apply_mass_matrix(du, out)
+    assert _rel(out.cpu().numpy(), oracle.apply_mass(m, J, u)) <= RTOL
+    uq_ref = oracle.interpolate(m, u)
+    duq = torch.full((m.local_nodes_quad,), float("nan"), dtype=torch.float64, device=gpu)
+    plan.interpolate(du, duq)
+    assert _rel(duq.cpu().numpy(), uq_ref) <= RTOL
+    fq = np.cos(uq_ref)
+    out2 = torch.full_like(du, float("nan"))
+    plan.apply_galerkin_integral(_t(fq, gpu), out2)
+    assert _rel(out2.cpu().numpy(), oracle.apply_galerkin(m, J, fq)) <= RTOL
+    d = [torch.full_like(du, float("nan")) for _ in range(3)]
+    plan.compute_dudr(du, *d)
+    dref = oracle.compute_dudr(m, u)
+    for i in range(3):
+        assert _rel(d[i].cpu().numpy(), dref[i]) <= RTOL
+
+
+def test_edge_cases(gpu, hiplib, oracle):
+    """empty plan, single element, ragged element count (not a multiple of elements-per-block)."""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    empty = Plan([], [], [], [], 0)
+    assert empty.local_nodes == 0
+    empty.set_geometry(np.zeros(0), np.zeros(0))
+    z = torch.zeros(0, dtype=torch.float64, device=gpu)
+    empty.apply_stiffness_matrix(z, z.clone())
+    torch.cuda.synchronize()
+    for count in (1, 3, 5, 7):  # p=1: 16 elements per wavefront -> ragged tail
+        m = M.BrickMesh(1, 1, first=0, count=count)
+        J, rst = m.geometry(M.SineMap(0.05)); u = m.field()
+        plan = _plan(m, J, rst)
+        du = _t(u, gpu); dAu = torch.full_like(du, float("nan"))
+        plan.apply_stiffness_matrix(du, dAu)
+        assert _rel(dAu.cpu().numpy(), oracle.apply_stiffness(m, J, rst, u)) <= RTOL
+
+
+def test_full_size_properties_config2(gpu, hiplib, oracle):
+    """BASELINE config 2 (level 4, p = 7, 2 097 152 DoF): properties that need no oracle at size,
+    plus an oracle spot-check on a sample of elements."""
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(4, 7)
+    mp = M.SineMap(0.05)
+    J, rst = m.geometry(mp)
+    plan = _plan(m, J, rst)
+    u = m.field(mp)
+    du = _t(u, gpu)
+    Au = torch.empty_like(du)
+    plan.apply_stiffness_matrix(du, Au)
+    scale = Au.abs().max().item()
+    # constants are in the null space of every element matrix: sum over each element is ~0
+    per_elem = Au.view(m.n_elements, -1).sum(dim=1).abs().max().item()
+    assert per_elem <= 1e-10 * scale * 512
+    ones = torch.ones_like(du); K1 = torch.empty_like(du)
+    plan.apply_stiffness_matrix(ones, K1)
+    assert K1.abs().max().item() <= 1e-11 * scale
+    # symmetry: v.(K u) == u.(K v); linearity: K(a u + v) = a K u + K v
+    v = _t(M.splitmix64_uniform(7, m.local_nodes), gpu)
+    Kv = torch.empty_like(du); plan.apply_stiffness_matrix(v, Kv)
+    s1, s2 = torch.dot(v, Au).item(), torch.dot(du, Kv).item()
+    assert abs(s1 - s2) <= 1e-11 * max(abs(s1), abs(s2))
+    lin = torch.empty_like(du); plan.apply_stiffness_matrix(2.5 * du + v, lin)
+    assert (lin - (2.5 * Au + Kv)).abs().max().item() <= 1e-12 * scale * 4
+    # positive semi-definite energy
+    assert torch.dot(du, Au).item() > 0
+    # determinism: two launches give identical bits
+    Au2 = torch.empty_like(du); plan.apply_stiffness_matrix(du, Au2)
+    assert torch.equal(Au, Au2)
+    # oracle spot-check on 64 elements spread over the Morton curve
+    got = Au.cpu().numpy()
+    for e in range(0, m.n_elements, 64):
+        sub = M.BrickMesh(4, 7, first=e, count=1)
+        Je, rste = sub.geometry(mp)
+        s = m.nodal_stride[e]
+        ref = oracle.apply_stiffness(sub, Je, rste, np.ascontiguousarray(u[s:s + 512]))
+        assert _rel(got[s:s + 512], ref) <= RTOL
