@@ -32,12 +32,15 @@ static double* dalloc(size_t n) {
 
 /* d4est_linalg.c:65-78: C(m x n) = A(m x l) B(l x n), row-major (dgemm there). */
 void oracle_linalg_mat_multiply(const double* A, const double* B, double* C, int m, int l, int n) {
+  const double* restrict a_ = A;
+  const double* restrict b_ = B;
+  double* restrict c_ = C;
   for (int i = 0; i < m; i++) {
-    for (int j = 0; j < n; j++) C[i * n + j] = 0.;
+    double* restrict c = &c_[(size_t)i * n];
+    for (int j = 0; j < n; j++) c[j] = 0.;
     for (int k = 0; k < l; k++) {
-      const double a = A[i * l + k];
-      const double* b = &B[k * n];
-      double* c = &C[i * n];
+      const double a = a_[(size_t)i * l + k];
+      const double* restrict b = &b_[(size_t)k * n];
       for (int j = 0; j < n; j++) c[j] += a * b[j];
     }
   }

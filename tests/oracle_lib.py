@@ -13,9 +13,18 @@ dp = ctypes.POINTER(ctypes.c_double)
 ip = ctypes.POINTER(ctypes.c_int)
 
 
-def build():
+LIB_NATIVE = os.path.join(ODIR, "libd4est_oracle_native.so")
+
+
+def build(native=False):
+    """native=True: -march=native build made ON the machine that runs it (bench.py's cpu_baseline leg)."""
     srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if native:
+        if (not os.path.exists(LIB_NATIVE)) or os.path.getmtime(LIB_NATIVE) < newest:
+            subprocess.check_call(["make", "-C", ODIR, "-s", "-B", "native"])
+        return LIB_NATIVE
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < newest:
         subprocess.check_call(["make", "-C", ODIR, "-s", "-B"])
     return LIB
 
@@ -172,11 +181,10 @@ class Oracle:
         return d
 
 
-_oracle = None
+_oracle = {}
 
 
-def load():
-    global _oracle
-    if _oracle is None:
-        _oracle = Oracle(ctypes.CDLL(build()))
-    return _oracle
+def load(native=False):
+    if native not in _oracle:
+        _oracle[native] = Oracle(ctypes.CDLL(build(native)))
+    return _oracle[native]
