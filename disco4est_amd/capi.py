@@ -29,6 +29,7 @@ SIGNATURES = {
     "d4est_hip_plan_create": (_vp, [ctypes.c_int, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int]),
     "d4est_hip_plan_destroy": (None, [_vp]),
     "d4est_hip_plan_set_stream": (None, [_vp, _vp]),
+    "d4est_hip_plan_set_tuning": (None, [_vp, ctypes.c_int, ctypes.c_int]),
     "d4est_hip_plan_local_nodes": (ctypes.c_int, [_vp]),
     "d4est_hip_plan_local_nodes_quad": (ctypes.c_int, [_vp]),
     "d4est_hip_plan_n_elements": (ctypes.c_int, [_vp]),
@@ -116,6 +117,9 @@ class Plan:
         """stream: a torch.cuda.Stream (its raw hipStream_t is passed through) or an int handle."""
         h = getattr(stream, "cuda_stream", stream)
         self.lib.d4est_hip_plan_set_stream(self.handle, ctypes.c_void_p(int(h)))
+
+    def set_tuning(self, key, value):
+        self.lib.d4est_hip_plan_set_tuning(self.handle, int(key), int(value))
 
     def set_geometry(self, J_quad, rst_xyz_quad):
         """J_quad[local_nodes_quad], rst_xyz_quad[9*local_nodes_quad] (reference SoA layout);

@@ -126,32 +126,44 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
     bk.d_w = upload(Tables1D::quad_weights(quad_type, bk.deg_quad));
     plan->buckets.push_back(bk);
   }
+  std::vector<int> ns_list(ids.size()), qs_list(ids.size());
+  for (size_t i = 0; i < ids.size(); ++i) {
+    ns_list[i] = nodal_stride[ids[i]];
+    qs_list[i] = quad_stride[ids[i]];
+  }
+  plan->elem_ids = ids;
   plan->d_elem_ids = upload_i(ids);
-  plan->d_nodal_stride = upload_i(plan->nodal_stride);
-  plan->d_quad_stride = upload_i(plan->quad_stride);
+  plan->d_ns_list = upload_i(ns_list);
+  plan->d_qs_list = upload_i(qs_list);
   return plan;
 }
 
 void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   if (!plan) return;
   for (Bucket& bk : plan->buckets) {
-    hipFree(bk.d_B);
-    hipFree(bk.d_G);
-    hipFree(bk.d_D);
-    hipFree(bk.d_w);
+    (void)hipFree(bk.d_B);
+    (void)hipFree(bk.d_G);
+    (void)hipFree(bk.d_D);
+    (void)hipFree(bk.d_w);
   }
-  hipFree(plan->d_elem_ids);
-  hipFree(plan->d_nodal_stride);
-  hipFree(plan->d_quad_stride);
-  hipFree(plan->d_J);
-  hipFree(plan->d_metric);
-  hipFree(plan->d_scratch);
+  (void)hipFree(plan->d_elem_ids);
+  (void)hipFree(plan->d_ns_list);
+  (void)hipFree(plan->d_qs_list);
+  (void)hipFree(plan->d_J);
+  (void)hipFree(plan->d_metric);
+  (void)hipFree(plan->d_scratch);
   delete plan;
 }
 
 void d4est_hip_plan_set_stream(d4est_hip_plan_t* plan, void* hip_stream) {
   check_plan(plan, "plan_set_stream");
   plan->stream = reinterpret_cast<hipStream_t>(hip_stream);
+}
+
+void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value) {
+  check_plan(plan, "plan_set_tuning");
+  if (key < 0 || key >= D4EST_HIP_TUNE_COUNT) D4EST_HIP_ABORT("plan_set_tuning: unknown key %d", key);
+  plan->tuning[key] = value;
 }
 
 int d4est_hip_plan_local_nodes(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes"); return plan->local_nodes; }

@@ -30,7 +30,7 @@ struct Bucket {
   int deg = 0, deg_quad = 0;
   int N = 0, NQ = 0;
   int n_elem = 0;
-  int elem_offset = 0;      // offset into Plan::d_elem_ids
+  int elem_offset = 0;      // offset into Plan::d_elem_ids / d_ns_list / d_qs_list
   // device 1-D tables (row-major)
   double* d_B = nullptr;    // NQ x N  interpolation Lobatto -> quadrature nodes
   double* d_G = nullptr;    // NQ x N  G = B * D  (derivative evaluated at quadrature nodes)
@@ -50,13 +50,16 @@ struct d4est_hip_plan {
   std::vector<int> deg, deg_quad, nodal_stride, quad_stride;  // host copies
   std::vector<d4est_hip::Bucket> buckets;
 
-  int* d_elem_ids = nullptr;      // element ids sorted by bucket
-  int* d_nodal_stride = nullptr;  // by element id
-  int* d_quad_stride = nullptr;   // by element id
+  std::vector<int> elem_ids;      // element ids sorted by bucket (host)
+  int* d_elem_ids = nullptr;      // same on the device
+  int* d_ns_list = nullptr;       // nodal_stride in bucket order (one load, wave-uniform when 1 element/wave)
+  int* d_qs_list = nullptr;       // quad_stride in bucket order
 
   bool has_geometry = false;
   double* d_J = nullptr;          // local_nodes_quad  (reference layout)
   double* d_metric = nullptr;     // 6 * local_nodes_quad, element-blocked: [e][c][n], c in (rr,rs,rt,ss,st,tt)
+
+  int tuning[D4EST_HIP_TUNE_COUNT] = {1};  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;

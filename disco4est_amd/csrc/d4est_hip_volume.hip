@@ -83,10 +83,12 @@ __device__ __forceinline__ void contract_t(const double* __restrict__ op, const 
 // ---------------------------------------------------------------------------
 // stiffness:  Au_e = sum_{lp,l} D_lp^T V^T [ M_{lp,l} (V D_l u_e) ]
 // ---------------------------------------------------------------------------
-template <int N, int NQ>
+// PF = true: the thread's 6*NQ metric entries are requested at kernel entry (before the
+// forward contractions) so that HBM latency overlaps the S1-S3 arithmetic; costs 12*NQ VGPRs.
+template <int N, int NQ, bool PF>
 __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
-    const int* __restrict__ elem_ids, const int* __restrict__ nodal_stride, const int* __restrict__ quad_stride,
+    const int* __restrict__ ns_list, const int* __restrict__ qs_list,
     int n_bucket, const double* __restrict__ Bop, const double* __restrict__ Gop) {
   using C = VolCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
@@ -105,9 +107,8 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 
   int ns = 0, qs = 0;
   if (active) {
-    const int e = elem_ids[ei];
-    ns = nodal_stride[e];
-    qs = quad_stride[e];
+    ns = ns_list[ei];
+    qs = qs_list[ei];
   }
 
   // ---- load u_e (coalesced) into R0[k][j][i], i fastest, padded PN
@@ -117,6 +118,15 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
       const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
       R0[i + PN * (j + N * k)] = u[ns + idx];
     }
+  }
+  // ---- metric prefetch: symmetric (rr,rs,rt,ss,st,tt) at the thread's quadrature column, coalesced along (iq,jq)
+  double mreg[PF ? 6 : 1][PF ? NQ : 1];
+  if (PF && active) {
+    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) mreg[c][kq] = m[c * NQ3 + NQ * NQ * kq];
   }
   __syncthreads();
 
@@ -178,8 +188,8 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq) {
       const int q = NQ * NQ * kq;
-      const double m0 = m[q], m1 = m[NQ3 + q], m2 = m[2 * NQ3 + q];
-      const double m3 = m[3 * NQ3 + q], m4 = m[4 * NQ3 + q], m5 = m[5 * NQ3 + q];
+      const double m0 = PF ? mreg[0][kq] : m[q], m1 = PF ? mreg[1][kq] : m[NQ3 + q], m2 = PF ? mreg[2][kq] : m[2 * NQ3 + q];
+      const double m3 = PF ? mreg[3][kq] : m[3 * NQ3 + q], m4 = PF ? mreg[4][kq] : m[4 * NQ3 + q], m5 = PF ? mreg[5][kq] : m[5 * NQ3 + q];
       const double r = gr[kq], s = gs[kq], t = gt[kq];
       gr[kq] = m0 * r + m1 * s + m2 * t;
       gs[kq] = m1 * r + m3 * s + m4 * t;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 template <int N, int NQ, int MODE>
 __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void mass_like_kernel(
     const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ Jq,
-    const int* __restrict__ elem_ids, const int* __restrict__ nodal_stride, const int* __restrict__ quad_stride,
+    const int* __restrict__ ns_list, const int* __restrict__ qs_list,
     int n_bucket, const double* __restrict__ Bop, const double* __restrict__ wq) {
   using C = VolCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ;
@@ -277,9 +287,8 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void mass_like_kernel(
 
   int ns = 0, qs = 0;
   if (active) {
-    const int e = elem_ids[ei];
-    ns = nodal_stride[e];
-    qs = quad_stride[e];
+    ns = ns_list[ei];
+    qs = qs_list[ei];
   }
 
   double g[NQ];  // values at quadrature nodes along kq for thread (iq=a, jq=b)
@@ -402,8 +411,8 @@ __device__ void gen_apply(const double* __restrict__ op, int rows, int so, int s
 
 __global__ __launch_bounds__(256) void generic_volume_kernel(
     int mode /* 0 mass, 1 galerkin, 2 interp, 3 stiffness */, const double* __restrict__ in, double* __restrict__ out,
-    const double* __restrict__ metric, const double* __restrict__ Jq, const int* __restrict__ elem_ids,
-    const int* __restrict__ nodal_stride, const int* __restrict__ quad_stride, int n_bucket, int N, int NQ,
+    const double* __restrict__ metric, const double* __restrict__ Jq, const int* __restrict__ ns_list,
+    const int* __restrict__ qs_list, int n_bucket, int N, int NQ,
     const double* __restrict__ Bop, const double* __restrict__ Gop, const double* __restrict__ wq, double* scratch,
     size_t scratch_per_block) {
   const int NM = N > NQ ? N : NQ;
@@ -412,8 +421,7 @@ __global__ __launch_bounds__(256) void generic_volume_kernel(
   double *t0 = s, *t1 = s + A, *t2 = s + 2 * A, *t3 = s + 3 * A, *t4 = s + 4 * A, *t5 = s + 5 * A, *t6 = s + 6 * A, *t7 = s + 7 * A;
   const int NQ3 = NQ * NQ * NQ;
   for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
-    const int e = elem_ids[ei];
-    const int ns = nodal_stride[e], qs = quad_stride[e];
+    const int ns = ns_list[ei], qs = qs_list[ei];
     const double* ue = in + ns;
     GenDims dn = {{N, N, N}};
     if (mode == 3) {
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(256) void generic_volume_kernel(
 template <int N>
 __global__ __launch_bounds__((VolCfg<N, N>::THREADS)) void dudr_kernel(
     const double* __restrict__ u, double* __restrict__ d0, double* __restrict__ d1, double* __restrict__ d2,
-    const int* __restrict__ elem_ids, const int* __restrict__ nodal_stride, int n_bucket, const double* __restrict__ Dop) {
+    const int* __restrict__ ns_list, int n_bucket, const double* __restrict__ Dop) {
   using C = VolCfg<N, N>;
   constexpr int PL = C::PL, PN = C::PN, N3 = N * N * N;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -498,7 +506,7 @@ __global__ __launch_bounds__((VolCfg<N, N>::THREADS)) void dudr_kernel(
   double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
   double* R1 = R0 + C::FS;
   int ns = 0;
-  if (active) ns = nodal_stride[elem_ids[ei]];
+  if (active) ns = ns_list[ei];
   if (active) {
 #pragma unroll
     for (int idx = te; idx < N3; idx += PL) {
@@ -540,11 +548,10 @@ __global__ __launch_bounds__((VolCfg<N, N>::THREADS)) void dudr_kernel(
 
 __global__ __launch_bounds__(256) void generic_dudr_kernel(const double* __restrict__ u, double* __restrict__ d0,
                                                            double* __restrict__ d1, double* __restrict__ d2,
-                                                           const int* __restrict__ elem_ids,
-                                                           const int* __restrict__ nodal_stride, int n_bucket, int N,
+                                                           const int* __restrict__ ns_list, int n_bucket, int N,
                                                            const double* __restrict__ Dop) {
   for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
-    const int ns = nodal_stride[elem_ids[ei]];
+    const int ns = ns_list[ei];
     GenDims dn = {{N, N, N}};
     gen_apply(Dop, N, N, 1, 0, u + ns, dn, d0 + ns, false);
     gen_apply(Dop, N, N, 1, 1, u + ns, dn, d1 + ns, false);
@@ -557,12 +564,12 @@ __global__ __launch_bounds__(256) void generic_dudr_kernel(const double* __restr
 // from the reference's SoA arrays (setup-time transform).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void metric_precombine_kernel(const double* __restrict__ J, const double* __restrict__ rst,
-                                                                size_t local_nodes_quad, const int* __restrict__ elem_ids,
-                                                                const int* __restrict__ quad_stride, int n_bucket, int NQ,
+                                                                size_t local_nodes_quad, const int* __restrict__ qs_list,
+                                                                int n_bucket, int NQ,
                                                                 const double* __restrict__ wq, double* __restrict__ metric) {
   const int NQ3 = NQ * NQ * NQ;
   for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
-    const int qs = quad_stride[elem_ids[ei]];
+    const int qs = qs_list[ei];
     double* m = metric + (size_t)6 * qs;
     for (int q = threadIdx.x; q < NQ3; q += blockDim.x) {
       const int iq = q % NQ, jq = (q / NQ) % NQ, kq = q / (NQ * NQ);
@@ -610,7 +617,7 @@ static void launch_generic(d4est_hip_plan* plan, const Bucket& bk, int mode, con
   const int grid = bk.n_elem < 1024 ? bk.n_elem : 1024;
   ensure_scratch(plan, per_block * grid);
   hipLaunchKernelGGL(generic_volume_kernel, dim3(grid), dim3(256), 0, plan->stream, mode, in, out, plan->d_metric, plan->d_J,
-                     plan->d_elem_ids + bk.elem_offset, plan->d_nodal_stride, plan->d_quad_stride, bk.n_elem, bk.N, bk.NQ,
+                     plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.N, bk.NQ,
                      bk.d_B, bk.d_G, bk.d_w, plan->d_scratch, per_block);
 }
 
@@ -623,11 +630,19 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   if (!done && bk.N == N_ && bk.NQ == NQ_) {                                                                    \
     using C = VolCfg<N_, NQ_>;                                                                                  \
     if (C::LDS_BYTES <= 160 * 1024) {                                                                           \
-      set_lds_limit(stiffness_kernel<N_, NQ_>, C::LDS_BYTES);                                                   \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                       \
-      hipLaunchKernelGGL((stiffness_kernel<N_, NQ_>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, \
-                         u, Au, plan->d_metric, plan->d_elem_ids + bk.elem_offset, plan->d_nodal_stride,        \
-                         plan->d_quad_stride, bk.n_elem, bk.d_B, bk.d_G);                                       \
+      constexpr bool kCanPF = (NQ_ <= 8);                                                                       \
+      if (kCanPF && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_PREFETCH]) {                                          \
+        set_lds_limit(stiffness_kernel<N_, NQ_, kCanPF>, C::LDS_BYTES);                                         \
+        hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, kCanPF>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,     \
+                           plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,              \
+                           plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);               \
+      } else {                                                                                                  \
+        set_lds_limit(stiffness_kernel<N_, NQ_, false>, C::LDS_BYTES);                                          \
+        hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, false>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,      \
+                           plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,              \
+                           plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);               \
+      }                                                                                                         \
       done = true;                                                                                              \
     }                                                                                                           \
   }
@@ -650,8 +665,8 @@ static void launch_mass_like_mode(d4est_hip_plan* plan, const double* in, double
       set_lds_limit(mass_like_kernel<N_, NQ_, MODE>, C::LDS_BYTES);                                                   \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                             \
       hipLaunchKernelGGL((mass_like_kernel<N_, NQ_, MODE>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, \
-                         in, out, plan->d_J, plan->d_elem_ids + bk.elem_offset, plan->d_nodal_stride,                 \
-                         plan->d_quad_stride, bk.n_elem, bk.d_B, bk.d_w);                                             \
+                         in, out, plan->d_J, plan->d_ns_list + bk.elem_offset,                                        \
+                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_w);                                             \
       done = true;                                                                                                    \
     }                                                                                                                 \
   }
@@ -681,8 +696,7 @@ void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, 
       set_lds_limit(dudr_kernel<N_>, C::LDS_BYTES);                                                        \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                  \
       hipLaunchKernelGGL((dudr_kernel<N_>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, u,   \
-                         d0, d1, d2, plan->d_elem_ids + bk.elem_offset, plan->d_nodal_stride, bk.n_elem,   \
-                         bk.d_D);                                                                          \
+                         d0, d1, d2, plan->d_ns_list + bk.elem_offset, bk.n_elem, bk.d_D);                                                                          \
       done = true;                                                                                         \
     }                                                                                                      \
   }
@@ -691,7 +705,7 @@ void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, 
     if (!done) {
       const int grid = bk.n_elem < 2048 ? bk.n_elem : 2048;
       hipLaunchKernelGGL(generic_dudr_kernel, dim3(grid), dim3(256), 0, plan->stream, u, d0, d1, d2,
-                         plan->d_elem_ids + bk.elem_offset, plan->d_nodal_stride, bk.n_elem, bk.N, bk.d_D);
+                         plan->d_ns_list + bk.elem_offset, bk.n_elem, bk.N, bk.d_D);
     }
   }
   HIP_CHECK(hipGetLastError());
@@ -702,8 +716,8 @@ void launch_metric_precombine(d4est_hip_plan* plan, const double* d_J, const dou
     if (bk.n_elem == 0) continue;
     const int grid = bk.n_elem < 4096 ? bk.n_elem : 4096;
     hipLaunchKernelGGL(metric_precombine_kernel, dim3(grid), dim3(256), 0, plan->stream, d_J, d_rst,
-                       (size_t)plan->local_nodes_quad, plan->d_elem_ids + bk.elem_offset, plan->d_quad_stride, bk.n_elem,
-                       bk.NQ, bk.d_w, plan->d_metric);
+                       (size_t)plan->local_nodes_quad, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.NQ, bk.d_w,
+                       plan->d_metric);
   }
   HIP_CHECK(hipGetLastError());
 }
