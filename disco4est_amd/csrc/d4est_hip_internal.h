@@ -59,7 +59,7 @@ struct d4est_hip_plan {
   double* d_J = nullptr;          // local_nodes_quad  (reference layout)
   double* d_metric = nullptr;     // 6 * local_nodes_quad, element-blocked: [e][c][n], c in (rr,rs,rt,ss,st,tt)
 
-  int tuning[D4EST_HIP_TUNE_COUNT] = {1};  // see d4est_hip_plan_set_tuning
+  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;

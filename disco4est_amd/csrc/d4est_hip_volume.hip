@@ -261,6 +261,234 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Single-wavefront variant (NQ*NQ <= 64, i.e. p <= 7): the whole element lives in one
+// wave, so LDS hand-offs need no s_barrier (program order + the waitcnt the compiler
+// inserts; __syncthreads() in a 64-thread workgroup lowers to exactly that) and only
+// TWO LDS fields are live at any time: the three S2 -> S3 (and S5 -> S6) fields are
+// passed one after the other through the same buffer.  9.2 KB of LDS per element at
+// p = 7 lets 16 waves (4 per SIMD) share a CU, which covers config 2 (4096 elements)
+// in a single resident round.
+// ---------------------------------------------------------------------------
+template <int N, int NQ>
+struct WaveCfg {
+  static constexpr int PL = NQ * NQ;
+  static_assert(PL <= 64, "single-wave kernel needs NQ*NQ <= 64");
+  static constexpr int EPB = 64 / PL;
+  static constexpr int PN = N | 1, PQ = NQ | 1;
+  static constexpr int FS = NQ * NQ * PQ;
+  static constexpr int LDS_PER_ELEM = 2 * FS;
+  static constexpr size_t LDS_BYTES = (size_t)EPB * LDS_PER_ELEM * sizeof(double);
+};
+
+template <int N, int NQ, bool PF>
+__global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
+    const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
+    const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
+    const double* __restrict__ Gop) {
+  using C = WaveCfg<N, NQ>;
+  constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
+  constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const int tid = threadIdx.x;
+  const int slot = tid / PL;
+  const int te = tid - slot * PL;
+  const int a = te % NQ, b = te / NQ;
+  const int ei = blockIdx.x * C::EPB + slot;
+  const bool active = (slot < C::EPB) && (ei < n_bucket);
+  double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
+  double* R1 = R0 + FS;
+
+  int ns = 0, qs = 0;
+  if (active) {
+    ns = ns_list[ei];
+    qs = qs_list[ei];
+  }
+
+  if (active) {
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      R0[i + PN * (j + N * k)] = u[ns + idx];
+    }
+  }
+  double mreg[PF ? 6 : 1][PF ? NQ : 1];
+  if (PF && active) {
+    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) mreg[c][kq] = m[c * NQ3 + NQ * NQ * kq];
+  }
+  __syncthreads();
+
+  // ---- S1: r-contraction, thread (j=a, k=b); u column -> registers, then R0 <- B u, R1 <- G u as [k][iq][j]
+  {
+    double x[N], br[NQ], gr[NQ];
+    const bool on = active && a < N && b < N;
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+      contract_n<N, NQ>(Bop, x, br);
+      contract_n<N, NQ>(Gop, x, gr);
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        R0[a + PN * (iq + NQ * b)] = br[iq];
+        R1[a + PN * (iq + NQ * b)] = gr[iq];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- S2 (thread (iq=a, k=b)) interleaved with S3 (thread (iq=a, jq=b)): one field at a time through R0
+  double gr[NQ], gs[NQ], gt[NQ];
+  {
+    double x1[N], x2[N], t[NQ], y[N];
+    const bool on2 = active && b < N;
+    if (on2) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        x1[j] = R0[j + PN * (a + NQ * b)];  // B_r u
+        x2[j] = R1[j + PN * (a + NQ * b)];  // G_r u
+      }
+    }
+    __syncthreads();
+    // field 1: B_s G_r u  -> gr = B_t(.)
+    if (on2) {
+      contract_n<N, NQ>(Bop, x2, t);
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) y[k] = R0[k + PN * (a + NQ * b)];
+      contract_n<N, NQ>(Bop, y, gr);
+    }
+    // field 2: G_s B_r u  -> gs = B_t(.)   (goes through R1 so the two transfers overlap)
+    if (on2) {
+      contract_n<N, NQ>(Gop, x1, t);
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) R1[b + PN * (a + NQ * jq)] = t[jq];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) y[k] = R1[k + PN * (a + NQ * b)];
+      contract_n<N, NQ>(Bop, y, gs);
+    }
+    // field 3: B_s B_r u  -> gt = G_t(.)
+    if (on2) {
+      contract_n<N, NQ>(Bop, x1, t);
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) y[k] = R0[k + PN * (a + NQ * b)];
+      contract_n<N, NQ>(Gop, y, gt);
+    }
+  }
+
+  // ---- quadrature-point stage
+  if (active) {
+    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) {
+      const int q = NQ * NQ * kq;
+      const double m0 = PF ? mreg[0][kq] : m[q], m1 = PF ? mreg[1][kq] : m[NQ3 + q], m2 = PF ? mreg[2][kq] : m[2 * NQ3 + q];
+      const double m3 = PF ? mreg[3][kq] : m[3 * NQ3 + q], m4 = PF ? mreg[4][kq] : m[4 * NQ3 + q], m5 = PF ? mreg[5][kq] : m[5 * NQ3 + q];
+      const double r = gr[kq], s = gs[kq], t = gt[kq];
+      gr[kq] = m0 * r + m1 * s + m2 * t;
+      gs[kq] = m1 * r + m3 * s + m4 * t;
+      gt[kq] = m2 * r + m4 * s + m5 * t;
+    }
+  }
+
+  // ---- S5 (thread (iq=a, jq=b), registers) interleaved with S6 (thread (iq=a, k=b)) through R0/R1
+  double ar[N], bs[N];
+  {
+    double c[N], x[NQ];
+    const bool on6 = active && b < N;
+    __syncthreads();
+    if (active) {
+      contract_t<NQ, N, false>(Bop, gr, c);
+#pragma unroll
+      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = c[k];  // [k][iq][jq]
+    }
+    __syncthreads();
+    if (on6) {
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+      contract_t<NQ, N, false>(Bop, x, ar);
+    }
+    if (active) {
+      contract_t<NQ, N, false>(Bop, gs, c);
+#pragma unroll
+      for (int k = 0; k < N; ++k) R1[b + PQ * (a + NQ * k)] = c[k];
+    }
+    __syncthreads();
+    if (on6) {
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = R1[jq + PQ * (a + NQ * b)];
+      contract_t<NQ, N, false>(Gop, x, bs);
+    }
+    if (active) {
+      contract_t<NQ, N, false>(Gop, gt, c);
+#pragma unroll
+      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = c[k];
+    }
+    __syncthreads();
+    if (on6) {
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+      contract_t<NQ, N, true>(Bop, x, bs);
+    }
+    __syncthreads();
+    if (on6) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {  // [k][j][iq]
+        R0[a + PQ * (j + N * b)] = ar[j];
+        R1[a + PQ * (j + N * b)] = bs[j];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- S7: r-contraction transposed, thread (j=a, k=b)
+  {
+    double x[NQ], y[NQ], o[N];
+    const bool on = active && a < N && b < N;
+    if (on) {
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        x[iq] = R0[iq + PQ * (a + N * b)];
+        y[iq] = R1[iq + PQ * (a + N * b)];
+      }
+      contract_t<NQ, N, false>(Gop, x, o);
+      contract_t<NQ, N, true>(Bop, y, o);
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = o[i];
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      Au[ns + idx] = R0[i + PN * (j + N * k)];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // mass-like applies (one field):
 //   MODE 0: out = V^T (W J) V in          (mass)            in: nodal, out: nodal
 //   MODE 1: out = V^T (W J) in_quad       (galerkin)        in: quad,  out: nodal
@@ -621,27 +849,54 @@ static void launch_generic(d4est_hip_plan* plan, const Bucket& bk, int mode, con
                      bk.d_B, bk.d_G, bk.d_w, plan->d_scratch, per_block);
 }
 
+template <int N, int NQ>
+static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool use_pf, const double* u, double* Au) {
+  if constexpr (NQ * NQ <= 64 && NQ >= N) {
+    using W = WaveCfg<N, NQ>;
+    const int grid = (bk.n_elem + W::EPB - 1) / W::EPB;
+    if (use_pf)
+      hipLaunchKernelGGL((stiffness_wave_kernel<N, NQ, true>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au,
+                         plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
+                         bk.d_B, bk.d_G);
+    else
+      hipLaunchKernelGGL((stiffness_wave_kernel<N, NQ, false>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au,
+                         plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
+                         bk.d_B, bk.d_G);
+  }
+}
+
 void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   if (!plan->has_geometry) D4EST_HIP_ABORT("apply_stiffness_matrix: d4est_hip_plan_set_geometry was not called");
   for (const Bucket& bk : plan->buckets) {
     if (bk.n_elem == 0) continue;
     bool done = false;
+    // auto-tuning (measured on MI355X, p = 7): up to ~2 resident rounds (16 one-wave workgroups per CU)
+    // the two-buffer wave kernel wins; for larger buckets the 3-buffer kernel with the metric requested
+    // at entry streams HBM best.  profiles/r01_*_ab.txt
+    const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE], tp = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_PREFETCH];
+    const bool use_wave = (tw < 0) ? (bk.n_elem <= 8192) : (tw != 0);
+    const bool use_pf = (tp < 0) ? !use_wave : (tp != 0);
 #define X(N_, NQ_)                                                                                              \
   if (!done && bk.N == N_ && bk.NQ == NQ_) {                                                                    \
     using C = VolCfg<N_, NQ_>;                                                                                  \
     if (C::LDS_BYTES <= 160 * 1024) {                                                                           \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                       \
-      constexpr bool kCanPF = (NQ_ <= 8);                                                                       \
-      if (kCanPF && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_PREFETCH]) {                                          \
-        set_lds_limit(stiffness_kernel<N_, NQ_, kCanPF>, C::LDS_BYTES);                                         \
-        hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, kCanPF>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,     \
-                           plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,              \
-                           plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);               \
+      constexpr bool kWave = (NQ_ * NQ_ <= 64);                                                                 \
+      if (kWave && use_wave) {                                               \
+        launch_stiffness_wave<N_, (kWave ? NQ_ : N_)>(plan, bk, use_pf, u, Au);                                 \
       } else {                                                                                                  \
-        set_lds_limit(stiffness_kernel<N_, NQ_, false>, C::LDS_BYTES);                                          \
-        hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, false>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,      \
-                           plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,              \
-                           plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);               \
+        constexpr bool kCanPF = (NQ_ <= 8);                                                                     \
+        if (kCanPF && use_pf) {                                        \
+          set_lds_limit(stiffness_kernel<N_, NQ_, kCanPF>, C::LDS_BYTES);                                       \
+          hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, kCanPF>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,   \
+                             plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
+                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);                      \
+        } else {                                                                                                \
+          set_lds_limit(stiffness_kernel<N_, NQ_, false>, C::LDS_BYTES);                                        \
+          hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, false>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,    \
+                             plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
+                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);                      \
+        }                                                                                                       \
       }                                                                                                         \
       done = true;                                                                                              \
     }                                                                                                           \

@@ -1,5 +1,5 @@
 """A/B timing of stiffness-kernel tuning variants in ONE process, interleaved rounds
-(cdna_hip_programming.md section 5.4 rule 24).  Usage: python tools/ab_stiffness.py [level] [deg] [key=v0,v1,...]"""
+(cdna_hip_programming.md section 5.4 rule 24).  Usage: python tools/ab_stiffness.py [level] [deg] [k=v,k=v ...]"""
 import os
 import sys
 
@@ -11,10 +11,9 @@ from disco4est_amd import Plan, mesh as M  # noqa: E402
 
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 deg = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-spec = sys.argv[3] if len(sys.argv) > 3 else "0=0,1"
-key, vals = spec.split("=")
-key = int(key)
-vals = [int(v) for v in vals.split(",")]
+# each remaining argument is one configuration: "key=value,key=value"
+cfgs = sys.argv[3:] if len(sys.argv) > 3 else ["0=0,1=0", "0=1,1=0", "0=0,1=1", "0=1,1=1"]
+vals = cfgs
 m = M.BrickMesh(level, deg)
 J, rst = m.geometry(None)
 u = m.field()
@@ -28,7 +27,9 @@ res = {v: [] for v in vals}
 steps = 50
 for rnd in range(12):
     for v in vals:
-        plan.set_tuning(key, v)
+        for kv in v.split(","):
+            k_, v_ = kv.split("=")
+            plan.set_tuning(int(k_), int(v_))
         for _ in range(5):
             plan.apply_stiffness_matrix(du, out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -46,5 +47,5 @@ for rnd in range(12):
 for v in vals:
     t = sorted(res[v])
     med, mn = t[len(t) // 2], t[0]
-    print("level=%d p=%d tune[%d]=%d: median %.2f us  min %.2f us  -> %.1f GDoF/s (median), %.1f GB/s algorithmic" %
-          (level, deg, key, v, med, mn, m.local_nodes / med / 1e3, 64.0 * m.local_nodes / med / 1e3))
+    print("level=%d p=%d tune{%s}: median %.2f us  min %.2f us  -> %.1f GDoF/s (median), %.1f GB/s algorithmic" %
+          (level, deg, v, med, mn, m.local_nodes / med / 1e3, 64.0 * m.local_nodes / med / 1e3))
