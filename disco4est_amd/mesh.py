@@ -74,6 +74,14 @@ class BrickMesh:
         self.quad_stride = np.concatenate([[0], np.cumsum(q3)[:-1]]).astype(np.int32)
         self.local_nodes = int(n3.sum())
         self.local_nodes_quad = int(q3.sum())
+        # global bookkeeping (for shards: where this rank's DoFs sit in the global element-ordered vector)
+        self.deg_global = deg_all
+        self.deg_quad_global = (deg_all + deg_quad_inc).astype(np.int32)
+        g3 = (deg_all.astype(np.int64) + 1) ** 3
+        self.global_nodal_stride = np.concatenate([[0], np.cumsum(g3)[:-1]])
+        self.global_nodes = int(g3.sum())
+        self.global_nodal_offset = int(self.global_nodal_stride[first]) if count > 0 else 0
+        self._ijk_all = ijk
 
     # -- coordinates ---------------------------------------------------------
     def _ref_coords(self, e, nodes_1d):
@@ -135,8 +143,139 @@ class BrickMesh:
         x, y, z = self.nodal_coords(mapping)
         u = x * x + y * y + z * z
         if noise:
-            u = u + noise * splitmix64_uniform(seed, self.local_nodes, offset=int(self.first) * 7919)
+            u = u + noise * splitmix64_uniform(seed, self.local_nodes, offset=self.global_nodal_offset)
         return u
+
+
+    # -- faces ---------------------------------------------------------------
+    def build_sides(self, mapping=None):
+        """Flat (element, face) side list + mortar geometric factors in the reference's layout.
+
+        Mirrors what d4est's face iteration and d4est_mesh_compute_mortar_quadrature_quantities produce
+        (src/Mesh/d4est_mortars.c:601-803, src/Mesh/d4est_mesh.c:868-1110): for side s = 6*e + f the (+)
+        neighbour (local id, -1 = domain boundary, <= -2 = ghost element g = -(v+2)), its face, the face
+        re-orientation code (always 0 inside one tree) and the offset of the side's mortar quadrature data:
+        sj[S+k], n[3S+d*T+k], drst[9S+(i+3j)*T+k] = d r_i/d x_j, hm/hp = J/sj (FACE_H_EQ_J_DIV_SJ_QUAD).
+        Ghost elements are the off-rank face neighbours, ordered by global Morton index.
+        """
+        n = 1 << self.level
+        lookup = -np.ones((n, n, n), dtype=np.int64)
+        lookup[self._ijk_all[:, 0], self._ijk_all[:, 1], self._ijk_all[:, 2]] = np.arange(self.global_elements)
+        ne = self.n_elements
+        side_nbr = np.full(6 * ne, -1, dtype=np.int32)
+        side_nbr_face = np.zeros(6 * ne, dtype=np.int32)
+        side_reorder = np.zeros(6 * ne, dtype=np.int32)
+        nbr_global = np.full(6 * ne, -1, dtype=np.int64)
+        for f in range(6):
+            d, sgn = f // 2, (1 if f % 2 else -1)
+            c = self.ijk.copy()
+            c[:, d] += sgn
+            inside = (c[:, d] >= 0) & (c[:, d] < n)
+            g = np.where(inside, lookup[np.clip(c[:, 0], 0, n - 1), np.clip(c[:, 1], 0, n - 1), np.clip(c[:, 2], 0, n - 1)], -1)
+            nbr_global[f::6] = g
+            side_nbr_face[f::6] = f ^ 1
+        local = (nbr_global >= self.first) & (nbr_global < self.first + ne)
+        ghost_ids = np.unique(nbr_global[(nbr_global >= 0) & ~local])
+        ghost_pos = {int(g): i for i, g in enumerate(ghost_ids)}
+        for s_ in range(6 * ne):
+            g = int(nbr_global[s_])
+            if g < 0:
+                side_nbr[s_] = -1
+            elif local[s_]:
+                side_nbr[s_] = g - self.first
+            else:
+                side_nbr[s_] = -(ghost_pos[g] + 2)
+        ghost_deg = self.deg_global[ghost_ids].astype(np.int32)
+        ghost_deg_quad = self.deg_quad_global[ghost_ids].astype(np.int32)
+        gn3 = (ghost_deg.astype(np.int64) + 1) ** 3
+        ghost_nodal_stride = np.concatenate([[0], np.cumsum(gn3)[:-1]]).astype(np.int32) if len(ghost_ids) else np.zeros(0, np.int32)
+        # per-side sizes / strides
+        deg_p = np.where(side_nbr >= 0, self.deg[np.clip(side_nbr, 0, None)], 0)
+        degq_p = np.where(side_nbr >= 0, self.deg_quad[np.clip(side_nbr, 0, None)], 0)
+        gh = side_nbr <= -2
+        if gh.any():
+            gi = -(side_nbr[gh] + 2)
+            deg_p[gh] = ghost_deg[gi]
+            degq_p[gh] = ghost_deg_quad[gi]
+        deg_m = np.repeat(self.deg, 6)
+        degq_m = np.repeat(self.deg_quad, 6)
+        bnd = side_nbr == -1
+        degq_mortar = np.where(bnd, degq_m, np.maximum(degq_m, degq_p))
+        T = (degq_mortar.astype(np.int64) + 1) ** 2
+        side_mortar_stride = np.concatenate([[0], np.cumsum(T)[:-1]]).astype(np.int32)
+        total = int(T.sum())
+        nb = np.where(bnd, (deg_m.astype(np.int64) + 1) ** 2, 0)
+        side_bndry_stride = np.concatenate([[0], np.cumsum(nb)[:-1]]).astype(np.int32)
+        total_bndry = int(nb.sum())
+        sj = np.empty(total); hm = np.empty(total); hp = np.empty(total)
+        nrm = np.zeros(3 * total); drst_m = np.zeros(9 * total); drst_p = np.zeros(9 * total)
+        bndry_xyz = np.zeros((3, total_bndry))
+        h = self.h
+        qcache, lcache = {}, {}
+        for s_ in range(6 * ne):
+            e, f = divmod(s_, 6)
+            d, sgn = f // 2, (1.0 if f % 2 else -1.0)
+            pq = int(degq_mortar[s_])
+            if pq not in qcache:
+                qcache[pq] = quad_nodes(self.quad_type, pq)
+            t = qcache[pq]
+            S, Tn = int(side_mortar_stride[s_]), int(T[s_])
+            x0 = self.ijk[e] * h
+            ax = [a for a in range(3) if a != d]           # tangential axes, increasing; first is fastest
+            ref = np.zeros((Tn, 3))
+            ref[:, d] = sgn
+            ref[:, ax[0]] = np.tile(t, pq + 1)
+            ref[:, ax[1]] = np.repeat(t, pq + 1)
+            X = x0[None, :] + 0.5 * h * (ref + 1.0)
+            if mapping is None:
+                DF = np.broadcast_to(np.eye(3), (Tn, 3, 3))
+            else:
+                DF = mapping.jacobian(X[:, 0], X[:, 1], X[:, 2])
+            dxdr = DF * (0.5 * h)
+            Jm = np.linalg.det(dxdr)
+            inv = np.linalg.inv(dxdr)
+            v = sgn * Jm[:, None] * inv[:, d, :]
+            sjv = np.linalg.norm(v, axis=1)
+            sj[S:S + Tn] = sjv
+            for j in range(3):
+                nrm[3 * S + j * Tn:3 * S + (j + 1) * Tn] = v[:, j] / sjv
+            for i in range(3):
+                for j in range(3):
+                    drst_m[9 * S + (i + 3 * j) * Tn:9 * S + (i + 3 * j + 1) * Tn] = inv[:, i, j]
+                    drst_p[9 * S + (i + 3 * j) * Tn:9 * S + (i + 3 * j + 1) * Tn] = inv[:, i, j]  # same size, same tree
+            hm[S:S + Tn] = Jm / sjv
+            hp[S:S + Tn] = Jm / sjv
+            if bnd[s_]:
+                p = int(self.deg[e])
+                if p not in lcache:
+                    lcache[p] = table("lobatto_nodes", p)
+                tl = lcache[p]
+                nbn = (p + 1) ** 2
+                refl = np.zeros((nbn, 3))
+                refl[:, d] = sgn
+                refl[:, ax[0]] = np.tile(tl, p + 1)
+                refl[:, ax[1]] = np.repeat(tl, p + 1)
+                XL = x0[None, :] + 0.5 * h * (refl + 1.0)
+                if mapping is not None:
+                    XL = np.stack(mapping.x(XL[:, 0], XL[:, 1], XL[:, 2]), axis=1)
+                B0 = int(side_bndry_stride[s_])
+                bndry_xyz[:, B0:B0 + nbn] = XL.T
+        return dict(side_nbr=side_nbr, side_nbr_face=side_nbr_face, side_reorder=side_reorder,
+                    side_mortar_stride=side_mortar_stride, side_bndry_stride=side_bndry_stride,
+                    total_mortar_nodes=total, total_bndry_nodes=total_bndry, bndry_xyz=bndry_xyz,
+                    sj=sj, n=nrm, drst_m=drst_m, drst_p=drst_p, hm=hm, hp=hp,
+                    ghost_global_ids=ghost_ids, ghost_deg=ghost_deg, ghost_deg_quad=ghost_deg_quad,
+                    ghost_nodal_stride=ghost_nodal_stride, ghost_nodes=int(gn3.sum()))
+
+    def gather_ghost(self, sides, u_global):
+        """ghost-element data (whole elements, as d4est_ghost_data_exchange delivers them,
+        src/Mesh/d4est_ghost_data.c:143-256) taken from a GLOBAL element-ordered vector"""
+        out = np.empty(sides["ghost_nodes"])
+        for i, g in enumerate(sides["ghost_global_ids"]):
+            n3 = (int(sides["ghost_deg"][i]) + 1) ** 3
+            s0 = int(self.global_nodal_stride[g])
+            out[sides["ghost_nodal_stride"][i]:sides["ghost_nodal_stride"][i] + n3] = u_global[s0:s0 + n3]
+        return out
 
 
 class SineMap:

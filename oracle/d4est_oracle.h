@@ -106,6 +106,25 @@ void oracle_laplacian_apply_mass_matrix(int quad_type, int n_elements, const int
 void oracle_laplacian_compute_dudr(int n_elements, const int* deg, const int* nodal_stride,
         const double* u, double* dudr0, double* dudr1, double* dudr2);                                  /* :237-282 */
 
+/* ---- face terms (oracle/d4est_oracle_flux.c): flat (element, face) side list ------------------------------
+ * side s = 6*e + f.  side_nbr[s]: >= 0 local (+) element, -1 boundary, <= -2 ghost element g = -(v+2).
+ * side_nbr_face[s] = f_p.  side_reorder[s] = flip0 | flip1<<1 | transpose<<2 (dGMath/d4est_operators.c:2031-2081).
+ * side_mortar_stride[s] = scalar offset S into the mortar geometry arrays, laid out as the reference does
+ * (dGMath/d4est_laplacian_flux.c:417-449): sj[S+k], n[3S + d*T + k], drst_m / drst_p[9S + (i+3j)*T + k]
+ * (= d r_i / d x_j), hm[S+k], hp[S+k], with T = (deg_mortar_quad+1)^2 nodes on the mortar.
+ * side_bndry_stride[s]: offset of the side's Dirichlet values (Lobatto face nodes) in bndry_lobatto, boundary sides only. */
+double oracle_sipg_penalty(int fcn, int deg_m, double h_m, int deg_p, double h_p, double prefactor); /* d4est_laplacian_flux_sipg.c:945-1005 */
+void oracle_reorient_face_data(const double* in, int deg, int code, double* out);                    /* d4est_operators.c:1993-2087 */
+void oracle_laplacian_apply_aij(int quad_type, int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
+                                const int* quad_stride, int local_nodes, int local_nodes_quad, const double* J_quad,
+                                const double* rst_xyz_quad, int n_ghost, const int* ghost_deg, const int* ghost_deg_quad,
+                                const int* ghost_nodal_stride, int ghost_nodes, const int* side_nbr, const int* side_nbr_face,
+                                const int* side_reorder, const int* side_mortar_stride, const int* side_bndry_stride,
+                                const double* sj, const double* n, const double* drst_m, const double* drst_p,
+                                const double* hm, const double* hp, double penalty_prefactor, int penalty_fcn,
+                                const double* u, const double* u_ghost, const double* bndry_lobatto, double* Au,
+                                int stiffness_threads);                                              /* d4est_laplacian.c:318-417 */
+
 #ifdef __cplusplus
 }
 #endif

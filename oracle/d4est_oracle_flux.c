@@ -1,0 +1,306 @@
+/*
+ * oracle/d4est_oracle_flux.c -- TEST INFRASTRUCTURE ONLY (see d4est_oracle.h).
+ *
+ * CPU restatement of the face part of d4est's weak Laplacian on a FLAT side list
+ * (one entry per (local element, face) "(-) side", the unit the reference's
+ * p4est_iterate face callback hands to the flux function, Mesh/d4est_mortars.c:601-803):
+ *   d4est_laplacian_flux_interface / _boundary   dGMath/d4est_laplacian_flux.c:232-1014, :23-230
+ *   d4est_laplacian_flux_sipg_interface / _dirichlet  dGMath/d4est_laplacian_flux_sipg.c:494-942, :15-336
+ *   d4est_laplacian_apply_aij                     dGMath/d4est_laplacian.c:318-417
+ * Covered: conforming mortars (faces_m = faces_p = 1) with different p on the two
+ * sides, p4est face re-orientation given as a (flip0, flip1, transpose) code
+ * (dGMath/d4est_operators.c:2031-2081), local or ghost (+) side, Dirichlet boundaries
+ * with the boundary function evaluated on the Lobatto face nodes
+ * (EVAL_BNDRY_FCN_ON_LOBATTO, d4est_laplacian_flux_sipg.c:108-112).  Hanging (1<->4)
+ * mortars are the next tier.
+ */
+#include "d4est_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FLUX_ABORT(msg) do { fprintf(stderr, "[ORACLE_ABORT] %s (%s:%d)\n", msg, __FILE__, __LINE__); abort(); } while (0)
+
+static double* dalloc(size_t n) {
+  double* p = (double*)malloc(sizeof(double) * (n ? n : 1));
+  if (!p) FLUX_ABORT("out of memory");
+  return p;
+}
+
+/* d4est_laplacian_flux_sipg.c:945-1005 */
+double oracle_sipg_penalty(int fcn, int deg_m, double h_m, int deg_p, double h_p, double prefactor) {
+  if (fcn == 0) { /* maxp_sqr_over_minh (default) */
+    double max_deg = (deg_m > deg_p) ? deg_m : deg_p;
+    double min_h = (h_m < h_p) ? h_m : h_p;
+    return (prefactor * (max_deg) * (max_deg)) / min_h;
+  } else if (fcn == 1) { /* meanp_sqr_over_meanh */
+    double mean_p = .5 * (deg_m + deg_p);
+    double mean_h = .5 * (h_m + h_p);
+    return (prefactor * mean_p * mean_p) / mean_h;
+  } else if (fcn == 2) { /* maxpp1_sqr_over_minh */
+    double max_deg = (deg_m > deg_p) ? deg_m : deg_p;
+    double min_h = (h_m < h_p) ? h_m : h_p;
+    return (prefactor * (max_deg + 1) * (max_deg + 1)) / min_h;
+  } else if (fcn == 3) { /* mean_p_sqr_over_h */
+    double mean_penalty = .5 * (deg_m * deg_m / h_m + deg_p * deg_p / h_p);
+    return prefactor * mean_penalty;
+  }
+  FLUX_ABORT("unknown penalty function");
+  return 0.;
+}
+
+/* d4est_operators.c:1993-2087 with the p4est_expand_face_transform result passed in as
+ * code = flip0 | flip1 << 1 | (not aligned) << 2 ; flips per d4est_operators.c:1951-1991 */
+void oracle_reorient_face_data(const double* in, int deg, int code, double* out) {
+  int n = deg + 1;
+  double* t0 = dalloc((size_t)n * n);
+  double* t1 = dalloc((size_t)n * n);
+  for (int b = 0; b < n; b++)
+    for (int a = 0; a < n; a++) t0[a + n * b] = (code & 1) ? in[(deg - a) + n * b] : in[a + n * b];
+  for (int b = 0; b < n; b++)
+    for (int a = 0; a < n; a++) t1[a + n * b] = (code & 2) ? t0[a + n * (deg - b)] : t0[a + n * b];
+  for (int b = 0; b < n; b++)
+    for (int a = 0; a < n; a++) out[a + n * b] = (code & 4) ? t1[b + n * a] : t1[a + n * b];
+  free(t0); free(t1);
+}
+
+/* 2-D versions of d4est_quadrature_interpolate (d4est_quadrature.c:966-1016, dim == 2 branch) and
+ * d4est_quadrature_apply_galerkin_integral with jac = 1 (d4est_quadrature.c:197-201) */
+static void interp2d(int quad_type, const double* in, int deg_lobatto, double* out, int deg_quad) {
+  int nl = deg_lobatto + 1, nq = deg_quad + 1;
+  double* I = dalloc((size_t)nq * nl);
+  oracle_quad_interp(quad_type, deg_lobatto, deg_quad, I);
+  oracle_kron_A1A2x_nonsqr(out, I, I, in, nq, nl, nq, nl);
+  free(I);
+}
+
+static void galerkin2d(int quad_type, const double* in_quad, int deg_lobatto, int deg_quad, double* out) {
+  int nl = deg_lobatto + 1, nq = deg_quad + 1;
+  double* I = dalloc((size_t)nq * nl);
+  double* It = dalloc((size_t)nq * nl);
+  double* w = dalloc(nq);
+  double* wx = dalloc((size_t)nq * nq);
+  oracle_quad_interp(quad_type, deg_lobatto, deg_quad, I);
+  oracle_linalg_mat_transpose_nonsqr(I, It, nq, nl);
+  oracle_quad_weights(quad_type, deg_quad, w);
+  /* d4est_kron_vec1_o_vec2_dot_xy with y = ones: w_i w_k x */
+  for (int i = 0; i < nq; i++)
+    for (int k = 0; k < nq; k++) wx[k + i * nq] = w[i] * w[k] * 1.0 * in_quad[k + i * nq];
+  oracle_kron_A1A2x_nonsqr(out, It, It, wx, nl, nq, nl, nq);
+  free(I); free(It); free(w); free(wx);
+}
+
+typedef struct {
+  int quad_type;
+  int n_elements;
+  const int *deg, *deg_quad, *nodal_stride;
+  int n_ghost;
+  const int *ghost_deg, *ghost_deg_quad, *ghost_nodal_stride;
+  const int *side_nbr, *side_nbr_face, *side_reorder, *side_mortar_stride, *side_bndry_stride;
+  const double *sj, *n, *drst_m, *drst_p, *hm, *hp;
+  double penalty_prefactor;
+  int penalty_fcn;
+} flux_ctx_t;
+
+static int nbr_deg(const flux_ctx_t* c, int nbr) { return nbr >= 0 ? c->deg[nbr] : c->ghost_deg[-(nbr + 2)]; }
+static int nbr_deg_quad(const flux_ctx_t* c, int nbr) { return nbr >= 0 ? c->deg_quad[nbr] : c->ghost_deg_quad[-(nbr + 2)]; }
+
+/* one conforming interface side: dGMath/d4est_laplacian_flux.c:232-1014 + d4est_laplacian_flux_sipg.c:494-942 */
+static void flux_interface_side(const flux_ctx_t* c, int e, int f_m, const double* u, const double* u_ghost,
+                                double* const dudr_local[3], double* const dudr_ghost[3], double* Au) {
+  const int s = 6 * e + f_m;
+  const int nbr = c->side_nbr[s], f_p = c->side_nbr_face[s], code = c->side_reorder[s];
+  const int deg_m = c->deg[e], deg_p = nbr_deg(c, nbr);
+  const int deg_mq = (c->deg_quad[e] > nbr_deg_quad(c, nbr)) ? c->deg_quad[e] : nbr_deg_quad(c, nbr); /* deg_mortar_quad */
+  const int deg_ml = (deg_m > deg_p) ? deg_m : deg_p;                                                 /* deg_mortar_lobatto */
+  const int fm = (deg_m + 1) * (deg_m + 1), fp = (deg_p + 1) * (deg_p + 1);
+  const int T = (deg_mq + 1) * (deg_mq + 1), TL = (deg_ml + 1) * (deg_ml + 1);
+  const int S = c->side_mortar_stride[s];
+  const double* sj = &c->sj[S];
+  const double* hm = &c->hm[S];
+  const double* hp = &c->hp[S];
+  const double* nrm[3];
+  const double *rm[3][3], *rp[3][3];
+  for (int d = 0; d < 3; d++) nrm[d] = &c->n[(size_t)3 * S + (size_t)d * T];
+  for (int d1 = 0; d1 < 3; d1++)
+    for (int d2 = 0; d2 < 3; d2++) {
+      rm[d1][d2] = &c->drst_m[(size_t)9 * S + (size_t)(d1 + 3 * d2) * T];
+      rp[d1][d2] = &c->drst_p[(size_t)9 * S + (size_t)(d1 + 3 * d2) * T];
+    }
+  const double* um = &u[c->nodal_stride[e]];
+  const double* up = nbr >= 0 ? &u[c->nodal_stride[nbr]] : &u_ghost[c->ghost_nodal_stride[-(nbr + 2)]];
+  const int p_off = nbr >= 0 ? c->nodal_stride[nbr] : c->ghost_nodal_stride[-(nbr + 2)];
+  double* const* dudr_p_src = nbr >= 0 ? dudr_local : dudr_ghost;
+
+  double* u_m_f = dalloc(fm); double* u_p_f = dalloc(fp); double* tmp = dalloc(fp > T ? fp : T);
+  double* u_m_mortar = dalloc(T); double* u_p_mortar = dalloc(T);
+  double* u_m_q = dalloc(T); double* u_p_q = dalloc(T);
+  double *dudr_m_q[3], *dudr_p_q[3], *dudx_m[3], *dudx_p_porder[3], *dudx_p[3];
+  for (int d = 0; d < 3; d++) { dudr_m_q[d] = dalloc(T); dudr_p_q[d] = dalloc(T); dudx_m[d] = dalloc(T); dudx_p_porder[d] = dalloc(T); dudx_p[d] = dalloc(T); }
+
+  /* traces of u, (+) side re-oriented to the (-) ordering (:575-633) */
+  oracle_apply_slicer(um, f_m, deg_m, u_m_f);
+  oracle_apply_slicer(up, f_p, deg_p, tmp);
+  oracle_reorient_face_data(tmp, deg_p, code, u_p_f);
+  /* project onto the mortar space (p-prolong to deg_mortar_quad) and interpolate to the quadrature nodes (:635-694) */
+  oracle_apply_p_prolong(u_m_f, deg_m, 2, deg_mq, u_m_mortar);
+  oracle_apply_p_prolong(u_p_f, deg_p, 2, deg_mq, u_p_mortar);
+  interp2d(c->quad_type, u_m_mortar, deg_mq, u_m_q, deg_mq);
+  interp2d(c->quad_type, u_p_mortar, deg_mq, u_p_q, deg_mq);
+  /* dudr traces: (-) side in (-) order, (+) side in its OWN order (:698-815) */
+  for (int d = 0; d < 3; d++) {
+    double* a = dalloc(fm > fp ? fm : fp);
+    double* b = dalloc(T);
+    oracle_apply_slicer(&dudr_local[d][c->nodal_stride[e]], f_m, deg_m, a);
+    oracle_apply_p_prolong(a, deg_m, 2, deg_mq, b);
+    interp2d(c->quad_type, b, deg_mq, dudr_m_q[d], deg_mq);
+    oracle_apply_slicer(&dudr_p_src[d][p_off], f_p, deg_p, a);
+    oracle_apply_p_prolong(a, deg_p, 2, deg_mq, b);
+    interp2d(c->quad_type, b, deg_mq, dudr_p_q[d], deg_mq);
+    free(a); free(b);
+  }
+  /* du/dx_j = sum_i (dr_i/dx_j) du/dr_i (:816-856) */
+  for (int j = 0; j < 3; j++) {
+    for (int k = 0; k < T; k++) { dudx_m[j][k] = 0.; dudx_p_porder[j][k] = 0.; }
+    for (int i = 0; i < 3; i++)
+      for (int k = 0; k < T; k++) {
+        dudx_m[j][k] += rm[i][j][k] * dudr_m_q[i][k];
+        dudx_p_porder[j][k] += rp[i][j][k] * dudr_p_q[i][k];
+      }
+  }
+  for (int d = 0; d < 3; d++) oracle_reorient_face_data(dudx_p_porder[d], deg_mq, code, dudx_p[d]); /* :858-900 */
+
+  /* SIPG terms at the mortar quadrature nodes (d4est_laplacian_flux_sipg.c:571-640) */
+  double* term1 = dalloc(T); double* term3 = dalloc(T); double* term2[3];
+  for (int l = 0; l < 3; l++) term2[l] = dalloc(T);
+  for (int k = 0; k < T; k++) {
+    double sigma = 1.0 * oracle_sipg_penalty(c->penalty_fcn, deg_m, hm[k], deg_p, hp[k], c->penalty_prefactor);
+    term1[k] = 0.;
+    for (int d = 0; d < 3; d++) term1[k] += -1. * nrm[d][k] * sj[k] * .5 * (dudx_p[d][k] + dudx_m[d][k]);
+    for (int l = 0; l < 3; l++) {
+      term2[l][k] = 0.;
+      for (int d = 0; d < 3; d++) term2[l][k] += -.5 * rm[l][d][k] * sj[k] * nrm[d][k] * (u_m_q[k] - u_p_q[k]);
+    }
+    term3[k] = sj[k] * sigma * (u_m_q[k] - u_p_q[k]);
+  }
+  /* V^T W on the mortar, project onto the (-) side, lift, D^T, accumulate (:641-790, :896-927) */
+  const int deg = deg_m, vn = (deg + 1) * (deg + 1) * (deg + 1);
+  double* vt = dalloc(TL); double* proj = dalloc(fm); double* lifted = dalloc(vn); double* dt = dalloc(vn);
+  double* Au_m = &Au[c->nodal_stride[e]];
+  double* acc2 = dalloc(vn); double* acc3 = dalloc(vn); double* acc1 = dalloc(vn);
+  double* t2sum = dalloc((size_t)3 * vn);
+  for (int l = 0; l < 3; l++) {
+    galerkin2d(c->quad_type, term2[l], deg_ml, deg_mq, vt);
+    oracle_apply_p_prolong_transpose(vt, deg_ml, 2, deg_m, proj);
+    oracle_apply_lift(proj, deg, f_m, lifted);
+    oracle_apply_dij_transpose(lifted, deg, l, &t2sum[(size_t)l * vn]);
+  }
+  galerkin2d(c->quad_type, term1, deg_ml, deg_mq, vt);
+  oracle_apply_p_prolong_transpose(vt, deg_ml, 2, deg_m, proj);
+  oracle_apply_lift(proj, deg, f_m, acc1);
+  galerkin2d(c->quad_type, term3, deg_ml, deg_mq, vt);
+  oracle_apply_p_prolong_transpose(vt, deg_ml, 2, deg_m, proj);
+  oracle_apply_lift(proj, deg, f_m, acc3);
+  for (int i = 0; i < vn; i++) {
+    for (int d = 0; d < 3; d++) Au_m[i] += t2sum[(size_t)d * vn + i];
+    Au_m[i] += acc3[i];
+    Au_m[i] += acc1[i];
+  }
+  free(u_m_f); free(u_p_f); free(tmp); free(u_m_mortar); free(u_p_mortar); free(u_m_q); free(u_p_q);
+  for (int d = 0; d < 3; d++) { free(dudr_m_q[d]); free(dudr_p_q[d]); free(dudx_m[d]); free(dudx_p_porder[d]); free(dudx_p[d]); free(term2[d]); }
+  free(term1); free(term3); free(vt); free(proj); free(lifted); free(dt); free(acc1); free(acc2); free(acc3); free(t2sum);
+}
+
+/* one Dirichlet boundary side: d4est_laplacian_flux.c:23-230 + d4est_laplacian_flux_sipg.c:15-336 */
+static void flux_boundary_side(const flux_ctx_t* c, int e, int f_m, const double* u, double* const dudr_local[3],
+                               const double* bndry_lobatto, double* Au) {
+  const int s = 6 * e + f_m;
+  const int deg = c->deg[e], deg_q = c->deg_quad[e];
+  const int fm = (deg + 1) * (deg + 1), T = (deg_q + 1) * (deg_q + 1), vn = fm * (deg + 1);
+  const int S = c->side_mortar_stride[s];
+  const double* sj = &c->sj[S];
+  const double* h = &c->hm[S];
+  const double* nrm[3];
+  const double* r[3][3];
+  for (int d = 0; d < 3; d++) nrm[d] = &c->n[(size_t)3 * S + (size_t)d * T];
+  for (int d1 = 0; d1 < 3; d1++)
+    for (int d2 = 0; d2 < 3; d2++) r[d1][d2] = &c->drst_m[(size_t)9 * S + (size_t)(d1 + 3 * d2) * T];
+  double* u_f = dalloc(fm); double* u_q = dalloc(T); double* g_q = dalloc(T);
+  double *dudr_q[3], *dudx[3], *term2[3];
+  double* a = dalloc(fm);
+  for (int d = 0; d < 3; d++) {
+    dudr_q[d] = dalloc(T); dudx[d] = dalloc(T); term2[d] = dalloc(T);
+    oracle_apply_slicer(&dudr_local[d][c->nodal_stride[e]], f_m, deg, a);
+    interp2d(c->quad_type, a, deg, dudr_q[d], deg_q);
+  }
+  oracle_apply_slicer(&u[c->nodal_stride[e]], f_m, deg, u_f);
+  for (int j = 0; j < 3; j++) {
+    for (int k = 0; k < T; k++) dudx[j][k] = 0.;
+    for (int i = 0; i < 3; i++)
+      for (int k = 0; k < T; k++) dudx[j][k] += r[i][j][k] * dudr_q[i][k];
+  }
+  interp2d(c->quad_type, u_f, deg, u_q, deg_q);
+  /* boundary values on the Lobatto face nodes, interpolated to the quadrature nodes (sipg.c:80-107) */
+  const double* g = (bndry_lobatto && c->side_bndry_stride) ? &bndry_lobatto[c->side_bndry_stride[s]] : NULL;
+  if (g) interp2d(c->quad_type, g, deg, g_q, deg_q);
+  else for (int k = 0; k < T; k++) g_q[k] = 0.;
+  double* term1 = dalloc(T); double* term3 = dalloc(T);
+  for (int k = 0; k < T; k++) {
+    double sigma = 1.0 * oracle_sipg_penalty(c->penalty_fcn, deg, h[k], deg, h[k], c->penalty_prefactor);
+    double du = u_q[k] - g_q[k];
+    term1[k] = 0.;
+    for (int d = 0; d < 3; d++) term1[k] += -1. * nrm[d][k] * sj[k] * (dudx[d][k]);
+    for (int l = 0; l < 3; l++) {
+      term2[l][k] = 0.;
+      for (int d = 0; d < 3; d++) term2[l][k] += -.5 * r[l][d][k] * nrm[d][k] * sj[k] * 2. * du;
+    }
+    term3[k] = sj[k] * sigma * du;
+  }
+  double* vt = dalloc(fm); double* lifted = dalloc(vn); double* t2 = dalloc((size_t)3 * vn); double* l1 = dalloc(vn); double* l3 = dalloc(vn);
+  galerkin2d(c->quad_type, term1, deg, deg_q, vt);
+  oracle_apply_lift(vt, deg, f_m, l1);
+  for (int d = 0; d < 3; d++) {
+    galerkin2d(c->quad_type, term2[d], deg, deg_q, vt);
+    oracle_apply_lift(vt, deg, f_m, lifted);
+    oracle_apply_dij_transpose(lifted, deg, d, &t2[(size_t)d * vn]);
+  }
+  galerkin2d(c->quad_type, term3, deg, deg_q, vt);
+  oracle_apply_lift(vt, deg, f_m, l3);
+  double* Au_m = &Au[c->nodal_stride[e]];
+  for (int i = 0; i < vn; i++) { /* sipg.c:318-326 */
+    for (int d = 0; d < 3; d++) Au_m[i] += t2[(size_t)d * vn + i];
+    Au_m[i] += l3[i];
+    Au_m[i] += l1[i];
+  }
+  free(u_f); free(u_q); free(g_q); free(a); free(term1); free(term3); free(vt); free(lifted); free(t2); free(l1); free(l3);
+  for (int d = 0; d < 3; d++) { free(dudr_q[d]); free(dudx[d]); free(term2[d]); }
+}
+
+/* d4est_laplacian_apply_aij (dGMath/d4est_laplacian.c:318-417): stiffness (overwrites Au), ghost data assumed
+ * exchanged (u_ghost), dudr on local + ghost elements, then the mortar terms accumulated into Au. */
+void oracle_laplacian_apply_aij(int quad_type, int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
+                                const int* quad_stride, int local_nodes, int local_nodes_quad, const double* J_quad,
+                                const double* rst_xyz_quad, int n_ghost, const int* ghost_deg, const int* ghost_deg_quad,
+                                const int* ghost_nodal_stride, int ghost_nodes, const int* side_nbr, const int* side_nbr_face,
+                                const int* side_reorder, const int* side_mortar_stride, const int* side_bndry_stride,
+                                const double* sj, const double* n, const double* drst_m, const double* drst_p,
+                                const double* hm, const double* hp, double penalty_prefactor, int penalty_fcn,
+                                const double* u, const double* u_ghost, const double* bndry_lobatto, double* Au,
+                                int stiffness_threads) {
+  flux_ctx_t c = {quad_type, n_elements, deg, deg_quad, nodal_stride, n_ghost, ghost_deg, ghost_deg_quad, ghost_nodal_stride,
+                  side_nbr, side_nbr_face, side_reorder, side_mortar_stride, side_bndry_stride, sj, n, drst_m, drst_p, hm, hp,
+                  penalty_prefactor, penalty_fcn};
+  oracle_laplacian_apply_stiffness_matrix(quad_type, n_elements, deg, deg_quad, nodal_stride, quad_stride, local_nodes_quad,
+                                          J_quad, rst_xyz_quad, u, Au, stiffness_threads);
+  double *dl[3], *dg[3];
+  for (int d = 0; d < 3; d++) { dl[d] = dalloc(local_nodes); dg[d] = dalloc(ghost_nodes); }
+  oracle_laplacian_compute_dudr(n_elements, deg, nodal_stride, u, dl[0], dl[1], dl[2]);
+  if (n_ghost > 0) oracle_laplacian_compute_dudr(n_ghost, ghost_deg, ghost_nodal_stride, u_ghost, dg[0], dg[1], dg[2]);
+  for (int e = 0; e < n_elements; e++)
+    for (int f = 0; f < 6; f++) {
+      if (side_nbr[6 * e + f] == -1) flux_boundary_side(&c, e, f, u, dl, bndry_lobatto, Au);
+      else flux_interface_side(&c, e, f, u, u_ghost, dl, dg, Au);
+    }
+  for (int d = 0; d < 3; d++) { free(dl[d]); free(dg[d]); }
+}

@@ -175,6 +175,24 @@ class Oracle:
             out[q:q + q3] = o
         return out
 
+    def apply_aij(self, mesh, J, rst, sides, u, u_ghost=None, bndry_lobatto=None, penalty_prefactor=10.0, penalty_fcn=0, nthreads=1):
+        """d4est_laplacian_apply_aij on the flat side list of mesh.build_sides()"""
+        Au = np.zeros(mesh.local_nodes)
+        ug = np.zeros(max(sides["ghost_nodes"], 1)) if u_ghost is None else np.ascontiguousarray(u_ghost)
+        bl = None if bndry_lobatto is None else np.ascontiguousarray(bndry_lobatto, dtype=np.float64)
+        f = self.lib.oracle_laplacian_apply_aij
+        f.argtypes = [ctypes.c_int, ctypes.c_int, ip, ip, ip, ip, ctypes.c_int, ctypes.c_int, dp, dp,
+                      ctypes.c_int, ip, ip, ip, ctypes.c_int, ip, ip, ip, ip, ip,
+                      dp, dp, dp, dp, dp, dp, ctypes.c_double, ctypes.c_int, dp, dp, dp, dp, ctypes.c_int]
+        gd, gq, gs = (np.ascontiguousarray(sides[k], dtype=np.int32) for k in ("ghost_deg", "ghost_deg_quad", "ghost_nodal_stride"))
+        f(mesh.quad_type, mesh.n_elements, I(mesh.deg), I(mesh.deg_quad), I(mesh.nodal_stride), I(mesh.quad_stride),
+          mesh.local_nodes, mesh.local_nodes_quad, P(J), P(rst), len(gd), I(gd), I(gq), I(gs), int(sides["ghost_nodes"]),
+          I(sides["side_nbr"]), I(sides["side_nbr_face"]), I(sides["side_reorder"]), I(sides["side_mortar_stride"]),
+          I(sides["side_bndry_stride"]), P(sides["sj"]), P(sides["n"]), P(sides["drst_m"]), P(sides["drst_p"]),
+          P(sides["hm"]), P(sides["hp"]), float(penalty_prefactor), int(penalty_fcn), P(u), P(ug),
+          (P(bl) if bl is not None else None), P(Au), nthreads)
+        return Au
+
     def compute_dudr(self, mesh, u):
         d = [np.zeros(mesh.local_nodes) for _ in range(3)]
         self.lib.oracle_laplacian_compute_dudr(mesh.n_elements, I(mesh.deg), I(mesh.nodal_stride), P(u), P(d[0]), P(d[1]), P(d[2]))
