@@ -13,6 +13,7 @@ SOURCES = [
     "d4est_hip_tables.cpp",
     "d4est_hip_capi.hip",
     "d4est_hip_volume.hip",
+    "d4est_hip_faces.hip",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

@@ -39,6 +39,17 @@ SIGNATURES = {
     "d4est_hip_apply_galerkin_integral": (None, [_vp, _vp, _vp]),
     "d4est_hip_interpolate": (None, [_vp, _vp, _vp]),
     "d4est_hip_compute_dudr": (None, [_vp, _vp, _vp, _vp, _vp]),
+    "d4est_hip_plan_set_faces": (None, [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, _c_int_p, _c_int_p]),
+    "d4est_hip_plan_set_sipg": (None, [_vp, ctypes.c_double, ctypes.c_int]),
+    "d4est_hip_plan_set_mortar_geometry": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
+    "d4est_hip_plan_set_dirichlet_values": (None, [_vp, _vp, ctypes.c_int]),
+    "d4est_hip_plan_trace_size": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_plan_ghost_trace_size": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_compute_ghost_traces": (None, [_vp, _vp, _vp]),
+    "d4est_hip_compute_face_traces": (None, [_vp, _vp, _vp]),
+    "d4est_hip_apply_flux": (None, [_vp, _vp, _vp, _vp]),
+    "d4est_hip_apply_aij": (None, [_vp, _vp, _vp, _vp]),
     "d4est_hip_apply_stiffness_matrix_host": (None, [_vp, _vp, _vp]),
 }
 
@@ -153,6 +164,43 @@ class Plan:
         for t in (u, d0, d1, d2):
             assert t.numel() == self.local_nodes
         self.lib.d4est_hip_compute_dudr(self.handle, _ptr(u), _ptr(d0), _ptr(d1), _ptr(d2))
+
+    # ---- faces
+    def set_faces(self, sides, penalty_prefactor=10.0, penalty_fcn=0):
+        """sides: the dict of mesh.BrickMesh.build_sides() (reference-layout side list + mortar factors)"""
+        keep = [_iarr(sides[k]) for k in ("side_nbr", "side_nbr_face", "side_reorder", "side_mortar_stride", "side_bndry_stride",
+                                         "ghost_deg", "ghost_deg_quad")]
+        self._keep_sides = keep
+        self.lib.d4est_hip_plan_set_faces(self.handle, keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
+                                          int(sides["total_mortar_nodes"]), int(sides["total_bndry_nodes"]),
+                                          len(keep[5][0]), keep[5][1], keep[6][1])
+        self.lib.d4est_hip_plan_set_sipg(self.handle, float(penalty_prefactor), int(penalty_fcn))
+        arrs = [np.ascontiguousarray(sides[k], dtype=np.float64) for k in ("sj", "n", "drst_m", "drst_p", "hm", "hp")]
+        self.lib.d4est_hip_plan_set_mortar_geometry(self.handle, *[a.ctypes.data_as(_vp) for a in arrs], 0)
+        self.trace_size = self.lib.d4est_hip_plan_trace_size(self.handle)
+        self.ghost_trace_size = self.lib.d4est_hip_plan_ghost_trace_size(self.handle)
+
+    def set_dirichlet_values(self, g):
+        if g is None:
+            self.lib.d4est_hip_plan_set_dirichlet_values(self.handle, None, 0)
+        else:
+            g = np.ascontiguousarray(g, dtype=np.float64)
+            self.lib.d4est_hip_plan_set_dirichlet_values(self.handle, g.ctypes.data_as(_vp), 0)
+
+    def compute_ghost_traces(self, u_ghost, ghost_trace):
+        assert ghost_trace.numel() == self.ghost_trace_size
+        self.lib.d4est_hip_compute_ghost_traces(self.handle, _ptr(u_ghost), _ptr(ghost_trace))
+
+    def compute_face_traces(self, u, trace):
+        assert u.numel() == self.local_nodes and trace.numel() == self.trace_size
+        self.lib.d4est_hip_compute_face_traces(self.handle, _ptr(u), _ptr(trace))
+
+    def apply_flux(self, trace, ghost_trace, Au):
+        self.lib.d4est_hip_apply_flux(self.handle, _ptr(trace), _ptr(ghost_trace) if ghost_trace is not None else None, _ptr(Au))
+
+    def apply_aij(self, u, Au, ghost_trace=None):
+        assert u.numel() == self.local_nodes and Au.numel() == self.local_nodes
+        self.lib.d4est_hip_apply_aij(self.handle, _ptr(u), _ptr(ghost_trace) if ghost_trace is not None else None, _ptr(Au))
 
     def apply_stiffness_matrix_host(self, u_host):
         u = np.ascontiguousarray(u_host, dtype=np.float64)

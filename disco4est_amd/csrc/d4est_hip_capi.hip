@@ -152,6 +152,7 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   (void)hipFree(plan->d_J);
   (void)hipFree(plan->d_metric);
   (void)hipFree(plan->d_scratch);
+  d4est_hip::faces_destroy(plan);
   delete plan;
 }
 
@@ -217,6 +218,83 @@ void d4est_hip_interpolate(d4est_hip_plan_t* plan, const double* u_dev, double* 
 void d4est_hip_compute_dudr(d4est_hip_plan_t* plan, const double* u_dev, double* dudr0_dev, double* dudr1_dev, double* dudr2_dev) {
   check_plan(plan, "compute_dudr");
   d4est_hip::launch_dudr(plan, u_dev, dudr0_dev, dudr1_dev, dudr2_dev);
+}
+
+void d4est_hip_plan_set_faces(d4est_hip_plan_t* plan, const int* side_nbr, const int* side_nbr_face, const int* side_reorder,
+                              const int* side_mortar_stride, const int* side_bndry_stride, int total_mortar_nodes,
+                              int total_bndry_nodes, int n_ghost, const int* ghost_deg, const int* ghost_deg_quad) {
+  check_plan(plan, "plan_set_faces");
+  if (plan->has_faces) D4EST_HIP_ABORT("plan_set_faces: faces already set (build a new plan per mesh)");
+  const size_t ns = 6 * (size_t)plan->n_elements;
+  if (ns > 0 && (!side_nbr || !side_nbr_face || !side_reorder || !side_mortar_stride || !side_bndry_stride)) D4EST_HIP_ABORT("plan_set_faces: NULL side array");
+  if (n_ghost < 0 || (n_ghost > 0 && (!ghost_deg || !ghost_deg_quad))) D4EST_HIP_ABORT("plan_set_faces: bad ghost arrays");
+  plan->side_nbr.assign(side_nbr, side_nbr + ns);
+  plan->side_nbr_face.assign(side_nbr_face, side_nbr_face + ns);
+  plan->side_reorder.assign(side_reorder, side_reorder + ns);
+  plan->side_mortar_stride.assign(side_mortar_stride, side_mortar_stride + ns);
+  plan->side_bndry_stride.assign(side_bndry_stride, side_bndry_stride + ns);
+  plan->total_mortar_nodes = total_mortar_nodes;
+  plan->total_bndry_nodes = total_bndry_nodes;
+  plan->n_ghost = n_ghost;
+  plan->ghost_deg.assign(ghost_deg, ghost_deg + n_ghost);
+  plan->ghost_deg_quad.assign(ghost_deg_quad, ghost_deg_quad + n_ghost);
+  for (size_t s = 0; s < ns; ++s) {
+    if (side_nbr_face[s] < 0 || side_nbr_face[s] > 5 || side_reorder[s] < 0 || side_reorder[s] > 7) D4EST_HIP_ABORT("plan_set_faces: side %zu has face %d / reorder %d", s, side_nbr_face[s], side_reorder[s]);
+  }
+  d4est_hip::faces_setup(plan);
+}
+
+void d4est_hip_plan_set_sipg(d4est_hip_plan_t* plan, double penalty_prefactor, int penalty_fcn) {
+  check_plan(plan, "plan_set_sipg");
+  if (penalty_fcn < 0 || penalty_fcn > 3) D4EST_HIP_ABORT("plan_set_sipg: unknown penalty function %d", penalty_fcn);
+  if (plan->has_face_geometry) D4EST_HIP_ABORT("plan_set_sipg: call before plan_set_mortar_geometry");
+  plan->sipg_prefactor = penalty_prefactor;
+  plan->sipg_penalty_fcn = penalty_fcn;
+}
+
+void d4est_hip_plan_set_mortar_geometry(d4est_hip_plan_t* plan, const double* sj, const double* n, const double* drst_dxyz_m,
+                                        const double* drst_dxyz_p_porder, const double* hm, const double* hp, int on_device) {
+  check_plan(plan, "plan_set_mortar_geometry");
+  if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_mortar_geometry: call plan_set_faces first");
+  d4est_hip::faces_set_geometry(plan, sj, n, drst_dxyz_m, drst_dxyz_p_porder, hm, hp, on_device);
+}
+
+void d4est_hip_plan_set_dirichlet_values(d4est_hip_plan_t* plan, const double* g_lobatto, int on_device) {
+  check_plan(plan, "plan_set_dirichlet_values");
+  if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_dirichlet_values: call plan_set_faces first");
+  const size_t bytes = (size_t)plan->total_bndry_nodes * sizeof(double);
+  if (bytes == 0) return;
+  if (!g_lobatto) HIP_CHECK(hipMemsetAsync(plan->d_bndry, 0, bytes, plan->stream));
+  else HIP_CHECK(hipMemcpyAsync(plan->d_bndry, g_lobatto, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, plan->stream));
+  if (!on_device) HIP_CHECK(hipStreamSynchronize(plan->stream));
+}
+
+long long d4est_hip_plan_trace_size(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_trace_size"); return plan->local_trace_doubles; }
+long long d4est_hip_plan_ghost_trace_size(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_ghost_trace_size"); return plan->ghost_trace_doubles; }
+
+void d4est_hip_compute_ghost_traces(d4est_hip_plan_t* plan, const double* u_ghost_dev, double* ghost_trace_dev) {
+  check_plan(plan, "compute_ghost_traces");
+  if (!plan->has_faces) D4EST_HIP_ABORT("compute_ghost_traces: call plan_set_faces first");
+  d4est_hip::launch_traces(plan, u_ghost_dev, ghost_trace_dev, true);
+}
+
+void d4est_hip_compute_face_traces(d4est_hip_plan_t* plan, const double* u_dev, double* trace_dev) {
+  check_plan(plan, "compute_face_traces");
+  if (!plan->has_faces) D4EST_HIP_ABORT("compute_face_traces: call plan_set_faces first");
+  d4est_hip::launch_traces(plan, u_dev, trace_dev, false);
+}
+
+void d4est_hip_apply_flux(d4est_hip_plan_t* plan, const double* trace_dev, const double* ghost_trace_dev, double* Au_dev) {
+  check_plan(plan, "apply_flux");
+  d4est_hip::launch_flux(plan, trace_dev, ghost_trace_dev, Au_dev);
+}
+
+void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const double* ghost_trace_dev, double* Au_dev) {
+  check_plan(plan, "apply_aij");
+  if (!plan->has_faces) D4EST_HIP_ABORT("apply_aij: call plan_set_faces first");
+  d4est_hip::launch_stiffness(plan, u_dev, Au_dev);
+  d4est_hip::launch_traces(plan, u_dev, plan->d_trace, false);
+  d4est_hip::launch_flux(plan, plan->d_trace, ghost_trace_dev, Au_dev);
 }
 
 void d4est_hip_apply_stiffness_matrix_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host) {

@@ -59,6 +59,24 @@ struct d4est_hip_plan {
   double* d_J = nullptr;          // local_nodes_quad  (reference layout)
   double* d_metric = nullptr;     // 6 * local_nodes_quad, element-blocked: [e][c][n], c in (rr,rs,rt,ss,st,tt)
 
+  // ---- faces (d4est_hip_faces.hip) ----
+  bool has_faces = false, has_face_geometry = false;
+  int n_ghost = 0;
+  std::vector<int> ghost_deg, ghost_deg_quad;
+  std::vector<int> side_nbr, side_nbr_face, side_reorder, side_mortar_stride, side_bndry_stride;  // host copies, 6*n_elements
+  int total_mortar_nodes = 0, total_bndry_nodes = 0;
+  long long local_trace_doubles = 0, ghost_trace_doubles = 0;
+  int* d_side_desc = nullptr;        // SideDesc per side (see d4est_hip_faces.hip)
+  long long* d_trace_offset = nullptr;  // per local element: offset of its 6x4xN^2 trace block
+  std::vector<long long> trace_offset, ghost_trace_offset;
+  double* d_face_ops = nullptr;      // concatenated 1-D face operators (C and E matrices)
+  double* d_face_geom = nullptr;     // 7 * total_mortar_nodes: am[3], ap[3], s3 per mortar quadrature node (side-blocked)
+  double* d_bndry = nullptr;         // Dirichlet values on boundary Lobatto face nodes (total_bndry_nodes), zero by default
+  double* d_trace = nullptr;         // plan-owned local trace buffer
+  double sipg_prefactor = 10.0;
+  int sipg_penalty_fcn = 0;
+  int max_face_lds_doubles = 0;
+
   int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
@@ -73,5 +91,16 @@ void launch_metric_precombine(d4est_hip_plan* plan, const double* d_J, const dou
 void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
 void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out);
 void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, double* d2);
+
+// d4est_hip_faces.hip
+void faces_setup(d4est_hip_plan* plan);
+void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n, const double* drst_m, const double* drst_p,
+                        const double* hm, const double* hp, int on_device);
+void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost);
+void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au);
+void faces_destroy(d4est_hip_plan* plan);
+
+// d4est_hip_blas1.hip
+
 
 }  // namespace d4est_hip

@@ -108,6 +108,44 @@ void d4est_hip_interpolate(d4est_hip_plan_t* plan, const double* u_dev, double* 
  * d4est_operators_apply_dij (d4est_operators.c:1385-1410) per element. */
 void d4est_hip_compute_dudr(d4est_hip_plan_t* plan, const double* u_dev, double* dudr0_dev, double* dudr1_dev, double* dudr2_dev);
 
+/* ---- faces: SIPG mortar terms (conforming mortars, Dirichlet boundaries) ------------------------------
+ * Flat side list, side s = 6*e + f ((-) element e, face f = 0..5 = -x,+x,-y,+y,-z,+z), HOST int arrays of 6*n_elements:
+ * what the reference's face iteration hands to its flux callback (src/Mesh/d4est_mortars.c:601-803):
+ *   side_nbr[s]        >= 0: local (+) element; -1: domain boundary; <= -2: ghost element g = -(v+2)
+ *   side_nbr_face[s]   face of the (+) element
+ *   side_reorder[s]    flip0 | flip1<<1 | transpose<<2, the result of p4est_expand_face_transform as used by
+ *                      d4est_operators_reorient_face_data (src/dGMath/d4est_operators.c:2031-2081); 0 inside one tree
+ *   side_mortar_stride[s]  scalar offset S of the side's mortar quadrature data (d4est_laplacian_flux.c:417-449)
+ *   side_bndry_stride[s]   offset of the side's Dirichlet values (boundary sides)
+ * Ghost elements: ghost_deg / ghost_deg_quad (n_ghost), as p4est_ghost_exchange_data ships them (Mesh/d4est_ghost.c:52). */
+void d4est_hip_plan_set_faces(d4est_hip_plan_t* plan, const int* side_nbr, const int* side_nbr_face, const int* side_reorder,
+                              const int* side_mortar_stride, const int* side_bndry_stride, int total_mortar_nodes,
+                              int total_bndry_nodes, int n_ghost, const int* ghost_deg, const int* ghost_deg_quad);
+/* SIPG parameters ([flux] sipg_penalty_prefactor, sipg_penalty_fcn; d4est_laplacian_flux_sipg.c:945-1005):
+ * fcn 0 maxp_sqr_over_minh (default), 1 meanp_sqr_over_meanh, 2 maxpp1_sqr_over_minh, 3 mean_p_sqr_over_h.
+ * Call BEFORE d4est_hip_plan_set_mortar_geometry (the penalty is folded into the face factors). */
+void d4est_hip_plan_set_sipg(d4est_hip_plan_t* plan, double penalty_prefactor, int penalty_fcn);
+/* Mortar geometric factors in the reference's layout (src/Mesh/d4est_mesh.c:946-1108): with T nodes on the side's mortar,
+ * sj[S+k], n[3S + d*T + k], drst_dxyz_m / drst_dxyz_p_porder[9S + (i+3j)*T + k] = d r_i/d x_j, hm[S+k], hp[S+k]. */
+void d4est_hip_plan_set_mortar_geometry(d4est_hip_plan_t* plan, const double* sj, const double* n, const double* drst_dxyz_m,
+                                        const double* drst_dxyz_p_porder, const double* hm, const double* hp, int on_device);
+/* Dirichlet values on the Lobatto face nodes of every boundary side (EVAL_BNDRY_FCN_ON_LOBATTO,
+ * d4est_laplacian_flux_sipg.c:80-112); NULL resets to zero (the homogeneous operator used by apply_lhs). */
+void d4est_hip_plan_set_dirichlet_values(d4est_hip_plan_t* plan, const double* g_lobatto, int on_device);
+/* sizes (in doubles) of the local / ghost trace buffers: 24 (deg+1)^2 per element = 6 faces x {u, du/dr_0..2} */
+long long d4est_hip_plan_trace_size(const d4est_hip_plan_t* plan);
+long long d4est_hip_plan_ghost_trace_size(const d4est_hip_plan_t* plan);
+/* ghost traces from whole-element ghost data packed in ghost order (what d4est_ghost_data_exchange delivers,
+ * src/Mesh/d4est_ghost_data.c:143-256); a trace-exchange (RCCL) fills the same buffer directly. */
+void d4est_hip_compute_ghost_traces(d4est_hip_plan_t* plan, const double* u_ghost_dev, double* ghost_trace_dev);
+/* local traces of u into trace_dev (d4est_hip_plan_trace_size doubles) */
+void d4est_hip_compute_face_traces(d4est_hip_plan_t* plan, const double* u_dev, double* trace_dev);
+/* Au += mortar terms, given local (and ghost) traces: d4est_laplacian_apply_mortar_matrices (d4est_laplacian.c:285-315) */
+void d4est_hip_apply_flux(d4est_hip_plan_t* plan, const double* trace_dev, const double* ghost_trace_dev, double* Au_dev);
+/* Au = A u : d4est_laplacian_apply_aij (src/dGMath/d4est_laplacian.c:318-417) = stiffness + traces + flux.
+ * ghost_trace_dev may be NULL when the plan has no ghost elements. */
+void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const double* ghost_trace_dev, double* Au_dev);
+
 /* Host-pointer convenience for a drop-in behind d4est's host double* API: copies u to the
  * device, applies, copies Au back (PCIe-inclusive; not the measured path). */
 void d4est_hip_apply_stiffness_matrix_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host);
