@@ -50,6 +50,12 @@ SIGNATURES = {
     "d4est_hip_compute_face_traces": (None, [_vp, _vp, _vp]),
     "d4est_hip_apply_flux": (None, [_vp, _vp, _vp, _vp]),
     "d4est_hip_apply_aij": (None, [_vp, _vp, _vp, _vp]),
+    "d4est_hip_plan_set_comm": (None, [_vp, _vp, _vp, _vp]),
+    "d4est_hip_apply_lhs": (None, [_vp, _vp, _vp]),
+    "d4est_hip_cheby_iterate": (None, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]),
+    "d4est_hip_cheby_update": (None, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp]),
+    "d4est_hip_cg_eigs": (ctypes.c_double, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _c_double_p]),
+    "d4est_hip_vec_dot": (None, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "d4est_hip_apply_stiffness_matrix_host": (None, [_vp, _vp, _vp]),
 }
 
@@ -201,6 +207,32 @@ class Plan:
     def apply_aij(self, u, Au, ghost_trace=None):
         assert u.numel() == self.local_nodes and Au.numel() == self.local_nodes
         self.lib.d4est_hip_apply_aij(self.handle, _ptr(u), _ptr(ghost_trace) if ghost_trace is not None else None, _ptr(Au))
+
+    # ---- smoother loops
+    EXCHANGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+    ALLREDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int)
+
+    def set_comm(self, exchange=None, allreduce=None):
+        """exchange(phase, trace_ptr, ghost_trace_ptr), allreduce(scalars_ptr, n): python callables (pointers are ints)"""
+        self._cb_ex = self.EXCHANGE_FN(lambda ctx, ph, a, b: exchange(ph, a, b)) if exchange else None
+        self._cb_ar = self.ALLREDUCE_FN(lambda ctx, p, n: allreduce(p, n)) if allreduce else None
+        self.lib.d4est_hip_plan_set_comm(self.handle, ctypes.cast(self._cb_ex, ctypes.c_void_p) if self._cb_ex else None,
+                                         ctypes.cast(self._cb_ar, ctypes.c_void_p) if self._cb_ar else None, None)
+
+    def apply_lhs(self, u, Au):
+        self.lib.d4est_hip_apply_lhs(self.handle, _ptr(u), _ptr(Au))
+
+    def cheby_iterate(self, u, rhs, Au, r, iters, lmin, lmax, residual_at_end=1):
+        self.lib.d4est_hip_cheby_iterate(self.handle, _ptr(u), _ptr(rhs), _ptr(Au), _ptr(r), int(iters), float(lmin), float(lmax),
+                                         int(residual_at_end))
+
+    def cg_eigs(self, u, rhs, Au, imax, use_new=1):
+        hist = np.zeros(2 * imax)
+        b = self.lib.d4est_hip_cg_eigs(self.handle, _ptr(u), _ptr(rhs), _ptr(Au), int(imax), int(use_new), hist.ctypes.data_as(_c_double_p))
+        return b, hist
+
+    def vec_dot(self, x, y, out):
+        self.lib.d4est_hip_vec_dot(self.handle, int(x.numel()), _ptr(x), _ptr(y), _ptr(out))
 
     def apply_stiffness_matrix_host(self, u_host):
         u = np.ascontiguousarray(u_host, dtype=np.float64)

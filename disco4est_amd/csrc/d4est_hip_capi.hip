@@ -153,6 +153,8 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   (void)hipFree(plan->d_metric);
   (void)hipFree(plan->d_scratch);
   d4est_hip::faces_destroy(plan);
+  (void)hipFree(plan->d_work_p); (void)hipFree(plan->d_work_d); (void)hipFree(plan->d_work_r);
+  (void)hipFree(plan->d_reduce); (void)hipFree(plan->d_ghost_trace);
   delete plan;
 }
 
@@ -295,6 +297,41 @@ void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const doub
   d4est_hip::launch_stiffness(plan, u_dev, Au_dev);
   d4est_hip::launch_traces(plan, u_dev, plan->d_trace, false);
   d4est_hip::launch_flux(plan, plan->d_trace, ghost_trace_dev, Au_dev);
+}
+
+void d4est_hip_plan_set_comm(d4est_hip_plan_t* plan, d4est_hip_exchange_fn exchange, d4est_hip_allreduce_fn allreduce, void* ctx) {
+  check_plan(plan, "plan_set_comm");
+  plan->exchange_fn = exchange;
+  plan->allreduce_fn = allreduce;
+  plan->comm_ctx = ctx;
+}
+
+void d4est_hip_apply_lhs(d4est_hip_plan_t* plan, const double* u_dev, double* Au_dev) {
+  check_plan(plan, "apply_lhs");
+  d4est_hip::apply_operator(plan, u_dev, Au_dev);
+}
+
+void d4est_hip_cheby_iterate(d4est_hip_plan_t* plan, double* u_dev, const double* rhs_dev, double* Au_dev, double* r_dev, int iter,
+                             double lmin, double lmax, int compute_residual_at_end) {
+  check_plan(plan, "cheby_iterate");
+  d4est_hip::cheby_iterate(plan, u_dev, rhs_dev, Au_dev, r_dev, iter, lmin, lmax, compute_residual_at_end);
+}
+
+void d4est_hip_cheby_update(d4est_hip_plan_t* plan, int n, const double* rhs_dev, const double* Au_dev, double alpha, double beta,
+                            double* r_dev, double* p_dev, double* u_dev) {
+  check_plan(plan, "cheby_update");
+  d4est_hip::launch_cheby_update(plan, n, rhs_dev, Au_dev, alpha, beta, r_dev, p_dev, u_dev);
+}
+
+double d4est_hip_cg_eigs(d4est_hip_plan_t* plan, double* u_dev, const double* rhs_dev, double* Au_dev, int imax, int use_new,
+                         double* history_host) {
+  check_plan(plan, "cg_eigs");
+  return d4est_hip::cg_eigs(plan, u_dev, rhs_dev, Au_dev, imax, use_new, history_host);
+}
+
+void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const double* y_dev, double* result_dev) {
+  check_plan(plan, "vec_dot");
+  d4est_hip::launch_dot(plan, n, x_dev, y_dev, result_dev);
 }
 
 void d4est_hip_apply_stiffness_matrix_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host) {

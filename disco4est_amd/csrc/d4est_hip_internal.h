@@ -77,6 +77,12 @@ struct d4est_hip_plan {
   int sipg_penalty_fcn = 0;
   int max_face_lds_doubles = 0;
 
+  // ---- solver workspace / communication hooks (d4est_hip_solver.hip) ----
+  double *d_work_p = nullptr, *d_work_d = nullptr, *d_work_r = nullptr, *d_reduce = nullptr, *d_ghost_trace = nullptr;
+  d4est_hip_exchange_fn exchange_fn = nullptr;
+  d4est_hip_allreduce_fn allreduce_fn = nullptr;
+  void* comm_ctx = nullptr;
+
   int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
@@ -100,7 +106,14 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
 void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au);
 void faces_destroy(d4est_hip_plan* plan);
 
-// d4est_hip_blas1.hip
+// d4est_hip_solver.hip
+void apply_operator(d4est_hip_plan* plan, const double* u, double* Au);
+void launch_dot(d4est_hip_plan* plan, int n, const double* x, const double* y, double* out_dev);
+void launch_cheby_update(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double alpha, double beta, double* r,
+                         double* p, double* u);
+void cheby_iterate(d4est_hip_plan* plan, double* u, const double* rhs, double* Au, double* r, int iter, double lmin, double lmax,
+                   int compute_residual_at_end);
+double cg_eigs(d4est_hip_plan* plan, double* u, const double* rhs, double* Au, int imax, int use_new, double* hist_out);
 
 
 }  // namespace d4est_hip

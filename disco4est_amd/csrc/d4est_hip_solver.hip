@@ -1,0 +1,217 @@
+// Device-resident smoother inner loops: Chebyshev iteration and the CG-Lanczos spectral bound.
+//
+// Replaces d4est_solver_multigrid_smoother_cheby_iterate_aux (src/Solver/d4est_solver_multigrid_smoother_cheby.c:81-176)
+// and cg_eigs (src/Solver/d4est_solver_cg_eigs.c:116-275).  The reference runs 5 BLAS-1 sweeps per Chebyshev
+// iteration and 3 blocking allreduces per CG iteration on the host; here the Chebyshev update is ONE fused sweep
+// (r, p, u updated together: 4 reads + 3 writes per node), the CG scalars (alpha, beta, the dots) never leave the
+// device, and the only host synchronisation is the final read-back of the (alpha_i, beta_i) history from which the
+// Gershgorin bound is formed.  Multi-rank runs hook an allreduce (RCCL) and a face-trace exchange through callbacks.
+#include <algorithm>
+#include <cmath>
+
+#include "d4est_hip_internal.h"
+
+namespace d4est_hip {
+
+constexpr int kRedBlocks = 1024;
+
+// r = alpha (rhs - Au); p = r + beta p; u += p   -- the reference's copy/xpby/scale/xpby/axpy sequence
+// (smoother_cheby.c:135-153), with each product/sum rounded separately like the BLAS-1 calls.
+__global__ __launch_bounds__(256) void cheby_update_kernel(int n, const double* __restrict__ rhs, const double* __restrict__ Au,
+                                                           double alpha, double beta, double* __restrict__ r,
+                                                           double* __restrict__ p, double* __restrict__ u) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double res = __dadd_rn(rhs[i], __dmul_rn(-1.0, Au[i]));
+    const double ri = __dmul_rn(alpha, res);
+    const double pi = __dadd_rn(__dmul_rn(beta, p[i]), ri);
+    r[i] = ri;
+    p[i] = pi;
+    u[i] = __dadd_rn(u[i], pi);
+  }
+}
+
+__global__ __launch_bounds__(256) void residual_kernel(int n, const double* __restrict__ rhs, const double* __restrict__ Au,
+                                                       double* __restrict__ r, double* __restrict__ copy) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double v = __dadd_rn(rhs[i], __dmul_rn(-1.0, Au[i]));
+    r[i] = v;
+    if (copy) copy[i] = v;
+  }
+}
+
+// deterministic two-stage dot product: fixed grid, fixed summation tree
+__global__ __launch_bounds__(256) void dot_partial_kernel(int n, const double* __restrict__ x, const double* __restrict__ y,
+                                                          double* __restrict__ partial) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s = fma(x[i], y[i], s);
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+__global__ __launch_bounds__(256) void dot_final_kernel(int nblocks, const double* __restrict__ partial, double* __restrict__ out) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sm[0];
+}
+
+// scal: [0] delta_new, [1] delta_old, [2] d.Au, [3] alpha, [4] beta ; hist: alpha_i at [i], beta_i at [imax + i]
+__global__ void cg_alpha_kernel(double* scal, double* hist, int i) {
+  const double a = scal[0] / scal[2];
+  scal[3] = a;
+  hist[i] = a;
+  scal[1] = scal[0];  // delta_old = delta_new (cg_eigs.c:206)
+}
+__global__ void cg_beta_kernel(double* scal, double* hist, int i, int imax) {
+  const double b = scal[0] / scal[1];
+  scal[4] = b;
+  hist[imax + i] = b;
+}
+// u += alpha d ; r -= alpha Au  (cg_eigs.c:203-204)
+__global__ __launch_bounds__(256) void cg_axpy2_kernel(int n, const double* __restrict__ scal, const double* __restrict__ d,
+                                                       const double* __restrict__ Au, double* __restrict__ u, double* __restrict__ r) {
+  const double a = scal[3];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    u[i] = __dadd_rn(u[i], __dmul_rn(a, d[i]));
+    r[i] = __dadd_rn(r[i], __dmul_rn(-a, Au[i]));
+  }
+}
+// d = r + beta d (cg_eigs.c:222)
+__global__ __launch_bounds__(256) void cg_xpby_kernel(int n, const double* __restrict__ scal, const double* __restrict__ r, double* __restrict__ d) {
+  const double b = scal[4];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = __dadd_rn(__dmul_rn(b, d[i]), r[i]);
+}
+
+static int grid_for(int n) {
+  int g = (n + 255) / 256;
+  return std::max(1, std::min(g, 4096));
+}
+
+void ensure_solver_workspace(d4est_hip_plan* plan) {
+  const size_t n = std::max<size_t>((size_t)plan->local_nodes, 1);
+  if (!plan->d_work_p) HIP_CHECK(hipMalloc(&plan->d_work_p, n * sizeof(double)));
+  if (!plan->d_work_d) HIP_CHECK(hipMalloc(&plan->d_work_d, n * sizeof(double)));
+  if (!plan->d_work_r) HIP_CHECK(hipMalloc(&plan->d_work_r, n * sizeof(double)));
+  if (!plan->d_reduce) HIP_CHECK(hipMalloc(&plan->d_reduce, (kRedBlocks + 16) * sizeof(double)));
+  if (!plan->d_ghost_trace && plan->ghost_trace_doubles > 0) HIP_CHECK(hipMalloc(&plan->d_ghost_trace, (size_t)plan->ghost_trace_doubles * sizeof(double)));
+}
+
+void launch_dot(d4est_hip_plan* plan, int n, const double* x, const double* y, double* out_dev) {
+  ensure_solver_workspace(plan);
+  const int g = std::max(1, std::min((n + 255) / 256, kRedBlocks));
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(g), dim3(256), 0, plan->stream, n, x, y, plan->d_reduce);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, plan->stream, g, plan->d_reduce, out_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+// Au = A u with the plan's communication hooks (or without ghosts)
+void apply_operator(d4est_hip_plan* plan, const double* u, double* Au) {
+  if (!plan->has_faces) D4EST_HIP_ABORT("smoother: the plan has no faces (plan_set_faces)");
+  ensure_solver_workspace(plan);
+  launch_traces(plan, u, plan->d_trace, false);
+  if (plan->n_ghost > 0) {
+    if (!plan->exchange_fn) D4EST_HIP_ABORT("smoother: plan has ghost elements but no exchange callback (plan_set_comm)");
+    plan->exchange_fn(plan->comm_ctx, 0, plan->d_trace, plan->d_ghost_trace);
+  }
+  launch_stiffness(plan, u, Au);  // overlaps the exchange: the volume term needs no ghost data
+  if (plan->n_ghost > 0) plan->exchange_fn(plan->comm_ctx, 1, plan->d_trace, plan->d_ghost_trace);
+  launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au);
+}
+
+void cheby_iterate(d4est_hip_plan* plan, double* u, const double* rhs, double* Au, double* r, int iter, double lmin, double lmax,
+                   int compute_residual_at_end) {
+  ensure_solver_workspace(plan);
+  const int n = plan->local_nodes;
+  const double d = (lmax + lmin) * .5, c = (lmax - lmin) * .5;
+  double alpha = 0.0, beta = 0.0;
+  HIP_CHECK(hipMemsetAsync(plan->d_work_p, 0, std::max<size_t>((size_t)n, 1) * sizeof(double), plan->stream));
+  for (int i = 0; i < iter; ++i) {
+    apply_operator(plan, u, Au);
+    if (i == 0) alpha = 1. / d;
+    else if (i == 1) alpha = 2. * d / (2 * d * d - c * c);
+    else alpha = 1. / (d - (alpha * c * c / 4.));
+    beta = alpha * d - 1.;
+    if (n > 0) hipLaunchKernelGGL(cheby_update_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, Au, alpha, beta, r, plan->d_work_p, u);
+  }
+  if (compute_residual_at_end == 1) {
+    apply_operator(plan, u, Au);
+    if (n > 0) hipLaunchKernelGGL(residual_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, Au, r, (double*)nullptr);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+static void gershgorin(int use_new, int i, int local_nodes, double a0, double b0, double a1, double b1, double* mx) {
+  // src/Solver/d4est_solver_cg_eigs.c:9-33 (old) and :36-64 (new)
+  double diag, off;
+  if (!use_new) {
+    if (i != 0 && i < local_nodes - 1) { diag = (1. / a1 + b0 / a0); off = std::fabs(std::sqrt(b1) / a1) + std::fabs(std::sqrt(b0) / a0); }
+    else if (i == 0) { diag = 1. / a1; off = std::sqrt(b1) / a1; }
+    else { diag = 1. / a1 + b0 / a0; off = std::fabs(std::sqrt(b0) / a0); }
+  } else {
+    if (i != 0) { diag = (1. / a1 + b0 / a0); off = std::fabs(std::sqrt(b0) / a0); }
+    else { diag = 1. / a1; off = std::sqrt(b1) / a1; }
+  }
+  *mx = diag + off;
+}
+
+double cg_eigs(d4est_hip_plan* plan, double* u, const double* rhs, double* Au, int imax, int use_new, double* hist_out) {
+  ensure_solver_workspace(plan);
+  const int n = plan->local_nodes;
+  if (imax < 1) D4EST_HIP_ABORT("cg_eigs: imax = %d", imax);
+  double* scal = plan->d_reduce + kRedBlocks;  // 16 doubles after the partial sums
+  double* hist = nullptr;
+  HIP_CHECK(hipMalloc(&hist, 2 * (size_t)imax * sizeof(double)));
+  double* d = plan->d_work_d;
+  double* r = plan->d_work_r;
+  const int g = grid_for(n);
+  apply_operator(plan, u, Au);
+  if (n > 0) hipLaunchKernelGGL(residual_kernel, dim3(g), dim3(256), 0, plan->stream, n, rhs, Au, r, d);  // r = rhs - Au ; d = r
+  launch_dot(plan, n, r, r, &scal[0]);
+  if (plan->allreduce_fn) plan->allreduce_fn(plan->comm_ctx, &scal[0], 1);
+  for (int i = 0; i < imax; ++i) {
+    apply_operator(plan, d, Au);
+    launch_dot(plan, n, d, Au, &scal[2]);
+    if (plan->allreduce_fn) plan->allreduce_fn(plan->comm_ctx, &scal[2], 1);
+    hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1), 0, plan->stream, scal, hist, i);
+    if (n > 0) hipLaunchKernelGGL(cg_axpy2_kernel, dim3(g), dim3(256), 0, plan->stream, n, scal, d, Au, u, r);
+    launch_dot(plan, n, r, r, &scal[0]);
+    if (plan->allreduce_fn) plan->allreduce_fn(plan->comm_ctx, &scal[0], 1);
+    hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(1), 0, plan->stream, scal, hist, i, imax);
+    if (n > 0) hipLaunchKernelGGL(cg_xpby_kernel, dim3(g), dim3(256), 0, plan->stream, n, scal, r, d);
+  }
+  HIP_CHECK(hipGetLastError());
+  std::vector<double> h(2 * (size_t)imax);
+  HIP_CHECK(hipMemcpyAsync(h.data(), hist, h.size() * sizeof(double), hipMemcpyDeviceToHost, plan->stream));
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  HIP_CHECK(hipFree(hist));
+  double bound = 0.0, a_old = -1., b_old = -1.;
+  for (int i = 0; i < imax; ++i) {
+    double mx;
+    gershgorin(use_new, i, n, a_old, b_old, h[i], h[imax + i], &mx);
+    bound = (i > 0) ? std::max(bound, mx) : mx;
+    a_old = h[i];
+    b_old = h[imax + i];
+  }
+  if (hist_out) std::copy(h.begin(), h.end(), hist_out);
+  return bound;
+}
+
+void launch_cheby_update(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double alpha, double beta, double* r,
+                         double* p, double* u) {
+  if (n > 0) hipLaunchKernelGGL(cheby_update_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, Au, alpha, beta, r, p, u);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace d4est_hip

@@ -146,6 +146,35 @@ void d4est_hip_apply_flux(d4est_hip_plan_t* plan, const double* trace_dev, const
  * ghost_trace_dev may be NULL when the plan has no ghost elements. */
 void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const double* ghost_trace_dev, double* Au_dev);
 
+/* ---- smoother inner loops (device resident) -----------------------------------------------------------
+ * Communication hooks for plans with ghost elements / several ranks (replace the reference's MPI calls:
+ * d4est_ghost_data_exchange, src/Mesh/d4est_ghost_data.c:143-256, and sc_allreduce, d4est_solver_cg_eigs.c:181-243).
+ * exchange(ctx, phase, trace_dev, ghost_trace_dev): phase 0 = post the face-trace exchange (the local trace buffer is
+ * complete on the plan's stream), phase 1 = make the plan's stream wait until ghost_trace_dev is filled.
+ * allreduce(ctx, scalars_dev, n): in-place SUM over ranks of n device doubles, ordered on the plan's stream. */
+typedef void (*d4est_hip_exchange_fn)(void* ctx, int phase, const double* trace_dev, double* ghost_trace_dev);
+typedef void (*d4est_hip_allreduce_fn)(void* ctx, double* scalars_dev, int n);
+void d4est_hip_plan_set_comm(d4est_hip_plan_t* plan, d4est_hip_exchange_fn exchange, d4est_hip_allreduce_fn allreduce, void* ctx);
+/* Au = A u using the plan-owned trace buffers and the communication hooks (apply_lhs of the Poisson problems,
+ * src/Problems/Poisson/poisson_sinx_fcns.h:110-128). */
+void d4est_hip_apply_lhs(d4est_hip_plan_t* plan, const double* u_dev, double* Au_dev);
+/* d4est_solver_multigrid_smoother_cheby_iterate_aux (src/Solver/d4est_solver_multigrid_smoother_cheby.c:81-176):
+ * iter Chebyshev iterations on u for A u = rhs with eigenvalue window [lmin, lmax]; r receives the residual
+ * rhs - A u when compute_residual_at_end == 1 (else alpha (rhs - A u) of the last iteration, as in the reference).
+ * u, rhs, Au (work), r are device vectors of local_nodes doubles. */
+void d4est_hip_cheby_iterate(d4est_hip_plan_t* plan, double* u_dev, const double* rhs_dev, double* Au_dev, double* r_dev, int iter,
+                             double lmin, double lmax, int compute_residual_at_end);
+/* one fused Chebyshev update  r = alpha (rhs - Au); p = r + beta p; u += p  (smoother_cheby.c:135-153) */
+void d4est_hip_cheby_update(d4est_hip_plan_t* plan, int n, const double* rhs_dev, const double* Au_dev, double alpha, double beta,
+                            double* r_dev, double* p_dev, double* u_dev);
+/* cg_eigs (src/Solver/d4est_solver_cg_eigs.c:116-275): imax CG iterations started from u (which they advance, as in the
+ * reference), returns the Gershgorin bound of the Lanczos tridiagonal (use_new selects :36-64 over :9-33).
+ * history_host (optional, 2*imax doubles) receives alpha_0..alpha_{imax-1}, beta_0..beta_{imax-1}. */
+double d4est_hip_cg_eigs(d4est_hip_plan_t* plan, double* u_dev, const double* rhs_dev, double* Au_dev, int imax, int use_new,
+                         double* history_host);
+/* deterministic device dot product; result_dev is a device double */
+void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const double* y_dev, double* result_dev);
+
 /* Host-pointer convenience for a drop-in behind d4est's host double* API: copies u to the
  * device, applies, copies Au back (PCIe-inclusive; not the measured path). */
 void d4est_hip_apply_stiffness_matrix_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host);

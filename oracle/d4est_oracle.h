@@ -125,6 +125,18 @@ void oracle_laplacian_apply_aij(int quad_type, int n_elements, const int* deg, c
                                 const double* u, const double* u_ghost, const double* bndry_lobatto, double* Au,
                                 int stiffness_threads);                                              /* d4est_laplacian.c:318-417 */
 
+/* ---- smoother inner loops (oracle/d4est_oracle_solver.c) ---- */
+void oracle_set_aij_operator(int quad_type, int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
+                             const int* quad_stride, int local_nodes, int local_nodes_quad, const double* J_quad,
+                             const double* rst_xyz_quad, const int* side_nbr, const int* side_nbr_face, const int* side_reorder,
+                             const int* side_mortar_stride, const int* side_bndry_stride, const double* sj, const double* n,
+                             const double* drst_m, const double* drst_p, const double* hm, const double* hp,
+                             double penalty_prefactor, int penalty_fcn, int threads);
+void oracle_cheby_iterate_aux(double* u, const double* rhs, double* Au, double* r, int iter, double lmin, double lmax,
+                              int compute_residual_at_end);                     /* d4est_solver_multigrid_smoother_cheby.c:81-176 */
+void oracle_cg_eigs(double* u, const double* rhs, double* Au, int imax, int use_new, double* spectral_bound); /* d4est_solver_cg_eigs.c:116-275 */
+double oracle_gershgorin_bound(const double* alpha_h, const double* beta_h, int imax, int local_nodes, int use_new);
+
 #ifdef __cplusplus
 }
 #endif

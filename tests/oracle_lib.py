@@ -193,6 +193,33 @@ class Oracle:
           (P(bl) if bl is not None else None), P(Au), nthreads)
         return Au
 
+    def set_operator(self, mesh, J, rst, sides, penalty_prefactor=10.0, penalty_fcn=0, threads=8):
+        f = self.lib.oracle_set_aij_operator
+        f.argtypes = [ctypes.c_int, ctypes.c_int, ip, ip, ip, ip, ctypes.c_int, ctypes.c_int, dp, dp, ip, ip, ip, ip, ip,
+                      dp, dp, dp, dp, dp, dp, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        self._op_keep = (mesh, J, rst, sides)
+        f(mesh.quad_type, mesh.n_elements, I(mesh.deg), I(mesh.deg_quad), I(mesh.nodal_stride), I(mesh.quad_stride),
+          mesh.local_nodes, mesh.local_nodes_quad, P(J), P(rst), I(sides["side_nbr"]), I(sides["side_nbr_face"]),
+          I(sides["side_reorder"]), I(sides["side_mortar_stride"]), I(sides["side_bndry_stride"]), P(sides["sj"]), P(sides["n"]),
+          P(sides["drst_m"]), P(sides["drst_p"]), P(sides["hm"]), P(sides["hp"]), float(penalty_prefactor), int(penalty_fcn), threads)
+
+    def cheby_iterate(self, u, rhs, iters, lmin, lmax, residual_at_end=1):
+        """returns (u_new, r); operator from set_operator()"""
+        u = u.copy(); Au = np.zeros_like(u); r = np.zeros_like(u)
+        f = self.lib.oracle_cheby_iterate_aux
+        f.argtypes = [dp, dp, dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+        f(P(u), P(np.ascontiguousarray(rhs)), P(Au), P(r), iters, lmin, lmax, residual_at_end)
+        return u, r
+
+    def cg_eigs(self, u, rhs, imax, use_new=1):
+        """returns (spectral_bound, u_after)"""
+        u = u.copy(); Au = np.zeros_like(u)
+        bound = ctypes.c_double(0.0)
+        f = self.lib.oracle_cg_eigs
+        f.argtypes = [dp, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        f(P(u), P(np.ascontiguousarray(rhs)), P(Au), imax, use_new, ctypes.byref(bound))
+        return bound.value, u
+
     def compute_dudr(self, mesh, u):
         d = [np.zeros(mesh.local_nodes) for _ in range(3)]
         self.lib.oracle_laplacian_compute_dudr(mesh.n_elements, I(mesh.deg), I(mesh.nodal_stride), P(u), P(d[0]), P(d[1]), P(d[2]))
