@@ -55,6 +55,9 @@ SIGNATURES = {
     "d4est_hip_cheby_iterate": (None, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]),
     "d4est_hip_cheby_update": (None, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp]),
     "d4est_hip_cg_eigs": (ctypes.c_double, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _c_double_p]),
+    "d4est_hip_copy_blocks": (None, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "d4est_hip_plan_trace_offset": (ctypes.c_longlong, [_vp, ctypes.c_int]),
+    "d4est_hip_plan_ghost_trace_offset": (ctypes.c_longlong, [_vp, ctypes.c_int]),
     "d4est_hip_vec_dot": (None, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "d4est_hip_apply_stiffness_matrix_host": (None, [_vp, _vp, _vp]),
 }
@@ -230,6 +233,11 @@ class Plan:
         hist = np.zeros(2 * imax)
         b = self.lib.d4est_hip_cg_eigs(self.handle, _ptr(u), _ptr(rhs), _ptr(Au), int(imax), int(use_new), hist.ctypes.data_as(_c_double_p))
         return b, hist
+
+    def copy_blocks(self, n_blocks, src, src_off, dst, dst_off, length):
+        """src/dst: float64 CUDA tensors; src_off/dst_off: int64 CUDA tensors; length: int32 CUDA tensor"""
+        self.lib.d4est_hip_copy_blocks(self.handle, int(n_blocks), _ptr(src), ctypes.c_void_p(src_off.data_ptr()), _ptr(dst),
+                                       ctypes.c_void_p(dst_off.data_ptr()), ctypes.c_void_p(length.data_ptr()))
 
     def vec_dot(self, x, y, out):
         self.lib.d4est_hip_vec_dot(self.handle, int(x.numel()), _ptr(x), _ptr(y), _ptr(out))

@@ -329,6 +329,24 @@ double d4est_hip_cg_eigs(d4est_hip_plan_t* plan, double* u_dev, const double* rh
   return d4est_hip::cg_eigs(plan, u_dev, rhs_dev, Au_dev, imax, use_new, history_host);
 }
 
+void d4est_hip_copy_blocks(d4est_hip_plan_t* plan, int n_blocks, const double* src_dev, const long long* src_off_dev,
+                           double* dst_dev, const long long* dst_off_dev, const int* len_dev) {
+  check_plan(plan, "copy_blocks");
+  d4est_hip::launch_copy_blocks(plan->stream, n_blocks, src_dev, src_off_dev, dst_dev, dst_off_dev, len_dev);
+}
+
+long long d4est_hip_plan_trace_offset(const d4est_hip_plan_t* plan, int element) {
+  check_plan(plan, "plan_trace_offset");
+  if (!plan->has_faces || element < 0 || element >= plan->n_elements) D4EST_HIP_ABORT("plan_trace_offset: element %d", element);
+  return plan->trace_offset[element];
+}
+
+long long d4est_hip_plan_ghost_trace_offset(const d4est_hip_plan_t* plan, int ghost) {
+  check_plan(plan, "plan_ghost_trace_offset");
+  if (!plan->has_faces || ghost < 0 || ghost >= plan->n_ghost) D4EST_HIP_ABORT("plan_ghost_trace_offset: ghost %d", ghost);
+  return plan->ghost_trace_offset[ghost];
+}
+
 void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const double* y_dev, double* result_dev) {
   check_plan(plan, "vec_dot");
   d4est_hip::launch_dot(plan, n, x_dev, y_dev, result_dev);

@@ -94,6 +94,24 @@ __global__ __launch_bounds__(256) void cg_xpby_kernel(int n, const double* __res
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = __dadd_rn(__dmul_rn(b, d[i]), r[i]);
 }
 
+// variable-length block copy: dst[dst_off[b] + i] = src[src_off[b] + i], i < len[b]  (pack / unpack of face traces)
+__global__ __launch_bounds__(256) void copy_blocks_kernel(int n_blocks, const double* __restrict__ src, const long long* __restrict__ src_off,
+                                                          double* __restrict__ dst, const long long* __restrict__ dst_off,
+                                                          const int* __restrict__ len) {
+  for (int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+    const double* s = src + src_off[b];
+    double* d = dst + dst_off[b];
+    for (int i = threadIdx.x; i < len[b]; i += blockDim.x) d[i] = s[i];
+  }
+}
+
+void launch_copy_blocks(hipStream_t stream, int n_blocks, const double* src, const long long* src_off, double* dst,
+                        const long long* dst_off, const int* len) {
+  if (n_blocks <= 0) return;
+  hipLaunchKernelGGL(copy_blocks_kernel, dim3(std::min(n_blocks, 4096)), dim3(256), 0, stream, n_blocks, src, src_off, dst, dst_off, len);
+  HIP_CHECK(hipGetLastError());
+}
+
 static int grid_for(int n) {
   int g = (n + 255) / 256;
   return std::max(1, std::min(g, 4096));

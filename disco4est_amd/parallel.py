@@ -1,0 +1,171 @@
+"""Multi-GPU sharding of the element hot path (host side).
+
+One process per GPU.  Elements are split into Morton-contiguous chunks balanced by DoF count -- what
+``p4est_partition`` does for the reference (src/driver.c:136-151) -- and the only data exchanged per operator
+apply are FACE TRACES of the elements adjacent to a partition boundary (u and du/dr_{0,1,2} on the shared face,
+4 N^2 doubles) instead of the reference's whole mirror elements ((p+1)^3 doubles per field,
+src/Mesh/d4est_ghost_data.c:143-256).  Neighbour traffic is point-to-point (``batch_isend_irecv`` = grouped
+ncclSend/ncclRecv over xGMI on the nccl backend; gloo on CPU for the tests); scalar reductions of the
+Lanczos/CG estimate use ``all_reduce``.
+
+The schedule needs no metadata exchange: both sides of a partition boundary enumerate the shared faces in the same
+canonical order (global element id of the SENDER, then face).
+"""
+import numpy as np
+
+
+def partition_by_dofs(deg_global, world):
+    """Morton-contiguous [first, count) ranges with (nearly) equal DoF counts; returns list of (first, count)."""
+    w = (np.asarray(deg_global, dtype=np.int64) + 1) ** 3
+    cum = np.concatenate([[0], np.cumsum(w)])
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        k = int(np.searchsorted(cum, target, side="left"))
+        k = min(max(k, cuts[-1]), len(w))
+        cuts.append(k)
+    cuts.append(len(w))
+    return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+
+
+def owner_of(parts, n_global):
+    owner = np.empty(n_global, dtype=np.int32)
+    for r, (f, c) in enumerate(parts):
+        owner[f:f + c] = r
+    return owner
+
+
+class TraceSchedule:
+    """Per-peer send / receive block lists for one rank.
+
+    send[peer] / recv[peer]: arrays (offset_in_trace_buffer, length) in canonical order, built from the rank's
+    own side list only (mesh.build_sides): every side whose (+) neighbour is a ghost owned by ``peer`` contributes
+      * one SEND block: my trace of (local element e, face f)                      (the peer's ghost data)
+      * one RECV block: the ghost's trace of (ghost element g, face f_p)           (my ghost data)
+    """
+
+    def __init__(self, mesh, sides, parts, trace_offset, ghost_trace_offset):
+        owner = owner_of(parts, mesh.global_elements)
+        ne = mesh.n_elements
+        send, recv = {}, {}
+        nbr = sides["side_nbr"]
+        for s in np.nonzero(nbr <= -2)[0]:
+            e, f = divmod(int(s), 6)
+            g = -(int(nbr[s]) + 2)
+            gid = int(sides["ghost_global_ids"][g])
+            peer = int(owner[gid])
+            f_p = int(sides["side_nbr_face"][s])
+            n_m = int(mesh.deg[e]) + 1
+            n_p = int(sides["ghost_deg"][g]) + 1
+            my_gid = mesh.first + e
+            send.setdefault(peer, []).append((my_gid, f, trace_offset(e) + f * 4 * n_m * n_m, 4 * n_m * n_m))
+            recv.setdefault(peer, []).append((gid, f_p, ghost_trace_offset(g) + f_p * 4 * n_p * n_p, 4 * n_p * n_p))
+        self.peers = sorted(set(send) | set(recv))
+        self.send = {p: np.array([(o, l) for _, _, o, l in sorted(send[p])], dtype=np.int64).reshape(-1, 2) for p in self.peers}
+        self.recv = {p: np.array([(o, l) for _, _, o, l in sorted(recv[p])], dtype=np.int64).reshape(-1, 2) for p in self.peers}
+        self.send_len = {p: int(self.send[p][:, 1].sum()) for p in self.peers}
+        self.recv_len = {p: int(self.recv[p][:, 1].sum()) for p in self.peers}
+
+    def pack_lists(self, which, peer):
+        """(buffer_offsets, packed_offsets, lengths) of one peer's blocks"""
+        blocks = (self.send if which == "send" else self.recv)[peer]
+        packed = np.concatenate([[0], np.cumsum(blocks[:, 1])[:-1]]).astype(np.int64) if len(blocks) else np.zeros(0, np.int64)
+        return blocks[:, 0].copy(), packed, blocks[:, 1].astype(np.int32)
+
+
+class TraceExchange:
+    """Runs the schedule: pack (HIP copy_blocks on the plan's stream) -> point-to-point -> unpack.
+
+    ``transport`` moves the packed per-peer buffers: DistTransport (torch.distributed) or an in-process
+    transport used by the single-GPU tests.  ``copy_blocks(n, src, src_off, dst, dst_off, len)`` is the
+    device block copy (Plan.copy_blocks)."""
+
+    def __init__(self, schedule, transport, copy_blocks, device):
+        import torch
+        self.s = schedule
+        self.transport = transport
+        self.copy_blocks = copy_blocks
+        self.dev = device
+        self.send_buf, self.recv_buf, self.idx = {}, {}, {}
+        for p in schedule.peers:
+            self.send_buf[p] = torch.empty(schedule.send_len[p], dtype=torch.float64, device=device)
+            self.recv_buf[p] = torch.empty(schedule.recv_len[p], dtype=torch.float64, device=device)
+            so, sp, sl = schedule.pack_lists("send", p)
+            ro, rp, rl = schedule.pack_lists("recv", p)
+            t = lambda a: torch.from_numpy(a).to(device)
+            self.idx[p] = (t(so), t(sp), t(sl), t(ro), t(rp), t(rl))
+        self._pending = None
+
+    def begin(self, trace):
+        for p in self.s.peers:
+            so, sp, sl, _, _, _ = self.idx[p]
+            self.copy_blocks(len(sl), trace, so, self.send_buf[p], sp, sl)
+        self._pending = self.transport.start(self.send_buf, self.recv_buf)
+
+    def end(self, ghost_trace):
+        self.transport.finish(self._pending)
+        self._pending = None
+        for p in self.s.peers:
+            _, _, _, ro, rp, rl = self.idx[p]
+            self.copy_blocks(len(rl), self.recv_buf[p], rp, ghost_trace, ro, rl)
+
+
+class DistTransport:
+    """torch.distributed point-to-point: one grouped isend/irecv per neighbouring rank
+    (ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd on the nccl = RCCL backend)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+
+    def start(self, send_buf, recv_buf):
+        dist = self.dist
+        ops = []
+        for p in sorted(recv_buf):
+            if recv_buf[p].numel():
+                ops.append(dist.P2POp(dist.irecv, recv_buf[p], p, group=self.group))
+        for p in sorted(send_buf):
+            if send_buf[p].numel():
+                ops.append(dist.P2POp(dist.isend, send_buf[p], p, group=self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def finish(self, reqs):
+        for r in reqs or []:
+            r.wait()
+
+    def allreduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+def attach(plan, mesh, sides, parts, transport, device):
+    """Wire a Plan (faces already set) to a transport: installs the exchange / allreduce hooks used by
+    apply_lhs, cheby_iterate and cg_eigs.  Returns the TraceExchange (keep it alive)."""
+    import ctypes
+    import torch
+    sched = TraceSchedule(mesh, sides, parts,
+                          lambda e: plan.lib.d4est_hip_plan_trace_offset(plan.handle, e),
+                          lambda g: plan.lib.d4est_hip_plan_ghost_trace_offset(plan.handle, g))
+    ex = TraceExchange(sched, transport, plan.copy_blocks, device)
+    n_trace, n_ghost = int(plan.trace_size), int(plan.ghost_trace_size)
+
+    def view(ptr, n):
+        # wrap a raw device pointer handed over by the C library as a tensor (no copy)
+        class _Holder:
+            pass
+        h = _Holder()
+        h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(h, device=device)
+
+    def exchange(phase, trace_ptr, ghost_ptr):
+        if phase == 0:
+            ex.begin(view(trace_ptr, n_trace))
+        else:
+            ex.end(view(ghost_ptr, n_ghost))
+
+    def allreduce(ptr, n):
+        transport.allreduce_sum(view(ptr, n))
+
+    plan.set_comm(exchange if n_ghost > 0 else None, allreduce if hasattr(transport, "allreduce_sum") else None)
+    return ex

@@ -172,6 +172,15 @@ void d4est_hip_cheby_update(d4est_hip_plan_t* plan, int n, const double* rhs_dev
  * history_host (optional, 2*imax doubles) receives alpha_0..alpha_{imax-1}, beta_0..beta_{imax-1}. */
 double d4est_hip_cg_eigs(d4est_hip_plan_t* plan, double* u_dev, const double* rhs_dev, double* Au_dev, int imax, int use_new,
                          double* history_host);
+/* pack / unpack of face-trace blocks for the ghost exchange: dst[dst_off[b]+i] = src[src_off[b]+i], i < len[b];
+ * the three index arrays are DEVICE arrays of n_blocks entries; runs on the plan's stream.  Replaces the per-mirror
+ * memcpy loop of d4est_ghost_data_exchange (src/Mesh/d4est_ghost_data.c:196-236). */
+void d4est_hip_copy_blocks(d4est_hip_plan_t* plan, int n_blocks, const double* src_dev, const long long* src_off_dev,
+                           double* dst_dev, const long long* dst_off_dev, const int* len_dev);
+/* offsets (in doubles) of the trace blocks of local element e / ghost element g inside the trace buffers:
+ * face f of an element with N nodes per direction starts at offset + f*4*N*N */
+long long d4est_hip_plan_trace_offset(const d4est_hip_plan_t* plan, int element);
+long long d4est_hip_plan_ghost_trace_offset(const d4est_hip_plan_t* plan, int ghost);
 /* deterministic device dot product; result_dev is a device double */
 void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const double* y_dev, double* result_dev);
 

@@ -1,0 +1,123 @@
+"""CPU tests of the multi-rank host logic: DoF-balanced Morton partition, the metadata-free trace schedule and the
+point-to-point exchange itself over torch.distributed/gloo with world_size 2 and 3 (the N > 1 path of bench/apply_lhs
+uses exactly this code with the nccl backend and HIP pack/unpack kernels)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _offsets(deg):
+    n2 = (np.asarray(deg, dtype=np.int64) + 1) ** 2
+    return np.concatenate([[0], np.cumsum(24 * n2)])
+
+
+def _np_copy_blocks(n, src, src_off, dst, dst_off, length):
+    s, d = src.numpy(), dst.numpy()
+    for b in range(n):
+        so, do, ln = int(src_off[b]), int(dst_off[b]), int(length[b])
+        d[do:do + ln] = s[so:so + ln]
+
+
+def _encode(gid, f, n):
+    """trace block content that identifies (global element, face, entry)"""
+    return gid * 1000.0 + f * 100.0 + np.arange(4 * n * n) / (4.0 * n * n)
+
+
+def test_partition_by_dofs():
+    from disco4est_amd import parallel as P
+    deg = np.array([3] * 32 + [7] * 32)
+    parts = P.partition_by_dofs(deg, 4)
+    assert parts[0][0] == 0 and sum(c for _, c in parts) == 64
+    for (f0, c0), (f1, _) in zip(parts[:-1], parts[1:]):
+        assert f0 + c0 == f1
+    w = (deg + 1) ** 3
+    loads = [w[f:f + c].sum() for f, c in parts]
+    assert max(loads) <= 1.3 * (w.sum() / 4)          # balanced by DoFs, not by element count
+    assert parts[0][1] > parts[-1][1]                  # low-p elements are cheaper -> more of them per rank
+    assert P.partition_by_dofs(np.full(8, 2), 1) == [(0, 8)]
+    assert (P.owner_of(parts, 64)[:parts[0][1]] == 0).all()
+
+
+def _worker(rank, world, port, level, deg_spec, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from disco4est_amd import mesh as M, parallel as P
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_global = 8 ** level
+        deg_global = np.array([deg_spec[i % len(deg_spec)] for i in range(n_global)])
+        parts = P.partition_by_dofs(deg_global, world)
+        first, count = parts[rank]
+        m = M.BrickMesh(level, deg_global, first=first, count=count)
+        sides = m.build_sides(None)
+        toff = _offsets(m.deg)
+        goff = _offsets(sides["ghost_deg"])
+        sched = P.TraceSchedule(m, sides, parts, lambda e: int(toff[e]), lambda g: int(goff[g]))
+        # local trace buffer with identifying content
+        trace = np.zeros(int(toff[-1]))
+        for e in range(m.n_elements):
+            n = int(m.deg[e]) + 1
+            for f in range(6):
+                o = int(toff[e]) + f * 4 * n * n
+                trace[o:o + 4 * n * n] = _encode(first + e, f, n)
+        ghost = np.full(int(goff[-1]), np.nan)
+        ex = P.TraceExchange(sched, P.DistTransport(), _np_copy_blocks, torch.device("cpu"))
+        tt, gt = torch.from_numpy(trace), torch.from_numpy(ghost)
+        ex.begin(tt)
+        ex.end(gt)
+        # every ghost face that one of my sides uses must now hold the owner's block
+        nbr = sides["side_nbr"]
+        checked = 0
+        for s in np.nonzero(nbr <= -2)[0]:
+            g = -(int(nbr[s]) + 2)
+            f_p = int(sides["side_nbr_face"][s])
+            n = int(sides["ghost_deg"][g]) + 1
+            o = int(goff[g]) + f_p * 4 * n * n
+            np.testing.assert_array_equal(ghost[o:o + 4 * n * n], _encode(int(sides["ghost_global_ids"][g]), f_p, n))
+            checked += 1
+        # blocks nobody needs stay untouched
+        assert np.isnan(ghost).sum() == ghost.size - sum(int(sched.recv_len[p]) for p in sched.peers)
+        # scalar reduction used by cg_eigs
+        t = torch.tensor([float(rank + 1), 2.0], dtype=torch.float64)
+        P.DistTransport().allreduce_sum(t)
+        assert t[0].item() == world * (world + 1) / 2 and t[1].item() == 2.0 * world
+        q.put((rank, "ok", checked, len(sched.peers)))
+    except Exception as exc:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail", traceback.format_exc(), str(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,level,deg_spec", [(2, 1, [3]), (2, 2, [2, 3, 4]), (3, 2, [3])])
+def test_trace_exchange_gloo(world, level, deg_spec):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, level, deg_spec, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r
+    assert sum(r[2] for r in res) > 0          # faces really crossed the partition boundary
+    assert all(r[3] >= 1 for r in res)
