@@ -85,6 +85,11 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
   d4est_hip_plan_t* plan = new d4est_hip_plan_t();
   plan->n_elements = n_elements;
   plan->quad_type = quad_type;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) plan->n_cus = prop.multiProcessorCount;
+  }
   plan->deg.assign(deg, deg + n_elements);
   plan->deg_quad.assign(deg_quad, deg_quad + n_elements);
   plan->nodal_stride.assign(nodal_stride, nodal_stride + n_elements);

@@ -46,6 +46,7 @@ struct d4est_hip_plan {
   int local_nodes_quad = 0;
   int quad_type = 0;
   hipStream_t stream = nullptr;
+  int n_cus = 0;  // multiProcessorCount of the device the plan was created on
 
   std::vector<int> deg, deg_quad, nodal_stride, quad_stride;  // host copies
   std::vector<d4est_hip::Bucket> buckets;

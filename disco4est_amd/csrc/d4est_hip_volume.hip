@@ -17,6 +17,8 @@
 // dimension so that every column read is bank-conflict free.  HBM traffic per
 // element is the algorithmic minimum: u once, the 6-entry symmetric metric once,
 // Au once (64 B/DoF at Nq = N).
+#include <algorithm>
+
 #include "d4est_hip_internal.h"
 
 namespace d4est_hip {
@@ -489,6 +491,204 @@ __global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Persistent, software-pipelined single-wavefront variant: the grid is sized to the machine
+// (2 waves per SIMD, 8 per CU) and every wave loops over elements e, e + G, e + 2G, ...
+// While element e runs its backward contractions and element e+G its forward contractions,
+// the 48 metric doubles (and u) of e+G are already in flight: the HBM/MALL stream and the
+// FP64 pipe overlap instead of alternating as in the one-element-per-wave kernels.
+// ---------------------------------------------------------------------------
+template <int N, int NQ>
+__global__ __launch_bounds__(64, 2) void stiffness_pipe_kernel(
+    const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
+    const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
+    const double* __restrict__ Gop) {
+  using C = WaveCfg<N, NQ>;
+  constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS, EPB = C::EPB;
+  constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
+  constexpr int LDS_PER_ELEM = 3 * FS;  // three fields: no register staging of the S2 / S6 inputs
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const int tid = threadIdx.x;
+  const int slot = tid / PL;
+  const int te = tid - slot * PL;
+  const int a = te % NQ, b = te / NQ;
+  const bool lane_on = slot < EPB;
+  double* R0 = smem + (lane_on ? slot : 0) * LDS_PER_ELEM;
+  double* R1 = R0 + FS;
+  double* R2 = R1 + FS;
+
+  int ei = blockIdx.x * EPB + slot;
+  bool active = lane_on && ei < n_bucket;
+  int ns = 0, qs = 0;
+  double mreg[6][NQ];
+  if (active) {
+    ns = ns_list[ei];
+    qs = qs_list[ei];
+    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) mreg[c][kq] = m[c * NQ3 + NQ * NQ * kq];
+  }
+
+  while (__any(active)) {  // wave-uniform: every lane of the wave sees the same answer
+    // ---- u_e -> LDS (padded [k][j][i])
+    if (active) {
+#pragma unroll
+      for (int idx = te; idx < N3; idx += PL) {
+        const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+        R0[i + PN * (j + N * k)] = u[ns + idx];
+      }
+    }
+    __syncthreads();
+
+    // ---- S1: thread (j=a, k=b): R1 <- B_r u, R2 <- G_r u as [k][iq][j]
+    if (active && a < N && b < N) {
+      double x[N], br[NQ], gr[NQ];
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+      contract_n<N, NQ>(Bop, x, br);
+      contract_n<N, NQ>(Gop, x, gr);
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        R1[a + PN * (iq + NQ * b)] = br[iq];
+        R2[a + PN * (iq + NQ * b)] = gr[iq];
+      }
+    }
+    __syncthreads();
+
+    // ---- S2 (thread (iq=a, k=b)) -> R0 -> S3 (thread (iq=a, jq=b)), one field at a time
+    double gr[NQ], gs[NQ], gt[NQ];
+    {
+      double x[N], t[NQ];
+      const bool on2 = active && b < N;
+      if (on2) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) x[j] = R2[j + PN * (a + NQ * b)];  // G_r u
+        contract_n<N, NQ>(Bop, x, t);
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
+      }
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
+        contract_n<N, NQ>(Bop, x, gr);
+      }
+      __syncthreads();
+      if (on2) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];  // B_r u
+        contract_n<N, NQ>(Gop, x, t);
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq) R2[b + PN * (a + NQ * jq)] = t[jq];  // R2's G_r u is consumed
+        contract_n<N, NQ>(Bop, x, t);
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
+      }
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) x[k] = R2[k + PN * (a + NQ * b)];
+        contract_n<N, NQ>(Bop, x, gs);
+#pragma unroll
+        for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
+        contract_n<N, NQ>(Gop, x, gt);
+      }
+    }
+
+    // ---- quadrature-point stage (metric requested one element ahead)
+    if (active) {
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) {
+        const double m0 = mreg[0][kq], m1 = mreg[1][kq], m2 = mreg[2][kq], m3 = mreg[3][kq], m4 = mreg[4][kq], m5 = mreg[5][kq];
+        const double r = gr[kq], s = gs[kq], t = gt[kq];
+        gr[kq] = m0 * r + m1 * s + m2 * t;
+        gs[kq] = m1 * r + m3 * s + m4 * t;
+        gt[kq] = m2 * r + m4 * s + m5 * t;
+      }
+    }
+
+    // ---- request the NEXT element's metric; it lands while this element runs backward and the next one forward
+    const int ns_cur = ns;
+    const bool active_cur = active;
+    ei += gridDim.x * EPB;
+    active = lane_on && ei < n_bucket;
+    if (active) {
+      ns = ns_list[ei];
+      qs = qs_list[ei];
+      const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) mreg[c][kq] = m[c * NQ3 + NQ * NQ * kq];
+    }
+
+    // ---- S5 (registers) -> LDS [k][iq][jq] -> S6 (thread (iq=a, k=b))
+    __syncthreads();
+    if (active_cur) {
+      double c[N];
+      contract_t<NQ, N, false>(Bop, gr, c);
+#pragma unroll
+      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = c[k];
+      contract_t<NQ, N, false>(Bop, gs, c);
+#pragma unroll
+      for (int k = 0; k < N; ++k) R1[b + PQ * (a + NQ * k)] = c[k];
+      contract_t<NQ, N, false>(Gop, gt, c);
+#pragma unroll
+      for (int k = 0; k < N; ++k) R2[b + PQ * (a + NQ * k)] = c[k];
+    }
+    __syncthreads();
+    {
+      double ar[N], bs[N], x[NQ];
+      const bool on6 = active_cur && b < N;
+      if (on6) {
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+        contract_t<NQ, N, false>(Bop, x, ar);
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq) x[jq] = R1[jq + PQ * (a + NQ * b)];
+        contract_t<NQ, N, false>(Gop, x, bs);
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq) x[jq] = R2[jq + PQ * (a + NQ * b)];
+        contract_t<NQ, N, true>(Bop, x, bs);
+      }
+      __syncthreads();
+      if (on6) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {  // [k][j][iq]
+          R0[a + PQ * (j + N * b)] = ar[j];
+          R1[a + PQ * (j + N * b)] = bs[j];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- S7: thread (j=a, k=b)
+    if (active_cur && a < N && b < N) {
+      double x[NQ], o[N];
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) x[iq] = R0[iq + PQ * (a + N * b)];
+      contract_t<NQ, N, false>(Gop, x, o);
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) x[iq] = R1[iq + PQ * (a + N * b)];
+      contract_t<NQ, N, true>(Bop, x, o);
+#pragma unroll
+      for (int i = 0; i < N; ++i) R2[i + PN * (a + N * b)] = o[i];
+    }
+    __syncthreads();
+    if (active_cur) {
+#pragma unroll
+      for (int idx = te; idx < N3; idx += PL) {
+        const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+        Au[ns_cur + idx] = R2[i + PN * (j + N * k)];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // mass-like applies (one field):
 //   MODE 0: out = V^T (W J) V in          (mass)            in: nodal, out: nodal
 //   MODE 1: out = V^T (W J) in_quad       (galerkin)        in: quad,  out: nodal
@@ -854,7 +1054,13 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
   if constexpr (NQ * NQ <= 64 && NQ >= N) {
     using W = WaveCfg<N, NQ>;
     const int grid = (bk.n_elem + W::EPB - 1) / W::EPB;
-    if (use_pf)
+    if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 2) {
+      int cus = plan->n_cus > 0 ? plan->n_cus : 256;
+      const int pgrid = std::min(grid, cus * 8);
+      hipLaunchKernelGGL((stiffness_pipe_kernel<N, NQ>), dim3(pgrid), dim3(64), (W::LDS_BYTES / 2) * 3, plan->stream, u, Au,
+                         plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
+                         bk.d_B, bk.d_G);
+    } else if (use_pf)
       hipLaunchKernelGGL((stiffness_wave_kernel<N, NQ, true>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au,
                          plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
                          bk.d_B, bk.d_G);

@@ -76,7 +76,7 @@ void d4est_hip_plan_set_stream(d4est_hip_plan_t* plan, void* hip_stream);
 /* Performance knobs (never change results beyond fp64 re-association).  Value -1 (default) = auto. */
 enum d4est_hip_tuning_key {
   D4EST_HIP_TUNE_STIFFNESS_PREFETCH = 0, /* 1: request the metric at kernel entry (deg_quad <= 7), 0: at the point of use */
-  D4EST_HIP_TUNE_STIFFNESS_WAVE = 1,     /* 1: single-wavefront two-buffer stiffness kernel where (deg_quad+1)^2 <= 64 */
+  D4EST_HIP_TUNE_STIFFNESS_WAVE = 1,     /* where (deg_quad+1)^2 <= 64: 1 single-wavefront two-buffer kernel, 2 persistent software-pipelined kernel */
   D4EST_HIP_TUNE_COUNT = 2
 };
 void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value);
