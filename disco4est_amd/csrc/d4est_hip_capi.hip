@@ -128,6 +128,9 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
     bk.d_B = upload(B);
     bk.d_G = upload(G);
     bk.d_D = upload(D);
+    bk.d_BT = upload(Tables1D::transpose(B, bk.NQ, bk.N));
+    bk.d_GT = upload(Tables1D::transpose(G, bk.NQ, bk.N));
+    bk.d_DT = upload(Tables1D::transpose(D, bk.N, bk.N));
     bk.d_w = upload(Tables1D::quad_weights(quad_type, bk.deg_quad));
     plan->buckets.push_back(bk);
   }
@@ -150,6 +153,9 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
     (void)hipFree(bk.d_G);
     (void)hipFree(bk.d_D);
     (void)hipFree(bk.d_w);
+    (void)hipFree(bk.d_BT);
+    (void)hipFree(bk.d_GT);
+    (void)hipFree(bk.d_DT);
   }
   (void)hipFree(plan->d_elem_ids);
   (void)hipFree(plan->d_ns_list);

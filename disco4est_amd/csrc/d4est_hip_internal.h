@@ -36,6 +36,9 @@ struct Bucket {
   double* d_G = nullptr;    // NQ x N  G = B * D  (derivative evaluated at quadrature nodes)
   double* d_D = nullptr;    // N x N   collocation derivative
   double* d_w = nullptr;    // NQ      quadrature weights
+  double* d_BT = nullptr;   // N x NQ  transposes (row i = column i of the operator: one scalar load feeds NQ FMA chains)
+  double* d_GT = nullptr;
+  double* d_DT = nullptr;
 };
 
 }  // namespace d4est_hip

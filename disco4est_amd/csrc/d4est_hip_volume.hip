@@ -53,16 +53,21 @@ __device__ __forceinline__ sdouble_ptr launder(const double* p) {
   return (sdouble_ptr)v;
 }
 
-// y = op x, op is NO x NI row-major
+// y = op x with op (NO x NI) passed TRANSPOSED: opT is NI x NO row-major.  Loop order i-outer so that one scalar
+// row opT[i][0..NO) feeds NO INDEPENDENT FMA chains (a dependent chain per output would serialise on the
+// FP64 FMA latency: measured 39 % issue-stall cycles with the o-outer form, profiles/r01_c_*).
 template <int NI, int NO>
-__device__ __forceinline__ void contract_n(const double* __restrict__ op, const double* x, double* y) {
+__device__ __forceinline__ void contract_n(const double* __restrict__ opT, const double* x, double* y) {
 #pragma unroll
-  for (int o = 0; o < NO; ++o) {
-    sdouble_ptr row = launder(op + o * NI);
-    double s = row[0] * x[0];
+  for (int i = 0; i < NI; ++i) {
+    sdouble_ptr row = launder(opT + i * NO);
+    if (i == 0) {
 #pragma unroll
-    for (int i = 1; i < NI; ++i) s = fma(row[i], x[i], s);
-    y[o] = s;
+      for (int o = 0; o < NO; ++o) y[o] = row[o] * x[0];
+    } else {
+#pragma unroll
+      for (int o = 0; o < NO; ++o) y[o] = fma(row[o], x[i], y[o]);
+    }
   }
 }
 
@@ -91,7 +96,8 @@ template <int N, int NQ, bool PF>
 __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list,
-    int n_bucket, const double* __restrict__ Bop, const double* __restrict__ Gop) {
+    int n_bucket, const double* __restrict__ Bop, const double* __restrict__ Gop,
+    const double* __restrict__ BopT, const double* __restrict__ GopT) {
   using C = VolCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
   constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
@@ -137,8 +143,8 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     double x[N], br[NQ], gr[NQ];
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-    contract_n<N, NQ>(Bop, x, br);
-    contract_n<N, NQ>(Gop, x, gr);
+    contract_n<N, NQ>(BopT, x, br);
+    contract_n<N, NQ>(GopT, x, gr);
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
       R1[a + PN * (iq + NQ * b)] = br[iq];
@@ -153,11 +159,11 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     double x[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];
-    contract_n<N, NQ>(Bop, x, t_bb);
-    contract_n<N, NQ>(Gop, x, t_gb);
+    contract_n<N, NQ>(BopT, x, t_bb);
+    contract_n<N, NQ>(GopT, x, t_gb);
 #pragma unroll
     for (int j = 0; j < N; ++j) x[j] = R2[j + PN * (a + NQ * b)];
-    contract_n<N, NQ>(Bop, x, t_bg);
+    contract_n<N, NQ>(BopT, x, t_bg);
   }
   __syncthreads();
   if (active && b < N) {
@@ -177,13 +183,13 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     double x[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
-    contract_n<N, NQ>(Bop, x, gr);
+    contract_n<N, NQ>(BopT, x, gr);
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = R1[k + PN * (a + NQ * b)];
-    contract_n<N, NQ>(Bop, x, gs);
+    contract_n<N, NQ>(BopT, x, gs);
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = R2[k + PN * (a + NQ * b)];
-    contract_n<N, NQ>(Gop, x, gt);
+    contract_n<N, NQ>(GopT, x, gt);
 
     // ---- quadrature-point stage: symmetric metric (rr,rs,rt,ss,st,tt), coalesced along (iq,jq)
     const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
@@ -286,7 +292,7 @@ template <int N, int NQ, bool PF>
 __global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
-    const double* __restrict__ Gop) {
+    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT) {
   using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
   constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
@@ -331,8 +337,8 @@ __global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
     if (on) {
 #pragma unroll
       for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-      contract_n<N, NQ>(Bop, x, br);
-      contract_n<N, NQ>(Gop, x, gr);
+      contract_n<N, NQ>(BopT, x, br);
+      contract_n<N, NQ>(GopT, x, gr);
     }
     __syncthreads();
     if (on) {
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
     __syncthreads();
     // field 1: B_s G_r u  -> gr = B_t(.)
     if (on2) {
-      contract_n<N, NQ>(Bop, x2, t);
+      contract_n<N, NQ>(BopT, x2, t);
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
     }
@@ -368,11 +374,11 @@ __global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
     if (active) {
 #pragma unroll
       for (int k = 0; k < N; ++k) y[k] = R0[k + PN * (a + NQ * b)];
-      contract_n<N, NQ>(Bop, y, gr);
+      contract_n<N, NQ>(BopT, y, gr);
     }
     // field 2: G_s B_r u  -> gs = B_t(.)   (goes through R1 so the two transfers overlap)
     if (on2) {
-      contract_n<N, NQ>(Gop, x1, t);
+      contract_n<N, NQ>(GopT, x1, t);
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) R1[b + PN * (a + NQ * jq)] = t[jq];
     }
@@ -380,11 +386,11 @@ __global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
     if (active) {
 #pragma unroll
       for (int k = 0; k < N; ++k) y[k] = R1[k + PN * (a + NQ * b)];
-      contract_n<N, NQ>(Bop, y, gs);
+      contract_n<N, NQ>(BopT, y, gs);
     }
     // field 3: B_s B_r u  -> gt = G_t(.)
     if (on2) {
-      contract_n<N, NQ>(Bop, x1, t);
+      contract_n<N, NQ>(BopT, x1, t);
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
     }
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
     if (active) {
 #pragma unroll
       for (int k = 0; k < N; ++k) y[k] = R0[k + PN * (a + NQ * b)];
-      contract_n<N, NQ>(Gop, y, gt);
+      contract_n<N, NQ>(GopT, y, gt);
     }
   }
 
@@ -501,7 +507,7 @@ template <int N, int NQ>
 __global__ __launch_bounds__(64, 2) void stiffness_pipe_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
-    const double* __restrict__ Gop) {
+    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT) {
   using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS, EPB = C::EPB;
   constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
@@ -547,8 +553,8 @@ __global__ __launch_bounds__(64, 2) void stiffness_pipe_kernel(
       double x[N], br[NQ], gr[NQ];
 #pragma unroll
       for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-      contract_n<N, NQ>(Bop, x, br);
-      contract_n<N, NQ>(Gop, x, gr);
+      contract_n<N, NQ>(BopT, x, br);
+      contract_n<N, NQ>(GopT, x, gr);
 #pragma unroll
       for (int iq = 0; iq < NQ; ++iq) {
         R1[a + PN * (iq + NQ * b)] = br[iq];
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(64, 2) void stiffness_pipe_kernel(
       if (on2) {
 #pragma unroll
         for (int j = 0; j < N; ++j) x[j] = R2[j + PN * (a + NQ * b)];  // G_r u
-        contract_n<N, NQ>(Bop, x, t);
+        contract_n<N, NQ>(BopT, x, t);
 #pragma unroll
         for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
       }
@@ -573,16 +579,16 @@ __global__ __launch_bounds__(64, 2) void stiffness_pipe_kernel(
       if (active) {
 #pragma unroll
         for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
-        contract_n<N, NQ>(Bop, x, gr);
+        contract_n<N, NQ>(BopT, x, gr);
       }
       __syncthreads();
       if (on2) {
 #pragma unroll
         for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];  // B_r u
-        contract_n<N, NQ>(Gop, x, t);
+        contract_n<N, NQ>(GopT, x, t);
 #pragma unroll
         for (int jq = 0; jq < NQ; ++jq) R2[b + PN * (a + NQ * jq)] = t[jq];  // R2's G_r u is consumed
-        contract_n<N, NQ>(Bop, x, t);
+        contract_n<N, NQ>(BopT, x, t);
 #pragma unroll
         for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
       }
@@ -590,10 +596,10 @@ __global__ __launch_bounds__(64, 2) void stiffness_pipe_kernel(
       if (active) {
 #pragma unroll
         for (int k = 0; k < N; ++k) x[k] = R2[k + PN * (a + NQ * b)];
-        contract_n<N, NQ>(Bop, x, gs);
+        contract_n<N, NQ>(BopT, x, gs);
 #pragma unroll
         for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
-        contract_n<N, NQ>(Gop, x, gt);
+        contract_n<N, NQ>(GopT, x, gt);
       }
     }
 
@@ -698,7 +704,7 @@ template <int N, int NQ, int MODE>
 __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void mass_like_kernel(
     const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ Jq,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list,
-    int n_bucket, const double* __restrict__ Bop, const double* __restrict__ wq) {
+    int n_bucket, const double* __restrict__ Bop, const double* __restrict__ BopT, const double* __restrict__ wq) {
   using C = VolCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ;
   constexpr int N3 = N * N * N;
@@ -733,7 +739,7 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void mass_like_kernel(
       double x[N], y[NQ];
 #pragma unroll
       for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-      contract_n<N, NQ>(Bop, x, y);
+      contract_n<N, NQ>(BopT, x, y);
 #pragma unroll
       for (int iq = 0; iq < NQ; ++iq) R1[a + PN * (iq + NQ * b)] = y[iq];
     }
@@ -742,7 +748,7 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void mass_like_kernel(
       double x[N], y[NQ];
 #pragma unroll
       for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];
-      contract_n<N, NQ>(Bop, x, y);
+      contract_n<N, NQ>(BopT, x, y);
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = y[jq];
     }
@@ -751,7 +757,7 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void mass_like_kernel(
       double x[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
-      contract_n<N, NQ>(Bop, x, g);
+      contract_n<N, NQ>(BopT, x, g);
     }
   } else if (active) {
 #pragma unroll
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(256) void generic_volume_kernel(
 template <int N>
 __global__ __launch_bounds__((VolCfg<N, N>::THREADS)) void dudr_kernel(
     const double* __restrict__ u, double* __restrict__ d0, double* __restrict__ d1, double* __restrict__ d2,
-    const int* __restrict__ ns_list, int n_bucket, const double* __restrict__ Dop) {
+    const int* __restrict__ ns_list, int n_bucket, const double* __restrict__ DopT) {
   using C = VolCfg<N, N>;
   constexpr int PL = C::PL, PN = C::PN, N3 = N * N * N;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -948,19 +954,19 @@ __global__ __launch_bounds__((VolCfg<N, N>::THREADS)) void dudr_kernel(
     double x[N], y[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = R0[a + PN * (b + N * k)];
-    contract_n<N, N>(Dop, x, y);
+    contract_n<N, N>(DopT, x, y);
 #pragma unroll
     for (int k = 0; k < N; ++k) d2[ns + a + N * (b + N * k)] = y[k];
     // direction s (dir 1): thread (i=a, k=b), column along j
 #pragma unroll
     for (int j = 0; j < N; ++j) x[j] = R0[a + PN * (j + N * b)];
-    contract_n<N, N>(Dop, x, y);
+    contract_n<N, N>(DopT, x, y);
 #pragma unroll
     for (int j = 0; j < N; ++j) d1[ns + a + N * (j + N * b)] = y[j];
     // direction r (dir 0): thread (j=a, k=b), column along i -> stage through LDS for a coalesced store
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-    contract_n<N, N>(Dop, x, y);
+    contract_n<N, N>(DopT, x, y);
 #pragma unroll
     for (int i = 0; i < N; ++i) R1[i + PN * (a + N * b)] = y[i];
   }
@@ -1059,15 +1065,15 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
       const int pgrid = std::min(grid, cus * 8);
       hipLaunchKernelGGL((stiffness_pipe_kernel<N, NQ>), dim3(pgrid), dim3(64), (W::LDS_BYTES / 2) * 3, plan->stream, u, Au,
                          plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
-                         bk.d_B, bk.d_G);
+                         bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);
     } else if (use_pf)
       hipLaunchKernelGGL((stiffness_wave_kernel<N, NQ, true>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au,
                          plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
-                         bk.d_B, bk.d_G);
+                         bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);
     else
       hipLaunchKernelGGL((stiffness_wave_kernel<N, NQ, false>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au,
                          plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
-                         bk.d_B, bk.d_G);
+                         bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);
   }
 }
 
@@ -1096,12 +1102,12 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
           set_lds_limit(stiffness_kernel<N_, NQ_, kCanPF>, C::LDS_BYTES);                                       \
           hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, kCanPF>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,   \
                              plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
-                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);                      \
+                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);                      \
         } else {                                                                                                \
           set_lds_limit(stiffness_kernel<N_, NQ_, false>, C::LDS_BYTES);                                        \
           hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, false>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,    \
                              plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
-                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);                      \
+                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);                      \
         }                                                                                                       \
       }                                                                                                         \
       done = true;                                                                                              \
@@ -1127,7 +1133,7 @@ static void launch_mass_like_mode(d4est_hip_plan* plan, const double* in, double
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                             \
       hipLaunchKernelGGL((mass_like_kernel<N_, NQ_, MODE>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, \
                          in, out, plan->d_J, plan->d_ns_list + bk.elem_offset,                                        \
-                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_w);                                             \
+                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_BT, bk.d_w);                                             \
       done = true;                                                                                                    \
     }                                                                                                                 \
   }
@@ -1157,7 +1163,7 @@ void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, 
       set_lds_limit(dudr_kernel<N_>, C::LDS_BYTES);                                                        \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                  \
       hipLaunchKernelGGL((dudr_kernel<N_>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, u,   \
-                         d0, d1, d2, plan->d_ns_list + bk.elem_offset, bk.n_elem, bk.d_D);                                                                          \
+                         d0, d1, d2, plan->d_ns_list + bk.elem_offset, bk.n_elem, bk.d_DT);                                                                          \
       done = true;                                                                                         \
     }                                                                                                      \
   }
