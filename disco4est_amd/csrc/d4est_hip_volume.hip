@@ -497,200 +497,235 @@ __global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Persistent, software-pipelined single-wavefront variant: the grid is sized to the machine
-// (2 waves per SIMD, 8 per CU) and every wave loops over elements e, e + G, e + 2G, ...
-// While element e runs its backward contractions and element e+G its forward contractions,
-// the 48 metric doubles (and u) of e+G are already in flight: the HBM/MALL stream and the
-// FP64 pipe overlap instead of alternating as in the one-element-per-wave kernels.
+// Two-wavefront variant (NQ*NQ <= 64): an element is owned by TWO waves; in every contraction each
+// wave produces one half of the OUTPUT indices of every column (from the full input column), so a
+// thread's register state is half a column per field.  That halves the VGPR cost of holding the
+// metric: the thread's 6 x NQ/2 metric doubles are requested at kernel entry (HBM latency overlaps
+// the forward contractions) and the kernel still fits 128 VGPRs = 4 waves/SIMD.  The price is one
+// extra LDS exchange (the flux at the quadrature nodes, before the transposed t-contraction) and
+// s_barriers between stages.
 // ---------------------------------------------------------------------------
+// y[0..NH) = rows [o0, o0+NH) of (op x), op given transposed (NI x NO row-major)
+template <int NI, int NO, int NH>
+__device__ __forceinline__ void contract_n_part(const double* __restrict__ opT, int o0, const double* x, double* y) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    sdouble_ptr row = launder(opT + i * NO + o0);
+    if (i == 0) {
+#pragma unroll
+      for (int o = 0; o < NH; ++o) y[o] = row[o] * x[0];
+    } else {
+#pragma unroll
+      for (int o = 0; o < NH; ++o) y[o] = fma(row[o], x[i], y[o]);
+    }
+  }
+}
+// y[0..NH) (+)= entries [o0, o0+NH) of (op^T x), op is NI x NO row-major
+template <int NI, int NO, int NH, bool ACC>
+__device__ __forceinline__ void contract_t_part(const double* __restrict__ op, int o0, const double* x, double* y) {
+  if (!ACC) {
+#pragma unroll
+    for (int o = 0; o < NH; ++o) y[o] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    sdouble_ptr row = launder(op + i * NO + o0);
+#pragma unroll
+    for (int o = 0; o < NH; ++o) y[o] = fma(row[o], x[i], y[o]);
+  }
+}
+
 template <int N, int NQ>
-__global__ __launch_bounds__(64, 2) void stiffness_pipe_kernel(
+__global__ __launch_bounds__(128, 4) void stiffness_pair_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
     const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT) {
+  static_assert(N % 2 == 0 && NQ % 2 == 0, "pair kernel splits the output indices in two equal halves");
   using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS, EPB = C::EPB;
   constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
-  constexpr int LDS_PER_ELEM = 3 * FS;  // three fields: no register staging of the S2 / S6 inputs
+  constexpr int HN = N / 2, HQ = NQ / 2;
+  constexpr int LDS_PER_ELEM = 3 * FS;
   extern __shared__ __attribute__((aligned(16))) double smem[];
 
-  const int tid = threadIdx.x;
-  const int slot = tid / PL;
-  const int te = tid - slot * PL;
+  // which half of the output indices this wave produces; readfirstlane makes the wave-uniformity explicit (SGPR)
+  const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / PL;
+  const int te = lane - slot * PL;
   const int a = te % NQ, b = te / NQ;
-  const bool lane_on = slot < EPB;
-  double* R0 = smem + (lane_on ? slot : 0) * LDS_PER_ELEM;
+  const int ei = blockIdx.x * EPB + slot;
+  const bool active = (slot < EPB) && (ei < n_bucket);
+  double* R0 = smem + (active ? slot : 0) * LDS_PER_ELEM;
   double* R1 = R0 + FS;
   double* R2 = R1 + FS;
+  const int q0 = h * HQ, n0 = h * HN;  // first output index of this wave's half
 
-  int ei = blockIdx.x * EPB + slot;
-  bool active = lane_on && ei < n_bucket;
   int ns = 0, qs = 0;
-  double mreg[6][NQ];
   if (active) {
     ns = ns_list[ei];
     qs = qs_list[ei];
-    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+  }
+  // ---- u_e -> LDS: both waves together, 2*PL threads per element
+  if (active) {
 #pragma unroll
-    for (int kq = 0; kq < NQ; ++kq)
+    for (int idx = te + h * PL; idx < N3; idx += 2 * PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      R0[i + PN * (j + N * k)] = u[ns + idx];
+    }
+  }
+  // ---- metric prefetch for this thread's HQ quadrature nodes of column (iq=a, jq=b)
+  double mreg[6][HQ];
+  if (active) {
+    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b) + NQ * NQ * q0;
+#pragma unroll
+    for (int kq = 0; kq < HQ; ++kq)
 #pragma unroll
       for (int c = 0; c < 6; ++c) mreg[c][kq] = m[c * NQ3 + NQ * NQ * kq];
   }
+  __syncthreads();
 
-  while (__any(active)) {  // wave-uniform: every lane of the wave sees the same answer
-    // ---- u_e -> LDS (padded [k][j][i])
+  // ---- S1: thread (j=a, k=b), outputs iq in [q0, q0+HQ): R1 <- B_r u, R2 <- G_r u as [k][iq][j]
+  if (active && a < N && b < N) {
+    double x[N], br[HQ], gr[HQ];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+    contract_n_part<N, NQ, HQ>(BopT, q0, x, br);
+    contract_n_part<N, NQ, HQ>(GopT, q0, x, gr);
+#pragma unroll
+    for (int iq = 0; iq < HQ; ++iq) {
+      R1[a + PN * (q0 + iq + NQ * b)] = br[iq];
+      R2[a + PN * (q0 + iq + NQ * b)] = gr[iq];
+    }
+  }
+  __syncthreads();
+
+  // ---- S2: thread (iq=a, k=b), outputs jq in [q0, q0+HQ)
+  {
+    double x[N], t_bb[HQ], t_gb[HQ], t_bg[HQ];
+    const bool on2 = active && b < N;
+    if (on2) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];
+      contract_n_part<N, NQ, HQ>(BopT, q0, x, t_bb);
+      contract_n_part<N, NQ, HQ>(GopT, q0, x, t_gb);
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] = R2[j + PN * (a + NQ * b)];
+      contract_n_part<N, NQ, HQ>(BopT, q0, x, t_bg);
+    }
+    __syncthreads();
+    if (on2) {
+#pragma unroll
+      for (int jq = 0; jq < HQ; ++jq) {  // [jq][iq][k]
+        R0[b + PN * (a + NQ * (q0 + jq))] = t_bg[jq];
+        R1[b + PN * (a + NQ * (q0 + jq))] = t_gb[jq];
+        R2[b + PN * (a + NQ * (q0 + jq))] = t_bb[jq];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- S3: thread (iq=a, jq=b), outputs kq in [q0, q0+HQ); then the metric multiply on those nodes
+  double fr[HQ], fs[HQ], ft[HQ];
+  if (active) {
+    double x[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
+    contract_n_part<N, NQ, HQ>(BopT, q0, x, fr);
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] = R1[k + PN * (a + NQ * b)];
+    contract_n_part<N, NQ, HQ>(BopT, q0, x, fs);
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] = R2[k + PN * (a + NQ * b)];
+    contract_n_part<N, NQ, HQ>(GopT, q0, x, ft);
+#pragma unroll
+    for (int kq = 0; kq < HQ; ++kq) {
+      const double r = fr[kq], s = fs[kq], t = ft[kq];
+      fr[kq] = mreg[0][kq] * r + mreg[1][kq] * s + mreg[2][kq] * t;
+      fs[kq] = mreg[1][kq] * r + mreg[3][kq] * s + mreg[4][kq] * t;
+      ft[kq] = mreg[2][kq] * r + mreg[4][kq] * s + mreg[5][kq] * t;
+    }
+  }
+  __syncthreads();
+  // ---- exchange the flux halves through LDS ([jq][iq][kq], kq fastest) so each wave sees the full kq column
+  if (active) {
+#pragma unroll
+    for (int kq = 0; kq < HQ; ++kq) {
+      R0[q0 + kq + PQ * (a + NQ * b)] = fr[kq];
+      R1[q0 + kq + PQ * (a + NQ * b)] = fs[kq];
+      R2[q0 + kq + PQ * (a + NQ * b)] = ft[kq];
+    }
+  }
+  __syncthreads();
+  // ---- S5: thread (iq=a, jq=b), outputs k in [n0, n0+HN)
+  {
+    double x[NQ], ca[HN], cb[HN], cc[HN];
     if (active) {
 #pragma unroll
-      for (int idx = te; idx < N3; idx += PL) {
-        const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-        R0[i + PN * (j + N * k)] = u[ns + idx];
-      }
+      for (int kq = 0; kq < NQ; ++kq) x[kq] = R0[kq + PQ * (a + NQ * b)];
+      contract_t_part<NQ, N, HN, false>(Bop, n0, x, ca);
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) x[kq] = R1[kq + PQ * (a + NQ * b)];
+      contract_t_part<NQ, N, HN, false>(Bop, n0, x, cb);
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) x[kq] = R2[kq + PQ * (a + NQ * b)];
+      contract_t_part<NQ, N, HN, false>(Gop, n0, x, cc);
     }
     __syncthreads();
-
-    // ---- S1: thread (j=a, k=b): R1 <- B_r u, R2 <- G_r u as [k][iq][j]
-    if (active && a < N && b < N) {
-      double x[N], br[NQ], gr[NQ];
-#pragma unroll
-      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-      contract_n<N, NQ>(BopT, x, br);
-      contract_n<N, NQ>(GopT, x, gr);
-#pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) {
-        R1[a + PN * (iq + NQ * b)] = br[iq];
-        R2[a + PN * (iq + NQ * b)] = gr[iq];
-      }
-    }
-    __syncthreads();
-
-    // ---- S2 (thread (iq=a, k=b)) -> R0 -> S3 (thread (iq=a, jq=b)), one field at a time
-    double gr[NQ], gs[NQ], gt[NQ];
-    {
-      double x[N], t[NQ];
-      const bool on2 = active && b < N;
-      if (on2) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) x[j] = R2[j + PN * (a + NQ * b)];  // G_r u
-        contract_n<N, NQ>(BopT, x, t);
-#pragma unroll
-        for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
-      }
-      __syncthreads();
-      if (active) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
-        contract_n<N, NQ>(BopT, x, gr);
-      }
-      __syncthreads();
-      if (on2) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];  // B_r u
-        contract_n<N, NQ>(GopT, x, t);
-#pragma unroll
-        for (int jq = 0; jq < NQ; ++jq) R2[b + PN * (a + NQ * jq)] = t[jq];  // R2's G_r u is consumed
-        contract_n<N, NQ>(BopT, x, t);
-#pragma unroll
-        for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
-      }
-      __syncthreads();
-      if (active) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) x[k] = R2[k + PN * (a + NQ * b)];
-        contract_n<N, NQ>(BopT, x, gs);
-#pragma unroll
-        for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
-        contract_n<N, NQ>(GopT, x, gt);
-      }
-    }
-
-    // ---- quadrature-point stage (metric requested one element ahead)
     if (active) {
 #pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) {
-        const double m0 = mreg[0][kq], m1 = mreg[1][kq], m2 = mreg[2][kq], m3 = mreg[3][kq], m4 = mreg[4][kq], m5 = mreg[5][kq];
-        const double r = gr[kq], s = gs[kq], t = gt[kq];
-        gr[kq] = m0 * r + m1 * s + m2 * t;
-        gs[kq] = m1 * r + m3 * s + m4 * t;
-        gt[kq] = m2 * r + m4 * s + m5 * t;
+      for (int k = 0; k < HN; ++k) {  // [k][iq][jq], jq fastest
+        R0[b + PQ * (a + NQ * (n0 + k))] = ca[k];
+        R1[b + PQ * (a + NQ * (n0 + k))] = cb[k];
+        R2[b + PQ * (a + NQ * (n0 + k))] = cc[k];
       }
     }
-
-    // ---- request the NEXT element's metric; it lands while this element runs backward and the next one forward
-    const int ns_cur = ns;
-    const bool active_cur = active;
-    ei += gridDim.x * EPB;
-    active = lane_on && ei < n_bucket;
-    if (active) {
-      ns = ns_list[ei];
-      qs = qs_list[ei];
-      const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+  }
+  __syncthreads();
+  // ---- S6: thread (iq=a, k=b), outputs j in [n0, n0+HN)
+  {
+    double x[NQ], ar[HN], bs[HN];
+    const bool on6 = active && b < N;
+    if (on6) {
 #pragma unroll
-      for (int kq = 0; kq < NQ; ++kq)
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+      contract_t_part<NQ, N, HN, false>(Bop, n0, x, ar);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) mreg[c][kq] = m[c * NQ3 + NQ * NQ * kq];
-    }
-
-    // ---- S5 (registers) -> LDS [k][iq][jq] -> S6 (thread (iq=a, k=b))
-    __syncthreads();
-    if (active_cur) {
-      double c[N];
-      contract_t<NQ, N, false>(Bop, gr, c);
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = R1[jq + PQ * (a + NQ * b)];
+      contract_t_part<NQ, N, HN, false>(Gop, n0, x, bs);
 #pragma unroll
-      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = c[k];
-      contract_t<NQ, N, false>(Bop, gs, c);
-#pragma unroll
-      for (int k = 0; k < N; ++k) R1[b + PQ * (a + NQ * k)] = c[k];
-      contract_t<NQ, N, false>(Gop, gt, c);
-#pragma unroll
-      for (int k = 0; k < N; ++k) R2[b + PQ * (a + NQ * k)] = c[k];
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = R2[jq + PQ * (a + NQ * b)];
+      contract_t_part<NQ, N, HN, true>(Bop, n0, x, bs);
     }
     __syncthreads();
-    {
-      double ar[N], bs[N], x[NQ];
-      const bool on6 = active_cur && b < N;
-      if (on6) {
+    if (on6) {
 #pragma unroll
-        for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
-        contract_t<NQ, N, false>(Bop, x, ar);
-#pragma unroll
-        for (int jq = 0; jq < NQ; ++jq) x[jq] = R1[jq + PQ * (a + NQ * b)];
-        contract_t<NQ, N, false>(Gop, x, bs);
-#pragma unroll
-        for (int jq = 0; jq < NQ; ++jq) x[jq] = R2[jq + PQ * (a + NQ * b)];
-        contract_t<NQ, N, true>(Bop, x, bs);
-      }
-      __syncthreads();
-      if (on6) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {  // [k][j][iq]
-          R0[a + PQ * (j + N * b)] = ar[j];
-          R1[a + PQ * (j + N * b)] = bs[j];
-        }
+      for (int j = 0; j < HN; ++j) {  // [k][j][iq]
+        R0[a + PQ * (n0 + j + N * b)] = ar[j];
+        R1[a + PQ * (n0 + j + N * b)] = bs[j];
       }
     }
-    __syncthreads();
-
-    // ---- S7: thread (j=a, k=b)
-    if (active_cur && a < N && b < N) {
-      double x[NQ], o[N];
+  }
+  __syncthreads();
+  // ---- S7: thread (j=a, k=b), outputs i in [n0, n0+HN)
+  if (active && a < N && b < N) {
+    double x[NQ], o[HN];
 #pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) x[iq] = R0[iq + PQ * (a + N * b)];
-      contract_t<NQ, N, false>(Gop, x, o);
+    for (int iq = 0; iq < NQ; ++iq) x[iq] = R0[iq + PQ * (a + N * b)];
+    contract_t_part<NQ, N, HN, false>(Gop, n0, x, o);
 #pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) x[iq] = R1[iq + PQ * (a + N * b)];
-      contract_t<NQ, N, true>(Bop, x, o);
+    for (int iq = 0; iq < NQ; ++iq) x[iq] = R1[iq + PQ * (a + N * b)];
+    contract_t_part<NQ, N, HN, true>(Bop, n0, x, o);
 #pragma unroll
-      for (int i = 0; i < N; ++i) R2[i + PN * (a + N * b)] = o[i];
+    for (int i = 0; i < HN; ++i) R2[n0 + i + PN * (a + N * b)] = o[i];
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int idx = te + h * PL; idx < N3; idx += 2 * PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      Au[ns + idx] = R2[i + PN * (j + N * k)];
     }
-    __syncthreads();
-    if (active_cur) {
-#pragma unroll
-      for (int idx = te; idx < N3; idx += PL) {
-        const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-        Au[ns_cur + idx] = R2[i + PN * (j + N * k)];
-      }
-    }
-    __syncthreads();
   }
 }
 
@@ -1060,12 +1095,11 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
   if constexpr (NQ * NQ <= 64 && NQ >= N) {
     using W = WaveCfg<N, NQ>;
     const int grid = (bk.n_elem + W::EPB - 1) / W::EPB;
-    if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 2) {
-      int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-      const int pgrid = std::min(grid, cus * 8);
-      hipLaunchKernelGGL((stiffness_pipe_kernel<N, NQ>), dim3(pgrid), dim3(64), (W::LDS_BYTES / 2) * 3, plan->stream, u, Au,
-                         plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
-                         bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);
+    if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 2 && N % 2 == 0 && NQ % 2 == 0) {
+      if constexpr (N % 2 == 0 && NQ % 2 == 0)
+        hipLaunchKernelGGL((stiffness_pair_kernel<N, NQ>), dim3(grid), dim3(128), (W::LDS_BYTES / 2) * 3, plan->stream, u, Au,
+                           plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
+                           bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);
     } else if (use_pf)
       hipLaunchKernelGGL((stiffness_wave_kernel<N, NQ, true>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au,
                          plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,

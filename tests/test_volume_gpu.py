@@ -61,6 +61,24 @@ def test_stiffness_parity(gpu, hiplib, oracle, level, deg, inc, qt, curved):
     plan.destroy()
 
 
+@pytest.mark.parametrize("deg,inc", [(1, 0), (3, 0), (5, 0), (7, 0), (3, 2), (5, 2), (2, 0), (6, 1)])
+@pytest.mark.parametrize("tune", [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2)])
+def test_stiffness_kernel_variants(gpu, hiplib, oracle, deg, inc, tune):
+    """every tuning variant (3-buffer / prefetch / single-wave / two-wave kernels) gives the oracle's answer"""
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(1, deg, deg_quad_inc=inc, count=7)
+    mp = M.SineMap(0.06)
+    J, rst = m.geometry(mp)
+    u = m.field(mp)
+    ref = oracle.apply_stiffness(m, J, rst, u, nthreads=4)
+    plan = _plan(m, J, rst)
+    plan.set_tuning(0, tune[0]); plan.set_tuning(1, tune[1])
+    du = _t(u, gpu); dAu = torch.full_like(du, float("nan"))
+    plan.apply_stiffness_matrix(du, dAu)
+    assert _rel(dAu.cpu().numpy(), ref) <= RTOL
+
+
 def test_stiffness_mixed_p_parity(gpu, hiplib, oracle):
     """config-4 style: mixed p = 3..9 in one plan (degree-bucketed launches)."""
     import torch
