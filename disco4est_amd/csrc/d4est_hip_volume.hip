@@ -730,6 +730,311 @@ __global__ __launch_bounds__(128, 4) void stiffness_pair_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Single-wavefront kernel with SOFTWARE-PIPELINED operator loads.  Scalar (SMEM) loads return out of
+// order, so the only wait is lgkmcnt(0): if the next operator rows are requested before the current
+// rows are waited for, the wait covers both and the load latency is fully exposed (measured: 43 % of
+// wave cycles in s_waitcnt, profiles/r01_c_*).  Here every step (two operator rows, 2*NO FMAs) first
+// forces the wait for ITS rows (an empty asm that consumes one SGPR of each row), THEN requests the next
+// step's rows, THEN runs its FMAs: the request overlaps 16 FP64 FMAs (64 cycles).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void sgpr_touch(double v) { asm volatile("" ::"s"(v)); }
+// launder a pointer in an asm that also CONSUMES two already-requested scalars: the loads through the returned
+// pointer cannot be issued before the s_waitcnt that makes d0/d1 available.
+__device__ __forceinline__ void launder2_after(const double* pa, const double* pb, double d0, double d1, sdouble_ptr& ra,
+                                               sdouble_ptr& rb) {
+  unsigned long long va = reinterpret_cast<unsigned long long>(pa), vb = reinterpret_cast<unsigned long long>(pb);
+  asm volatile("" : "+s"(va), "+s"(vb) : "s"(d0), "s"(d1));
+  ra = (sdouble_ptr)va;
+  rb = (sdouble_ptr)vb;
+}
+
+// yA (+)= sum_i rowA_i * xA[i], yB (+)= sum_i rowB_i * xB[i]; row_i = NO consecutive doubles at op + i*NO
+// (op = the operator TRANSPOSED for y = op x, or the operator itself for y = op^T x)
+template <int NI, int NO, bool ACCA, bool ACCB>
+__device__ __forceinline__ void contract_pair(const double* __restrict__ opA, const double* xA, double* yA,
+                                              const double* __restrict__ opB, const double* xB, double* yB) {
+  double ca[NO], cb[NO], na[NO], nb[NO];
+  {
+    sdouble_ptr ra = launder(opA), rb = launder(opB);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) { ca[o] = ra[o]; cb[o] = rb[o]; }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    if (i + 1 < NI) {
+      sdouble_ptr ra, rb;
+      launder2_after(opA + (i + 1) * NO, opB + (i + 1) * NO, ca[0], cb[0], ra, rb);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) { na[o] = ra[o]; nb[o] = rb[o]; }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      yA[o] = (i == 0 && !ACCA) ? ca[o] * xA[0] : fma(ca[o], xA[i], yA[o]);
+      yB[o] = (i == 0 && !ACCB) ? cb[o] * xB[0] : fma(cb[o], xB[i], yB[o]);
+    }
+    if (i + 1 < NI) {
+#pragma unroll
+      for (int o = 0; o < NO; ++o) { ca[o] = na[o]; cb[o] = nb[o]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the next step's wait/launder asm behind this step's FMAs
+  }
+}
+
+// y (+)= sum_i row_i * x[i], two rows per step
+template <int NI, int NO, bool ACC>
+__device__ __forceinline__ void contract_single(const double* __restrict__ op, const double* x, double* y) {
+  constexpr int STEPS = (NI + 1) / 2;
+  double c0[NO], c1[NO], n0[NO], n1[NO];
+  {
+    sdouble_ptr r0 = launder(op);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) c0[o] = r0[o];
+    if (NI > 1) {
+      sdouble_ptr r1 = launder(op + NO);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) c1[o] = r1[o];
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int i0 = 2 * st, i1 = 2 * st + 1;
+    if (i0 + 2 < NI) {
+      sdouble_ptr r0, r1;
+      launder2_after(op + (i0 + 2) * NO, op + ((i1 + 2 < NI) ? (i1 + 2) : (i0 + 2)) * NO, c0[0], (i1 < NI) ? c1[0] : c0[0], r0, r1);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) n0[o] = r0[o];
+      if (i1 + 2 < NI) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) n1[o] = r1[o];
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      y[o] = (i0 == 0 && !ACC) ? c0[o] * x[0] : fma(c0[o], x[i0], y[o]);
+      if (i1 < NI) y[o] = fma(c1[o], x[i1], y[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      if (i0 + 2 < NI) c0[o] = n0[o];
+      if (i1 + 2 < NI) c1[o] = n1[o];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int N, int NQ>
+__global__ __launch_bounds__(64, 4) void stiffness_wave2_kernel(
+    const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
+    const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
+    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT) {
+  using C = WaveCfg<N, NQ>;
+  constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
+  constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const int tid = threadIdx.x;
+  const int slot = tid / PL;
+  const int te = tid - slot * PL;
+  const int a = te % NQ, b = te / NQ;
+  const int ei = blockIdx.x * C::EPB + slot;
+  const bool active = (slot < C::EPB) && (ei < n_bucket);
+  double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
+  double* R1 = R0 + FS;
+  int ns = 0, qs = 0;
+  if (active) {
+    ns = ns_list[ei];
+    qs = qs_list[ei];
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      R0[i + PN * (j + N * k)] = u[ns + idx];
+    }
+  }
+  __syncthreads();
+
+  // ---- S1: thread (j=a, k=b)
+  {
+    double x[N], br[NQ], gr[NQ];
+    const bool on = active && a < N && b < N;
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+      contract_pair<N, NQ, false, false>(BopT, x, br, GopT, x, gr);
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        R0[a + PN * (iq + NQ * b)] = br[iq];
+        R1[a + PN * (iq + NQ * b)] = gr[iq];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- S2 (thread (iq=a, k=b)) and S3 (thread (iq=a, jq=b))
+  double gr[NQ], gs[NQ], gt[NQ];
+  {
+    double x1[N], x2[N], t1[NQ], t2[NQ], t3[NQ];
+    const bool on2 = active && b < N;
+    if (on2) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        x1[j] = R0[j + PN * (a + NQ * b)];  // B_r u
+        x2[j] = R1[j + PN * (a + NQ * b)];  // G_r u
+      }
+      contract_pair<N, NQ, false, false>(BopT, x2, t1, GopT, x1, t2);  // B_s G_r u | G_s B_r u
+      contract_single<N, NQ, false>(BopT, x1, t3);                      // B_s B_r u
+    }
+    __syncthreads();
+    if (on2) {
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) {  // [jq][iq][k]
+        R0[b + PN * (a + NQ * jq)] = t1[jq];
+        R1[b + PN * (a + NQ * jq)] = t2[jq];
+      }
+    }
+    __syncthreads();
+    if (active) {
+      double y1[N], y2[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        y1[k] = R0[k + PN * (a + NQ * b)];
+        y2[k] = R1[k + PN * (a + NQ * b)];
+      }
+      contract_pair<N, NQ, false, false>(BopT, y1, gr, BopT, y2, gs);
+    }
+    __syncthreads();
+    if (on2) {
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t3[jq];
+    }
+    __syncthreads();
+    if (active) {
+      double y3[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) y3[k] = R0[k + PN * (a + NQ * b)];
+      contract_single<N, NQ, false>(GopT, y3, gt);
+    }
+  }
+
+  // ---- quadrature-point stage
+  if (active) {
+    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) {
+      const int q = NQ * NQ * kq;
+      const double m0 = m[q], m1 = m[NQ3 + q], m2 = m[2 * NQ3 + q], m3 = m[3 * NQ3 + q], m4 = m[4 * NQ3 + q], m5 = m[5 * NQ3 + q];
+      const double r = gr[kq], s = gs[kq], t = gt[kq];
+      gr[kq] = m0 * r + m1 * s + m2 * t;
+      gs[kq] = m1 * r + m3 * s + m4 * t;
+      gt[kq] = m2 * r + m4 * s + m5 * t;
+    }
+  }
+
+  // ---- S5 (registers) / S6 (thread (iq=a, k=b))
+  {
+    double ca[N], cb[N], cc[N], ar[N], bs[N];
+    const bool on6 = active && b < N;
+    if (active) {
+      contract_pair<NQ, N, false, false>(Bop, gr, ca, Bop, gs, cb);
+      contract_single<NQ, N, false>(Gop, gt, cc);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {  // [k][iq][jq]
+        R0[b + PQ * (a + NQ * k)] = ca[k];
+        R1[b + PQ * (a + NQ * k)] = cb[k];
+      }
+    }
+    __syncthreads();
+    if (on6) {
+      double x[NQ], y[NQ];
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) {
+        x[jq] = R0[jq + PQ * (a + NQ * b)];
+        y[jq] = R1[jq + PQ * (a + NQ * b)];
+      }
+      contract_pair<NQ, N, false, false>(Bop, x, ar, Gop, y, bs);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = cc[k];
+    }
+    __syncthreads();
+    if (on6) {
+      double z[NQ];
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) z[jq] = R0[jq + PQ * (a + NQ * b)];
+      contract_single<NQ, N, true>(Bop, z, bs);
+    }
+    __syncthreads();
+    if (on6) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {  // [k][j][iq]
+        R0[a + PQ * (j + N * b)] = ar[j];
+        R1[a + PQ * (j + N * b)] = bs[j];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- S7: thread (j=a, k=b)
+  {
+    double x[NQ], y[NQ], o[N], o2[N];
+    const bool on = active && a < N && b < N;
+    if (on) {
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        x[iq] = R0[iq + PQ * (a + N * b)];
+        y[iq] = R1[iq + PQ * (a + N * b)];
+      }
+      contract_pair<NQ, N, false, false>(Gop, x, o, Bop, y, o2);
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = o[i] + o2[i];
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      Au[ns + idx] = R0[i + PN * (j + N * k)];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// DIAGNOSTIC (tuning value 9, never selected automatically; results are NOT the stiffness apply):
+// the stiffness kernel's exact memory access pattern with the arithmetic removed -- the streaming floor
+// of "read u, read 6 metric entries per node, write Au" for this thread mapping.
+// ---------------------------------------------------------------------------
+template <int N, int NQ>
+__global__ __launch_bounds__(64, 4) void stiffness_stream_only_kernel(const double* __restrict__ u, double* __restrict__ Au,
+                                                                      const double* __restrict__ metric,
+                                                                      const int* __restrict__ ns_list,
+                                                                      const int* __restrict__ qs_list, int n_bucket) {
+  constexpr int PL = NQ * NQ, EPB = 64 / PL, N3 = N * N * N, NQ3 = NQ * NQ * NQ;
+  const int slot = threadIdx.x / PL, te = threadIdx.x % PL;
+  const int ei = blockIdx.x * EPB + slot;
+  if (slot >= EPB || ei >= n_bucket) return;
+  const int ns = ns_list[ei], qs = qs_list[ei];
+  double acc = 0.0;
+  const double* __restrict__ m = metric + (size_t)6 * qs + te;
+#pragma unroll
+  for (int kq = 0; kq < NQ; ++kq)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc += m[c * NQ3 + PL * kq];
+#pragma unroll
+  for (int idx = te; idx < N3; idx += PL) Au[ns + idx] = u[ns + idx] + acc;
+}
+
+// ---------------------------------------------------------------------------
 // mass-like applies (one field):
 //   MODE 0: out = V^T (W J) V in          (mass)            in: nodal, out: nodal
 //   MODE 1: out = V^T (W J) in_quad       (galerkin)        in: quad,  out: nodal
@@ -1095,7 +1400,14 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
   if constexpr (NQ * NQ <= 64 && NQ >= N) {
     using W = WaveCfg<N, NQ>;
     const int grid = (bk.n_elem + W::EPB - 1) / W::EPB;
-    if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 2 && N % 2 == 0 && NQ % 2 == 0) {
+    if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 3) {
+      hipLaunchKernelGGL((stiffness_wave2_kernel<N, NQ>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
+                         plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT,
+                         bk.d_GT);
+    } else if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 9) {
+      hipLaunchKernelGGL((stiffness_stream_only_kernel<N, NQ>), dim3(grid), dim3(64), 0, plan->stream, u, Au, plan->d_metric,
+                         plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem);
+    } else if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 2 && N % 2 == 0 && NQ % 2 == 0) {
       if constexpr (N % 2 == 0 && NQ % 2 == 0)
         hipLaunchKernelGGL((stiffness_pair_kernel<N, NQ>), dim3(grid), dim3(128), (W::LDS_BYTES / 2) * 3, plan->stream, u, Au,
                            plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
