@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--geometry", choices=["affine", "sine"], default="affine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -206,11 +207,37 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel": "d4est_hip::stiffness_kernel<%d,%d>" % (N, NQ),
+            "kernel": plan.last_kernel(),
             "kernel_avg_ms": kernel_ms,
             "algorithmic_bytes_per_dof": bpd,
         },
     }
+    # ---- secondary, single-GPU only (reported, not the headline): the full operator A u (volume + SIPG faces,
+    # d4est_laplacian_apply_aij) and one Chebyshev smoother iteration (apply + fused update), SURVEY.md section 8d
+    if rank == 0 and world == 1 and not args.no_secondary:
+        try:
+            sides = mesh.build_sides(mp)
+            plan.set_faces(sides, 10.0, 0)
+            rhs = torch.zeros_like(du)
+            r = torch.empty_like(du)
+            sec = {}
+            for name, fn, applies in (("apply_aij", lambda: plan.apply_aij(du, dAu), 1),
+                                      ("cheby_5_iterations", lambda: plan.cheby_iterate(du, rhs, dAu, r, 5, 1.0, 30.0, 0), 5)):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 30
+                e0.record(stream)
+                for _ in range(reps):
+                    fn()
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9}
+            out["secondary"] = sec
+        except Exception as exc:  # secondary numbers must never break the headline line
+            out["secondary"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(mesh, J, rst, u)
     elif rank == 0:

@@ -30,6 +30,7 @@ SIGNATURES = {
     "d4est_hip_plan_destroy": (None, [_vp]),
     "d4est_hip_plan_set_stream": (None, [_vp, _vp]),
     "d4est_hip_plan_set_tuning": (None, [_vp, ctypes.c_int, ctypes.c_int]),
+    "d4est_hip_plan_last_kernel": (ctypes.c_char_p, [_vp]),
     "d4est_hip_plan_local_nodes": (ctypes.c_int, [_vp]),
     "d4est_hip_plan_local_nodes_quad": (ctypes.c_int, [_vp]),
     "d4est_hip_plan_n_elements": (ctypes.c_int, [_vp]),
@@ -137,6 +138,9 @@ class Plan:
         """stream: a torch.cuda.Stream (its raw hipStream_t is passed through) or an int handle."""
         h = getattr(stream, "cuda_stream", stream)
         self.lib.d4est_hip_plan_set_stream(self.handle, ctypes.c_void_p(int(h)))
+
+    def last_kernel(self):
+        return self.lib.d4est_hip_plan_last_kernel(self.handle).decode()
 
     def set_tuning(self, key, value):
         self.lib.d4est_hip_plan_set_tuning(self.handle, int(key), int(value))

@@ -180,6 +180,7 @@ void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value) {
   plan->tuning[key] = value;
 }
 
+const char* d4est_hip_plan_last_kernel(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_last_kernel"); return plan->last_kernel; }
 int d4est_hip_plan_local_nodes(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes"); return plan->local_nodes; }
 int d4est_hip_plan_local_nodes_quad(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes_quad"); return plan->local_nodes_quad; }
 int d4est_hip_plan_n_elements(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_n_elements"); return plan->n_elements; }

@@ -50,6 +50,7 @@ struct d4est_hip_plan {
   int quad_type = 0;
   hipStream_t stream = nullptr;
   int n_cus = 0;  // multiProcessorCount of the device the plan was created on
+  char last_kernel[128] = "";  // name of the stiffness kernel selected by the last apply (largest bucket last)
 
   std::vector<int> deg, deg_quad, nodal_stride, quad_stride;  // host copies
   std::vector<d4est_hip::Bucket> buckets;
@@ -87,7 +88,7 @@ struct d4est_hip_plan {
   d4est_hip_allreduce_fn allreduce_fn = nullptr;
   void* comm_ctx = nullptr;
 
-  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
+  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;

@@ -292,7 +292,14 @@ template <int N, int NQ, bool PF>
 __global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
-    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT) {
+    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT, int stagger) {
+  // Phase stagger for single-round grids: when every resident wave starts at once, all waves load u, then all
+  // contract, then all stream the metric ... and the memory pipe idles during the arithmetic phases.  Delaying every
+  // other resident "row" of workgroups (block id bit 8 = the second batch the dispatcher places on each CU) by about
+  // one forward phase lets one half's metric stream run under the other half's contractions.
+  if (stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+    for (int s_ = 0; s_ < stagger; ++s_) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles per iteration
+  }
   using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
   constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
@@ -826,7 +833,10 @@ template <int N, int NQ>
 __global__ __launch_bounds__(64, 4) void stiffness_wave2_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
-    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT) {
+    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT, int stagger) {
+  if (stagger > 0 && ((blockIdx.x >> 8) & 1)) {  // phase stagger, see stiffness_wave_kernel
+    for (int s_ = 0; s_ < stagger; ++s_) __builtin_amdgcn_s_sleep(16);
+  }
   using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
   constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
@@ -1400,26 +1410,38 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
   if constexpr (NQ * NQ <= 64 && NQ >= N) {
     using W = WaveCfg<N, NQ>;
     const int grid = (bk.n_elem + W::EPB - 1) / W::EPB;
-    if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 3) {
+    const int ts = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER];
+    const int cus_ = plan->n_cus > 0 ? plan->n_cus : 256;
+    // auto: stagger only when the grid is ONE resident round with both workgroup rows populated (measured +3 % at
+    // config 2; multi-round grids de-synchronise by themselves)
+    const int stagger = ts < 0 ? ((grid > 8 * cus_ && grid <= 16 * cus_) ? 8 : 0) : ts;
+    const int tw_ = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
+    if (tw_ == 3 || tw_ < 0) {
+      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave2_kernel<%d,%d>", N, NQ);
       hipLaunchKernelGGL((stiffness_wave2_kernel<N, NQ>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
                          plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT,
-                         bk.d_GT);
+                         bk.d_GT, stagger);
     } else if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 9) {
+      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "DIAGNOSTIC stream-only");
       hipLaunchKernelGGL((stiffness_stream_only_kernel<N, NQ>), dim3(grid), dim3(64), 0, plan->stream, u, Au, plan->d_metric,
                          plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem);
     } else if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 2 && N % 2 == 0 && NQ % 2 == 0) {
+      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_pair_kernel<%d,%d>", N, NQ);
       if constexpr (N % 2 == 0 && NQ % 2 == 0)
         hipLaunchKernelGGL((stiffness_pair_kernel<N, NQ>), dim3(grid), dim3(128), (W::LDS_BYTES / 2) * 3, plan->stream, u, Au,
                            plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
                            bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);
-    } else if (use_pf)
+    } else if (use_pf) {
+      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,true>", N, NQ);
       hipLaunchKernelGGL((stiffness_wave_kernel<N, NQ, true>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au,
                          plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
-                         bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);
-    else
+                         bk.d_B, bk.d_G, bk.d_BT, bk.d_GT, stagger);
+    } else {
+      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,false>", N, NQ);
       hipLaunchKernelGGL((stiffness_wave_kernel<N, NQ, false>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au,
                          plan->d_metric, plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem,
-                         bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);
+                         bk.d_B, bk.d_G, bk.d_BT, bk.d_GT, stagger);
+    }
   }
 }
 
@@ -1444,6 +1466,7 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
         launch_stiffness_wave<N_, (kWave ? NQ_ : N_)>(plan, bk, use_pf, u, Au);                                 \
       } else {                                                                                                  \
         constexpr bool kCanPF = (NQ_ <= 8);                                                                     \
+        std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_kernel<%d,%d,%s>", N_, NQ_, (kCanPF && use_pf) ? "true" : "false"); \
         if (kCanPF && use_pf) {                                        \
           set_lds_limit(stiffness_kernel<N_, NQ_, kCanPF>, C::LDS_BYTES);                                       \
           hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, kCanPF>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,   \
@@ -1461,7 +1484,10 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   }
     D4EST_HIP_FAST_PAIRS(X)
 #undef X
-    if (!done) launch_generic(plan, bk, 3, u, Au);
+    if (!done) {
+      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::generic_volume_kernel (N=%d,NQ=%d)", bk.N, bk.NQ);
+      launch_generic(plan, bk, 3, u, Au);
+    }
   }
   HIP_CHECK(hipGetLastError());
 }

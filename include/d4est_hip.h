@@ -76,10 +76,13 @@ void d4est_hip_plan_set_stream(d4est_hip_plan_t* plan, void* hip_stream);
 /* Performance knobs (never change results beyond fp64 re-association).  Value -1 (default) = auto. */
 enum d4est_hip_tuning_key {
   D4EST_HIP_TUNE_STIFFNESS_PREFETCH = 0, /* 1: request the metric at kernel entry (deg_quad <= 7), 0: at the point of use */
-  D4EST_HIP_TUNE_STIFFNESS_WAVE = 1,     /* where (deg_quad+1)^2 <= 64: 1 single-wavefront two-buffer kernel, 2 persistent software-pipelined kernel */
-  D4EST_HIP_TUNE_COUNT = 2
+  D4EST_HIP_TUNE_STIFFNESS_WAVE = 1,     /* where (deg_quad+1)^2 <= 64: 0 multi-buffer kernel, 1 single-wavefront kernel, 2 two-wavefront kernel with metric prefetch, 3 single-wavefront kernel with pipelined operator loads (auto default) */
+  D4EST_HIP_TUNE_STIFFNESS_STAGGER = 2,  /* single-wave kernel: delay (units of 1024 cycles) of every other resident workgroup row */
+  D4EST_HIP_TUNE_COUNT = 3
 };
 void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value);
+/* name of the stiffness kernel the last d4est_hip_apply_stiffness_matrix selected (for reports / profiles) */
+const char* d4est_hip_plan_last_kernel(const d4est_hip_plan_t* plan);
 int d4est_hip_plan_local_nodes(const d4est_hip_plan_t* plan);
 int d4est_hip_plan_local_nodes_quad(const d4est_hip_plan_t* plan);
 int d4est_hip_plan_n_elements(const d4est_hip_plan_t* plan);

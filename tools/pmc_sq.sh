@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
-ARGS="--steps 30 --warmup 5 --no-cpu-baseline --no-check $@"
+ARGS="--steps 30 --warmup 5 --no-cpu-baseline --no-check --no-secondary $@"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/p1 -- python3 bench.py $ARGS > $OUT/b1.json 2> $OUT/p1.err || { tail -20 $OUT/p1.err; exit 1; }
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVES --output-format csv -d $OUT/p2 -- python3 bench.py $ARGS > $OUT/b2.json 2> $OUT/p2.err || { tail -20 $OUT/p2.err; exit 1; }
 python3 - <<PY
