@@ -264,6 +264,147 @@ __global__ __launch_bounds__(256) void flux_kernel(const double* __restrict__ tr
 }
 
 // ---------------------------------------------------------------------------
+// (2b) fast flux kernel for plans whose sides all have N, Np, NQ <= 8 (p <= 7): one workgroup of six wavefronts per
+// element, wavefront f <-> face f, lane <-> face node.  The 2-D tensor applies keep their results in registers, the
+// four lifted fields (term1+3 and the three term2_l) are scattered into LDS volume fields W_0..W_3 in three
+// conflict-free phases (opposite faces touch disjoint nodes), and one pass applies  W_0 + sum_l D_l^T W_l  and adds
+// it to Au_e.  12 barriers per element instead of ~80 in the generic kernel.
+// ---------------------------------------------------------------------------
+constexpr int kFW = 8;  // max nodes per direction on the fast path
+
+// out_c(a',b') = sum_{a,b} op[a'][a] op[b'][b] in_c(a,b), c < NF; lane = a' + rows*b'; result in registers
+template <int NF>
+__device__ __forceinline__ void wave_apply2d(const double* __restrict__ op, int rows, int cols, const double* in /*[NF][64]*/,
+                                             double* tmp /*[NF][64]*/, int lane, double* out /*[NF]*/) {
+  // pass 1: lane (a', b), a' < rows, b < cols
+  {
+    const int ap = lane % rows, b = lane / rows;
+    if (lane < rows * cols) {
+      double c[kFW];
+#pragma unroll
+      for (int a = 0; a < kFW; ++a) c[a] = (a < cols) ? op[ap * cols + a] : 0.0;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < kFW; ++a)
+          if (a < cols) s = fma(c[a], in[f * 64 + a + cols * b], s);
+        tmp[f * 64 + ap + rows * b] = s;
+      }
+    }
+  }
+  __syncthreads();
+  // pass 2: lane (a', b')
+  {
+    const int ap = lane % rows, bp = lane / rows;
+    if (lane < rows * rows) {
+      double c[kFW];
+#pragma unroll
+      for (int b = 0; b < kFW; ++b) c[b] = (b < cols) ? op[bp * cols + b] : 0.0;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < kFW; ++b)
+          if (b < cols) s = fma(c[b], tmp[f * 64 + ap + rows * b], s);
+        out[f] = s;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict__ trace, const double* __restrict__ ghost_trace,
+                                                        double* __restrict__ Au, const SideDesc* __restrict__ sd,
+                                                        const int* __restrict__ elem_N, const int* __restrict__ elem_ns,
+                                                        const long long* __restrict__ trace_offset,
+                                                        const double* const* __restrict__ elem_D,
+                                                        const double* __restrict__ face_ops, const double* __restrict__ geom,
+                                                        const double* __restrict__ bndry, int n_elem) {
+  __shared__ double s_in[6][4][64];   // per wave: 4 fields on the side's nodes
+  __shared__ double s_tmp[6][4][64];
+  __shared__ double s_W[4][512];      // lifted volume fields: W_0 (terms 1+3), W_1..3 (term 2_l)
+  __shared__ double s_D[64];
+  const int f = threadIdx.x >> 6;     // wave = face
+  const int lane = threadIdx.x & 63;
+  double(*in)[64] = s_in[f];
+  double(*tmp)[64] = s_tmp[f];
+  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+    const int N = elem_N[e], N2 = N * N, N3 = N2 * N;
+    for (int i = threadIdx.x; i < 4 * 512; i += blockDim.x) (&s_W[0][0])[i] = 0.0;
+    if (threadIdx.x < N2) s_D[threadIdx.x] = elem_D[e][threadIdx.x];
+    const SideDesc d = sd[6 * e + f];
+    const int NQ = d.NQ, T = NQ * NQ;
+    const double* Tm = trace + trace_offset[e] + (size_t)f * 4 * N2;
+    // ---- (-) side: 4 fields to the mortar quadrature nodes
+    if (lane < N2) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) in[c][lane] = Tm[c * N2 + lane];
+    }
+    __syncthreads();
+    double qm[4], qp[4] = {0.0, 0.0, 0.0, 0.0};
+    wave_apply2d<4>(face_ops + d.offC_m, NQ, N, &in[0][0], &tmp[0][0], lane, qm);
+    // ---- (+) side (re-ordered to the (-) ordering) or the Dirichlet data
+    if (d.kind != 0) {
+      const int Np = d.Np, Np2 = Np * Np;
+      const double* Tp = ((d.kind == 1) ? trace : ghost_trace) + d.nbr_trace + (size_t)d.f_p * 4 * Np2;
+      if (lane < Np2) {
+        const int src = reorder_index(d.code, Np - 1, lane % Np, lane / Np);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) in[c][lane] = Tp[c * Np2 + src];
+      }
+      __syncthreads();
+      wave_apply2d<4>(face_ops + d.offC_p, NQ, Np, &in[0][0], &tmp[0][0], lane, qp);
+    } else {
+      if (lane < N2) in[0][lane] = bndry[d.bndry + lane];
+      __syncthreads();
+      wave_apply2d<1>(face_ops + d.offC_m, NQ, N, &in[0][0], &tmp[0][0], lane, qp);
+    }
+    // ---- SIPG terms at the quadrature node of this lane
+    if (lane < T) {
+      const double* g = geom + (size_t)7 * d.geom;
+      double t1 = 0.0, am[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        am[i] = g[i * T + lane];
+        t1 += am[i] * qm[1 + i];
+        if (d.kind != 0) t1 += g[(3 + i) * T + lane] * qp[1 + i];
+      }
+      const double jump = qm[0] - qp[0];
+      const double w1 = (d.kind != 0) ? -0.5 : -1.0;
+      in[0][lane] = w1 * t1 + g[6 * T + lane] * jump;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) in[1 + l][lane] = w1 * am[l] * jump;
+    }
+    __syncthreads();
+    // ---- integrate and project onto the (-) side: 4 fields on the N x N face nodes
+    double res[4] = {0.0, 0.0, 0.0, 0.0};
+    wave_apply2d<4>(face_ops + d.offE, N, NQ, &in[0][0], &tmp[0][0], lane, res);
+    // ---- lift: scatter into the volume fields, opposite faces together (disjoint node sets)
+    for (int phase = 0; phase < 3; ++phase) {
+      if ((f >> 1) == phase && lane < N2) {
+        const int v = face_vol_index(f, N, lane % N, lane / N);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_W[c][v] += res[c];
+      }
+      __syncthreads();
+    }
+    // ---- Au_e += W_0 + sum_l D_l^T W_l
+    for (int idx = threadIdx.x; idx < N3; idx += blockDim.x) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / N2;
+      double v = s_W[0][idx];
+      for (int q = 0; q < N; ++q) {
+        v = fma(s_D[q * N + i], s_W[1][q + N * (j + N * k)], v);
+        v = fma(s_D[q * N + j], s_W[2][i + N * (q + N * k)], v);
+        v = fma(s_D[q * N + k], s_W[3][i + N * (j + N * q)], v);
+      }
+      Au[elem_ns[e] + idx] += v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 namespace {
@@ -417,6 +558,7 @@ void faces_setup(d4est_hip_plan* plan) {
       max_fld = std::max(max_fld, std::max(d.NQ * d.NQ, std::max(d.NQ * d.Np, d.NQ * (deg_m + 1))));
     }
   plan->max_face_lds_doubles = 24 * max_fld + maxN * maxN * maxN + maxN * maxN;
+  plan->face_fast = (max_fld <= 64);  // every N, Np, NQ <= 8
   if ((size_t)plan->max_face_lds_doubles * sizeof(double) > 160 * 1024) D4EST_HIP_ABORT("face kernel needs %d LDS doubles", plan->max_face_lds_doubles);
 
   static_assert(sizeof(SideDesc) % sizeof(int) == 0, "SideDesc layout");
@@ -494,6 +636,14 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   if (!plan->has_faces || !plan->has_face_geometry) D4EST_HIP_ABORT("apply flux: plan_set_faces / plan_set_mortar_geometry were not called");
   if (plan->n_elements == 0) return;
   if (plan->n_ghost > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost elements but no ghost trace buffer was given", plan->n_ghost);
+  if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+    const int grid = plan->n_elements < 8192 ? plan->n_elements : 8192;
+    hipLaunchKernelGGL(flux_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
+                       (const SideDesc*)plan->d_side_desc, fh.d_elem_N, fh.d_elem_ns, plan->d_trace_offset, fh.d_elem_D,
+                       plan->d_face_ops, plan->d_face_geom, plan->d_bndry, plan->n_elements);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   const size_t lds = (size_t)plan->max_face_lds_doubles * sizeof(double);
   if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int fld_stride = (plan->max_face_lds_doubles > 0) ? 0 : 0;

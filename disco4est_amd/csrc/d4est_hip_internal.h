@@ -81,6 +81,7 @@ struct d4est_hip_plan {
   double sipg_prefactor = 10.0;
   int sipg_penalty_fcn = 0;
   int max_face_lds_doubles = 0;
+  bool face_fast = false;  // all sides have N, Np, NQ <= 8: flux_wave_kernel applies
 
   // ---- solver workspace / communication hooks (d4est_hip_solver.hip) ----
   double *d_work_p = nullptr, *d_work_d = nullptr, *d_work_r = nullptr, *d_reduce = nullptr, *d_ghost_trace = nullptr;
@@ -88,7 +89,7 @@ struct d4est_hip_plan {
   d4est_hip_allreduce_fn allreduce_fn = nullptr;
   void* comm_ctx = nullptr;
 
-  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
+  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;
