@@ -323,6 +323,7 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
                                                         const double* __restrict__ bndry, int n_elem) {
   __shared__ double s_in[6][4][64];   // per wave: 4 fields on the side's nodes
   __shared__ double s_tmp[6][4][64];
+  __shared__ double s_ops[6][3][64];  // per wave: C_m, C_p, E of its side (one global latency instead of six)
   __shared__ double s_W[4][512];      // lifted volume fields: W_0 (terms 1+3), W_1..3 (term 2_l)
   __shared__ double s_D[64];
   const int f = threadIdx.x >> 6;     // wave = face
@@ -331,55 +332,79 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
   double(*tmp)[64] = s_tmp[f];
   for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
     const int N = elem_N[e], N2 = N * N, N3 = N2 * N;
-    for (int i = threadIdx.x; i < 4 * 512; i += blockDim.x) (&s_W[0][0])[i] = 0.0;
-    if (threadIdx.x < N2) s_D[threadIdx.x] = elem_D[e][threadIdx.x];
     const SideDesc d = sd[6 * e + f];
     const int NQ = d.NQ, T = NQ * NQ;
+    const int Np = d.Np, Np2 = Np * Np;
+    // ---- issue every global load of this side up front (independent requests: one memory latency)
     const double* Tm = trace + trace_offset[e] + (size_t)f * 4 * N2;
-    // ---- (-) side: 4 fields to the mortar quadrature nodes
+    double tm[4] = {0, 0, 0, 0}, tp[4] = {0, 0, 0, 0}, gq[7] = {0, 0, 0, 0, 0, 0, 0};
     if (lane < N2) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) in[c][lane] = Tm[c * N2 + lane];
+      for (int c = 0; c < 4; ++c) tm[c] = Tm[c * N2 + lane];
     }
-    __syncthreads();
-    double qm[4], qp[4] = {0.0, 0.0, 0.0, 0.0};
-    wave_apply2d<4>(face_ops + d.offC_m, NQ, N, &in[0][0], &tmp[0][0], lane, qm);
-    // ---- (+) side (re-ordered to the (-) ordering) or the Dirichlet data
     if (d.kind != 0) {
-      const int Np = d.Np, Np2 = Np * Np;
       const double* Tp = ((d.kind == 1) ? trace : ghost_trace) + d.nbr_trace + (size_t)d.f_p * 4 * Np2;
       if (lane < Np2) {
         const int src = reorder_index(d.code, Np - 1, lane % Np, lane / Np);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) in[c][lane] = Tp[c * Np2 + src];
+        for (int c = 0; c < 4; ++c) tp[c] = Tp[c * Np2 + src];
+      }
+    } else if (lane < N2) {
+      tp[0] = bndry[d.bndry + lane];
+    }
+    if (lane < T) {
+      const double* g = geom + (size_t)7 * d.geom;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) gq[c] = g[c * T + lane];
+    }
+    const double opm = (lane < NQ * N) ? face_ops[d.offC_m + lane] : 0.0;
+    const double opp = (lane < NQ * Np) ? face_ops[d.offC_p + lane] : 0.0;
+    const double ope = (lane < N * NQ) ? face_ops[d.offE + lane] : 0.0;
+    const double dval = (threadIdx.x < N2) ? elem_D[e][threadIdx.x] : 0.0;
+    for (int i = threadIdx.x; i < 4 * 512; i += blockDim.x) (&s_W[0][0])[i] = 0.0;
+    s_ops[f][0][lane] = opm;
+    s_ops[f][1][lane] = opp;
+    s_ops[f][2][lane] = ope;
+    if (threadIdx.x < N2) s_D[threadIdx.x] = dval;
+    if (lane < N2) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) in[c][lane] = tm[c];
+    }
+    __syncthreads();
+    // ---- (-) side: 4 fields to the mortar quadrature nodes
+    double qm[4], qp[4] = {0.0, 0.0, 0.0, 0.0};
+    wave_apply2d<4>(s_ops[f][0], NQ, N, &in[0][0], &tmp[0][0], lane, qm);
+    // ---- (+) side (re-ordered to the (-) ordering) or the Dirichlet data
+    if (d.kind != 0) {
+      if (lane < Np2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) in[c][lane] = tp[c];
       }
       __syncthreads();
-      wave_apply2d<4>(face_ops + d.offC_p, NQ, Np, &in[0][0], &tmp[0][0], lane, qp);
+      wave_apply2d<4>(s_ops[f][1], NQ, Np, &in[0][0], &tmp[0][0], lane, qp);
     } else {
-      if (lane < N2) in[0][lane] = bndry[d.bndry + lane];
+      if (lane < N2) in[0][lane] = tp[0];
       __syncthreads();
-      wave_apply2d<1>(face_ops + d.offC_m, NQ, N, &in[0][0], &tmp[0][0], lane, qp);
+      wave_apply2d<1>(s_ops[f][0], NQ, N, &in[0][0], &tmp[0][0], lane, qp);
     }
     // ---- SIPG terms at the quadrature node of this lane
     if (lane < T) {
-      const double* g = geom + (size_t)7 * d.geom;
-      double t1 = 0.0, am[3];
+      double t1 = 0.0;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        am[i] = g[i * T + lane];
-        t1 += am[i] * qm[1 + i];
-        if (d.kind != 0) t1 += g[(3 + i) * T + lane] * qp[1 + i];
+        t1 += gq[i] * qm[1 + i];
+        if (d.kind != 0) t1 += gq[3 + i] * qp[1 + i];
       }
       const double jump = qm[0] - qp[0];
       const double w1 = (d.kind != 0) ? -0.5 : -1.0;
-      in[0][lane] = w1 * t1 + g[6 * T + lane] * jump;
+      in[0][lane] = w1 * t1 + gq[6] * jump;
 #pragma unroll
-      for (int l = 0; l < 3; ++l) in[1 + l][lane] = w1 * am[l] * jump;
+      for (int l = 0; l < 3; ++l) in[1 + l][lane] = w1 * gq[l] * jump;
     }
     __syncthreads();
     // ---- integrate and project onto the (-) side: 4 fields on the N x N face nodes
     double res[4] = {0.0, 0.0, 0.0, 0.0};
-    wave_apply2d<4>(face_ops + d.offE, N, NQ, &in[0][0], &tmp[0][0], lane, res);
+    wave_apply2d<4>(s_ops[f][2], N, NQ, &in[0][0], &tmp[0][0], lane, res);
     // ---- lift: scatter into the volume fields, opposite faces together (disjoint node sets)
     for (int phase = 0; phase < 3; ++phase) {
       if ((f >> 1) == phase && lane < N2) {
