@@ -272,44 +272,34 @@ __global__ __launch_bounds__(256) void flux_kernel(const double* __restrict__ tr
 // ---------------------------------------------------------------------------
 constexpr int kFW = 8;  // max nodes per direction on the fast path
 
-// out_c(a',b') = sum_{a,b} op[a'][a] op[b'][b] in_c(a,b), c < NF; lane = a' + rows*b'; result in registers
+// All face arrays of the fast path live on a fixed 8 x 8 grid (index a + 8 b) and the operators are stored
+// zero-padded to 8 x 8 in LDS, so the tensor applies are branch-free and fully unrolled for every p <= 7
+// (the padding multiplies zeros).  out_c(a',b') = sum_{a,b} op[a'][a] op[b'][b] in_c(a,b); lane = a' + 8 b'.
 template <int NF>
-__device__ __forceinline__ void wave_apply2d(const double* __restrict__ op, int rows, int cols, const double* in /*[NF][64]*/,
+__device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/, const double* in /*[NF][64]*/,
                                              double* tmp /*[NF][64]*/, int lane, double* out /*[NF]*/) {
-  // pass 1: lane (a', b), a' < rows, b < cols
-  {
-    const int ap = lane % rows, b = lane / rows;
-    if (lane < rows * cols) {
-      double c[kFW];
+  const int lo = lane & 7, hi = lane >> 3;
+  double c[kFW];
+  // pass 1: lane (a' = lo, b = hi): tmp_c(a', b) = sum_a op[a'][a] in_c(a, b)
 #pragma unroll
-      for (int a = 0; a < kFW; ++a) c[a] = (a < cols) ? op[ap * cols + a] : 0.0;
+  for (int a = 0; a < kFW; ++a) c[a] = op[lo * 8 + a];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        double s = 0.0;
+  for (int f = 0; f < NF; ++f) {
+    double s = 0.0;
 #pragma unroll
-        for (int a = 0; a < kFW; ++a)
-          if (a < cols) s = fma(c[a], in[f * 64 + a + cols * b], s);
-        tmp[f * 64 + ap + rows * b] = s;
-      }
-    }
+    for (int a = 0; a < kFW; ++a) s = fma(c[a], in[f * 64 + a + 8 * hi], s);
+    tmp[f * 64 + lane] = s;
   }
   __syncthreads();
-  // pass 2: lane (a', b')
-  {
-    const int ap = lane % rows, bp = lane / rows;
-    if (lane < rows * rows) {
-      double c[kFW];
+  // pass 2: lane (a' = lo, b' = hi): out_c = sum_b op[b'][b] tmp_c(a', b)
 #pragma unroll
-      for (int b = 0; b < kFW; ++b) c[b] = (b < cols) ? op[bp * cols + b] : 0.0;
+  for (int b = 0; b < kFW; ++b) c[b] = op[hi * 8 + b];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        double s = 0.0;
+  for (int f = 0; f < NF; ++f) {
+    double s = 0.0;
 #pragma unroll
-        for (int b = 0; b < kFW; ++b)
-          if (b < cols) s = fma(c[b], tmp[f * 64 + ap + rows * b], s);
-        out[f] = s;
-      }
-    }
+    for (int b = 0; b < kFW; ++b) s = fma(c[b], tmp[f * 64 + lo + 8 * b], s);
+    out[f] = s;
   }
   __syncthreads();
 }
@@ -321,13 +311,14 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
                                                         const double* const* __restrict__ elem_D,
                                                         const double* __restrict__ face_ops, const double* __restrict__ geom,
                                                         const double* __restrict__ bndry, int n_elem) {
-  __shared__ double s_in[6][4][64];   // per wave: 4 fields on the side's nodes
+  __shared__ double s_in[6][4][64];   // per wave: 4 fields on the 8 x 8 grid
   __shared__ double s_tmp[6][4][64];
-  __shared__ double s_ops[6][3][64];  // per wave: C_m, C_p, E of its side (one global latency instead of six)
+  __shared__ double s_ops[6][3][64];  // per wave: C_m, C_p, E of its side, zero-padded to 8 x 8
   __shared__ double s_W[4][512];      // lifted volume fields: W_0 (terms 1+3), W_1..3 (term 2_l)
   __shared__ double s_D[64];
   const int f = threadIdx.x >> 6;     // wave = face
   const int lane = threadIdx.x & 63;
+  const int lo = lane & 7, hi = lane >> 3;
   double(*in)[64] = s_in[f];
   double(*tmp)[64] = s_tmp[f];
   for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
@@ -335,66 +326,55 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
     const SideDesc d = sd[6 * e + f];
     const int NQ = d.NQ, T = NQ * NQ;
     const int Np = d.Np, Np2 = Np * Np;
+    const bool on_m = lo < N && hi < N, on_p = lo < Np && hi < Np, on_q = lo < NQ && hi < NQ;
     // ---- issue every global load of this side up front (independent requests: one memory latency)
     const double* Tm = trace + trace_offset[e] + (size_t)f * 4 * N2;
     double tm[4] = {0, 0, 0, 0}, tp[4] = {0, 0, 0, 0}, gq[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (lane < N2) {
+    if (on_m) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) tm[c] = Tm[c * N2 + lane];
+      for (int c = 0; c < 4; ++c) tm[c] = Tm[c * N2 + lo + N * hi];
     }
     if (d.kind != 0) {
       const double* Tp = ((d.kind == 1) ? trace : ghost_trace) + d.nbr_trace + (size_t)d.f_p * 4 * Np2;
-      if (lane < Np2) {
-        const int src = reorder_index(d.code, Np - 1, lane % Np, lane / Np);
+      if (on_p) {
+        const int src = reorder_index(d.code, Np - 1, lo, hi);
 #pragma unroll
         for (int c = 0; c < 4; ++c) tp[c] = Tp[c * Np2 + src];
       }
-    } else if (lane < N2) {
-      tp[0] = bndry[d.bndry + lane];
+    } else if (on_m) {
+      tp[0] = bndry[d.bndry + lo + N * hi];
     }
-    if (lane < T) {
+    if (on_q) {
       const double* g = geom + (size_t)7 * d.geom;
 #pragma unroll
-      for (int c = 0; c < 7; ++c) gq[c] = g[c * T + lane];
+      for (int c = 0; c < 7; ++c) gq[c] = g[c * T + lo + NQ * hi];
     }
-    const double opm = (lane < NQ * N) ? face_ops[d.offC_m + lane] : 0.0;
-    const double opp = (lane < NQ * Np) ? face_ops[d.offC_p + lane] : 0.0;
-    const double ope = (lane < N * NQ) ? face_ops[d.offE + lane] : 0.0;
+    // operators: entry (row hi, col lo) of the padded 8 x 8 images
+    const double opm = (hi < NQ && lo < N) ? face_ops[d.offC_m + hi * N + lo] : 0.0;
+    const double opp = (hi < NQ && lo < Np) ? face_ops[d.offC_p + hi * Np + lo] : 0.0;
+    const double ope = (hi < N && lo < NQ) ? face_ops[d.offE + hi * NQ + lo] : 0.0;
     const double dval = (threadIdx.x < N2) ? elem_D[e][threadIdx.x] : 0.0;
     for (int i = threadIdx.x; i < 4 * 512; i += blockDim.x) (&s_W[0][0])[i] = 0.0;
     s_ops[f][0][lane] = opm;
     s_ops[f][1][lane] = opp;
     s_ops[f][2][lane] = ope;
     if (threadIdx.x < N2) s_D[threadIdx.x] = dval;
-    if (lane < N2) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) in[c][lane] = tm[c];
-    }
+    for (int c = 0; c < 4; ++c) in[c][lane] = tm[c];
     __syncthreads();
     // ---- (-) side: 4 fields to the mortar quadrature nodes
-    double qm[4], qp[4] = {0.0, 0.0, 0.0, 0.0};
-    wave_apply2d<4>(s_ops[f][0], NQ, N, &in[0][0], &tmp[0][0], lane, qm);
-    // ---- (+) side (re-ordered to the (-) ordering) or the Dirichlet data
-    if (d.kind != 0) {
-      if (lane < Np2) {
+    double qm[4], qp[4];
+    wave_apply2d<4>(s_ops[f][0], &in[0][0], &tmp[0][0], lane, qm);
+    // ---- (+) side (re-ordered to the (-) ordering) or the Dirichlet data (field 0 only; the others are zero)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) in[c][lane] = tp[c];
-      }
-      __syncthreads();
-      wave_apply2d<4>(s_ops[f][1], NQ, Np, &in[0][0], &tmp[0][0], lane, qp);
-    } else {
-      if (lane < N2) in[0][lane] = tp[0];
-      __syncthreads();
-      wave_apply2d<1>(s_ops[f][0], NQ, N, &in[0][0], &tmp[0][0], lane, qp);
-    }
-    // ---- SIPG terms at the quadrature node of this lane
-    if (lane < T) {
+    for (int c = 0; c < 4; ++c) in[c][lane] = tp[c];
+    __syncthreads();
+    wave_apply2d<4>(s_ops[f][(d.kind != 0) ? 1 : 0], &in[0][0], &tmp[0][0], lane, qp);
+    // ---- SIPG terms at the quadrature node of this lane (padding lanes carry zeros)
+    {
       double t1 = 0.0;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        t1 += gq[i] * qm[1 + i];
-        if (d.kind != 0) t1 += gq[3 + i] * qp[1 + i];
-      }
+      for (int i = 0; i < 3; ++i) t1 += gq[i] * qm[1 + i] + gq[3 + i] * qp[1 + i];  // gq[3..5] = 0 on boundary sides
       const double jump = qm[0] - qp[0];
       const double w1 = (d.kind != 0) ? -0.5 : -1.0;
       in[0][lane] = w1 * t1 + gq[6] * jump;
@@ -403,12 +383,12 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
     }
     __syncthreads();
     // ---- integrate and project onto the (-) side: 4 fields on the N x N face nodes
-    double res[4] = {0.0, 0.0, 0.0, 0.0};
-    wave_apply2d<4>(s_ops[f][2], N, NQ, &in[0][0], &tmp[0][0], lane, res);
+    double res[4];
+    wave_apply2d<4>(s_ops[f][2], &in[0][0], &tmp[0][0], lane, res);
     // ---- lift: scatter into the volume fields, opposite faces together (disjoint node sets)
     for (int phase = 0; phase < 3; ++phase) {
-      if ((f >> 1) == phase && lane < N2) {
-        const int v = face_vol_index(f, N, lane % N, lane / N);
+      if ((f >> 1) == phase && on_m) {
+        const int v = face_vol_index(f, N, lo, hi);
 #pragma unroll
         for (int c = 0; c < 4; ++c) s_W[c][v] += res[c];
       }
