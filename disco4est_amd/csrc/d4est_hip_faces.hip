@@ -37,6 +37,14 @@ struct SideDesc {
   long long nbr_trace;  // offset of the (+) element's trace block (local or ghost buffer)
 };
 
+struct ElemDesc {
+  int N;                // nodes per direction
+  int ns;               // nodal stride
+  long long trace_off;  // offset of the element's trace block
+  int offD;             // offset of the (N x N) derivative matrix inside face_ops
+  int pad;
+};
+
 __host__ __device__ inline int face_fix(int f, int N) { return (f & 1) ? (N - 1) : 0; }
 
 // volume index of face node (a,b) of face f (a fastest; tangential axes in increasing order)
@@ -306,9 +314,7 @@ __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/,
 
 __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict__ trace, const double* __restrict__ ghost_trace,
                                                         double* __restrict__ Au, const SideDesc* __restrict__ sd,
-                                                        const int* __restrict__ elem_N, const int* __restrict__ elem_ns,
-                                                        const long long* __restrict__ trace_offset,
-                                                        const double* const* __restrict__ elem_D,
+                                                        const ElemDesc* __restrict__ ed,
                                                         const double* __restrict__ face_ops, const double* __restrict__ geom,
                                                         const double* __restrict__ bndry, int n_elem) {
   __shared__ double s_in[6][4][64];   // per wave: 4 fields on the 8 x 8 grid
@@ -321,14 +327,26 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
   const int lo = lane & 7, hi = lane >> 3;
   double(*in)[64] = s_in[f];
   double(*tmp)[64] = s_tmp[f];
-  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
-    const int N = elem_N[e], N2 = N * N, N3 = N2 * N;
-    const SideDesc d = sd[6 * e + f];
+  // persistent workgroups: the descriptors of the NEXT element are requested while this one is computed
+  int e = blockIdx.x;
+  ElemDesc edn = ed[e < n_elem ? e : 0];
+  SideDesc dn = sd[6 * (e < n_elem ? e : 0) + f];
+  for (; e < n_elem; e += gridDim.x) {
+    const ElemDesc el = edn;
+    const SideDesc d = dn;
+    {
+      const int en = e + gridDim.x;
+      if (en < n_elem) {
+        edn = ed[en];
+        dn = sd[6 * en + f];
+      }
+    }
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
     const int NQ = d.NQ, T = NQ * NQ;
     const int Np = d.Np, Np2 = Np * Np;
     const bool on_m = lo < N && hi < N, on_p = lo < Np && hi < Np, on_q = lo < NQ && hi < NQ;
     // ---- issue every global load of this side up front (independent requests: one memory latency)
-    const double* Tm = trace + trace_offset[e] + (size_t)f * 4 * N2;
+    const double* Tm = trace + el.trace_off + (size_t)f * 4 * N2;
     double tm[4] = {0, 0, 0, 0}, tp[4] = {0, 0, 0, 0}, gq[7] = {0, 0, 0, 0, 0, 0, 0};
     if (on_m) {
 #pragma unroll
@@ -353,7 +371,11 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
     const double opm = (hi < NQ && lo < N) ? face_ops[d.offC_m + hi * N + lo] : 0.0;
     const double opp = (hi < NQ && lo < Np) ? face_ops[d.offC_p + hi * Np + lo] : 0.0;
     const double ope = (hi < N && lo < NQ) ? face_ops[d.offE + hi * NQ + lo] : 0.0;
-    const double dval = (threadIdx.x < N2) ? elem_D[e][threadIdx.x] : 0.0;
+    const double dval = (threadIdx.x < N2) ? face_ops[el.offD + threadIdx.x] : 0.0;
+    // Au_e is read now (2 values per thread) so that the final update only stores
+    double au0 = 0.0, au1 = 0.0;
+    if ((int)threadIdx.x < N3) au0 = Au[el.ns + threadIdx.x];
+    if ((int)threadIdx.x + 384 < N3) au1 = Au[el.ns + threadIdx.x + 384];
     for (int i = threadIdx.x; i < 4 * 512; i += blockDim.x) (&s_W[0][0])[i] = 0.0;
     s_ops[f][0][lane] = opm;
     s_ops[f][1][lane] = opp;
@@ -395,15 +417,19 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
       __syncthreads();
     }
     // ---- Au_e += W_0 + sum_l D_l^T W_l
-    for (int idx = threadIdx.x; idx < N3; idx += blockDim.x) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / N2;
-      double v = s_W[0][idx];
-      for (int q = 0; q < N; ++q) {
-        v = fma(s_D[q * N + i], s_W[1][q + N * (j + N * k)], v);
-        v = fma(s_D[q * N + j], s_W[2][i + N * (q + N * k)], v);
-        v = fma(s_D[q * N + k], s_W[3][i + N * (j + N * q)], v);
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int idx = threadIdx.x + rep * 384;
+      if (idx < N3) {
+        const int i = idx % N, j = (idx / N) % N, k = idx / N2;
+        double v = s_W[0][idx];
+        for (int q = 0; q < N; ++q) {
+          v = fma(s_D[q * N + i], s_W[1][q + N * (j + N * k)], v);
+          v = fma(s_D[q * N + j], s_W[2][i + N * (q + N * k)], v);
+          v = fma(s_D[q * N + k], s_W[3][i + N * (j + N * q)], v);
+        }
+        Au[el.ns + idx] = (rep == 0 ? au0 : au1) + v;
       }
-      Au[elem_ns[e] + idx] += v;
     }
     __syncthreads();
   }
@@ -520,6 +546,26 @@ void faces_setup(d4est_hip_plan* plan) {
     return off;
   };
 
+  // derivative matrices inside the face-operator buffer (one load level less than a pointer table)
+  std::map<int, int> offD_of;
+  for (int e = 0; e < ne; ++e) {
+    const int deg = plan->deg[e];
+    if (!offD_of.count(deg)) {
+      std::vector<double> D = Tables1D::dij(deg);
+      offD_of[deg] = (int)ops.size();
+      ops.insert(ops.end(), D.begin(), D.end());
+    }
+  }
+  std::vector<ElemDesc> edv(ne);
+  for (int e = 0; e < ne; ++e) {
+    edv[e].N = plan->deg[e] + 1;
+    edv[e].ns = plan->nodal_stride[e];
+    edv[e].trace_off = plan->trace_offset[e];
+    edv[e].offD = offD_of[plan->deg[e]];
+    edv[e].pad = 0;
+  }
+  HIP_CHECK(hipMalloc(&plan->d_elem_desc, std::max<size_t>(edv.size(), 1) * sizeof(ElemDesc)));
+  if (!edv.empty()) HIP_CHECK(hipMemcpy(plan->d_elem_desc, edv.data(), edv.size() * sizeof(ElemDesc), hipMemcpyHostToDevice));
   std::vector<SideDesc> sd(6 * (size_t)ne);
   fh.side_deg_m.assign(6 * (size_t)ne, 0);
   fh.side_deg_p.assign(6 * (size_t)ne, 0);
@@ -642,10 +688,14 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   if (plan->n_elements == 0) return;
   if (plan->n_ghost > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost elements but no ghost trace buffer was given", plan->n_ghost);
   if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
-    const int grid = plan->n_elements < 8192 ? plan->n_elements : 8192;
+    // persistent grid: 3 workgroups per CU are resident (LDS), each loops over elements
+    const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
+    const int resident = 3 * cus;
+    const int rounds = (plan->n_elements + resident - 1) / resident;
+    const int grid = (plan->n_elements + rounds - 1) / rounds;
     hipLaunchKernelGGL(flux_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
-                       (const SideDesc*)plan->d_side_desc, fh.d_elem_N, fh.d_elem_ns, plan->d_trace_offset, fh.d_elem_D,
-                       plan->d_face_ops, plan->d_face_geom, plan->d_bndry, plan->n_elements);
+                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops,
+                       plan->d_face_geom, plan->d_bndry, plan->n_elements);
     HIP_CHECK(hipGetLastError());
     return;
   }
@@ -675,6 +725,7 @@ void faces_destroy(d4est_hip_plan* plan) {
     for (auto& kv : fh.d_Dmat) (void)hipFree(kv.second);
     g_face_host.erase(it);
   }
+  (void)hipFree(plan->d_elem_desc);
   (void)hipFree(plan->d_side_desc); (void)hipFree(plan->d_trace_offset); (void)hipFree(plan->d_face_ops);
   (void)hipFree(plan->d_face_geom); (void)hipFree(plan->d_bndry); (void)hipFree(plan->d_trace);
 }

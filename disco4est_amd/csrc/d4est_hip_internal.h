@@ -72,6 +72,7 @@ struct d4est_hip_plan {
   int total_mortar_nodes = 0, total_bndry_nodes = 0;
   long long local_trace_doubles = 0, ghost_trace_doubles = 0;
   int* d_side_desc = nullptr;        // SideDesc per side (see d4est_hip_faces.hip)
+  void* d_elem_desc = nullptr;       // ElemDesc per element
   long long* d_trace_offset = nullptr;  // per local element: offset of its 6x4xN^2 trace block
   std::vector<long long> trace_offset, ghost_trace_offset;
   double* d_face_ops = nullptr;      // concatenated 1-D face operators (C and E matrices)
