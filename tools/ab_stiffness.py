@@ -40,10 +40,10 @@ for rnd in range(12):
         e1.record()
         torch.cuda.synchronize()
         res[v].append(e0.elapsed_time(e1) / steps * 1e3)
-        if ref is None and "1=9" not in v:
+        if ref is None and not any(t in v for t in ("1=9", "1=7", "1=8")):
             ref = out.clone()
         else:
-            assert "1=9" in v or (out - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+            assert any(t in v for t in ("1=9", "1=7", "1=8")) or (out - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
 for v in vals:
     t = sorted(res[v])
     med, mn = t[len(t) // 2], t[0]
