@@ -58,15 +58,16 @@ __device__ __forceinline__ sdouble_ptr launder(const double* p) {
 // FP64 FMA latency: measured 39 % issue-stall cycles with the o-outer form, profiles/r01_c_*).
 template <int NI, int NO>
 __device__ __forceinline__ void contract_n(const double* __restrict__ opT, const double* x, double* y) {
+  // outputs in chunks of <= 8: one scalar row chunk is <= 16 SGPRs (longer rows spill SGPRs through v_readlane)
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    sdouble_ptr row = launder(opT + i * NO);
-    if (i == 0) {
+  for (int o0 = 0; o0 < NO; o0 += 8) {
 #pragma unroll
-      for (int o = 0; o < NO; ++o) y[o] = row[o] * x[0];
-    } else {
+    for (int i = 0; i < NI; ++i) {
+      sdouble_ptr row = launder(opT + i * NO + o0);
 #pragma unroll
-      for (int o = 0; o < NO; ++o) y[o] = fma(row[o], x[i], y[o]);
+      for (int o = 0; o < 8; ++o) {
+        if (o0 + o < NO) y[o0 + o] = (i == 0) ? row[o] * x[0] : fma(row[o], x[i], y[o0 + o]);
+      }
     }
   }
 }
@@ -75,15 +76,16 @@ __device__ __forceinline__ void contract_n(const double* __restrict__ opT, const
 // row op[i][0..NO) is consumed by NO independent FMA chains.
 template <int NI, int NO, bool ACC>
 __device__ __forceinline__ void contract_t(const double* __restrict__ op, const double* x, double* y) {
-  if (!ACC) {
 #pragma unroll
-    for (int o = 0; o < NO; ++o) y[o] = 0.0;
-  }
+  for (int o0 = 0; o0 < NO; o0 += 8) {
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    sdouble_ptr row = launder(op + i * NO);
+    for (int i = 0; i < NI; ++i) {
+      sdouble_ptr row = launder(op + i * NO + o0);
 #pragma unroll
-    for (int o = 0; o < NO; ++o) y[o] = fma(row[o], x[i], y[o]);
+      for (int o = 0; o < 8; ++o) {
+        if (o0 + o < NO) y[o0 + o] = (i == 0 && !ACC) ? row[o] * x[0] : fma(row[o], x[i], y[o0 + o]);
+      }
+    }
   }
 }
 
@@ -280,8 +282,8 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 template <int N, int NQ>
 struct WaveCfg {
   static constexpr int PL = NQ * NQ;
-  static_assert(PL <= 64, "single-wave kernel needs NQ*NQ <= 64");
-  static constexpr int EPB = 64 / PL;
+  static constexpr int EPB = (PL <= 64) ? 64 / PL : 1;
+  static constexpr int THREADS = (PL <= 64) ? 64 : ((PL + 63) / 64) * 64;  // > 64: one element per multi-wave workgroup
   static constexpr int PN = N | 1, PQ = NQ | 1;
   static constexpr int FS = NQ * NQ * PQ;
   static constexpr int LDS_PER_ELEM = 2 * FS;
@@ -289,7 +291,7 @@ struct WaveCfg {
 };
 
 template <int N, int NQ, bool PF>
-__global__ __launch_bounds__(64, (PF ? 3 : 4)) void stiffness_wave_kernel(
+__global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS == 64 ? (PF ? 3 : 4) : 1)) void stiffness_wave_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
     const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT, int stagger) {
@@ -1678,6 +1680,14 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
       constexpr bool kWave = (NQ_ * NQ_ <= 64);                                                                 \
       if (kWave && use_wave) {                                               \
         launch_stiffness_wave<N_, (kWave ? NQ_ : N_)>(plan, bk, use_pf, u, Au);                                 \
+      } else if (!kWave && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] != 0) {                                  \
+        /* p >= 8: multi-wave workgroup, two LDS fields (sequential field hand-off) -> 1.5x the residency */  \
+        using W = WaveCfg<N_, NQ_>;                                                                             \
+        std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,false> (%d threads)", N_, NQ_, W::THREADS); \
+        set_lds_limit(stiffness_wave_kernel<N_, NQ_, false>, W::LDS_BYTES);                                     \
+        hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
+                           plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,               \
+                           plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, bk.d_GT, 0);   \
       } else {                                                                                                  \
         constexpr bool kCanPF = (NQ_ <= 8);                                                                     \
         std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_kernel<%d,%d,%s>", N_, NQ_, (kCanPF && use_pf) ? "true" : "false"); \

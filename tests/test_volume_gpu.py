@@ -79,6 +79,23 @@ def test_stiffness_kernel_variants(gpu, hiplib, oracle, deg, inc, tune):
     assert _rel(dAu.cpu().numpy(), ref) <= RTOL
 
 
+@pytest.mark.parametrize("deg,inc", [(8, 0), (9, 0), (11, 0), (15, 0), (8, 1)])
+@pytest.mark.parametrize("bigp", [0, 1])
+def test_stiffness_high_p_variants(gpu, hiplib, oracle, deg, inc, bigp):
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(1, deg, deg_quad_inc=inc, count=3)
+    mp = M.SineMap(0.06)
+    J, rst = m.geometry(mp)
+    u = m.field(mp)
+    ref = oracle.apply_stiffness(m, J, rst, u, nthreads=4)
+    plan = _plan(m, J, rst)
+    plan.set_tuning(4, bigp)
+    du = _t(u, gpu); dAu = torch.full_like(du, float("nan"))
+    plan.apply_stiffness_matrix(du, dAu)
+    assert _rel(dAu.cpu().numpy(), ref) <= RTOL
+
+
 def test_stiffness_mixed_p_parity(gpu, hiplib, oracle):
     """config-4 style: mixed p = 3..9 in one plan (degree-bucketed launches)."""
     import torch
