@@ -59,6 +59,7 @@ SIGNATURES = {
     "d4est_hip_copy_blocks": (None, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "d4est_hip_plan_trace_offset": (ctypes.c_longlong, [_vp, ctypes.c_int]),
     "d4est_hip_plan_ghost_trace_offset": (ctypes.c_longlong, [_vp, ctypes.c_int]),
+    "d4est_hip_plan_trace_block_len": (ctypes.c_int, [_vp, ctypes.c_int]),
     "d4est_hip_vec_dot": (None, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "d4est_hip_apply_stiffness_matrix_host": (None, [_vp, _vp, _vp]),
 }

@@ -276,11 +276,7 @@ void d4est_hip_plan_set_mortar_geometry(d4est_hip_plan_t* plan, const double* sj
 void d4est_hip_plan_set_dirichlet_values(d4est_hip_plan_t* plan, const double* g_lobatto, int on_device) {
   check_plan(plan, "plan_set_dirichlet_values");
   if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_dirichlet_values: call plan_set_faces first");
-  const size_t bytes = (size_t)plan->total_bndry_nodes * sizeof(double);
-  if (bytes == 0) return;
-  if (!g_lobatto) HIP_CHECK(hipMemsetAsync(plan->d_bndry, 0, bytes, plan->stream));
-  else HIP_CHECK(hipMemcpyAsync(plan->d_bndry, g_lobatto, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, plan->stream));
-  if (!on_device) HIP_CHECK(hipStreamSynchronize(plan->stream));
+  d4est_hip::faces_set_dirichlet(plan, g_lobatto, on_device);
 }
 
 long long d4est_hip_plan_trace_size(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_trace_size"); return plan->local_trace_doubles; }
@@ -347,16 +343,23 @@ void d4est_hip_copy_blocks(d4est_hip_plan_t* plan, int n_blocks, const double* s
   d4est_hip::launch_copy_blocks(plan->stream, n_blocks, src_dev, src_off_dev, dst_dev, dst_off_dev, len_dev);
 }
 
-long long d4est_hip_plan_trace_offset(const d4est_hip_plan_t* plan, int element) {
+long long d4est_hip_plan_trace_offset(const d4est_hip_plan_t* plan, int side) {
   check_plan(plan, "plan_trace_offset");
-  if (!plan->has_faces || element < 0 || element >= plan->n_elements) D4EST_HIP_ABORT("plan_trace_offset: element %d", element);
-  return plan->trace_offset[element];
+  if (!plan->has_faces || side < 0 || side >= 6 * plan->n_elements) D4EST_HIP_ABORT("plan_trace_offset: side %d", side);
+  return plan->trace_offset[side];
 }
 
-long long d4est_hip_plan_ghost_trace_offset(const d4est_hip_plan_t* plan, int ghost) {
+long long d4est_hip_plan_ghost_trace_offset(const d4est_hip_plan_t* plan, int side) {
   check_plan(plan, "plan_ghost_trace_offset");
-  if (!plan->has_faces || ghost < 0 || ghost >= plan->n_ghost) D4EST_HIP_ABORT("plan_ghost_trace_offset: ghost %d", ghost);
-  return plan->ghost_trace_offset[ghost];
+  if (!plan->has_faces || side < 0 || side >= 6 * plan->n_elements) D4EST_HIP_ABORT("plan_ghost_trace_offset: side %d", side);
+  return plan->ghost_trace_offset[side];
+}
+
+int d4est_hip_plan_trace_block_len(const d4est_hip_plan_t* plan, int side) {
+  check_plan(plan, "plan_trace_block_len");
+  if (!plan->has_faces || side < 0 || side >= 6 * plan->n_elements) D4EST_HIP_ABORT("plan_trace_block_len: side %d", side);
+  const long long next = (side + 1 < 6 * plan->n_elements) ? plan->trace_offset[side + 1] : plan->local_trace_doubles;
+  return (int)(next - plan->trace_offset[side]);
 }
 
 void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const double* y_dev, double* result_dev) {

@@ -1,18 +1,21 @@
 // Face (mortar) part of the weak Laplacian: SIPG flux on conforming mortars and Dirichlet boundaries.
 //
 // Replaces, for all local (element, face) sides at once,
-//   d4est_laplacian_compute_dudr              (src/dGMath/d4est_laplacian.c:237-282)  -> only the face TRACES are formed
+//   d4est_laplacian_compute_dudr              (src/dGMath/d4est_laplacian.c:237-282)  -> only face TRACES are formed
 //   d4est_laplacian_flux_interface/_boundary  (src/dGMath/d4est_laplacian_flux.c:232-1014, :23-230)
 //   d4est_laplacian_flux_sipg_interface/_dirichlet (src/dGMath/d4est_laplacian_flux_sipg.c:494-942, :15-336)
 //   d4est_mortars_compute_flux_on_local_elements   (src/Mesh/d4est_mortars.c:601-840; the serial p4est_iterate walk)
 //
 // Design: element-centric and two-phase.
-//  (1) trace kernel: every element writes the traces of u and of du/dr_{0,1,2} on its six faces
-//      (4 N^2 doubles per face) -- the only data a neighbour (or another GPU) ever needs, instead of the
-//      reference's three full dudr vectors and whole-element ghost copies.
-//  (2) flux kernel: one workgroup per element walks its six sides, reads its own and the neighbour's trace,
-//      evaluates the three SIPG terms at the mortar quadrature nodes, integrates, projects back, lifts and
-//      applies D^T into an LDS accumulator, and adds it to Au_e once: race-free and deterministic, no atomics.
+//  (1) trace kernel: every element writes, for each of its six sides, the traces of u and of du/dr_{0,1,2}
+//      ALREADY INTERPOLATED to the side's mortar quadrature nodes (4 T doubles per side, T = (deg_mortar_quad+1)^2).
+//      The reference interpolates every side twice per apply -- once as the (-) side of its own flux call and once as
+//      the (+) side of the neighbour's -- here it happens once, and the mortar-node trace is also the only thing a
+//      neighbouring GPU needs (instead of the reference's whole ghost elements).
+//  (2) flux kernel: one workgroup per element walks its six sides, reads its own and the neighbour's mortar-node
+//      traces (the neighbour's re-ordered by the p4est flip/transpose code), evaluates the three SIPG terms,
+//      integrates and projects back (one tensor apply), scatters the four lifted fields into LDS volume fields and
+//      applies  W_0 + sum_l D_l^T W_l  into Au_e once: race-free and deterministic, no atomics.
 // The reference's 24 doubles of mortar geometry per quadrature node are pre-combined at set-up into 7:
 //   am_i = sum_d sj n_d (dr_i/dx_d)^-,  ap_i = sum_d sj n_d (dr_i/dx_d)^+ (re-ordered to the (-) side),  s3 = sj sigma.
 #include <algorithm>
@@ -26,23 +29,31 @@ namespace d4est_hip {
 
 struct SideDesc {
   int kind;           // 0 boundary, 1 interface with local (+), 2 interface with ghost (+)
-  int f_p;            // face of the (+) element
   int code;           // flip0 | flip1<<1 | transpose<<2   (dGMath/d4est_operators.c:2031-2081)
-  int Np;             // nodes/dir of the (+) element
   int NQ;             // mortar quadrature nodes/dir
-  int offC_m, offC_p; // offsets into face_ops: (NQ x N) and (NQ x Np) side -> mortar-quadrature operators
-  int offE;           // (N x NQ) mortar-quadrature -> side operator (P^T I^T W)
-  int geom;           // scalar stride S of the side (face_geom at 7*S)
-  int bndry;          // offset of Dirichlet values (boundary sides)
-  long long nbr_trace;  // offset of the (+) element's trace block (local or ghost buffer)
+  int offC;           // (NQ x N)  side nodes -> mortar quadrature nodes (p-prolong then Lobatto->quadrature)
+  int offE;           // (N x NQ)  mortar quadrature -> side operator (P^T I^T W)
+  int geom;           // scalar stride S of the side (face_geom at 7*S; Dirichlet data at S)
+  long long qoff;     // offset of this side's mortar-node trace block (4 T doubles) in the local buffer
+  long long nbr_qoff; // offset of the (+) side's block (local buffer for kind 1, ghost buffer for kind 2)
 };
 
 struct ElemDesc {
-  int N;                // nodes per direction
-  int ns;               // nodal stride
-  long long trace_off;  // offset of the element's trace block
-  int offD;             // offset of the (N x N) derivative matrix inside face_ops
+  int N;     // nodes per direction
+  int ns;    // nodal stride
+  int offD;  // offset of the zero-padded 8 x 8 (fast path) or N x N (generic) derivative matrix inside face_ops
   int pad;
+};
+
+struct GhostSideDesc {
+  int N;       // nodes/dir of the ghost element
+  int f;       // its face
+  int NQ;
+  int offC;    // (NQ x N)
+  int offD;    // N x N
+  int pad;
+  long long u_off;  // offset of the ghost element in the packed ghost vector
+  long long goff;   // offset of the block in the ghost trace buffer
 };
 
 __host__ __device__ inline int face_fix(int f, int N) { return (f & 1) ? (N - 1) : 0; }
@@ -55,40 +66,132 @@ __device__ inline int face_vol_index(int f, int N, int a, int b) {
   return a + N * (b + N * fix);
 }
 
+__device__ inline int reorder_index(int code, int deg, int a, int b) {
+  // out(a,b) = in(a2,b2) for out = transpose?(flip1?(flip0?(in)))  (dGMath/d4est_operators.c:2044-2081)
+  int a1 = (code & 4) ? b : a, b1 = (code & 4) ? a : b;
+  if (code & 2) b1 = deg - b1;
+  if (code & 1) a1 = deg - a1;
+  return a1 + (deg + 1) * b1;
+}
+
+// value c (0: u, 1..3: du/dr_{c-1}) at face node (a,b) of face f from the element values ue (N^3, x fastest)
+__device__ inline double nodal_trace(const double* ue, const double* D /* row-major, leading dim ldD */, int ldD, int N, int f,
+                                     int a, int b, int c) {
+  const int v = face_vol_index(f, N, a, b);
+  if (c == 0) return ue[v];
+  const int d = c - 1;
+  const int stride = (d == 0) ? 1 : (d == 1 ? N : N * N);
+  const int pos = (v / stride) % N;
+  const int base = v - pos * stride;
+  double val = 0.0;
+  for (int i = 0; i < N; ++i) val = fma(D[pos * ldD + i], ue[base + i * stride], val);
+  return val;
+}
+
 // ---------------------------------------------------------------------------
-// (1) traces: T[e][f][c][a + N b], c = 0: u, c = 1..3: du/dr_{c-1}
+// generic tensor apply (runtime sizes, whole workgroup): out (rows x rows) = (op (x) op) in (cols x cols)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trace_kernel(const double* __restrict__ u, double* __restrict__ trace,
-                                                    const int* __restrict__ elem_N, const int* __restrict__ elem_ns,
-                                                    const long long* __restrict__ trace_offset,
-                                                    const double* const* __restrict__ elem_D, int n_elem) {
+__device__ inline void apply2d(const double* __restrict__ op, int rows, int cols, const double* in, double* tmp, double* out,
+                               int nfields, int in_stride, int out_stride, int tmp_stride) {
+  for (int idx = threadIdx.x; idx < nfields * rows * cols; idx += blockDim.x) {
+    const int fld = idx / (rows * cols), r = idx % (rows * cols), ap = r % rows, b = r / rows;
+    const double* x = in + fld * in_stride + cols * b;
+    double s = 0.0;
+    for (int a = 0; a < cols; ++a) s = fma(op[ap * cols + a], x[a], s);
+    tmp[fld * tmp_stride + ap + rows * b] = s;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < nfields * rows * rows; idx += blockDim.x) {
+    const int fld = idx / (rows * rows), r = idx % (rows * rows), ap = r % rows, bp = r / rows;
+    const double* x = tmp + fld * tmp_stride + ap;
+    double s = 0.0;
+    for (int b = 0; b < cols; ++b) s = fma(op[bp * cols + b], x[rows * b], s);
+    out[fld * out_stride + ap + rows * bp] = s;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// (1) generic trace kernel: any degree, one 256-thread workgroup per element
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trace_generic_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
+                                                            const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
+                                                            const double* __restrict__ face_ops, int n_elem, int fld_stride) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* A = smem;                     // 4 nodal fields
+  double* tmp = A + 4 * fld_stride;
+  double* Q = tmp + 4 * fld_stride;     // 4 fields at the mortar nodes
+  double* ue = Q + 4 * fld_stride;
   for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
-    const int N = elem_N[e], N2 = N * N, N3 = N2 * N;
-    const double* __restrict__ D = elem_D[e];
-    double* ue = smem;
-    double* Ds = smem + N3;
-    for (int i = threadIdx.x; i < N3; i += blockDim.x) ue[i] = u[elem_ns[e] + i];
-    for (int i = threadIdx.x; i < N2; i += blockDim.x) Ds[i] = D[i];
+    const ElemDesc el = ed[e];
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
+    double* Ds = ue + N3;
+    for (int i = threadIdx.x; i < N3; i += blockDim.x) ue[i] = u[el.ns + i];
+    for (int i = threadIdx.x; i < N2; i += blockDim.x) Ds[i] = face_ops[el.offD + i];
     __syncthreads();
-    double* T = trace + trace_offset[e];
-    for (int idx = threadIdx.x; idx < 24 * N2; idx += blockDim.x) {
-      const int f = idx / (4 * N2), c = (idx / N2) & 3, ab = idx % N2, a = ab % N, b = ab / N;
-      const int v = face_vol_index(f, N, a, b);
-      double val;
-      if (c == 0) {
-        val = ue[v];
-      } else {
-        const int d = c - 1;
-        const int stride = (d == 0) ? 1 : (d == 1 ? N : N2);
-        const int pos = (v / stride) % N;  // index along direction d
-        const int base = v - pos * stride;
-        val = 0.0;
-        for (int i = 0; i < N; ++i) val = fma(Ds[pos * N + i], ue[base + i * stride], val);
+    for (int f = 0; f < 6; ++f) {
+      const SideDesc d = sd[6 * e + f];
+      const int NQ = d.NQ, T = NQ * NQ;
+      for (int idx = threadIdx.x; idx < 4 * N2; idx += blockDim.x) {
+        const int c = idx / N2, ab = idx % N2;
+        A[c * fld_stride + ab] = nodal_trace(ue, Ds, N, N, f, ab % N, ab / N, c);
       }
-      T[idx] = val;
+      __syncthreads();
+      apply2d(face_ops + d.offC, NQ, N, A, tmp, Q, 4, fld_stride, fld_stride, fld_stride);
+      for (int idx = threadIdx.x; idx < 4 * T; idx += blockDim.x) qtrace[d.qoff + idx] = Q[(idx / T) * fld_stride + idx % T];
+      __syncthreads();
+    }
+  }
+}
+
+// ghost sides: the same for face f of a ghost element given as a whole element (reference-style ghost data)
+__global__ __launch_bounds__(256) void ghost_trace_kernel(const double* __restrict__ u_ghost, double* __restrict__ ghost_qtrace,
+                                                          const GhostSideDesc* __restrict__ gd, const double* __restrict__ face_ops,
+                                                          int n_ghost_sides, int fld_stride) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* A = smem;
+  double* tmp = A + 4 * fld_stride;
+  double* Q = tmp + 4 * fld_stride;
+  double* ue = Q + 4 * fld_stride;
+  for (int s = blockIdx.x; s < n_ghost_sides; s += gridDim.x) {
+    const GhostSideDesc g = gd[s];
+    const int N = g.N, N2 = N * N, N3 = N2 * N, T = g.NQ * g.NQ;
+    double* Ds = ue + N3;
+    for (int i = threadIdx.x; i < N3; i += blockDim.x) ue[i] = u_ghost[g.u_off + i];
+    for (int i = threadIdx.x; i < N2; i += blockDim.x) Ds[i] = face_ops[g.offD + i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 4 * N2; idx += blockDim.x) {
+      const int c = idx / N2, ab = idx % N2;
+      A[c * fld_stride + ab] = nodal_trace(ue, Ds, N, N, g.f, ab % N, ab / N, c);
     }
     __syncthreads();
+    apply2d(face_ops + g.offC, g.NQ, N, A, tmp, Q, 4, fld_stride, fld_stride, fld_stride);
+    for (int idx = threadIdx.x; idx < 4 * T; idx += blockDim.x) ghost_qtrace[g.goff + idx] = Q[(idx / T) * fld_stride + idx % T];
+    __syncthreads();
+  }
+}
+
+// Dirichlet data: Lobatto face nodes -> mortar quadrature nodes (d4est_laplacian_flux_sipg.c:80-107), set-up time
+__global__ __launch_bounds__(64) void bndry_interp_kernel(const double* __restrict__ g_lobatto, double* __restrict__ g_quad,
+                                                          const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
+                                                          const int* __restrict__ side_bndry_stride,
+                                                          const double* __restrict__ face_ops, int n_sides) {
+  for (int s = blockIdx.x; s < n_sides; s += gridDim.x) {
+    const SideDesc d = sd[s];
+    if (d.kind != 0) continue;
+    const int N = ed[s / 6].N, NQ = d.NQ;
+    const double* C = face_ops + d.offC;
+    const double* g = g_lobatto + side_bndry_stride[s];
+    for (int k = threadIdx.x; k < NQ * NQ; k += blockDim.x) {
+      const int ap = k % NQ, bp = k / NQ;
+      double v = 0.0;
+      for (int b = 0; b < N; ++b) {
+        double r = 0.0;
+        for (int a = 0; a < N; ++a) r = fma(C[ap * N + a], g[a + N * b], r);
+        v = fma(C[bp * N + b], r, v);
+      }
+      g_quad[d.geom + k] = v;
+    }
   }
 }
 
@@ -110,20 +213,12 @@ __device__ inline double sipg_penalty(int fcn, int deg_m, double h_m, int deg_p,
   return prefactor * .5 * (deg_m * deg_m / h_m + deg_p * deg_p / h_p);
 }
 
-__device__ inline int reorder_index(int code, int deg, int a, int b) {
-  // out(a,b) = in(a2,b2) for out = transpose?(flip1?(flip0?(in)))  (dGMath/d4est_operators.c:2044-2081)
-  int a1 = (code & 4) ? b : a, b1 = (code & 4) ? a : b;
-  if (code & 2) b1 = deg - b1;
-  if (code & 1) a1 = deg - a1;
-  return a1 + (deg + 1) * b1;
-}
-
-__global__ __launch_bounds__(256) void face_geom_kernel(const SideDesc* __restrict__ sd, const int* __restrict__ side_deg_m,
-                                                        const int* __restrict__ side_deg_p, int n_sides,
-                                                        const double* __restrict__ sj, const double* __restrict__ nrm,
-                                                        const double* __restrict__ drst_m, const double* __restrict__ drst_p,
-                                                        const double* __restrict__ hm, const double* __restrict__ hp,
-                                                        double prefactor, int fcn, double* __restrict__ geom) {
+__global__ __launch_bounds__(64) void face_geom_kernel(const SideDesc* __restrict__ sd, const int* __restrict__ side_deg_m,
+                                                       const int* __restrict__ side_deg_p, int n_sides,
+                                                       const double* __restrict__ sj, const double* __restrict__ nrm,
+                                                       const double* __restrict__ drst_m, const double* __restrict__ drst_p,
+                                                       const double* __restrict__ hm, const double* __restrict__ hp,
+                                                       double prefactor, int fcn, double* __restrict__ geom) {
   for (int s = blockIdx.x; s < n_sides; s += gridDim.x) {
     const SideDesc d = sd[s];
     const int NQ = d.NQ, T = NQ * NQ;
@@ -151,84 +246,40 @@ __global__ __launch_bounds__(256) void face_geom_kernel(const SideDesc* __restri
 }
 
 // ---------------------------------------------------------------------------
-// (2) flux kernel: one workgroup per element
+// (2) generic flux kernel: any degree, one 256-thread workgroup per element, sides in sequence
 // ---------------------------------------------------------------------------
-// out[r x r'] (rows x rows) = (op (x) op) in[cols x cols], op is rows x cols row-major; tmp holds rows x cols
-__device__ inline void apply2d(const double* __restrict__ op, int rows, int cols, const double* in, double* tmp, double* out,
-                               int nfields, int in_stride, int out_stride, int tmp_stride) {
-  // pass 1: tmp(a', b) = sum_a op[a'][a] in(a, b)
-  for (int idx = threadIdx.x; idx < nfields * rows * cols; idx += blockDim.x) {
-    const int fld = idx / (rows * cols), r = idx % (rows * cols), ap = r % rows, b = r / rows;
-    const double* x = in + fld * in_stride + cols * b;
-    double s = 0.0;
-    for (int a = 0; a < cols; ++a) s = fma(op[ap * cols + a], x[a], s);
-    tmp[fld * tmp_stride + ap + rows * b] = s;
-  }
-  __syncthreads();
-  // pass 2: out(a', b') = sum_b op[b'][b] tmp(a', b)
-  for (int idx = threadIdx.x; idx < nfields * rows * rows; idx += blockDim.x) {
-    const int fld = idx / (rows * rows), r = idx % (rows * rows), ap = r % rows, bp = r / rows;
-    const double* x = tmp + fld * tmp_stride + ap;
-    double s = 0.0;
-    for (int b = 0; b < cols; ++b) s = fma(op[bp * cols + b], x[rows * b], s);
-    out[fld * out_stride + ap + rows * bp] = s;
-  }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void flux_kernel(const double* __restrict__ trace, const double* __restrict__ ghost_trace,
-                                                   double* __restrict__ Au, const SideDesc* __restrict__ sd,
-                                                   const int* __restrict__ elem_N, const int* __restrict__ elem_ns,
-                                                   const long long* __restrict__ trace_offset,
-                                                   const double* const* __restrict__ elem_D,
-                                                   const double* __restrict__ face_ops, const double* __restrict__ geom,
-                                                   const double* __restrict__ bndry, int n_elem, int fld_stride) {
+__global__ __launch_bounds__(256) void flux_generic_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
+                                                           double* __restrict__ Au, const SideDesc* __restrict__ sd,
+                                                           const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
+                                                           const double* __restrict__ geom, const double* __restrict__ bndry_q,
+                                                           int n_elem, int fld_stride) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  // LDS carve: fields A[8][fld_stride], B[8][fld_stride], tmp[8][fld_stride], acc[N^3], D[N^2]
-  double* A = smem;
-  double* Bq = A + 8 * fld_stride;
-  double* tmp = Bq + 8 * fld_stride;
-  double* acc = tmp + 8 * fld_stride;
+  double* A = smem;                     // 4 term fields at the mortar nodes
+  double* tmp = A + 4 * fld_stride;
+  double* R = tmp + 4 * fld_stride;     // 4 fields on the side's nodes
+  double* acc = R + 4 * fld_stride;
   for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
-    const int N = elem_N[e], N2 = N * N, N3 = N2 * N;
+    const ElemDesc el = ed[e];
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
     double* Ds = acc + N3;
     for (int i = threadIdx.x; i < N3; i += blockDim.x) acc[i] = 0.0;
-    for (int i = threadIdx.x; i < N2; i += blockDim.x) Ds[i] = elem_D[e][i];
+    for (int i = threadIdx.x; i < N2; i += blockDim.x) Ds[i] = face_ops[el.offD + i];
     __syncthreads();
-    const double* Tm = trace + trace_offset[e];
     for (int f = 0; f < 6; ++f) {
       const SideDesc d = sd[6 * e + f];
       const int NQ = d.NQ, T = NQ * NQ;
-      const double* Cm = face_ops + d.offC_m;
-      const double* E = face_ops + d.offE;
       const double* g = geom + (size_t)7 * d.geom;
-      // (-) side trace fields 0..3 -> A[0..3]; (+) side (re-ordered to the (-) ordering) -> A[4..7]
-      for (int idx = threadIdx.x; idx < 4 * N2; idx += blockDim.x) A[(idx / N2) * fld_stride + idx % N2] = Tm[f * 4 * N2 + idx];
-      if (d.kind != 0) {
-        const int Np = d.Np, Np2 = Np * Np;
-        const double* Tp = ((d.kind == 1) ? trace : ghost_trace) + d.nbr_trace + (size_t)d.f_p * 4 * Np2;
-        for (int idx = threadIdx.x; idx < 4 * Np2; idx += blockDim.x) {
-          const int c = idx / Np2, ab = idx % Np2;
-          A[(4 + c) * fld_stride + ab] = Tp[c * Np2 + reorder_index(d.code, Np - 1, ab % Np, ab / Np)];
-        }
-      } else {
-        // Dirichlet data g on the Lobatto face nodes plays the role of u_p (d4est_laplacian_flux_sipg.c:80-112)
-        for (int idx = threadIdx.x; idx < N2; idx += blockDim.x) A[4 * fld_stride + idx] = bndry[d.bndry + idx];
-      }
-      __syncthreads();
-      // to the mortar quadrature nodes: Bq[c] = (C (x) C) A[c]
-      apply2d(Cm, NQ, N, A, tmp, Bq, 4, fld_stride, fld_stride, fld_stride);
-      if (d.kind != 0) apply2d(face_ops + d.offC_p, NQ, d.Np, A + 4 * fld_stride, tmp, Bq + 4 * fld_stride, 4, fld_stride, fld_stride, fld_stride);
-      else apply2d(Cm, NQ, N, A + 4 * fld_stride, tmp, Bq + 4 * fld_stride, 1, fld_stride, fld_stride, fld_stride);
-      // SIPG terms at the quadrature nodes -> A[0]: term1 + term3 (both lifted without D^T), A[1..3]: term2_l
+      const double* qm = qtrace + d.qoff;
+      const double* qp = ((d.kind == 2) ? ghost_qtrace : qtrace) + d.nbr_qoff;
       for (int k = threadIdx.x; k < T; k += blockDim.x) {
-        const double um = Bq[k], up = Bq[4 * fld_stride + k];
-        double t1 = 0.0;
-        double am[3];
+        const int kp = (d.kind == 0) ? k : reorder_index(d.code, NQ - 1, k % NQ, k / NQ);
+        const double um = qm[k];
+        const double up = (d.kind == 0) ? bndry_q[d.geom + k] : qp[kp];
+        double t1 = 0.0, am[3];
         for (int i = 0; i < 3; ++i) {
           am[i] = g[i * T + k];
-          t1 += am[i] * Bq[(1 + i) * fld_stride + k];
-          if (d.kind != 0) t1 += g[(3 + i) * T + k] * Bq[(5 + i) * fld_stride + k];
+          t1 += am[i] * qm[(1 + i) * T + k];
+          if (d.kind != 0) t1 += g[(3 + i) * T + k] * qp[(1 + i) * T + kp];
         }
         const double jump = um - up;
         // interface: t1 = -1/2 sj n.(grad u_m + grad u_p), t2_l = -1/2 am_l [u]; boundary: t1 = -sj n.grad u_m, t2_l = -am_l (u - g)
@@ -237,28 +288,24 @@ __global__ __launch_bounds__(256) void flux_kernel(const double* __restrict__ tr
         for (int l = 0; l < 3; ++l) A[(1 + l) * fld_stride + k] = w1 * am[l] * jump;
       }
       __syncthreads();
-      // integrate + project onto the (-) side: Bq[c] (N x N) = (E (x) E) A[c]
-      apply2d(E, N, NQ, A, tmp, Bq, 4, fld_stride, fld_stride, fld_stride);
+      apply2d(face_ops + d.offE, N, NQ, A, tmp, R, 4, fld_stride, fld_stride, fld_stride);
       // lift (+ D_l^T for the term-2 fields) into the element accumulator
       const int dir = f >> 1, fix = face_fix(f, N);
       const int sdir = (dir == 0) ? 1 : (dir == 1 ? N : N2);
       for (int idx = threadIdx.x; idx < N3; idx += blockDim.x) {
-        // node (pos along dir, a, b)
         const int pos = (idx / sdir) % N;
         int a, b;
         if (dir == 0) { a = (idx / N) % N; b = idx / N2; }
         else if (dir == 1) { a = idx % N; b = idx / N2; }
         else { a = idx % N; b = (idx / N) % N; }
-        // normal direction: D^T lift of term2_dir touches every node of the line: D[fix][pos] * t2(a,b)
-        double v = Ds[fix * N + pos] * Bq[(1 + dir) * fld_stride + a + N * b];
+        double v = Ds[fix * N + pos] * R[(1 + dir) * fld_stride + a + N * b];
         if (pos == fix) {
-          v += Bq[a + N * b];
-          // tangential directions: (D^T)(a, a') within the face
-          const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;  // tangential reference directions, a <-> t0, b <-> t1d
+          v += R[a + N * b];
+          const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;  // tangential reference directions of a and b
           double s0 = 0.0, s1 = 0.0;
           for (int q = 0; q < N; ++q) {
-            s0 = fma(Ds[q * N + a], Bq[(1 + t0) * fld_stride + q + N * b], s0);
-            s1 = fma(Ds[q * N + b], Bq[(1 + t1d) * fld_stride + a + N * q], s1);
+            s0 = fma(Ds[q * N + a], R[(1 + t0) * fld_stride + q + N * b], s0);
+            s1 = fma(Ds[q * N + b], R[(1 + t1d) * fld_stride + a + N * q], s1);
           }
           v += s0 + s1;
         }
@@ -266,29 +313,24 @@ __global__ __launch_bounds__(256) void flux_kernel(const double* __restrict__ tr
       }
       __syncthreads();
     }
-    for (int i = threadIdx.x; i < N3; i += blockDim.x) Au[elem_ns[e] + i] += acc[i];
+    for (int i = threadIdx.x; i < N3; i += blockDim.x) Au[el.ns + i] += acc[i];
     __syncthreads();
   }
 }
 
 // ---------------------------------------------------------------------------
-// (2b) fast flux kernel for plans whose sides all have N, Np, NQ <= 8 (p <= 7): one workgroup of six wavefronts per
-// element, wavefront f <-> face f, lane <-> face node.  The 2-D tensor applies keep their results in registers, the
-// four lifted fields (term1+3 and the three term2_l) are scattered into LDS volume fields W_0..W_3 in three
-// conflict-free phases (opposite faces touch disjoint nodes), and one pass applies  W_0 + sum_l D_l^T W_l  and adds
-// it to Au_e.  12 barriers per element instead of ~80 in the generic kernel.
+// fast path (every N, Np, NQ <= 8, i.e. p <= 7): workgroup of six wavefronts per element, wavefront f <-> side f,
+// lane <-> node of a fixed 8 x 8 grid (index a + 8 b).  Operators are zero-padded to 8 x 8 in LDS so the tensor
+// applies are branch-free and fully unrolled (the padding multiplies zeros).
 // ---------------------------------------------------------------------------
-constexpr int kFW = 8;  // max nodes per direction on the fast path
+constexpr int kFW = 8;
 
-// All face arrays of the fast path live on a fixed 8 x 8 grid (index a + 8 b) and the operators are stored
-// zero-padded to 8 x 8 in LDS, so the tensor applies are branch-free and fully unrolled for every p <= 7
-// (the padding multiplies zeros).  out_c(a',b') = sum_{a,b} op[a'][a] op[b'][b] in_c(a,b); lane = a' + 8 b'.
+// out_c(a',b') = sum_{a,b} op[a'][a] op[b'][b] in_c(a,b); lane = a' + 8 b'; result in registers
 template <int NF>
 __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/, const double* in /*[NF][64]*/,
                                              double* tmp /*[NF][64]*/, int lane, double* out /*[NF]*/) {
   const int lo = lane & 7, hi = lane >> 3;
   double c[kFW];
-  // pass 1: lane (a' = lo, b = hi): tmp_c(a', b) = sum_a op[a'][a] in_c(a, b)
 #pragma unroll
   for (int a = 0; a < kFW; ++a) c[a] = op[lo * 8 + a];
 #pragma unroll
@@ -299,7 +341,6 @@ __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/,
     tmp[f * 64 + lane] = s;
   }
   __syncthreads();
-  // pass 2: lane (a' = lo, b' = hi): out_c = sum_b op[b'][b] tmp_c(a', b)
 #pragma unroll
   for (int b = 0; b < kFW; ++b) c[b] = op[hi * 8 + b];
 #pragma unroll
@@ -312,21 +353,71 @@ __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/,
   __syncthreads();
 }
 
-__global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict__ trace, const double* __restrict__ ghost_trace,
-                                                        double* __restrict__ Au, const SideDesc* __restrict__ sd,
-                                                        const ElemDesc* __restrict__ ed,
-                                                        const double* __restrict__ face_ops, const double* __restrict__ geom,
-                                                        const double* __restrict__ bndry, int n_elem) {
-  __shared__ double s_in[6][4][64];   // per wave: 4 fields on the 8 x 8 grid
+__global__ __launch_bounds__(384) void trace_wave_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
+                                                         const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
+                                                         const double* __restrict__ face_ops, int n_elem) {
+  __shared__ double s_u[512];
+  __shared__ double s_D[64];          // zero-padded 8 x 8
+  __shared__ double s_in[6][4][64];
   __shared__ double s_tmp[6][4][64];
-  __shared__ double s_ops[6][3][64];  // per wave: C_m, C_p, E of its side, zero-padded to 8 x 8
+  __shared__ double s_C[6][64];       // zero-padded 8 x 8
+  const int f = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 7, hi = lane >> 3;
+  int e = blockIdx.x;
+  ElemDesc edn = ed[e < n_elem ? e : 0];
+  SideDesc dn = sd[6 * (e < n_elem ? e : 0) + f];
+  for (; e < n_elem; e += gridDim.x) {
+    const ElemDesc el = edn;
+    const SideDesc d = dn;
+    {
+      const int en = e + gridDim.x;
+      if (en < n_elem) {
+        edn = ed[en];
+        dn = sd[6 * en + f];
+      }
+    }
+    const int N = el.N, N2 = N * N, N3 = N2 * N, NQ = d.NQ, T = NQ * NQ;
+    double uv0 = 0.0, uv1 = 0.0;
+    if ((int)threadIdx.x < N3) uv0 = u[el.ns + threadIdx.x];
+    if ((int)threadIdx.x + 384 < N3) uv1 = u[el.ns + threadIdx.x + 384];
+    const double opc = (hi < NQ && lo < N) ? face_ops[d.offC + hi * N + lo] : 0.0;
+    const double dval = (threadIdx.x < 64) ? face_ops[el.offD + threadIdx.x] : 0.0;
+    if ((int)threadIdx.x < N3) s_u[threadIdx.x] = uv0;
+    if ((int)threadIdx.x + 384 < N3) s_u[threadIdx.x + 384] = uv1;
+    if (threadIdx.x < 64) s_D[threadIdx.x] = dval;
+    s_C[f][lane] = opc;
+    __syncthreads();
+    // nodal traces of this side at lane (a = lo, b = hi)
+    {
+      double t[4] = {0.0, 0.0, 0.0, 0.0};
+      if (lo < N && hi < N) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = nodal_trace(s_u, s_D, 8, N, f, lo, hi, c);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s_in[f][c][lane] = t[c];
+    }
+    __syncthreads();
+    double q[4];
+    wave_apply2d<4>(s_C[f], &s_in[f][0][0], &s_tmp[f][0][0], lane, q);
+    if (lo < NQ && hi < NQ) {
+      double* out = qtrace + d.qoff + lo + NQ * hi;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[c * T] = q[c];
+    }
+  }
+}
+
+__global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
+                                                        double* __restrict__ Au, const SideDesc* __restrict__ sd,
+                                                        const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
+                                                        const double* __restrict__ geom, const double* __restrict__ bndry_q,
+                                                        int n_elem) {
+  __shared__ double s_in[6][4][64];   // per wave: 4 term fields on the 8 x 8 grid
+  __shared__ double s_tmp[6][4][64];
+  __shared__ double s_E[6][64];       // per wave: E of its side, zero-padded to 8 x 8
   __shared__ double s_W[4][512];      // lifted volume fields: W_0 (terms 1+3), W_1..3 (term 2_l)
-  __shared__ double s_D[64];
-  const int f = threadIdx.x >> 6;     // wave = face
-  const int lane = threadIdx.x & 63;
-  const int lo = lane & 7, hi = lane >> 3;
-  double(*in)[64] = s_in[f];
-  double(*tmp)[64] = s_tmp[f];
+  __shared__ double s_D[64];          // zero-padded 8 x 8
+  const int f = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 7, hi = lane >> 3;
   // persistent workgroups: the descriptors of the NEXT element are requested while this one is computed
   int e = blockIdx.x;
   ElemDesc edn = ed[e < n_elem ? e : 0];
@@ -341,57 +432,35 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
         dn = sd[6 * en + f];
       }
     }
-    const int N = el.N, N2 = N * N, N3 = N2 * N;
-    const int NQ = d.NQ, T = NQ * NQ;
-    const int Np = d.Np, Np2 = Np * Np;
-    const bool on_m = lo < N && hi < N, on_p = lo < Np && hi < Np, on_q = lo < NQ && hi < NQ;
-    // ---- issue every global load of this side up front (independent requests: one memory latency)
-    const double* Tm = trace + el.trace_off + (size_t)f * 4 * N2;
-    double tm[4] = {0, 0, 0, 0}, tp[4] = {0, 0, 0, 0}, gq[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (on_m) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) tm[c] = Tm[c * N2 + lo + N * hi];
-    }
-    if (d.kind != 0) {
-      const double* Tp = ((d.kind == 1) ? trace : ghost_trace) + d.nbr_trace + (size_t)d.f_p * 4 * Np2;
-      if (on_p) {
-        const int src = reorder_index(d.code, Np - 1, lo, hi);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) tp[c] = Tp[c * Np2 + src];
-      }
-    } else if (on_m) {
-      tp[0] = bndry[d.bndry + lo + N * hi];
-    }
+    const int N = el.N, N2 = N * N, N3 = N2 * N, NQ = d.NQ, T = NQ * NQ;
+    const bool on_m = lo < N && hi < N, on_q = lo < NQ && hi < NQ;
+    // ---- every global load of this side up front (independent requests: one memory latency)
+    double qm[4] = {0, 0, 0, 0}, qp[4] = {0, 0, 0, 0}, gq[7] = {0, 0, 0, 0, 0, 0, 0};
     if (on_q) {
-      const double* g = geom + (size_t)7 * d.geom;
+      const int k = lo + NQ * hi;
+      const double* m = qtrace + d.qoff + k;
 #pragma unroll
-      for (int c = 0; c < 7; ++c) gq[c] = g[c * T + lo + NQ * hi];
+      for (int c = 0; c < 4; ++c) qm[c] = m[c * T];
+      if (d.kind != 0) {
+        const double* p = ((d.kind == 2) ? ghost_qtrace : qtrace) + d.nbr_qoff + reorder_index(d.code, NQ - 1, lo, hi);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qp[c] = p[c * T];
+      } else {
+        qp[0] = bndry_q[d.geom + k];
+      }
+      const double* g = geom + (size_t)7 * d.geom + k;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) gq[c] = g[c * T];
     }
-    // operators: entry (row hi, col lo) of the padded 8 x 8 images
-    const double opm = (hi < NQ && lo < N) ? face_ops[d.offC_m + hi * N + lo] : 0.0;
-    const double opp = (hi < NQ && lo < Np) ? face_ops[d.offC_p + hi * Np + lo] : 0.0;
     const double ope = (hi < N && lo < NQ) ? face_ops[d.offE + hi * NQ + lo] : 0.0;
-    const double dval = (threadIdx.x < N2) ? face_ops[el.offD + threadIdx.x] : 0.0;
+    const double dval = (threadIdx.x < 64) ? face_ops[el.offD + threadIdx.x] : 0.0;
     // Au_e is read now (2 values per thread) so that the final update only stores
     double au0 = 0.0, au1 = 0.0;
     if ((int)threadIdx.x < N3) au0 = Au[el.ns + threadIdx.x];
     if ((int)threadIdx.x + 384 < N3) au1 = Au[el.ns + threadIdx.x + 384];
     for (int i = threadIdx.x; i < 4 * 512; i += blockDim.x) (&s_W[0][0])[i] = 0.0;
-    s_ops[f][0][lane] = opm;
-    s_ops[f][1][lane] = opp;
-    s_ops[f][2][lane] = ope;
-    if (threadIdx.x < N2) s_D[threadIdx.x] = dval;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) in[c][lane] = tm[c];
-    __syncthreads();
-    // ---- (-) side: 4 fields to the mortar quadrature nodes
-    double qm[4], qp[4];
-    wave_apply2d<4>(s_ops[f][0], &in[0][0], &tmp[0][0], lane, qm);
-    // ---- (+) side (re-ordered to the (-) ordering) or the Dirichlet data (field 0 only; the others are zero)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) in[c][lane] = tp[c];
-    __syncthreads();
-    wave_apply2d<4>(s_ops[f][(d.kind != 0) ? 1 : 0], &in[0][0], &tmp[0][0], lane, qp);
+    s_E[f][lane] = ope;
+    if (threadIdx.x < 64) s_D[threadIdx.x] = dval;
     // ---- SIPG terms at the quadrature node of this lane (padding lanes carry zeros)
     {
       double t1 = 0.0;
@@ -399,14 +468,14 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
       for (int i = 0; i < 3; ++i) t1 += gq[i] * qm[1 + i] + gq[3 + i] * qp[1 + i];  // gq[3..5] = 0 on boundary sides
       const double jump = qm[0] - qp[0];
       const double w1 = (d.kind != 0) ? -0.5 : -1.0;
-      in[0][lane] = w1 * t1 + gq[6] * jump;
+      s_in[f][0][lane] = w1 * t1 + gq[6] * jump;
 #pragma unroll
-      for (int l = 0; l < 3; ++l) in[1 + l][lane] = w1 * gq[l] * jump;
+      for (int l = 0; l < 3; ++l) s_in[f][1 + l][lane] = w1 * gq[l] * jump;
     }
     __syncthreads();
     // ---- integrate and project onto the (-) side: 4 fields on the N x N face nodes
     double res[4];
-    wave_apply2d<4>(s_ops[f][2], &in[0][0], &tmp[0][0], lane, res);
+    wave_apply2d<4>(s_E[f], &s_in[f][0][0], &s_tmp[f][0][0], lane, res);
     // ---- lift: scatter into the volume fields, opposite faces together (disjoint node sets)
     for (int phase = 0; phase < 3; ++phase) {
       if ((f >> 1) == phase && on_m) {
@@ -424,9 +493,9 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
         const int i = idx % N, j = (idx / N) % N, k = idx / N2;
         double v = s_W[0][idx];
         for (int q = 0; q < N; ++q) {
-          v = fma(s_D[q * N + i], s_W[1][q + N * (j + N * k)], v);
-          v = fma(s_D[q * N + j], s_W[2][i + N * (q + N * k)], v);
-          v = fma(s_D[q * N + k], s_W[3][i + N * (j + N * q)], v);
+          v = fma(s_D[q * 8 + i], s_W[1][q + N * (j + N * k)], v);
+          v = fma(s_D[q * 8 + j], s_W[2][i + N * (q + N * k)], v);
+          v = fma(s_D[q * 8 + k], s_W[3][i + N * (j + N * q)], v);
         }
         Au[el.ns + idx] = (rep == 0 ? au0 : au1) + v;
       }
@@ -441,18 +510,15 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
 namespace {
 
 struct FaceHost {
-  std::vector<int> elem_N, elem_ns, side_deg_m, side_deg_p;
-  std::vector<const double*> elem_D;
-  int* d_elem_N = nullptr;
-  int* d_elem_ns = nullptr;
+  std::vector<int> side_deg_m, side_deg_p;
   int* d_side_deg_m = nullptr;
   int* d_side_deg_p = nullptr;
-  const double** d_elem_D = nullptr;
-  long long* d_ghost_trace_offset = nullptr;
-  int* d_ghost_N = nullptr;
-  int* d_ghost_ns = nullptr;
-  const double** d_ghost_D = nullptr;
-  std::map<int, double*> d_Dmat;  // per degree
+  int* d_side_bndry_stride = nullptr;
+  GhostSideDesc* d_ghost_sides = nullptr;
+  int n_ghost_sides = 0;
+  int fld_stride = 0;   // generic kernels: doubles per field buffer
+  int max_N = 1;
+  ElemDesc* d_elem_desc_generic = nullptr;  // offD -> unpadded N x N matrices
 };
 std::map<d4est_hip_plan*, FaceHost> g_face_host;
 
@@ -470,48 +536,6 @@ void faces_setup(d4est_hip_plan* plan) {
   FaceHost& fh = g_face_host[plan];
   const int ne = plan->n_elements;
   const int qt = plan->quad_type;
-  // per-degree derivative matrices
-  auto get_D = [&](int deg) -> const double* {
-    auto it = fh.d_Dmat.find(deg);
-    if (it != fh.d_Dmat.end()) return it->second;
-    double* d = upload_vec(Tables1D::dij(deg));
-    fh.d_Dmat[deg] = d;
-    return d;
-  };
-  fh.elem_N.resize(ne);
-  fh.elem_ns.resize(ne);
-  fh.elem_D.resize(ne);
-  plan->trace_offset.resize(ne);
-  long long toff = 0;
-  int maxN = 1;
-  for (int e = 0; e < ne; ++e) {
-    const int N = plan->deg[e] + 1;
-    fh.elem_N[e] = N;
-    fh.elem_ns[e] = plan->nodal_stride[e];
-    fh.elem_D[e] = get_D(plan->deg[e]);
-    plan->trace_offset[e] = toff;
-    toff += 24LL * N * N;
-    maxN = std::max(maxN, N);
-  }
-  plan->local_trace_doubles = toff;
-  plan->ghost_trace_offset.resize(plan->n_ghost);
-  long long goff = 0;
-  std::vector<int> ghost_N(plan->n_ghost), ghost_ns(plan->n_ghost);
-  std::vector<const double*> ghost_D(plan->n_ghost);
-  int gns = 0;
-  for (int g = 0; g < plan->n_ghost; ++g) {
-    const int N = plan->ghost_deg[g] + 1;
-    plan->ghost_trace_offset[g] = goff;
-    goff += 24LL * N * N;
-    ghost_N[g] = N;
-    ghost_ns[g] = gns;
-    gns += N * N * N;
-    ghost_D[g] = get_D(plan->ghost_deg[g]);
-    maxN = std::max(maxN, N);
-  }
-  plan->ghost_trace_doubles = goff;
-
-  // face operators, de-duplicated
   std::vector<double> ops;
   std::map<std::tuple<int, int, int, int>, int> op_index;  // (kind, deg_a, deg_b, deg_c) -> offset
   auto get_C = [&](int deg_side, int deg_mq) {
@@ -545,93 +569,148 @@ void faces_setup(d4est_hip_plan* plan) {
     op_index[key] = off;
     return off;
   };
-
-  // derivative matrices inside the face-operator buffer (one load level less than a pointer table)
-  std::map<int, int> offD_of;
-  for (int e = 0; e < ne; ++e) {
-    const int deg = plan->deg[e];
-    if (!offD_of.count(deg)) {
-      std::vector<double> D = Tables1D::dij(deg);
-      offD_of[deg] = (int)ops.size();
+  // derivative matrices: unpadded (generic kernels) and zero-padded 8 x 8 (fast path, degrees <= 7)
+  auto get_D = [&](int deg, bool padded) {
+    auto key = std::make_tuple(padded ? 3 : 2, deg, 0, 0);
+    auto it = op_index.find(key);
+    if (it != op_index.end()) return it->second;
+    std::vector<double> D = Tables1D::dij(deg);
+    const int n = deg + 1;
+    const int off = (int)ops.size();
+    if (!padded) {
       ops.insert(ops.end(), D.begin(), D.end());
+    } else {
+      std::vector<double> P(64, 0.0);
+      for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) P[r * 8 + c] = D[(size_t)r * n + c];
+      ops.insert(ops.end(), P.begin(), P.end());
+    }
+    op_index[key] = off;
+    return off;
+  };
+
+  // per side sizes; the local trace block of side s is 4 T_s doubles in side order
+  const size_t ns = 6 * (size_t)ne;
+  std::vector<SideDesc> sd(ns);
+  fh.side_deg_m.assign(ns, 0);
+  fh.side_deg_p.assign(ns, 0);
+  plan->trace_offset.assign(ns, 0);
+  plan->ghost_trace_offset.assign(ns, -1);
+  std::vector<GhostSideDesc> gsides;
+  std::vector<long long> ghost_u_off(plan->n_ghost, 0);
+  {
+    long long o = 0;
+    for (int g = 0; g < plan->n_ghost; ++g) {
+      ghost_u_off[g] = o;
+      const long long n = plan->ghost_deg[g] + 1;
+      o += n * n * n;
     }
   }
-  std::vector<ElemDesc> edv(ne);
-  for (int e = 0; e < ne; ++e) {
-    edv[e].N = plan->deg[e] + 1;
-    edv[e].ns = plan->nodal_stride[e];
-    edv[e].trace_off = plan->trace_offset[e];
-    edv[e].offD = offD_of[plan->deg[e]];
-    edv[e].pad = 0;
-  }
-  HIP_CHECK(hipMalloc(&plan->d_elem_desc, std::max<size_t>(edv.size(), 1) * sizeof(ElemDesc)));
-  if (!edv.empty()) HIP_CHECK(hipMemcpy(plan->d_elem_desc, edv.data(), edv.size() * sizeof(ElemDesc), hipMemcpyHostToDevice));
-  std::vector<SideDesc> sd(6 * (size_t)ne);
-  fh.side_deg_m.assign(6 * (size_t)ne, 0);
-  fh.side_deg_p.assign(6 * (size_t)ne, 0);
-  int max_fld = maxN * maxN;
+  long long qoff = 0, goff = 0;
+  int maxN = 1, maxNQ = 1, max_fld = 1;
+  bool fast = true;
+  for (int e = 0; e < ne; ++e) maxN = std::max(maxN, plan->deg[e] + 1);
+  for (int g = 0; g < plan->n_ghost; ++g) maxN = std::max(maxN, plan->ghost_deg[g] + 1);
+  // first pass: mortar degrees and offsets
+  std::vector<int> deg_mq_of(ns), deg_p_of(ns);
+  for (int e = 0; e < ne; ++e)
+    for (int f = 0; f < 6; ++f) {
+      const size_t s = 6 * (size_t)e + f;
+      const int nbr = plan->side_nbr[s];
+      const int deg_m = plan->deg[e], degq_m = plan->deg_quad[e];
+      int deg_p = deg_m, degq_p = degq_m;
+      if (nbr >= 0) {
+        if (nbr >= ne) D4EST_HIP_ABORT("plan_set_faces: side %zu neighbour %d out of range", s, nbr);
+        deg_p = plan->deg[nbr];
+        degq_p = plan->deg_quad[nbr];
+      } else if (nbr <= -2) {
+        const int g = -(nbr + 2);
+        if (g >= plan->n_ghost) D4EST_HIP_ABORT("plan_set_faces: side %zu ghost %d out of range", s, g);
+        deg_p = plan->ghost_deg[g];
+        degq_p = plan->ghost_deg_quad[g];
+      }
+      deg_mq_of[s] = (nbr == -1) ? degq_m : std::max(degq_m, degq_p);
+      deg_p_of[s] = deg_p;
+      const long long T = (long long)(deg_mq_of[s] + 1) * (deg_mq_of[s] + 1);
+      plan->trace_offset[s] = qoff;
+      qoff += 4 * T;
+      maxNQ = std::max(maxNQ, deg_mq_of[s] + 1);
+    }
+  plan->local_trace_doubles = qoff;
+  fast = (maxN <= 8 && maxNQ <= 8);
   for (int e = 0; e < ne; ++e)
     for (int f = 0; f < 6; ++f) {
       const size_t s = 6 * (size_t)e + f;
       SideDesc d{};
       const int nbr = plan->side_nbr[s];
-      const int deg_m = plan->deg[e], degq_m = plan->deg_quad[e];
-      int deg_p = deg_m, degq_p = degq_m;
-      if (nbr == -1) {
-        d.kind = 0;
-      } else if (nbr >= 0) {
-        if (nbr >= ne) D4EST_HIP_ABORT("plan_set_faces: side %zu neighbour %d out of range", s, nbr);
-        d.kind = 1;
-        deg_p = plan->deg[nbr];
-        degq_p = plan->deg_quad[nbr];
-        d.nbr_trace = plan->trace_offset[nbr];
-      } else {
-        const int g = -(nbr + 2);
-        if (g >= plan->n_ghost) D4EST_HIP_ABORT("plan_set_faces: side %zu ghost %d out of range", s, g);
-        d.kind = 2;
-        deg_p = plan->ghost_deg[g];
-        degq_p = plan->ghost_deg_quad[g];
-        d.nbr_trace = plan->ghost_trace_offset[g];
-      }
-      const int deg_mq = std::max(degq_m, degq_p), deg_ml = std::max(deg_m, deg_p);
-      d.f_p = plan->side_nbr_face[s];
+      const int deg_m = plan->deg[e], deg_p = deg_p_of[s], deg_mq = deg_mq_of[s];
+      const int deg_ml = std::max(deg_m, deg_p);
+      d.kind = (nbr == -1) ? 0 : (nbr >= 0 ? 1 : 2);
       d.code = plan->side_reorder[s];
-      d.Np = deg_p + 1;
       d.NQ = deg_mq + 1;
-      d.offC_m = get_C(deg_m, deg_mq);
-      d.offC_p = (d.kind == 0) ? d.offC_m : get_C(deg_p, deg_mq);
+      d.offC = get_C(deg_m, deg_mq);
       d.offE = get_E(deg_m, d.kind == 0 ? deg_m : deg_ml, deg_mq);
       d.geom = plan->side_mortar_stride[s];
-      d.bndry = plan->side_bndry_stride[s];
+      d.qoff = plan->trace_offset[s];
+      d.nbr_qoff = 0;
+      if (d.kind == 1) {
+        const size_t sp = 6 * (size_t)nbr + plan->side_nbr_face[s];
+        if (deg_mq_of[sp] != deg_mq) D4EST_HIP_ABORT("plan_set_faces: sides %zu and %zu disagree on the mortar degree (non-conforming mortar?)", s, sp);
+        d.nbr_qoff = plan->trace_offset[sp];
+      } else if (d.kind == 2) {
+        const int g = -(nbr + 2);
+        plan->ghost_trace_offset[s] = goff;
+        d.nbr_qoff = goff;
+        GhostSideDesc gs{};
+        gs.N = plan->ghost_deg[g] + 1;
+        gs.f = plan->side_nbr_face[s];
+        gs.NQ = deg_mq + 1;
+        gs.offC = get_C(plan->ghost_deg[g], deg_mq);
+        gs.offD = get_D(plan->ghost_deg[g], false);
+        gs.u_off = ghost_u_off[g];
+        gs.goff = goff;
+        gsides.push_back(gs);
+        goff += 4LL * (deg_mq + 1) * (deg_mq + 1);
+      }
       sd[s] = d;
       fh.side_deg_m[s] = deg_m;
       fh.side_deg_p[s] = deg_p;
-      max_fld = std::max(max_fld, std::max(d.NQ * d.NQ, std::max(d.NQ * d.Np, d.NQ * (deg_m + 1))));
+      max_fld = std::max(max_fld, std::max(d.NQ * d.NQ, d.NQ * (deg_m + 1)));
+      max_fld = std::max(max_fld, d.NQ * (deg_p + 1));
     }
-  plan->max_face_lds_doubles = 24 * max_fld + maxN * maxN * maxN + maxN * maxN;
-  plan->face_fast = (max_fld <= 64);  // every N, Np, NQ <= 8
-  if ((size_t)plan->max_face_lds_doubles * sizeof(double) > 160 * 1024) D4EST_HIP_ABORT("face kernel needs %d LDS doubles", plan->max_face_lds_doubles);
+  plan->ghost_trace_doubles = goff;
+  max_fld = std::max(max_fld, maxN * maxN);
+  fh.fld_stride = max_fld;
+  fh.max_N = maxN;
+  fh.n_ghost_sides = (int)gsides.size();
+  plan->face_fast = fast;
+  plan->max_face_lds_doubles = 12 * max_fld + maxN * maxN * maxN + maxN * maxN;
+  if ((size_t)plan->max_face_lds_doubles * sizeof(double) > 160 * 1024) D4EST_HIP_ABORT("face kernels need %d LDS doubles", plan->max_face_lds_doubles);
 
-  static_assert(sizeof(SideDesc) % sizeof(int) == 0, "SideDesc layout");
+  std::vector<ElemDesc> edv(ne), edg(ne);
+  for (int e = 0; e < ne; ++e) {
+    edv[e].N = edg[e].N = plan->deg[e] + 1;
+    edv[e].ns = edg[e].ns = plan->nodal_stride[e];
+    edg[e].offD = get_D(plan->deg[e], false);
+    edv[e].offD = fast ? get_D(plan->deg[e], true) : edg[e].offD;
+    edv[e].pad = edg[e].pad = 0;
+  }
+  ops.resize(ops.size() + 64, 0.0);  // slack: the fast kernels read 64-entry images
+  plan->d_elem_desc = upload_vec(edv);
+  fh.d_elem_desc_generic = upload_vec(edg);
   HIP_CHECK(hipMalloc(&plan->d_side_desc, std::max<size_t>(sd.size(), 1) * sizeof(SideDesc)));
   if (!sd.empty()) HIP_CHECK(hipMemcpy(plan->d_side_desc, sd.data(), sd.size() * sizeof(SideDesc), hipMemcpyHostToDevice));
-  plan->d_trace_offset = upload_vec(plan->trace_offset);
   plan->d_face_ops = upload_vec(ops);
-  fh.d_elem_N = upload_vec(fh.elem_N);
-  fh.d_elem_ns = upload_vec(fh.elem_ns);
-  fh.d_elem_D = upload_vec(fh.elem_D);
   fh.d_side_deg_m = upload_vec(fh.side_deg_m);
   fh.d_side_deg_p = upload_vec(fh.side_deg_p);
-  fh.d_ghost_trace_offset = upload_vec(plan->ghost_trace_offset);
-  fh.d_ghost_N = upload_vec(ghost_N);
-  fh.d_ghost_ns = upload_vec(ghost_ns);
-  fh.d_ghost_D = upload_vec(ghost_D);
+  fh.d_side_bndry_stride = upload_vec(plan->side_bndry_stride);
+  fh.d_ghost_sides = upload_vec(gsides);
+  const size_t tm = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
   HIP_CHECK(hipMalloc(&plan->d_trace, std::max<size_t>((size_t)plan->local_trace_doubles, 1) * sizeof(double)));
-  HIP_CHECK(hipMalloc(&plan->d_bndry, std::max<size_t>((size_t)plan->total_bndry_nodes, 1) * sizeof(double)));
-  HIP_CHECK(hipMemset(plan->d_bndry, 0, std::max<size_t>((size_t)plan->total_bndry_nodes, 1) * sizeof(double)));
-  HIP_CHECK(hipMalloc(&plan->d_face_geom, std::max<size_t>(7 * (size_t)plan->total_mortar_nodes, 1) * sizeof(double)));
+  HIP_CHECK(hipMalloc(&plan->d_bndry, tm * sizeof(double)));  // Dirichlet data at the mortar quadrature nodes, by geom stride
+  HIP_CHECK(hipMemset(plan->d_bndry, 0, tm * sizeof(double)));
+  HIP_CHECK(hipMalloc(&plan->d_face_geom, 7 * tm * sizeof(double)));
   plan->has_faces = true;
-  (void)max_fld;
 }
 
 void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n, const double* drst_m, const double* drst_p,
@@ -666,19 +745,62 @@ void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n,
   plan->has_face_geometry = true;
 }
 
+void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_device) {
+  FaceHost& fh = g_face_host[plan];
+  const size_t tm = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
+  if (!g_lobatto) {
+    HIP_CHECK(hipMemsetAsync(plan->d_bndry, 0, tm * sizeof(double), plan->stream));
+    return;
+  }
+  const size_t nb = (size_t)plan->total_bndry_nodes;
+  if (nb == 0) return;
+  const double* dev = g_lobatto;
+  double* tmp = nullptr;
+  if (!on_device) {
+    HIP_CHECK(hipMalloc(&tmp, nb * sizeof(double)));
+    HIP_CHECK(hipMemcpy(tmp, g_lobatto, nb * sizeof(double), hipMemcpyHostToDevice));
+    dev = tmp;
+  }
+  const int n_sides = 6 * plan->n_elements;
+  hipLaunchKernelGGL(bndry_interp_kernel, dim3(std::min(n_sides, 8192)), dim3(64), 0, plan->stream, dev, plan->d_bndry,
+                     (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, fh.d_side_bndry_stride,
+                     plan->d_face_ops, n_sides);
+  HIP_CHECK(hipGetLastError());
+  if (tmp) {
+    HIP_CHECK(hipStreamSynchronize(plan->stream));
+    HIP_CHECK(hipFree(tmp));
+  }
+}
+
+static size_t generic_lds_bytes(const d4est_hip_plan* plan) { return (size_t)plan->max_face_lds_doubles * sizeof(double); }
+
 void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost) {
   FaceHost& fh = g_face_host[plan];
-  const int n = ghost ? plan->n_ghost : plan->n_elements;
+  if (ghost) {
+    if (fh.n_ghost_sides == 0) return;
+    const size_t lds = generic_lds_bytes(plan);
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ghost_trace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ghost_trace_kernel, dim3(std::min(fh.n_ghost_sides, 16384)), dim3(256), lds, plan->stream, u, trace,
+                       fh.d_ghost_sides, plan->d_face_ops, fh.n_ghost_sides, fh.fld_stride);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
+  const int n = plan->n_elements;
   if (n == 0) return;
-  int maxN = 1;
-  if (ghost) for (int g = 0; g < n; ++g) maxN = std::max(maxN, plan->ghost_deg[g] + 1);
-  else for (int e = 0; e < n; ++e) maxN = std::max(maxN, plan->deg[e] + 1);
-  const size_t lds = ((size_t)maxN * maxN * maxN + (size_t)maxN * maxN) * sizeof(double);
-  if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = n < 16384 ? n : 16384;
-  hipLaunchKernelGGL(trace_kernel, dim3(grid), dim3(256), lds, plan->stream, u, trace, ghost ? fh.d_ghost_N : fh.d_elem_N,
-                     ghost ? fh.d_ghost_ns : fh.d_elem_ns, ghost ? fh.d_ghost_trace_offset : plan->d_trace_offset,
-                     ghost ? fh.d_ghost_D : fh.d_elem_D, n);
+  if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+    const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
+    const int resident = 4 * cus;
+    const int rounds = (n + resident - 1) / resident;
+    const int grid = (n + rounds - 1) / rounds;
+    hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
+                       (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n);
+  } else {
+    const size_t lds = generic_lds_bytes(plan);
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(trace_generic_kernel, dim3(std::min(n, 16384)), dim3(256), lds, plan->stream, u, trace,
+                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n,
+                       fh.fld_stride);
+  }
   HIP_CHECK(hipGetLastError());
 }
 
@@ -686,32 +808,24 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   FaceHost& fh = g_face_host[plan];
   if (!plan->has_faces || !plan->has_face_geometry) D4EST_HIP_ABORT("apply flux: plan_set_faces / plan_set_mortar_geometry were not called");
   if (plan->n_elements == 0) return;
-  if (plan->n_ghost > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost elements but no ghost trace buffer was given", plan->n_ghost);
+  if (fh.n_ghost_sides > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost sides but no ghost trace buffer was given", fh.n_ghost_sides);
+  const int n = plan->n_elements;
   if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     // persistent grid: 3 workgroups per CU are resident (LDS), each loops over elements
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
     const int resident = 3 * cus;
-    const int rounds = (plan->n_elements + resident - 1) / resident;
-    const int grid = (plan->n_elements + rounds - 1) / rounds;
+    const int rounds = (n + resident - 1) / resident;
+    const int grid = (n + rounds - 1) / rounds;
     hipLaunchKernelGGL(flux_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
                        (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops,
-                       plan->d_face_geom, plan->d_bndry, plan->n_elements);
-    HIP_CHECK(hipGetLastError());
-    return;
+                       plan->d_face_geom, plan->d_bndry, n);
+  } else {
+    const size_t lds = generic_lds_bytes(plan);
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(flux_generic_kernel, dim3(std::min(n, 16384)), dim3(256), lds, plan->stream, trace, ghost_trace, Au,
+                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
+                       plan->d_face_geom, plan->d_bndry, n, fh.fld_stride);
   }
-  const size_t lds = (size_t)plan->max_face_lds_doubles * sizeof(double);
-  if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int fld_stride = (plan->max_face_lds_doubles > 0) ? 0 : 0;
-  (void)fld_stride;
-  // fld_stride recomputed exactly as in faces_setup
-  int maxN = 1;
-  for (int e = 0; e < plan->n_elements; ++e) maxN = std::max(maxN, plan->deg[e] + 1);
-  for (int g = 0; g < plan->n_ghost; ++g) maxN = std::max(maxN, plan->ghost_deg[g] + 1);
-  const int fs = (plan->max_face_lds_doubles - maxN * maxN * maxN - maxN * maxN) / 24;
-  const int grid = plan->n_elements < 16384 ? plan->n_elements : 16384;
-  hipLaunchKernelGGL(flux_kernel, dim3(grid), dim3(256), lds, plan->stream, trace, ghost_trace, Au,
-                     (const SideDesc*)plan->d_side_desc, fh.d_elem_N, fh.d_elem_ns, plan->d_trace_offset, fh.d_elem_D,
-                     plan->d_face_ops, plan->d_face_geom, plan->d_bndry, plan->n_elements, fs);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -719,14 +833,12 @@ void faces_destroy(d4est_hip_plan* plan) {
   auto it = g_face_host.find(plan);
   if (it != g_face_host.end()) {
     FaceHost& fh = it->second;
-    (void)hipFree(fh.d_elem_N); (void)hipFree(fh.d_elem_ns); (void)hipFree(fh.d_elem_D);
-    (void)hipFree(fh.d_side_deg_m); (void)hipFree(fh.d_side_deg_p);
-    (void)hipFree(fh.d_ghost_trace_offset); (void)hipFree(fh.d_ghost_N); (void)hipFree(fh.d_ghost_ns); (void)hipFree(fh.d_ghost_D);
-    for (auto& kv : fh.d_Dmat) (void)hipFree(kv.second);
+    (void)hipFree(fh.d_side_deg_m); (void)hipFree(fh.d_side_deg_p); (void)hipFree(fh.d_side_bndry_stride);
+    (void)hipFree(fh.d_ghost_sides); (void)hipFree(fh.d_elem_desc_generic);
     g_face_host.erase(it);
   }
   (void)hipFree(plan->d_elem_desc);
-  (void)hipFree(plan->d_side_desc); (void)hipFree(plan->d_trace_offset); (void)hipFree(plan->d_face_ops);
+  (void)hipFree(plan->d_side_desc); (void)hipFree(plan->d_face_ops);
   (void)hipFree(plan->d_face_geom); (void)hipFree(plan->d_bndry); (void)hipFree(plan->d_trace);
 }
 

@@ -73,8 +73,7 @@ struct d4est_hip_plan {
   long long local_trace_doubles = 0, ghost_trace_doubles = 0;
   int* d_side_desc = nullptr;        // SideDesc per side (see d4est_hip_faces.hip)
   void* d_elem_desc = nullptr;       // ElemDesc per element
-  long long* d_trace_offset = nullptr;  // per local element: offset of its 6x4xN^2 trace block
-  std::vector<long long> trace_offset, ghost_trace_offset;
+  std::vector<long long> trace_offset, ghost_trace_offset;  // per SIDE: offset of its 4 T mortar-node trace block (ghost: -1 if none)
   double* d_face_ops = nullptr;      // concatenated 1-D face operators (C and E matrices)
   double* d_face_geom = nullptr;     // 7 * total_mortar_nodes: am[3], ap[3], s3 per mortar quadrature node (side-blocked)
   double* d_bndry = nullptr;         // Dirichlet values on boundary Lobatto face nodes (total_bndry_nodes), zero by default
@@ -109,6 +108,7 @@ void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, 
 void faces_setup(d4est_hip_plan* plan);
 void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n, const double* drst_m, const double* drst_p,
                         const double* hm, const double* hp, int on_device);
+void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_device);
 void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost);
 void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au);
 void faces_destroy(d4est_hip_plan* plan);

@@ -39,28 +39,28 @@ def owner_of(parts, n_global):
 class TraceSchedule:
     """Per-peer send / receive block lists for one rank.
 
-    send[peer] / recv[peer]: arrays (offset_in_trace_buffer, length) in canonical order, built from the rank's
-    own side list only (mesh.build_sides): every side whose (+) neighbour is a ghost owned by ``peer`` contributes
-      * one SEND block: my trace of (local element e, face f)                      (the peer's ghost data)
-      * one RECV block: the ghost's trace of (ghost element g, face f_p)           (my ghost data)
+    send[peer] / recv[peer]: arrays (offset, length) in canonical order, built from the rank's own side list only
+    (mesh.build_sides): every side s = (e, f) whose (+) neighbour is a ghost owned by ``peer`` contributes
+      * one SEND block: my mortar-node trace of side s        (trace_offset(s), block_len(s)) -- the peer's ghost data
+      * one RECV block: the ghost's trace on its face f_p      (ghost_trace_offset(s), block_len(s)) -- my ghost data
+    Both ends sort by (global element id of the SENDER, its face): no metadata is exchanged.
     """
 
-    def __init__(self, mesh, sides, parts, trace_offset, ghost_trace_offset):
+    def __init__(self, mesh, sides, parts, trace_offset, ghost_trace_offset, block_len):
         owner = owner_of(parts, mesh.global_elements)
-        ne = mesh.n_elements
         send, recv = {}, {}
         nbr = sides["side_nbr"]
         for s in np.nonzero(nbr <= -2)[0]:
-            e, f = divmod(int(s), 6)
+            s = int(s)
+            e, f = divmod(s, 6)
             g = -(int(nbr[s]) + 2)
             gid = int(sides["ghost_global_ids"][g])
             peer = int(owner[gid])
             f_p = int(sides["side_nbr_face"][s])
-            n_m = int(mesh.deg[e]) + 1
-            n_p = int(sides["ghost_deg"][g]) + 1
             my_gid = mesh.first + e
-            send.setdefault(peer, []).append((my_gid, f, trace_offset(e) + f * 4 * n_m * n_m, 4 * n_m * n_m))
-            recv.setdefault(peer, []).append((gid, f_p, ghost_trace_offset(g) + f_p * 4 * n_p * n_p, 4 * n_p * n_p))
+            ln = int(block_len(s))
+            send.setdefault(peer, []).append((my_gid, f, int(trace_offset(s)), ln))
+            recv.setdefault(peer, []).append((gid, f_p, int(ghost_trace_offset(s)), ln))
         self.peers = sorted(set(send) | set(recv))
         self.send = {p: np.array([(o, l) for _, _, o, l in sorted(send[p])], dtype=np.int64).reshape(-1, 2) for p in self.peers}
         self.recv = {p: np.array([(o, l) for _, _, o, l in sorted(recv[p])], dtype=np.int64).reshape(-1, 2) for p in self.peers}
@@ -139,14 +139,32 @@ class DistTransport:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
+def plan_schedule(plan, mesh, sides, parts):
+    """TraceSchedule with the block offsets of a Plan whose faces are set"""
+    lib, h = plan.lib, plan.handle
+    return TraceSchedule(mesh, sides, parts, lambda s: lib.d4est_hip_plan_trace_offset(h, s),
+                         lambda s: lib.d4est_hip_plan_ghost_trace_offset(h, s), lambda s: lib.d4est_hip_plan_trace_block_len(h, s))
+
+
+def side_block_layout(sides):
+    """(trace_offset, ghost_trace_offset, block_len) per side computed on the host from a side list -- the same layout
+    the C library uses (4 T doubles per side in side order; ghost blocks in side order) -- for CPU-only tests"""
+    stride = np.asarray(sides["side_mortar_stride"], dtype=np.int64)
+    total = int(sides["total_mortar_nodes"])
+    T = np.diff(np.concatenate([stride, [total]]))
+    off = 4 * stride
+    is_ghost = np.asarray(sides["side_nbr"]) <= -2
+    goff = np.full(len(stride), -1, dtype=np.int64)
+    goff[is_ghost] = np.concatenate([[0], np.cumsum(4 * T[is_ghost])[:-1]]) if is_ghost.any() else []
+    return off, goff, 4 * T
+
+
 def attach(plan, mesh, sides, parts, transport, device):
     """Wire a Plan (faces already set) to a transport: installs the exchange / allreduce hooks used by
     apply_lhs, cheby_iterate and cg_eigs.  Returns the TraceExchange (keep it alive)."""
     import ctypes
     import torch
-    sched = TraceSchedule(mesh, sides, parts,
-                          lambda e: plan.lib.d4est_hip_plan_trace_offset(plan.handle, e),
-                          lambda g: plan.lib.d4est_hip_plan_ghost_trace_offset(plan.handle, g))
+    sched = plan_schedule(plan, mesh, sides, parts)
     ex = TraceExchange(sched, transport, plan.copy_blocks, device)
     n_trace, n_ghost = int(plan.trace_size), int(plan.ghost_trace_size)
 

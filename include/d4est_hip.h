@@ -137,11 +137,15 @@ void d4est_hip_plan_set_mortar_geometry(d4est_hip_plan_t* plan, const double* sj
 /* Dirichlet values on the Lobatto face nodes of every boundary side (EVAL_BNDRY_FCN_ON_LOBATTO,
  * d4est_laplacian_flux_sipg.c:80-112); NULL resets to zero (the homogeneous operator used by apply_lhs). */
 void d4est_hip_plan_set_dirichlet_values(d4est_hip_plan_t* plan, const double* g_lobatto, int on_device);
-/* sizes (in doubles) of the local / ghost trace buffers: 24 (deg+1)^2 per element = 6 faces x {u, du/dr_0..2} */
+/* Trace buffers.  For every side s the engine keeps u and du/dr_{0,1,2} INTERPOLATED TO THE SIDE'S MORTAR QUADRATURE
+ * NODES (what d4est_laplacian_flux_interface forms at src/dGMath/d4est_laplacian_flux.c:635-815, once per side instead
+ * of once per flux call): a block of 4 T doubles, T = (deg_mortar_quad+1)^2, field c at c*T, node a + NQ*b in the
+ * side's own face ordering.  Local blocks are in side order; the ghost buffer holds one block per local side whose (+)
+ * element is a ghost (the (+) element's trace on ITS face), also in side order. */
 long long d4est_hip_plan_trace_size(const d4est_hip_plan_t* plan);
 long long d4est_hip_plan_ghost_trace_size(const d4est_hip_plan_t* plan);
-/* ghost traces from whole-element ghost data packed in ghost order (what d4est_ghost_data_exchange delivers,
- * src/Mesh/d4est_ghost_data.c:143-256); a trace-exchange (RCCL) fills the same buffer directly. */
+/* ghost blocks from whole-element ghost data packed in ghost order (what d4est_ghost_data_exchange delivers,
+ * src/Mesh/d4est_ghost_data.c:143-256); a trace exchange (RCCL) fills the same buffer directly. */
 void d4est_hip_compute_ghost_traces(d4est_hip_plan_t* plan, const double* u_ghost_dev, double* ghost_trace_dev);
 /* local traces of u into trace_dev (d4est_hip_plan_trace_size doubles) */
 void d4est_hip_compute_face_traces(d4est_hip_plan_t* plan, const double* u_dev, double* trace_dev);
@@ -182,10 +186,11 @@ double d4est_hip_cg_eigs(d4est_hip_plan_t* plan, double* u_dev, const double* rh
  * memcpy loop of d4est_ghost_data_exchange (src/Mesh/d4est_ghost_data.c:196-236). */
 void d4est_hip_copy_blocks(d4est_hip_plan_t* plan, int n_blocks, const double* src_dev, const long long* src_off_dev,
                            double* dst_dev, const long long* dst_off_dev, const int* len_dev);
-/* offsets (in doubles) of the trace blocks of local element e / ghost element g inside the trace buffers:
- * face f of an element with N nodes per direction starts at offset + f*4*N*N */
-long long d4est_hip_plan_trace_offset(const d4est_hip_plan_t* plan, int element);
-long long d4est_hip_plan_ghost_trace_offset(const d4est_hip_plan_t* plan, int ghost);
+/* offset / length (in doubles) of side s' block in the local trace buffer, and the offset of the block that side s
+ * RECEIVES in the ghost buffer (-1 when its (+) element is not a ghost): the send / receive lists of an exchange */
+long long d4est_hip_plan_trace_offset(const d4est_hip_plan_t* plan, int side);
+long long d4est_hip_plan_ghost_trace_offset(const d4est_hip_plan_t* plan, int side);
+int d4est_hip_plan_trace_block_len(const d4est_hip_plan_t* plan, int side);
 /* deterministic device dot product; result_dev is a device double */
 void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const double* y_dev, double* result_dev);
 

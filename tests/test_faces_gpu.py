@@ -75,24 +75,38 @@ def test_apply_aij_mixed_p(gpu, hiplib, oracle):
         assert _rel(got[s:s + n3], ref[s:s + n3]) <= 20 * RTOL
 
 
-def test_traces_match_dudr(gpu, hiplib, oracle):
-    """trace kernel = slicer of u and of the three dudr fields (d4est_laplacian_flux.c:575-815 inputs)."""
+@pytest.mark.parametrize("deg,inc", [(4, 0), (3, 2), (9, 0)])
+def test_traces_match_reference_chain(gpu, hiplib, oracle, deg, inc):
+    """trace kernel = slicer -> project onto the mortar space -> interpolate to the mortar quadrature nodes, for u and
+    the three dudr fields (d4est_laplacian_flux.c:575-815), evaluated once per side."""
+    import ctypes
     import torch
     from disco4est_amd import mesh as M
-    m = M.BrickMesh(1, 4)
+    m = M.BrickMesh(1, deg, deg_quad_inc=inc)
     J, rst = m.geometry(None); sides = m.build_sides(None); u = m.field()
     plan = _plan(m, J, rst, sides)
     tr = torch.empty(plan.trace_size, dtype=torch.float64, device=gpu)
     plan.compute_face_traces(_t(u, gpu), tr)
-    tr = tr.cpu().numpy().reshape(m.n_elements, 6, 4, 25)
+    tr = tr.cpu().numpy()
     d = oracle.compute_dudr(m, u)
+    n3 = (deg + 1) ** 3
+    pq = deg + inc
+    T = (pq + 1) ** 2
+    I = oracle.lobatto_to_gauss(pq, pq)
     for e in range(m.n_elements):
-        s = m.nodal_stride[e]
+        s0 = m.nodal_stride[e]
         for f in range(6):
-            np.testing.assert_array_equal(tr[e, f, 0], oracle.apply_slicer(np.ascontiguousarray(u[s:s + 125]), f, 4))
-            for c in range(3):
-                ref = oracle.apply_slicer(np.ascontiguousarray(d[c][s:s + 125]), f, 4)
-                assert np.abs(tr[e, f, 1 + c] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1)
+            off = plan.lib.d4est_hip_plan_trace_offset(plan.handle, 6 * e + f)
+            assert plan.lib.d4est_hip_plan_trace_block_len(plan.handle, 6 * e + f) == 4 * T
+            fields = [u] + d
+            for c in range(4):
+                nodal = oracle.apply_slicer(np.ascontiguousarray(fields[c][s0:s0 + n3]), f, deg)
+                mort = np.zeros(T)
+                oracle.lib.oracle_apply_p_prolong(nodal.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), deg, 2, pq,
+                                                  mort.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+                ref = oracle.kron_A1A2x(I, I, mort)
+                got = tr[off + c * T: off + (c + 1) * T]
+                assert np.abs(got - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1)
 
 
 def test_sharded_equals_global(gpu, hiplib, oracle):

@@ -11,11 +11,6 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _offsets(deg):
-    n2 = (np.asarray(deg, dtype=np.int64) + 1) ** 2
-    return np.concatenate([[0], np.cumsum(24 * n2)])
-
-
 def _np_copy_blocks(n, src, src_off, dst, dst_off, length):
     s, d = src.numpy(), dst.numpy()
     for b in range(n):
@@ -23,9 +18,9 @@ def _np_copy_blocks(n, src, src_off, dst, dst_off, length):
         d[do:do + ln] = s[so:so + ln]
 
 
-def _encode(gid, f, n):
+def _encode(gid, f, length):
     """trace block content that identifies (global element, face, entry)"""
-    return gid * 1000.0 + f * 100.0 + np.arange(4 * n * n) / (4.0 * n * n)
+    return gid * 1000.0 + f * 100.0 + np.arange(length) / float(length)
 
 
 def test_partition_by_dofs():
@@ -58,33 +53,29 @@ def _worker(rank, world, port, level, deg_spec, q):
         first, count = parts[rank]
         m = M.BrickMesh(level, deg_global, first=first, count=count)
         sides = m.build_sides(None)
-        toff = _offsets(m.deg)
-        goff = _offsets(sides["ghost_deg"])
-        sched = P.TraceSchedule(m, sides, parts, lambda e: int(toff[e]), lambda g: int(goff[g]))
+        toff, goff, blen = P.side_block_layout(sides)
+        sched = P.TraceSchedule(m, sides, parts, lambda s: toff[s], lambda s: goff[s], lambda s: blen[s])
         # local trace buffer with identifying content
-        trace = np.zeros(int(toff[-1]))
+        trace = np.zeros(int((toff + blen).max()))
         for e in range(m.n_elements):
-            n = int(m.deg[e]) + 1
             for f in range(6):
-                o = int(toff[e]) + f * 4 * n * n
-                trace[o:o + 4 * n * n] = _encode(first + e, f, n)
-        ghost = np.full(int(goff[-1]), np.nan)
+                s = 6 * e + f
+                trace[toff[s]:toff[s] + blen[s]] = _encode(first + e, f, blen[s])
+        n_ghost_doubles = int(blen[goff >= 0].sum())
+        ghost = np.full(n_ghost_doubles, np.nan)
         ex = P.TraceExchange(sched, P.DistTransport(), _np_copy_blocks, torch.device("cpu"))
         tt, gt = torch.from_numpy(trace), torch.from_numpy(ghost)
         ex.begin(tt)
         ex.end(gt)
-        # every ghost face that one of my sides uses must now hold the owner's block
+        # every ghost side must now hold the owner's block of (ghost element, its face)
         nbr = sides["side_nbr"]
         checked = 0
         for s in np.nonzero(nbr <= -2)[0]:
             g = -(int(nbr[s]) + 2)
             f_p = int(sides["side_nbr_face"][s])
-            n = int(sides["ghost_deg"][g]) + 1
-            o = int(goff[g]) + f_p * 4 * n * n
-            np.testing.assert_array_equal(ghost[o:o + 4 * n * n], _encode(int(sides["ghost_global_ids"][g]), f_p, n))
+            np.testing.assert_array_equal(ghost[goff[s]:goff[s] + blen[s]], _encode(int(sides["ghost_global_ids"][g]), f_p, blen[s]))
             checked += 1
-        # blocks nobody needs stay untouched
-        assert np.isnan(ghost).sum() == ghost.size - sum(int(sched.recv_len[p]) for p in sched.peers)
+        assert not np.isnan(ghost).any()
         # scalar reduction used by cg_eigs
         t = torch.tensor([float(rank + 1), 2.0], dtype=torch.float64)
         P.DistTransport().allreduce_sum(t)

@@ -45,8 +45,13 @@ def test_virtual_ranks_match_single_rank(gpu, hiplib, oracle, world, level, deg_
         J, rst = m.geometry(mp); s = m.build_sides(mp)
         plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
         plan.set_geometry(J, rst); plan.set_faces(s)
-        sched = P.TraceSchedule(m, s, parts, lambda e, pl=plan: pl.lib.d4est_hip_plan_trace_offset(pl.handle, e),
-                                lambda g, pl=plan: pl.lib.d4est_hip_plan_ghost_trace_offset(pl.handle, g))
+        sched = P.plan_schedule(plan, m, s, parts)
+        # the host-side layout formula used by the CPU-only tests is the library's layout
+        toff, goff, blen = P.side_block_layout(s)
+        for sd in range(6 * m.n_elements):
+            assert plan.lib.d4est_hip_plan_trace_offset(plan.handle, sd) == toff[sd]
+            assert plan.lib.d4est_hip_plan_ghost_trace_offset(plan.handle, sd) == goff[sd]
+            assert plan.lib.d4est_hip_plan_trace_block_len(plan.handle, sd) == blen[sd]
         ex = P.TraceExchange(sched, _LocalTransport(r, mb), plan.copy_blocks, gpu)
         u = torch.from_numpy(m.field(mp)).to(gpu)
         tr = torch.empty(plan.trace_size, dtype=torch.float64, device=gpu)
