@@ -32,6 +32,8 @@ struct SideDesc {
   int code;           // flip0 | flip1<<1 | transpose<<2   (dGMath/d4est_operators.c:2031-2081)
   int NQ;             // mortar quadrature nodes/dir
   int offC;           // (NQ x N)  side nodes -> mortar quadrature nodes (p-prolong then Lobatto->quadrature)
+  int offCD;          // (NQ x N)  C * D: tangential derivative fused with the interpolation (fast trace kernel)
+  int pad0;
   int offE;           // (N x NQ)  mortar quadrature -> side operator (P^T I^T W)
   int geom;           // scalar stride S of the side (face_geom at 7*S; Dirichlet data at S)
   long long qoff;     // offset of this side's mortar-node trace block (4 T doubles) in the local buffer
@@ -356,12 +358,17 @@ __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/,
 __global__ __launch_bounds__(384) void trace_wave_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
                                                          const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
                                                          const double* __restrict__ face_ops, int n_elem) {
+  // Per side only TWO nodal fields are formed -- the trace tr(a,b) of u and the normal derivative n(a,b) -- because the
+  // tangential derivatives commute with the interpolation:  (C (x) C)(D_a tr) = ((C D) (x) C) tr.  Pass 1 contracts the
+  // face index a with C and CD, pass 2 the index b: 56 FMAs and ~90 LDS reads per lane instead of 152 / 130.
   __shared__ double s_u[512];
   __shared__ double s_D[64];          // zero-padded 8 x 8
-  __shared__ double s_in[6][4][64];
-  __shared__ double s_tmp[6][4][64];
-  __shared__ double s_C[6][64];       // zero-padded 8 x 8
+  __shared__ double s_in[6][2][64];   // tr, n
+  __shared__ double s_tmp[6][3][64];  // C tr, CD tr, C n
+  __shared__ double s_C[6][2][64];    // C, CD zero-padded 8 x 8
   const int f = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 7, hi = lane >> 3;
+  const int dir = f >> 1;
+  const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;  // reference directions of the face indices a and b
   int e = blockIdx.x;
   ElemDesc edn = ed[e < n_elem ? e : 0];
   SideDesc dn = sd[6 * (e < n_elem ? e : 0) + f];
@@ -379,31 +386,73 @@ __global__ __launch_bounds__(384) void trace_wave_kernel(const double* __restric
     double uv0 = 0.0, uv1 = 0.0;
     if ((int)threadIdx.x < N3) uv0 = u[el.ns + threadIdx.x];
     if ((int)threadIdx.x + 384 < N3) uv1 = u[el.ns + threadIdx.x + 384];
-    const double opc = (hi < NQ && lo < N) ? face_ops[d.offC + hi * N + lo] : 0.0;
+    const bool opl = hi < NQ && lo < N;
+    const double opc = opl ? face_ops[d.offC + hi * N + lo] : 0.0;
+    const double opcd = opl ? face_ops[d.offCD + hi * N + lo] : 0.0;
     const double dval = (threadIdx.x < 64) ? face_ops[el.offD + threadIdx.x] : 0.0;
     if ((int)threadIdx.x < N3) s_u[threadIdx.x] = uv0;
     if ((int)threadIdx.x + 384 < N3) s_u[threadIdx.x + 384] = uv1;
     if (threadIdx.x < 64) s_D[threadIdx.x] = dval;
-    s_C[f][lane] = opc;
+    s_C[f][0][lane] = opc;
+    s_C[f][1][lane] = opcd;
     __syncthreads();
-    // nodal traces of this side at lane (a = lo, b = hi)
+    // ---- nodal trace and normal derivative at lane (a = lo, b = hi)
     {
-      double t[4] = {0.0, 0.0, 0.0, 0.0};
+      const int sn = (dir == 0) ? 1 : (dir == 1 ? N : N2);
+      const int sa = (dir == 0) ? N : 1, sb = (dir == 2) ? N : N2;
+      const int fix = face_fix(f, N);
+      double tr = 0.0, nd = 0.0;
       if (lo < N && hi < N) {
+        const int base = lo * sa + hi * sb;
+        tr = s_u[base + fix * sn];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) t[c] = nodal_trace(s_u, s_D, 8, N, f, lo, hi, c);
+        for (int i = 0; i < kFW; ++i) nd = fma(s_D[fix * 8 + i], s_u[base + (i < N ? i : N - 1) * sn], nd);  // padded D columns are 0
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) s_in[f][c][lane] = t[c];
+      s_in[f][0][lane] = tr;
+      s_in[f][1][lane] = nd;
     }
     __syncthreads();
-    double q[4];
-    wave_apply2d<4>(s_C[f], &s_in[f][0][0], &s_tmp[f][0][0], lane, q);
-    if (lo < NQ && hi < NQ) {
-      double* out = qtrace + d.qoff + lo + NQ * hi;
+    // ---- pass 1: lane (a' = lo, b = hi): contract the face index a
+    {
+      double c1[kFW], c2[kFW];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) out[c * T] = q[c];
+      for (int a = 0; a < kFW; ++a) { c1[a] = s_C[f][0][lo * 8 + a]; c2[a] = s_C[f][1][lo * 8 + a]; }
+      double P = 0.0, R = 0.0, S = 0.0;
+#pragma unroll
+      for (int a = 0; a < kFW; ++a) {
+        const double t = s_in[f][0][a + 8 * hi], n = s_in[f][1][a + 8 * hi];
+        P = fma(c1[a], t, P);
+        R = fma(c2[a], t, R);
+        S = fma(c1[a], n, S);
+      }
+      s_tmp[f][0][lane] = P;
+      s_tmp[f][1][lane] = R;
+      s_tmp[f][2][lane] = S;
     }
+    __syncthreads();
+    // ---- pass 2: lane (a' = lo, b' = hi): contract the face index b
+    {
+      double c1[kFW], c2[kFW];
+#pragma unroll
+      for (int b = 0; b < kFW; ++b) { c1[b] = s_C[f][0][hi * 8 + b]; c2[b] = s_C[f][1][hi * 8 + b]; }
+      double qu = 0.0, qtb = 0.0, qta = 0.0, qn = 0.0;
+#pragma unroll
+      for (int b = 0; b < kFW; ++b) {
+        const double P = s_tmp[f][0][lo + 8 * b], R = s_tmp[f][1][lo + 8 * b], S = s_tmp[f][2][lo + 8 * b];
+        qu = fma(c1[b], P, qu);
+        qtb = fma(c2[b], P, qtb);
+        qta = fma(c1[b], R, qta);
+        qn = fma(c1[b], S, qn);
+      }
+      if (lo < NQ && hi < NQ) {
+        double* out = qtrace + d.qoff + lo + NQ * hi;
+        out[0] = qu;
+        out[(1 + dir) * T] = qn;
+        out[(1 + t0) * T] = qta;
+        out[(1 + t1d) * T] = qtb;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -551,6 +600,18 @@ void faces_setup(d4est_hip_plan* plan) {
     op_index[key] = off;
     return off;
   };
+  auto get_CD = [&](int deg_side, int deg_mq) {
+    auto key = std::make_tuple(4, deg_side, deg_mq, 0);
+    auto it = op_index.find(key);
+    if (it != op_index.end()) return it->second;
+    const int offC = get_C(deg_side, deg_mq);
+    std::vector<double> C(ops.begin() + offC, ops.begin() + offC + (size_t)(deg_mq + 1) * (deg_side + 1));
+    std::vector<double> CD = Tables1D::matmul(C, Tables1D::dij(deg_side), deg_mq + 1, deg_side + 1, deg_side + 1);
+    const int off = (int)ops.size();
+    ops.insert(ops.end(), CD.begin(), CD.end());
+    op_index[key] = off;
+    return off;
+  };
   auto get_E = [&](int deg_m, int deg_ml, int deg_mq) {
     auto key = std::make_tuple(1, deg_m, deg_ml, deg_mq);
     auto it = op_index.find(key);
@@ -649,6 +710,8 @@ void faces_setup(d4est_hip_plan* plan) {
       d.code = plan->side_reorder[s];
       d.NQ = deg_mq + 1;
       d.offC = get_C(deg_m, deg_mq);
+      d.offCD = get_CD(deg_m, deg_mq);
+      d.pad0 = 0;
       d.offE = get_E(deg_m, d.kind == 0 ? deg_m : deg_ml, deg_mq);
       d.geom = plan->side_mortar_stride[s];
       d.qoff = plan->trace_offset[s];
