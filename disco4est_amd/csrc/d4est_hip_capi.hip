@@ -166,6 +166,7 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   d4est_hip::faces_destroy(plan);
   (void)hipFree(plan->d_work_p); (void)hipFree(plan->d_work_d); (void)hipFree(plan->d_work_r);
   (void)hipFree(plan->d_reduce); (void)hipFree(plan->d_ghost_trace);
+  if (plan->side_stream) { (void)hipStreamDestroy(plan->side_stream); (void)hipEventDestroy(plan->ev_fork); (void)hipEventDestroy(plan->ev_join); }
   delete plan;
 }
 
@@ -302,6 +303,10 @@ void d4est_hip_apply_flux(d4est_hip_plan_t* plan, const double* trace_dev, const
 void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const double* ghost_trace_dev, double* Au_dev) {
   check_plan(plan, "apply_aij");
   if (!plan->has_faces) D4EST_HIP_ABORT("apply_aij: call plan_set_faces first");
+  if (!ghost_trace_dev && plan->ghost_trace_doubles == 0) {
+    d4est_hip::apply_operator(plan, u_dev, Au_dev);  // two-stream fork-join of the trace and volume kernels
+    return;
+  }
   d4est_hip::launch_stiffness(plan, u_dev, Au_dev);
   d4est_hip::launch_traces(plan, u_dev, plan->d_trace, false);
   d4est_hip::launch_flux(plan, plan->d_trace, ghost_trace_dev, Au_dev);

@@ -134,17 +134,39 @@ void launch_dot(d4est_hip_plan* plan, int n, const double* x, const double* y, d
   HIP_CHECK(hipGetLastError());
 }
 
-// Au = A u with the plan's communication hooks (or without ghosts)
+// Au = A u with the plan's communication hooks (or without ghosts).
+// Fork-join on two streams: the trace kernel (and, through the hooks, the ghost exchange) runs on the plan's side
+// stream while the volume kernel runs on the main stream -- they only share the read-only u -- and the flux kernel
+// joins them.  At config 2 both kernels are latency-structured (~28 us each), so running them side by side hides one.
 void apply_operator(d4est_hip_plan* plan, const double* u, double* Au) {
   if (!plan->has_faces) D4EST_HIP_ABORT("smoother: the plan has no faces (plan_set_faces)");
   ensure_solver_workspace(plan);
-  launch_traces(plan, u, plan->d_trace, false);
-  if (plan->n_ghost > 0) {
-    if (!plan->exchange_fn) D4EST_HIP_ABORT("smoother: plan has ghost elements but no exchange callback (plan_set_comm)");
-    plan->exchange_fn(plan->comm_ctx, 0, plan->d_trace, plan->d_ghost_trace);
+  const bool has_ghost = plan->ghost_trace_doubles > 0;
+  if (has_ghost && !plan->exchange_fn) D4EST_HIP_ABORT("apply_lhs: plan has ghost sides but no exchange callback (plan_set_comm)");
+  const bool fork = plan->tuning[D4EST_HIP_TUNE_OVERLAP_TRACES] != 0 && !has_ghost;
+  if (fork) {
+    if (!plan->side_stream) {
+      HIP_CHECK(hipStreamCreateWithFlags(&plan->side_stream, hipStreamNonBlocking));
+      HIP_CHECK(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming));
+    }
+    hipStream_t main = plan->stream;
+    HIP_CHECK(hipEventRecord(plan->ev_fork, main));
+    HIP_CHECK(hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0));
+    plan->stream = plan->side_stream;
+    launch_traces(plan, u, plan->d_trace, false);
+    plan->stream = main;
+    HIP_CHECK(hipEventRecord(plan->ev_join, plan->side_stream));
+    launch_stiffness(plan, u, Au);
+    HIP_CHECK(hipStreamWaitEvent(main, plan->ev_join, 0));
+    launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au);
+    return;
   }
+  // with ghost sides the exchange callbacks enqueue on the plan's (single) stream: traces, post, volume, complete, flux
+  launch_traces(plan, u, plan->d_trace, false);
+  if (has_ghost) plan->exchange_fn(plan->comm_ctx, 0, plan->d_trace, plan->d_ghost_trace);
   launch_stiffness(plan, u, Au);  // overlaps the exchange: the volume term needs no ghost data
-  if (plan->n_ghost > 0) plan->exchange_fn(plan->comm_ctx, 1, plan->d_trace, plan->d_ghost_trace);
+  if (has_ghost) plan->exchange_fn(plan->comm_ctx, 1, plan->d_trace, plan->d_ghost_trace);
   launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au);
 }
 
