@@ -143,7 +143,9 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au) {
   ensure_solver_workspace(plan);
   const bool has_ghost = plan->ghost_trace_doubles > 0;
   if (has_ghost && !plan->exchange_fn) D4EST_HIP_ABORT("apply_lhs: plan has ghost sides but no exchange callback (plan_set_comm)");
-  const bool fork = plan->tuning[D4EST_HIP_TUNE_OVERLAP_TRACES] != 0 && !has_ghost;
+  // measured: the two cross-stream event waits cost more than the overlap buys (config 2: 119 -> 129 us; 512 elements:
+  // 16 -> 44 us), so the fork is opt-in (tuning value 1) and the default is one stream
+  const bool fork = plan->tuning[D4EST_HIP_TUNE_OVERLAP_TRACES] > 0 && !has_ghost;
   if (fork) {
     if (!plan->side_stream) {
       HIP_CHECK(hipStreamCreateWithFlags(&plan->side_stream, hipStreamNonBlocking));

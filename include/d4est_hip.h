@@ -80,7 +80,7 @@ enum d4est_hip_tuning_key {
   D4EST_HIP_TUNE_STIFFNESS_STAGGER = 2,  /* single-wave kernel: delay (units of 1024 cycles) of every other resident workgroup row */
   D4EST_HIP_TUNE_FLUX_FAST = 3,          /* 0: always the generic flux kernel; else the wave-per-face kernel where all degrees <= 7 */
   D4EST_HIP_TUNE_STIFFNESS_BIGP = 4,     /* p >= 8: 0 three-field kernel, else two-field multi-wave kernel (default) */
-  D4EST_HIP_TUNE_OVERLAP_TRACES = 5,     /* 0: one stream; else the trace kernel runs on a side stream beside the volume kernel */
+  D4EST_HIP_TUNE_OVERLAP_TRACES = 5,     /* 1: the trace kernel runs on a side stream beside the volume kernel (default off: the event waits cost more) */
   D4EST_HIP_TUNE_COUNT = 6
 };
 void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value);
