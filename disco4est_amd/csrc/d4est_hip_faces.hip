@@ -464,7 +464,8 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
   __shared__ double s_in[6][4][64];   // per wave: 4 term fields on the 8 x 8 grid
   __shared__ double s_tmp[6][4][64];
   __shared__ double s_E[6][64];       // per wave: E of its side, zero-padded to 8 x 8
-  __shared__ double s_W[4][512];      // lifted volume fields: W_0 (terms 1+3), W_1..3 (term 2_l)
+  __shared__ double s_W[512];         // lifted face-local part: terms 1+3 and the tangential D^T of term 2
+  __shared__ double s_N[6][64];       // per side: term 2 of the normal direction (D^T spreads it along the normal lines)
   __shared__ double s_D[64];          // zero-padded 8 x 8
   const int f = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 7, hi = lane >> 3;
   // persistent workgroups: the descriptors of the NEXT element are requested while this one is computed
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
     double au0 = 0.0, au1 = 0.0;
     if ((int)threadIdx.x < N3) au0 = Au[el.ns + threadIdx.x];
     if ((int)threadIdx.x + 384 < N3) au1 = Au[el.ns + threadIdx.x + 384];
-    for (int i = threadIdx.x; i < 4 * 512; i += blockDim.x) (&s_W[0][0])[i] = 0.0;
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_W[i] = 0.0;
     s_E[f][lane] = ope;
     if (threadIdx.x < 64) s_D[threadIdx.x] = dval;
     // ---- SIPG terms at the quadrature node of this lane (padding lanes carry zeros)
@@ -525,27 +526,37 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
     // ---- integrate and project onto the (-) side: 4 fields on the N x N face nodes
     double res[4];
     wave_apply2d<4>(s_E[f], &s_in[f][0][0], &s_tmp[f][0][0], lane, res);
-    // ---- lift: scatter into the volume fields, opposite faces together (disjoint node sets)
-    for (int phase = 0; phase < 3; ++phase) {
-      if ((f >> 1) == phase && on_m) {
-        const int v = face_vol_index(f, N, lo, hi);
+    // ---- D^T of the two TANGENTIAL term-2 fields stays inside the face: val = t13 + D_a^T t2_a + D_b^T t2_b
+    const int dir = f >> 1;
+    const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;  // reference directions of the face indices a and b
+    s_in[f][0][lane] = res[1 + t0];
+    s_in[f][1][lane] = res[1 + t1d];
+    s_N[f][lane] = res[1 + dir];
+    __syncthreads();
+    double val = res[0];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s_W[c][v] += res[c];
-      }
+    for (int q = 0; q < kFW; ++q) {
+      val = fma(s_D[q * 8 + lo], s_in[f][0][q + 8 * hi], val);   // padded rows/columns of D are zero
+      val = fma(s_D[q * 8 + hi], s_in[f][1][lo + 8 * q], val);
+    }
+    // ---- lift the face-local part, opposite faces together (disjoint node sets)
+    for (int phase = 0; phase < 3; ++phase) {
+      if (dir == phase && on_m) s_W[face_vol_index(f, N, lo, hi)] += val;
       __syncthreads();
     }
-    // ---- Au_e += W_0 + sum_l D_l^T W_l
+    // ---- Au_e += W + sum over the six sides of D[fix][.] (x) N_f  (the normal D^T touches the whole line)
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       const int idx = threadIdx.x + rep * 384;
       if (idx < N3) {
         const int i = idx % N, j = (idx / N) % N, k = idx / N2;
-        double v = s_W[0][idx];
-        for (int q = 0; q < N; ++q) {
-          v = fma(s_D[q * 8 + i], s_W[1][q + N * (j + N * k)], v);
-          v = fma(s_D[q * 8 + j], s_W[2][i + N * (q + N * k)], v);
-          v = fma(s_D[q * 8 + k], s_W[3][i + N * (j + N * q)], v);
-        }
+        double v = s_W[idx];
+        v = fma(s_D[i], s_N[0][j + 8 * k], v);
+        v = fma(s_D[(N - 1) * 8 + i], s_N[1][j + 8 * k], v);
+        v = fma(s_D[j], s_N[2][i + 8 * k], v);
+        v = fma(s_D[(N - 1) * 8 + j], s_N[3][i + 8 * k], v);
+        v = fma(s_D[k], s_N[4][i + 8 * j], v);
+        v = fma(s_D[(N - 1) * 8 + k], s_N[5][i + 8 * j], v);
         Au[el.ns + idx] = (rep == 0 ? au0 : au1) + v;
       }
     }
@@ -876,7 +887,7 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     // persistent grid: 3 workgroups per CU are resident (LDS), each loops over elements
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-    const int resident = 3 * cus;
+    const int resident = 4 * cus;
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     hipLaunchKernelGGL(flux_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,

@@ -1259,11 +1259,11 @@ __global__ __launch_bounds__(64, 4) void stiffness_stream_only_kernel(const doub
 //   MODE 2: out_quad = V in               (interpolate)     in: nodal, out: quad
 // ---------------------------------------------------------------------------
 template <int N, int NQ, int MODE>
-__global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void mass_like_kernel(
+__global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
     const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ Jq,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list,
     int n_bucket, const double* __restrict__ Bop, const double* __restrict__ BopT, const double* __restrict__ wq) {
-  using C = VolCfg<N, NQ>;
+  using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ;
   constexpr int N3 = N * N * N;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1483,10 +1483,10 @@ __global__ __launch_bounds__(256) void generic_volume_kernel(
 // collocation derivatives  dudr_i = D_i u   (3 outputs), one element per NxN threads
 // ---------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__((VolCfg<N, N>::THREADS)) void dudr_kernel(
+__global__ __launch_bounds__((WaveCfg<N, N>::THREADS)) void dudr_kernel(
     const double* __restrict__ u, double* __restrict__ d0, double* __restrict__ d1, double* __restrict__ d2,
     const int* __restrict__ ns_list, int n_bucket, const double* __restrict__ DopT) {
-  using C = VolCfg<N, N>;
+  using C = WaveCfg<N, N>;
   constexpr int PL = C::PL, PN = C::PN, N3 = N * N * N;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
@@ -1723,7 +1723,7 @@ static void launch_mass_like_mode(d4est_hip_plan* plan, const double* in, double
     bool done = false;
 #define X(N_, NQ_)                                                                                                    \
   if (!done && bk.N == N_ && bk.NQ == NQ_) {                                                                          \
-    using C = VolCfg<N_, NQ_>;                                                                                        \
+    using C = WaveCfg<N_, NQ_>;                                                                                         \
     if (C::LDS_BYTES <= 160 * 1024) {                                                                                 \
       set_lds_limit(mass_like_kernel<N_, NQ_, MODE>, C::LDS_BYTES);                                                   \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                             \
@@ -1754,7 +1754,7 @@ void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, 
     bool done = false;
 #define X(N_, NQ_)                                                                                         \
   if (!done && N_ == NQ_ && bk.N == N_) {                                                                  \
-    using C = VolCfg<N_, N_>;                                                                              \
+    using C = WaveCfg<N_, N_>;                                                                               \
     if (C::LDS_BYTES <= 160 * 1024) {                                                                      \
       set_lds_limit(dudr_kernel<N_>, C::LDS_BYTES);                                                        \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                  \
