@@ -95,9 +95,6 @@ def main():
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    if build.needs_build():
-        if rank == 0:
-            build.build_library(verbose=False)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -105,7 +102,15 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        try:
+            dist.init_process_group(backend="nccl", device_id=dev)
+        except TypeError:  # older signature without device_id
+            dist.init_process_group(backend="nccl")
+        dist.barrier()
+    # the library normally travels pre-built; if the sources look newer, rank 0 rebuilds and everybody waits
+    if build.needs_build() and rank == 0:
+        build.build_library(verbose=False)
+    if dist is not None:
         dist.barrier()
 
     # ---- workload: config 2 of BASELINE.json, one brick per rank (weak scaling)
