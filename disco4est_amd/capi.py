@@ -39,6 +39,10 @@ SIGNATURES = {
     "d4est_hip_apply_mass_matrix": (None, [_vp, _vp, _vp]),
     "d4est_hip_apply_galerkin_integral": (None, [_vp, _vp, _vp]),
     "d4est_hip_interpolate": (None, [_vp, _vp, _vp]),
+    "d4est_hip_apply_weighted_mass_matrix": (None, [_vp, _vp, _vp, _vp]),
+    "d4est_hip_apply_inverse_mass_matrix": (None, [_vp, _vp, _vp]),
+    "d4est_hip_apply_mij": (None, [_vp, _vp, _vp]),
+    "d4est_hip_apply_invmij": (None, [_vp, _vp, _vp]),
     "d4est_hip_compute_dudr": (None, [_vp, _vp, _vp, _vp, _vp]),
     "d4est_hip_plan_set_faces": (None, [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _c_int_p, _c_int_p]),
@@ -173,6 +177,23 @@ class Plan:
     def interpolate(self, u, u_quad):
         assert u.numel() == self.local_nodes and u_quad.numel() == self.local_nodes_quad
         self.lib.d4est_hip_interpolate(self.handle, _ptr(u), _ptr(u_quad))
+
+    def apply_weighted_mass_matrix(self, u, coeff_quad, out):
+        assert u.numel() == self.local_nodes and out.numel() == self.local_nodes
+        assert coeff_quad.numel() == self.local_nodes_quad
+        self.lib.d4est_hip_apply_weighted_mass_matrix(self.handle, _ptr(u), _ptr(coeff_quad), _ptr(out))
+
+    def apply_inverse_mass_matrix(self, x, out):
+        assert x.numel() == self.local_nodes and out.numel() == self.local_nodes
+        self.lib.d4est_hip_apply_inverse_mass_matrix(self.handle, _ptr(x), _ptr(out))
+
+    def apply_mij(self, x, out):
+        assert x.numel() == self.local_nodes and out.numel() == self.local_nodes
+        self.lib.d4est_hip_apply_mij(self.handle, _ptr(x), _ptr(out))
+
+    def apply_invmij(self, x, out):
+        assert x.numel() == self.local_nodes and out.numel() == self.local_nodes
+        self.lib.d4est_hip_apply_invmij(self.handle, _ptr(x), _ptr(out))
 
     def compute_dudr(self, u, d0, d1, d2):
         for t in (u, d0, d1, d2):

@@ -132,6 +132,18 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
     bk.d_GT = upload(Tables1D::transpose(G, bk.NQ, bk.N));
     bk.d_DT = upload(Tables1D::transpose(D, bk.N, bk.N));
     bk.d_w = upload(Tables1D::quad_weights(quad_type, bk.deg_quad));
+    std::vector<double> M = Tables1D::mij(bk.deg), Minv = Tables1D::invmij(bk.deg);
+    bk.d_M = upload(M);
+    bk.d_MT = upload(Tables1D::transpose(M, bk.N, bk.N));
+    bk.d_Minv = upload(Minv);
+    bk.d_MinvT = upload(Tables1D::transpose(Minv, bk.N, bk.N));
+    if (bk.N == bk.NQ) {
+      std::vector<double> Binv = Tables1D::lobatto_to_gauss(bk.deg, bk.deg);
+      if (!Tables1D::invert(Binv, bk.N)) D4EST_HIP_ABORT("plan_create: singular lobatto_to_gauss interpolation at deg %d", bk.deg);
+      bk.d_Binv = upload(Binv);
+      bk.d_BinvT = upload(Tables1D::transpose(Binv, bk.N, bk.N));
+      bk.d_wGL = upload(Tables1D::quad_weights(d4est_hip::QUAD_LEGENDRE, bk.deg));
+    }
     plan->buckets.push_back(bk);
   }
   std::vector<int> ns_list(ids.size()), qs_list(ids.size());
@@ -156,6 +168,13 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
     (void)hipFree(bk.d_BT);
     (void)hipFree(bk.d_GT);
     (void)hipFree(bk.d_DT);
+    (void)hipFree(bk.d_M);
+    (void)hipFree(bk.d_MT);
+    (void)hipFree(bk.d_Minv);
+    (void)hipFree(bk.d_MinvT);
+    (void)hipFree(bk.d_Binv);
+    (void)hipFree(bk.d_BinvT);
+    (void)hipFree(bk.d_wGL);
   }
   (void)hipFree(plan->d_elem_ids);
   (void)hipFree(plan->d_ns_list);
@@ -228,6 +247,27 @@ void d4est_hip_apply_galerkin_integral(d4est_hip_plan_t* plan, const double* f_q
 void d4est_hip_interpolate(d4est_hip_plan_t* plan, const double* u_dev, double* u_quad_dev) {
   check_plan(plan, "interpolate");
   d4est_hip::launch_mass_like(plan, 2, u_dev, u_quad_dev);
+}
+
+void d4est_hip_apply_weighted_mass_matrix(d4est_hip_plan_t* plan, const double* u_dev, const double* coeff_quad_dev, double* out_dev) {
+  check_plan(plan, "apply_weighted_mass_matrix");
+  if (!coeff_quad_dev) D4EST_HIP_ABORT("apply_weighted_mass_matrix: coeff_quad is NULL");
+  d4est_hip::launch_mass_like(plan, 3, u_dev, out_dev, coeff_quad_dev, 0);
+}
+
+void d4est_hip_apply_inverse_mass_matrix(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev) {
+  check_plan(plan, "apply_inverse_mass_matrix");
+  d4est_hip::launch_mass_like(plan, 4, in_dev, out_dev, nullptr, 1);
+}
+
+void d4est_hip_apply_mij(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev) {
+  check_plan(plan, "apply_mij");
+  d4est_hip::launch_mass_like(plan, 2, in_dev, out_dev, nullptr, 2);
+}
+
+void d4est_hip_apply_invmij(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev) {
+  check_plan(plan, "apply_invmij");
+  d4est_hip::launch_mass_like(plan, 2, in_dev, out_dev, nullptr, 3);
 }
 
 void d4est_hip_compute_dudr(d4est_hip_plan_t* plan, const double* u_dev, double* dudr0_dev, double* dudr1_dev, double* dudr2_dev) {

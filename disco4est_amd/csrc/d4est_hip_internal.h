@@ -39,6 +39,15 @@ struct Bucket {
   double* d_BT = nullptr;   // N x NQ  transposes (row i = column i of the operator: one scalar load feeds NQ FMA chains)
   double* d_GT = nullptr;
   double* d_DT = nullptr;
+  // square N x N tables for the nodal mass applies (d4est_operators.c:891-928) and the Gauss inverse mass
+  // (d4est_quadrature.c:1222-1331; only when deg_quad == deg, else null)
+  double* d_M = nullptr;
+  double* d_MT = nullptr;
+  double* d_Minv = nullptr;
+  double* d_MinvT = nullptr;
+  double* d_Binv = nullptr;   // (lobatto_to_gauss_interp)^-1
+  double* d_BinvT = nullptr;  // its transpose = (lobatto_to_gauss_interp_trans)^-1
+  double* d_wGL = nullptr;    // Gauss weights
 };
 
 }  // namespace d4est_hip
@@ -103,7 +112,9 @@ namespace d4est_hip {
 // d4est_hip_volume.hip
 void launch_metric_precombine(d4est_hip_plan* plan, const double* d_J, const double* d_rst);
 void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
-void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out);
+// mode: 0 mass, 1 galerkin, 2 interpolate / square tensor apply, 3 weighted mass, 4 inverse mass;
+// which: 0 quadrature interpolation, 1 inverse Gauss interpolation, 2 M (1-D mass), 3 M^-1
+void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out, const double* coeff = nullptr, int which = 0);
 void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, double* d2);
 
 // d4est_hip_faces.hip

@@ -1256,13 +1256,17 @@ __global__ __launch_bounds__(64, 4) void stiffness_stream_only_kernel(const doub
 // mass-like applies (one field):
 //   MODE 0: out = V^T (W J) V in          (mass)            in: nodal, out: nodal
 //   MODE 1: out = V^T (W J) in_quad       (galerkin)        in: quad,  out: nodal
-//   MODE 2: out_quad = V in               (interpolate)     in: nodal, out: quad
+//   MODE 2: out_quad = V in               (interpolate)     in: nodal, out: quad  (also any square tensor apply A(x)A(x)A)
+//   MODE 3: out = V^T (W J c) V in        (weighted mass: d4est_quadrature_apply_fofufofvlilj with the coefficient
+//                                          f(u) f(v) given at the quadrature nodes, d4est_quadrature.c:593-774)
+//   MODE 4: out = V^-1 (W J)^-1 V^-T in   (inverse mass, d4est_quadrature.c:1222-1331; Bop = V^-T, BopT = V^-1)
 // ---------------------------------------------------------------------------
 template <int N, int NQ, int MODE>
 __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
     const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ Jq,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list,
-    int n_bucket, const double* __restrict__ Bop, const double* __restrict__ BopT, const double* __restrict__ wq) {
+    int n_bucket, const double* __restrict__ Bop, const double* __restrict__ BopT, const double* __restrict__ wq,
+    const double* __restrict__ coeff) {
   using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ;
   constexpr int N3 = N * N * N;
@@ -1334,7 +1338,13 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
   if (active) {
     const double wab = wq[a] * wq[b];
 #pragma unroll
-    for (int kq = 0; kq < NQ; ++kq) g[kq] *= (wq[kq] * wab) * Jq[qs + a + NQ * (b + NQ * kq)];
+    for (int kq = 0; kq < NQ; ++kq) {
+      const int q = qs + a + NQ * (b + NQ * kq);
+      double sc = (wq[kq] * wab) * Jq[q];
+      if (MODE == 3) sc *= coeff[q];
+      if (MODE == 4) g[kq] = (1. / sc) * g[kq];  // d4est_kron_oneover_vec_o_vec_o_vec_dot_oneover_x_dot_y (d4est_kron.h:387-397)
+      else g[kq] *= sc;
+    }
     contract_t<NQ, N, false>(Bop, g, c);
   }
   __syncthreads();
@@ -1402,11 +1412,11 @@ __device__ void gen_apply(const double* __restrict__ op, int rows, int so, int s
 }
 
 __global__ __launch_bounds__(256) void generic_volume_kernel(
-    int mode /* 0 mass, 1 galerkin, 2 interp, 3 stiffness */, const double* __restrict__ in, double* __restrict__ out,
+    int mode /* 0 mass, 1 galerkin, 2 interp / square tensor apply, 3 stiffness, 4 weighted mass, 5 inverse mass */, const double* __restrict__ in, double* __restrict__ out,
     const double* __restrict__ metric, const double* __restrict__ Jq, const int* __restrict__ ns_list,
     const int* __restrict__ qs_list, int n_bucket, int N, int NQ,
     const double* __restrict__ Bop, const double* __restrict__ Gop, const double* __restrict__ wq, double* scratch,
-    size_t scratch_per_block) {
+    size_t scratch_per_block, const double* __restrict__ coeff) {
   const int NM = N > NQ ? N : NQ;
   const size_t A = (size_t)NM * NM * NM;
   double* s = scratch + (size_t)blockIdx.x * scratch_per_block;
@@ -1466,7 +1476,9 @@ __global__ __launch_bounds__(256) void generic_volume_kernel(
       }
       for (int q = threadIdx.x; q < NQ3; q += blockDim.x) {
         const int iq = q % NQ, jq = (q / NQ) % NQ, kq = q / (NQ * NQ);
-        t3[q] = gq[q] * (wq[kq] * (wq[iq] * wq[jq])) * Jq[qs + q];
+        double sc = (wq[kq] * (wq[iq] * wq[jq])) * Jq[qs + q];
+        if (mode == 4) sc *= coeff[qs + q];           // weighted mass
+        t3[q] = (mode == 5) ? (1. / sc) * gq[q] : gq[q] * sc;  // 5: inverse mass
       }
       __syncthreads();
       GenDims dq = {{NQ, NQ, NQ}};
@@ -1603,14 +1615,20 @@ static void ensure_scratch(d4est_hip_plan* plan, size_t doubles) {
   plan->scratch_doubles = doubles;
 }
 
-static void launch_generic(d4est_hip_plan* plan, const Bucket& bk, int mode, const double* in, double* out) {
-  const int NM = bk.N > bk.NQ ? bk.N : bk.NQ;
+static void launch_generic(d4est_hip_plan* plan, const Bucket& bk, int mode, const double* in, double* out,
+                           const double* coeff = nullptr, const double* op = nullptr, const int* qs_list = nullptr, int NQe = -1,
+                           const double* wts = nullptr) {
+  if (!wts) wts = bk.d_w;
+  if (!op) op = bk.d_B;
+  if (!qs_list) qs_list = plan->d_qs_list + bk.elem_offset;
+  if (NQe < 0) NQe = bk.NQ;
+  const int NM = bk.N > NQe ? bk.N : NQe;
   const size_t per_block = (size_t)8 * NM * NM * NM;
   const int grid = bk.n_elem < 1024 ? bk.n_elem : 1024;
   ensure_scratch(plan, per_block * grid);
   hipLaunchKernelGGL(generic_volume_kernel, dim3(grid), dim3(256), 0, plan->stream, mode, in, out, plan->d_metric, plan->d_J,
-                     plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.N, bk.NQ,
-                     bk.d_B, bk.d_G, bk.d_w, plan->d_scratch, per_block);
+                     plan->d_ns_list + bk.elem_offset, qs_list, bk.n_elem, bk.N, NQe, op, bk.d_G, wts, plan->d_scratch,
+                     per_block, coeff);
 }
 
 template <int N, int NQ>
@@ -1716,35 +1734,45 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   HIP_CHECK(hipGetLastError());
 }
 
+// which = 0: the quadrature interpolation B; 1: B^-1 (inverse mass); 2: 1-D mass M; 3: M^-1 (square nodal applies)
 template <int MODE>
-static void launch_mass_like_mode(d4est_hip_plan* plan, const double* in, double* out) {
+static void launch_mass_like_mode(d4est_hip_plan* plan, const double* in, double* out, const double* coeff, int which) {
   for (const Bucket& bk : plan->buckets) {
     if (bk.n_elem == 0) continue;
+    if (which == 1 && bk.N != bk.NQ) D4EST_HIP_ABORT("apply_inverse_mass_matrix needs deg_quad == deg (reference asserts the same, d4est_quadrature.c:1233)");
+    const double* op = which == 0 ? bk.d_B : (which == 1 ? bk.d_BinvT : (which == 2 ? bk.d_M : bk.d_Minv));
+    const double* opT = which == 0 ? bk.d_BT : (which == 1 ? bk.d_Binv : (which == 2 ? bk.d_MT : bk.d_MinvT));
+    // square nodal applies write to the nodal layout
+    const int* qs_list = (which >= 2) ? plan->d_ns_list + bk.elem_offset : plan->d_qs_list + bk.elem_offset;
+    const int NQe = (which >= 2) ? bk.N : bk.NQ;
+    const double* wts = (which == 1) ? bk.d_wGL : bk.d_w;  // the inverse mass is always Gauss-Legendre (d4est_quadrature.c:1239-1241)
     bool done = false;
 #define X(N_, NQ_)                                                                                                    \
-  if (!done && bk.N == N_ && bk.NQ == NQ_) {                                                                          \
-    using C = WaveCfg<N_, NQ_>;                                                                                         \
+  if (!done && bk.N == N_ && NQe == NQ_) {                                                                            \
+    using C = WaveCfg<N_, NQ_>;                                                                                       \
     if (C::LDS_BYTES <= 160 * 1024) {                                                                                 \
       set_lds_limit(mass_like_kernel<N_, NQ_, MODE>, C::LDS_BYTES);                                                   \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                             \
       hipLaunchKernelGGL((mass_like_kernel<N_, NQ_, MODE>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, \
-                         in, out, plan->d_J, plan->d_ns_list + bk.elem_offset,                                        \
-                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_BT, bk.d_w);                                             \
+                         in, out, plan->d_J, plan->d_ns_list + bk.elem_offset, qs_list, bk.n_elem, op, opT, wts,       \
+                         coeff);                                                                                      \
       done = true;                                                                                                    \
     }                                                                                                                 \
   }
     D4EST_HIP_FAST_PAIRS(X)
 #undef X
-    if (!done) launch_generic(plan, bk, MODE, in, out);
+    if (!done) launch_generic(plan, bk, MODE == 3 ? 4 : (MODE == 4 ? 5 : MODE), in, out, coeff, op, qs_list, NQe, wts);
   }
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out) {
+void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out, const double* coeff, int which) {
   if (mode != 2 && !plan->has_geometry) D4EST_HIP_ABORT("mass/galerkin apply: d4est_hip_plan_set_geometry was not called");
-  if (mode == 0) launch_mass_like_mode<0>(plan, in, out);
-  else if (mode == 1) launch_mass_like_mode<1>(plan, in, out);
-  else if (mode == 2) launch_mass_like_mode<2>(plan, in, out);
+  if (mode == 0) launch_mass_like_mode<0>(plan, in, out, coeff, which);
+  else if (mode == 1) launch_mass_like_mode<1>(plan, in, out, coeff, which);
+  else if (mode == 2) launch_mass_like_mode<2>(plan, in, out, coeff, which);
+  else if (mode == 3) launch_mass_like_mode<3>(plan, in, out, coeff, which);
+  else if (mode == 4) launch_mass_like_mode<4>(plan, in, out, coeff, which);
   else D4EST_HIP_ABORT("launch_mass_like: bad mode %d", mode);
 }
 

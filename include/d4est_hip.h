@@ -110,6 +110,20 @@ void d4est_hip_apply_mass_matrix(d4est_hip_plan_t* plan, const double* u_dev, do
 void d4est_hip_apply_galerkin_integral(d4est_hip_plan_t* plan, const double* f_quad_dev, double* out_dev);
 /* u_quad = V u : d4est_quadrature_interpolate (d4est_quadrature.c:966-1016) */
 void d4est_hip_interpolate(d4est_hip_plan_t* plan, const double* u_dev, double* u_quad_dev);
+/* out = V^T (W J c) V u : d4est_quadrature_apply_fofufofvlilj with QUAD_APPLY_MATRIX (d4est_quadrature.c:593-774) =
+ * d4est_quadrature_apply_mass_matrix with jac_quad replaced by jac_quad * f(u) f(v).  The reference evaluates the
+ * callbacks f(u), f(v) on the host at the quadrature nodes (:661-683); here the caller hands their product
+ * coeff_quad_dev (local_nodes_quad doubles, element e at quad_stride[e]) -- e.g. d4est_hip_interpolate + one
+ * elementwise kernel of its own. */
+void d4est_hip_apply_weighted_mass_matrix(d4est_hip_plan_t* plan, const double* u_dev, const double* coeff_quad_dev, double* out_dev);
+/* out = V^-1 (W J)^-1 V^-T in : d4est_quadrature_apply_inverse_mass_matrix (d4est_quadrature.c:1222-1331).  As in the
+ * reference this is always Gauss-Legendre and needs deg_quad == deg on every element (the assert at :1233); aborts
+ * otherwise. */
+void d4est_hip_apply_inverse_mass_matrix(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev);
+/* out = (M (x) M (x) M) in and (M^-1 (x) M^-1 (x) M^-1) in per element, M the 1-D reference mass matrix:
+ * d4est_operators_apply_mij / d4est_operators_apply_invmij (d4est_operators.c:891-928), batched over the plan. */
+void d4est_hip_apply_mij(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev);
+void d4est_hip_apply_invmij(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev);
 /* dudr_i = D_i u, i = 0..2 : d4est_laplacian_compute_dudr (d4est_laplacian.c:237-282), 3 applies of
  * d4est_operators_apply_dij (d4est_operators.c:1385-1410) per element. */
 void d4est_hip_compute_dudr(d4est_hip_plan_t* plan, const double* u_dev, double* dudr0_dev, double* dudr1_dev, double* dudr2_dev);

@@ -750,6 +750,42 @@ void oracle_quadrature_interpolate(int quad_type, const double* in, int deg_loba
   oracle_kron_A1A2A3x_nonsqr(out_quad, qt->interp, qt->interp, qt->interp, in, nq, nl, nq, nl, nq, nl);
 }
 
+/* d4est_quadrature.c:1222-1331 (dim == 3 branch, :1288-1324).  Always Gauss-Legendre, deg_Gauss == deg_Lobatto
+ * (assert :1233).  The two inverse tables are d4est_linalg_invert of the interpolation and of its transpose
+ * (d4est_operators.c:494-520). */
+void oracle_quadrature_apply_inverse_mass_matrix(const double* in, int deg_lobatto, const double* jac_gauss, int deg_gauss, double* out) {
+  if (deg_lobatto != deg_gauss) ORACLE_ABORT("inverse mass: deg_Lobatto != deg_Gauss");
+  int n = deg_lobatto + 1, v = n * n * n;
+  quad_tables_t* qt = get_quad(0, deg_lobatto, deg_gauss);
+  double* inv = dalloc(n * n);
+  double* inv_t = dalloc(n * n);
+  for (int i = 0; i < n * n; i++) { inv[i] = qt->interp[i]; inv_t[i] = qt->interp_t[i]; }
+  if (oracle_linalg_invert(inv, n) || oracle_linalg_invert(inv_t, n)) ORACLE_ABORT("inverse mass: singular interpolation");
+  double* in_gauss = dalloc(v);
+  double* one_over = dalloc(v);
+  oracle_kron_A1A2A3x_nonsqr(in_gauss, inv_t, inv_t, inv_t, in, n, n, n, n, n, n);
+  /* d4est_kron_oneover_vec_o_vec_o_vec_dot_oneover_x_dot_y, d4est_kron.h:386-397 */
+  for (int m = 0; m < n; m++)
+    for (int i = 0; i < n; i++)
+      for (int k = 0; k < n; k++) {
+        int q = k + i * n + m * n * n;
+        one_over[q] = (1. / (qt->w[m] * qt->w[i] * qt->w[k] * jac_gauss[q])) * in_gauss[q];
+      }
+  oracle_kron_A1A2A3x_nonsqr(out, inv, inv, inv, one_over, n, n, n, n, n, n);
+  free(inv); free(inv_t); free(in_gauss); free(one_over);
+}
+
+/* d4est_quadrature.c:593-774, QUAD_APPLY_MATRIX, interpolate_f == 0, volume object: the callbacks' product f(u) f(v)
+ * at the quadrature nodes is handed over as coeff_quad (what :661-683 builds), then :731-746. */
+void oracle_quadrature_apply_fofufofvlilj(int quad_type, const double* vec, int deg_lobatto, const double* coeff_quad,
+        const double* jac_quad, int deg_quad, double* out) {
+  int nq = deg_quad + 1, vq = nq * nq * nq;
+  double* fofu_fofv_jac = dalloc(vq);
+  for (int i = 0; i < vq; i++) { fofu_fofv_jac[i] = jac_quad[i]; fofu_fofv_jac[i] *= coeff_quad[i]; }
+  oracle_quadrature_apply_mass_matrix(quad_type, vec, deg_lobatto, fofu_fofv_jac, deg_quad, out);
+  free(fofu_fofv_jac);
+}
+
 /* ------------------------------------------------------------------------- */
 /* Laplacian element loops                                                    */
 /* ------------------------------------------------------------------------- */
@@ -783,6 +819,28 @@ void oracle_laplacian_apply_mass_matrix(int quad_type, int n_elements, const int
 #endif
   for (int e = 0; e < n_elements; e++)
     oracle_quadrature_apply_mass_matrix(quad_type, &u[nodal_stride[e]], deg[e], &J_quad[quad_stride[e]], deg_quad[e], &Mu[nodal_stride[e]]);
+}
+
+/* element loops for the remaining per-element applies (the reference calls them inside element loops of the same shape,
+ * e.g. Solver/d4est_solver_jacobi.c, Estimators) */
+void oracle_elements_apply_weighted_mass_matrix(int quad_type, int n_elements, const int* deg, const int* deg_quad,
+        const int* nodal_stride, const int* quad_stride, const double* J_quad, const double* coeff_quad, const double* u, double* out) {
+  for (int e = 0; e < n_elements; e++)
+    oracle_quadrature_apply_fofufofvlilj(quad_type, &u[nodal_stride[e]], deg[e], &coeff_quad[quad_stride[e]], &J_quad[quad_stride[e]],
+                                         deg_quad[e], &out[nodal_stride[e]]);
+}
+
+void oracle_elements_apply_inverse_mass_matrix(int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
+        const int* quad_stride, const double* J_quad, const double* in, double* out) {
+  for (int e = 0; e < n_elements; e++)
+    oracle_quadrature_apply_inverse_mass_matrix(&in[nodal_stride[e]], deg[e], &J_quad[quad_stride[e]], deg_quad[e], &out[nodal_stride[e]]);
+}
+
+void oracle_elements_apply_mij(int n_elements, const int* deg, const int* nodal_stride, const double* in, double* out, int inverse) {
+  for (int e = 0; e < n_elements; e++) {
+    if (inverse) oracle_apply_invmij(&in[nodal_stride[e]], deg[e], &out[nodal_stride[e]]);
+    else oracle_apply_mij(&in[nodal_stride[e]], deg[e], &out[nodal_stride[e]]);
+  }
 }
 
 /* d4est_laplacian.c:237-282 (local elements) */

@@ -94,6 +94,15 @@ void oracle_quadrature_apply_galerkin_integral(int quad_type, const double* in_q
         const double* jac_quad, int deg_quad, double* out);                                         /* :142-213 */
 void oracle_quadrature_interpolate(int quad_type, const double* in, int deg_lobatto, double* out_quad, int deg_quad); /* :966-1016 */
 
+void oracle_quadrature_apply_inverse_mass_matrix(const double* in, int deg_lobatto, const double* jac_gauss, int deg_gauss, double* out); /* :1222-1331 */
+void oracle_quadrature_apply_fofufofvlilj(int quad_type, const double* vec, int deg_lobatto, const double* coeff_quad,
+        const double* jac_quad, int deg_quad, double* out);                                         /* :593-774 (coeff = f(u) f(v) at the quadrature nodes) */
+void oracle_elements_apply_weighted_mass_matrix(int quad_type, int n_elements, const int* deg, const int* deg_quad,
+        const int* nodal_stride, const int* quad_stride, const double* J_quad, const double* coeff_quad, const double* u, double* out);
+void oracle_elements_apply_inverse_mass_matrix(int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
+        const int* quad_stride, const double* J_quad, const double* in, double* out);
+void oracle_elements_apply_mij(int n_elements, const int* deg, const int* nodal_stride, const double* in, double* out, int inverse);
+
 /* ---- Laplacian element loops (dGMath/d4est_laplacian.c) on a flat element list ---- */
 /* element e: deg[e], deg_quad[e], nodal_stride[e], quad_stride[e] (Mesh/d4est_element_data.h:13-48);
  * J_quad[local_nodes_quad]; rst_xyz_quad[(3*i+j)*local_nodes_quad + quad_stride + n] (Mesh/d4est_mesh.c:2757-2776) */

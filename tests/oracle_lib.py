@@ -154,6 +154,24 @@ class Oracle:
             P(J), P(u), P(Mu), nthreads)
         return Mu
 
+    def apply_weighted_mass(self, mesh, J, coeff_q, u):
+        out = np.zeros(mesh.local_nodes)
+        self.lib.oracle_elements_apply_weighted_mass_matrix(
+            mesh.quad_type, mesh.n_elements, I(mesh.deg), I(mesh.deg_quad), I(mesh.nodal_stride), I(mesh.quad_stride),
+            P(J), P(coeff_q), P(u), P(out))
+        return out
+
+    def apply_inverse_mass(self, mesh, J, x):
+        out = np.zeros(mesh.local_nodes)
+        self.lib.oracle_elements_apply_inverse_mass_matrix(
+            mesh.n_elements, I(mesh.deg), I(mesh.deg_quad), I(mesh.nodal_stride), I(mesh.quad_stride), P(J), P(x), P(out))
+        return out
+
+    def apply_mij(self, mesh, x, inverse=False):
+        out = np.zeros(mesh.local_nodes)
+        self.lib.oracle_elements_apply_mij(mesh.n_elements, I(mesh.deg), I(mesh.nodal_stride), P(x), P(out), int(inverse))
+        return out
+
     def apply_galerkin(self, mesh, J, fq):
         out = np.zeros(mesh.local_nodes)
         for e in range(mesh.n_elements):

@@ -165,3 +165,27 @@ def test_mass_galerkin_interp(oracle):
     vol = oracle.apply_mass(m, J, one).sum()
     # volume of the mapped cube: map is the identity on the boundary -> volume 1
     assert abs(vol - 1.0) < 1e-6
+
+
+def test_inverse_mass_and_weighted_mass(oracle):
+    """oracle_quadrature_apply_inverse_mass_matrix inverts the Gauss mass matrix (d4est_quadrature.c:1222-1331 is
+    V^-1 (WJ)^-1 V^-T by construction); the weighted mass with coefficient 1 is the mass matrix, and is linear in
+    the coefficient (d4est_quadrature.c:661-683)."""
+    from disco4est_amd import mesh as M
+    for deg in (1, 2, 4, 7):
+        m = M.BrickMesh(1, deg)
+        mp = M.SineMap(0.06)
+        J, rst = m.geometry(mp)
+        u = m.field(mp)
+        Mu = oracle.apply_mass(m, J, u)
+        back = oracle.apply_inverse_mass(m, J, Mu)
+        assert np.abs(back - u).max() <= 1e-11 * np.abs(u).max()
+        ones = np.ones(m.local_nodes_quad)
+        assert np.array_equal(oracle.apply_weighted_mass(m, J, ones, u), Mu)
+        c = 1.0 + np.cos(np.arange(m.local_nodes_quad) * 0.37) ** 2
+        a = oracle.apply_weighted_mass(m, J, c, u)
+        b = oracle.apply_weighted_mass(m, J, 2 * c, u)
+        assert np.abs(b - 2 * a).max() <= 1e-13 * np.abs(a).max()
+        # mij / invmij are inverse of each other
+        x = oracle.apply_mij(m, u)
+        assert np.abs(oracle.apply_mij(m, x, inverse=True) - u).max() <= 1e-10 * np.abs(u).max()

@@ -169,6 +169,42 @@ def test_mass_galerkin_interp_dudr_parity(gpu, hiplib, oracle, level, deg, inc, 
         assert _rel(d[i].cpu().numpy(), dref[i]) <= RTOL
 
 
+@pytest.mark.parametrize("level,deg,inc,qt", [(1, 1, 0, 0), (1, 2, 0, 0), (1, 3, 0, 0), (1, 3, 2, 0), (1, 5, 1, 0), (1, 7, 0, 0), (1, 7, 1, 0),
+                                              (1, 4, 0, 1), (1, 9, 0, 0), (0, 12, 0, 0), (0, 15, 0, 0), (0, 18, 0, 0), (0, 18, 1, 0)])
+def test_weighted_inverse_mass_mij_parity(gpu, hiplib, oracle, level, deg, inc, qt):
+    """d4est_quadrature_apply_fofufofvlilj / apply_inverse_mass_matrix, d4est_operators_apply_mij / invmij."""
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(level, deg, deg_quad_inc=inc, quad_type=qt)
+    mp = M.SineMap(0.06)
+    J, rst = m.geometry(mp)
+    u = m.field(mp)
+    plan = _plan(m, J, rst)
+    du = _t(u, gpu)
+    # weighted mass with the nonlinear-Poisson style coefficient f(u) = 1 + u^2 at the quadrature nodes
+    uq = oracle.interpolate(m, u)
+    coeff = 1.0 + uq * uq
+    out = torch.full_like(du, float("nan"))
+    plan.apply_weighted_mass_matrix(du, _t(coeff, gpu), out)
+    assert _rel(out.cpu().numpy(), oracle.apply_weighted_mass(m, J, coeff, u)) <= RTOL
+    # nodal mass applies
+    for inverse in (False, True):
+        o = torch.full_like(du, float("nan"))
+        (plan.apply_invmij if inverse else plan.apply_mij)(du, o)
+        assert _rel(o.cpu().numpy(), oracle.apply_mij(m, u, inverse)) <= RTOL
+    if inc == 0:
+        # the inverse mass is Gauss-only in the reference; the tolerance carries the conditioning of V^-1 (grows with p)
+        o = torch.full_like(du, float("nan"))
+        plan.apply_inverse_mass_matrix(du, o)
+        ref = oracle.apply_inverse_mass(m, J, u)
+        assert _rel(o.cpu().numpy(), ref) <= 1e-11 * max(1, deg)
+        if qt == 0:
+            # M^-1 M u = u (the reference's identity test, d4est_test_operators / inverse mass definition)
+            Mu = torch.empty_like(du); plan.apply_mass_matrix(du, Mu)
+            back = torch.empty_like(du); plan.apply_inverse_mass_matrix(Mu, back)
+            assert _rel(back.cpu().numpy(), u) <= 1e-10 * max(1, deg)
+
+
 def test_edge_cases(gpu, hiplib, oracle):
     """empty plan, single element, ragged element count (not a multiple of elements-per-block)."""
     import torch
