@@ -132,6 +132,12 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
     bk.d_GT = upload(Tables1D::transpose(G, bk.NQ, bk.N));
     bk.d_DT = upload(Tables1D::transpose(D, bk.N, bk.N));
     bk.d_w = upload(Tables1D::quad_weights(quad_type, bk.deg_quad));
+    if (bk.N % 2 == 0 && bk.NQ % 2 == 0) {
+      bk.d_EBf = upload(Tables1D::eo_table(B, bk.NQ, bk.N, false));
+      bk.d_EGf = upload(Tables1D::eo_table(G, bk.NQ, bk.N, true));
+      bk.d_EBb = upload(Tables1D::eo_table(Tables1D::transpose(B, bk.NQ, bk.N), bk.N, bk.NQ, false));
+      bk.d_EGb = upload(Tables1D::eo_table(Tables1D::transpose(G, bk.NQ, bk.N), bk.N, bk.NQ, true));
+    }
     std::vector<double> M = Tables1D::mij(bk.deg), Minv = Tables1D::invmij(bk.deg);
     bk.d_M = upload(M);
     bk.d_MT = upload(Tables1D::transpose(M, bk.N, bk.N));
@@ -151,6 +157,17 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
     ns_list[i] = nodal_stride[ids[i]];
     qs_list[i] = quad_stride[ids[i]];
   }
+  for (Bucket& bk : plan->buckets) {
+    if (bk.n_elem == 0) continue;
+    const int* nl = ns_list.data() + bk.elem_offset;
+    const int* ql = qs_list.data() + bk.elem_offset;
+    const int dn = bk.n_elem > 1 ? nl[1] - nl[0] : bk.N * bk.N * bk.N, dq = bk.n_elem > 1 ? ql[1] - ql[0] : bk.NQ * bk.NQ * bk.NQ;
+    bool affine = dn >= 0 && dq >= 0;
+    for (int i = 1; i < bk.n_elem && affine; ++i) affine = (nl[i] - nl[i - 1] == dn) && (ql[i] - ql[i - 1] == dq);
+    if (affine) {
+      bk.ns0 = nl[0]; bk.ns_stride = dn; bk.qs0 = ql[0]; bk.qs_stride = dq;
+    }
+  }
   plan->elem_ids = ids;
   plan->d_elem_ids = upload_i(ids);
   plan->d_ns_list = upload_i(ns_list);
@@ -168,6 +185,10 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
     (void)hipFree(bk.d_BT);
     (void)hipFree(bk.d_GT);
     (void)hipFree(bk.d_DT);
+    (void)hipFree(bk.d_EBf);
+    (void)hipFree(bk.d_EGf);
+    (void)hipFree(bk.d_EBb);
+    (void)hipFree(bk.d_EGb);
     (void)hipFree(bk.d_M);
     (void)hipFree(bk.d_MT);
     (void)hipFree(bk.d_Minv);

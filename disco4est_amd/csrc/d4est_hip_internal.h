@@ -41,6 +41,14 @@ struct Bucket {
   double* d_DT = nullptr;
   // square N x N tables for the nodal mass applies (d4est_operators.c:891-928) and the Gauss inverse mass
   // (d4est_quadrature.c:1222-1331; only when deg_quad == deg, else null)
+  // affine strides of the bucket-ordered element list (ns = ns0 + i*ns_stride); ns_stride < 0: not affine, use the lists
+  int ns0 = 0, ns_stride = -1, qs0 = 0, qs_stride = -1;
+  // even-odd tables (see stiffness_wave_eo_kernel), only when N and NQ are even: forward B, G (N/2 rows of NQ) and
+  // backward B^T, G^T (NQ/2 rows of N)
+  double* d_EBf = nullptr;
+  double* d_EGf = nullptr;
+  double* d_EBb = nullptr;
+  double* d_EGb = nullptr;
   double* d_M = nullptr;
   double* d_MT = nullptr;
   double* d_Minv = nullptr;

@@ -269,6 +269,18 @@ std::vector<double> Tables1D::quad_weights(int quad_type, int deg_quad) {
   return w;
 }
 
+std::vector<double> Tables1D::eo_table(const std::vector<double>& M, int R, int C, bool antisymmetric) {
+  std::vector<double> T((size_t)(C / 2) * R);
+  for (int c = 0; c < C / 2; ++c)
+    for (int r = 0; r < R / 2; ++r) {
+      const double me = 0.5 * (M[(size_t)r * C + c] + M[(size_t)r * C + (C - 1 - c)]);
+      const double mo = 0.5 * (M[(size_t)r * C + c] - M[(size_t)r * C + (C - 1 - c)]);
+      T[(size_t)c * R + r] = antisymmetric ? mo : me;
+      T[(size_t)c * R + R / 2 + r] = antisymmetric ? me : mo;
+    }
+  return T;
+}
+
 std::vector<double> Tables1D::quad_interp(int quad_type, int deg, int deg_quad) {
   if (quad_type == QUAD_LEGENDRE) return lobatto_to_gauss(deg, deg_quad);
   if (quad_type == QUAD_LOBATTO) return p_prolong(deg, deg_quad);

@@ -1021,6 +1021,589 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave2_kernel(
   }
 }
 
+// KH > 0: the first KH quadrature planes (kq < KH) of all six metric components are REQUESTED AT ENTRY, right behind the
+// loads of u (6*KH doubles per thread stay in flight / in VGPRs during the forward contractions), so the metric stream
+// starts at t = 0 instead of after the forward phase; the remaining planes are loaded at the quadrature stage.
+// ns_stride >= 0: the bucket's strides are affine (ns = ns0 + ei*ns_stride, the normal case of a uniform-degree bucket),
+// which removes the dependent list load in front of the first load of u.
+template <int N, int NQ, int KH, int G>
+__global__ __launch_bounds__(64, 4) void stiffness_wave3_kernel(
+    const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
+    const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
+    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT, int ns0, int ns_stride,
+    int qs0, int qs_stride) {
+  using C = WaveCfg<N, NQ>;
+  constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
+  constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const int tid = threadIdx.x;
+  const int slot = tid / PL;
+  const int te = tid - slot * PL;
+  const int a = te % NQ, b = te / NQ;
+  const int ei = blockIdx.x * C::EPB + slot;
+  const bool active = (slot < C::EPB) && (ei < n_bucket);
+  double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
+  double* R1 = R0 + FS;
+  int ns = 0, qs = 0;
+  double mp[6][KH > 0 ? KH : 1];
+  if (active) {
+    if (ns_stride >= 0) {
+      ns = ns0 + ei * ns_stride;
+      qs = qs0 + ei * qs_stride;
+    } else {
+      ns = ns_list[ei];
+      qs = qs_list[ei];
+    }
+    if (C::EPB == 1) {  // one element per wave: the strides are wave-uniform -> scalar base addresses
+      ns = __builtin_amdgcn_readfirstlane(ns);
+      qs = __builtin_amdgcn_readfirstlane(qs);
+    }
+    double ureg[(N3 + PL - 1) / PL];
+#pragma unroll
+    for (int idx = te, c = 0; idx < N3; idx += PL, ++c) ureg[c] = u[ns + idx];
+    if (KH > 0) {
+      const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int kq = 0; kq < KH; ++kq) mp[c][kq] = m[c * NQ3 + NQ * NQ * kq];
+    }
+#pragma unroll
+    for (int idx = te, c = 0; idx < N3; idx += PL, ++c) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      R0[i + PN * (j + N * k)] = ureg[c];
+    }
+  }
+  __syncthreads();
+
+  // ---- S1: thread (j=a, k=b)
+  {
+    double x[N], br[NQ], gr[NQ];
+    const bool on = active && a < N && b < N;
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+      contract_pair<N, NQ, false, false>(BopT, x, br, GopT, x, gr);
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        R0[a + PN * (iq + NQ * b)] = br[iq];
+        R1[a + PN * (iq + NQ * b)] = gr[iq];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- S2 (thread (iq=a, k=b)) and S3 (thread (iq=a, jq=b))
+  double gr[NQ], gs[NQ], gt[NQ];
+  {
+    double x1[N], x2[N], t1[NQ], t2[NQ], t3[NQ];
+    const bool on2 = active && b < N;
+    if (on2) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        x1[j] = R0[j + PN * (a + NQ * b)];  // B_r u
+        x2[j] = R1[j + PN * (a + NQ * b)];  // G_r u
+      }
+      contract_pair<N, NQ, false, false>(BopT, x2, t1, GopT, x1, t2);  // B_s G_r u | G_s B_r u
+      contract_single<N, NQ, false>(BopT, x1, t3);                      // B_s B_r u
+    }
+    __syncthreads();
+    if (on2) {
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) {  // [jq][iq][k]
+        R0[b + PN * (a + NQ * jq)] = t1[jq];
+        R1[b + PN * (a + NQ * jq)] = t2[jq];
+      }
+    }
+    __syncthreads();
+    if (active) {
+      double y1[N], y2[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        y1[k] = R0[k + PN * (a + NQ * b)];
+        y2[k] = R1[k + PN * (a + NQ * b)];
+      }
+      contract_pair<N, NQ, false, false>(BopT, y1, gr, BopT, y2, gs);
+    }
+    __syncthreads();
+    if (on2) {
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t3[jq];
+    }
+    __syncthreads();
+    if (active) {
+      double y3[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) y3[k] = R0[k + PN * (a + NQ * b)];
+      contract_single<N, NQ, false>(GopT, y3, gt);
+    }
+  }
+
+  // ---- quadrature-point stage: the planes requested at entry first, then the rest in batches of G planes
+  // (6*G loads in flight per batch; the batch is issued as a whole before its first use)
+  if (active) {
+    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+    for (int kq = 0; kq < KH; ++kq) {
+      const double r = gr[kq], s = gs[kq], t = gt[kq];
+      gr[kq] = mp[0][kq] * r + mp[1][kq] * s + mp[2][kq] * t;
+      gs[kq] = mp[1][kq] * r + mp[3][kq] * s + mp[4][kq] * t;
+      gt[kq] = mp[2][kq] * r + mp[4][kq] * s + mp[5][kq] * t;
+    }
+#pragma unroll
+    for (int k0 = KH; k0 < NQ; k0 += G) {
+      double mq[6][G];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (k0 + g < NQ) mq[c][g] = m[c * NQ3 + NQ * NQ * (k0 + g)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int kq = k0 + g;
+        if (kq < NQ) {
+          const double r = gr[kq], s = gs[kq], t = gt[kq];
+          gr[kq] = mq[0][g] * r + mq[1][g] * s + mq[2][g] * t;
+          gs[kq] = mq[1][g] * r + mq[3][g] * s + mq[4][g] * t;
+          gt[kq] = mq[2][g] * r + mq[4][g] * s + mq[5][g] * t;
+        }
+      }
+    }
+  }
+
+  // ---- S5 (registers) / S6 (thread (iq=a, k=b))
+  {
+    double ca[N], cb[N], cc[N], ar[N], bs[N];
+    const bool on6 = active && b < N;
+    if (active) {
+      contract_pair<NQ, N, false, false>(Bop, gr, ca, Bop, gs, cb);
+      contract_single<NQ, N, false>(Gop, gt, cc);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {  // [k][iq][jq]
+        R0[b + PQ * (a + NQ * k)] = ca[k];
+        R1[b + PQ * (a + NQ * k)] = cb[k];
+      }
+    }
+    __syncthreads();
+    if (on6) {
+      double x[NQ], y[NQ];
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) {
+        x[jq] = R0[jq + PQ * (a + NQ * b)];
+        y[jq] = R1[jq + PQ * (a + NQ * b)];
+      }
+      contract_pair<NQ, N, false, false>(Bop, x, ar, Gop, y, bs);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = cc[k];
+    }
+    __syncthreads();
+    if (on6) {
+      double z[NQ];
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) z[jq] = R0[jq + PQ * (a + NQ * b)];
+      contract_single<NQ, N, true>(Bop, z, bs);
+    }
+    __syncthreads();
+    if (on6) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {  // [k][j][iq]
+        R0[a + PQ * (j + N * b)] = ar[j];
+        R1[a + PQ * (j + N * b)] = bs[j];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- S7: thread (j=a, k=b)
+  {
+    double x[NQ], y[NQ], o[N], o2[N];
+    const bool on = active && a < N && b < N;
+    if (on) {
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        x[iq] = R0[iq + PQ * (a + N * b)];
+        y[iq] = R1[iq + PQ * (a + N * b)];
+      }
+      contract_pair<NQ, N, false, false>(Gop, x, o, Bop, y, o2);
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = o[i] + o2[i];
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      Au[ns + idx] = R0[i + PN * (j + N * k)];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// EVEN-ODD single-wavefront kernel.  The 1-D operators on symmetric node sets are centro-symmetric
+// (B: B[R-1-r][C-1-c] = B[r][c]) or centro-antisymmetric (G = B D).  With xe = x[c] + x[C-1-c], xo = x[c] - x[C-1-c]
+// one apply is two half-size products  ye = Me xe, yo = Mo xo  (Me/Mo = (M[r][c] +- M[r][C-1-c]) / 2, r < R/2, c < C/2)
+// and  y[r] = ye + yo, y[R-1-r] = +-(ye - yo):  R*C/2 FMAs + R + C adds instead of R*C FMAs (-25 % FP64 issue slots at
+// N = 8, -31 % where B and G share the input) and half the scalar operator traffic.
+// EO table of an operator: C/2 rows of R doubles, row c = [first half | second half] with
+//   symmetric:      first = Me[0..R/2)[c] (multiplies xe), second = Mo[..][c] (multiplies xo)
+//   antisymmetric:  first = Mo[..][c]     (multiplies xo), second = Me[..][c] (multiplies xe)
+// so that in both cases  y[r] = a[r] + b[r],  y[R-1-r] = a[r] - b[r]  with (a | b) the accumulated row halves, and
+// products of different operators can be summed in (a | b) form before the final butterfly.
+// ---------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void eo_pre(const double* x, double* xe, double* xo) {
+#pragma unroll
+  for (int c = 0; c < C / 2; ++c) {
+    xe[c] = x[c] + x[C - 1 - c];
+    xo[c] = x[c] - x[C - 1 - c];
+  }
+}
+template <int R>
+__device__ __forceinline__ void eo_post(const double* ab, double* y) {
+#pragma unroll
+  for (int r = 0; r < R / 2; ++r) {
+    y[r] = ab[r] + ab[R / 2 + r];
+    y[R - 1 - r] = ab[r] - ab[R / 2 + r];
+  }
+}
+
+// two operators at once, one EO row of each per step: yA (+)= sum_c rowA_c * (xfA[c] | xsA[c]), same for B.  HC = C/2 rows.
+template <int HC, int R, bool ACCA, bool ACCB>
+__device__ __forceinline__ void contract_pair_eo(const double* __restrict__ opA, const double* xfA, const double* xsA, double* yA,
+                                                 const double* __restrict__ opB, const double* xfB, const double* xsB, double* yB) {
+  constexpr int HR = R / 2;
+  double ca[R], cb[R], na[R], nb[R];
+  {
+    sdouble_ptr ra = launder(opA), rb = launder(opB);
+#pragma unroll
+    for (int o = 0; o < R; ++o) { ca[o] = ra[o]; cb[o] = rb[o]; }
+  }
+#pragma unroll
+  for (int i = 0; i < HC; ++i) {
+    if (i + 1 < HC) {
+      sdouble_ptr ra, rb;
+      launder2_after(opA + (i + 1) * R, opB + (i + 1) * R, ca[0], cb[0], ra, rb);
+#pragma unroll
+      for (int o = 0; o < R; ++o) { na[o] = ra[o]; nb[o] = rb[o]; }
+    }
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+      const double xa = (o < HR) ? xfA[i] : xsA[i], xb = (o < HR) ? xfB[i] : xsB[i];
+      yA[o] = (i == 0 && !ACCA) ? ca[o] * xa : fma(ca[o], xa, yA[o]);
+      yB[o] = (i == 0 && !ACCB) ? cb[o] * xb : fma(cb[o], xb, yB[o]);
+    }
+    if (i + 1 < HC) {
+#pragma unroll
+      for (int o = 0; o < R; ++o) { ca[o] = na[o]; cb[o] = nb[o]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// one operator, two EO rows per step
+template <int HC, int R, bool ACC>
+__device__ __forceinline__ void contract_single_eo(const double* __restrict__ op, const double* xf, const double* xs, double* y) {
+  constexpr int HR = R / 2;
+  constexpr int STEPS = (HC + 1) / 2;
+  double c0[R], c1[R], n0[R], n1[R];
+  {
+    sdouble_ptr r0 = launder(op);
+#pragma unroll
+    for (int o = 0; o < R; ++o) c0[o] = r0[o];
+    if (HC > 1) {
+      sdouble_ptr r1 = launder(op + R);
+#pragma unroll
+      for (int o = 0; o < R; ++o) c1[o] = r1[o];
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int i0 = 2 * st, i1 = 2 * st + 1;
+    if (i0 + 2 < HC) {
+      sdouble_ptr r0, r1;
+      launder2_after(op + (i0 + 2) * R, op + ((i1 + 2 < HC) ? (i1 + 2) : (i0 + 2)) * R, c0[0], (i1 < HC) ? c1[0] : c0[0], r0, r1);
+#pragma unroll
+      for (int o = 0; o < R; ++o) n0[o] = r0[o];
+      if (i1 + 2 < HC) {
+#pragma unroll
+        for (int o = 0; o < R; ++o) n1[o] = r1[o];
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+      const double x0 = (o < HR) ? xf[i0] : xs[i0];
+      y[o] = (i0 == 0 && !ACC) ? c0[o] * x0 : fma(c0[o], x0, y[o]);
+      if (i1 < HC) {
+        const double x1 = (o < HR) ? xf[i1] : xs[i1];
+        y[o] = fma(c1[o], x1, y[o]);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+      if (i0 + 2 < HC) c0[o] = n0[o];
+      if (i1 + 2 < HC) c1[o] = n1[o];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// EBf / EGf: EO tables of y = B x / y = G x (N/2 rows of NQ);  EBb / EGb: of y = B^T x / y = G^T x (NQ/2 rows of N).
+// N and NQ even.  Strides: affine (ns_stride >= 0) or from the lists.
+template <int N, int NQ>
+__global__ __launch_bounds__(64, 4) void stiffness_wave_eo_kernel(
+    const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
+    const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ EBf,
+    const double* __restrict__ EGf, const double* __restrict__ EBb, const double* __restrict__ EGb, int ns0, int ns_stride,
+    int qs0, int qs_stride) {
+  using C = WaveCfg<N, NQ>;
+  constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
+  constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
+  constexpr int HN = N / 2, HQ = NQ / 2;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+
+  const int tid = threadIdx.x;
+  const int slot = tid / PL;
+  const int te = tid - slot * PL;
+  const int a = te % NQ, b = te / NQ;
+  const int ei = blockIdx.x * C::EPB + slot;
+  const bool active = (slot < C::EPB) && (ei < n_bucket);
+  double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
+  double* R1 = R0 + FS;
+  int ns = 0, qs = 0;
+  if (active) {
+    if (ns_stride >= 0) {
+      ns = ns0 + ei * ns_stride;
+      qs = qs0 + ei * qs_stride;
+    } else {
+      ns = ns_list[ei];
+      qs = qs_list[ei];
+    }
+    if (C::EPB == 1) {
+      ns = __builtin_amdgcn_readfirstlane(ns);
+      qs = __builtin_amdgcn_readfirstlane(qs);
+    }
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      R0[i + PN * (j + N * k)] = u[ns + idx];
+    }
+  }
+  __syncthreads();
+
+  // ---- S1: thread (j=a, k=b): B_r u, G_r u
+  {
+    double x[N], xe[HN], xo[HN], br[NQ], gr[NQ];
+    const bool on = active && a < N && b < N;
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+      eo_pre<N>(x, xe, xo);
+      contract_pair_eo<HN, NQ, false, false>(EBf, xe, xo, br, EGf, xo, xe, gr);
+    }
+    __syncthreads();
+    if (on) {
+      double y[NQ];
+      eo_post<NQ>(br, y);
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) R0[a + PN * (iq + NQ * b)] = y[iq];
+      eo_post<NQ>(gr, y);
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) R1[a + PN * (iq + NQ * b)] = y[iq];
+    }
+  }
+  __syncthreads();
+
+  // ---- S2 (thread (iq=a, k=b)) and S3 (thread (iq=a, jq=b))
+  double gr[NQ], gs[NQ], gt[NQ];
+  {
+    double t3[NQ];
+    const bool on2 = active && b < N;
+    {
+      double x1[N], x2[N], x1e[HN], x1o[HN], x2e[HN], x2o[HN], t1[NQ], t2[NQ];
+      if (on2) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          x1[j] = R0[j + PN * (a + NQ * b)];  // B_r u
+          x2[j] = R1[j + PN * (a + NQ * b)];  // G_r u
+        }
+        eo_pre<N>(x1, x1e, x1o);
+        eo_pre<N>(x2, x2e, x2o);
+        contract_pair_eo<HN, NQ, false, false>(EBf, x2e, x2o, t1, EGf, x1o, x1e, t2);  // B_s G_r u | G_s B_r u
+        contract_single_eo<HN, NQ, false>(EBf, x1e, x1o, t3);                           // B_s B_r u
+      }
+      __syncthreads();
+      if (on2) {
+        double y[NQ];
+        eo_post<NQ>(t1, y);
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = y[jq];  // [jq][iq][k]
+        eo_post<NQ>(t2, y);
+#pragma unroll
+        for (int jq = 0; jq < NQ; ++jq) R1[b + PN * (a + NQ * jq)] = y[jq];
+      }
+    }
+    __syncthreads();
+    if (active) {
+      double y1[N], y2[N], y1e[HN], y1o[HN], y2e[HN], y2o[HN], ge[NQ], he[NQ];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        y1[k] = R0[k + PN * (a + NQ * b)];
+        y2[k] = R1[k + PN * (a + NQ * b)];
+      }
+      eo_pre<N>(y1, y1e, y1o);
+      eo_pre<N>(y2, y2e, y2o);
+      contract_pair_eo<HN, NQ, false, false>(EBf, y1e, y1o, ge, EBf, y2e, y2o, he);
+      eo_post<NQ>(ge, gr);
+      eo_post<NQ>(he, gs);
+    }
+    __syncthreads();
+    if (on2) {
+      double y[NQ];
+      eo_post<NQ>(t3, y);
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = y[jq];
+    }
+    __syncthreads();
+    if (active) {
+      double y3[N], y3e[HN], y3o[HN], ge[NQ];
+#pragma unroll
+      for (int k = 0; k < N; ++k) y3[k] = R0[k + PN * (a + NQ * b)];
+      eo_pre<N>(y3, y3e, y3o);
+      contract_single_eo<HN, NQ, false>(EGf, y3o, y3e, ge);
+      eo_post<NQ>(ge, gt);
+    }
+  }
+
+  // ---- quadrature-point stage
+  if (active) {
+    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) {
+      const int q = NQ * NQ * kq;
+      const double m0 = m[q], m1 = m[NQ3 + q], m2 = m[2 * NQ3 + q], m3 = m[3 * NQ3 + q], m4 = m[4 * NQ3 + q], m5 = m[5 * NQ3 + q];
+      const double r = gr[kq], s = gs[kq], t = gt[kq];
+      gr[kq] = m0 * r + m1 * s + m2 * t;
+      gs[kq] = m1 * r + m3 * s + m4 * t;
+      gt[kq] = m2 * r + m4 * s + m5 * t;
+    }
+  }
+
+  // ---- S5 (registers) / S6 (thread (iq=a, k=b))
+  {
+    double cc[N], ar[N], bs[N];
+    const bool on6 = active && b < N;
+    {
+      double ca[N], cb[N];
+      if (active) {
+        double re[HQ], ro[HQ], se[HQ], so[HQ], te_[HQ], to[HQ];
+        eo_pre<NQ>(gr, re, ro);
+        eo_pre<NQ>(gs, se, so);
+        eo_pre<NQ>(gt, te_, to);
+        contract_pair_eo<HQ, N, false, false>(EBb, re, ro, ca, EBb, se, so, cb);
+        contract_single_eo<HQ, N, false>(EGb, to, te_, cc);
+      }
+      __syncthreads();
+      if (active) {
+        double y[N];
+        eo_post<N>(ca, y);
+#pragma unroll
+        for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = y[k];  // [k][iq][jq]
+        eo_post<N>(cb, y);
+#pragma unroll
+        for (int k = 0; k < N; ++k) R1[b + PQ * (a + NQ * k)] = y[k];
+      }
+    }
+    __syncthreads();
+    if (on6) {
+      double x[NQ], y[NQ], xe[HQ], xo[HQ], ye[HQ], yo[HQ];
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) {
+        x[jq] = R0[jq + PQ * (a + NQ * b)];
+        y[jq] = R1[jq + PQ * (a + NQ * b)];
+      }
+      eo_pre<NQ>(x, xe, xo);
+      eo_pre<NQ>(y, ye, yo);
+      contract_pair_eo<HQ, N, false, false>(EBb, xe, xo, ar, EGb, yo, ye, bs);
+    }
+    __syncthreads();
+    if (active) {
+      double y[N];
+      eo_post<N>(cc, y);
+#pragma unroll
+      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = y[k];
+    }
+    __syncthreads();
+    if (on6) {
+      double z[NQ], ze[HQ], zo[HQ];
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) z[jq] = R0[jq + PQ * (a + NQ * b)];
+      eo_pre<NQ>(z, ze, zo);
+      contract_single_eo<HQ, N, true>(EBb, ze, zo, bs);  // summed in (a | b) form with G_s^T(...)
+    }
+    __syncthreads();
+    if (on6) {
+      double y[N];
+      eo_post<N>(ar, y);
+#pragma unroll
+      for (int j = 0; j < N; ++j) R0[a + PQ * (j + N * b)] = y[j];  // [k][j][iq]
+      eo_post<N>(bs, y);
+#pragma unroll
+      for (int j = 0; j < N; ++j) R1[a + PQ * (j + N * b)] = y[j];
+    }
+  }
+  __syncthreads();
+
+  // ---- S7: thread (j=a, k=b)
+  {
+    double o[N], o2[N];
+    const bool on = active && a < N && b < N;
+    if (on) {
+      double x[NQ], y[NQ], xe[HQ], xo[HQ], ye[HQ], yo[HQ];
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        x[iq] = R0[iq + PQ * (a + N * b)];
+        y[iq] = R1[iq + PQ * (a + N * b)];
+      }
+      eo_pre<NQ>(x, xe, xo);
+      eo_pre<NQ>(y, ye, yo);
+      contract_pair_eo<HQ, N, false, false>(EGb, xo, xe, o, EBb, ye, yo, o2);
+    }
+    __syncthreads();
+    if (on) {
+      double y[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) o[i] += o2[i];
+      eo_post<N>(o, y);
+#pragma unroll
+      for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = y[i];
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int idx = te; idx < N3; idx += PL) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+      Au[ns + idx] = R0[i + PN * (j + N * k)];
+    }
+  }
+}
+
 // ABL != 0 are timing-only ablations (wrong results): 1 = no backward contractions, 2 = no forward contractions
 template <int N, int NQ, int ABL>
 __global__ __launch_bounds__(64, 4) void stiffness_wave2_abl_kernel(
@@ -1643,7 +2226,24 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
     (void)cus_;
     const int stagger = ts < 0 ? 0 : ts;
     const int tw_ = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
-    if (tw_ == 3 || tw_ < 0) {
+    if ((tw_ == 11 || tw_ < 0) && N % 2 == 0 && NQ % 2 == 0 && bk.d_EBf) {
+      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_eo_kernel<%d,%d>", N, NQ);
+      if constexpr (N % 2 == 0 && NQ % 2 == 0)
+        hipLaunchKernelGGL((stiffness_wave_eo_kernel<N, NQ>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
+                           plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBf, bk.d_EGf,
+                           bk.d_EBb, bk.d_EGb, bk.ns0, bk.ns_stride, bk.qs0, bk.qs_stride);
+    } else if (tw_ == 4 || tw_ == 5 || tw_ == 6 || tw_ == 10) {
+      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave3_kernel<%d,%d> variant %d", N, NQ, tw_);
+#define W3(KH_, G_)                                                                                                              \
+  hipLaunchKernelGGL((stiffness_wave3_kernel<N, NQ, (KH_ < NQ ? KH_ : 0), G_>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric, \
+                     plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, \
+                     bk.d_GT, bk.ns0, bk.ns_stride, bk.qs0, bk.qs_stride)
+      if (tw_ == 4) W3(2, 6);
+      else if (tw_ == 5) W3(2, 3);
+      else if (tw_ == 6) W3(0, 4);
+      else W3(0, 2);
+#undef W3
+    } else if (tw_ == 3 || tw_ < 0) {
       std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave2_kernel<%d,%d>", N, NQ);
       hipLaunchKernelGGL((stiffness_wave2_kernel<N, NQ>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
                          plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT,

@@ -76,7 +76,7 @@ void d4est_hip_plan_set_stream(d4est_hip_plan_t* plan, void* hip_stream);
 /* Performance knobs (never change results beyond fp64 re-association).  Value -1 (default) = auto. */
 enum d4est_hip_tuning_key {
   D4EST_HIP_TUNE_STIFFNESS_PREFETCH = 0, /* 1: request the metric at kernel entry (deg_quad <= 7), 0: at the point of use */
-  D4EST_HIP_TUNE_STIFFNESS_WAVE = 1,     /* where (deg_quad+1)^2 <= 64: 0 multi-buffer kernel, 1 single-wavefront kernel, 2 two-wavefront kernel with metric prefetch, 3 single-wavefront kernel with pipelined operator loads (auto default) */
+  D4EST_HIP_TUNE_STIFFNESS_WAVE = 1,     /* where (deg_quad+1)^2 <= 64: 0 multi-buffer kernel, 1 single-wavefront kernel, 2 two-wavefront kernel with metric prefetch, 3 single-wavefront kernel with pipelined operator loads (auto default for odd N), 4/5/6/10 its metric-batching variants, 11 even-odd single-wavefront kernel (auto default for even N, NQ), 7/8/9 timing-only diagnostics */
   D4EST_HIP_TUNE_STIFFNESS_STAGGER = 2,  /* single-wave kernel: delay (units of 1024 cycles) of every other resident workgroup row */
   D4EST_HIP_TUNE_FLUX_FAST = 3,          /* 0: always the generic flux kernel; else the wave-per-face kernel where all degrees <= 7 */
   D4EST_HIP_TUNE_STIFFNESS_BIGP = 4,     /* p >= 8: 0 three-field kernel, else two-field multi-wave kernel (default) */
