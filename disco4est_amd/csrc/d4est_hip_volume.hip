@@ -89,12 +89,71 @@ __device__ __forceinline__ void contract_t(const double* __restrict__ op, const 
   }
 }
 
+
+// ---- even-odd form of the same contractions (see stiffness_wave_eo_kernel below for the derivation and table layout):
+// tab = EO table of the operator, C/2 rows of R doubles, row = [first half | second half]
+template <int C>
+__device__ __forceinline__ void eo_pre(const double* x, double* xe, double* xo) {
+#pragma unroll
+  for (int c = 0; c < C / 2; ++c) {
+    xe[c] = x[c] + x[C - 1 - c];
+    xo[c] = x[c] - x[C - 1 - c];
+  }
+}
+template <int R>
+__device__ __forceinline__ void eo_post(const double* ab, double* y) {
+#pragma unroll
+  for (int r = 0; r < R / 2; ++r) {
+    y[r] = ab[r] + ab[R / 2 + r];
+    y[R - 1 - r] = ab[r] - ab[R / 2 + r];
+  }
+}
+// y (+)= M x for a centro-symmetric (ANTI = false) or centro-antisymmetric (ANTI = true) operator M (R x C, both even)
+template <int C, int R, bool ANTI, bool ACC>
+__device__ __forceinline__ void apply_eo(const double* __restrict__ tab, const double* x, double* y) {
+  constexpr int HC = C / 2, HR = R / 2;
+  double xe[HC], xo[HC], ab[R];
+  eo_pre<C>(x, xe, xo);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const double* xx = ((half == 0) != ANTI) ? xe : xo;  // first half multiplies xe (symmetric) / xo (antisymmetric)
+#pragma unroll
+    for (int o0 = 0; o0 < HR; o0 += 8) {
+#pragma unroll
+      for (int c = 0; c < HC; ++c) {
+        sdouble_ptr row = launder(tab + c * R + half * HR + o0);
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+          if (o0 + o < HR) ab[half * HR + o0 + o] = (c == 0) ? row[o] * xx[0] : fma(row[o], xx[c], ab[half * HR + o0 + o]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < HR; ++r) {
+    const double p = ab[r] + ab[HR + r], m = ab[r] - ab[HR + r];
+    y[r] = ACC ? y[r] + p : p;
+    y[R - 1 - r] = ACC ? y[R - 1 - r] + m : m;
+  }
+}
+// y = op x (operator given transposed, or as EO table when EO); y (+)= op^T x (operator itself, or EO table of op^T)
+template <int NI, int NO, bool EO, bool ANTI>
+__device__ __forceinline__ void fwd(const double* __restrict__ tab, const double* x, double* y) {
+  if constexpr (EO) apply_eo<NI, NO, ANTI, false>(tab, x, y);
+  else contract_n<NI, NO>(tab, x, y);
+}
+template <int NI, int NO, bool EO, bool ANTI, bool ACC>
+__device__ __forceinline__ void bwd(const double* __restrict__ tab, const double* x, double* y) {
+  if constexpr (EO) apply_eo<NI, NO, ANTI, ACC>(tab, x, y);
+  else contract_t<NI, NO, ACC>(tab, x, y);
+}
+
 // ---------------------------------------------------------------------------
 // stiffness:  Au_e = sum_{lp,l} D_lp^T V^T [ M_{lp,l} (V D_l u_e) ]
 // ---------------------------------------------------------------------------
 // PF = true: the thread's 6*NQ metric entries are requested at kernel entry (before the
 // forward contractions) so that HBM latency overlaps the S1-S3 arithmetic; costs 12*NQ VGPRs.
-template <int N, int NQ, bool PF>
+// EO = true: the four operator arguments are the even-odd tables (Bop = B^T's, Gop = G^T's, BopT = B's, GopT = G's)
+template <int N, int NQ, bool PF, bool EO = false>
 __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list,
@@ -145,8 +204,8 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     double x[N], br[NQ], gr[NQ];
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-    contract_n<N, NQ>(BopT, x, br);
-    contract_n<N, NQ>(GopT, x, gr);
+    fwd<N, NQ, EO, false>(BopT, x, br);
+    fwd<N, NQ, EO, true>(GopT, x, gr);
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
       R1[a + PN * (iq + NQ * b)] = br[iq];
@@ -161,11 +220,11 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     double x[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];
-    contract_n<N, NQ>(BopT, x, t_bb);
-    contract_n<N, NQ>(GopT, x, t_gb);
+    fwd<N, NQ, EO, false>(BopT, x, t_bb);
+    fwd<N, NQ, EO, true>(GopT, x, t_gb);
 #pragma unroll
     for (int j = 0; j < N; ++j) x[j] = R2[j + PN * (a + NQ * b)];
-    contract_n<N, NQ>(BopT, x, t_bg);
+    fwd<N, NQ, EO, false>(BopT, x, t_bg);
   }
   __syncthreads();
   if (active && b < N) {
@@ -185,13 +244,13 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     double x[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
-    contract_n<N, NQ>(BopT, x, gr);
+    fwd<N, NQ, EO, false>(BopT, x, gr);
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = R1[k + PN * (a + NQ * b)];
-    contract_n<N, NQ>(BopT, x, gs);
+    fwd<N, NQ, EO, false>(BopT, x, gs);
 #pragma unroll
     for (int k = 0; k < N; ++k) x[k] = R2[k + PN * (a + NQ * b)];
-    contract_n<N, NQ>(GopT, x, gt);
+    fwd<N, NQ, EO, true>(GopT, x, gt);
 
     // ---- quadrature-point stage: symmetric metric (rr,rs,rt,ss,st,tt), coalesced along (iq,jq)
     const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
@@ -207,9 +266,9 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     }
 
     // ---- S5: t-contraction transposed (registers)
-    contract_t<NQ, N, false>(Bop, gr, ca);
-    contract_t<NQ, N, false>(Bop, gs, cb);
-    contract_t<NQ, N, false>(Gop, gt, cc);
+    bwd<NQ, N, EO, false, false>(Bop, gr, ca);
+    bwd<NQ, N, EO, false, false>(Bop, gs, cb);
+    bwd<NQ, N, EO, true, false>(Gop, gt, cc);
   }
   __syncthreads();
   if (active) {
@@ -228,13 +287,13 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     double x[NQ];
 #pragma unroll
     for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
-    contract_t<NQ, N, false>(Bop, x, ar);
+    bwd<NQ, N, EO, false, false>(Bop, x, ar);
 #pragma unroll
     for (int jq = 0; jq < NQ; ++jq) x[jq] = R1[jq + PQ * (a + NQ * b)];
-    contract_t<NQ, N, false>(Gop, x, bs);
+    bwd<NQ, N, EO, true, false>(Gop, x, bs);
 #pragma unroll
     for (int jq = 0; jq < NQ; ++jq) x[jq] = R2[jq + PQ * (a + NQ * b)];
-    contract_t<NQ, N, true>(Bop, x, bs);
+    bwd<NQ, N, EO, false, true>(Bop, x, bs);
   }
   __syncthreads();
   if (active && b < N) {
@@ -251,10 +310,10 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     double x[NQ], o[N];
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) x[iq] = R0[iq + PQ * (a + N * b)];
-    contract_t<NQ, N, false>(Gop, x, o);
+    bwd<NQ, N, EO, true, false>(Gop, x, o);
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) x[iq] = R1[iq + PQ * (a + N * b)];
-    contract_t<NQ, N, true>(Bop, x, o);
+    bwd<NQ, N, EO, false, true>(Bop, x, o);
 #pragma unroll
     for (int i = 0; i < N; ++i) R2[i + PN * (a + N * b)] = o[i];
   }
@@ -290,7 +349,7 @@ struct WaveCfg {
   static constexpr size_t LDS_BYTES = (size_t)EPB * LDS_PER_ELEM * sizeof(double);
 };
 
-template <int N, int NQ, bool PF>
+template <int N, int NQ, bool PF, bool EO = false>
 __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS == 64 ? (PF ? 3 : 4) : 1)) void stiffness_wave_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
@@ -346,8 +405,8 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     if (on) {
 #pragma unroll
       for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-      contract_n<N, NQ>(BopT, x, br);
-      contract_n<N, NQ>(GopT, x, gr);
+      fwd<N, NQ, EO, false>(BopT, x, br);
+      fwd<N, NQ, EO, true>(GopT, x, gr);
     }
     __syncthreads();
     if (on) {
@@ -375,7 +434,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     __syncthreads();
     // field 1: B_s G_r u  -> gr = B_t(.)
     if (on2) {
-      contract_n<N, NQ>(BopT, x2, t);
+      fwd<N, NQ, EO, false>(BopT, x2, t);
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
     }
@@ -383,11 +442,11 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     if (active) {
 #pragma unroll
       for (int k = 0; k < N; ++k) y[k] = R0[k + PN * (a + NQ * b)];
-      contract_n<N, NQ>(BopT, y, gr);
+      fwd<N, NQ, EO, false>(BopT, y, gr);
     }
     // field 2: G_s B_r u  -> gs = B_t(.)   (goes through R1 so the two transfers overlap)
     if (on2) {
-      contract_n<N, NQ>(GopT, x1, t);
+      fwd<N, NQ, EO, true>(GopT, x1, t);
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) R1[b + PN * (a + NQ * jq)] = t[jq];
     }
@@ -395,11 +454,11 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     if (active) {
 #pragma unroll
       for (int k = 0; k < N; ++k) y[k] = R1[k + PN * (a + NQ * b)];
-      contract_n<N, NQ>(BopT, y, gs);
+      fwd<N, NQ, EO, false>(BopT, y, gs);
     }
     // field 3: B_s B_r u  -> gt = G_t(.)
     if (on2) {
-      contract_n<N, NQ>(BopT, x1, t);
+      fwd<N, NQ, EO, false>(BopT, x1, t);
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
     }
@@ -407,7 +466,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     if (active) {
 #pragma unroll
       for (int k = 0; k < N; ++k) y[k] = R0[k + PN * (a + NQ * b)];
-      contract_n<N, NQ>(GopT, y, gt);
+      fwd<N, NQ, EO, true>(GopT, y, gt);
     }
   }
 
@@ -433,7 +492,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     const bool on6 = active && b < N;
     __syncthreads();
     if (active) {
-      contract_t<NQ, N, false>(Bop, gr, c);
+      bwd<NQ, N, EO, false, false>(Bop, gr, c);
 #pragma unroll
       for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = c[k];  // [k][iq][jq]
     }
@@ -441,10 +500,10 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     if (on6) {
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
-      contract_t<NQ, N, false>(Bop, x, ar);
+      bwd<NQ, N, EO, false, false>(Bop, x, ar);
     }
     if (active) {
-      contract_t<NQ, N, false>(Bop, gs, c);
+      bwd<NQ, N, EO, false, false>(Bop, gs, c);
 #pragma unroll
       for (int k = 0; k < N; ++k) R1[b + PQ * (a + NQ * k)] = c[k];
     }
@@ -452,10 +511,10 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     if (on6) {
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) x[jq] = R1[jq + PQ * (a + NQ * b)];
-      contract_t<NQ, N, false>(Gop, x, bs);
+      bwd<NQ, N, EO, true, false>(Gop, x, bs);
     }
     if (active) {
-      contract_t<NQ, N, false>(Gop, gt, c);
+      bwd<NQ, N, EO, true, false>(Gop, gt, c);
 #pragma unroll
       for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = c[k];
     }
@@ -463,7 +522,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     if (on6) {
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
-      contract_t<NQ, N, true>(Bop, x, bs);
+      bwd<NQ, N, EO, false, true>(Bop, x, bs);
     }
     __syncthreads();
     if (on6) {
@@ -486,8 +545,8 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
         x[iq] = R0[iq + PQ * (a + N * b)];
         y[iq] = R1[iq + PQ * (a + N * b)];
       }
-      contract_t<NQ, N, false>(Gop, x, o);
-      contract_t<NQ, N, true>(Bop, y, o);
+      bwd<NQ, N, EO, true, false>(Gop, x, o);
+      bwd<NQ, N, EO, false, true>(Bop, y, o);
     }
     __syncthreads();
     if (on) {
@@ -1266,23 +1325,6 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave3_kernel(
 // so that in both cases  y[r] = a[r] + b[r],  y[R-1-r] = a[r] - b[r]  with (a | b) the accumulated row halves, and
 // products of different operators can be summed in (a | b) form before the final butterfly.
 // ---------------------------------------------------------------------------
-template <int C>
-__device__ __forceinline__ void eo_pre(const double* x, double* xe, double* xo) {
-#pragma unroll
-  for (int c = 0; c < C / 2; ++c) {
-    xe[c] = x[c] + x[C - 1 - c];
-    xo[c] = x[c] - x[C - 1 - c];
-  }
-}
-template <int R>
-__device__ __forceinline__ void eo_post(const double* ab, double* y) {
-#pragma unroll
-  for (int r = 0; r < R / 2; ++r) {
-    y[r] = ab[r] + ab[R / 2 + r];
-    y[R - 1 - r] = ab[r] - ab[R / 2 + r];
-  }
-}
-
 // two operators at once, one EO row of each per step: yA (+)= sum_c rowA_c * (xfA[c] | xsA[c]), same for B.  HC = C/2 rows.
 template <int HC, int R, bool ACCA, bool ACCB>
 __device__ __forceinline__ void contract_pair_eo(const double* __restrict__ opA, const double* xfA, const double* xsA, double* yA,
@@ -2296,30 +2338,42 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
     if (C::LDS_BYTES <= 160 * 1024) {                                                                           \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                       \
       constexpr bool kWave = (NQ_ * NQ_ <= 64);                                                                 \
+      constexpr bool kEven = (N_ % 2 == 0) && (NQ_ % 2 == 0);                                                   \
+      const bool use_eo = kEven && bk.d_EBf && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0;                  \
       if (kWave && use_wave) {                                               \
         launch_stiffness_wave<N_, (kWave ? NQ_ : N_)>(plan, bk, use_pf, u, Au);                                 \
       } else if (!kWave && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] != 0) {                                  \
         /* p >= 8: multi-wave workgroup, two LDS fields (sequential field hand-off) -> 1.5x the residency */  \
         using W = WaveCfg<N_, NQ_>;                                                                             \
-        std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,false> (%d threads)", N_, NQ_, W::THREADS); \
-        set_lds_limit(stiffness_wave_kernel<N_, NQ_, false>, W::LDS_BYTES);                                     \
-        hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
-                           plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,               \
-                           plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, bk.d_GT, 0);   \
+        std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,false,%s> (%d threads)", N_, NQ_, use_eo ? "eo" : "plain", W::THREADS); \
+        if (use_eo) {                                                                                           \
+          set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven>, W::LDS_BYTES);                            \
+          hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
+                             plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
+                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, 0); \
+        } else {                                                                                                \
+          set_lds_limit(stiffness_wave_kernel<N_, NQ_, false>, W::LDS_BYTES);                                   \
+          hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
+                             plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
+                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, bk.d_GT, 0); \
+        }                                                                                                       \
       } else {                                                                                                  \
         constexpr bool kCanPF = (NQ_ <= 8);                                                                     \
-        std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_kernel<%d,%d,%s>", N_, NQ_, (kCanPF && use_pf) ? "true" : "false"); \
-        if (kCanPF && use_pf) {                                        \
-          set_lds_limit(stiffness_kernel<N_, NQ_, kCanPF>, C::LDS_BYTES);                                       \
-          hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, kCanPF>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,   \
-                             plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
-                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);                      \
-        } else {                                                                                                \
-          set_lds_limit(stiffness_kernel<N_, NQ_, false>, C::LDS_BYTES);                                        \
-          hipLaunchKernelGGL((stiffness_kernel<N_, NQ_, false>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES,    \
-                             plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
-                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, bk.d_GT);                      \
-        }                                                                                                       \
+        const bool pf = kCanPF && use_pf;                                                                       \
+        std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_kernel<%d,%d,%s,%s>", N_, NQ_, pf ? "true" : "false", use_eo ? "eo" : "plain"); \
+        const double* o0 = use_eo ? bk.d_EBb : bk.d_B;                                                          \
+        const double* o1 = use_eo ? bk.d_EGb : bk.d_G;                                                          \
+        const double* o2 = use_eo ? bk.d_EBf : bk.d_BT;                                                         \
+        const double* o3 = use_eo ? bk.d_EGf : bk.d_GT;                                                         \
+        auto go = [&](auto kern) {                                                                              \
+          set_lds_limit(kern, C::LDS_BYTES);                                                                    \
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, u, Au, plan->d_metric, \
+                             plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, o0, o1, o2, o3); \
+        };                                                                                                      \
+        if (pf && use_eo) go(stiffness_kernel<N_, NQ_, kCanPF, kEven>);                                         \
+        else if (pf) go(stiffness_kernel<N_, NQ_, kCanPF, false>);                                              \
+        else if (use_eo) go(stiffness_kernel<N_, NQ_, false, kEven>);                                           \
+        else go(stiffness_kernel<N_, NQ_, false, false>);                                                       \
       }                                                                                                         \
       done = true;                                                                                              \
     }                                                                                                           \

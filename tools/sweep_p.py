@@ -10,6 +10,9 @@ for deg, level, count in ((1, 6, None), (2, 5, None), (3, 5, None), (5, 5, 16384
     plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=torch.cuda.current_stream())
     plan.set_geometry(J, rst)
     du = torch.from_numpy(u).to(dev); out = torch.empty_like(du)
+    if len(sys.argv) > 1:  # "key=value,key=value" tuning overrides
+        for kv in sys.argv[1].split(","):
+            k_, v_ = kv.split("="); plan.set_tuning(int(k_), int(v_))
     for _ in range(5): plan.apply_stiffness_matrix(du, out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
