@@ -49,6 +49,7 @@ SIGNATURES = {
     "d4est_hip_plan_set_sipg": (None, [_vp, ctypes.c_double, ctypes.c_int]),
     "d4est_hip_plan_set_mortar_geometry": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "d4est_hip_plan_set_dirichlet_values": (None, [_vp, _vp, ctypes.c_int]),
+    "d4est_hip_plan_set_robin_values": (None, [_vp, _vp, _vp, ctypes.c_int]),
     "d4est_hip_plan_trace_size": (ctypes.c_longlong, [_vp]),
     "d4est_hip_plan_ghost_trace_size": (ctypes.c_longlong, [_vp]),
     "d4est_hip_compute_ghost_traces": (None, [_vp, _vp, _vp]),
@@ -221,6 +222,15 @@ class Plan:
         else:
             g = np.ascontiguousarray(g, dtype=np.float64)
             self.lib.d4est_hip_plan_set_dirichlet_values(self.handle, g.ctypes.data_as(_vp), 0)
+
+    def set_robin_values(self, coeff_quad, rhs_quad):
+        """Robin data at the boundary sides' mortar quadrature nodes (indexed like sj); None switches back to Dirichlet"""
+        if coeff_quad is None:
+            self.lib.d4est_hip_plan_set_robin_values(self.handle, None, None, 0)
+            return
+        c = np.ascontiguousarray(coeff_quad, dtype=np.float64)
+        r = np.ascontiguousarray(rhs_quad, dtype=np.float64)
+        self.lib.d4est_hip_plan_set_robin_values(self.handle, c.ctypes.data_as(_vp), r.ctypes.data_as(_vp), 0)
 
     def compute_ghost_traces(self, u_ghost, ghost_trace):
         assert ghost_trace.numel() == self.ghost_trace_size

@@ -341,6 +341,12 @@ void d4est_hip_plan_set_dirichlet_values(d4est_hip_plan_t* plan, const double* g
   d4est_hip::faces_set_dirichlet(plan, g_lobatto, on_device);
 }
 
+void d4est_hip_plan_set_robin_values(d4est_hip_plan_t* plan, const double* coeff_quad, const double* rhs_quad, int on_device) {
+  check_plan(plan, "plan_set_robin_values");
+  if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_robin_values: call d4est_hip_plan_set_faces first");
+  d4est_hip::faces_set_robin(plan, coeff_quad, rhs_quad, on_device);
+}
+
 long long d4est_hip_plan_trace_size(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_trace_size"); return plan->local_trace_doubles; }
 long long d4est_hip_plan_ghost_trace_size(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_ghost_trace_size"); return plan->ghost_trace_doubles; }
 

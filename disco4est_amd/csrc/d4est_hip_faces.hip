@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void flux_generic_kernel(const double* __restr
                                                            double* __restrict__ Au, const SideDesc* __restrict__ sd,
                                                            const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                            const double* __restrict__ geom, const double* __restrict__ bndry_q,
+                                                           const double* __restrict__ robin_c, const double* __restrict__ robin_r,
                                                            int n_elem, int fld_stride) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* A = smem;                     // 4 term fields at the mortar nodes
@@ -274,6 +275,12 @@ __global__ __launch_bounds__(256) void flux_generic_kernel(const double* __restr
       const double* qm = qtrace + d.qoff;
       const double* qp = ((d.kind == 2) ? ghost_qtrace : qtrace) + d.nbr_qoff;
       for (int k = threadIdx.x; k < T; k += blockDim.x) {
+        if (d.kind == 0 && robin_c) {
+          // Robin boundary (d4est_laplacian_flux_sipg.c:339-489): only  sj (coeff u_m - rhs), integrated and lifted
+          A[k] = robin_c[d.geom + k] * qm[k] - robin_r[d.geom + k];
+          for (int l = 0; l < 3; ++l) A[(1 + l) * fld_stride + k] = 0.0;
+          continue;
+        }
         const int kp = (d.kind == 0) ? k : reorder_index(d.code, NQ - 1, k % NQ, k / NQ);
         const double um = qm[k];
         const double up = (d.kind == 0) ? bndry_q[d.geom + k] : qp[kp];
@@ -460,6 +467,7 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
                                                         double* __restrict__ Au, const SideDesc* __restrict__ sd,
                                                         const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                         const double* __restrict__ geom, const double* __restrict__ bndry_q,
+                                                        const double* __restrict__ robin_c, const double* __restrict__ robin_r,
                                                         int n_elem) {
   __shared__ double s_in[6][4][64];   // per wave: 4 term fields on the 8 x 8 grid
   __shared__ double s_tmp[6][4][64];
@@ -495,12 +503,18 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
         const double* p = ((d.kind == 2) ? ghost_qtrace : qtrace) + d.nbr_qoff + reorder_index(d.code, NQ - 1, lo, hi);
 #pragma unroll
         for (int c = 0; c < 4; ++c) qp[c] = p[c * T];
+      } else if (robin_c) {
+        qp[0] = robin_r[d.geom + k];
       } else {
         qp[0] = bndry_q[d.geom + k];
       }
-      const double* g = geom + (size_t)7 * d.geom + k;
+      if (d.kind == 0 && robin_c) {
+        gq[6] = robin_c[d.geom + k];  // am = ap = 0: no term 1 / term 2 on a Robin side
+      } else {
+        const double* g = geom + (size_t)7 * d.geom + k;
 #pragma unroll
-      for (int c = 0; c < 7; ++c) gq[c] = g[c * T];
+        for (int c = 0; c < 7; ++c) gq[c] = g[c * T];
+      }
     }
     const double ope = (hi < N && lo < NQ) ? face_ops[d.offE + hi * NQ + lo] : 0.0;
     const double dval = (threadIdx.x < 64) ? face_ops[el.offD + threadIdx.x] : 0.0;
@@ -518,7 +532,8 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
       for (int i = 0; i < 3; ++i) t1 += gq[i] * qm[1 + i] + gq[3 + i] * qp[1 + i];  // gq[3..5] = 0 on boundary sides
       const double jump = qm[0] - qp[0];
       const double w1 = (d.kind != 0) ? -0.5 : -1.0;
-      s_in[f][0][lane] = w1 * t1 + gq[6] * jump;
+      // Robin boundary (d4est_laplacian_flux_sipg.c:339-489): sj (coeff u_m - rhs) only
+      s_in[f][0][lane] = (d.kind == 0 && robin_c) ? gq[6] * qm[0] - qp[0] : w1 * t1 + gq[6] * jump;
 #pragma unroll
       for (int l = 0; l < 3; ++l) s_in[f][1 + l][lane] = w1 * gq[l] * jump;
     }
@@ -570,6 +585,10 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
 namespace {
 
 struct FaceHost {
+  double* d_sj = nullptr;       // raw sj (for Robin data)
+  double* d_robin_c = nullptr;  // sj * coeff, sj * rhs at the mortar nodes of the boundary sides
+  double* d_robin_r = nullptr;
+  bool robin = false;
   std::vector<int> side_deg_m, side_deg_p;
   int* d_side_deg_m = nullptr;
   int* d_side_deg_p = nullptr;
@@ -813,6 +832,9 @@ void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n,
                        plan->sipg_prefactor, plan->sipg_penalty_fcn, plan->d_face_geom);
     HIP_CHECK(hipGetLastError());
   }
+  // raw sj is kept for Robin boundary data (faces_set_robin)
+  if (!fh.d_sj) HIP_CHECK(hipMalloc(&fh.d_sj, std::max<size_t>(T, 1) * sizeof(double)));
+  if (T > 0) HIP_CHECK(hipMemcpyAsync(fh.d_sj, dev[0], T * sizeof(double), hipMemcpyDeviceToDevice, plan->stream));
   HIP_CHECK(hipStreamSynchronize(plan->stream));
   for (int i = 0; i < 6; ++i)
     if (tmp[i]) HIP_CHECK(hipFree(tmp[i]));
@@ -843,6 +865,52 @@ void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_d
   if (tmp) {
     HIP_CHECK(hipStreamSynchronize(plan->stream));
     HIP_CHECK(hipFree(tmp));
+  }
+}
+
+__global__ __launch_bounds__(256) void robin_setup_kernel(const double* __restrict__ sj, const double* __restrict__ coeff,
+                                                          const double* __restrict__ rhs, double* __restrict__ c,
+                                                          double* __restrict__ r, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    c[i] = sj[i] * coeff[i];
+    r[i] = sj[i] * rhs[i];
+  }
+}
+
+// Robin boundary data at the mortar quadrature nodes of the boundary sides (indexed like sj: side stride S + k).
+// coeff_quad == NULL switches the boundary sides back to Dirichlet.
+void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const double* rhs_quad, int on_device) {
+  FaceHost& fh = g_face_host[plan];
+  if (!plan->has_face_geometry) D4EST_HIP_ABORT("plan_set_robin_values: call d4est_hip_plan_set_mortar_geometry first (needs sj)");
+  if (!coeff_quad) {
+    fh.robin = false;
+    return;
+  }
+  if (!rhs_quad) D4EST_HIP_ABORT("plan_set_robin_values: rhs_quad is NULL");
+  const size_t tm = (size_t)plan->total_mortar_nodes;
+  if (!fh.d_robin_c) {
+    HIP_CHECK(hipMalloc(&fh.d_robin_c, std::max<size_t>(tm, 1) * sizeof(double)));
+    HIP_CHECK(hipMalloc(&fh.d_robin_r, std::max<size_t>(tm, 1) * sizeof(double)));
+  }
+  fh.robin = true;
+  if (tm == 0) return;
+  const double* dc = coeff_quad;
+  const double* dr = rhs_quad;
+  double *tc = nullptr, *tr = nullptr;
+  if (!on_device) {
+    HIP_CHECK(hipMalloc(&tc, tm * sizeof(double)));
+    HIP_CHECK(hipMalloc(&tr, tm * sizeof(double)));
+    HIP_CHECK(hipMemcpy(tc, coeff_quad, tm * sizeof(double), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(tr, rhs_quad, tm * sizeof(double), hipMemcpyHostToDevice));
+    dc = tc;
+    dr = tr;
+  }
+  hipLaunchKernelGGL(robin_setup_kernel, dim3(1024), dim3(256), 0, plan->stream, fh.d_sj, dc, dr, fh.d_robin_c, fh.d_robin_r, tm);
+  HIP_CHECK(hipGetLastError());
+  if (tc) {
+    HIP_CHECK(hipStreamSynchronize(plan->stream));
+    HIP_CHECK(hipFree(tc));
+    HIP_CHECK(hipFree(tr));
   }
 }
 
@@ -892,13 +960,14 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     const int grid = (n + rounds - 1) / rounds;
     hipLaunchKernelGGL(flux_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
                        (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops,
-                       plan->d_face_geom, plan->d_bndry, n);
+                       plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n);
   } else {
     const size_t lds = generic_lds_bytes(plan);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(flux_generic_kernel, dim3(std::min(n, 16384)), dim3(256), lds, plan->stream, trace, ghost_trace, Au,
                        (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
-                       plan->d_face_geom, plan->d_bndry, n, fh.fld_stride);
+                       plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n,
+                       fh.fld_stride);
   }
   HIP_CHECK(hipGetLastError());
 }
@@ -909,6 +978,7 @@ void faces_destroy(d4est_hip_plan* plan) {
     FaceHost& fh = it->second;
     (void)hipFree(fh.d_side_deg_m); (void)hipFree(fh.d_side_deg_p); (void)hipFree(fh.d_side_bndry_stride);
     (void)hipFree(fh.d_ghost_sides); (void)hipFree(fh.d_elem_desc_generic);
+    (void)hipFree(fh.d_sj); (void)hipFree(fh.d_robin_c); (void)hipFree(fh.d_robin_r);
     g_face_host.erase(it);
   }
   (void)hipFree(plan->d_elem_desc);

@@ -130,6 +130,7 @@ void faces_setup(d4est_hip_plan* plan);
 void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n, const double* drst_m, const double* drst_p,
                         const double* hm, const double* hp, int on_device);
 void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_device);
+void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const double* rhs_quad, int on_device);
 void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost);
 void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au);
 void faces_destroy(d4est_hip_plan* plan);

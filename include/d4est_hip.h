@@ -153,6 +153,12 @@ void d4est_hip_plan_set_mortar_geometry(d4est_hip_plan_t* plan, const double* sj
 /* Dirichlet values on the Lobatto face nodes of every boundary side (EVAL_BNDRY_FCN_ON_LOBATTO,
  * d4est_laplacian_flux_sipg.c:80-112); NULL resets to zero (the homogeneous operator used by apply_lhs). */
 void d4est_hip_plan_set_dirichlet_values(d4est_hip_plan_t* plan, const double* g_lobatto, int on_device);
+/* Robin boundary condition on ALL boundary sides instead of Dirichlet (BC_ROBIN of d4est_laplacian_flux_new;
+ * d4est_laplacian_flux_sipg_robin, d4est_laplacian_flux_sipg.c:339-489): the side adds  V^T W sj (coeff u_m - rhs), lifted.
+ * The reference evaluates the callbacks robin_coeff / robin_rhs at the boundary mortar quadrature nodes (:388-412); here the
+ * caller hands the two arrays, indexed like sj (side_mortar_stride[s] + k, total_mortar_nodes doubles; only the boundary
+ * sides' entries are read).  coeff_quad == NULL switches back to Dirichlet.  Call after plan_set_mortar_geometry. */
+void d4est_hip_plan_set_robin_values(d4est_hip_plan_t* plan, const double* coeff_quad, const double* rhs_quad, int on_device);
 /* Trace buffers.  For every side s the engine keeps u and du/dr_{0,1,2} INTERPOLATED TO THE SIDE'S MORTAR QUADRATURE
  * NODES (what d4est_laplacian_flux_interface forms at src/dGMath/d4est_laplacian_flux.c:635-815, once per side instead
  * of once per flux call): a block of 4 T doubles, T = (deg_mortar_quad+1)^2, field c at c*T, node a + NQ*b in the

@@ -134,6 +134,10 @@ void oracle_laplacian_apply_aij(int quad_type, int n_elements, const int* deg, c
                                 const double* u, const double* u_ghost, const double* bndry_lobatto, double* Au,
                                 int stiffness_threads);                                              /* d4est_laplacian.c:318-417 */
 
+/* Robin boundary data for the next oracle_laplacian_apply_aij calls (BC_ROBIN, d4est_laplacian_flux_sipg.c:339-489): coeff and rhs at
+ * the boundary mortar quadrature nodes, indexed like sj; NULL, NULL = Dirichlet (default). */
+void oracle_flux_set_robin(const double* coeff_quad, const double* rhs_quad);
+
 /* ---- smoother inner loops (oracle/d4est_oracle_solver.c) ---- */
 void oracle_set_aij_operator(int quad_type, int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
                              const int* quad_stride, int local_nodes, int local_nodes_quad, const double* J_quad,

@@ -212,6 +212,34 @@ static void flux_interface_side(const flux_ctx_t* c, int e, int f_m, const doubl
   free(term1); free(term3); free(vt); free(proj); free(lifted); free(dt); free(acc1); free(acc2); free(acc3); free(t2sum);
 }
 
+/* Robin boundary data (BC_ROBIN): the callbacks robin_coeff / robin_rhs of d4est_laplacian_robin_bc_t evaluated at the
+ * boundary mortar quadrature nodes (d4est_laplacian_flux_sipg.c:388-412), indexed like sj.  NULL = Dirichlet. */
+static const double* g_robin_coeff = NULL;
+static const double* g_robin_rhs = NULL;
+void oracle_flux_set_robin(const double* coeff_quad, const double* rhs_quad) {
+  g_robin_coeff = coeff_quad;
+  g_robin_rhs = rhs_quad;
+}
+
+/* one Robin boundary side: d4est_laplacian_flux.c:23-230 (trace + interpolation) + d4est_laplacian_flux_sipg.c:339-489 */
+static void flux_robin_side(const flux_ctx_t* c, int e, int f_m, const double* u, double* Au) {
+  const int s = 6 * e + f_m;
+  const int deg = c->deg[e], deg_q = c->deg_quad[e];
+  const int fm = (deg + 1) * (deg + 1), T = (deg_q + 1) * (deg_q + 1), vn = fm * (deg + 1);
+  const int S = c->side_mortar_stride[s];
+  const double* sj = &c->sj[S];
+  double* u_f = dalloc(fm); double* u_q = dalloc(T); double* term1 = dalloc(T);
+  double* vt = dalloc(fm); double* lifted = dalloc(vn);
+  oracle_apply_slicer(&u[c->nodal_stride[e]], f_m, deg, u_f);
+  interp2d(c->quad_type, u_f, deg, u_q, deg_q);
+  for (int k = 0; k < T; k++) term1[k] = sj[k] * (g_robin_coeff[S + k] * u_q[k] - g_robin_rhs[S + k]); /* :414-415 */
+  galerkin2d(c->quad_type, term1, deg, deg_q, vt);                                                       /* :419-432 */
+  oracle_apply_lift(vt, deg, f_m, lifted);                                                               /* :435-441 */
+  double* Au_m = &Au[c->nodal_stride[e]];
+  for (int i = 0; i < vn; i++) Au_m[i] += lifted[i];                                                     /* :480-483 */
+  free(u_f); free(u_q); free(term1); free(vt); free(lifted);
+}
+
 /* one Dirichlet boundary side: d4est_laplacian_flux.c:23-230 + d4est_laplacian_flux_sipg.c:15-336 */
 static void flux_boundary_side(const flux_ctx_t* c, int e, int f_m, const double* u, double* const dudr_local[3],
                                const double* bndry_lobatto, double* Au) {
@@ -299,7 +327,10 @@ void oracle_laplacian_apply_aij(int quad_type, int n_elements, const int* deg, c
   if (n_ghost > 0) oracle_laplacian_compute_dudr(n_ghost, ghost_deg, ghost_nodal_stride, u_ghost, dg[0], dg[1], dg[2]);
   for (int e = 0; e < n_elements; e++)
     for (int f = 0; f < 6; f++) {
-      if (side_nbr[6 * e + f] == -1) flux_boundary_side(&c, e, f, u, dl, bndry_lobatto, Au);
+      if (side_nbr[6 * e + f] == -1) {
+        if (g_robin_coeff) flux_robin_side(&c, e, f, u, Au);
+        else flux_boundary_side(&c, e, f, u, dl, bndry_lobatto, Au);
+      }
       else flux_interface_side(&c, e, f, u, u_ghost, dl, dg, Au);
     }
   for (int d = 0; d < 3; d++) { free(dl[d]); free(dg[d]); }

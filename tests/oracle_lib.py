@@ -193,8 +193,20 @@ class Oracle:
             out[q:q + q3] = o
         return out
 
-    def apply_aij(self, mesh, J, rst, sides, u, u_ghost=None, bndry_lobatto=None, penalty_prefactor=10.0, penalty_fcn=0, nthreads=1):
-        """d4est_laplacian_apply_aij on the flat side list of mesh.build_sides()"""
+    def apply_aij(self, mesh, J, rst, sides, u, u_ghost=None, bndry_lobatto=None, penalty_prefactor=10.0, penalty_fcn=0, nthreads=1,
+                  robin=None):
+        """d4est_laplacian_apply_aij on the flat side list of mesh.build_sides(); robin = (coeff_quad, rhs_quad) switches
+        the boundary sides to BC_ROBIN"""
+        self.lib.oracle_flux_set_robin.argtypes = [dp, dp]
+        if robin is not None:
+            rc, rr = (np.ascontiguousarray(a, dtype=np.float64) for a in robin)
+            self.lib.oracle_flux_set_robin(P(rc), P(rr))
+        try:
+            return self._apply_aij(mesh, J, rst, sides, u, u_ghost, bndry_lobatto, penalty_prefactor, penalty_fcn, nthreads)
+        finally:
+            self.lib.oracle_flux_set_robin(None, None)
+
+    def _apply_aij(self, mesh, J, rst, sides, u, u_ghost, bndry_lobatto, penalty_prefactor, penalty_fcn, nthreads):
         Au = np.zeros(mesh.local_nodes)
         ug = np.zeros(max(sides["ghost_nodes"], 1)) if u_ghost is None else np.ascontiguousarray(u_ghost)
         bl = None if bndry_lobatto is None else np.ascontiguousarray(bndry_lobatto, dtype=np.float64)

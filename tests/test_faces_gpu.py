@@ -56,6 +56,35 @@ def test_apply_aij_parity(gpu, hiplib, oracle, level, deg, inc, curved, fcn):
     plan.destroy()
 
 
+@pytest.mark.parametrize("level,deg,inc", [(1, 2, 0), (1, 3, 1), (1, 7, 0), (1, 9, 0), (0, 4, 2)])
+def test_apply_aij_robin_parity(gpu, hiplib, oracle, level, deg, inc):
+    """BC_ROBIN boundary sides (d4est_laplacian_flux_sipg_robin), then back to Dirichlet."""
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(level, deg, deg_quad_inc=inc)
+    mp = M.SineMap(0.05)
+    J, rst = m.geometry(mp)
+    sides = m.build_sides(mp)
+    u = m.field(mp)
+    tm = int(sides["total_mortar_nodes"])
+    coeff = 0.5 + M.splitmix64_uniform(11, tm)
+    rhs = M.splitmix64_uniform(12, tm) - 0.5
+    coeff[::7] = 0.0  # Neumann nodes: coeff = 0 must not divide
+    ref = oracle.apply_aij(m, J, rst, sides, u, penalty_prefactor=7.5, nthreads=8, robin=(coeff, rhs))
+    plan = _plan(m, J, rst, sides, 7.5, 0)
+    plan.set_robin_values(coeff, rhs)
+    du = _t(u, gpu)
+    dAu = torch.full_like(du, float("nan"))
+    plan.apply_aij(du, dAu)
+    assert _rel(dAu.cpu().numpy(), ref) <= RTOL
+    plan.set_robin_values(None, None)
+    plan.apply_aij(du, dAu)
+    ref0 = oracle.apply_aij(m, J, rst, sides, u, penalty_prefactor=7.5, nthreads=8)
+    assert _rel(dAu.cpu().numpy(), ref0) <= RTOL
+    assert _rel(ref, ref0) > 1e-6  # the two boundary conditions really differ
+    plan.destroy()
+
+
 def test_apply_aij_mixed_p(gpu, hiplib, oracle):
     """p-nonconforming mortars (different degree on the two sides of a face), config-4 style."""
     import torch

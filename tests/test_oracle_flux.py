@@ -75,3 +75,31 @@ def test_rank_count_invariance(oracle):
         Au = oracle.apply_aij(m, J, rst, s, u, u_ghost=m.gather_ghost(s, ug))
         got[m.global_nodal_offset:m.global_nodal_offset + m.local_nodes] = Au
     assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_robin_boundary(oracle):
+    """BC_ROBIN (d4est_laplacian_flux_sipg.c:339-489): with coeff = rhs = 0 the boundary sides add nothing, so the operator is
+    the pure-Neumann one: constants are in its null space; and the Robin term is linear in (coeff, rhs)."""
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(1, 3)
+    mp = M.SineMap(0.05)
+    J, rst = m.geometry(mp)
+    sides = m.build_sides(mp)
+    tm = int(sides["total_mortar_nodes"])
+    z = np.zeros(tm)
+    ones = np.ones(m.local_nodes)
+    A1 = oracle.apply_aij(m, J, rst, sides, ones, robin=(z, z))
+    u = m.field(mp)
+    scale = np.abs(oracle.apply_aij(m, J, rst, sides, u, robin=(z, z))).max()
+    assert np.abs(A1).max() <= 1e-11 * scale
+    c = 0.5 + M.splitmix64_uniform(3, tm)
+    r = M.splitmix64_uniform(4, tm)
+    a0 = oracle.apply_aij(m, J, rst, sides, u, robin=(z, z))
+    a1 = oracle.apply_aij(m, J, rst, sides, u, robin=(c, r))
+    a2 = oracle.apply_aij(m, J, rst, sides, u, robin=(2 * c, 2 * r))
+    assert np.abs((a2 - a0) - 2 * (a1 - a0)).max() <= 1e-12 * scale
+    # symmetry of the Robin operator (rhs = 0): v.A u == u.A v
+    v = M.splitmix64_uniform(5, m.local_nodes)
+    Au = oracle.apply_aij(m, J, rst, sides, u, robin=(c, z))
+    Av = oracle.apply_aij(m, J, rst, sides, v, robin=(c, z))
+    assert abs(v @ Au - u @ Av) <= 1e-11 * abs(v @ Au)
