@@ -46,6 +46,7 @@ SIGNATURES = {
     "d4est_hip_compute_dudr": (None, [_vp, _vp, _vp, _vp, _vp]),
     "d4est_hip_plan_set_faces": (None, [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _c_int_p, _c_int_p]),
+    "d4est_hip_plan_set_hanging": (None, [_vp, _vp, _vp, _vp, _vp]),
     "d4est_hip_plan_set_sipg": (None, [_vp, ctypes.c_double, ctypes.c_int]),
     "d4est_hip_plan_set_mortar_geometry": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "d4est_hip_plan_set_dirichlet_values": (None, [_vp, _vp, ctypes.c_int]),
@@ -207,6 +208,10 @@ class Plan:
         keep = [_iarr(sides[k]) for k in ("side_nbr", "side_nbr_face", "side_reorder", "side_mortar_stride", "side_bndry_stride",
                                          "ghost_deg", "ghost_deg_quad")]
         self._keep_sides = keep
+        if "side_hang" in sides and np.any(np.asarray(sides["side_hang"]) != 0):
+            hk = [_iarr(sides[k]) for k in ("side_hang", "side_sub", "side_nbr4", "side_orientation")]
+            self._keep_hang = hk
+            self.lib.d4est_hip_plan_set_hanging(self.handle, hk[0][1], hk[1][1], hk[2][1], hk[3][1])
         self.lib.d4est_hip_plan_set_faces(self.handle, keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
                                           int(sides["total_mortar_nodes"]), int(sides["total_bndry_nodes"]),
                                           len(keep[5][0]), keep[5][1], keep[6][1])

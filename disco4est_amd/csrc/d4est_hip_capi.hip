@@ -320,6 +320,18 @@ void d4est_hip_plan_set_faces(d4est_hip_plan_t* plan, const int* side_nbr, const
   d4est_hip::faces_setup(plan);
 }
 
+void d4est_hip_plan_set_hanging(d4est_hip_plan_t* plan, const int* side_hang, const int* side_sub, const int* side_nbr4,
+                                const int* side_orientation) {
+  check_plan(plan, "plan_set_hanging");
+  if (plan->has_faces) D4EST_HIP_ABORT("plan_set_hanging: call before d4est_hip_plan_set_faces");
+  const size_t ns = 6 * (size_t)plan->n_elements;
+  if (ns > 0 && (!side_hang || !side_sub || !side_nbr4 || !side_orientation)) D4EST_HIP_ABORT("plan_set_hanging: NULL array");
+  plan->side_hang.assign(side_hang, side_hang + ns);
+  plan->side_sub.assign(side_sub, side_sub + ns);
+  plan->side_nbr4.assign(side_nbr4, side_nbr4 + 4 * ns);
+  plan->side_orientation.assign(side_orientation, side_orientation + ns);
+}
+
 void d4est_hip_plan_set_sipg(d4est_hip_plan_t* plan, double penalty_prefactor, int penalty_fcn) {
   check_plan(plan, "plan_set_sipg");
   if (penalty_fcn < 0 || penalty_fcn > 3) D4EST_HIP_ABORT("plan_set_sipg: unknown penalty function %d", penalty_fcn);

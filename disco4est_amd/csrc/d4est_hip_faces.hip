@@ -328,6 +328,198 @@ __global__ __launch_bounds__(256) void flux_generic_kernel(const double* __restr
 }
 
 // ---------------------------------------------------------------------------
+// Non-conforming (hanging 1 <-> 4) meshes: mortar-record path.  Every side owns 1 record (conforming, boundary, or the
+// hanging "small" side: faces_m = 4, faces_p = 1, seen from one of the four small elements) or 4 records (the "big" side:
+// faces_m = 1, faces_p = 4).  A record's mortar-node trace block is produced by its own element with
+//   conforming / small:  p-prolong + interpolation              (Mesh/d4est_mortars.c:556-566, d4est_laplacian_flux.c:659-694)
+//   big, sub-mortar i:   hp-prolong child (i & 1, i >> 1) + interpolation   (Mesh/d4est_mortars.c:568-579)
+// and consumed by the element itself and by the element across the mortar.  du/dr in a block is with respect to the
+// producing element's own reference coordinates; the mortar's metric (given on the mortar-sized cell) is twice the big
+// element's, hence the factors fm / fp = 1/2 on the big element's gradient and w2 = 1/2 on the big side's term 2
+// (d4est_laplacian_flux.c:905-915, d4est_laplacian_flux_sipg.c:806-808).
+// ---------------------------------------------------------------------------
+struct HpMortar {
+  int elem, face;
+  int kind;          // 0 boundary, 1 interface
+  int code;          // reorder code applied when reading the (+) block
+  int N, NQ;         // side nodes / mortar quadrature nodes per direction
+  int offCa, offCb;  // (NQ x N) side -> mortar quadrature nodes along the face axes a, b (hp_ops)
+  int offEa, offEb;  // (N x NQ) mortar quadrature nodes -> side
+  int first, last;   // first / last record of its side
+  int gidx;          // scalar index of the mortar's first node in the precombined geometry / boundary arrays (S + off)
+  int pad;
+  double fm, fp, w2, pad2;
+  long long qoff, nbr_qoff;
+};
+
+struct HpGeomSrc {   // where the record's factors sit in the reference-layout arrays (set-up only)
+  int S, off, Ttot, off_p;
+  int deg_m, deg_p, pad0, pad1;
+};
+
+// out (rows x rows) = (opb (x) opa) in (cols x cols): opa contracts the fast face index a, opb the slow index b
+__device__ inline void apply2d_ab(const double* __restrict__ opa, const double* __restrict__ opb, int rows, int cols, const double* in,
+                                  double* tmp, double* out, int nfields, int in_stride, int out_stride, int tmp_stride, bool accumulate) {
+  for (int idx = threadIdx.x; idx < nfields * rows * cols; idx += blockDim.x) {
+    const int fld = idx / (rows * cols), r = idx % (rows * cols), ap = r % rows, b = r / rows;
+    const double* x = in + fld * in_stride + cols * b;
+    double s = 0.0;
+    for (int a = 0; a < cols; ++a) s = fma(opa[ap * cols + a], x[a], s);
+    tmp[fld * tmp_stride + ap + rows * b] = s;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < nfields * rows * rows; idx += blockDim.x) {
+    const int fld = idx / (rows * rows), r = idx % (rows * rows), ap = r % rows, bp = r / rows;
+    const double* x = tmp + fld * tmp_stride + ap;
+    double s = 0.0;
+    for (int b = 0; b < cols; ++b) s = fma(opb[bp * cols + b], x[rows * b], s);
+    if (accumulate) out[fld * out_stride + ap + rows * bp] += s;
+    else out[fld * out_stride + ap + rows * bp] = s;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void trace_hp_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
+                                                       const HpMortar* __restrict__ md, const int* __restrict__ elem_first,
+                                                       const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
+                                                       const double* __restrict__ hp_ops, int n_elem, int fld_stride) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* A = smem;                     // 4 nodal fields of the current side
+  double* tmp = A + 4 * fld_stride;
+  double* Q = tmp + 4 * fld_stride;     // 4 fields at the mortar nodes
+  double* ue = Q + 4 * fld_stride;
+  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+    const ElemDesc el = ed[e];
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
+    double* Ds = ue + N3;
+    for (int i = threadIdx.x; i < N3; i += blockDim.x) ue[i] = u[el.ns + i];
+    for (int i = threadIdx.x; i < N2; i += blockDim.x) Ds[i] = face_ops[el.offD + i];
+    __syncthreads();
+    for (int r = elem_first[e]; r < elem_first[e + 1]; ++r) {
+      const HpMortar m = md[r];
+      const int NQ = m.NQ, T = NQ * NQ;
+      if (m.first) {
+        for (int idx = threadIdx.x; idx < 4 * N2; idx += blockDim.x) {
+          const int c = idx / N2, ab = idx % N2;
+          A[c * fld_stride + ab] = nodal_trace(ue, Ds, N, N, m.face, ab % N, ab / N, c);
+        }
+        __syncthreads();
+      }
+      apply2d_ab(hp_ops + m.offCa, hp_ops + m.offCb, NQ, N, A, tmp, Q, 4, fld_stride, fld_stride, fld_stride, false);
+      for (int idx = threadIdx.x; idx < 4 * T; idx += blockDim.x) qtrace[m.qoff + idx] = Q[(idx / T) * fld_stride + idx % T];
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void face_geom_hp_kernel(const HpMortar* __restrict__ md, const HpGeomSrc* __restrict__ gs, int n_rec,
+                                                          const double* __restrict__ sj, const double* __restrict__ nrm,
+                                                          const double* __restrict__ drst_m, const double* __restrict__ drst_p,
+                                                          const double* __restrict__ hm, const double* __restrict__ hp,
+                                                          double prefactor, int fcn, double* __restrict__ geom) {
+  for (int r = blockIdx.x; r < n_rec; r += gridDim.x) {
+    const HpMortar m = md[r];
+    const HpGeomSrc g = gs[r];
+    const int NQ = m.NQ, T = NQ * NQ;
+    const size_t S = (size_t)g.S, TT = (size_t)g.Ttot;
+    for (int k = threadIdx.x; k < T; k += blockDim.x) {
+      const int a = k % NQ, b = k / NQ;
+      const int kp = (m.kind == 0) ? k : reorder_index(m.code, NQ - 1, a, b);
+      const double sjk = sj[S + g.off + k];
+      double sn[3];
+      for (int x = 0; x < 3; ++x) sn[x] = sjk * nrm[3 * S + (size_t)x * TT + g.off + k];
+      for (int i = 0; i < 3; ++i) {
+        double am = 0.0, ap = 0.0;
+        for (int x = 0; x < 3; ++x) {
+          am += sn[x] * drst_m[9 * S + (size_t)(i + 3 * x) * TT + g.off + k];
+          // (+) side factors are stored in the (+) side's sub-mortar order and orientation (d4est_laplacian_flux.c:858-900)
+          if (m.kind != 0) ap += sn[x] * drst_p[9 * S + (size_t)(i + 3 * x) * TT + g.off_p + kp];
+        }
+        geom[7 * (size_t)m.gidx + (size_t)i * T + k] = am;
+        geom[7 * (size_t)m.gidx + (size_t)(3 + i) * T + k] = ap;
+      }
+      const double hmk = hm[S + g.off + k], hpk = (m.kind == 0) ? hmk : hp[S + g.off + k];
+      geom[7 * (size_t)m.gidx + (size_t)6 * T + k] = sjk * sipg_penalty(fcn, g.deg_m, hmk, (m.kind == 0) ? g.deg_m : g.deg_p, hpk, prefactor);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void flux_hp_kernel(const double* __restrict__ qtrace, double* __restrict__ Au,
+                                                      const HpMortar* __restrict__ md, const int* __restrict__ elem_first,
+                                                      const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
+                                                      const double* __restrict__ hp_ops, const double* __restrict__ geom,
+                                                      const double* __restrict__ bndry_q, const double* __restrict__ robin_c,
+                                                      const double* __restrict__ robin_r, int n_elem, int fld_stride) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* A = smem;                     // 4 term fields at the mortar nodes
+  double* tmp = A + 4 * fld_stride;
+  double* R = tmp + 4 * fld_stride;     // 4 fields on the side's nodes, summed over the side's mortars
+  double* acc = R + 4 * fld_stride;
+  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+    const ElemDesc el = ed[e];
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
+    double* Ds = acc + N3;
+    for (int i = threadIdx.x; i < N3; i += blockDim.x) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < N2; i += blockDim.x) Ds[i] = face_ops[el.offD + i];
+    __syncthreads();
+    for (int r = elem_first[e]; r < elem_first[e + 1]; ++r) {
+      const HpMortar m = md[r];
+      const int NQ = m.NQ, T = NQ * NQ, f = m.face;
+      const double* g = geom + (size_t)7 * m.gidx;
+      const double* qm = qtrace + m.qoff;
+      const double* qp = qtrace + m.nbr_qoff;
+      for (int k = threadIdx.x; k < T; k += blockDim.x) {
+        if (m.kind == 0 && robin_c) {
+          A[k] = robin_c[m.gidx + k] * qm[k] - robin_r[m.gidx + k];
+          for (int l = 0; l < 3; ++l) A[(1 + l) * fld_stride + k] = 0.0;
+          continue;
+        }
+        const int kp = (m.kind == 0) ? k : reorder_index(m.code, NQ - 1, k % NQ, k / NQ);
+        const double um = qm[k];
+        const double up = (m.kind == 0) ? bndry_q[m.gidx + k] : qp[kp];
+        double tm = 0.0, tp = 0.0, am[3];
+        for (int i = 0; i < 3; ++i) {
+          am[i] = g[i * T + k];
+          tm += am[i] * qm[(1 + i) * T + k];
+          if (m.kind != 0) tp += g[(3 + i) * T + k] * qp[(1 + i) * T + kp];
+        }
+        const double jump = um - up;
+        const double w1 = (m.kind != 0) ? -0.5 : -1.0;
+        A[k] = w1 * (m.fm * tm + m.fp * tp) + g[6 * T + k] * jump;
+        for (int l = 0; l < 3; ++l) A[(1 + l) * fld_stride + k] = w1 * m.w2 * am[l] * jump;
+      }
+      __syncthreads();
+      apply2d_ab(hp_ops + m.offEa, hp_ops + m.offEb, N, NQ, A, tmp, R, 4, fld_stride, fld_stride, fld_stride, !m.first);
+      if (!m.last) continue;
+      const int dir = f >> 1, fix = face_fix(f, N);
+      const int sdir = (dir == 0) ? 1 : (dir == 1 ? N : N2);
+      for (int idx = threadIdx.x; idx < N3; idx += blockDim.x) {
+        const int pos = (idx / sdir) % N;
+        int a, b;
+        if (dir == 0) { a = (idx / N) % N; b = idx / N2; }
+        else if (dir == 1) { a = idx % N; b = idx / N2; }
+        else { a = idx % N; b = (idx / N) % N; }
+        double v = Ds[fix * N + pos] * R[(1 + dir) * fld_stride + a + N * b];
+        if (pos == fix) {
+          v += R[a + N * b];
+          const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;
+          double s0 = 0.0, s1 = 0.0;
+          for (int q = 0; q < N; ++q) {
+            s0 = fma(Ds[q * N + a], R[(1 + t0) * fld_stride + q + N * b], s0);
+            s1 = fma(Ds[q * N + b], R[(1 + t1d) * fld_stride + a + N * q], s1);
+          }
+          v += s0 + s1;
+        }
+        acc[idx] += v;
+      }
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < N3; i += blockDim.x) Au[el.ns + i] += acc[i];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // fast path (every N, Np, NQ <= 8, i.e. p <= 7): workgroup of six wavefronts per element, wavefront f <-> side f,
 // lane <-> node of a fixed 8 x 8 grid (index a + 8 b).  Operators are zero-padded to 8 x 8 in LDS so the tensor
 // applies are branch-free and fully unrolled (the padding multiplies zeros).
@@ -585,6 +777,15 @@ __global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict
 namespace {
 
 struct FaceHost {
+  // hanging-mesh (mortar record) path
+  bool hp = false;
+  int n_rec = 0;
+  HpMortar* d_rec = nullptr;
+  HpGeomSrc* d_gsrc = nullptr;
+  int* d_elem_first = nullptr;
+  double* d_hp_ops = nullptr;
+  int hp_fld_stride = 0;
+  size_t hp_lds_doubles = 0;
   double* d_sj = nullptr;       // raw sj (for Robin data)
   double* d_robin_c = nullptr;  // sj * coeff, sj * rhs at the mortar nodes of the boundary sides
   double* d_robin_r = nullptr;
@@ -611,10 +812,198 @@ T* upload_vec(const std::vector<T>& v) {
 
 }  // namespace
 
+// dGMath/d4est_reference.c:3-12, :84-110: index, in the (+) side's own order, of the sub-face that is i in (-) order
+int reorient_face_order(int f_m, int f_p, int o, int i) {
+  static const int FToF_code[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
+                                      {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
+  static const int code_to_perm[3][4] = {{1, 2, 5, 6}, {0, 3, 4, 7}, {0, 4, 3, 7}};
+  static const int perm_to_order[8][4] = {{0, 1, 2, 3}, {0, 2, 1, 3}, {1, 0, 3, 2}, {1, 3, 0, 2},
+                                          {2, 0, 3, 1}, {2, 3, 0, 1}, {3, 1, 2, 0}, {3, 2, 1, 0}};
+  return perm_to_order[code_to_perm[FToF_code[f_m][f_p]][o]][i];
+}
+
+// Mortar records of a mesh with hanging faces (plan->side_hang etc. set by d4est_hip_plan_set_hanging).
+static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
+  const int ne = plan->n_elements;
+  const int qt = plan->quad_type;
+  if (plan->n_ghost > 0) D4EST_HIP_ABORT("plan_set_faces: hanging faces across ranks (ghost elements) are not supported yet");
+  std::vector<double> ops;
+  std::map<std::tuple<int, int, int, int, int>, int> op_index;
+  // C: side (deg_side) -> mortar quadrature nodes (deg_mq); child = -1: p-prolong, 0/1: hp-prolong onto that half
+  auto get_C = [&](int deg_side, int deg_mq, int child) {
+    auto key = std::make_tuple(0, deg_side, deg_mq, child, 0);
+    auto it = op_index.find(key);
+    if (it != op_index.end()) return it->second;
+    const int nh = deg_mq + 1, nH = deg_side + 1;
+    std::vector<double> P;
+    if (child < 0) P = Tables1D::p_prolong(deg_side, deg_mq);
+    else {
+      std::vector<double> P2 = Tables1D::hp_prolong(deg_side, deg_mq);
+      P.assign(P2.begin() + (size_t)child * nh * nH, P2.begin() + (size_t)(child + 1) * nh * nH);
+    }
+    std::vector<double> I = Tables1D::quad_interp(qt, deg_mq, deg_mq);
+    std::vector<double> C = Tables1D::matmul(I, P, nh, nh, nH);
+    const int off = (int)ops.size();
+    ops.insert(ops.end(), C.begin(), C.end());
+    op_index[key] = off;
+    return off;
+  };
+  // E: mortar quadrature nodes (deg_mq) -> Lobatto nodes of deg_ml (V^T W) -> side (p- or hp-prolong transposed)
+  auto get_E = [&](int deg_m, int deg_ml, int deg_mq, int child) {
+    auto key = std::make_tuple(1, deg_m, deg_ml, deg_mq, child);
+    auto it = op_index.find(key);
+    if (it != op_index.end()) return it->second;
+    std::vector<double> I = Tables1D::quad_interp(qt, deg_ml, deg_mq);
+    std::vector<double> w = Tables1D::quad_weights(qt, deg_mq);
+    std::vector<double> ItW = Tables1D::transpose(I, deg_mq + 1, deg_ml + 1);
+    for (int r = 0; r <= deg_ml; ++r)
+      for (int c = 0; c <= deg_mq; ++c) ItW[(size_t)r * (deg_mq + 1) + c] *= w[c];
+    const int nh = deg_ml + 1, nH = deg_m + 1;
+    std::vector<double> P;
+    if (child < 0) P = Tables1D::p_prolong(deg_m, deg_ml);
+    else {
+      std::vector<double> P2 = Tables1D::hp_prolong(deg_m, deg_ml);
+      P.assign(P2.begin() + (size_t)child * nh * nH, P2.begin() + (size_t)(child + 1) * nh * nH);
+    }
+    std::vector<double> Pt = Tables1D::transpose(P, nh, nH);
+    std::vector<double> E = Tables1D::matmul(Pt, ItW, nH, nh, deg_mq + 1);
+    const int off = (int)ops.size();
+    ops.insert(ops.end(), E.begin(), E.end());
+    op_index[key] = off;
+    return off;
+  };
+  const size_t ns = 6 * (size_t)ne;
+  auto degq_mortar = [&](int em, int ep) { return std::max(plan->deg_quad[em], plan->deg_quad[ep]); };
+  auto nodes2 = [](int deg) { return (deg + 1) * (deg + 1); };
+  std::vector<HpMortar> rec;
+  std::vector<HpGeomSrc> gsrc;
+  std::vector<int> elem_first(ne + 1, 0), side_first(ns, 0);
+  long long qoff = 0;
+  int max_fld = 1, maxN = 1;
+  for (int e = 0; e < ne; ++e) {
+    elem_first[e] = (int)rec.size();
+    const int deg_m = plan->deg[e], degq_m = plan->deg_quad[e];
+    maxN = std::max(maxN, deg_m + 1);
+    for (int f = 0; f < 6; ++f) {
+      const size_t s = 6 * (size_t)e + f;
+      side_first[s] = (int)rec.size();
+      plan->trace_offset[s] = qoff;
+      const int hang = plan->side_hang[s], nbr = plan->side_nbr[s], f_p = plan->side_nbr_face[s], o = plan->side_orientation[s];
+      if (hang < 0 || hang > 2) D4EST_HIP_ABORT("plan_set_hanging: side %zu has side_hang %d", s, hang);
+      if (o < 0 || o > 3) D4EST_HIP_ABORT("plan_set_hanging: side %zu has orientation %d", s, o);
+      const int n_sub = (hang == 1) ? 4 : 1;
+      const int* n4 = &plan->side_nbr4[4 * s];
+      if (hang != 0)
+        for (int i = 0; i < 4; ++i)
+          if (n4[i] < 0 || n4[i] >= ne) D4EST_HIP_ABORT("plan_set_hanging: side %zu: side_nbr4[%d] = %d is not a local element", s, i, n4[i]);
+      if (hang == 2 && (nbr < 0 || nbr >= ne)) D4EST_HIP_ABORT("plan_set_hanging: small side %zu needs a local (+) element", s);
+      // mortar sizes of the whole hanging face, in (-) order and in (+) order
+      int T_m[4] = {0, 0, 0, 0}, T_p[4] = {0, 0, 0, 0};
+      if (hang != 0) {
+        for (int i = 0; i < 4; ++i) {
+          T_m[i] = nodes2(hang == 1 ? degq_mortar(e, n4[i]) : degq_mortar(n4[i], nbr));
+          T_p[reorient_face_order(f, f_p, o, i)] = T_m[i];
+        }
+      }
+      for (int i = 0; i < n_sub; ++i) {
+        HpMortar m{};
+        HpGeomSrc g{};
+        m.elem = e;
+        m.face = f;
+        m.code = plan->side_reorder[s];
+        m.N = deg_m + 1;
+        m.first = (i == 0);
+        m.last = (i == n_sub - 1);
+        m.fm = m.fp = m.w2 = 1.0;
+        int ep = -1, sub_m = 0;   // (+) element of this mortar; index of the mortar in the face's (-) order
+        if (hang == 0) {
+          if (nbr <= -2) D4EST_HIP_ABORT("plan_set_faces: ghost sides are not supported together with hanging faces");
+          m.kind = (nbr == -1) ? 0 : 1;
+          ep = nbr;
+        } else if (hang == 1) {
+          m.kind = 1;
+          ep = n4[i];
+          sub_m = i;
+          m.fm = 0.5;   // the big element's gradient on the half-size mortar
+          m.w2 = 0.5;
+        } else {
+          m.kind = 1;
+          ep = nbr;
+          sub_m = plan->side_sub[s];
+          if (sub_m < 0 || sub_m > 3 || n4[sub_m] != e) D4EST_HIP_ABORT("plan_set_hanging: small side %zu: side_sub %d does not point at the element in side_nbr4", s, sub_m);
+          m.fp = 0.5;
+        }
+        const int deg_p = (m.kind == 0) ? deg_m : plan->deg[ep];
+        const int deg_mq = (m.kind == 0) ? degq_m : degq_mortar(e, ep);
+        const int deg_ml = std::max(deg_m, deg_p);
+        m.NQ = deg_mq + 1;
+        const int ca = (hang == 1) ? (i & 1) : -1, cb = (hang == 1) ? (i >> 1) : -1;
+        m.offCa = get_C(deg_m, deg_mq, ca);
+        m.offCb = get_C(deg_m, deg_mq, cb);
+        m.offEa = get_E(deg_m, deg_ml, deg_mq, ca);
+        m.offEb = get_E(deg_m, deg_ml, deg_mq, cb);
+        g.S = plan->side_mortar_stride[s];
+        g.off = 0;
+        g.off_p = 0;
+        g.Ttot = nodes2(deg_mq);
+        if (hang != 0) {
+          g.Ttot = T_m[0] + T_m[1] + T_m[2] + T_m[3];
+          for (int j = 0; j < sub_m; ++j) g.off += T_m[j];
+          const int sub_p = reorient_face_order(f, f_p, o, sub_m);
+          for (int j = 0; j < sub_p; ++j) g.off_p += T_p[j];
+        }
+        g.deg_m = deg_m;
+        g.deg_p = deg_p;
+        m.gidx = g.S + g.off;
+        if ((long long)m.gidx + nodes2(deg_mq) > plan->total_mortar_nodes) D4EST_HIP_ABORT("plan_set_faces: side %zu mortar data exceeds total_mortar_nodes", s);
+        m.qoff = qoff;
+        qoff += 4LL * nodes2(deg_mq);
+        max_fld = std::max(max_fld, std::max(m.NQ * m.NQ, m.NQ * m.N));
+        rec.push_back(m);
+        gsrc.push_back(g);
+      }
+    }
+  }
+  elem_first[ne] = (int)rec.size();
+  // (+) blocks
+  for (size_t r = 0; r < rec.size(); ++r) {
+    HpMortar& m = rec[r];
+    if (m.kind == 0) continue;
+    const size_t s = 6 * (size_t)m.elem + m.face;
+    const int hang = plan->side_hang[s], f_p = plan->side_nbr_face[s], o = plan->side_orientation[s];
+    int ep, sub_p = 0;
+    if (hang == 1) ep = plan->side_nbr4[4 * s + (int)(r - side_first[s])];
+    else ep = plan->side_nbr[s];
+    const size_t sp = 6 * (size_t)ep + f_p;
+    const int hang_p = plan->side_hang[sp];
+    if ((hang == 0 && hang_p != 0) || (hang == 1 && hang_p != 2) || (hang == 2 && hang_p != 1))
+      D4EST_HIP_ABORT("plan_set_hanging: sides %zu and %zu disagree about the hanging face", s, sp);
+    if (hang == 2) sub_p = reorient_face_order(m.face, f_p, o, plan->side_sub[s]);   // the big element's own sub-mortar index
+    const HpMortar& mp = rec[side_first[sp] + sub_p];
+    if (mp.NQ != m.NQ) D4EST_HIP_ABORT("plan_set_hanging: sides %zu and %zu disagree on the mortar degree", s, sp);
+    m.nbr_qoff = mp.qoff;
+  }
+  plan->local_trace_doubles = qoff;
+  max_fld = std::max(max_fld, maxN * maxN);
+  fh.hp = true;
+  fh.n_rec = (int)rec.size();
+  fh.hp_fld_stride = max_fld;
+  fh.hp_lds_doubles = (size_t)12 * max_fld + (size_t)maxN * maxN * maxN + (size_t)maxN * maxN;
+  if (fh.hp_lds_doubles * sizeof(double) > 160 * 1024) D4EST_HIP_ABORT("hanging-face kernels need %zu LDS doubles", fh.hp_lds_doubles);
+  fh.d_rec = upload_vec(rec);
+  fh.d_gsrc = upload_vec(gsrc);
+  fh.d_elem_first = upload_vec(elem_first);
+  fh.d_hp_ops = upload_vec(ops);
+  plan->face_fast = false;
+}
+
 void faces_setup(d4est_hip_plan* plan) {
   FaceHost& fh = g_face_host[plan];
   const int ne = plan->n_elements;
   const int qt = plan->quad_type;
+  bool hp = false;
+  if (!plan->side_hang.empty())
+    for (int v : plan->side_hang) hp = hp || (v != 0);
   std::vector<double> ops;
   std::map<std::tuple<int, int, int, int>, int> op_index;  // (kind, deg_a, deg_b, deg_c) -> offset
   auto get_C = [&](int deg_side, int deg_mq) {
@@ -707,7 +1096,8 @@ void faces_setup(d4est_hip_plan* plan) {
   for (int e = 0; e < ne; ++e)
     for (int f = 0; f < 6; ++f) {
       const size_t s = 6 * (size_t)e + f;
-      const int nbr = plan->side_nbr[s];
+      const bool hanging = hp && plan->side_hang[s] != 0;
+      const int nbr = hanging ? -1 : plan->side_nbr[s];   // hanging sides are served by the mortar records only
       const int deg_m = plan->deg[e], degq_m = plan->deg_quad[e];
       int deg_p = deg_m, degq_p = degq_m;
       if (nbr >= 0) {
@@ -733,10 +1123,11 @@ void faces_setup(d4est_hip_plan* plan) {
     for (int f = 0; f < 6; ++f) {
       const size_t s = 6 * (size_t)e + f;
       SideDesc d{};
-      const int nbr = plan->side_nbr[s];
+      const bool hanging = hp && plan->side_hang[s] != 0;
+      const int nbr = hanging ? -1 : plan->side_nbr[s];
       const int deg_m = plan->deg[e], deg_p = deg_p_of[s], deg_mq = deg_mq_of[s];
       const int deg_ml = std::max(deg_m, deg_p);
-      d.kind = (nbr == -1) ? 0 : (nbr >= 0 ? 1 : 2);
+      d.kind = hanging ? 3 : ((nbr == -1) ? 0 : (nbr >= 0 ? 1 : 2));
       d.code = plan->side_reorder[s];
       d.NQ = deg_mq + 1;
       d.offC = get_C(deg_m, deg_mq);
@@ -746,7 +1137,7 @@ void faces_setup(d4est_hip_plan* plan) {
       d.geom = plan->side_mortar_stride[s];
       d.qoff = plan->trace_offset[s];
       d.nbr_qoff = 0;
-      if (d.kind == 1) {
+      if (d.kind == 1 && !hp) {
         const size_t sp = 6 * (size_t)nbr + plan->side_nbr_face[s];
         if (deg_mq_of[sp] != deg_mq) D4EST_HIP_ABORT("plan_set_faces: sides %zu and %zu disagree on the mortar degree (non-conforming mortar?)", s, sp);
         d.nbr_qoff = plan->trace_offset[sp];
@@ -798,6 +1189,7 @@ void faces_setup(d4est_hip_plan* plan) {
   fh.d_side_deg_p = upload_vec(fh.side_deg_p);
   fh.d_side_bndry_stride = upload_vec(plan->side_bndry_stride);
   fh.d_ghost_sides = upload_vec(gsides);
+  if (hp) faces_setup_hp(plan, fh);
   const size_t tm = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
   HIP_CHECK(hipMalloc(&plan->d_trace, std::max<size_t>((size_t)plan->local_trace_doubles, 1) * sizeof(double)));
   HIP_CHECK(hipMalloc(&plan->d_bndry, tm * sizeof(double)));  // Dirichlet data at the mortar quadrature nodes, by geom stride
@@ -825,7 +1217,12 @@ void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n,
     }
   }
   const int n_sides = 6 * plan->n_elements;
-  if (n_sides > 0) {
+  if (fh.hp) {
+    if (fh.n_rec > 0)
+      hipLaunchKernelGGL(face_geom_hp_kernel, dim3(std::min(fh.n_rec, 8192)), dim3(64), 0, plan->stream, fh.d_rec, fh.d_gsrc, fh.n_rec,
+                         dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], plan->sipg_prefactor, plan->sipg_penalty_fcn, plan->d_face_geom);
+    HIP_CHECK(hipGetLastError());
+  } else if (n_sides > 0) {
     const int grid = n_sides < 8192 ? n_sides : 8192;
     hipLaunchKernelGGL(face_geom_kernel, dim3(grid), dim3(64), 0, plan->stream, (const SideDesc*)plan->d_side_desc,
                        fh.d_side_deg_m, fh.d_side_deg_p, n_sides, dev[0], dev[1], dev[2], dev[3], dev[4], dev[5],
@@ -929,7 +1326,12 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
   }
   const int n = plan->n_elements;
   if (n == 0) return;
-  if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+  if (fh.hp) {
+    const size_t lds = fh.hp_lds_doubles * sizeof(double);
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(trace_hp_kernel, dim3(std::min(n, 16384)), dim3(256), lds, plan->stream, u, trace, fh.d_rec, fh.d_elem_first,
+                       (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, n, fh.hp_fld_stride);
+  } else if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
     const int resident = 4 * cus;
     const int rounds = (n + resident - 1) / resident;
@@ -952,7 +1354,13 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   if (plan->n_elements == 0) return;
   if (fh.n_ghost_sides > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost sides but no ghost trace buffer was given", fh.n_ghost_sides);
   const int n = plan->n_elements;
-  if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+  if (fh.hp) {
+    const size_t lds = fh.hp_lds_doubles * sizeof(double);
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_hp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(flux_hp_kernel, dim3(std::min(n, 16384)), dim3(256), lds, plan->stream, trace, Au, fh.d_rec, fh.d_elem_first,
+                       (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom, plan->d_bndry,
+                       fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, fh.hp_fld_stride);
+  } else if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     // persistent grid: 3 workgroups per CU are resident (LDS), each loops over elements
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
     const int resident = 4 * cus;
@@ -979,6 +1387,7 @@ void faces_destroy(d4est_hip_plan* plan) {
     (void)hipFree(fh.d_side_deg_m); (void)hipFree(fh.d_side_deg_p); (void)hipFree(fh.d_side_bndry_stride);
     (void)hipFree(fh.d_ghost_sides); (void)hipFree(fh.d_elem_desc_generic);
     (void)hipFree(fh.d_sj); (void)hipFree(fh.d_robin_c); (void)hipFree(fh.d_robin_r);
+    (void)hipFree(fh.d_rec); (void)hipFree(fh.d_gsrc); (void)hipFree(fh.d_elem_first); (void)hipFree(fh.d_hp_ops);
     g_face_host.erase(it);
   }
   (void)hipFree(plan->d_elem_desc);

@@ -86,6 +86,7 @@ struct d4est_hip_plan {
   int n_ghost = 0;
   std::vector<int> ghost_deg, ghost_deg_quad;
   std::vector<int> side_nbr, side_nbr_face, side_reorder, side_mortar_stride, side_bndry_stride;  // host copies, 6*n_elements
+  std::vector<int> side_hang, side_sub, side_nbr4, side_orientation;  // hanging faces (d4est_hip_plan_set_hanging); empty = conforming
   int total_mortar_nodes = 0, total_bndry_nodes = 0;
   long long local_trace_doubles = 0, ghost_trace_doubles = 0;
   int* d_side_desc = nullptr;        // SideDesc per side (see d4est_hip_faces.hip)

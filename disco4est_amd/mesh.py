@@ -278,6 +278,259 @@ class BrickMesh:
         return out
 
 
+class HangingBrickMesh(BrickMesh):
+    """Single-tree brick with ONE level of local refinement: the base cells flagged in ``refine`` (bool array over the
+    8**level base cells in Morton order) are replaced, in place, by their 8 children (z-order).  Neighbouring levels
+    differ by at most one, so the mesh is 2:1 balanced and has hanging (1 <-> 4) faces wherever a refined cell touches an
+    unrefined one -- the non-conforming mortars of src/Mesh/d4est_mortars.c:601-803.
+    ``deg`` is an int or an array over the final elements.  One rank only (no ghost layer)."""
+
+    def __init__(self, level, refine, deg, deg_quad_inc=0, quad_type=0):
+        self.level = level
+        self.quad_type = quad_type
+        base = morton_order(level)
+        refine = np.asarray(refine, dtype=bool)
+        assert refine.size == base.shape[0]
+        org, size = [], []          # origin in units of the FINE grid (2^(level+1) per side), size 1 or 2
+        for b in range(base.shape[0]):
+            o = 2 * base[b]
+            if refine[b]:
+                for c in range(8):
+                    org.append(o + np.array([c & 1, (c >> 1) & 1, (c >> 2) & 1]))
+                    size.append(1)
+            else:
+                org.append(o)
+                size.append(2)
+        self.org = np.asarray(org, dtype=np.int64)
+        self.size = np.asarray(size, dtype=np.int64)
+        total = self.org.shape[0]
+        deg_all = np.full(total, deg, dtype=np.int32) if np.isscalar(deg) else np.asarray(deg, dtype=np.int32)
+        assert deg_all.size == total
+        self.global_elements = total
+        self.first = 0
+        self.n_elements = total
+        self.deg = deg_all.copy()
+        self.deg_quad = (self.deg + deg_quad_inc).astype(np.int32)
+        self.hf = 1.0 / (1 << (level + 1))      # fine grid spacing
+        self.h_elem = self.size * self.hf
+        n3 = (self.deg.astype(np.int64) + 1) ** 3
+        q3 = (self.deg_quad.astype(np.int64) + 1) ** 3
+        self.nodal_stride = np.concatenate([[0], np.cumsum(n3)[:-1]]).astype(np.int32)
+        self.quad_stride = np.concatenate([[0], np.cumsum(q3)[:-1]]).astype(np.int32)
+        self.local_nodes = int(n3.sum())
+        self.local_nodes_quad = int(q3.sum())
+        self.deg_global = deg_all
+        self.deg_quad_global = self.deg_quad
+        self.global_nodal_stride = self.nodal_stride.astype(np.int64)
+        self.global_nodes = self.local_nodes
+        self.global_nodal_offset = 0
+
+    def _ref_coords(self, e, nodes_1d):
+        n = nodes_1d.size
+        x0 = self.org[e] * self.hf
+        t = 0.5 * self.h_elem[e] * (nodes_1d + 1.0)
+        X = np.broadcast_to(x0[0] + t[None, None, :], (n, n, n)).ravel()
+        Y = np.broadcast_to(x0[1] + t[None, :, None], (n, n, n)).ravel()
+        Z = np.broadcast_to(x0[2] + t[:, None, None], (n, n, n)).ravel()
+        return X, Y, Z
+
+    def geometry(self, mapping=None):
+        nq = self.local_nodes_quad
+        J = np.empty(nq)
+        rst = np.zeros((9, nq))
+        cache = {}
+        for e in range(self.n_elements):
+            pq = int(self.deg_quad[e])
+            if pq not in cache:
+                cache[pq] = quad_nodes(self.quad_type, pq)
+            X, Y, Z = self._ref_coords(e, cache[pq])
+            DF = mapping.jacobian(X, Y, Z) if mapping is not None else np.broadcast_to(np.eye(3), (X.size, 3, 3))
+            dxdr = DF * (0.5 * self.h_elem[e])
+            s = self.quad_stride[e]
+            q3 = (pq + 1) ** 3
+            J[s:s + q3] = np.linalg.det(dxdr)
+            inv = np.linalg.inv(dxdr)
+            for i in range(3):
+                for j in range(3):
+                    rst[3 * i + j, s:s + q3] = inv[:, i, j]
+        return J, rst.reshape(-1)
+
+    def _mortar_geom(self, x0, hm, f, pq, mapping):
+        """geometric factors on one mortar face: the face f of a (virtual) cell with origin x0 and size hm
+        (src/Mesh/d4est_mortars.c:19-190: the mortar is its own reference square, dq = mortar_dq)"""
+        d, sgn = f // 2, (1.0 if f % 2 else -1.0)
+        t = quad_nodes(self.quad_type, pq)
+        Tn = (pq + 1) ** 2
+        ax = [a for a in range(3) if a != d]
+        ref = np.zeros((Tn, 3))
+        ref[:, d] = sgn
+        ref[:, ax[0]] = np.tile(t, pq + 1)
+        ref[:, ax[1]] = np.repeat(t, pq + 1)
+        X = x0[None, :] + 0.5 * hm * (ref + 1.0)
+        DF = mapping.jacobian(X[:, 0], X[:, 1], X[:, 2]) if mapping is not None else np.broadcast_to(np.eye(3), (Tn, 3, 3))
+        dxdr = DF * (0.5 * hm)
+        Jm = np.linalg.det(dxdr)
+        inv = np.linalg.inv(dxdr)
+        v = sgn * Jm[:, None] * inv[:, d, :]
+        sjv = np.linalg.norm(v, axis=1)
+        return sjv, v / sjv[:, None], inv, Jm / sjv
+
+    def build_sides(self, mapping=None):
+        """Side list with hanging faces.  In addition to BrickMesh.build_sides():
+          side_hang[s]        0 conforming / boundary, 1 big side (this face is split: faces_m = 1, faces_p = 4),
+                              2 small side (this element is one of the 4 hanging elements: faces_m = 4, faces_p = 1)
+          side_sub[s]         small side: index c of this element among the 4 (z-order of the face children)
+          side_nbr4[4s..4s+3] big side: the 4 (+) elements in (-) order; small side: the 4 members of its own group
+          side_orientation[s] p4est orientation (0 inside one tree)
+        Mortar data in the reference's layout (src/Mesh/d4est_mesh.c:868-1110): a big side owns one block of its 4
+        sub-mortars; the 4 small sides of a hanging face SHARE one block (same side_mortar_stride) holding the 4
+        sub-mortars one after another; vector/matrix components are strided by the block's total node count."""
+        ne = self.n_elements
+        nf = 1 << (self.level + 1)
+        owner = -np.ones((nf, nf, nf), dtype=np.int64)
+        for e in range(ne):
+            o, sz = self.org[e], self.size[e]
+            owner[o[0]:o[0] + sz, o[1]:o[1] + sz, o[2]:o[2] + sz] = e
+        side_nbr = np.full(6 * ne, -1, dtype=np.int32)
+        side_nbr_face = np.zeros(6 * ne, dtype=np.int32)
+        side_reorder = np.zeros(6 * ne, dtype=np.int32)
+        side_hang = np.zeros(6 * ne, dtype=np.int32)
+        side_sub = np.zeros(6 * ne, dtype=np.int32)
+        side_nbr4 = np.full(4 * 6 * ne, -1, dtype=np.int32)
+        for e in range(ne):
+            o, sz = self.org[e], int(self.size[e])
+            for f in range(6):
+                s_ = 6 * e + f
+                d, pos = f // 2, f % 2
+                ax = [a for a in range(3) if a != d]
+                side_nbr_face[s_] = f ^ 1
+                c0 = o.copy()
+                c0[d] = o[d] + sz if pos else o[d] - 1
+                if c0[d] < 0 or c0[d] >= nf:
+                    continue
+                g = int(owner[c0[0], c0[1], c0[2]])
+                gs = int(self.size[g])
+                if gs == sz:
+                    side_nbr[s_] = g
+                    side_nbr4[4 * s_] = g
+                elif gs < sz:  # this element is the big one
+                    side_hang[s_] = 1
+                    for i in range(4):
+                        ci = c0.copy()
+                        ci[ax[0]] += i & 1
+                        ci[ax[1]] += i >> 1
+                        side_nbr4[4 * s_ + i] = int(owner[ci[0], ci[1], ci[2]])
+                    side_nbr[s_] = side_nbr4[4 * s_]
+                else:          # this element is one of the four small ones
+                    side_hang[s_] = 2
+                    side_nbr[s_] = g
+                    go = self.org[g]
+                    ia, ib = int(o[ax[0]] - go[ax[0]]), int(o[ax[1]] - go[ax[1]])
+                    side_sub[s_] = ia + 2 * ib
+                    for i in range(4):   # own group: the children of the big neighbour's face, z-order
+                        ci = o.copy()
+                        ci[ax[0]] = go[ax[0]] + (i & 1)
+                        ci[ax[1]] = go[ax[1]] + (i >> 1)
+                        side_nbr4[4 * s_ + i] = int(owner[ci[0], ci[1], ci[2]])
+        # ---- mortar blocks
+        degq = self.deg_quad
+        side_mortar_stride = np.zeros(6 * ne, dtype=np.int32)
+        blocks = []   # (stride S, [(x0, hm, f, pq_m, x0p, f_p)] per sub-mortar, owner side)
+        total = 0
+        for s_ in range(6 * ne):
+            e, f = divmod(s_, 6)
+            hang = side_hang[s_]
+            if hang == 0:
+                g = side_nbr[s_]
+                pq = int(degq[e]) if g < 0 else int(max(degq[e], degq[g]))
+                side_mortar_stride[s_] = total
+                blocks.append((total, [(self.org[e] * self.hf, self.h_elem[e], f, pq)], s_))
+                total += (pq + 1) ** 2
+            elif hang == 1:
+                d = f // 2
+                ax = [a for a in range(3) if a != d]
+                subs = []
+                side_mortar_stride[s_] = total
+                S0 = total
+                for i in range(4):
+                    g = side_nbr4[4 * s_ + i]
+                    pq = int(max(degq[e], degq[g]))
+                    hm = 0.5 * self.h_elem[e]
+                    x0 = self.org[e] * self.hf
+                    x0 = x0.copy()
+                    x0[ax[0]] += (i & 1) * hm
+                    x0[ax[1]] += (i >> 1) * hm
+                    if f % 2:
+                        x0[d] += hm   # the virtual child touching the +face
+                    subs.append((x0, hm, f, pq))
+                    total += (pq + 1) ** 2
+                blocks.append((S0, subs, s_))
+            else:
+                if side_sub[s_] != 0:
+                    continue   # the block is created by the group's first member
+                grp = side_nbr4[4 * s_:4 * s_ + 4]
+                g = side_nbr[s_]
+                subs = []
+                S0 = total
+                for i in range(4):
+                    em = int(grp[i])
+                    pq = int(max(degq[em], degq[g]))
+                    subs.append((self.org[em] * self.hf, self.h_elem[em], f, pq))
+                    side_mortar_stride[6 * em + f] = S0
+                    total += (pq + 1) ** 2
+                blocks.append((S0, subs, s_))
+        sj = np.empty(total); hm_a = np.empty(total); hp_a = np.empty(total)
+        nrm = np.zeros(3 * total); drst_m = np.zeros(9 * total); drst_p = np.zeros(9 * total)
+        for S0, subs, s_ in blocks:
+            Ttot = sum((pq + 1) ** 2 for (_, _, _, pq) in subs)
+            off = 0
+            for (x0, hm, f, pq) in subs:
+                Tn = (pq + 1) ** 2
+                sjv, nv, inv, hv = self._mortar_geom(np.asarray(x0, dtype=np.float64), hm, f, pq, mapping)
+                sj[S0 + off:S0 + off + Tn] = sjv
+                hm_a[S0 + off:S0 + off + Tn] = hv
+                hp_a[S0 + off:S0 + off + Tn] = hv   # same mortar seen from the other side (continuous map, orientation 0)
+                for j in range(3):
+                    nrm[3 * S0 + j * Ttot + off:3 * S0 + j * Ttot + off + Tn] = nv[:, j]
+                for i in range(3):
+                    for j in range(3):
+                        a0 = 9 * S0 + (i + 3 * j) * Ttot + off
+                        drst_m[a0:a0 + Tn] = inv[:, i, j]
+                        drst_p[a0:a0 + Tn] = inv[:, i, j]   # (+) side, (+) order == (-) order inside one tree
+                off += Tn
+        # boundary sides: Dirichlet values live on the Lobatto face nodes
+        bnd = side_nbr == -1
+        deg_m = np.repeat(self.deg, 6)
+        nb = np.where(bnd, (deg_m.astype(np.int64) + 1) ** 2, 0)
+        side_bndry_stride = np.concatenate([[0], np.cumsum(nb)[:-1]]).astype(np.int32)
+        total_bndry = int(nb.sum())
+        bndry_xyz = np.zeros((3, total_bndry))
+        for s_ in np.nonzero(bnd)[0]:
+            e, f = divmod(int(s_), 6)
+            d, sgn = f // 2, (1.0 if f % 2 else -1.0)
+            ax = [a for a in range(3) if a != d]
+            p = int(self.deg[e])
+            tl = table("lobatto_nodes", p)
+            nbn = (p + 1) ** 2
+            refl = np.zeros((nbn, 3))
+            refl[:, d] = sgn
+            refl[:, ax[0]] = np.tile(tl, p + 1)
+            refl[:, ax[1]] = np.repeat(tl, p + 1)
+            XL = (self.org[e] * self.hf)[None, :] + 0.5 * self.h_elem[e] * (refl + 1.0)
+            if mapping is not None:
+                XL = np.stack(mapping.x(XL[:, 0], XL[:, 1], XL[:, 2]), axis=1)
+            B0 = int(side_bndry_stride[s_])
+            bndry_xyz[:, B0:B0 + nbn] = XL.T
+        z = np.zeros(0, np.int32)
+        return dict(side_nbr=side_nbr, side_nbr_face=side_nbr_face, side_reorder=side_reorder,
+                    side_mortar_stride=side_mortar_stride, side_bndry_stride=side_bndry_stride,
+                    total_mortar_nodes=total, total_bndry_nodes=total_bndry, bndry_xyz=bndry_xyz,
+                    sj=sj, n=nrm, drst_m=drst_m, drst_p=drst_p, hm=hm_a, hp=hp_a,
+                    side_hang=side_hang, side_sub=side_sub, side_nbr4=side_nbr4,
+                    side_orientation=np.zeros(6 * ne, dtype=np.int32),
+                    ghost_global_ids=np.zeros(0, np.int64), ghost_deg=z, ghost_deg_quad=z, ghost_nodal_stride=z, ghost_nodes=0)
+
+
 class SineMap:
     """Smooth invertible map of the unit cube, x = X + a * sin(pi X) sin(pi Y) sin(pi Z) * c,
     giving every element a full, spatially varying 3x3 dr/dx (stand-in for curved geometries)."""

@@ -142,6 +142,21 @@ void d4est_hip_compute_dudr(d4est_hip_plan_t* plan, const double* u_dev, double*
 void d4est_hip_plan_set_faces(d4est_hip_plan_t* plan, const int* side_nbr, const int* side_nbr_face, const int* side_reorder,
                               const int* side_mortar_stride, const int* side_bndry_stride, int total_mortar_nodes,
                               int total_bndry_nodes, int n_ghost, const int* ghost_deg, const int* ghost_deg_quad);
+/* Non-conforming (hanging, 1 <-> 4) faces of a 2:1 balanced mesh; call BEFORE d4est_hip_plan_set_faces (conforming meshes skip it).
+ * HOST int arrays over the sides s = 6*e + f, mirroring the two calls the reference's face iteration makes per hanging face
+ * (src/Mesh/d4est_mortars.c:700-803: (e_m[4], faces_m = 4 | e_p[1]) and (e_m[1] | e_p[4], faces_p = 4)):
+ *   side_hang[s]        0 conforming or boundary; 1 "big" side: this face is split, (+) side = 4 small elements;
+ *                       2 "small" side: this element is one of the 4 hanging elements, (+) side = the big element (side_nbr[s])
+ *   side_sub[s]         small side: index of this element among the 4 (p4est order of the hanging quadrants = z-order on the face)
+ *   side_nbr4[4s..4s+3] big side: the four (+) elements in (-) order (e_p_oriented, src/Mesh/d4est_element_data.c:130-150);
+ *                       small side: the four members e_m[0..3] of its own group
+ *   side_orientation[s] p4est face orientation 0..3 (selects d4est_reference_reorient_face_order, dGMath/d4est_reference.c:84-110)
+ * Mortar data layout as the reference allocates it (src/Mesh/d4est_mesh.c:956-979): the block of a hanging face holds its 4
+ * sub-mortars one after another (scalars), vector / matrix components are strided by the block's TOTAL node count, the four small
+ * sides share ONE block (the same side_mortar_stride), and drst_dxyz_p_porder is stored in the (+) side's sub-face order.
+ * Local elements only (no ghost layer) in this version. */
+void d4est_hip_plan_set_hanging(d4est_hip_plan_t* plan, const int* side_hang, const int* side_sub, const int* side_nbr4,
+                                const int* side_orientation);
 /* SIPG parameters ([flux] sipg_penalty_prefactor, sipg_penalty_fcn; d4est_laplacian_flux_sipg.c:945-1005):
  * fcn 0 maxp_sqr_over_minh (default), 1 meanp_sqr_over_meanh, 2 maxpp1_sqr_over_minh, 3 mean_p_sqr_over_h.
  * Call BEFORE d4est_hip_plan_set_mortar_geometry (the penalty is folded into the face factors). */

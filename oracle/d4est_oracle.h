@@ -138,6 +138,14 @@ void oracle_laplacian_apply_aij(int quad_type, int n_elements, const int* deg, c
  * the boundary mortar quadrature nodes, indexed like sj; NULL, NULL = Dirichlet (default). */
 void oracle_flux_set_robin(const double* coeff_quad, const double* rhs_quad);
 
+/* Hanging (1 <-> 4) faces for the next oracle_laplacian_apply_aij calls (NULL = all conforming).  Arrays over sides s = 6e+f:
+ * side_hang 0 conforming / 1 big side (faces_m = 1, faces_p = 4) / 2 small side (faces_m = 4, faces_p = 1); side_sub: small side's index
+ * in its group; side_nbr4[4s..]: big side: e_p_oriented[0..3], small side: its group e_m[0..3]; side_orientation: p4est orientation.
+ * A hanging face's mortar block holds its 4 sub-mortars one after another (vector components strided by the block total), and the
+ * 4 small sides share one block, as in Mesh/d4est_mesh.c:956-962. */
+void oracle_flux_set_hanging(const int* side_hang, const int* side_sub, const int* side_nbr4, const int* side_orientation);
+int oracle_reorient_face_order(int f_m, int f_p, int o, int i);   /* dGMath/d4est_reference.c:84-110 */
+
 /* ---- smoother inner loops (oracle/d4est_oracle_solver.c) ---- */
 void oracle_set_aij_operator(int quad_type, int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
                              const int* quad_stride, int local_nodes, int local_nodes_quad, const double* J_quad,

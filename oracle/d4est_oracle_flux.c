@@ -11,8 +11,8 @@
  * sides, p4est face re-orientation given as a (flip0, flip1, transpose) code
  * (dGMath/d4est_operators.c:2031-2081), local or ghost (+) side, Dirichlet boundaries
  * with the boundary function evaluated on the Lobatto face nodes
- * (EVAL_BNDRY_FCN_ON_LOBATTO, d4est_laplacian_flux_sipg.c:108-112).  Hanging (1<->4)
- * mortars are the next tier.
+ * (EVAL_BNDRY_FCN_ON_LOBATTO, d4est_laplacian_flux_sipg.c:108-112), Robin boundaries, and hanging (1<->4)
+ * mortars between local elements (flux_interface_general).
  */
 #include "d4est_oracle.h"
 #include <math.h>
@@ -212,6 +212,244 @@ static void flux_interface_side(const flux_ctx_t* c, int e, int f_m, const doubl
   free(term1); free(term3); free(vt); free(proj); free(lifted); free(dt); free(acc1); free(acc2); free(acc3); free(t2sum);
 }
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Non-conforming (hanging, 1 <-> 4) interfaces: the general form of d4est_laplacian_flux_interface
+ * (dGMath/d4est_laplacian_flux.c:232-1014) + d4est_laplacian_flux_sipg_interface (d4est_laplacian_flux_sipg.c:494-942)
+ * for faces_m, faces_p in {1, 4}.  Local elements only.
+ * --------------------------------------------------------------------------------------------------------- */
+static const int* g_side_hang = NULL;        /* 0 conforming, 1 big side (faces_m = 1, faces_p = 4), 2 small side (faces_m = 4, faces_p = 1) */
+static const int* g_side_sub = NULL;         /* small side: index of the element in its group */
+static const int* g_side_nbr4 = NULL;        /* big side: e_p_oriented[0..3]; small side: the group e_m[0..3] */
+static const int* g_side_orientation = NULL; /* p4est orientation */
+void oracle_flux_set_hanging(const int* side_hang, const int* side_sub, const int* side_nbr4, const int* side_orientation) {
+  g_side_hang = side_hang; g_side_sub = side_sub; g_side_nbr4 = side_nbr4; g_side_orientation = side_orientation;
+}
+
+/* dGMath/d4est_reference.c:3-12 (tables), :84-110 (face_dim == 2 branch) */
+int oracle_reorient_face_order(int f_m, int f_p, int o, int i) {
+  static const int FToF_code[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
+                                      {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
+  static const int code_to_perm[3][4] = {{1, 2, 5, 6}, {0, 3, 4, 7}, {0, 4, 3, 7}};
+  static const int perm_to_order[8][4] = {{0, 1, 2, 3}, {0, 2, 1, 3}, {1, 0, 3, 2}, {1, 3, 0, 2},
+                                          {2, 0, 3, 1}, {2, 3, 0, 1}, {3, 1, 2, 0}, {3, 2, 1, 0}};
+  int perm = code_to_perm[FToF_code[f_m][f_p]][o];
+  return perm_to_order[perm][i];
+}
+
+/* Mesh/d4est_mortars.c:550-598 */
+static void project_side_onto_mortar_space(const double* in_side, int faces_side, const int* deg_side, double* out_mortar,
+                                           int faces_mortar, const int* deg_mortar) {
+  if (faces_side == 1 && faces_mortar == 1) oracle_apply_p_prolong(in_side, deg_side[0], 2, deg_mortar[0], out_mortar);
+  else if (faces_side == 1 && faces_mortar == 4) oracle_apply_hp_prolong(in_side, deg_side[0], 2, deg_mortar, out_mortar);
+  else if (faces_side == 4 && faces_mortar == 4) {
+    int ss = 0, sm = 0;
+    for (int i = 0; i < 4; i++) {
+      oracle_apply_p_prolong(&in_side[ss], deg_side[i], 2, deg_mortar[i], &out_mortar[sm]);
+      ss += (deg_side[i] + 1) * (deg_side[i] + 1);
+      sm += (deg_mortar[i] + 1) * (deg_mortar[i] + 1);
+    }
+  } else FLUX_ABORT("project_side_onto_mortar_space");
+}
+
+/* Mesh/d4est_mortars.c:510-547 */
+static void project_mass_mortar_onto_side(const double* in_mortar, int faces_mortar, const int* deg_mortar, double* out_side,
+                                          int faces_side, const int* deg_side) {
+  if (faces_side == 1 && faces_mortar == 1) oracle_apply_p_prolong_transpose(in_mortar, deg_mortar[0], 2, deg_side[0], out_side);
+  else if (faces_side == 1 && faces_mortar == 4) oracle_apply_hp_prolong_transpose(in_mortar, deg_mortar, 2, deg_side[0], out_side);
+  else if (faces_side == 4 && faces_mortar == 4) {
+    int ss = 0, sm = 0;
+    for (int i = 0; i < 4; i++) {
+      oracle_apply_p_prolong_transpose(&in_mortar[sm], deg_mortar[i], 2, deg_side[i], &out_side[ss]);
+      ss += (deg_side[i] + 1) * (deg_side[i] + 1);
+      sm += (deg_mortar[i] + 1) * (deg_mortar[i] + 1);
+    }
+  } else FLUX_ABORT("project_mass_mortar_onto_side");
+}
+
+static void flux_interface_general(const flux_ctx_t* c, const int* e_m, int faces_m, int f_m, const int* e_p_oriented, int faces_p,
+                                   int f_p, int orientation, int code, int S, const double* u, double* const dudr_local[3],
+                                   double* Au) {
+  const int faces_mortar = (faces_m > faces_p) ? faces_m : faces_p;
+  int e_p[4];
+  int deg_m_lobatto[4], deg_m_quad[4], deg_p_lobatto[4], deg_p_quad[4], deg_p_lobatto_porder[4];
+  int face_nodes_m_lobatto[4], face_nodes_p_lobatto[4];
+  int deg_mortar_quad[4], deg_mortar_lobatto[4], nodes_mortar_quad[4], nodes_mortar_lobatto[4];
+  int deg_mortar_quad_porder[4], nodes_mortar_quad_porder[4];
+  /* e_p_oriented[i] = e_p[reorient(i)]  (Mesh/d4est_element_data.c:130-150) */
+  if (faces_p == 1) e_p[0] = e_p_oriented[0];
+  else for (int i = 0; i < 4; i++) e_p[oracle_reorient_face_order(f_m, f_p, orientation, i)] = e_p_oriented[i];
+  int total_side_nodes_m_lobatto = 0, total_side_nodes_p_lobatto = 0;
+  for (int i = 0; i < faces_m; i++) {                                        /* :277-288 */
+    deg_m_lobatto[i] = c->deg[e_m[i]]; deg_m_quad[i] = c->deg_quad[e_m[i]];
+    face_nodes_m_lobatto[i] = (deg_m_lobatto[i] + 1) * (deg_m_lobatto[i] + 1);
+    total_side_nodes_m_lobatto += face_nodes_m_lobatto[i];
+  }
+  for (int i = 0; i < faces_p; i++) {                                        /* :293-305 */
+    deg_p_lobatto[i] = c->deg[e_p_oriented[i]]; deg_p_quad[i] = c->deg_quad[e_p_oriented[i]];
+    deg_p_lobatto_porder[i] = c->deg[e_p[i]];
+    face_nodes_p_lobatto[i] = (deg_p_lobatto[i] + 1) * (deg_p_lobatto[i] + 1);
+    total_side_nodes_p_lobatto += face_nodes_p_lobatto[i];
+  }
+  int total_nodes_mortar_quad = 0, total_nodes_mortar_lobatto = 0;
+  for (int i = 0; i < faces_m; i++)
+    for (int j = 0; j < faces_p; j++) {                                      /* :310-323 */
+      deg_mortar_quad[i + j] = (deg_m_quad[i] > deg_p_quad[j]) ? deg_m_quad[i] : deg_p_quad[j];
+      deg_mortar_lobatto[i + j] = (deg_m_lobatto[i] > deg_p_lobatto[j]) ? deg_m_lobatto[i] : deg_p_lobatto[j];
+      nodes_mortar_quad[i + j] = (deg_mortar_quad[i + j] + 1) * (deg_mortar_quad[i + j] + 1);
+      nodes_mortar_lobatto[i + j] = (deg_mortar_lobatto[i + j] + 1) * (deg_mortar_lobatto[i + j] + 1);
+      total_nodes_mortar_quad += nodes_mortar_quad[i + j];
+      total_nodes_mortar_lobatto += nodes_mortar_lobatto[i + j];
+    }
+  for (int i = 0; i < faces_mortar; i++) {                                   /* :329-337 */
+    int inew = (faces_mortar == 4) ? oracle_reorient_face_order(f_m, f_p, orientation, i) : i;
+    deg_mortar_quad_porder[inew] = deg_mortar_quad[i];
+    nodes_mortar_quad_porder[inew] = nodes_mortar_quad[i];
+  }
+  const int TT = total_nodes_mortar_quad;
+  const double* sj = &c->sj[S];
+  const double* hm = &c->hm[S];
+  const double* hp = &c->hp[S];
+  const double* nrm[3];
+  const double *rm[3][3], *rp[3][3];
+  for (int d = 0; d < 3; d++) nrm[d] = &c->n[(size_t)3 * S + (size_t)d * TT];  /* :417-449 */
+  for (int d1 = 0; d1 < 3; d1++)
+    for (int d2 = 0; d2 < 3; d2++) {
+      rm[d1][d2] = &c->drst_m[(size_t)9 * S + (size_t)(d1 + 3 * d2) * TT];
+      rp[d1][d2] = &c->drst_p[(size_t)9 * S + (size_t)(d1 + 3 * d2) * TT];
+    }
+  double* u_m_on_f_m = dalloc(total_side_nodes_m_lobatto);
+  double* u_p_on_f_p = dalloc(total_side_nodes_p_lobatto);
+  double* u_m_mortar = dalloc(TT); double* u_m_q = dalloc(TT); double* u_p_mortar = dalloc(TT); double* u_p_q = dalloc(TT);
+  double* tmp = dalloc(total_side_nodes_p_lobatto + 1);
+  int stride = 0;
+  for (int i = 0; i < faces_m; i++) {                                        /* :513-557 */
+    oracle_apply_slicer(&u[c->nodal_stride[e_m[i]]], f_m, deg_m_lobatto[i], &u_m_on_f_m[stride]);
+    stride += face_nodes_m_lobatto[i];
+  }
+  stride = 0;
+  for (int i = 0; i < faces_p; i++) {                                        /* :575-633 */
+    oracle_apply_slicer(&u[c->nodal_stride[e_p_oriented[i]]], f_p, deg_p_lobatto[i], tmp);
+    oracle_reorient_face_data(tmp, deg_p_lobatto[i], code, &u_p_on_f_p[stride]);
+    stride += face_nodes_p_lobatto[i];
+  }
+  project_side_onto_mortar_space(u_m_on_f_m, faces_m, deg_m_lobatto, u_m_mortar, faces_mortar, deg_mortar_quad);   /* :635-645 */
+  project_side_onto_mortar_space(u_p_on_f_p, faces_p, deg_p_lobatto, u_p_mortar, faces_mortar, deg_mortar_quad);   /* :647-657 */
+  stride = 0;
+  for (int f = 0; f < faces_mortar; f++) {                                   /* :659-694 */
+    interp2d(c->quad_type, &u_m_mortar[stride], deg_mortar_quad[f], &u_m_q[stride], deg_mortar_quad[f]);
+    interp2d(c->quad_type, &u_p_mortar[stride], deg_mortar_quad[f], &u_p_q[stride], deg_mortar_quad[f]);
+    stride += nodes_mortar_quad[f];
+  }
+  double *dudr_m_q[3], *dudr_p_q_porder[3], *dudx_m[3], *dudx_p_porder[3], *dudx_p[3];
+  for (int d = 0; d < 3; d++) {
+    dudr_m_q[d] = dalloc(TT); dudr_p_q_porder[d] = dalloc(TT); dudx_m[d] = dalloc(TT); dudx_p_porder[d] = dalloc(TT); dudx_p[d] = dalloc(TT);
+    double* a_m = dalloc(total_side_nodes_m_lobatto); double* a_p = dalloc(total_side_nodes_p_lobatto);
+    double* b = dalloc(TT);
+    stride = 0;
+    for (int f = 0; f < faces_m; f++) {                                      /* :700-731 */
+      oracle_apply_slicer(&dudr_local[d][c->nodal_stride[e_m[f]]], f_m, deg_m_lobatto[f], &a_m[stride]);
+      stride += face_nodes_m_lobatto[f];
+    }
+    stride = 0;
+    for (int f = 0; f < faces_p; f++) {                                      /* :733-768: (+) side in ITS order */
+      oracle_apply_slicer(&dudr_local[d][c->nodal_stride[e_p[f]]], f_p, deg_p_lobatto_porder[f], &a_p[stride]);
+      stride += (deg_p_lobatto_porder[f] + 1) * (deg_p_lobatto_porder[f] + 1);
+    }
+    project_side_onto_mortar_space(a_p, faces_p, deg_p_lobatto_porder, b, faces_mortar, deg_mortar_quad_porder);   /* :770-780 */
+    stride = 0;
+    for (int f = 0; f < faces_mortar; f++) {                                 /* :812-830 */
+      interp2d(c->quad_type, &b[stride], deg_mortar_quad_porder[f], &dudr_p_q_porder[d][stride], deg_mortar_quad_porder[f]);
+      stride += nodes_mortar_quad_porder[f];
+    }
+    project_side_onto_mortar_space(a_m, faces_m, deg_m_lobatto, b, faces_mortar, deg_mortar_quad);                 /* :782-792 */
+    stride = 0;
+    for (int f = 0; f < faces_mortar; f++) {                                 /* :794-810 */
+      interp2d(c->quad_type, &b[stride], deg_mortar_quad[f], &dudr_m_q[d][stride], deg_mortar_quad[f]);
+      stride += nodes_mortar_quad[f];
+    }
+    free(a_m); free(a_p); free(b);
+  }
+  for (int j = 0; j < 3; j++) {                                              /* :833-856 */
+    for (int k = 0; k < TT; k++) { dudx_m[j][k] = 0.; dudx_p_porder[j][k] = 0.; }
+    for (int i = 0; i < 3; i++)
+      for (int k = 0; k < TT; k++) {
+        dudx_m[j][k] += rm[i][j][k] * dudr_m_q[i][k];
+        dudx_p_porder[j][k] += rp[i][j][k] * dudr_p_q_porder[i][k];
+      }
+  }
+  int face_mortar_stride = 0;
+  for (int face = 0; face < faces_mortar; face++) {                          /* :858-900 */
+    int face_p = (faces_mortar == 4) ? oracle_reorient_face_order(f_m, f_p, orientation, face) : face;
+    int oriented_face_mortar_stride = 0;
+    for (int b = 0; b < face_p; b++) oriented_face_mortar_stride += nodes_mortar_quad_porder[b];
+    for (int d = 0; d < 3; d++)
+      oracle_reorient_face_data(&dudx_p_porder[d][oriented_face_mortar_stride], deg_mortar_quad[face], code, &dudx_p[d][face_mortar_stride]);
+    face_mortar_stride += nodes_mortar_quad[face];
+  }
+  if (faces_m != faces_mortar)                                               /* :905-915 "another dr/dx factor" */
+    for (int d = 0; d < 3; d++) for (int k = 0; k < TT; k++) dudx_m[d][k] *= .5;
+  if (faces_p != faces_mortar)
+    for (int d = 0; d < 3; d++) for (int k = 0; k < TT; k++) dudx_p[d][k] *= .5;
+
+  /* ---- d4est_laplacian_flux_sipg_interface_aux (d4est_laplacian_flux_sipg.c:494-833) */
+  double* term1 = dalloc(TT); double* term3 = dalloc(TT); double* term2[3];
+  double* vt1 = dalloc(total_nodes_mortar_lobatto); double* vt3 = dalloc(total_nodes_mortar_lobatto); double* vt2[3];
+  for (int l = 0; l < 3; l++) { term2[l] = dalloc(TT); vt2[l] = dalloc(total_nodes_mortar_lobatto); }
+  stride = 0;
+  int stride_lobatto = 0;
+  for (int f = 0; f < faces_mortar; f++) {
+    for (int k = 0; k < nodes_mortar_quad[f]; k++) {
+      int ks = k + stride;
+      double sigma = 1.0 * oracle_sipg_penalty(c->penalty_fcn, (faces_m == faces_mortar) ? deg_m_lobatto[f] : deg_m_lobatto[0], hm[ks],
+                                               (faces_p == faces_mortar) ? deg_p_lobatto[f] : deg_p_lobatto[0], hp[ks],
+                                               c->penalty_prefactor);                                        /* :577-592 */
+      term1[ks] = 0.;
+      for (int d = 0; d < 3; d++) term1[ks] += -1. * nrm[d][ks] * sj[ks] * .5 * (dudx_p[d][ks] + dudx_m[d][ks]);
+      for (int l = 0; l < 3; l++) {
+        term2[l][ks] = 0.;
+        for (int d = 0; d < 3; d++) term2[l][ks] += -.5 * rm[l][d][ks] * sj[ks] * nrm[d][ks] * (u_m_q[ks] - u_p_q[ks]);
+      }
+      term3[ks] = sj[ks] * sigma * (u_m_q[ks] - u_p_q[ks]);
+    }
+    galerkin2d(c->quad_type, &term1[stride], deg_mortar_lobatto[f], deg_mortar_quad[f], &vt1[stride_lobatto]);  /* :641-690 */
+    for (int d = 0; d < 3; d++) galerkin2d(c->quad_type, &term2[d][stride], deg_mortar_lobatto[f], deg_mortar_quad[f], &vt2[d][stride_lobatto]);
+    galerkin2d(c->quad_type, &term3[stride], deg_mortar_lobatto[f], deg_mortar_quad[f], &vt3[stride_lobatto]);
+    stride += nodes_mortar_quad[f];
+    stride_lobatto += nodes_mortar_lobatto[f];
+  }
+  double* proj1 = dalloc(total_side_nodes_m_lobatto); double* proj3 = dalloc(total_side_nodes_m_lobatto); double* proj2[3];
+  for (int d = 0; d < 3; d++) {                                              /* :732-768 */
+    proj2[d] = dalloc(total_side_nodes_m_lobatto);
+    project_mass_mortar_onto_side(vt2[d], faces_mortar, deg_mortar_lobatto, proj2[d], faces_m, deg_m_lobatto);
+  }
+  project_mass_mortar_onto_side(vt1, faces_mortar, deg_mortar_lobatto, proj1, faces_m, deg_m_lobatto);
+  project_mass_mortar_onto_side(vt3, faces_mortar, deg_mortar_lobatto, proj3, faces_m, deg_m_lobatto);
+  stride = 0;
+  for (int f = 0; f < faces_m; f++) {                                        /* :770-826, :896-927 */
+    const int deg = deg_m_lobatto[f], vn = (deg + 1) * (deg + 1) * (deg + 1);
+    double* lifted = dalloc(vn); double* dt = dalloc(vn); double* l1 = dalloc(vn); double* l3 = dalloc(vn);
+    double* t2sum = dalloc((size_t)3 * vn);
+    oracle_apply_lift(&proj1[stride], deg, f_m, l1);
+    for (int d = 0; d < 3; d++) {
+      oracle_apply_lift(&proj2[d][stride], deg, f_m, lifted);
+      oracle_apply_dij_transpose(lifted, deg, d, &t2sum[(size_t)d * vn]);
+      if (faces_m != faces_mortar) for (int i = 0; i < vn; i++) t2sum[(size_t)d * vn + i] *= .5;
+    }
+    oracle_apply_lift(&proj3[stride], deg, f_m, l3);
+    double* Au_m = &Au[c->nodal_stride[e_m[f]]];
+    for (int i = 0; i < vn; i++) {
+      for (int d = 0; d < 3; d++) Au_m[i] += t2sum[(size_t)d * vn + i];
+      Au_m[i] += l3[i];
+      Au_m[i] += l1[i];
+    }
+    free(lifted); free(dt); free(l1); free(l3); free(t2sum);
+    stride += face_nodes_m_lobatto[f];
+  }
+  free(u_m_on_f_m); free(u_p_on_f_p); free(u_m_mortar); free(u_m_q); free(u_p_mortar); free(u_p_q); free(tmp);
+  for (int d = 0; d < 3; d++) { free(dudr_m_q[d]); free(dudr_p_q_porder[d]); free(dudx_m[d]); free(dudx_p_porder[d]); free(dudx_p[d]); free(term2[d]); free(vt2[d]); free(proj2[d]); }
+  free(term1); free(term3); free(vt1); free(vt3); free(proj1); free(proj3);
+}
+
 /* Robin boundary data (BC_ROBIN): the callbacks robin_coeff / robin_rhs of d4est_laplacian_robin_bc_t evaluated at the
  * boundary mortar quadrature nodes (d4est_laplacian_flux_sipg.c:388-412), indexed like sj.  NULL = Dirichlet. */
 static const double* g_robin_coeff = NULL;
@@ -330,6 +568,18 @@ void oracle_laplacian_apply_aij(int quad_type, int n_elements, const int* deg, c
       if (side_nbr[6 * e + f] == -1) {
         if (g_robin_coeff) flux_robin_side(&c, e, f, u, Au);
         else flux_boundary_side(&c, e, f, u, dl, bndry_lobatto, Au);
+      }
+      else if (g_side_hang && g_side_hang[6 * e + f] == 1) {
+        int em[1] = {e};
+        flux_interface_general(&c, em, 1, f, &g_side_nbr4[4 * (6 * e + f)], 4, side_nbr_face[6 * e + f], g_side_orientation[6 * e + f],
+                               side_reorder[6 * e + f], side_mortar_stride[6 * e + f], u, dl, Au);
+      } else if (g_side_hang && g_side_hang[6 * e + f] == 2) {
+        /* the reference's callback handles the 4 hanging elements of the face together: once, at the group's first member */
+        if (g_side_sub[6 * e + f] == 0) {
+          int ep[1] = {side_nbr[6 * e + f]};
+          flux_interface_general(&c, &g_side_nbr4[4 * (6 * e + f)], 4, f, ep, 1, side_nbr_face[6 * e + f], g_side_orientation[6 * e + f],
+                                 side_reorder[6 * e + f], side_mortar_stride[6 * e + f], u, dl, Au);
+        }
       }
       else flux_interface_side(&c, e, f, u, u_ghost, dl, dg, Au);
     }

@@ -201,10 +201,15 @@ class Oracle:
         if robin is not None:
             rc, rr = (np.ascontiguousarray(a, dtype=np.float64) for a in robin)
             self.lib.oracle_flux_set_robin(P(rc), P(rr))
+        self.lib.oracle_flux_set_hanging.argtypes = [ip, ip, ip, ip]
+        if "side_hang" in sides:
+            self._hang_keep = [np.ascontiguousarray(sides[k], dtype=np.int32) for k in ("side_hang", "side_sub", "side_nbr4", "side_orientation")]
+            self.lib.oracle_flux_set_hanging(*[I(a) for a in self._hang_keep])
         try:
             return self._apply_aij(mesh, J, rst, sides, u, u_ghost, bndry_lobatto, penalty_prefactor, penalty_fcn, nthreads)
         finally:
             self.lib.oracle_flux_set_robin(None, None)
+            self.lib.oracle_flux_set_hanging(None, None, None, None)
 
     def _apply_aij(self, mesh, J, rst, sides, u, u_ghost, bndry_lobatto, penalty_prefactor, penalty_fcn, nthreads):
         Au = np.zeros(mesh.local_nodes)

@@ -85,6 +85,56 @@ def test_apply_aij_robin_parity(gpu, hiplib, oracle, level, deg, inc):
     plan.destroy()
 
 
+def _hanging_mesh(level, pattern, deg, inc, mixed):
+    from disco4est_amd import mesh as M
+    nb = 8 ** level
+    refine = np.zeros(nb, dtype=bool)
+    refine[np.asarray(pattern) % nb] = True
+    m0 = M.HangingBrickMesh(level, refine, deg, deg_quad_inc=inc)
+    if mixed:
+        d = deg + (np.arange(m0.n_elements) * 7 % 3)  # degrees deg..deg+2 scattered over big and small elements
+        return M.HangingBrickMesh(level, refine, d, deg_quad_inc=inc)
+    return m0
+
+
+@pytest.mark.parametrize("level,pattern,deg,inc,mixed,curved", [
+    (1, [0], 2, 0, False, False), (1, [0, 5, 6], 2, 0, False, True), (1, [3], 3, 1, False, True), (1, [1, 2, 4, 7], 2, 0, True, True),
+    (1, [0, 7], 4, 0, True, True), (2, [0, 9, 21, 42, 63], 2, 1, True, True), (1, [6], 7, 0, False, True), (1, [2, 5], 8, 0, False, True),
+])
+def test_apply_aij_hanging_parity(gpu, hiplib, oracle, level, pattern, deg, inc, mixed, curved):
+    """Non-conforming (1 <-> 4) mortars, uniform and mixed p: full apply_aij against the oracle's restatement of the general
+    d4est_laplacian_flux_interface (faces_m, faces_p in {1, 4}), Dirichlet data on, then off."""
+    import torch
+    from disco4est_amd import mesh as M
+    m = _hanging_mesh(level, pattern, deg, inc, mixed)
+    mp = M.SineMap(0.04) if curved else None
+    J, rst = m.geometry(mp)
+    sides = m.build_sides(mp)
+    assert (sides["side_hang"] == 1).sum() > 0 and (sides["side_hang"] == 2).sum() == 4 * (sides["side_hang"] == 1).sum()
+    u = m.field(mp)
+    bx = sides["bndry_xyz"]
+    g = np.sin(bx[0]) + bx[1] * bx[2]
+    ref = oracle.apply_aij(m, J, rst, sides, u, bndry_lobatto=g, penalty_prefactor=7.5, nthreads=8)
+    plan = _plan(m, J, rst, sides, 7.5, 0)
+    plan.set_dirichlet_values(g)
+    du = _t(u, gpu)
+    dAu = torch.full_like(du, float("nan"))
+    plan.apply_aij(du, dAu)
+    got = dAu.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert _rel(got, ref) <= RTOL
+    plan.set_dirichlet_values(None)
+    plan.apply_aij(du, dAu)
+    ref0 = oracle.apply_aij(m, J, rst, sides, u, penalty_prefactor=7.5, nthreads=8)
+    assert _rel(dAu.cpu().numpy(), ref0) <= RTOL
+    # symmetry of the device operator on the hanging mesh (the reference's d4est_test_laplacian_symmetry idea)
+    v = _t(M.splitmix64_uniform(9, m.local_nodes), gpu)
+    Av = torch.empty_like(v); plan.apply_aij(v, Av)
+    s1, s2 = torch.dot(v, dAu).item(), torch.dot(du, Av).item()
+    assert abs(s1 - s2) <= 1e-11 * max(abs(s1), abs(s2))
+    plan.destroy()
+
+
 def test_apply_aij_mixed_p(gpu, hiplib, oracle):
     """p-nonconforming mortars (different degree on the two sides of a face), config-4 style."""
     import torch

@@ -103,3 +103,35 @@ def test_robin_boundary(oracle):
     Au = oracle.apply_aij(m, J, rst, sides, u, robin=(c, z))
     Av = oracle.apply_aij(m, J, rst, sides, v, robin=(c, z))
     assert abs(v @ Au - u @ Av) <= 1e-11 * abs(v @ Au)
+
+
+@pytest.mark.parametrize("deg,inc,mixed", [(2, 0, False), (3, 1, False), (2, 0, True)])
+def test_hanging_faces_consistency_and_symmetry(oracle, deg, inc, mixed):
+    """Hanging (1 <-> 4) mortars: the reference's own identities on an adapted mesh -- A(x^2+y^2+z^2) with exact Dirichlet
+    data equals M(-6) on the affine brick (d4est_test_laplacian_consistency.c:418-426 runs exactly this on a randomly
+    hp-refined mesh) and A = A^T (d4est_test_laplacian_symmetry.c:299-312), also on a curved map."""
+    from disco4est_amd import mesh as M
+    refine = np.zeros(8, dtype=bool)
+    refine[[0, 5, 6]] = True
+    m = M.HangingBrickMesh(1, refine, deg, deg_quad_inc=inc)
+    if mixed:
+        m = M.HangingBrickMesh(1, refine, deg + (np.arange(m.n_elements) * 5 % 3), deg_quad_inc=inc)
+    sides = m.build_sides(None)
+    assert (sides["side_hang"] == 1).sum() > 0
+    J, rst = m.geometry(None)
+    x, y, z = m.nodal_coords(None)
+    u = x * x + y * y + z * z
+    bx = sides["bndry_xyz"]
+    g = bx[0] ** 2 + bx[1] ** 2 + bx[2] ** 2
+    Au = oracle.apply_aij(m, J, rst, sides, u, bndry_lobatto=g)
+    Mf = oracle.apply_mass(m, J, np.full(m.local_nodes, -6.0))
+    assert np.abs(Au - Mf).max() <= 1e-12 * max(1.0, np.abs(Mf).max())
+    mp = M.SineMap(0.04)
+    sides = m.build_sides(mp)
+    J, rst = m.geometry(mp)
+    v = M.splitmix64_uniform(1, m.local_nodes)
+    w = M.splitmix64_uniform(2, m.local_nodes)
+    Av = oracle.apply_aij(m, J, rst, sides, v)
+    Aw = oracle.apply_aij(m, J, rst, sides, w)
+    assert abs(w @ Av - v @ Aw) <= 1e-12 * abs(w @ Av)
+    assert v @ Av > 0
