@@ -7,7 +7,7 @@ torch CUDA tensors (torch is used for device memory and streams only) and the
 synthetic-mesh helpers.  There is NO CPU fallback: if the library is missing or
 fails to load, importing :mod:`disco4est_amd.capi` raises.
 """
-from .capi import Plan, load_library, table, TABLE  # noqa: F401
+from .capi import Plan, Transfer, load_library, table, TABLE  # noqa: F401
 from . import mesh  # noqa: F401
 
-__all__ = ["Plan", "load_library", "table", "TABLE", "mesh"]
+__all__ = ["Plan", "Transfer", "load_library", "table", "TABLE", "mesh"]

@@ -47,6 +47,13 @@ SIGNATURES = {
     "d4est_hip_plan_set_faces": (None, [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _c_int_p, _c_int_p]),
     "d4est_hip_plan_set_hanging": (None, [_vp, _vp, _vp, _vp, _vp]),
+    "d4est_hip_transfer_create": (_vp, [ctypes.c_int, _vp, _vp, _vp]),
+    "d4est_hip_transfer_destroy": (None, [_vp]),
+    "d4est_hip_transfer_set_stream": (None, [_vp, _vp]),
+    "d4est_hip_transfer_coarse_nodes": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_transfer_fine_nodes": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_transfer_prolong": (None, [_vp, _vp, _vp]),
+    "d4est_hip_transfer_restrict": (None, [_vp, _vp, _vp]),
     "d4est_hip_plan_set_sipg": (None, [_vp, ctypes.c_double, ctypes.c_int]),
     "d4est_hip_plan_set_mortar_geometry": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "d4est_hip_plan_set_dirichlet_values": (None, [_vp, _vp, ctypes.c_int]),
@@ -300,3 +307,31 @@ class Plan:
             self.destroy()
         except Exception:
             pass
+
+
+class Transfer:
+    """hp-multigrid inter-grid transfer (d4est_hip_transfer_*): items = coarse elements in traversal order,
+    hrefine[k] 0 (1 <-> 1, p only) or 1 (8 children <-> parent), degH[k], degh[8k..8k+7]."""
+
+    def __init__(self, hrefine, degH, degh, stream=None):
+        self.lib = load_library()
+        h, dH, dh = _iarr(hrefine), _iarr(degH), _iarr(degh)
+        assert len(dh[0]) == 8 * len(h[0]) and len(dH[0]) == len(h[0])
+        self.handle = self.lib.d4est_hip_transfer_create(len(h[0]), h[1], dH[1], dh[1])
+        if stream is not None:
+            self.lib.d4est_hip_transfer_set_stream(self.handle, ctypes.c_void_p(stream.cuda_stream))
+        self.coarse_nodes = self.lib.d4est_hip_transfer_coarse_nodes(self.handle)
+        self.fine_nodes = self.lib.d4est_hip_transfer_fine_nodes(self.handle)
+
+    def prolong(self, x_coarse, x_fine):
+        assert x_coarse.numel() == self.coarse_nodes and x_fine.numel() == self.fine_nodes
+        self.lib.d4est_hip_transfer_prolong(self.handle, _ptr(x_coarse), _ptr(x_fine))
+
+    def restrict(self, x_fine, x_coarse):
+        assert x_coarse.numel() == self.coarse_nodes and x_fine.numel() == self.fine_nodes
+        self.lib.d4est_hip_transfer_restrict(self.handle, _ptr(x_fine), _ptr(x_coarse))
+
+    def destroy(self):
+        if self.handle:
+            self.lib.d4est_hip_transfer_destroy(self.handle)
+            self.handle = None

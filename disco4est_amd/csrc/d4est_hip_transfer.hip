@@ -1,0 +1,224 @@
+// hp-multigrid inter-grid transfer on the device.
+//
+// Replaces the per-element walk of the reference's V-cycle transfer callbacks
+//   d4est_solver_multigrid_refine_and_apply_prolongation        (src/Solver/d4est_solver_multigrid_callbacks.h:245-330)
+//   d4est_solver_multigrid_apply_restriction (coarsen callback)  (same file :100-200)
+// which call, per coarse element,
+//   d4est_operators_apply_p_prolong / _hp_prolong                     (src/dGMath/d4est_operators.c:1107-1132, :1091-1105)
+//   d4est_operators_apply_p_prolong_transpose / _hp_prolong_transpose (:1719-1749, :1689-1717)
+// A transfer object is the flat list of coarse elements ("items") in the traversal order of both grids:
+//   hrefine == 0: one fine element of degree degh[0] <-> the coarse element of degree degH (p-coarsening; a copy if equal)
+//   hrefine == 1: eight children (z-order, degrees degh[0..7]) <-> their parent (h- and p-coarsening at once)
+// Vectors are element-ordered and contiguous on both grids, as in the reference (fine_stride / coarse_stride advance).
+#include <map>
+#include <vector>
+
+#include "d4est_hip_internal.h"
+#include "d4est_hip_tables.h"
+
+struct d4est_hip_transfer {
+  int n_items = 0, n_children = 0;
+  long long coarse_nodes = 0, fine_nodes = 0;
+  int max_n = 1;
+  int* d_child = nullptr;      // per (item, child): 8 ints {item, NH, Nh, off_x, off_y, off_z, first child of item?, n children of item}
+  long long* d_off = nullptr;  // per (item, child): {coarse offset, fine offset}
+  int* d_item_first = nullptr; // per item: index of its first child record (n_items + 1)
+  double* d_ops = nullptr;
+  hipStream_t stream = nullptr;
+};
+
+namespace d4est_hip {
+
+// out (n_out^3) = (Az (x) Ay (x) Ax) in (n_in^3), A* given as n_out x n_in (TRANS = false) or applied transposed
+// (A* is n_in x n_out, TRANS = true).  in/out/tmp are LDS arrays of >= max(n_in, n_out)^3 doubles.
+template <bool TRANS>
+__device__ inline void tensor3(const double* __restrict__ Ax, const double* __restrict__ Ay, const double* __restrict__ Az, int n_in,
+                               int n_out, double* a, double* b) {
+  // x: a [n_in z][n_in y][n_in x] -> b [z][y][n_out]
+  for (int idx = threadIdx.x; idx < n_in * n_in * n_out; idx += blockDim.x) {
+    const int o = idx % n_out, r = idx / n_out;
+    double s = 0.0;
+    for (int i = 0; i < n_in; ++i) s = fma(TRANS ? Ax[i * n_out + o] : Ax[o * n_in + i], a[r * n_in + i], s);
+    b[r * n_out + o] = s;
+  }
+  __syncthreads();
+  // y: b [z][n_in y][n_out x] -> a [z][n_out][n_out]
+  for (int idx = threadIdx.x; idx < n_in * n_out * n_out; idx += blockDim.x) {
+    const int x = idx % n_out, o = (idx / n_out) % n_out, z = idx / (n_out * n_out);
+    double s = 0.0;
+    for (int i = 0; i < n_in; ++i) s = fma(TRANS ? Ay[i * n_out + o] : Ay[o * n_in + i], b[(z * n_in + i) * n_out + x], s);
+    a[(z * n_out + o) * n_out + x] = s;
+  }
+  __syncthreads();
+  // z: a [n_in z][n_out][n_out] -> b [n_out][n_out][n_out]
+  for (int idx = threadIdx.x; idx < n_out * n_out * n_out; idx += blockDim.x) {
+    const int xy = idx % (n_out * n_out), o = idx / (n_out * n_out);
+    double s = 0.0;
+    for (int i = 0; i < n_in; ++i) s = fma(TRANS ? Az[i * n_out + o] : Az[o * n_in + i], a[i * n_out * n_out + xy], s);
+    b[idx] = s;
+  }
+  __syncthreads();
+}
+
+// one workgroup per fine element
+__global__ __launch_bounds__(256) void prolong_kernel(const double* __restrict__ xc, double* __restrict__ xf,
+                                                      const int* __restrict__ child, const long long* __restrict__ off,
+                                                      const double* __restrict__ ops, int n_children, int max_n3) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* a = smem;
+  double* b = smem + max_n3;
+  for (int c = blockIdx.x; c < n_children; c += gridDim.x) {
+    const int* d = child + 8 * c;
+    const int NH = d[1], Nh = d[2];
+    const long long co = off[2 * c], fo = off[2 * c + 1];
+    for (int i = threadIdx.x; i < NH * NH * NH; i += blockDim.x) a[i] = xc[co + i];
+    __syncthreads();
+    tensor3<false>(ops + d[3], ops + d[4], ops + d[5], NH, Nh, a, b);
+    for (int i = threadIdx.x; i < Nh * Nh * Nh; i += blockDim.x) xf[fo + i] = b[i];
+    __syncthreads();
+  }
+}
+
+// one workgroup per coarse element: sum over its children of P_c^T x_c
+__global__ __launch_bounds__(256) void restrict_kernel(const double* __restrict__ xf, double* __restrict__ xc,
+                                                       const int* __restrict__ child, const long long* __restrict__ off,
+                                                       const int* __restrict__ item_first, const double* __restrict__ ops,
+                                                       int n_items, int max_n3) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* a = smem;
+  double* b = smem + max_n3;
+  double* acc = smem + 2 * max_n3;
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int c0 = item_first[it], c1 = item_first[it + 1];
+    const int NH = child[8 * c0 + 1];
+    for (int i = threadIdx.x; i < NH * NH * NH; i += blockDim.x) acc[i] = 0.0;
+    for (int c = c0; c < c1; ++c) {
+      const int* d = child + 8 * c;
+      const int Nh = d[2];
+      const long long fo = off[2 * c + 1];
+      for (int i = threadIdx.x; i < Nh * Nh * Nh; i += blockDim.x) a[i] = xf[fo + i];
+      __syncthreads();
+      tensor3<true>(ops + d[3], ops + d[4], ops + d[5], Nh, NH, a, b);
+      for (int i = threadIdx.x; i < NH * NH * NH; i += blockDim.x) acc[i] += b[i];   // same thread <-> same entries: no race
+      __syncthreads();
+    }
+    const long long co = off[2 * c0];
+    for (int i = threadIdx.x; i < NH * NH * NH; i += blockDim.x) xc[co + i] = acc[i];
+    __syncthreads();
+  }
+}
+
+}  // namespace d4est_hip
+
+using d4est_hip::Tables1D;
+
+extern "C" {
+
+d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine, const int* degH, const int* degh) {
+  if (n_items < 0 || (n_items > 0 && (!hrefine || !degH || !degh))) D4EST_HIP_ABORT("transfer_create: bad arguments");
+  d4est_hip_transfer* t = new d4est_hip_transfer();
+  t->n_items = n_items;
+  std::vector<double> ops;
+  std::map<std::pair<int, int>, int> p_index, hp_index;
+  auto get_p = [&](int dH, int dh) {
+    auto key = std::make_pair(dH, dh);
+    auto it = p_index.find(key);
+    if (it != p_index.end()) return it->second;
+    std::vector<double> P = Tables1D::p_prolong(dH, dh);   // identity when dH == dh (d4est_operators.c:1114-1118 copies)
+    const int o = (int)ops.size();
+    ops.insert(ops.end(), P.begin(), P.end());
+    p_index[key] = o;
+    return o;
+  };
+  auto get_hp = [&](int dH, int dh) {
+    auto key = std::make_pair(dH, dh);
+    auto it = hp_index.find(key);
+    if (it != hp_index.end()) return it->second;
+    std::vector<double> P = Tables1D::hp_prolong(dH, dh);  // 2 x (dh+1) x (dH+1)
+    const int o = (int)ops.size();
+    ops.insert(ops.end(), P.begin(), P.end());
+    hp_index[key] = o;
+    return o;
+  };
+  std::vector<int> child, item_first(n_items + 1, 0);
+  std::vector<long long> off;
+  long long co = 0, fo = 0;
+  for (int it = 0; it < n_items; ++it) {
+    item_first[it] = (int)(child.size() / 8);
+    const int dH = degH[it];
+    const int nc = hrefine[it] == 1 ? 8 : 1;
+    if (hrefine[it] != 0 && hrefine[it] != 1) D4EST_HIP_ABORT("transfer_create: item %d has hrefine %d (0: p only, 1: eight children)", it, hrefine[it]);
+    if (dH < 1 || dH > Tables1D::kMaxDeg) D4EST_HIP_ABORT("transfer_create: item %d has degH %d", it, dH);
+    for (int c = 0; c < nc; ++c) {
+      const int dh = degh[8 * it + c];
+      if (dh < dH || dh > Tables1D::kMaxDeg) D4EST_HIP_ABORT("transfer_create: item %d child %d has degh %d < degH %d (the reference asserts degH <= degh, d4est_operators.c:379)", it, c, dh, dH);
+      const int nH = dH + 1, nh = dh + 1;
+      int ox, oy, oz;
+      if (nc == 1) ox = oy = oz = get_p(dH, dh);
+      else {
+        const int base = get_hp(dH, dh);
+        ox = base + (c & 1) * nh * nH;          // d4est_operators.c:394-404: child c = (cx, cy, cz) bits
+        oy = base + ((c >> 1) & 1) * nh * nH;
+        oz = base + ((c >> 2) & 1) * nh * nH;
+      }
+      const int rec[8] = {it, nH, nh, ox, oy, oz, c == 0, nc};
+      child.insert(child.end(), rec, rec + 8);
+      off.push_back(co);
+      off.push_back(fo);
+      fo += (long long)nh * nh * nh;
+      t->max_n = std::max(t->max_n, std::max(nH, nh));
+    }
+    co += (long long)(dH + 1) * (dH + 1) * (dH + 1);
+  }
+  item_first[n_items] = (int)(child.size() / 8);
+  t->n_children = item_first[n_items];
+  t->coarse_nodes = co;
+  t->fine_nodes = fo;
+  auto up_i = [](const std::vector<int>& v) { int* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(int))); if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice)); return d; };
+  t->d_child = up_i(child);
+  t->d_item_first = up_i(item_first);
+  HIP_CHECK(hipMalloc(&t->d_off, std::max<size_t>(off.size(), 1) * sizeof(long long)));
+  if (!off.empty()) HIP_CHECK(hipMemcpy(t->d_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMalloc(&t->d_ops, std::max<size_t>(ops.size(), 1) * sizeof(double)));
+  if (!ops.empty()) HIP_CHECK(hipMemcpy(t->d_ops, ops.data(), ops.size() * sizeof(double), hipMemcpyHostToDevice));
+  return t;
+}
+
+void d4est_hip_transfer_destroy(d4est_hip_transfer_t* t) {
+  if (!t) return;
+  (void)hipFree(t->d_child); (void)hipFree(t->d_off); (void)hipFree(t->d_item_first); (void)hipFree(t->d_ops);
+  delete t;
+}
+
+void d4est_hip_transfer_set_stream(d4est_hip_transfer_t* t, void* hip_stream) {
+  if (!t) D4EST_HIP_ABORT("transfer_set_stream: NULL transfer");
+  t->stream = (hipStream_t)hip_stream;
+}
+
+long long d4est_hip_transfer_coarse_nodes(const d4est_hip_transfer_t* t) { return t ? t->coarse_nodes : -1; }
+long long d4est_hip_transfer_fine_nodes(const d4est_hip_transfer_t* t) { return t ? t->fine_nodes : -1; }
+
+void d4est_hip_transfer_prolong(d4est_hip_transfer_t* t, const double* x_coarse_dev, double* x_fine_dev) {
+  if (!t) D4EST_HIP_ABORT("transfer_prolong: NULL transfer");
+  if (t->n_children == 0) return;
+  const int n3 = t->max_n * t->max_n * t->max_n;
+  const size_t lds = (size_t)2 * n3 * sizeof(double);
+  if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(d4est_hip::prolong_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(d4est_hip::prolong_kernel, dim3(std::min(t->n_children, 65536)), dim3(256), lds, t->stream, x_coarse_dev, x_fine_dev,
+                     t->d_child, t->d_off, t->d_ops, t->n_children, n3);
+  HIP_CHECK(hipGetLastError());
+}
+
+void d4est_hip_transfer_restrict(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev) {
+  if (!t) D4EST_HIP_ABORT("transfer_restrict: NULL transfer");
+  if (t->n_items == 0) return;
+  const int n3 = t->max_n * t->max_n * t->max_n;
+  const size_t lds = (size_t)3 * n3 * sizeof(double);
+  if (lds > 160 * 1024) D4EST_HIP_ABORT("transfer_restrict: degree too high for the LDS-resident kernel");
+  if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(d4est_hip::restrict_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(d4est_hip::restrict_kernel, dim3(std::min(t->n_items, 65536)), dim3(256), lds, t->stream, x_fine_dev, x_coarse_dev,
+                     t->d_child, t->d_off, t->d_item_first, t->d_ops, t->n_items, n3);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // extern "C"

@@ -235,6 +235,25 @@ void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const
  * device, applies, copies Au back (PCIe-inclusive; not the measured path). */
 void d4est_hip_apply_stiffness_matrix_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host);
 
+/* ---- hp-multigrid inter-grid transfer ---------------------------------------------------
+ * The V-cycle's restriction / prolongation callbacks (src/Solver/d4est_solver_multigrid_callbacks.h:100-200, :245-330) walk the
+ * coarse grid and call, per coarse element, d4est_operators_apply_p_prolong / _hp_prolong (prolongation) or their transposes
+ * (restriction of residuals; src/dGMath/d4est_operators.c:1091-1132, :1689-1749).  A transfer object is that walk as a flat list:
+ * item k has hrefine[k] = 0 (one fine element of degree degh[8k] <-> coarse element of degree degH[k]; equal degrees copy) or 1
+ * (eight children in z-order with degrees degh[8k..8k+7] <-> their parent); d4est's third case (an element that is not coarsened,
+ * copied child by child) is hrefine = 0 with degh = degH.  Both vectors are element-ordered and contiguous in item order, like the
+ * reference's fine_stride / coarse_stride.  degh >= degH as the reference asserts (d4est_operators.c:379). */
+typedef struct d4est_hip_transfer d4est_hip_transfer_t;
+d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine, const int* degH, const int* degh);
+void d4est_hip_transfer_destroy(d4est_hip_transfer_t* t);
+void d4est_hip_transfer_set_stream(d4est_hip_transfer_t* t, void* hip_stream);
+long long d4est_hip_transfer_coarse_nodes(const d4est_hip_transfer_t* t);
+long long d4est_hip_transfer_fine_nodes(const d4est_hip_transfer_t* t);
+/* x_fine = P x_coarse (d4est_operators_apply_p_prolong / _hp_prolong per item) */
+void d4est_hip_transfer_prolong(d4est_hip_transfer_t* t, const double* x_coarse_dev, double* x_fine_dev);
+/* x_coarse = P^T x_fine (d4est_operators_apply_p_prolong_transpose / _hp_prolong_transpose per item; overwrites x_coarse) */
+void d4est_hip_transfer_restrict(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev);
+
 #ifdef __cplusplus
 }
 #endif
