@@ -41,6 +41,8 @@ SIGNATURES = {
     "d4est_hip_interpolate": (None, [_vp, _vp, _vp]),
     "d4est_hip_apply_weighted_mass_matrix": (None, [_vp, _vp, _vp, _vp]),
     "d4est_hip_apply_inverse_mass_matrix": (None, [_vp, _vp, _vp]),
+    "d4est_hip_apply_dij": (None, [_vp, _vp, ctypes.c_int, _vp]),
+    "d4est_hip_apply_dij_transpose": (None, [_vp, _vp, ctypes.c_int, _vp]),
     "d4est_hip_apply_mij": (None, [_vp, _vp, _vp]),
     "d4est_hip_apply_invmij": (None, [_vp, _vp, _vp]),
     "d4est_hip_compute_dudr": (None, [_vp, _vp, _vp, _vp, _vp]),
@@ -203,6 +205,11 @@ class Plan:
     def apply_invmij(self, x, out):
         assert x.numel() == self.local_nodes and out.numel() == self.local_nodes
         self.lib.d4est_hip_apply_invmij(self.handle, _ptr(x), _ptr(out))
+
+    def apply_dij(self, x, direction, out, transpose=False):
+        assert x.numel() == self.local_nodes and out.numel() == self.local_nodes
+        fn = self.lib.d4est_hip_apply_dij_transpose if transpose else self.lib.d4est_hip_apply_dij
+        fn(self.handle, _ptr(x), int(direction), _ptr(out))
 
     def compute_dudr(self, u, d0, d1, d2):
         for t in (u, d0, d1, d2):

@@ -291,6 +291,16 @@ void d4est_hip_apply_invmij(d4est_hip_plan_t* plan, const double* in_dev, double
   d4est_hip::launch_mass_like(plan, 2, in_dev, out_dev, nullptr, 3);
 }
 
+void d4est_hip_apply_dij(d4est_hip_plan_t* plan, const double* in_dev, int dir, double* out_dev) {
+  check_plan(plan, "apply_dij");
+  d4est_hip::launch_dij(plan, in_dev, out_dev, dir, 0);
+}
+
+void d4est_hip_apply_dij_transpose(d4est_hip_plan_t* plan, const double* in_dev, int dir, double* out_dev) {
+  check_plan(plan, "apply_dij_transpose");
+  d4est_hip::launch_dij(plan, in_dev, out_dev, dir, 1);
+}
+
 void d4est_hip_compute_dudr(d4est_hip_plan_t* plan, const double* u_dev, double* dudr0_dev, double* dudr1_dev, double* dudr2_dev) {
   check_plan(plan, "compute_dudr");
   d4est_hip::launch_dudr(plan, u_dev, dudr0_dev, dudr1_dev, dudr2_dev);

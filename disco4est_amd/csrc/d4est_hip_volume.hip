@@ -2188,6 +2188,18 @@ __global__ __launch_bounds__(256) void generic_dudr_kernel(const double* __restr
   }
 }
 
+// out = D_dir in (transpose = 0) or D_dir^T in (1): d4est_operators_apply_dij / _dij_transpose
+// (src/dGMath/d4est_operators.c:1385-1410, :2259-2284), batched; a utility entry (the operator path never forms these)
+__global__ __launch_bounds__(256) void generic_dij_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                          const int* __restrict__ ns_list, int n_bucket, int N,
+                                                          const double* __restrict__ Dop, int dir, int transpose) {
+  for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
+    const int ns = ns_list[ei];
+    GenDims dn = {{N, N, N}};
+    gen_apply(Dop, N, transpose ? 1 : N, transpose ? N : 1, dir, in + ns, dn, out + ns, false);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // geometry pre-combination: symmetric metric  M_{ab} = w_i w_j w_k J sum_d r_{a,d} r_{b,d}
 // from the reference's SoA arrays (setup-time transform).
@@ -2452,6 +2464,18 @@ void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, 
       hipLaunchKernelGGL(generic_dudr_kernel, dim3(grid), dim3(256), 0, plan->stream, u, d0, d1, d2,
                          plan->d_ns_list + bk.elem_offset, bk.n_elem, bk.N, bk.d_D);
     }
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_dij(d4est_hip_plan* plan, const double* in, double* out, int dir, int transpose) {
+  if (dir < 0 || dir > 2) D4EST_HIP_ABORT("apply_dij: direction %d", dir);
+  if (in == out) D4EST_HIP_ABORT("apply_dij: in and out must not alias");
+  for (const Bucket& bk : plan->buckets) {
+    if (bk.n_elem == 0) continue;
+    const int grid = bk.n_elem < 16384 ? bk.n_elem : 16384;
+    hipLaunchKernelGGL(generic_dij_kernel, dim3(grid), dim3(256), 0, plan->stream, in, out, plan->d_ns_list + bk.elem_offset,
+                       bk.n_elem, bk.N, bk.d_D, dir, transpose);
   }
   HIP_CHECK(hipGetLastError());
 }

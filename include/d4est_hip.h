@@ -125,6 +125,10 @@ void d4est_hip_apply_inverse_mass_matrix(d4est_hip_plan_t* plan, const double* i
  * d4est_operators_apply_mij / d4est_operators_apply_invmij (d4est_operators.c:891-928), batched over the plan. */
 void d4est_hip_apply_mij(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev);
 void d4est_hip_apply_invmij(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev);
+/* out = D_dir in and out = D_dir^T in per element, dir = 0, 1, 2 = r, s, t: d4est_operators_apply_dij / _dij_transpose
+ * (d4est_operators.c:1385-1410, :2259-2284), batched over the plan; in and out must not alias. */
+void d4est_hip_apply_dij(d4est_hip_plan_t* plan, const double* in_dev, int dir, double* out_dev);
+void d4est_hip_apply_dij_transpose(d4est_hip_plan_t* plan, const double* in_dev, int dir, double* out_dev);
 /* dudr_i = D_i u, i = 0..2 : d4est_laplacian_compute_dudr (d4est_laplacian.c:237-282), 3 applies of
  * d4est_operators_apply_dij (d4est_operators.c:1385-1410) per element. */
 void d4est_hip_compute_dudr(d4est_hip_plan_t* plan, const double* u_dev, double* dudr0_dev, double* dudr1_dev, double* dudr2_dev);

@@ -192,6 +192,23 @@ def test_weighted_inverse_mass_mij_parity(gpu, hiplib, oracle, level, deg, inc, 
         o = torch.full_like(du, float("nan"))
         (plan.apply_invmij if inverse else plan.apply_mij)(du, o)
         assert _rel(o.cpu().numpy(), oracle.apply_mij(m, u, inverse)) <= RTOL
+    # d4est_operators_apply_dij / _dij_transpose, one direction at a time
+    import ctypes
+    dp = ctypes.POINTER(ctypes.c_double)
+    oracle.lib.oracle_apply_dij.argtypes = [dp, ctypes.c_int, ctypes.c_int, dp]
+    oracle.lib.oracle_apply_dij_transpose.argtypes = [dp, ctypes.c_int, ctypes.c_int, dp]
+    for direction in range(3):
+        for tr in (False, True):
+            o = torch.full_like(du, float("nan"))
+            plan.apply_dij(du, direction, o, transpose=tr)
+            ref = np.zeros(m.local_nodes)
+            fn = oracle.lib.oracle_apply_dij_transpose if tr else oracle.lib.oracle_apply_dij
+            for e in range(m.n_elements):
+                s0, n3 = int(m.nodal_stride[e]), (int(m.deg[e]) + 1) ** 3
+                src = np.ascontiguousarray(u[s0:s0 + n3]); dst = np.zeros(n3)
+                fn(src.ctypes.data_as(dp), int(m.deg[e]), direction, dst.ctypes.data_as(dp))
+                ref[s0:s0 + n3] = dst
+            assert _rel(o.cpu().numpy(), ref) <= RTOL
     if inc == 0:
         # the inverse mass is Gauss-only in the reference; the tolerance carries the conditioning of V^-1 (grows with p)
         o = torch.full_like(du, float("nan"))
