@@ -108,23 +108,49 @@ __device__ __forceinline__ void eo_post(const double* ab, double* y) {
     y[R - 1 - r] = ab[r] - ab[R / 2 + r];
   }
 }
-// y (+)= M x for a centro-symmetric (ANTI = false) or centro-antisymmetric (ANTI = true) operator M (R x C, both even)
+// which EO contraction form a (C, R) pair uses: measured on MI355X with tools/sweep_p.py (GDoF/s pipelined | hoisted):
+// p=5 75.6|76.8, 7 81.5|83.1, 9 62.8|63.6, 11 51.1|48.7, 13 44.1|40.9, 15 39.9|46.8, 17 34.1|26.9, 19 38.7|18.5
+template <int C, int R>
+constexpr bool kEoPipelined = ((C > R ? C : R) >= 12) && ((C > R ? C : R) != 16);
+
+// software-pipelined row contraction, defined below: y[o] (+)= sum_i op[i*LD + o] x[i], o < NO, two rows per step
+template <int NI, int NO, bool ACC, int LD = NO>
+__device__ __forceinline__ void contract_single(const double* __restrict__ op, const double* x, double* y);
+
+// y (+)= M x for a centro-symmetric (ANTI = false) or centro-antisymmetric (ANTI = true) operator M (R x C, both even).
+// Each half of the EO rows is contracted in chunks of <= 8 outputs by the software-pipelined contract_single (two scalar
+// rows in flight, sched_barrier per step): without the pipelining barriers the compiler hoists every row load to the top and
+// spills 1000+ SGPRs at N >= 16.
 template <int C, int R, bool ANTI, bool ACC>
 __device__ __forceinline__ void apply_eo(const double* __restrict__ tab, const double* x, double* y) {
   constexpr int HC = C / 2, HR = R / 2;
   double xe[HC], xo[HC], ab[R];
   eo_pre<C>(x, xe, xo);
+  const double* xf = ANTI ? xo : xe;  // first half multiplies xe (symmetric) / xo (antisymmetric)
+  const double* xs = ANTI ? xe : xo;
+  if constexpr (kEoPipelined<C, R>) {
+    constexpr int CH0 = HR < 8 ? HR : 8, CH1 = (HR - 8 > 0) ? (HR - 8 < 8 ? HR - 8 : 8) : 0, CH2 = (HR - 16 > 0) ? HR - 16 : 0;
+    static_assert(HR <= 24, "apply_eo: row halves longer than 24 are not supported");
+    contract_single<HC, CH0, false, R>(tab, xf, ab);
+    if constexpr (CH1 > 0) contract_single<HC, CH1, false, R>(tab + 8, xf, ab + 8);
+    if constexpr (CH2 > 0) contract_single<HC, CH2, false, R>(tab + 16, xf, ab + 16);
+    contract_single<HC, CH0, false, R>(tab + HR, xs, ab + HR);
+    if constexpr (CH1 > 0) contract_single<HC, CH1, false, R>(tab + HR + 8, xs, ab + HR + 8);
+    if constexpr (CH2 > 0) contract_single<HC, CH2, false, R>(tab + HR + 16, xs, ab + HR + 16);
+  } else {
+    // free scheduling: the compiler hoists the row loads (deep memory-level parallelism, at the price of SGPR spills)
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const double* xx = ((half == 0) != ANTI) ? xe : xo;  // first half multiplies xe (symmetric) / xo (antisymmetric)
+    for (int half = 0; half < 2; ++half) {
+      const double* xx = half == 0 ? xf : xs;
 #pragma unroll
-    for (int o0 = 0; o0 < HR; o0 += 8) {
+      for (int o0 = 0; o0 < HR; o0 += 8) {
 #pragma unroll
-      for (int c = 0; c < HC; ++c) {
-        sdouble_ptr row = launder(tab + c * R + half * HR + o0);
+        for (int c = 0; c < HC; ++c) {
+          sdouble_ptr row = launder(tab + c * R + half * HR + o0);
 #pragma unroll
-        for (int o = 0; o < 8; ++o)
-          if (o0 + o < HR) ab[half * HR + o0 + o] = (c == 0) ? row[o] * xx[0] : fma(row[o], xx[c], ab[half * HR + o0 + o]);
+          for (int o = 0; o < 8; ++o)
+            if (o0 + o < HR) ab[half * HR + o0 + o] = (c == 0) ? row[o] * xx[0] : fma(row[o], xx[c], ab[half * HR + o0 + o]);
+        }
       }
     }
   }
@@ -849,7 +875,7 @@ __device__ __forceinline__ void contract_pair(const double* __restrict__ opA, co
 }
 
 // y (+)= sum_i row_i * x[i], two rows per step
-template <int NI, int NO, bool ACC>
+template <int NI, int NO, bool ACC, int LD>
 __device__ __forceinline__ void contract_single(const double* __restrict__ op, const double* x, double* y) {
   constexpr int STEPS = (NI + 1) / 2;
   double c0[NO], c1[NO], n0[NO], n1[NO];
@@ -858,7 +884,7 @@ __device__ __forceinline__ void contract_single(const double* __restrict__ op, c
 #pragma unroll
     for (int o = 0; o < NO; ++o) c0[o] = r0[o];
     if (NI > 1) {
-      sdouble_ptr r1 = launder(op + NO);
+      sdouble_ptr r1 = launder(op + LD);
 #pragma unroll
       for (int o = 0; o < NO; ++o) c1[o] = r1[o];
     }
@@ -868,7 +894,7 @@ __device__ __forceinline__ void contract_single(const double* __restrict__ op, c
     const int i0 = 2 * st, i1 = 2 * st + 1;
     if (i0 + 2 < NI) {
       sdouble_ptr r0, r1;
-      launder2_after(op + (i0 + 2) * NO, op + ((i1 + 2 < NI) ? (i1 + 2) : (i0 + 2)) * NO, c0[0], (i1 < NI) ? c1[0] : c0[0], r0, r1);
+      launder2_after(op + (i0 + 2) * LD, op + ((i1 + 2 < NI) ? (i1 + 2) : (i0 + 2)) * LD, c0[0], (i1 < NI) ? c1[0] : c0[0], r0, r1);
 #pragma unroll
       for (int o = 0; o < NO; ++o) n0[o] = r0[o];
       if (i1 + 2 < NI) {
@@ -2240,6 +2266,9 @@ __global__ __launch_bounds__(256) void metric_precombine_kernel(const double* __
   X(13, 13) X(14, 14) X(15, 15) X(16, 16)                                                       \
   X(2, 3) X(3, 4) X(4, 5) X(8, 9) X(3, 6) X(4, 6) X(8, 10)
 
+// p = 16 .. 19 (the reference's tables stop at 20 Lobatto points): only the two-field multi-wave kernels fit the 160 KB LDS
+#define D4EST_HIP_BIG_PAIRS(X) X(17, 17) X(18, 18) X(19, 19) X(20, 20)
+
 template <typename K>
 static void set_lds_limit(K kernel, size_t bytes) {
   if (bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -2392,6 +2421,28 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   }
     D4EST_HIP_FAST_PAIRS(X)
 #undef X
+#define X(N_, NQ_)                                                                                              \
+  if (!done && bk.N == N_ && bk.NQ == NQ_ && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] != 0) {                \
+    using W = WaveCfg<N_, NQ_>;                                                                                 \
+    static_assert(W::LDS_BYTES <= 160 * 1024, "two-field kernel does not fit the LDS");                         \
+    constexpr bool kEven = (N_ % 2 == 0) && (NQ_ % 2 == 0);                                                     \
+    const bool use_eo = kEven && bk.d_EBf && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0;                    \
+    std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,false,%s> (%d threads)", N_, NQ_, use_eo ? "eo" : "plain", W::THREADS); \
+    if (use_eo) {                                                                                               \
+      set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven>, W::LDS_BYTES);                                \
+      hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
+                         plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,                 \
+                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, 0); \
+    } else {                                                                                                    \
+      set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, false>, W::LDS_BYTES);                                \
+      hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, false>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
+                         plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,                 \
+                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, bk.d_GT, 0);     \
+    }                                                                                                           \
+    done = true;                                                                                                \
+  }
+    D4EST_HIP_BIG_PAIRS(X)
+#undef X
     if (!done) {
       std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::generic_volume_kernel (N=%d,NQ=%d)", bk.N, bk.NQ);
       launch_generic(plan, bk, 3, u, Au);
@@ -2426,6 +2477,7 @@ static void launch_mass_like_mode(d4est_hip_plan* plan, const double* in, double
     }                                                                                                                 \
   }
     D4EST_HIP_FAST_PAIRS(X)
+    D4EST_HIP_BIG_PAIRS(X)
 #undef X
     if (!done) launch_generic(plan, bk, MODE == 3 ? 4 : (MODE == 4 ? 5 : MODE), in, out, coeff, op, qs_list, NQe, wts);
   }
@@ -2458,6 +2510,7 @@ void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, 
     }                                                                                                      \
   }
     D4EST_HIP_FAST_PAIRS(X)
+    D4EST_HIP_BIG_PAIRS(X)
 #undef X
     if (!done) {
       const int grid = bk.n_elem < 2048 ? bk.n_elem : 2048;

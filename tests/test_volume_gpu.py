@@ -35,7 +35,8 @@ CASES = [
     (1, 9, 0, 0, True), (1, 11, 0, 0, True), (0, 15, 0, 0, True), (1, 12, 0, 0, True),
     (1, 2, 3, 0, True), (1, 3, 1, 0, True), (1, 7, 1, 0, True), (1, 7, 2, 0, True), (1, 3, 2, 0, True),
     (1, 3, 0, 1, True), (1, 7, 0, 1, True), (1, 2, 1, 1, True),
-    (0, 17, 0, 0, True), (0, 19, 0, 0, False), (1, 5, 2, 0, True), (1, 1, 1, 0, True),
+    (0, 17, 0, 0, True), (0, 19, 0, 0, False), (1, 5, 2, 0, True), (1, 1, 1, 0, True), (0, 16, 0, 0, True), (0, 18, 0, 0, True),
+    (1, 13, 0, 0, True), (0, 19, 1, 0, True),
 ]
 
 

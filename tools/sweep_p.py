@@ -4,7 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from disco4est_amd import Plan, mesh as M
 dev = torch.device("cuda:0")
-for deg, level, count in ((1, 6, None), (2, 5, None), (3, 5, None), (5, 5, 16384), (7, 5, 16384), (9, 4, None), (11, 4, None), (15, 4, 2048), (19, 3, None)):
+for deg, level, count in ((1, 6, None), (2, 5, None), (3, 5, None), (5, 5, 16384), (7, 5, 16384), (9, 4, None), (11, 4, None), (13, 4, 2048), (15, 4, 2048), (17, 3, None), (19, 3, None)):
     m = M.BrickMesh(level, deg, count=count)
     J, rst = m.geometry(None); u = m.field()
     plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=torch.cuda.current_stream())
