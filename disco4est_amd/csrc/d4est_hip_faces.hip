@@ -554,7 +554,7 @@ __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/,
   __syncthreads();
 }
 
-__global__ __launch_bounds__(384) void trace_wave_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
+__global__ __launch_bounds__(384, 6) void trace_wave_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
                                                          const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
                                                          const double* __restrict__ face_ops, int n_elem) {
   // Per side only TWO nodal fields are formed -- the trace tr(a,b) of u and the normal derivative n(a,b) -- because the
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(384) void trace_wave_kernel(const double* __restric
   }
 }
 
-__global__ __launch_bounds__(384) void flux_wave_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
+__global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
                                                         double* __restrict__ Au, const SideDesc* __restrict__ sd,
                                                         const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                         const double* __restrict__ geom, const double* __restrict__ bndry_q,
@@ -1311,6 +1311,17 @@ void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const doubl
   }
 }
 
+// resident workgroups per CU assumed by the persistent fast kernels (experiment knob: D4EST_HIP_FACE_WG_PER_CU)
+static int face_wg_per_cu() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = std::getenv("D4EST_HIP_FACE_WG_PER_CU");
+    v = e ? std::atoi(e) : 4;
+    if (v < 1) v = 4;
+  }
+  return v;
+}
+
 static size_t generic_lds_bytes(const d4est_hip_plan* plan) { return (size_t)plan->max_face_lds_doubles * sizeof(double); }
 
 void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost) {
@@ -1333,7 +1344,7 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
                        (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, n, fh.hp_fld_stride);
   } else if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-    const int resident = 4 * cus;
+    const int resident = face_wg_per_cu() * cus;
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
@@ -1363,7 +1374,7 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   } else if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     // persistent grid: 3 workgroups per CU are resident (LDS), each loops over elements
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-    const int resident = 4 * cus;
+    const int resident = face_wg_per_cu() * cus;
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     hipLaunchKernelGGL(flux_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
