@@ -238,6 +238,15 @@ class Oracle:
           I(sides["side_reorder"]), I(sides["side_mortar_stride"]), I(sides["side_bndry_stride"]), P(sides["sj"]), P(sides["n"]),
           P(sides["drst_m"]), P(sides["drst_p"]), P(sides["hm"]), P(sides["hp"]), float(penalty_prefactor), int(penalty_fcn), threads)
 
+    def set_hanging(self, sides):
+        """keep the hanging-face arrays of `sides` active for the following calls (None switches back to conforming)"""
+        self.lib.oracle_flux_set_hanging.argtypes = [ip, ip, ip, ip]
+        if sides is None or "side_hang" not in sides:
+            self.lib.oracle_flux_set_hanging(None, None, None, None)
+            return
+        self._hang_keep2 = [np.ascontiguousarray(sides[k], dtype=np.int32) for k in ("side_hang", "side_sub", "side_nbr4", "side_orientation")]
+        self.lib.oracle_flux_set_hanging(*[I(a) for a in self._hang_keep2])
+
     def cheby_iterate(self, u, rhs, iters, lmin, lmax, residual_at_end=1):
         """returns (u_new, r); operator from set_operator()"""
         u = u.copy(); Au = np.zeros_like(u); r = np.zeros_like(u)

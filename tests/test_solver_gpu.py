@@ -47,6 +47,39 @@ def test_cheby_iterate_parity(gpu, hiplib, oracle, level, deg, curved):
     assert np.linalg.norm(r_ref) < np.linalg.norm(r0)
 
 
+def test_smoother_on_hanging_mesh(gpu, hiplib, oracle):
+    """Chebyshev iteration and cg_eigs on a locally refined, mixed-p mesh (hanging 1 <-> 4 mortars in the operator)."""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    refine = np.zeros(8, dtype=bool)
+    refine[[1, 6]] = True
+    m0 = M.HangingBrickMesh(1, refine, 2)
+    m = M.HangingBrickMesh(1, refine, 2 + (np.arange(m0.n_elements) % 2))
+    mp = M.SineMap(0.04)
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan.set_geometry(J, rst)
+    plan.set_faces(sides, 10.0, 0)
+    oracle.set_operator(m, J, rst, sides, 10.0, 0)
+    oracle.set_hanging(sides)
+    try:
+        u0 = M.splitmix64_uniform(21, m.local_nodes)
+        rhs = M.splitmix64_uniform(22, m.local_nodes) - 0.5
+        b_ref, _ = oracle.cg_eigs(np.zeros(m.local_nodes), rhs, 10, 1)
+        du = _t(np.zeros(m.local_nodes), gpu); drhs = _t(rhs, gpu); dAu = torch.empty_like(du)
+        b, _ = plan.cg_eigs(du, drhs, dAu, 10, 1)
+        assert abs(b - b_ref) <= 1e-9 * abs(b_ref)
+        lmax, lmin = b_ref, b_ref / 30.0
+        u_ref, r_ref = oracle.cheby_iterate(u0, rhs, 5, lmin, lmax, 1)
+        du = _t(u0, gpu); dr = torch.full_like(du, float("nan"))
+        plan.cheby_iterate(du, drhs, dAu, dr, 5, lmin, lmax, 1)
+        assert _rel(du.cpu().numpy(), u_ref) <= 1e-11
+        assert _rel(dr.cpu().numpy(), r_ref) <= 1e-10
+    finally:
+        oracle.set_hanging(None)
+    plan.destroy()
+
+
 @pytest.mark.parametrize("use_new", [1, 0])
 def test_cg_eigs_parity(gpu, hiplib, oracle, use_new):
     import torch
