@@ -240,6 +240,29 @@ def main():
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / reps
                 sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9}
+            # stiffness apply at the other degrees SURVEY.md section 8d names (same general path, ~2-8 MDoF each)
+            for deg, level, count in ((3, 5, None), (11, 4, None), (15, 4, 2048)):
+                m2 = M.BrickMesh(level, deg, count=count)
+                J2, rst2 = m2.geometry(None)
+                p2 = Plan(m2.deg, m2.deg_quad, m2.nodal_stride, m2.quad_stride, 0, stream=stream)
+                p2.set_geometry(J2, rst2)
+                x2 = torch.from_numpy(m2.field()).to(dev)
+                y2 = torch.empty_like(x2)
+                for _ in range(3):
+                    p2.apply_stiffness_matrix(x2, y2)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 20
+                e0.record(stream)
+                for _ in range(reps):
+                    p2.apply_stiffness_matrix(x2, y2)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                sec["stiffness_p%d" % deg] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes,
+                                              "kernel": p2.last_kernel()}
+                p2.destroy()
+                del x2, y2
             out["secondary"] = sec
         except Exception as exc:  # secondary numbers must never break the headline line
             out["secondary"] = {"error": repr(exc)}

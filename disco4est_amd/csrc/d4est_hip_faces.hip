@@ -47,6 +47,13 @@ struct ElemDesc {
   int pad;
 };
 
+// uniform plans (one degree, one mortar degree, contiguous strides): the trace kernel computes its addresses instead of loading
+// descriptors, which removes one dependent global-load latency from every workgroup (the kernel is latency bound)
+struct TraceUniform {
+  int N, NQ, offC, offCD, offD, ns0, ns_stride, pad;  // N == 0: not uniform
+  long long q0, q_stride;                              // qoff of side s = q0 + s * q_stride
+};
+
 struct GhostSideDesc {
   int N;       // nodes/dir of the ghost element
   int f;       // its face
@@ -556,7 +563,7 @@ __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/,
 
 __global__ __launch_bounds__(384, 6) void trace_wave_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
                                                          const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
-                                                         const double* __restrict__ face_ops, int n_elem) {
+                                                         const double* __restrict__ face_ops, int n_elem, TraceUniform uni) {
   // Per side only TWO nodal fields are formed -- the trace tr(a,b) of u and the normal derivative n(a,b) -- because the
   // tangential derivatives commute with the interpolation:  (C (x) C)(D_a tr) = ((C D) (x) C) tr.  Pass 1 contracts the
   // face index a with C and CD, pass 2 the index b: 56 FMAs and ~90 LDS reads per lane instead of 152 / 130.
@@ -569,16 +576,28 @@ __global__ __launch_bounds__(384, 6) void trace_wave_kernel(const double* __rest
   const int dir = f >> 1;
   const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;  // reference directions of the face indices a and b
   int e = blockIdx.x;
-  ElemDesc edn = ed[e < n_elem ? e : 0];
-  SideDesc dn = sd[6 * (e < n_elem ? e : 0) + f];
+  ElemDesc edn{};
+  SideDesc dn{};
+  auto uniform_desc = [&](int e_, ElemDesc& el_, SideDesc& d_) {
+    el_.N = uni.N; el_.ns = uni.ns0 + e_ * uni.ns_stride; el_.offD = uni.offD;
+    d_.NQ = uni.NQ; d_.offC = uni.offC; d_.offCD = uni.offCD; d_.qoff = uni.q0 + (long long)(6 * e_ + f) * uni.q_stride;
+  };
+  if (uni.N > 0) uniform_desc(e < n_elem ? e : 0, edn, dn);
+  else {
+    edn = ed[e < n_elem ? e : 0];
+    dn = sd[6 * (e < n_elem ? e : 0) + f];
+  }
   for (; e < n_elem; e += gridDim.x) {
     const ElemDesc el = edn;
     const SideDesc d = dn;
     {
       const int en = e + gridDim.x;
       if (en < n_elem) {
-        edn = ed[en];
-        dn = sd[6 * en + f];
+        if (uni.N > 0) uniform_desc(en, edn, dn);
+        else {
+          edn = ed[en];
+          dn = sd[6 * en + f];
+        }
       }
     }
     const int N = el.N, N2 = N * N, N3 = N2 * N, NQ = d.NQ, T = NQ * NQ;
@@ -777,6 +796,7 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
 namespace {
 
 struct FaceHost {
+  TraceUniform uni{};            // N == 0: descriptors are loaded
   // hanging-mesh (mortar record) path
   bool hp = false;
   int n_rec = 0;
@@ -1179,6 +1199,20 @@ void faces_setup(d4est_hip_plan* plan) {
     edv[e].offD = fast ? get_D(plan->deg[e], true) : edg[e].offD;
     edv[e].pad = edg[e].pad = 0;
   }
+  // uniform plan? (one degree, one mortar degree, contiguous element and trace strides)
+  fh.uni = TraceUniform{};
+  if (fast && ne > 0 && !hp) {
+    bool uniform = true;
+    const int N0 = edv[0].N, n3 = N0 * N0 * N0;
+    for (int e = 0; e < ne && uniform; ++e) uniform = (edv[e].N == N0) && (edv[e].ns == edv[0].ns + e * n3);
+    const long long qs = 4LL * sd[0].NQ * sd[0].NQ;
+    for (size_t s_ = 0; s_ < ns && uniform; ++s_)
+      uniform = (sd[s_].NQ == sd[0].NQ) && (sd[s_].offC == sd[0].offC) && (sd[s_].offCD == sd[0].offCD) && (sd[s_].qoff == sd[0].qoff + (long long)s_ * qs);
+    if (uniform) {
+      fh.uni.N = N0; fh.uni.NQ = sd[0].NQ; fh.uni.offC = sd[0].offC; fh.uni.offCD = sd[0].offCD; fh.uni.offD = edv[0].offD;
+      fh.uni.ns0 = edv[0].ns; fh.uni.ns_stride = n3; fh.uni.q0 = sd[0].qoff; fh.uni.q_stride = qs;
+    }
+  }
   ops.resize(ops.size() + 64, 0.0);  // slack: the fast kernels read 64-entry images
   plan->d_elem_desc = upload_vec(edv);
   fh.d_elem_desc_generic = upload_vec(edg);
@@ -1322,6 +1356,20 @@ static int face_wg_per_cu() {
   return v;
 }
 
+static void debug_occupancy_once() {
+  static bool done = false;
+  if (done || !std::getenv("D4EST_HIP_DEBUG_OCC")) return;
+  done = true;
+  int nt = -1, nf = -1;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nt, reinterpret_cast<const void*>(trace_wave_kernel), 384, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, reinterpret_cast<const void*>(flux_wave_kernel), 384, 0);
+  hipFuncAttributes at{}, af{};
+  (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(trace_wave_kernel));
+  (void)hipFuncGetAttributes(&af, reinterpret_cast<const void*>(flux_wave_kernel));
+  std::fprintf(stderr, "[d4est_hip] occupancy: trace_wave %d wg/CU (regs %d, lds %zu, scratch %zu) flux_wave %d wg/CU (regs %d, lds %zu, scratch %zu)\n",
+               nt, at.numRegs, at.sharedSizeBytes, at.localSizeBytes, nf, af.numRegs, af.sharedSizeBytes, af.localSizeBytes);
+}
+
 static size_t generic_lds_bytes(const d4est_hip_plan* plan) { return (size_t)plan->max_face_lds_doubles * sizeof(double); }
 
 void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost) {
@@ -1347,8 +1395,9 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     const int resident = face_wg_per_cu() * cus;
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
+    debug_occupancy_once();
     hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
-                       (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n);
+                       (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, fh.uni);
   } else {
     const size_t lds = generic_lds_bytes(plan);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
