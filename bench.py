@@ -123,6 +123,9 @@ def main():
     stream = torch.cuda.current_stream()
     plan = Plan(mesh.deg, mesh.deg_quad, mesh.nodal_stride, mesh.quad_stride, 0, stream=stream)
     plan.set_geometry(J, rst)
+    # headline = the GENERAL path (per-node metric streamed from HBM, 64 B/DoF, like the reference): the affine shortcut the
+    # engine would take by itself on this brick is switched off here and reported separately under "secondary"
+    plan.set_tuning(7, 0)
     du = torch.from_numpy(u).to(dev)
     dAu = torch.empty_like(du)
 
@@ -240,12 +243,29 @@ def main():
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / reps
                 sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9}
+            # the affine path: same brick, metric rebuilt from 6 numbers per element, 16 B/DoF
+            if args.geometry != "sine":
+                plan.set_tuning(7, -1)
+                for _ in range(3):
+                    plan.apply_stiffness_matrix(du, dAu)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(30):
+                    plan.apply_stiffness_matrix(du, dAu)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 30
+                sec["stiffness_p%d_affine_path" % args.deg] = {"ms": ms, "GDoF_per_s": dofs_per_rank / (ms * 1e-3) / 1e9,
+                                                                "algorithmic_bytes_per_dof": 16.0, "kernel": plan.last_kernel()}
+                plan.set_tuning(7, 0)
             # stiffness apply at the other degrees SURVEY.md section 8d names (same general path, ~2-8 MDoF each)
             for deg, level, count in ((3, 5, None), (11, 4, None), (15, 4, 2048)):
                 m2 = M.BrickMesh(level, deg, count=count)
                 J2, rst2 = m2.geometry(None)
                 p2 = Plan(m2.deg, m2.deg_quad, m2.nodal_stride, m2.quad_stride, 0, stream=stream)
                 p2.set_geometry(J2, rst2)
+                p2.set_tuning(7, 0)
                 x2 = torch.from_numpy(m2.field()).to(dev)
                 y2 = torch.empty_like(x2)
                 for _ in range(3):

@@ -202,6 +202,8 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   (void)hipFree(plan->d_qs_list);
   (void)hipFree(plan->d_J);
   (void)hipFree(plan->d_metric);
+  (void)hipFree(plan->d_metric_affine);
+  (void)hipFree(plan->d_nonaffine);
   (void)hipFree(plan->d_scratch);
   d4est_hip::faces_destroy(plan);
   (void)hipFree(plan->d_work_p); (void)hipFree(plan->d_work_d); (void)hipFree(plan->d_work_r);

@@ -43,6 +43,7 @@ struct Bucket {
   // (d4est_quadrature.c:1222-1331; only when deg_quad == deg, else null)
   // affine strides of the bucket-ordered element list (ns = ns0 + i*ns_stride); ns_stride < 0: not affine, use the lists
   int ns0 = 0, ns_stride = -1, qs0 = 0, qs_stride = -1;
+  bool affine = false;  // every element has a node-independent J (dr/dx)(dr/dx)^T (detected in plan_set_geometry)
   // even-odd tables (see stiffness_wave_eo_kernel), only when N and NQ are even: forward B, G (N/2 rows of NQ) and
   // backward B^T, G^T (NQ/2 rows of N)
   double* d_EBf = nullptr;
@@ -79,7 +80,9 @@ struct d4est_hip_plan {
 
   bool has_geometry = false;
   double* d_J = nullptr;          // local_nodes_quad  (reference layout)
-  double* d_metric = nullptr;     // 6 * local_nodes_quad, element-blocked: [e][c][n], c in (rr,rs,rt,ss,st,tt)
+  double* d_metric = nullptr;
+  double* d_metric_affine = nullptr;  // 6 per element (bucket order): J (dr/dx)(dr/dx)^T of node 0
+  int* d_nonaffine = nullptr;         // per bucket: set by the precombine kernel when an element is not affine     // 6 * local_nodes_quad, element-blocked: [e][c][n], c in (rr,rs,rt,ss,st,tt)
 
   // ---- faces (d4est_hip_faces.hip) ----
   bool has_faces = false, has_face_geometry = false;
@@ -109,7 +112,7 @@ struct d4est_hip_plan {
   d4est_hip_allreduce_fn allreduce_fn = nullptr;
   void* comm_ctx = nullptr;
 
-  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
+  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;

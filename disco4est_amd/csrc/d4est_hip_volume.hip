@@ -1433,12 +1433,14 @@ __device__ __forceinline__ void contract_single_eo(const double* __restrict__ op
 
 // EBf / EGf: EO tables of y = B x / y = G x (N/2 rows of NQ);  EBb / EGb: of y = B^T x / y = G^T x (NQ/2 rows of N).
 // N and NQ even.  Strides: affine (ns_stride >= 0) or from the lists.
-template <int N, int NQ>
+// AFF = true: affine bucket -- the metric of node (a, b, kq) is rebuilt as (w_a w_b w_kq) * c[0..5] from the element's six
+// constants (affine + 6 * element) instead of being streamed: 16 B/DoF of traffic instead of 64 (SURVEY.md section 8d "affine path")
+template <int N, int NQ, bool AFF = false>
 __global__ __launch_bounds__(64, 4) void stiffness_wave_eo_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ EBf,
     const double* __restrict__ EGf, const double* __restrict__ EBb, const double* __restrict__ EGb, int ns0, int ns_stride,
-    int qs0, int qs_stride) {
+    int qs0, int qs_stride, const double* __restrict__ affine = nullptr, const double* __restrict__ wq = nullptr) {
   using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
   constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
@@ -1560,15 +1562,29 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave_eo_kernel(
 
   // ---- quadrature-point stage
   if (active) {
-    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+    if constexpr (AFF) {
+      const double* __restrict__ c = affine + (size_t)6 * ei;
+      const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+      const double wab = wq[b] * wq[a];
 #pragma unroll
-    for (int kq = 0; kq < NQ; ++kq) {
-      const int q = NQ * NQ * kq;
-      const double m0 = m[q], m1 = m[NQ3 + q], m2 = m[2 * NQ3 + q], m3 = m[3 * NQ3 + q], m4 = m[4 * NQ3 + q], m5 = m[5 * NQ3 + q];
-      const double r = gr[kq], s = gs[kq], t = gt[kq];
-      gr[kq] = m0 * r + m1 * s + m2 * t;
-      gs[kq] = m1 * r + m3 * s + m4 * t;
-      gt[kq] = m2 * r + m4 * s + m5 * t;
+      for (int kq = 0; kq < NQ; ++kq) {
+        const double w3 = wq[kq] * wab;
+        const double r = w3 * gr[kq], s = w3 * gs[kq], t = w3 * gt[kq];
+        gr[kq] = c0 * r + c1 * s + c2 * t;
+        gs[kq] = c1 * r + c3 * s + c4 * t;
+        gt[kq] = c2 * r + c4 * s + c5 * t;
+      }
+    } else {
+      const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) {
+        const int q = NQ * NQ * kq;
+        const double m0 = m[q], m1 = m[NQ3 + q], m2 = m[2 * NQ3 + q], m3 = m[3 * NQ3 + q], m4 = m[4 * NQ3 + q], m5 = m[5 * NQ3 + q];
+        const double r = gr[kq], s = gs[kq], t = gt[kq];
+        gr[kq] = m0 * r + m1 * s + m2 * t;
+        gs[kq] = m1 * r + m3 * s + m4 * t;
+        gt[kq] = m2 * r + m4 * s + m5 * t;
+      }
     }
   }
 
@@ -2233,14 +2249,36 @@ __global__ __launch_bounds__(256) void generic_dij_kernel(const double* __restri
 __global__ __launch_bounds__(256) void metric_precombine_kernel(const double* __restrict__ J, const double* __restrict__ rst,
                                                                 size_t local_nodes_quad, const int* __restrict__ qs_list,
                                                                 int n_bucket, int NQ,
-                                                                const double* __restrict__ wq, double* __restrict__ metric) {
+                                                                const double* __restrict__ wq, double* __restrict__ metric,
+                                                                double* __restrict__ affine /* 6 per bucket element */,
+                                                                int* __restrict__ nonaffine_flag) {
   const int NQ3 = NQ * NQ * NQ;
+  __shared__ double g0[6];
   for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
     const int qs = qs_list[ei];
     double* m = metric + (size_t)6 * qs;
+    // the unweighted J (dr/dx)(dr/dx)^T of node 0: an element is AFFINE when every node reproduces it (to 4 ulp)
+    if (threadIdx.x < 6) {
+      int i = 0, j = 0, c = 0;
+      for (int a = 0; a < 3; ++a)
+        for (int b = a; b < 3; ++b) {
+          if (c == (int)threadIdx.x) { i = a; j = b; }
+          ++c;
+        }
+      double sum = 0.0;
+      for (int d = 0; d < 3; ++d)
+        sum += rst[(size_t)(3 * i + d) * local_nodes_quad + qs] * rst[(size_t)(3 * j + d) * local_nodes_quad + qs];
+      g0[threadIdx.x] = J[qs] * sum;
+      affine[(size_t)6 * ei + threadIdx.x] = g0[threadIdx.x];
+    }
+    __syncthreads();
+    double scale = 0.0;
+    for (int c = 0; c < 6; ++c) scale = fmax(scale, fabs(g0[c]));
+    bool deviates = false;
     for (int q = threadIdx.x; q < NQ3; q += blockDim.x) {
       const int iq = q % NQ, jq = (q / NQ) % NQ, kq = q / (NQ * NQ);
-      const double wj = (wq[kq] * (wq[jq] * wq[iq])) * J[qs + q];
+      const double Jq = J[qs + q];
+      const double wj = (wq[kq] * (wq[jq] * wq[iq])) * Jq;
       double r[3][3];
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -2251,10 +2289,14 @@ __global__ __launch_bounds__(256) void metric_precombine_kernel(const double* __
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = i; j < 3; ++j) {
-          m[(size_t)c * NQ3 + q] = wj * (r[i][0] * r[j][0] + r[i][1] * r[j][1] + r[i][2] * r[j][2]);
+          const double gsum = r[i][0] * r[j][0] + r[i][1] * r[j][1] + r[i][2] * r[j][2];
+          m[(size_t)c * NQ3 + q] = wj * gsum;
+          if (fabs(Jq * gsum - g0[c]) > 1e-15 * scale) deviates = true;
           ++c;
         }
     }
+    if (deviates) atomicOr(nonaffine_flag, 1);
+    __syncthreads();
   }
 }
 
@@ -2309,7 +2351,15 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
     (void)cus_;
     const int stagger = ts < 0 ? 0 : ts;
     const int tw_ = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
-    if ((tw_ == 11 || tw_ < 0) && N % 2 == 0 && NQ % 2 == 0 && bk.d_EBf) {
+    const bool use_affine = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && N % 2 == 0 && NQ % 2 == 0 && bk.d_EBf && (tw_ == 11 || tw_ < 0);
+    if (use_affine) {
+      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_eo_kernel<%d,%d,affine>", N, NQ);
+      if constexpr (N % 2 == 0 && NQ % 2 == 0)
+        hipLaunchKernelGGL((stiffness_wave_eo_kernel<N, NQ, true>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
+                           plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBf, bk.d_EGf,
+                           bk.d_EBb, bk.d_EGb, bk.ns0, bk.ns_stride, bk.qs0, bk.qs_stride,
+                           plan->d_metric_affine + (size_t)6 * bk.elem_offset, bk.d_w);
+    } else if ((tw_ == 11 || tw_ < 0) && N % 2 == 0 && NQ % 2 == 0 && bk.d_EBf) {
       std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_eo_kernel<%d,%d>", N, NQ);
       if constexpr (N % 2 == 0 && NQ % 2 == 0)
         hipLaunchKernelGGL((stiffness_wave_eo_kernel<N, NQ>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
@@ -2371,7 +2421,8 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
     // the two-buffer wave kernel wins; for larger buckets the 3-buffer kernel with the metric requested
     // at entry streams HBM best.  profiles/r01_*_ab.txt
     const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE], tp = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_PREFETCH];
-    const bool use_wave = (tw < 0) ? (bk.n_elem <= 8192) : (tw != 0);
+    const bool affine_ok = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && bk.N % 2 == 0 && bk.NQ % 2 == 0;
+    const bool use_wave = (tw < 0) ? (bk.n_elem <= 8192 || affine_ok) : (tw != 0);
     const bool use_pf = (tp < 0) ? !use_wave : (tp != 0);
 #define X(N_, NQ_)                                                                                              \
   if (!done && bk.N == N_ && bk.NQ == NQ_) {                                                                    \
@@ -2534,14 +2585,26 @@ void launch_dij(d4est_hip_plan* plan, const double* in, double* out, int dir, in
 }
 
 void launch_metric_precombine(d4est_hip_plan* plan, const double* d_J, const double* d_rst) {
-  for (const Bucket& bk : plan->buckets) {
+  if (!plan->d_metric_affine) {
+    HIP_CHECK(hipMalloc(&plan->d_metric_affine, std::max<size_t>((size_t)6 * plan->n_elements, 1) * sizeof(double)));
+    HIP_CHECK(hipMalloc(&plan->d_nonaffine, std::max<size_t>(plan->buckets.size(), 1) * sizeof(int)));
+  }
+  HIP_CHECK(hipMemsetAsync(plan->d_nonaffine, 0, std::max<size_t>(plan->buckets.size(), 1) * sizeof(int), plan->stream));
+  for (size_t bi = 0; bi < plan->buckets.size(); ++bi) {
+    const Bucket& bk = plan->buckets[bi];
     if (bk.n_elem == 0) continue;
     const int grid = bk.n_elem < 4096 ? bk.n_elem : 4096;
     hipLaunchKernelGGL(metric_precombine_kernel, dim3(grid), dim3(256), 0, plan->stream, d_J, d_rst,
                        (size_t)plan->local_nodes_quad, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.NQ, bk.d_w,
-                       plan->d_metric);
+                       plan->d_metric, plan->d_metric_affine + (size_t)6 * bk.elem_offset, plan->d_nonaffine + bi);
   }
   HIP_CHECK(hipGetLastError());
+  // affine buckets (every element has a constant J (dr/dx)(dr/dx)^T): the stiffness kernel can rebuild the metric from
+  // 6 numbers per element and the 1-D weights instead of streaming 48 B per node (set-up time: one small read-back)
+  std::vector<int> flags(plan->buckets.size(), 1);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  if (!flags.empty()) HIP_CHECK(hipMemcpy(flags.data(), plan->d_nonaffine, flags.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t b = 0; b < plan->buckets.size(); ++b) plan->buckets[b].affine = (flags[b] == 0) && plan->buckets[b].n_elem > 0;
 }
 
 }  // namespace d4est_hip

@@ -223,6 +223,35 @@ def test_weighted_inverse_mass_mij_parity(gpu, hiplib, oracle, level, deg, inc, 
             assert _rel(back.cpu().numpy(), u) <= 1e-10 * max(1, deg)
 
 
+@pytest.mark.parametrize("level,deg,inc", [(1, 1, 0), (1, 3, 0), (2, 3, 2), (1, 5, 0), (1, 7, 0), (2, 7, 0)])
+def test_affine_path_parity(gpu, hiplib, oracle, level, deg, inc):
+    """Affine bricks: the engine rebuilds the metric from 6 numbers per element (tuning key 7 auto); same results as the
+    general path and as the oracle.  A curved mesh must NOT be detected as affine; a mesh with ONE curved element neither."""
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(level, deg, deg_quad_inc=inc)
+    J, rst = m.geometry(None)
+    u = m.field()
+    plan = _plan(m, J, rst)
+    du = _t(u, gpu); a = torch.full_like(du, float("nan")); g = torch.full_like(du, float("nan"))
+    plan.apply_stiffness_matrix(du, a)
+    assert "affine" in plan.last_kernel()
+    plan.set_tuning(7, 0)
+    plan.apply_stiffness_matrix(du, g)
+    assert "affine" not in plan.last_kernel()
+    ref = oracle.apply_stiffness(m, J, rst, u)
+    assert _rel(a.cpu().numpy(), ref) <= RTOL and _rel(g.cpu().numpy(), ref) <= RTOL
+    plan.destroy()
+    # perturb the geometry of one quadrature node of the last element: the bucket is no longer affine
+    rst2 = rst.copy().reshape(9, -1)
+    rst2[0, -1] *= 1.0 + 1e-9
+    plan2 = _plan(m, J, rst2.reshape(-1))
+    plan2.apply_stiffness_matrix(du, a)
+    assert "affine" not in plan2.last_kernel()
+    assert _rel(a.cpu().numpy(), oracle.apply_stiffness(m, J, rst2.reshape(-1), u)) <= RTOL
+    plan2.destroy()
+
+
 def test_edge_cases(gpu, hiplib, oracle):
     """empty plan, single element, ragged element count (not a multiple of elements-per-block)."""
     import torch

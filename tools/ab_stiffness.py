@@ -19,7 +19,7 @@ J, rst = m.geometry(None)
 u = m.field()
 dev = torch.device("cuda:0")
 plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=torch.cuda.current_stream())
-plan.set_geometry(J, rst)
+plan.set_geometry(J, rst); plan.set_tuning(7, 0)  # general path unless overridden
 du = torch.from_numpy(u).to(dev)
 out = torch.empty_like(du)
 ref = None

@@ -8,7 +8,7 @@ for deg, level, count in ((1, 6, None), (2, 5, None), (3, 5, None), (5, 5, 16384
     m = M.BrickMesh(level, deg, count=count)
     J, rst = m.geometry(None); u = m.field()
     plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=torch.cuda.current_stream())
-    plan.set_geometry(J, rst)
+    plan.set_geometry(J, rst); plan.set_tuning(7, 0)  # general path unless overridden
     du = torch.from_numpy(u).to(dev); out = torch.empty_like(du)
     if len(sys.argv) > 1:  # "key=value,key=value" tuning overrides
         for kv in sys.argv[1].split(","):
