@@ -674,6 +674,185 @@ __global__ __launch_bounds__(384, 6) void trace_wave_kernel(const double* __rest
   }
 }
 
+// ---------------------------------------------------------------------------
+// MFMA form of the trace kernel.  The two interpolation passes of a face are 8 x 8 x 8 matrix products; on the vector ALU
+// every lane re-reads its operator row and its data column from LDS (45 KB of LDS traffic per wave and element: the kernel was
+// LDS-bound, tools/pmc_faces.sh).  v_mfma_f64_16x16x4 takes the stacked operator [C; CD] (16 x 8) as a 2-register operand that
+// never leaves the lane, so per element a lane only moves its own few values through LDS to re-shape them into MFMA operands:
+//   pass 1:  Y (16 x 16) = [C; CD] (16 x 8) . [tr | nd] (8 x 16)         rows 0-7: C.tr | C.nd,  rows 8-15: CD.tr | (unused)
+//   pass 2:  Z1 = [C.tr; CD.tr] (16 x 8) . [C^T | CD^T] (8 x 16)          -> qu | qtb ;  qta | (unused)
+//            Z2 = [C.nd; 0]     (16 x 8) . [C^T | CD^T]                    -> qn
+// Operand layouts (cdna_hip_programming.md): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// C/D reg r: row (lane >> 4) + 4 r, col lane & 15.  [C^T | CD^T] as a B operand holds the same values as [C; CD] as an A operand.
+// ---------------------------------------------------------------------------
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// one workgroup = 3 waves = the three reference directions of one element; wave `dir` serves the two faces 2 dir, 2 dir + 1,
+// which share the same lines of u (trace = first / last entry, normal derivative = row 0 / row N-1 of D)
+__global__ __launch_bounds__(192) void trace_mfma_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
+                                                         const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
+                                                         const double* __restrict__ face_ops, int n_elem, int diag) {
+  constexpr int LDM = 18;                 // padded row length of the 8 x 16 re-shaping buffer (<= 2-way bank conflicts)
+  constexpr int UJ = 9, UK = 72;          // padded strides of the LDS copy of u: conflict-free face reads in all three directions
+  constexpr int TPB = 192;
+  __shared__ double s_u[8 * UK];
+  __shared__ double s_x[3][2][8 * LDM];   // per wave and face: [a][(field, b)]
+  // the direction is wave-uniform: with it in an SGPR the descriptor loads become scalar loads and cost no VGPRs
+  const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, lo = lane & 7, hi = lane >> 3;
+  const int mi = lane & 15, mk = lane >> 4;   // MFMA operand coordinates of this lane
+  const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;
+  int cur_off[2][2] = {{-1, -1}, {-1, -1}}, cur_offD = -1, cur_N = -1, cur_NQ[2] = {-1, -1};
+  double opA[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, drow[2][kFW];
+#pragma unroll
+  for (int i = 0; i < kFW; ++i) drow[0][i] = drow[1][i] = 0.0;
+  // persistent loop, software-pipelined: descriptors two elements ahead, u (3 values per thread) one element ahead
+  int e = blockIdx.x;
+  ElemDesc el = ed[e < n_elem ? e : 0];
+  SideDesc d0 = sd[6 * (e < n_elem ? e : 0) + 2 * dir], d1 = sd[6 * (e < n_elem ? e : 0) + 2 * dir + 1];
+  double uv[3] = {0.0, 0.0, 0.0};
+  {
+    const int n3 = el.N * el.N * el.N;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (e < n_elem && (int)threadIdx.x + TPB * r < n3) uv[r] = u[el.ns + threadIdx.x + TPB * r];
+  }
+  ElemDesc edn = el;
+  SideDesc dn0 = d0, dn1 = d1;
+  if (e + (int)gridDim.x < n_elem) {
+    edn = ed[e + gridDim.x];
+    dn0 = sd[6 * (e + gridDim.x) + 2 * dir];
+    dn1 = sd[6 * (e + gridDim.x) + 2 * dir + 1];
+  }
+  for (; e < n_elem; e += gridDim.x) {
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int t = threadIdx.x + TPB * r;
+      if (t < N3) s_u[(t % N) + UJ * ((t / N) % N) + UK * (t / N2)] = uv[r];
+    }
+    const ElemDesc el_next = edn;
+    const SideDesc d0_next = dn0, d1_next = dn1;
+    {
+      const int en = e + gridDim.x;
+      if (en < n_elem) {
+        const int n3 = el_next.N * el_next.N * el_next.N;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) uv[r] = ((int)threadIdx.x + TPB * r < n3) ? u[el_next.ns + threadIdx.x + TPB * r] : 0.0;
+        const int en2 = en + gridDim.x;
+        if (en2 < n_elem) {
+          edn = ed[en2];
+          dn0 = sd[6 * en2 + 2 * dir];
+          dn1 = sd[6 * en2 + 2 * dir + 1];
+        }
+      }
+    }
+    // operator registers: reloaded only when the side's operators change (wave-uniform test)
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const SideDesc& d = s_ ? d1 : d0;
+      if (d.offC != cur_off[s_][0] || d.offCD != cur_off[s_][1] || N != cur_N || d.NQ != cur_NQ[s_]) {
+        const int row = mi & 7, off = (mi < 8) ? d.offC : d.offCD;
+        opA[s_][0] = (row < d.NQ && mk < N) ? face_ops[off + row * N + mk] : 0.0;
+        opA[s_][1] = (row < d.NQ && mk + 4 < N) ? face_ops[off + row * N + mk + 4] : 0.0;
+        cur_off[s_][0] = d.offC; cur_off[s_][1] = d.offCD; cur_NQ[s_] = d.NQ;
+      }
+    }
+    if (el.offD != cur_offD || N != cur_N) {
+#pragma unroll
+      for (int i = 0; i < kFW; ++i) {
+        drow[0][i] = face_ops[el.offD + i];                 // zero-padded 8 x 8 image: row 0 and row N-1
+        drow[1][i] = face_ops[el.offD + (N - 1) * 8 + i];
+      }
+      cur_offD = el.offD;
+    }
+    cur_N = N;
+    __syncthreads();
+    if (diag == 1) {  // DIAGNOSTIC (timing only): memory skeleton of the kernel, no arithmetic
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const SideDesc& d = s_ ? d1 : d0;
+        if (lo < d.NQ && hi < d.NQ) {
+          double* out = qtrace + d.qoff + lo + d.NQ * hi;
+          const int T = d.NQ * d.NQ;
+          const double v = s_u[lane];
+          out[0] = v; out[T] = v; out[2 * T] = v; out[3 * T] = v;
+        }
+      }
+      __syncthreads();
+      el = el_next; d0 = d0_next; d1 = d1_next;
+      continue;
+    }
+    // ---- nodal traces and normal derivatives of both faces at lane (a = lo, b = hi): one pass over the line of u
+    {
+      const int sn = (dir == 0) ? 1 : (dir == 1 ? UJ : UK);
+      const int sa = (dir == 0) ? UJ : 1, sb = (dir == 2) ? UJ : UK;
+      double tr0 = 0.0, nd0 = 0.0, tr1 = 0.0, nd1 = 0.0;
+      if (lo < N && hi < N) {
+        const int base = lo * sa + hi * sb;
+#pragma unroll
+        for (int i = 0; i < kFW; ++i) {
+          const double ui = s_u[base + (i < N ? i : N - 1) * sn];   // padded D columns are 0
+          if (i == 0) tr0 = ui;
+          if (i == N - 1) tr1 = ui;
+          nd0 = fma(drow[0][i], ui, nd0);
+          nd1 = fma(drow[1][i], ui, nd1);
+        }
+      }
+      s_x[dir][0][lo * LDM + hi] = tr0;        // row k = a, column j = b
+      s_x[dir][0][lo * LDM + 8 + hi] = nd0;    // column j = 8 + b
+      s_x[dir][1][lo * LDM + hi] = tr1;
+      s_x[dir][1][lo * LDM + 8 + hi] = nd1;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const SideDesc& d = s_ ? d1 : d0;
+      const int NQ = d.NQ, T = NQ * NQ;
+      const double* sx = s_x[dir][s_];
+      // ---- pass 1, transposed:  Y^T (16 x 16) = [tr | nd]^T (16 x 8) . [C^T | CD^T] (8 x 16)
+      //      rows (field, b), columns (operator, a'); the operator B operand holds the same values as the A operand [C; CD]
+      mfma_d4 y = {0.0, 0.0, 0.0, 0.0};
+      {
+        const double a0 = sx[mk * LDM + mi], a1 = sx[(mk + 4) * LDM + mi];   // A[i = (field, b)][k = a]
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, opA[s_][0], y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, opA[s_][1], y, 0, 0, 0);
+      }
+      // ---- pass 2:  Z = [C; CD] (16 x 8, along b) . Y^T rows.  The C/D registers of pass 1 ARE the B operands of pass 2:
+      //      reg r holds row (lane >> 4) + 4 r = (field r >> 1, b = (lane >> 4) + 4 (r & 1)), i.e. k-step r & 1 of field r >> 1
+      mfma_d4 z1 = {0.0, 0.0, 0.0, 0.0}, z2 = {0.0, 0.0, 0.0, 0.0};
+      z1 = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s_][0], y[0], z1, 0, 0, 0);
+      z1 = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s_][1], y[1], z1, 0, 0, 0);
+      z2 = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s_][0], y[2], z2, 0, 0, 0);
+      z2 = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[s_][1], y[3], z2, 0, 0, 0);
+      // ---- store: column lane & 15 = (operator along a, a'), reg r: row (lane >> 4) + 4 r = (operator along b, b')
+      //      z1 rows C:  cols C -> qu, cols CD -> qta;  z1 rows CD: cols C -> qtb;  z2 rows C, cols C -> qn
+      double* out = qtrace + d.qoff;
+      const int aq = mi & 7;
+      if (aq < NQ) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int bq = mk + 4 * r;
+          if (bq < NQ) {
+            out[((mi < 8) ? 0 : (1 + t0) * T) + aq + NQ * bq] = z1[r];
+            if (mi < 8) {
+              out[(1 + t1d) * T + aq + NQ * bq] = z1[2 + r];
+              out[(1 + dir) * T + aq + NQ * bq] = z2[r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    el = el_next; d0 = d0_next; d1 = d1_next;
+  }
+}
+
 __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
                                                         double* __restrict__ Au, const SideDesc* __restrict__ sd,
                                                         const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
@@ -1396,8 +1575,12 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     debug_occupancy_once();
-    hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
-                       (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, fh.uni);
+    if (plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1)   // auto: MFMA form of the two interpolation passes
+      hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
+                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, std::getenv("D4EST_HIP_TRACE_DIAG") ? std::atoi(std::getenv("D4EST_HIP_TRACE_DIAG")) : 0);
+    else
+      hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
+                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, fh.uni);
   } else {
     const size_t lds = generic_lds_bytes(plan);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
