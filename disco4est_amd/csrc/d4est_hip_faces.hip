@@ -865,7 +865,9 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
   __shared__ double s_W[512];         // lifted face-local part: terms 1+3 and the tangential D^T of term 2
   __shared__ double s_N[6][64];       // per side: term 2 of the normal direction (D^T spreads it along the normal lines)
   __shared__ double s_D[64];          // zero-padded 8 x 8
-  const int f = threadIdx.x >> 6, lane = threadIdx.x & 63, lo = lane & 7, hi = lane >> 3;
+  // the face index is wave-uniform: in an SGPR it turns the descriptor loads into scalar loads (no VGPRs for descriptors)
+  const int f = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, lo = lane & 7, hi = lane >> 3;
   // persistent workgroups: the descriptors of the NEXT element are requested while this one is computed
   int e = blockIdx.x;
   ElemDesc edn = ed[e < n_elem ? e : 0];
@@ -1571,11 +1573,13 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
                        (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, n, fh.hp_fld_stride);
   } else if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-    const int resident = face_wg_per_cu() * cus;
+    const bool mfma = plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1;
+    // resident workgroups per CU: 8 of the 3-wave MFMA kernel (47 VGPRs, 11.5 KB LDS), 4 of the 6-wave kernel
+    const int resident = (std::getenv("D4EST_HIP_FACE_WG_PER_CU") ? face_wg_per_cu() : (mfma ? 8 : 4)) * cus;
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     debug_occupancy_once();
-    if (plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1)   // auto: MFMA form of the two interpolation passes
+    if (mfma)   // auto: MFMA form of the two interpolation passes
       hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
                          (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, std::getenv("D4EST_HIP_TRACE_DIAG") ? std::atoi(std::getenv("D4EST_HIP_TRACE_DIAG")) : 0);
     else
