@@ -853,6 +853,131 @@ __global__ __launch_bounds__(192) void trace_mfma_kernel(const double* __restric
   }
 }
 
+// The same kernel for 8 < N or NQ <= 16 (p = 8 .. 15): every 16 x 16 operand block is one MFMA tile, the contraction length
+// N <= 16 is 4 k-steps.  Per face: pass 1 = 3 tiles (tr.C^T, tr.CD^T, nd.C^T) x 4 k-steps, pass 2 = 4 tiles (qu, qta, qtb, qn) x
+// 4 k-steps = 28 MFMAs, all useful at N = 16.  Replaces the generic trace kernel, whose per-node LDS dot products made the
+// face path five times more expensive than the volume kernel at p >= 9.
+__global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
+                                                           const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
+                                                           const double* __restrict__ face_ops, int n_elem) {
+  constexpr int LDM = 34;                  // staging rows: 32 columns (field, b) + padding
+  constexpr int UJ = 17, UK = 272;         // padded strides of the LDS copy of u (<= 2-way bank conflicts in all directions)
+  constexpr int TPB = 192;
+  extern __shared__ __attribute__((aligned(16))) double smem16[];
+  double* s_u = smem16;                    // 16 * UK
+  const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* stage = smem16 + 16 * UK + dir * (2 * 16 * LDM);   // per wave: 2 faces x [a (16)][(field, b) 32]
+  const int lane = threadIdx.x & 63;
+  const int mi = lane & 15, mk = lane >> 4;
+  const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;
+  int cur_off[2][2] = {{-1, -1}, {-1, -1}}, cur_offD = -1, cur_N = -1, cur_NQ[2] = {-1, -1};
+  double op[2][2][4];   // [face][C / CD][k-step]: OP[row mi][col 4 ks + mk], zero-padded
+  double drow[2][16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) drow[0][i] = drow[1][i] = 0.0;
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+      for (int c_ = 0; c_ < 4; ++c_) op[a_][b_][c_] = 0.0;
+  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+    const ElemDesc el = ed[e];
+    const SideDesc d0 = sd[6 * e + 2 * dir], d1 = sd[6 * e + 2 * dir + 1];
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
+    for (int t = threadIdx.x; t < N3; t += TPB) s_u[(t % N) + UJ * ((t / N) % N) + UK * (t / N2)] = u[el.ns + t];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const SideDesc& d = s_ ? d1 : d0;
+      if (d.offC != cur_off[s_][0] || d.offCD != cur_off[s_][1] || N != cur_N || d.NQ != cur_NQ[s_]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int col = 4 * ks + mk;
+          const bool in = mi < d.NQ && col < N;
+          op[s_][0][ks] = in ? face_ops[d.offC + mi * N + col] : 0.0;
+          op[s_][1][ks] = in ? face_ops[d.offCD + mi * N + col] : 0.0;
+        }
+        cur_off[s_][0] = d.offC; cur_off[s_][1] = d.offCD; cur_NQ[s_] = d.NQ;
+      }
+    }
+    if (el.offD != cur_offD || N != cur_N) {   // unpadded N x N derivative matrix: rows 0 and N-1
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        drow[0][i] = (i < N) ? face_ops[el.offD + i] : 0.0;
+        drow[1][i] = (i < N) ? face_ops[el.offD + (N - 1) * N + i] : 0.0;
+      }
+      cur_offD = el.offD;
+    }
+    cur_N = N;
+    __syncthreads();
+    // ---- nodal traces / normal derivatives of both faces: 256 face nodes in 4 chunks of 64 lanes
+    {
+      const int sn = (dir == 0) ? 1 : (dir == 1 ? UJ : UK);
+      const int sa = (dir == 0) ? UJ : 1, sb = (dir == 2) ? UJ : UK;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int idx = 64 * c + lane, a = idx & 15, b = idx >> 4;
+        double tr0 = 0.0, nd0 = 0.0, tr1 = 0.0, nd1 = 0.0;
+        if (a < N && b < N) {
+          const int base = a * sa + b * sb;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const double ui = s_u[base + (i < N ? i : N - 1) * sn];   // drow is zero beyond N
+            if (i == 0) tr0 = ui;
+            if (i == N - 1) tr1 = ui;
+            nd0 = fma(drow[0][i], ui, nd0);
+            nd1 = fma(drow[1][i], ui, nd1);
+          }
+        }
+        stage[a * LDM + b] = tr0;
+        stage[a * LDM + 16 + b] = nd0;
+        stage[16 * LDM + a * LDM + b] = tr1;
+        stage[16 * LDM + a * LDM + 16 + b] = nd1;
+      }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const SideDesc& d = s_ ? d1 : d0;
+      const int NQ = d.NQ, T = NQ * NQ;
+      const double* st = stage + s_ * 16 * LDM;
+      // pass 1 (transposed): rows (field, b), K = a, columns (operator, a')
+      mfma_d4 ytc = {0.0, 0.0, 0.0, 0.0}, ytd = {0.0, 0.0, 0.0, 0.0}, ync = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double atr = st[(4 * ks + mk) * LDM + mi], and_ = st[(4 * ks + mk) * LDM + 16 + mi];
+        ytc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr, op[s_][0][ks], ytc, 0, 0, 0);
+        ytd = __builtin_amdgcn_mfma_f64_16x16x4f64(atr, op[s_][1][ks], ytd, 0, 0, 0);
+        ync = __builtin_amdgcn_mfma_f64_16x16x4f64(and_, op[s_][0][ks], ync, 0, 0, 0);
+      }
+      // pass 2: reg r of a pass-1 tile = rows 4 r .. 4 r + 3 (the b index) = B operand of k-step r
+      mfma_d4 qu = {0.0, 0.0, 0.0, 0.0}, qta = {0.0, 0.0, 0.0, 0.0}, qtb = {0.0, 0.0, 0.0, 0.0}, qn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        qu = __builtin_amdgcn_mfma_f64_16x16x4f64(op[s_][0][r], ytc[r], qu, 0, 0, 0);
+        qta = __builtin_amdgcn_mfma_f64_16x16x4f64(op[s_][0][r], ytd[r], qta, 0, 0, 0);
+        qtb = __builtin_amdgcn_mfma_f64_16x16x4f64(op[s_][1][r], ytc[r], qtb, 0, 0, 0);
+        qn = __builtin_amdgcn_mfma_f64_16x16x4f64(op[s_][0][r], ync[r], qn, 0, 0, 0);
+      }
+      // store: column mi = a', reg r: row mk + 4 r = b'
+      double* out = qtrace + d.qoff;
+      if (mi < NQ) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int bq = mk + 4 * r;
+          if (bq < NQ) {
+            out[mi + NQ * bq] = qu[r];
+            out[(1 + t0) * T + mi + NQ * bq] = qta[r];
+            out[(1 + t1d) * T + mi + NQ * bq] = qtb[r];
+            out[(1 + dir) * T + mi + NQ * bq] = qn[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
                                                         double* __restrict__ Au, const SideDesc* __restrict__ sd,
                                                         const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
@@ -972,6 +1097,154 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
 }
 
 // ---------------------------------------------------------------------------
+// Tiled MFMA flux kernel for N, NQ <= 16 (the p = 8 .. 15 counterpart of flux_wave_kernel).  One workgroup = 3 waves = the three
+// reference directions of one element; wave `dir` serves faces 2 dir and 2 dir + 1.  Per face:
+//   terms   lane (mi, mk) evaluates the 4 SIPG term fields at its 4 mortar nodes (a' = mi, b' = 4 ks + mk) -- exactly the values
+//           it needs as the A operand of the first contraction, so the term fields never touch LDS
+//   pass 1  Y_c = A_c . E^T   (contract b', 4 k-steps, tile: column = side index b, rows = a')
+//   pass 2  R_c = E . Y_c     (contract a'; the tile registers of pass 1 are the B operands)            32 MFMAs for 4 fields
+//   D^T     val = R_0 + D^T . R_t0  (tile registers again)  +  R_t1 . D  (one tile transposed through LDS)    8 MFMAs
+// then the face-local part `val` and the normal term-2 field (whose D^T spreads along the whole normal line) of the six faces
+// are combined into Au_e by all threads from LDS tiles.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
+                                                          double* __restrict__ Au, const SideDesc* __restrict__ sd,
+                                                          const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
+                                                          const double* __restrict__ geom, const double* __restrict__ bndry_q,
+                                                          const double* __restrict__ robin_c, const double* __restrict__ robin_r,
+                                                          int n_elem) {
+  constexpr int LT = 17;                    // padded row length of a 16 x 16 tile in LDS
+  constexpr int TPB = 192;
+  __shared__ double s_tile[6][2][16 * LT];  // per face: val, normal field   (rows a, columns b)
+  __shared__ double s_tr[3][16 * LT];       // per wave: transposition buffer
+  __shared__ double s_Dfix[6][16];          // per face: row `fix` of D (the normal D^T)
+  const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int mi = lane & 15, mk = lane >> 4;
+  const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;   // reference directions of the face indices a and b
+  int cur_offE[2] = {-1, -1}, cur_offD = -1, cur_N = -1, cur_NQ[2] = {-1, -1};
+  double opE[2][4], opD[4];   // E[mi][4 ks + mk] (N x NQ) per face;  D[4 ks + mk][mi]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) opE[0][i] = opE[1][i] = opD[i] = 0.0;
+  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+    const ElemDesc el = ed[e];
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
+    if (el.offD != cur_offD || N != cur_N) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) opD[ks] = (4 * ks + mk < N && mi < N) ? face_ops[el.offD + (4 * ks + mk) * N + mi] : 0.0;
+      cur_offD = el.offD;
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int f = 2 * dir + s_;
+      const SideDesc d = sd[6 * e + f];
+      const int NQ = d.NQ, T = NQ * NQ;
+      if (d.offE != cur_offE[s_] || N != cur_N || NQ != cur_NQ[s_]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) opE[s_][ks] = (mi < N && 4 * ks + mk < NQ) ? face_ops[d.offE + mi * NQ + 4 * ks + mk] : 0.0;
+        cur_offE[s_] = d.offE; cur_NQ[s_] = NQ;
+      }
+      if (lane < 16) s_Dfix[f][lane] = (lane < N) ? face_ops[el.offD + face_fix(f, N) * N + lane] : 0.0;
+      // ---- SIPG terms at this lane's 4 mortar nodes (a' = mi, b' = 4 ks + mk): the A operands of pass 1
+      double A[4][4];
+      const bool robin = (d.kind == 0) && robin_c;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int bq = 4 * ks + mk;
+        A[0][ks] = A[1][ks] = A[2][ks] = A[3][ks] = 0.0;
+        if (mi < NQ && bq < NQ) {
+          const int k = mi + NQ * bq;
+          const double* m = qtrace + d.qoff + k;
+          const double um = m[0];
+          if (robin) {
+            A[0][ks] = robin_c[d.geom + k] * um - robin_r[d.geom + k];
+          } else {
+            const double* g = geom + (size_t)7 * d.geom + k;
+            double up, t1 = 0.0, am[3];
+            if (d.kind != 0) {
+              const double* pp = ((d.kind == 2) ? ghost_qtrace : qtrace) + d.nbr_qoff + reorder_index(d.code, NQ - 1, mi, bq);
+              up = pp[0];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                am[i] = g[i * T];
+                t1 += am[i] * m[(1 + i) * T] + g[(3 + i) * T] * pp[(1 + i) * T];
+              }
+            } else {
+              up = bndry_q[d.geom + k];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                am[i] = g[i * T];
+                t1 += am[i] * m[(1 + i) * T];
+              }
+            }
+            const double jump = um - up;
+            const double w1 = (d.kind != 0) ? -0.5 : -1.0;
+            A[0][ks] = w1 * t1 + g[6 * T] * jump;
+            A[1][ks] = w1 * am[t0] * jump;    // field order: tangential a, tangential b, normal
+            A[2][ks] = w1 * am[t1d] * jump;
+            A[3][ks] = w1 * am[dir] * jump;
+          }
+        }
+      }
+      // ---- pass 1 / pass 2 per field
+      mfma_d4 R[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        mfma_d4 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) y = __builtin_amdgcn_mfma_f64_16x16x4f64(A[c][ks], opE[s_][ks], y, 0, 0, 0);
+        mfma_d4 rr = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rr = __builtin_amdgcn_mfma_f64_16x16x4f64(opE[s_][r], y[r], rr, 0, 0, 0);
+        R[c] = rr;   // tile: column mi = b, reg r: row mk + 4 r = a
+      }
+      // ---- val = R_0 + D_a^T R_ta + R_tb D
+      mfma_d4 val = R[0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) val = __builtin_amdgcn_mfma_f64_16x16x4f64(opD[r], R[1][r], val, 0, 0, 0);   // A = D^T: D[4 r + mk][mi]
+      {
+        double* tb = s_tr[dir];
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[(mk + 4 * r) * LT + mi] = R[2][r];
+        wave_lds_fence();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const double a_ = tb[mi * LT + 4 * ks + mk];            // A[i = a][k = q]
+          val = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, opD[ks], val, 0, 0, 0);   // B = D[k = q][j = b]
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s_tile[f][0][(mk + 4 * r) * LT + mi] = val[r];
+        s_tile[f][1][(mk + 4 * r) * LT + mi] = R[3][r];
+      }
+    }
+    cur_N = N;
+    __syncthreads();
+    // ---- Au_e += lift(val_f) + D[fix_f][.] (x) Nrm_f over the six faces
+    for (int idx = threadIdx.x; idx < N3; idx += TPB) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / N2;
+      double v = 0.0;
+      v = fma(s_Dfix[0][i], s_tile[0][1][j * LT + k], v);
+      v = fma(s_Dfix[1][i], s_tile[1][1][j * LT + k], v);
+      v = fma(s_Dfix[2][j], s_tile[2][1][i * LT + k], v);
+      v = fma(s_Dfix[3][j], s_tile[3][1][i * LT + k], v);
+      v = fma(s_Dfix[4][k], s_tile[4][1][i * LT + j], v);
+      v = fma(s_Dfix[5][k], s_tile[5][1][i * LT + j], v);
+      if (i == 0) v += s_tile[0][0][j * LT + k];
+      if (i == N - 1) v += s_tile[1][0][j * LT + k];
+      if (j == 0) v += s_tile[2][0][i * LT + k];
+      if (j == N - 1) v += s_tile[3][0][i * LT + k];
+      if (k == 0) v += s_tile[4][0][i * LT + j];
+      if (k == N - 1) v += s_tile[5][0][i * LT + j];
+      Au[el.ns + idx] += v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 namespace {
@@ -998,7 +1271,7 @@ struct FaceHost {
   GhostSideDesc* d_ghost_sides = nullptr;
   int n_ghost_sides = 0;
   int fld_stride = 0;   // generic kernels: doubles per field buffer
-  int max_N = 1;
+  int max_N = 1, max_NQ = 1;
   ElemDesc* d_elem_desc_generic = nullptr;  // offD -> unpadded N x N matrices
 };
 std::map<d4est_hip_plan*, FaceHost> g_face_host;
@@ -1367,6 +1640,7 @@ void faces_setup(d4est_hip_plan* plan) {
   max_fld = std::max(max_fld, maxN * maxN);
   fh.fld_stride = max_fld;
   fh.max_N = maxN;
+  fh.max_NQ = maxNQ;
   fh.n_ghost_sides = (int)gsides.size();
   plan->face_fast = fast;
   plan->max_face_lds_doubles = 12 * max_fld + maxN * maxN * maxN + maxN * maxN;
@@ -1585,6 +1859,12 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     else
       hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
                          (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, fh.uni);
+  } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+    // p = 8 .. 15: tiled MFMA trace kernel (descriptors with unpadded N x N derivative matrices)
+    const size_t lds = (size_t)(16 * 272 + 3 * 2 * 16 * 34) * sizeof(double);
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(n, 4 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), lds, plan->stream, u, trace,
+                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n);
   } else {
     const size_t lds = generic_lds_bytes(plan);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1615,6 +1895,10 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     const int grid = (n + rounds - 1) / rounds;
     hipLaunchKernelGGL(flux_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
                        (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops,
+                       plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n);
+  } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+    hipLaunchKernelGGL(flux_mfma16_kernel, dim3(std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), 0, plan->stream, trace,
+                       ghost_trace, Au, (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
                        plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n);
   } else {
     const size_t lds = generic_lds_bytes(plan);
