@@ -881,6 +881,10 @@ __global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restr
     for (int b_ = 0; b_ < 2; ++b_)
 #pragma unroll
       for (int c_ = 0; c_ < 4; ++c_) op[a_][b_][c_] = 0.0;
+  // the staging rows / columns beyond N are never written again: zero them once (they meet zero operator entries, but LDS
+  // garbage could be NaN)
+  for (int i = lane; i < 2 * 16 * LDM; i += 64) stage[i] = 0.0;
+  wave_lds_fence();
   for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
     const ElemDesc el = ed[e];
     const SideDesc d0 = sd[6 * e + 2 * dir], d1 = sd[6 * e + 2 * dir + 1];
@@ -916,23 +920,25 @@ __global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restr
       const int sa = (dir == 0) ? UJ : 1, sb = (dir == 2) ? UJ : UK;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+        if (4 * c >= N) continue;   // wave-uniform: this chunk holds only padding
         const int idx = 64 * c + lane, a = idx & 15, b = idx >> 4;
-        double tr0 = 0.0, nd0 = 0.0, tr1 = 0.0, nd1 = 0.0;
         if (a < N && b < N) {
+          double tr0 = 0.0, nd0 = 0.0, tr1 = 0.0, nd1 = 0.0;
           const int base = a * sa + b * sb;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const double ui = s_u[base + (i < N ? i : N - 1) * sn];   // drow is zero beyond N
+            if (i >= N) continue;   // wave-uniform
+            const double ui = s_u[base + i * sn];
             if (i == 0) tr0 = ui;
             if (i == N - 1) tr1 = ui;
             nd0 = fma(drow[0][i], ui, nd0);
             nd1 = fma(drow[1][i], ui, nd1);
           }
+          stage[a * LDM + b] = tr0;
+          stage[a * LDM + 16 + b] = nd0;
+          stage[16 * LDM + a * LDM + b] = tr1;
+          stage[16 * LDM + a * LDM + 16 + b] = nd1;
         }
-        stage[a * LDM + b] = tr0;
-        stage[a * LDM + 16 + b] = nd0;
-        stage[16 * LDM + a * LDM + b] = tr1;
-        stage[16 * LDM + a * LDM + 16 + b] = nd1;
       }
     }
     wave_lds_fence();
@@ -943,8 +949,10 @@ __global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restr
       const double* st = stage + s_ * 16 * LDM;
       // pass 1 (transposed): rows (field, b), K = a, columns (operator, a')
       mfma_d4 ytc = {0.0, 0.0, 0.0, 0.0}, ytd = {0.0, 0.0, 0.0, 0.0}, ync = {0.0, 0.0, 0.0, 0.0};
+      const int KN = (N + 3) >> 2;   // k-steps that hold data (wave-uniform): the others multiply zero padding
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
+        if (ks >= KN) continue;
         const double atr = st[(4 * ks + mk) * LDM + mi], and_ = st[(4 * ks + mk) * LDM + 16 + mi];
         ytc = __builtin_amdgcn_mfma_f64_16x16x4f64(atr, op[s_][0][ks], ytc, 0, 0, 0);
         ytd = __builtin_amdgcn_mfma_f64_16x16x4f64(atr, op[s_][1][ks], ytd, 0, 0, 0);
@@ -954,6 +962,7 @@ __global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restr
       mfma_d4 qu = {0.0, 0.0, 0.0, 0.0}, qta = {0.0, 0.0, 0.0, 0.0}, qtb = {0.0, 0.0, 0.0, 0.0}, qn = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if (r >= KN) continue;
         qu = __builtin_amdgcn_mfma_f64_16x16x4f64(op[s_][0][r], ytc[r], qu, 0, 0, 0);
         qta = __builtin_amdgcn_mfma_f64_16x16x4f64(op[s_][0][r], ytd[r], qta, 0, 0, 0);
         qtb = __builtin_amdgcn_mfma_f64_16x16x4f64(op[s_][1][r], ytc[r], qtb, 0, 0, 0);
@@ -1188,20 +1197,24 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
       }
       // ---- pass 1 / pass 2 per field
       mfma_d4 R[4];
+      const int KQ = (NQ + 3) >> 2, KN = (N + 3) >> 2;   // k-steps that hold data (wave-uniform)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         mfma_d4 y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) y = __builtin_amdgcn_mfma_f64_16x16x4f64(A[c][ks], opE[s_][ks], y, 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks)
+          if (ks < KQ) y = __builtin_amdgcn_mfma_f64_16x16x4f64(A[c][ks], opE[s_][ks], y, 0, 0, 0);
         mfma_d4 rr = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rr = __builtin_amdgcn_mfma_f64_16x16x4f64(opE[s_][r], y[r], rr, 0, 0, 0);
+        for (int r = 0; r < 4; ++r)
+          if (r < KQ) rr = __builtin_amdgcn_mfma_f64_16x16x4f64(opE[s_][r], y[r], rr, 0, 0, 0);
         R[c] = rr;   // tile: column mi = b, reg r: row mk + 4 r = a
       }
       // ---- val = R_0 + D_a^T R_ta + R_tb D
       mfma_d4 val = R[0];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) val = __builtin_amdgcn_mfma_f64_16x16x4f64(opD[r], R[1][r], val, 0, 0, 0);   // A = D^T: D[4 r + mk][mi]
+      for (int r = 0; r < 4; ++r)
+        if (r < KN) val = __builtin_amdgcn_mfma_f64_16x16x4f64(opD[r], R[1][r], val, 0, 0, 0);   // A = D^T: D[4 r + mk][mi]
       {
         double* tb = s_tr[dir];
         wave_lds_fence();
@@ -1210,6 +1223,7 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
         wave_lds_fence();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+          if (ks >= KN) continue;
           const double a_ = tb[mi * LT + 4 * ks + mk];            // A[i = a][k = q]
           val = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, opD[ks], val, 0, 0, 0);   // B = D[k = q][j = b]
         }
