@@ -351,6 +351,7 @@ struct HpMortar {
   int code;          // reorder code applied when reading the (+) block
   int N, NQ;         // side nodes / mortar quadrature nodes per direction
   int offCa, offCb;  // (NQ x N) side -> mortar quadrature nodes along the face axes a, b (hp_ops)
+  int offCDa, offCDb; // C . D: tangential derivative fused with the interpolation (MFMA kernels)
   int offEa, offEb;  // (N x NQ) mortar quadrature nodes -> side
   int first, last;   // first / last record of its side
   int gidx;          // scalar index of the mortar's first node in the precombined geometry / boundary arrays (S + off)
@@ -1259,6 +1260,270 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
 }
 
 // ---------------------------------------------------------------------------
+// Mortar-record (hanging-face) counterparts of the tiled MFMA kernels, N, NQ <= 16: separate 1-D operators along the two
+// face axes (the hp-prolongation child of a big side differs per axis), 1 or 4 records per side; the nodal trace of a big
+// side is formed once and interpolated onto its four sub-mortars, and the four sub-mortar contributions of a big side are
+// summed in the MFMA accumulators before the lift.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void trace_hp_mfma16_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
+                                                              const HpMortar* __restrict__ md, const int* __restrict__ side_first,
+                                                              const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
+                                                              const double* __restrict__ hp_ops, int n_elem) {
+  constexpr int LDM = 34;
+  constexpr int UJ = 17, UK = 272;
+  constexpr int TPB = 192;
+  extern __shared__ __attribute__((aligned(16))) double smem16[];
+  double* s_u = smem16;
+  const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* stage = smem16 + 16 * UK + dir * (2 * 16 * LDM);
+  const int lane = threadIdx.x & 63;
+  const int mi = lane & 15, mk = lane >> 4;
+  const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;
+  int cur_offD = -1, cur_N = -1;
+  double drow[2][16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) drow[0][i] = drow[1][i] = 0.0;
+  for (int i = lane; i < 2 * 16 * LDM; i += 64) stage[i] = 0.0;
+  wave_lds_fence();
+  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+    const ElemDesc el = ed[e];
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
+    for (int t = threadIdx.x; t < N3; t += TPB) s_u[(t % N) + UJ * ((t / N) % N) + UK * (t / N2)] = u[el.ns + t];
+    if (el.offD != cur_offD || N != cur_N) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        drow[0][i] = (i < N) ? face_ops[el.offD + i] : 0.0;
+        drow[1][i] = (i < N) ? face_ops[el.offD + (N - 1) * N + i] : 0.0;
+      }
+      cur_offD = el.offD;
+      cur_N = N;
+    }
+    __syncthreads();
+    {
+      const int sn = (dir == 0) ? 1 : (dir == 1 ? UJ : UK);
+      const int sa = (dir == 0) ? UJ : 1, sb = (dir == 2) ? UJ : UK;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (4 * c >= N) continue;
+        const int idx = 64 * c + lane, a = idx & 15, b = idx >> 4;
+        if (a < N && b < N) {
+          double tr0 = 0.0, nd0 = 0.0, tr1 = 0.0, nd1 = 0.0;
+          const int base = a * sa + b * sb;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (i >= N) continue;
+            const double ui = s_u[base + i * sn];
+            if (i == 0) tr0 = ui;
+            if (i == N - 1) tr1 = ui;
+            nd0 = fma(drow[0][i], ui, nd0);
+            nd1 = fma(drow[1][i], ui, nd1);
+          }
+          stage[a * LDM + b] = tr0;
+          stage[a * LDM + 16 + b] = nd0;
+          stage[16 * LDM + a * LDM + b] = tr1;
+          stage[16 * LDM + a * LDM + 16 + b] = nd1;
+        }
+      }
+    }
+    wave_lds_fence();
+    const int KN = (N + 3) >> 2;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int sidx = 6 * e + 2 * dir + s_;
+      const double* st = stage + s_ * 16 * LDM;
+      double aval[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        aval[0][ks] = st[(4 * ks + mk) * LDM + mi];
+        aval[1][ks] = st[(4 * ks + mk) * LDM + 16 + mi];
+      }
+      for (int r_ = side_first[sidx]; r_ < side_first[sidx + 1]; ++r_) {
+        const HpMortar m = md[r_];
+        const int NQ = m.NQ, T = NQ * NQ;
+        double oa[2][4], ob[2][4];   // along a: C, CD ; along b: C, CD   -- OP[row mi][col 4 ks + mk]
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int col = 4 * ks + mk;
+          const bool in = mi < NQ && col < N;
+          oa[0][ks] = in ? hp_ops[m.offCa + mi * N + col] : 0.0;
+          oa[1][ks] = in ? hp_ops[m.offCDa + mi * N + col] : 0.0;
+          ob[0][ks] = in ? hp_ops[m.offCb + mi * N + col] : 0.0;
+          ob[1][ks] = in ? hp_ops[m.offCDb + mi * N + col] : 0.0;
+        }
+        mfma_d4 ytc = {0.0, 0.0, 0.0, 0.0}, ytd = {0.0, 0.0, 0.0, 0.0}, ync = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks >= KN) continue;
+          ytc = __builtin_amdgcn_mfma_f64_16x16x4f64(aval[0][ks], oa[0][ks], ytc, 0, 0, 0);
+          ytd = __builtin_amdgcn_mfma_f64_16x16x4f64(aval[0][ks], oa[1][ks], ytd, 0, 0, 0);
+          ync = __builtin_amdgcn_mfma_f64_16x16x4f64(aval[1][ks], oa[0][ks], ync, 0, 0, 0);
+        }
+        mfma_d4 qu = {0.0, 0.0, 0.0, 0.0}, qta = {0.0, 0.0, 0.0, 0.0}, qtb = {0.0, 0.0, 0.0, 0.0}, qn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r >= KN) continue;
+          qu = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[0][r], ytc[r], qu, 0, 0, 0);
+          qta = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[0][r], ytd[r], qta, 0, 0, 0);
+          qtb = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[1][r], ytc[r], qtb, 0, 0, 0);
+          qn = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[0][r], ync[r], qn, 0, 0, 0);
+        }
+        double* out = qtrace + m.qoff;
+        if (mi < NQ) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int bq = mk + 4 * r;
+            if (bq < NQ) {
+              out[mi + NQ * bq] = qu[r];
+              out[(1 + t0) * T + mi + NQ * bq] = qta[r];
+              out[(1 + t1d) * T + mi + NQ * bq] = qtb[r];
+              out[(1 + dir) * T + mi + NQ * bq] = qn[r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __restrict__ qtrace, double* __restrict__ Au,
+                                                             const HpMortar* __restrict__ md, const int* __restrict__ side_first,
+                                                             const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
+                                                             const double* __restrict__ hp_ops, const double* __restrict__ geom,
+                                                             const double* __restrict__ bndry_q, const double* __restrict__ robin_c,
+                                                             const double* __restrict__ robin_r, int n_elem) {
+  constexpr int LT = 17;
+  constexpr int TPB = 192;
+  __shared__ double s_tile[6][2][16 * LT];
+  __shared__ double s_tr[3][16 * LT];
+  __shared__ double s_Dfix[6][16];
+  const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int mi = lane & 15, mk = lane >> 4;
+  const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;
+  int cur_offD = -1, cur_N = -1;
+  double opD[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+    const ElemDesc el = ed[e];
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
+    if (el.offD != cur_offD || N != cur_N) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) opD[ks] = (4 * ks + mk < N && mi < N) ? face_ops[el.offD + (4 * ks + mk) * N + mi] : 0.0;
+      cur_offD = el.offD;
+      cur_N = N;
+    }
+    const int KN = (N + 3) >> 2;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int f = 2 * dir + s_, sidx = 6 * e + f;
+      if (lane < 16) s_Dfix[f][lane] = (lane < N) ? face_ops[el.offD + face_fix(f, N) * N + lane] : 0.0;
+      mfma_d4 R[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) R[c] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+      for (int r_ = side_first[sidx]; r_ < side_first[sidx + 1]; ++r_) {
+        const HpMortar m = md[r_];
+        const int NQ = m.NQ, T = NQ * NQ, KQ = (NQ + 3) >> 2;
+        double oea[4], oeb[4];   // E along a / b: E[mi][4 ks + mk]  (N x NQ)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bool in = mi < N && 4 * ks + mk < NQ;
+          oea[ks] = in ? hp_ops[m.offEa + mi * NQ + 4 * ks + mk] : 0.0;
+          oeb[ks] = in ? hp_ops[m.offEb + mi * NQ + 4 * ks + mk] : 0.0;
+        }
+        double A[4][4];
+        const bool robin = (m.kind == 0) && robin_c;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int bq = 4 * ks + mk;
+          A[0][ks] = A[1][ks] = A[2][ks] = A[3][ks] = 0.0;
+          if (mi < NQ && bq < NQ) {
+            const int k = mi + NQ * bq;
+            const double* qm = qtrace + m.qoff + k;
+            const double um = qm[0];
+            if (robin) {
+              A[0][ks] = robin_c[m.gidx + k] * um - robin_r[m.gidx + k];
+            } else {
+              const double* g = geom + (size_t)7 * m.gidx + k;
+              double up, tm = 0.0, tp = 0.0, am[3];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                am[i] = g[i * T];
+                tm += am[i] * qm[(1 + i) * T];
+              }
+              if (m.kind != 0) {
+                const double* pp = qtrace + m.nbr_qoff + reorder_index(m.code, NQ - 1, mi, bq);
+                up = pp[0];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) tp += g[(3 + i) * T] * pp[(1 + i) * T];
+              } else {
+                up = bndry_q[m.gidx + k];
+              }
+              const double jump = um - up;
+              const double w1 = (m.kind != 0) ? -0.5 : -1.0;
+              A[0][ks] = w1 * (m.fm * tm + m.fp * tp) + g[6 * T] * jump;
+              A[1][ks] = w1 * m.w2 * am[t0] * jump;
+              A[2][ks] = w1 * m.w2 * am[t1d] * jump;
+              A[3][ks] = w1 * m.w2 * am[dir] * jump;
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          mfma_d4 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            if (ks < KQ) y = __builtin_amdgcn_mfma_f64_16x16x4f64(A[c][ks], oeb[ks], y, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < KQ) R[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(oea[r], y[r], R[c], 0, 0, 0);   // summed over the side's mortars
+        }
+      }
+      mfma_d4 val = R[0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < KN) val = __builtin_amdgcn_mfma_f64_16x16x4f64(opD[r], R[1][r], val, 0, 0, 0);
+      {
+        double* tb = s_tr[dir];
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[(mk + 4 * r) * LT + mi] = R[2][r];
+        wave_lds_fence();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks >= KN) continue;
+          const double a_ = tb[mi * LT + 4 * ks + mk];
+          val = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, opD[ks], val, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s_tile[f][0][(mk + 4 * r) * LT + mi] = val[r];
+        s_tile[f][1][(mk + 4 * r) * LT + mi] = R[3][r];
+      }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < N3; idx += TPB) {
+      const int i = idx % N, j = (idx / N) % N, k = idx / N2;
+      double v = 0.0;
+      v = fma(s_Dfix[0][i], s_tile[0][1][j * LT + k], v);
+      v = fma(s_Dfix[1][i], s_tile[1][1][j * LT + k], v);
+      v = fma(s_Dfix[2][j], s_tile[2][1][i * LT + k], v);
+      v = fma(s_Dfix[3][j], s_tile[3][1][i * LT + k], v);
+      v = fma(s_Dfix[4][k], s_tile[4][1][i * LT + j], v);
+      v = fma(s_Dfix[5][k], s_tile[5][1][i * LT + j], v);
+      if (i == 0) v += s_tile[0][0][j * LT + k];
+      if (i == N - 1) v += s_tile[1][0][j * LT + k];
+      if (j == 0) v += s_tile[2][0][i * LT + k];
+      if (j == N - 1) v += s_tile[3][0][i * LT + k];
+      if (k == 0) v += s_tile[4][0][i * LT + j];
+      if (k == N - 1) v += s_tile[5][0][i * LT + j];
+      Au[el.ns + idx] += v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 namespace {
@@ -1271,6 +1536,8 @@ struct FaceHost {
   HpMortar* d_rec = nullptr;
   HpGeomSrc* d_gsrc = nullptr;
   int* d_elem_first = nullptr;
+  int* d_side_first = nullptr;   // first record of side s (6 n_elements + 1 entries)
+  int hp_max_N = 1, hp_max_NQ = 1;
   double* d_hp_ops = nullptr;
   int hp_fld_stride = 0;
   size_t hp_lds_doubles = 0;
@@ -1333,6 +1600,18 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
     std::vector<double> C = Tables1D::matmul(I, P, nh, nh, nH);
     const int off = (int)ops.size();
     ops.insert(ops.end(), C.begin(), C.end());
+    op_index[key] = off;
+    return off;
+  };
+  auto get_CD = [&](int deg_side, int deg_mq, int child) {
+    auto key = std::make_tuple(2, deg_side, deg_mq, child, 0);
+    auto it = op_index.find(key);
+    if (it != op_index.end()) return it->second;
+    const int offC = get_C(deg_side, deg_mq, child);
+    std::vector<double> C(ops.begin() + offC, ops.begin() + offC + (size_t)(deg_mq + 1) * (deg_side + 1));
+    std::vector<double> CD = Tables1D::matmul(C, Tables1D::dij(deg_side), deg_mq + 1, deg_side + 1, deg_side + 1);
+    const int off = (int)ops.size();
+    ops.insert(ops.end(), CD.begin(), CD.end());
     op_index[key] = off;
     return off;
   };
@@ -1428,6 +1707,8 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
         const int ca = (hang == 1) ? (i & 1) : -1, cb = (hang == 1) ? (i >> 1) : -1;
         m.offCa = get_C(deg_m, deg_mq, ca);
         m.offCb = get_C(deg_m, deg_mq, cb);
+        m.offCDa = get_CD(deg_m, deg_mq, ca);
+        m.offCDb = get_CD(deg_m, deg_mq, cb);
         m.offEa = get_E(deg_m, deg_ml, deg_mq, ca);
         m.offEb = get_E(deg_m, deg_ml, deg_mq, cb);
         g.S = plan->side_mortar_stride[s];
@@ -1481,6 +1762,14 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
   fh.d_rec = upload_vec(rec);
   fh.d_gsrc = upload_vec(gsrc);
   fh.d_elem_first = upload_vec(elem_first);
+  {
+    std::vector<int> sf(side_first.begin(), side_first.end());
+    sf.push_back((int)rec.size());
+    fh.d_side_first = upload_vec(sf);
+  }
+  fh.hp_max_N = maxN;
+  fh.hp_max_NQ = 1;
+  for (const HpMortar& m_ : rec) fh.hp_max_NQ = std::max(fh.hp_max_NQ, m_.NQ);
   fh.d_hp_ops = upload_vec(ops);
   plan->face_fast = false;
 }
@@ -1854,7 +2143,12 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
   }
   const int n = plan->n_elements;
   if (n == 0) return;
-  if (fh.hp) {
+  if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+    const size_t lds = (size_t)(16 * 272 + 3 * 2 * 16 * 34) * sizeof(double);
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(trace_hp_mfma16_kernel, dim3(std::min(n, 4 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), lds, plan->stream, u, trace,
+                       fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, n);
+  } else if (fh.hp) {
     const size_t lds = fh.hp_lds_doubles * sizeof(double);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(trace_hp_kernel, dim3(std::min(n, 16384)), dim3(256), lds, plan->stream, u, trace, fh.d_rec, fh.d_elem_first,
@@ -1895,7 +2189,11 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   if (plan->n_elements == 0) return;
   if (fh.n_ghost_sides > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost sides but no ghost trace buffer was given", fh.n_ghost_sides);
   const int n = plan->n_elements;
-  if (fh.hp) {
+  if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+    hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), 0, plan->stream, trace, Au,
+                       fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
+                       plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n);
+  } else if (fh.hp) {
     const size_t lds = fh.hp_lds_doubles * sizeof(double);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_hp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(flux_hp_kernel, dim3(std::min(n, 16384)), dim3(256), lds, plan->stream, trace, Au, fh.d_rec, fh.d_elem_first,
@@ -1932,7 +2230,7 @@ void faces_destroy(d4est_hip_plan* plan) {
     (void)hipFree(fh.d_side_deg_m); (void)hipFree(fh.d_side_deg_p); (void)hipFree(fh.d_side_bndry_stride);
     (void)hipFree(fh.d_ghost_sides); (void)hipFree(fh.d_elem_desc_generic);
     (void)hipFree(fh.d_sj); (void)hipFree(fh.d_robin_c); (void)hipFree(fh.d_robin_r);
-    (void)hipFree(fh.d_rec); (void)hipFree(fh.d_gsrc); (void)hipFree(fh.d_elem_first); (void)hipFree(fh.d_hp_ops);
+    (void)hipFree(fh.d_rec); (void)hipFree(fh.d_gsrc); (void)hipFree(fh.d_elem_first); (void)hipFree(fh.d_side_first); (void)hipFree(fh.d_hp_ops);
     g_face_host.erase(it);
   }
   (void)hipFree(plan->d_elem_desc);
