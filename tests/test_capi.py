@@ -68,3 +68,15 @@ def test_mesh_layout():
     u1 = M.splitmix64_uniform(102321, 10)
     u2 = M.splitmix64_uniform(102321, 10)
     assert (u1 == u2).all() and (0 <= u1).all() and (u1 < 1).all() and len(set(u1)) == 10
+
+
+def test_error_convention_aborts_like_d4est():
+    """Invalid input aborts the process with a message (D4EST_ABORT = SC_ABORT semantics, src/Utilities/d4est_util.h:171): a NULL plan
+    is caught before any HIP call, so this runs without a GPU."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from disco4est_amd import capi; lib = capi.load_library(); "
+            "lib.d4est_hip_apply_stiffness_matrix(None, None, None)") % str(ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "[D4EST_HIP_ABORT]" in r.stderr and "apply_stiffness_matrix" in r.stderr

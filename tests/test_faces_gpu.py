@@ -135,12 +135,14 @@ def test_apply_aij_hanging_parity(gpu, hiplib, oracle, level, pattern, deg, inc,
     plan.destroy()
 
 
-def test_apply_aij_mixed_p(gpu, hiplib, oracle):
-    """p-nonconforming mortars (different degree on the two sides of a face), config-4 style."""
+@pytest.mark.parametrize("base,span,inc,level", [(2, 5, 0, 2), (6, 4, 0, 1), (5, 8, 1, 1), (12, 5, 0, 1)])
+def test_apply_aij_mixed_p(gpu, hiplib, oracle, base, span, inc, level):
+    """p-nonconforming mortars (different degree on the two sides of a face), config-4 style: degrees within the wave-per-face
+    kernels (p <= 7), straddling them (tiled MFMA kernels with per-side N, NQ) and reaching past p = 15 (generic kernels)."""
     import torch
     from disco4est_amd import mesh as M
-    deg = 2 + (np.arange(64) * 5) % 5
-    m = M.BrickMesh(2, deg, deg_quad_inc=0)
+    deg = base + (np.arange(8 ** level) * 5) % span
+    m = M.BrickMesh(level, deg, deg_quad_inc=inc)
     mp = M.SineMap(0.04)
     J, rst = m.geometry(mp); sides = m.build_sides(mp); u = m.field(mp)
     ref = oracle.apply_aij(m, J, rst, sides, u, nthreads=8)
