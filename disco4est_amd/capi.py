@@ -73,6 +73,11 @@ SIGNATURES = {
     "d4est_hip_cg_eigs": (ctypes.c_double, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _c_double_p]),
     "d4est_hip_copy_blocks": (None, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "d4est_hip_plan_trace_offset": (ctypes.c_longlong, [_vp, ctypes.c_int]),
+    "d4est_hip_plan_side_blocks": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "d4est_hip_reorient_face_order": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "d4est_hip_plan_trace_offset_sub": (ctypes.c_longlong, [_vp, ctypes.c_int, ctypes.c_int]),
+    "d4est_hip_plan_ghost_trace_offset_sub": (ctypes.c_longlong, [_vp, ctypes.c_int, ctypes.c_int]),
+    "d4est_hip_plan_trace_block_len_sub": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "d4est_hip_plan_ghost_trace_offset": (ctypes.c_longlong, [_vp, ctypes.c_int]),
     "d4est_hip_plan_trace_block_len": (ctypes.c_int, [_vp, ctypes.c_int]),
     "d4est_hip_vec_dot": (None, [_vp, ctypes.c_int, _vp, _vp, _vp]),

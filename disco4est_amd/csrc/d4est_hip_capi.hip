@@ -458,6 +458,43 @@ int d4est_hip_plan_trace_block_len(const d4est_hip_plan_t* plan, int side) {
   return (int)(next - plan->trace_offset[side]);
 }
 
+int d4est_hip_reorient_face_order(int f_m, int f_p, int orientation, int i) {
+  if (f_m < 0 || f_m > 5 || f_p < 0 || f_p > 5 || orientation < 0 || orientation > 3 || i < 0 || i > 3) D4EST_HIP_ABORT("reorient_face_order: bad argument");
+  return d4est_hip::reorient_face_order(f_m, f_p, orientation, i);
+}
+
+int d4est_hip_plan_side_blocks(const d4est_hip_plan_t* plan, int side) {
+  check_plan(plan, "plan_side_blocks");
+  if (!plan->has_faces || side < 0 || side >= 6 * plan->n_elements) D4EST_HIP_ABORT("plan_side_blocks: side %d", side);
+  if (plan->side_first_rec.empty()) return 1;
+  return plan->side_first_rec[side + 1] - plan->side_first_rec[side];
+}
+
+static int sub_record(const d4est_hip_plan_t* plan, int side, int sub, const char* who) {
+  if (!plan->has_faces || side < 0 || side >= 6 * plan->n_elements) D4EST_HIP_ABORT("%s: side %d", who, side);
+  const int nb = plan->side_first_rec.empty() ? 1 : plan->side_first_rec[side + 1] - plan->side_first_rec[side];
+  if (sub < 0 || sub >= nb) D4EST_HIP_ABORT("%s: side %d has %d block(s), asked for %d", who, side, nb, sub);
+  return plan->side_first_rec.empty() ? -1 : plan->side_first_rec[side] + sub;
+}
+
+long long d4est_hip_plan_trace_offset_sub(const d4est_hip_plan_t* plan, int side, int sub) {
+  check_plan(plan, "plan_trace_offset_sub");
+  const int r = sub_record(plan, side, sub, "plan_trace_offset_sub");
+  return r < 0 ? plan->trace_offset[side] : plan->rec_qoff[r];
+}
+
+long long d4est_hip_plan_ghost_trace_offset_sub(const d4est_hip_plan_t* plan, int side, int sub) {
+  check_plan(plan, "plan_ghost_trace_offset_sub");
+  const int r = sub_record(plan, side, sub, "plan_ghost_trace_offset_sub");
+  return r < 0 ? plan->ghost_trace_offset[side] : plan->rec_goff[r];
+}
+
+int d4est_hip_plan_trace_block_len_sub(const d4est_hip_plan_t* plan, int side, int sub) {
+  check_plan(plan, "plan_trace_block_len_sub");
+  const int r = sub_record(plan, side, sub, "plan_trace_block_len_sub");
+  return r < 0 ? d4est_hip_plan_trace_block_len(plan, side) : plan->rec_len[r];
+}
+
 void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const double* y_dev, double* result_dev) {
   check_plan(plan, "vec_dot");
   d4est_hip::launch_dot(plan, n, x_dev, y_dev, result_dev);

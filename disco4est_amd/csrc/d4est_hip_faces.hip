@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void flux_generic_kernel(const double* __restr
 // ---------------------------------------------------------------------------
 struct HpMortar {
   int elem, face;
-  int kind;          // 0 boundary, 1 interface
+  int kind;          // 0 boundary, 1 interface with a local (+) element, 2 with a ghost (+) element
   int code;          // reorder code applied when reading the (+) block
   int N, NQ;         // side nodes / mortar quadrature nodes per direction
   int offCa, offCb;  // (NQ x N) side -> mortar quadrature nodes along the face axes a, b (hp_ops)
@@ -452,7 +452,8 @@ __global__ __launch_bounds__(64) void face_geom_hp_kernel(const HpMortar* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void flux_hp_kernel(const double* __restrict__ qtrace, double* __restrict__ Au,
+__global__ __launch_bounds__(256) void flux_hp_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
+                                                      double* __restrict__ Au,
                                                       const HpMortar* __restrict__ md, const int* __restrict__ elem_first,
                                                       const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                       const double* __restrict__ hp_ops, const double* __restrict__ geom,
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void flux_hp_kernel(const double* __restrict__
       const int NQ = m.NQ, T = NQ * NQ, f = m.face;
       const double* g = geom + (size_t)7 * m.gidx;
       const double* qm = qtrace + m.qoff;
-      const double* qp = qtrace + m.nbr_qoff;
+      const double* qp = ((m.kind == 2) ? ghost_qtrace : qtrace) + m.nbr_qoff;
       for (int k = threadIdx.x; k < T; k += blockDim.x) {
         if (m.kind == 0 && robin_c) {
           A[k] = robin_c[m.gidx + k] * qm[k] - robin_r[m.gidx + k];
@@ -1386,7 +1387,8 @@ __global__ __launch_bounds__(192) void trace_hp_mfma16_kernel(const double* __re
   }
 }
 
-__global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __restrict__ qtrace, double* __restrict__ Au,
+__global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
+                                                             double* __restrict__ Au,
                                                              const HpMortar* __restrict__ md, const int* __restrict__ side_first,
                                                              const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                              const double* __restrict__ hp_ops, const double* __restrict__ geom,
@@ -1451,7 +1453,7 @@ __global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __res
                 tm += am[i] * qm[(1 + i) * T];
               }
               if (m.kind != 0) {
-                const double* pp = qtrace + m.nbr_qoff + reorder_index(m.code, NQ - 1, mi, bq);
+                const double* pp = ((m.kind == 2) ? ghost_qtrace : qtrace) + m.nbr_qoff + reorder_index(m.code, NQ - 1, mi, bq);
                 up = pp[0];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) tp += g[(3 + i) * T] * pp[(1 + i) * T];
@@ -1581,7 +1583,6 @@ int reorient_face_order(int f_m, int f_p, int o, int i) {
 static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
   const int ne = plan->n_elements;
   const int qt = plan->quad_type;
-  if (plan->n_ghost > 0) D4EST_HIP_ABORT("plan_set_faces: hanging faces across ranks (ghost elements) are not supported yet");
   std::vector<double> ops;
   std::map<std::tuple<int, int, int, int, int>, int> op_index;
   // C: side (deg_side) -> mortar quadrature nodes (deg_mq); child = -1: p-prolong, 0/1: hp-prolong onto that half
@@ -1640,7 +1641,11 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
     return off;
   };
   const size_t ns = 6 * (size_t)ne;
-  auto degq_mortar = [&](int em, int ep) { return std::max(plan->deg_quad[em], plan->deg_quad[ep]); };
+  // element references: >= 0 local, <= -2 ghost g = -(ref + 2)
+  auto valid_ref = [&](int ref) { return (ref >= 0 && ref < ne) || (ref <= -2 && -(ref + 2) < plan->n_ghost); };
+  auto deg_of = [&](int ref) { return ref >= 0 ? plan->deg[ref] : plan->ghost_deg[-(ref + 2)]; };
+  auto degq_of = [&](int ref) { return ref >= 0 ? plan->deg_quad[ref] : plan->ghost_deg_quad[-(ref + 2)]; };
+  auto degq_mortar = [&](int em, int ep) { return std::max(degq_of(em), degq_of(ep)); };
   auto nodes2 = [](int deg) { return (deg + 1) * (deg + 1); };
   std::vector<HpMortar> rec;
   std::vector<HpGeomSrc> gsrc;
@@ -1662,8 +1667,8 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
       const int* n4 = &plan->side_nbr4[4 * s];
       if (hang != 0)
         for (int i = 0; i < 4; ++i)
-          if (n4[i] < 0 || n4[i] >= ne) D4EST_HIP_ABORT("plan_set_hanging: side %zu: side_nbr4[%d] = %d is not a local element", s, i, n4[i]);
-      if (hang == 2 && (nbr < 0 || nbr >= ne)) D4EST_HIP_ABORT("plan_set_hanging: small side %zu needs a local (+) element", s);
+          if (!valid_ref(n4[i])) D4EST_HIP_ABORT("plan_set_hanging: side %zu: side_nbr4[%d] = %d is neither a local nor a ghost element", s, i, n4[i]);
+      if (hang == 2 && !valid_ref(nbr)) D4EST_HIP_ABORT("plan_set_hanging: small side %zu: (+) element %d is neither local nor ghost", s, nbr);
       // mortar sizes of the whole hanging face, in (-) order and in (+) order
       int T_m[4] = {0, 0, 0, 0}, T_p[4] = {0, 0, 0, 0};
       if (hang != 0) {
@@ -1684,7 +1689,7 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
         m.fm = m.fp = m.w2 = 1.0;
         int ep = -1, sub_m = 0;   // (+) element of this mortar; index of the mortar in the face's (-) order
         if (hang == 0) {
-          if (nbr <= -2) D4EST_HIP_ABORT("plan_set_faces: ghost sides are not supported together with hanging faces");
+          if (nbr != -1 && !valid_ref(nbr)) D4EST_HIP_ABORT("plan_set_faces: side %zu neighbour %d out of range", s, nbr);
           m.kind = (nbr == -1) ? 0 : 1;
           ep = nbr;
         } else if (hang == 1) {
@@ -1700,7 +1705,8 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
           if (sub_m < 0 || sub_m > 3 || n4[sub_m] != e) D4EST_HIP_ABORT("plan_set_hanging: small side %zu: side_sub %d does not point at the element in side_nbr4", s, sub_m);
           m.fp = 0.5;
         }
-        const int deg_p = (m.kind == 0) ? deg_m : plan->deg[ep];
+        if (m.kind != 0 && ep <= -2) m.kind = 2;
+        const int deg_p = (m.kind == 0) ? deg_m : deg_of(ep);
         const int deg_mq = (m.kind == 0) ? degq_m : degq_mortar(e, ep);
         const int deg_ml = std::max(deg_m, deg_p);
         m.NQ = deg_mq + 1;
@@ -1734,9 +1740,23 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
     }
   }
   elem_first[ne] = (int)rec.size();
-  // (+) blocks
+  // (+) blocks: local ones by record lookup; ghost ones get consecutive slots of the ghost trace buffer in record order
+  long long goff = 0;
+  plan->rec_qoff.assign(rec.size(), 0);
+  plan->rec_goff.assign(rec.size(), -1);
+  plan->rec_len.assign(rec.size(), 0);
+  plan->side_first_rec.assign(side_first.begin(), side_first.end());
+  plan->side_first_rec.push_back((int)rec.size());
   for (size_t r = 0; r < rec.size(); ++r) {
     HpMortar& m = rec[r];
+    plan->rec_qoff[r] = m.qoff;
+    plan->rec_len[r] = 4 * m.NQ * m.NQ;
+    if (m.kind == 2) {
+      m.nbr_qoff = goff;
+      plan->rec_goff[r] = goff;
+      goff += 4LL * m.NQ * m.NQ;
+      continue;
+    }
     if (m.kind == 0) continue;
     const size_t s = 6 * (size_t)m.elem + m.face;
     const int hang = plan->side_hang[s], f_p = plan->side_nbr_face[s], o = plan->side_orientation[s];
@@ -1753,6 +1773,8 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
     m.nbr_qoff = mp.qoff;
   }
   plan->local_trace_doubles = qoff;
+  plan->ghost_trace_doubles = goff;
+  for (size_t s_ = 0; s_ < ns; ++s_) plan->ghost_trace_offset[s_] = plan->rec_goff[side_first[s_]];
   max_fld = std::max(max_fld, maxN * maxN);
   fh.hp = true;
   fh.n_rec = (int)rec.size();
@@ -1918,7 +1940,7 @@ void faces_setup(d4est_hip_plan* plan) {
         const size_t sp = 6 * (size_t)nbr + plan->side_nbr_face[s];
         if (deg_mq_of[sp] != deg_mq) D4EST_HIP_ABORT("plan_set_faces: sides %zu and %zu disagree on the mortar degree (non-conforming mortar?)", s, sp);
         d.nbr_qoff = plan->trace_offset[sp];
-      } else if (d.kind == 2) {
+      } else if (d.kind == 2 && !hp) {
         const int g = -(nbr + 2);
         plan->ghost_trace_offset[s] = goff;
         d.nbr_qoff = goff;
@@ -1939,7 +1961,7 @@ void faces_setup(d4est_hip_plan* plan) {
       max_fld = std::max(max_fld, std::max(d.NQ * d.NQ, d.NQ * (deg_m + 1)));
       max_fld = std::max(max_fld, d.NQ * (deg_p + 1));
     }
-  plan->ghost_trace_doubles = goff;
+  plan->ghost_trace_doubles = goff;   // (hanging plans: overwritten by faces_setup_hp)
   max_fld = std::max(max_fld, maxN * maxN);
   fh.fld_stride = max_fld;
   fh.max_N = maxN;
@@ -2133,6 +2155,7 @@ static size_t generic_lds_bytes(const d4est_hip_plan* plan) { return (size_t)pla
 void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost) {
   FaceHost& fh = g_face_host[plan];
   if (ghost) {
+    if (fh.hp) D4EST_HIP_ABORT("compute_ghost_traces: plans with hanging faces take their ghost traces from the trace exchange (d4est_hip_plan_*_sub offsets), not from whole ghost elements");
     if (fh.n_ghost_sides == 0) return;
     const size_t lds = generic_lds_bytes(plan);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ghost_trace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2190,13 +2213,13 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   if (fh.n_ghost_sides > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost sides but no ghost trace buffer was given", fh.n_ghost_sides);
   const int n = plan->n_elements;
   if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
-    hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), 0, plan->stream, trace, Au,
+    hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
                        fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
                        plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n);
   } else if (fh.hp) {
     const size_t lds = fh.hp_lds_doubles * sizeof(double);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_hp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(flux_hp_kernel, dim3(std::min(n, 16384)), dim3(256), lds, plan->stream, trace, Au, fh.d_rec, fh.d_elem_first,
+    hipLaunchKernelGGL(flux_hp_kernel, dim3(std::min(n, 16384)), dim3(256), lds, plan->stream, trace, ghost_trace, Au, fh.d_rec, fh.d_elem_first,
                        (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom, plan->d_bndry,
                        fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, fh.hp_fld_stride);
   } else if (plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {

@@ -94,6 +94,9 @@ struct d4est_hip_plan {
   long long local_trace_doubles = 0, ghost_trace_doubles = 0;
   int* d_side_desc = nullptr;        // SideDesc per side (see d4est_hip_faces.hip)
   void* d_elem_desc = nullptr;       // ElemDesc per element
+  // per mortar record (hanging plans; empty on conforming plans where a side has exactly one block)
+  std::vector<long long> rec_qoff, rec_goff;
+  std::vector<int> rec_len, side_first_rec;
   std::vector<long long> trace_offset, ghost_trace_offset;  // per SIDE: offset of its 4 T mortar-node trace block (ghost: -1 if none)
   double* d_face_ops = nullptr;      // concatenated 1-D face operators (C and E matrices)
   double* d_face_geom = nullptr;     // 7 * total_mortar_nodes: am[3], ap[3], s3 per mortar quadrature node (side-blocked)
@@ -134,6 +137,7 @@ void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, 
 void faces_setup(d4est_hip_plan* plan);
 void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n, const double* drst_m, const double* drst_p,
                         const double* hm, const double* hp, int on_device);
+int reorient_face_order(int f_m, int f_p, int o, int i);  // dGMath/d4est_reference.c:84-110
 void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_device);
 void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const double* rhs_quad, int on_device);
 void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost);

@@ -283,9 +283,10 @@ class HangingBrickMesh(BrickMesh):
     8**level base cells in Morton order) are replaced, in place, by their 8 children (z-order).  Neighbouring levels
     differ by at most one, so the mesh is 2:1 balanced and has hanging (1 <-> 4) faces wherever a refined cell touches an
     unrefined one -- the non-conforming mortars of src/Mesh/d4est_mortars.c:601-803.
-    ``deg`` is an int or an array over the final elements.  One rank only (no ghost layer)."""
+    ``deg`` is an int or an array over the GLOBAL elements; ``first``/``count`` select a contiguous range of the global
+    (Morton) element list = the shard of one rank; off-rank face neighbours become ghost elements."""
 
-    def __init__(self, level, refine, deg, deg_quad_inc=0, quad_type=0):
+    def __init__(self, level, refine, deg, deg_quad_inc=0, quad_type=0, first=0, count=None):
         self.level = level
         self.quad_type = quad_type
         base = morton_order(level)
@@ -301,29 +302,34 @@ class HangingBrickMesh(BrickMesh):
             else:
                 org.append(o)
                 size.append(2)
-        self.org = np.asarray(org, dtype=np.int64)
-        self.size = np.asarray(size, dtype=np.int64)
-        total = self.org.shape[0]
+        self._org_all = np.asarray(org, dtype=np.int64)
+        self._size_all = np.asarray(size, dtype=np.int64)
+        total = self._org_all.shape[0]
         deg_all = np.full(total, deg, dtype=np.int32) if np.isscalar(deg) else np.asarray(deg, dtype=np.int32)
         assert deg_all.size == total
+        count = total - first if count is None else count
         self.global_elements = total
-        self.first = 0
-        self.n_elements = total
-        self.deg = deg_all.copy()
+        self.first = first
+        self.n_elements = count
+        self.org = self._org_all[first:first + count]
+        self.size = self._size_all[first:first + count]
+        self.deg = deg_all[first:first + count].copy()
         self.deg_quad = (self.deg + deg_quad_inc).astype(np.int32)
         self.hf = 1.0 / (1 << (level + 1))      # fine grid spacing
         self.h_elem = self.size * self.hf
+        self._h_all = self._size_all * self.hf
         n3 = (self.deg.astype(np.int64) + 1) ** 3
         q3 = (self.deg_quad.astype(np.int64) + 1) ** 3
-        self.nodal_stride = np.concatenate([[0], np.cumsum(n3)[:-1]]).astype(np.int32)
-        self.quad_stride = np.concatenate([[0], np.cumsum(q3)[:-1]]).astype(np.int32)
+        self.nodal_stride = np.concatenate([[0], np.cumsum(n3)[:-1]]).astype(np.int32) if count else np.zeros(0, np.int32)
+        self.quad_stride = np.concatenate([[0], np.cumsum(q3)[:-1]]).astype(np.int32) if count else np.zeros(0, np.int32)
         self.local_nodes = int(n3.sum())
         self.local_nodes_quad = int(q3.sum())
         self.deg_global = deg_all
-        self.deg_quad_global = self.deg_quad
-        self.global_nodal_stride = self.nodal_stride.astype(np.int64)
-        self.global_nodes = self.local_nodes
-        self.global_nodal_offset = 0
+        self.deg_quad_global = (deg_all + deg_quad_inc).astype(np.int32)
+        g3 = (deg_all.astype(np.int64) + 1) ** 3
+        self.global_nodal_stride = np.concatenate([[0], np.cumsum(g3)[:-1]])
+        self.global_nodes = int(g3.sum())
+        self.global_nodal_offset = int(self.global_nodal_stride[first]) if count > 0 else 0
 
     def _ref_coords(self, e, nodes_1d):
         n = nodes_1d.size
@@ -382,21 +388,24 @@ class HangingBrickMesh(BrickMesh):
           side_sub[s]         small side: index c of this element among the 4 (z-order of the face children)
           side_nbr4[4s..4s+3] big side: the 4 (+) elements in (-) order; small side: the 4 members of its own group
           side_orientation[s] p4est orientation (0 inside one tree)
+        Element references (side_nbr, side_nbr4) are local ids, or -(g+2) for ghost element g (off-rank, ordered by global id).
         Mortar data in the reference's layout (src/Mesh/d4est_mesh.c:868-1110): a big side owns one block of its 4
-        sub-mortars; the 4 small sides of a hanging face SHARE one block (same side_mortar_stride) holding the 4
+        sub-mortars; the LOCAL small sides of a hanging face share one block (same side_mortar_stride) holding the 4
         sub-mortars one after another; vector/matrix components are strided by the block's total node count."""
         ne = self.n_elements
         nf = 1 << (self.level + 1)
         owner = -np.ones((nf, nf, nf), dtype=np.int64)
-        for e in range(ne):
-            o, sz = self.org[e], self.size[e]
-            owner[o[0]:o[0] + sz, o[1]:o[1] + sz, o[2]:o[2] + sz] = e
-        side_nbr = np.full(6 * ne, -1, dtype=np.int32)
+        for g in range(self.global_elements):
+            o, sz = self._org_all[g], self._size_all[g]
+            owner[o[0]:o[0] + sz, o[1]:o[1] + sz, o[2]:o[2] + sz] = g
+        first = self.first
+        is_local = lambda g: first <= g < first + ne
+        # pass 1: global neighbour ids per side
+        nbr_g = np.full(6 * ne, -1, dtype=np.int64)
+        nbr4_g = np.full(4 * 6 * ne, -1, dtype=np.int64)
         side_nbr_face = np.zeros(6 * ne, dtype=np.int32)
-        side_reorder = np.zeros(6 * ne, dtype=np.int32)
         side_hang = np.zeros(6 * ne, dtype=np.int32)
         side_sub = np.zeros(6 * ne, dtype=np.int32)
-        side_nbr4 = np.full(4 * 6 * ne, -1, dtype=np.int32)
         for e in range(ne):
             o, sz = self.org[e], int(self.size[e])
             for f in range(6):
@@ -409,42 +418,57 @@ class HangingBrickMesh(BrickMesh):
                 if c0[d] < 0 or c0[d] >= nf:
                     continue
                 g = int(owner[c0[0], c0[1], c0[2]])
-                gs = int(self.size[g])
+                gs = int(self._size_all[g])
                 if gs == sz:
-                    side_nbr[s_] = g
-                    side_nbr4[4 * s_] = g
+                    nbr_g[s_] = g
+                    nbr4_g[4 * s_] = g
                 elif gs < sz:  # this element is the big one
                     side_hang[s_] = 1
                     for i in range(4):
                         ci = c0.copy()
                         ci[ax[0]] += i & 1
                         ci[ax[1]] += i >> 1
-                        side_nbr4[4 * s_ + i] = int(owner[ci[0], ci[1], ci[2]])
-                    side_nbr[s_] = side_nbr4[4 * s_]
+                        nbr4_g[4 * s_ + i] = int(owner[ci[0], ci[1], ci[2]])
+                    nbr_g[s_] = nbr4_g[4 * s_]
                 else:          # this element is one of the four small ones
                     side_hang[s_] = 2
-                    side_nbr[s_] = g
-                    go = self.org[g]
+                    nbr_g[s_] = g
+                    go = self._org_all[g]
                     ia, ib = int(o[ax[0]] - go[ax[0]]), int(o[ax[1]] - go[ax[1]])
                     side_sub[s_] = ia + 2 * ib
                     for i in range(4):   # own group: the children of the big neighbour's face, z-order
                         ci = o.copy()
                         ci[ax[0]] = go[ax[0]] + (i & 1)
                         ci[ax[1]] = go[ax[1]] + (i >> 1)
-                        side_nbr4[4 * s_ + i] = int(owner[ci[0], ci[1], ci[2]])
-        # ---- mortar blocks
-        degq = self.deg_quad
+                        nbr4_g[4 * s_ + i] = int(owner[ci[0], ci[1], ci[2]])
+        # ghosts: every off-rank element referenced
+        refd = np.concatenate([nbr_g, nbr4_g])
+        refd = refd[refd >= 0]
+        ghost_ids = np.unique(refd[(refd < first) | (refd >= first + ne)])
+        ghost_pos = {int(g): i for i, g in enumerate(ghost_ids)}
+        enc = lambda g: -1 if g < 0 else (int(g) - first if is_local(g) else -(ghost_pos[int(g)] + 2))
+        side_nbr = np.array([enc(g) for g in nbr_g], dtype=np.int32)
+        side_nbr4 = np.array([enc(g) if g >= 0 else -1 for g in nbr4_g], dtype=np.int32)
+        side_reorder = np.zeros(6 * ne, dtype=np.int32)
+        ghost_deg = self.deg_global[ghost_ids].astype(np.int32)
+        ghost_deg_quad = self.deg_quad_global[ghost_ids].astype(np.int32)
+        gn3 = (ghost_deg.astype(np.int64) + 1) ** 3
+        ghost_nodal_stride = np.concatenate([[0], np.cumsum(gn3)[:-1]]).astype(np.int32) if len(ghost_ids) else np.zeros(0, np.int32)
+        degq_g = self.deg_quad_global
+        # ---- mortar blocks (local (-) sides only)
         side_mortar_stride = np.zeros(6 * ne, dtype=np.int32)
-        blocks = []   # (stride S, [(x0, hm, f, pq_m, x0p, f_p)] per sub-mortar, owner side)
+        blocks = []   # (stride S, [(x0, hm, f, pq)] per sub-mortar)
         total = 0
+        done_group = {}
         for s_ in range(6 * ne):
             e, f = divmod(s_, 6)
+            ge = first + e
             hang = side_hang[s_]
             if hang == 0:
-                g = side_nbr[s_]
-                pq = int(degq[e]) if g < 0 else int(max(degq[e], degq[g]))
+                g = int(nbr_g[s_])
+                pq = int(degq_g[ge]) if g < 0 else int(max(degq_g[ge], degq_g[g]))
                 side_mortar_stride[s_] = total
-                blocks.append((total, [(self.org[e] * self.hf, self.h_elem[e], f, pq)], s_))
+                blocks.append((total, [(self.org[e] * self.hf, self.h_elem[e], f, pq)]))
                 total += (pq + 1) ** 2
             elif hang == 1:
                 d = f // 2
@@ -453,35 +477,37 @@ class HangingBrickMesh(BrickMesh):
                 side_mortar_stride[s_] = total
                 S0 = total
                 for i in range(4):
-                    g = side_nbr4[4 * s_ + i]
-                    pq = int(max(degq[e], degq[g]))
+                    g = int(nbr4_g[4 * s_ + i])
+                    pq = int(max(degq_g[ge], degq_g[g]))
                     hm = 0.5 * self.h_elem[e]
-                    x0 = self.org[e] * self.hf
-                    x0 = x0.copy()
+                    x0 = (self.org[e] * self.hf).copy()
                     x0[ax[0]] += (i & 1) * hm
                     x0[ax[1]] += (i >> 1) * hm
                     if f % 2:
                         x0[d] += hm   # the virtual child touching the +face
                     subs.append((x0, hm, f, pq))
                     total += (pq + 1) ** 2
-                blocks.append((S0, subs, s_))
+                blocks.append((S0, subs))
             else:
-                if side_sub[s_] != 0:
-                    continue   # the block is created by the group's first member
-                grp = side_nbr4[4 * s_:4 * s_ + 4]
-                g = side_nbr[s_]
+                grp = tuple(int(x) for x in nbr4_g[4 * s_:4 * s_ + 4])
+                key = (grp, f)
+                if key in done_group:          # the block was created by the group's first LOCAL member (d4est_mesh.c:956-962)
+                    side_mortar_stride[s_] = done_group[key]
+                    continue
+                g = int(nbr_g[s_])
                 subs = []
                 S0 = total
                 for i in range(4):
-                    em = int(grp[i])
-                    pq = int(max(degq[em], degq[g]))
-                    subs.append((self.org[em] * self.hf, self.h_elem[em], f, pq))
-                    side_mortar_stride[6 * em + f] = S0
+                    em = grp[i]
+                    pq = int(max(degq_g[em], degq_g[g]))
+                    subs.append((self._org_all[em] * self.hf, self._h_all[em], f, pq))
                     total += (pq + 1) ** 2
-                blocks.append((S0, subs, s_))
+                done_group[key] = S0
+                side_mortar_stride[s_] = S0
+                blocks.append((S0, subs))
         sj = np.empty(total); hm_a = np.empty(total); hp_a = np.empty(total)
         nrm = np.zeros(3 * total); drst_m = np.zeros(9 * total); drst_p = np.zeros(9 * total)
-        for S0, subs, s_ in blocks:
+        for S0, subs in blocks:
             Ttot = sum((pq + 1) ** 2 for (_, _, _, pq) in subs)
             off = 0
             for (x0, hm, f, pq) in subs:
@@ -499,10 +525,10 @@ class HangingBrickMesh(BrickMesh):
                         drst_p[a0:a0 + Tn] = inv[:, i, j]   # (+) side, (+) order == (-) order inside one tree
                 off += Tn
         # boundary sides: Dirichlet values live on the Lobatto face nodes
-        bnd = side_nbr == -1
+        bnd = nbr_g == -1
         deg_m = np.repeat(self.deg, 6)
         nb = np.where(bnd, (deg_m.astype(np.int64) + 1) ** 2, 0)
-        side_bndry_stride = np.concatenate([[0], np.cumsum(nb)[:-1]]).astype(np.int32)
+        side_bndry_stride = np.concatenate([[0], np.cumsum(nb)[:-1]]).astype(np.int32) if ne else np.zeros(0, np.int32)
         total_bndry = int(nb.sum())
         bndry_xyz = np.zeros((3, total_bndry))
         for s_ in np.nonzero(bnd)[0]:
@@ -521,14 +547,14 @@ class HangingBrickMesh(BrickMesh):
                 XL = np.stack(mapping.x(XL[:, 0], XL[:, 1], XL[:, 2]), axis=1)
             B0 = int(side_bndry_stride[s_])
             bndry_xyz[:, B0:B0 + nbn] = XL.T
-        z = np.zeros(0, np.int32)
         return dict(side_nbr=side_nbr, side_nbr_face=side_nbr_face, side_reorder=side_reorder,
                     side_mortar_stride=side_mortar_stride, side_bndry_stride=side_bndry_stride,
                     total_mortar_nodes=total, total_bndry_nodes=total_bndry, bndry_xyz=bndry_xyz,
                     sj=sj, n=nrm, drst_m=drst_m, drst_p=drst_p, hm=hm_a, hp=hp_a,
                     side_hang=side_hang, side_sub=side_sub, side_nbr4=side_nbr4,
                     side_orientation=np.zeros(6 * ne, dtype=np.int32),
-                    ghost_global_ids=np.zeros(0, np.int64), ghost_deg=z, ghost_deg_quad=z, ghost_nodal_stride=z, ghost_nodes=0)
+                    ghost_global_ids=ghost_ids, ghost_deg=ghost_deg, ghost_deg_quad=ghost_deg_quad,
+                    ghost_nodal_stride=ghost_nodal_stride, ghost_nodes=int(gn3.sum()))
 
 
 class SineMap:

@@ -46,24 +46,38 @@ class TraceSchedule:
     Both ends sort by (global element id of the SENDER, its face): no metadata is exchanged.
     """
 
-    def __init__(self, mesh, sides, parts, trace_offset, ghost_trace_offset, block_len):
+    def __init__(self, mesh, sides, parts, trace_offset, ghost_trace_offset, block_len, side_blocks=None, reorient=None):
+        """trace_offset / ghost_trace_offset / block_len take (side, sub); side_blocks(side) = number of own blocks (4 on the
+        big side of a hanging face).  On meshes with hanging faces the counterpart of a big side's block i is small element
+        i's block; the counterpart of a small side's block is the big element's block reorient(f_m, f_p, orientation, c)."""
         owner = owner_of(parts, mesh.global_elements)
         send, recv = {}, {}
         nbr = sides["side_nbr"]
-        for s in np.nonzero(nbr <= -2)[0]:
-            s = int(s)
+        hang = sides.get("side_hang")
+        for s in range(6 * mesh.n_elements):
             e, f = divmod(s, 6)
-            g = -(int(nbr[s]) + 2)
-            gid = int(sides["ghost_global_ids"][g])
-            peer = int(owner[gid])
-            f_p = int(sides["side_nbr_face"][s])
-            my_gid = mesh.first + e
-            ln = int(block_len(s))
-            send.setdefault(peer, []).append((my_gid, f, int(trace_offset(s)), ln))
-            recv.setdefault(peer, []).append((gid, f_p, int(ghost_trace_offset(s)), ln))
+            nb = 1 if side_blocks is None else int(side_blocks(s))
+            h = 0 if hang is None else int(hang[s])
+            for sub in range(nb):
+                goff = int(ghost_trace_offset(s, sub))
+                if goff < 0:
+                    continue
+                ref = int(sides["side_nbr4"][4 * s + sub]) if h == 1 else int(nbr[s])
+                gid = int(sides["ghost_global_ids"][-(ref + 2)])
+                peer = int(owner[gid])
+                f_p = int(sides["side_nbr_face"][s])
+                sender_sub = 0
+                if h == 2:   # the (+) element is the big one: it sends the sub-block that faces me
+                    c = int(sides["side_sub"][s])
+                    o = int(sides["side_orientation"][s])
+                    sender_sub = c if reorient is None else int(reorient(f, f_p, o, c))
+                my_gid = mesh.first + e
+                ln = int(block_len(s, sub))
+                send.setdefault(peer, []).append((my_gid, f, sub, int(trace_offset(s, sub)), ln))
+                recv.setdefault(peer, []).append((gid, f_p, sender_sub, goff, ln))
         self.peers = sorted(set(send) | set(recv))
-        self.send = {p: np.array([(o, l) for _, _, o, l in sorted(send[p])], dtype=np.int64).reshape(-1, 2) for p in self.peers}
-        self.recv = {p: np.array([(o, l) for _, _, o, l in sorted(recv[p])], dtype=np.int64).reshape(-1, 2) for p in self.peers}
+        self.send = {p: np.array([(o, l) for _, _, _, o, l in sorted(send[p])], dtype=np.int64).reshape(-1, 2) for p in self.peers}
+        self.recv = {p: np.array([(o, l) for _, _, _, o, l in sorted(recv[p])], dtype=np.int64).reshape(-1, 2) for p in self.peers}
         self.send_len = {p: int(self.send[p][:, 1].sum()) for p in self.peers}
         self.recv_len = {p: int(self.recv[p][:, 1].sum()) for p in self.peers}
 
@@ -142,8 +156,10 @@ class DistTransport:
 def plan_schedule(plan, mesh, sides, parts):
     """TraceSchedule with the block offsets of a Plan whose faces are set"""
     lib, h = plan.lib, plan.handle
-    return TraceSchedule(mesh, sides, parts, lambda s: lib.d4est_hip_plan_trace_offset(h, s),
-                         lambda s: lib.d4est_hip_plan_ghost_trace_offset(h, s), lambda s: lib.d4est_hip_plan_trace_block_len(h, s))
+    return TraceSchedule(mesh, sides, parts, lambda s, b: lib.d4est_hip_plan_trace_offset_sub(h, s, b),
+                         lambda s, b: lib.d4est_hip_plan_ghost_trace_offset_sub(h, s, b),
+                         lambda s, b: lib.d4est_hip_plan_trace_block_len_sub(h, s, b),
+                         side_blocks=lambda s: lib.d4est_hip_plan_side_blocks(h, s), reorient=lib.d4est_hip_reorient_face_order)
 
 
 def side_block_layout(sides):

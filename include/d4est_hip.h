@@ -159,7 +159,9 @@ void d4est_hip_plan_set_faces(d4est_hip_plan_t* plan, const int* side_nbr, const
  * Mortar data layout as the reference allocates it (src/Mesh/d4est_mesh.c:956-979): the block of a hanging face holds its 4
  * sub-mortars one after another (scalars), vector / matrix components are strided by the block's TOTAL node count, the four small
  * sides share ONE block (the same side_mortar_stride), and drst_dxyz_p_porder is stored in the (+) side's sub-face order.
- * Local elements only (no ghost layer) in this version. */
+ * Element references (side_nbr, side_nbr4) are local ids or ghost codes -(g + 2), as in side_nbr.  Plans with hanging faces
+ * and ghost elements take the ghost traces from the trace exchange (the *_sub block accessors below); d4est_hip_compute_ghost_traces
+ * (whole ghost elements) serves conforming plans only. */
 void d4est_hip_plan_set_hanging(d4est_hip_plan_t* plan, const int* side_hang, const int* side_sub, const int* side_nbr4,
                                 const int* side_orientation);
 /* SIPG parameters ([flux] sipg_penalty_prefactor, sipg_penalty_fcn; d4est_laplacian_flux_sipg.c:945-1005):
@@ -233,6 +235,19 @@ void d4est_hip_copy_blocks(d4est_hip_plan_t* plan, int n_blocks, const double* s
 long long d4est_hip_plan_trace_offset(const d4est_hip_plan_t* plan, int side);
 long long d4est_hip_plan_ghost_trace_offset(const d4est_hip_plan_t* plan, int side);
 int d4est_hip_plan_trace_block_len(const d4est_hip_plan_t* plan, int side);
+/* Plans with hanging faces: a big side owns FOUR blocks (one per sub-mortar, in (-) order), every other side one.  Block `sub` of
+ * side `side`: where it sits in the local trace buffer, how long it is, and -- if the element across that mortar is a ghost --
+ * where its counterpart is expected in the ghost trace buffer (-1 otherwise).  The counterpart of a big side's block i is the single
+ * block of small element i's side; the counterpart of a small side's block is the big element's block
+ * d4est_reference_reorient_face_order(f_m, f_p, orientation, side_sub).  With sub = 0 these equal the three functions above on
+ * conforming plans. */
+int d4est_hip_plan_side_blocks(const d4est_hip_plan_t* plan, int side);
+/* d4est_reference_reorient_face_order (dGMath/d4est_reference.c:84-110), face_dim = 2: index in the (+) side's own order of the
+ * sub-face that is i in (-) order */
+int d4est_hip_reorient_face_order(int f_m, int f_p, int orientation, int i);
+long long d4est_hip_plan_trace_offset_sub(const d4est_hip_plan_t* plan, int side, int sub);
+long long d4est_hip_plan_ghost_trace_offset_sub(const d4est_hip_plan_t* plan, int side, int sub);
+int d4est_hip_plan_trace_block_len_sub(const d4est_hip_plan_t* plan, int side, int sub);
 /* deterministic device dot product; result_dev is a device double */
 void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const double* y_dev, double* result_dev);
 

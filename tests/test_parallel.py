@@ -54,7 +54,7 @@ def _worker(rank, world, port, level, deg_spec, q):
         m = M.BrickMesh(level, deg_global, first=first, count=count)
         sides = m.build_sides(None)
         toff, goff, blen = P.side_block_layout(sides)
-        sched = P.TraceSchedule(m, sides, parts, lambda s: toff[s], lambda s: goff[s], lambda s: blen[s])
+        sched = P.TraceSchedule(m, sides, parts, lambda s, b: toff[s], lambda s, b: goff[s], lambda s, b: blen[s])
         # local trace buffer with identifying content
         trace = np.zeros(int((toff + blen).max()))
         for e in range(m.n_elements):

@@ -71,6 +71,53 @@ def test_virtual_ranks_match_single_rank(gpu, hiplib, oracle, world, level, deg_
     assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("world,level,pattern,deg_spec", [(2, 1, [0, 5, 6], [2]), (3, 1, [1, 2, 4, 7], [2, 3]), (4, 2, [0, 9, 21, 42, 63], [3]),
+                                                          (3, 1, [3, 6], [7]), (2, 1, [2], [9])])
+def test_virtual_ranks_hanging_mesh(gpu, hiplib, oracle, world, level, pattern, deg_spec):
+    """Hanging (1 <-> 4) faces ACROSS rank boundaries: a big side sends one block per sub-mortar to the owners of its four small
+    neighbours, a small side receives the big element's sub-block that faces it; the assembled operator equals the single-rank one."""
+    import torch
+    from disco4est_amd import Plan, mesh as M, parallel as P
+    refine = np.zeros(8 ** level, dtype=bool)
+    refine[np.asarray(pattern)] = True
+    m0 = M.HangingBrickMesh(level, refine, deg_spec[0])
+    deg_global = np.array([deg_spec[i % len(deg_spec)] for i in range(m0.global_elements)])
+    mp = M.SineMap(0.04)
+    mg = M.HangingBrickMesh(level, refine, deg_global)
+    Jg, rstg = mg.geometry(mp); sg = mg.build_sides(mp); ug = mg.field(mp)
+    ref = oracle.apply_aij(mg, Jg, rstg, sg, ug, nthreads=8)
+    parts = P.partition_by_dofs(deg_global, world)
+    mb = _Mailbox()
+    ranks = []
+    crossing = 0
+    for r, (first, count) in enumerate(parts):
+        m = M.HangingBrickMesh(level, refine, deg_global, first=first, count=count)
+        J, rst = m.geometry(mp); s = m.build_sides(mp)
+        plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+        plan.set_geometry(J, rst); plan.set_faces(s)
+        sched = P.plan_schedule(plan, m, s, parts)
+        hang, nbr, n4 = s["side_hang"], s["side_nbr"], s["side_nbr4"]
+        crossing += int(((hang == 2) & (nbr <= -2)).sum()) + int(sum((n4[4 * i:4 * i + 4] <= -2).sum() for i in np.nonzero(hang == 1)[0]))
+        ex = P.TraceExchange(sched, _LocalTransport(r, mb), plan.copy_blocks, gpu)
+        u = torch.from_numpy(m.field(mp)).to(gpu)
+        tr = torch.empty(plan.trace_size, dtype=torch.float64, device=gpu)
+        gt = torch.full((max(plan.ghost_trace_size, 1),), float("nan"), dtype=torch.float64, device=gpu)
+        ranks.append((m, plan, ex, u, tr, gt))
+    assert crossing > 0, "the partition must cut at least one hanging face"
+    for m, plan, ex, u, tr, gt in ranks:
+        plan.compute_face_traces(u, tr)
+        ex.begin(tr)
+    got = np.zeros_like(ref)
+    for m, plan, ex, u, tr, gt in ranks:
+        ex.end(gt)
+        Au = torch.full_like(u, float("nan"))
+        plan.apply_stiffness_matrix(u, Au)
+        plan.apply_flux(tr, gt, Au)
+        got[m.global_nodal_offset:m.global_nodal_offset + m.local_nodes] = Au.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
 def test_apply_lhs_hooks_single_rank_with_self_exchange(gpu, hiplib, oracle):
     """apply_lhs / cheby through the C callback hooks: a 2-rank split where the 'remote' rank is served in-process."""
     import torch
