@@ -1928,7 +1928,8 @@ __global__ __launch_bounds__(64, 4) void stiffness_stream_only_kernel(const doub
 //                                          f(u) f(v) given at the quadrature nodes, d4est_quadrature.c:593-774)
 //   MODE 4: out = V^-1 (W J)^-1 V^-T in   (inverse mass, d4est_quadrature.c:1222-1331; Bop = V^-T, BopT = V^-1)
 // ---------------------------------------------------------------------------
-template <int N, int NQ, int MODE>
+// EO = true: Bop / BopT are the even-odd tables of B^T / B (the symmetric interpolation), see apply_eo
+template <int N, int NQ, int MODE, bool EO = false>
 __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
     const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ Jq,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list,
@@ -1968,7 +1969,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
       double x[N], y[NQ];
 #pragma unroll
       for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-      contract_n<N, NQ>(BopT, x, y);
+      fwd<N, NQ, EO, false>(BopT, x, y);
 #pragma unroll
       for (int iq = 0; iq < NQ; ++iq) R1[a + PN * (iq + NQ * b)] = y[iq];
     }
@@ -1977,7 +1978,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
       double x[N], y[NQ];
 #pragma unroll
       for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];
-      contract_n<N, NQ>(BopT, x, y);
+      fwd<N, NQ, EO, false>(BopT, x, y);
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = y[jq];
     }
@@ -1986,7 +1987,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
       double x[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
-      contract_n<N, NQ>(BopT, x, g);
+      fwd<N, NQ, EO, false>(BopT, x, g);
     }
   } else if (active) {
 #pragma unroll
@@ -2012,7 +2013,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
       if (MODE == 4) g[kq] = (1. / sc) * g[kq];  // d4est_kron_oneover_vec_o_vec_o_vec_dot_oneover_x_dot_y (d4est_kron.h:387-397)
       else g[kq] *= sc;
     }
-    contract_t<NQ, N, false>(Bop, g, c);
+    bwd<NQ, N, EO, false, false>(Bop, g, c);
   }
   __syncthreads();
   if (active) {
@@ -2024,7 +2025,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
     double x[NQ], y[N];
 #pragma unroll
     for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
-    contract_t<NQ, N, false>(Bop, x, y);
+    bwd<NQ, N, EO, false, false>(Bop, x, y);
 #pragma unroll
     for (int j = 0; j < N; ++j) R1[a + PQ * (j + N * b)] = y[j];
   }
@@ -2033,7 +2034,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
     double x[NQ], o[N];
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) x[iq] = R1[iq + PQ * (a + N * b)];
-    contract_t<NQ, N, false>(Bop, x, o);
+    bwd<NQ, N, EO, false, false>(Bop, x, o);
 #pragma unroll
     for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = o[i];
   }
@@ -2519,11 +2520,19 @@ static void launch_mass_like_mode(d4est_hip_plan* plan, const double* in, double
   if (!done && bk.N == N_ && NQe == NQ_) {                                                                            \
     using C = WaveCfg<N_, NQ_>;                                                                                       \
     if (C::LDS_BYTES <= 160 * 1024) {                                                                                 \
-      set_lds_limit(mass_like_kernel<N_, NQ_, MODE>, C::LDS_BYTES);                                                   \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                             \
-      hipLaunchKernelGGL((mass_like_kernel<N_, NQ_, MODE>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, \
-                         in, out, plan->d_J, plan->d_ns_list + bk.elem_offset, qs_list, bk.n_elem, op, opT, wts,       \
-                         coeff);                                                                                      \
+      constexpr bool kEven = (N_ % 2 == 0) && (NQ_ % 2 == 0);                                                         \
+      if (kEven && which == 0 && bk.d_EBf && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0) {                        \
+        set_lds_limit(mass_like_kernel<N_, NQ_, MODE, kEven>, C::LDS_BYTES);                                          \
+        hipLaunchKernelGGL((mass_like_kernel<N_, NQ_, MODE, kEven>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, \
+                           in, out, plan->d_J, plan->d_ns_list + bk.elem_offset, qs_list, bk.n_elem, bk.d_EBb, bk.d_EBf, wts, \
+                           coeff);                                                                                    \
+      } else {                                                                                                        \
+        set_lds_limit(mass_like_kernel<N_, NQ_, MODE, false>, C::LDS_BYTES);                                          \
+        hipLaunchKernelGGL((mass_like_kernel<N_, NQ_, MODE, false>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, \
+                           in, out, plan->d_J, plan->d_ns_list + bk.elem_offset, qs_list, bk.n_elem, op, opT, wts,     \
+                           coeff);                                                                                    \
+      }                                                                                                               \
       done = true;                                                                                                    \
     }                                                                                                                 \
   }
