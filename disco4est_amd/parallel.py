@@ -175,6 +175,37 @@ def side_block_layout(sides):
     return off, goff, 4 * T
 
 
+def side_block_layout_hp(mesh, sides):
+    """Per (side, sub) block layout of a plan WITH hanging faces, computed on the host exactly as the C library does
+    (mortar records in side order; a big side owns 4 blocks; T from the larger quadrature degree of the two elements
+    of a mortar; ghost blocks in record order).  Returns (n_blocks[side], offset(side, sub), ghost_offset(side, sub), length(side, sub))."""
+    ne = mesh.n_elements
+    degq_l = np.asarray(mesh.deg_quad)
+    degq_g = np.asarray(sides["ghost_deg_quad"])
+    dq = lambda ref: int(degq_l[ref]) if ref >= 0 else int(degq_g[-(ref + 2)])
+    nblk = np.ones(6 * ne, dtype=np.int32)
+    off, goff, ln = {}, {}, {}
+    q = g = 0
+    for s in range(6 * ne):
+        e = s // 6
+        h = int(sides["side_hang"][s])
+        nb = 4 if h == 1 else 1
+        nblk[s] = nb
+        for sub in range(nb):
+            ref = int(sides["side_nbr4"][4 * s + sub]) if h == 1 else int(sides["side_nbr"][s])
+            pq = int(degq_l[e]) if ref == -1 else max(int(degq_l[e]), dq(ref))
+            T = (pq + 1) ** 2
+            off[(s, sub)] = q
+            ln[(s, sub)] = 4 * T
+            q += 4 * T
+            if ref <= -2:
+                goff[(s, sub)] = g
+                g += 4 * T
+            else:
+                goff[(s, sub)] = -1
+    return nblk, off, goff, ln, q, g
+
+
 def attach(plan, mesh, sides, parts, transport, device):
     """Wire a Plan (faces already set) to a transport: installs the exchange / allreduce hooks used by
     apply_lhs, cheby_iterate and cg_eigs.  Returns the TraceExchange (keep it alive)."""

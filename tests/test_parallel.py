@@ -88,6 +88,76 @@ def _worker(rank, world, port, level, deg_spec, q):
         dist.destroy_process_group()
 
 
+def _worker_hp(rank, world, port, level, pattern, deg_spec, q):
+    """hanging faces across ranks: every block that arrives must be the SENDER's block (global element, face, sub)"""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from disco4est_amd import mesh as M, parallel as P
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        refine = np.zeros(8 ** level, dtype=bool)
+        refine[np.asarray(pattern)] = True
+        n_global = M.HangingBrickMesh(level, refine, 2).global_elements
+        deg_global = np.array([deg_spec[i % len(deg_spec)] for i in range(n_global)])
+        parts = P.partition_by_dofs(deg_global, world)
+        first, count = parts[rank]
+        m = M.HangingBrickMesh(level, refine, deg_global, first=first, count=count)
+        sides = m.build_sides(None)
+        nblk, off, goff, ln, n_trace, n_ghost = P.side_block_layout_hp(m, sides)
+        sched = P.TraceSchedule(m, sides, parts, lambda s, b: off[(s, b)], lambda s, b: goff[(s, b)], lambda s, b: ln[(s, b)],
+                                side_blocks=lambda s: nblk[s])
+        trace = np.zeros(n_trace)
+        for (s, sub), o in off.items():
+            e, f = divmod(s, 6)
+            trace[o:o + ln[(s, sub)]] = _encode(first + e, 10 * f + sub, ln[(s, sub)])   # identity (element, face, sub)
+        ghost = np.full(max(n_ghost, 1), np.nan)
+        ex = P.TraceExchange(sched, P.DistTransport(), _np_copy_blocks, torch.device("cpu"))
+        tt, gt = torch.from_numpy(trace), torch.from_numpy(ghost)
+        ex.begin(tt)
+        ex.end(gt)
+        checked = crossing = 0
+        for (s, sub), go in goff.items():
+            if go < 0:
+                continue
+            h = int(sides["side_hang"][s])
+            ref = int(sides["side_nbr4"][4 * s + sub]) if h == 1 else int(sides["side_nbr"][s])
+            gid = int(sides["ghost_global_ids"][-(ref + 2)])
+            f_p = int(sides["side_nbr_face"][s])
+            sender_sub = int(sides["side_sub"][s]) if h == 2 else 0     # orientation 0 inside one tree
+            np.testing.assert_array_equal(ghost[go:go + ln[(s, sub)]], _encode(gid, 10 * f_p + sender_sub, ln[(s, sub)]))
+            checked += 1
+            crossing += int(h != 0)
+        if n_ghost:
+            assert not np.isnan(ghost).any()
+        q.put((rank, "ok", checked, crossing))
+    except Exception as exc:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail", traceback.format_exc(), str(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,level,pattern,deg_spec", [(2, 1, [0, 5, 6], [2]), (3, 1, [1, 2, 4, 7], [2, 3])])
+def test_trace_exchange_gloo_hanging(world, level, pattern, deg_spec):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hp, args=(r, world, port, level, pattern, deg_spec, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r
+    assert sum(r[2] for r in res) > 0
+    assert sum(r[3] for r in res) > 0, "the partition must cut at least one hanging face"
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -96,6 +96,15 @@ def test_virtual_ranks_hanging_mesh(gpu, hiplib, oracle, world, level, pattern, 
         plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
         plan.set_geometry(J, rst); plan.set_faces(s)
         sched = P.plan_schedule(plan, m, s, parts)
+        # the host-side layout formula used by the CPU-only tests is the library's layout
+        nblk, off, goff, ln, n_trace, n_ghost = P.side_block_layout_hp(m, s)
+        assert plan.trace_size == n_trace and plan.ghost_trace_size == n_ghost
+        for sd in range(6 * m.n_elements):
+            assert plan.lib.d4est_hip_plan_side_blocks(plan.handle, sd) == nblk[sd]
+            for sub in range(nblk[sd]):
+                assert plan.lib.d4est_hip_plan_trace_offset_sub(plan.handle, sd, sub) == off[(sd, sub)]
+                assert plan.lib.d4est_hip_plan_ghost_trace_offset_sub(plan.handle, sd, sub) == goff[(sd, sub)]
+                assert plan.lib.d4est_hip_plan_trace_block_len_sub(plan.handle, sd, sub) == ln[(sd, sub)]
         hang, nbr, n4 = s["side_hang"], s["side_nbr"], s["side_nbr4"]
         crossing += int(((hang == 2) & (nbr <= -2)).sum()) + int(sum((n4[4 * i:4 * i + 4] <= -2).sum() for i in np.nonzero(hang == 1)[0]))
         ex = P.TraceExchange(sched, _LocalTransport(r, mb), plan.copy_blocks, gpu)
