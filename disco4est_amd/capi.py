@@ -49,6 +49,8 @@ SIGNATURES = {
     "d4est_hip_plan_set_faces": (None, [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _c_int_p, _c_int_p]),
     "d4est_hip_plan_set_hanging": (None, [_vp, _vp, _vp, _vp, _vp]),
+    "d4est_hip_plan_set_geometry_brick": (None, [_vp, _vp, ctypes.c_double, _vp]),
+    "d4est_hip_plan_set_mortar_geometry_brick": (None, [_vp, _vp, ctypes.c_double, _vp]),
     "d4est_hip_transfer_create": (_vp, [ctypes.c_int, _vp, _vp, _vp]),
     "d4est_hip_transfer_destroy": (None, [_vp]),
     "d4est_hip_transfer_set_stream": (None, [_vp, _vp]),
@@ -194,6 +196,13 @@ class Plan:
         assert u.numel() == self.local_nodes and u_quad.numel() == self.local_nodes_quad
         self.lib.d4est_hip_interpolate(self.handle, _ptr(u), _ptr(u_quad))
 
+    def set_geometry_brick(self, elem_dq, root_len, extents, mortars=False):
+        """device-generated factors of the reference's brick geometry (volume, or the mortars when mortars=True)"""
+        dq = _iarr(elem_dq)
+        ex = np.ascontiguousarray(extents, dtype=np.float64)
+        fn = self.lib.d4est_hip_plan_set_mortar_geometry_brick if mortars else self.lib.d4est_hip_plan_set_geometry_brick
+        fn(self.handle, dq[1], float(root_len), ex.ctypes.data_as(_vp))
+
     def apply_weighted_mass_matrix(self, u, coeff_quad, out):
         assert u.numel() == self.local_nodes and out.numel() == self.local_nodes
         assert coeff_quad.numel() == self.local_nodes_quad
@@ -222,8 +231,9 @@ class Plan:
         self.lib.d4est_hip_compute_dudr(self.handle, _ptr(u), _ptr(d0), _ptr(d1), _ptr(d2))
 
     # ---- faces
-    def set_faces(self, sides, penalty_prefactor=10.0, penalty_fcn=0):
-        """sides: the dict of mesh.BrickMesh.build_sides() (reference-layout side list + mortar factors)"""
+    def set_faces(self, sides, penalty_prefactor=10.0, penalty_fcn=0, brick=None):
+        """sides: the dict of mesh.BrickMesh.build_sides() (reference-layout side list + mortar factors);
+        brick = (elem_dq, root_len, extents): generate the mortar factors of the brick geometry on the device instead"""
         keep = [_iarr(sides[k]) for k in ("side_nbr", "side_nbr_face", "side_reorder", "side_mortar_stride", "side_bndry_stride",
                                          "ghost_deg", "ghost_deg_quad")]
         self._keep_sides = keep
@@ -235,8 +245,11 @@ class Plan:
                                           int(sides["total_mortar_nodes"]), int(sides["total_bndry_nodes"]),
                                           len(keep[5][0]), keep[5][1], keep[6][1])
         self.lib.d4est_hip_plan_set_sipg(self.handle, float(penalty_prefactor), int(penalty_fcn))
-        arrs = [np.ascontiguousarray(sides[k], dtype=np.float64) for k in ("sj", "n", "drst_m", "drst_p", "hm", "hp")]
-        self.lib.d4est_hip_plan_set_mortar_geometry(self.handle, *[a.ctypes.data_as(_vp) for a in arrs], 0)
+        if brick is not None:
+            self.set_geometry_brick(brick[0], brick[1], brick[2], mortars=True)
+        else:
+            arrs = [np.ascontiguousarray(sides[k], dtype=np.float64) for k in ("sj", "n", "drst_m", "drst_p", "hm", "hp")]
+            self.lib.d4est_hip_plan_set_mortar_geometry(self.handle, *[a.ctypes.data_as(_vp) for a in arrs], 0)
         self.trace_size = self.lib.d4est_hip_plan_trace_size(self.handle)
         self.ghost_trace_size = self.lib.d4est_hip_plan_ghost_trace_size(self.handle)
 

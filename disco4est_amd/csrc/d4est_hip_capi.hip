@@ -252,6 +252,37 @@ void d4est_hip_plan_set_geometry(d4est_hip_plan_t* plan, const double* J_quad, c
   plan->has_geometry = true;
 }
 
+static int* upload_elem_dq(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents, const char* who) {
+  if (plan->n_elements > 0 && !elem_dq) D4EST_HIP_ABORT("%s: elem_dq is NULL", who);
+  if (!extents || !(root_len > 0.) || !(extents[1] > extents[0]) || !(extents[3] > extents[2]) || !(extents[5] > extents[4]))
+    D4EST_HIP_ABORT("%s: bad brick extents / root length", who);
+  int* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, std::max<size_t>((size_t)plan->n_elements, 1) * sizeof(int)));
+  if (plan->n_elements > 0) HIP_CHECK(hipMemcpy(d, elem_dq, (size_t)plan->n_elements * sizeof(int), hipMemcpyHostToDevice));
+  return d;
+}
+
+void d4est_hip_plan_set_geometry_brick(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents) {
+  check_plan(plan, "plan_set_geometry_brick");
+  int* d_dq = upload_elem_dq(plan, elem_dq, root_len, extents, "plan_set_geometry_brick");
+  const size_t nq = (size_t)plan->local_nodes_quad;
+  if (!plan->d_J) HIP_CHECK(hipMalloc(&plan->d_J, std::max<size_t>(nq, 1) * sizeof(double)));
+  if (!plan->d_metric) HIP_CHECK(hipMalloc(&plan->d_metric, std::max<size_t>(6 * nq, 1) * sizeof(double)));
+  d4est_hip::launch_brick_geometry(plan, d_dq, root_len, extents);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  HIP_CHECK(hipFree(d_dq));
+  plan->has_geometry = true;
+}
+
+void d4est_hip_plan_set_mortar_geometry_brick(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents) {
+  check_plan(plan, "plan_set_mortar_geometry_brick");
+  if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_mortar_geometry_brick: call plan_set_faces first");
+  int* d_dq = upload_elem_dq(plan, elem_dq, root_len, extents, "plan_set_mortar_geometry_brick");
+  d4est_hip::faces_set_geometry_brick(plan, d_dq, root_len, extents);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  HIP_CHECK(hipFree(d_dq));
+}
+
 void d4est_hip_apply_stiffness_matrix(d4est_hip_plan_t* plan, const double* u_dev, double* Au_dev) {
   check_plan(plan, "apply_stiffness_matrix");
   d4est_hip::launch_stiffness(plan, u_dev, Au_dev);

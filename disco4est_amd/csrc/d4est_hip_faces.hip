@@ -2079,6 +2079,76 @@ void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_d
   }
 }
 
+// brick geometry on the mortars (d4est_mesh_compute_mortar_quadrature_quantities on the brick map): constant per mortar;
+// the mortar is the face of a cell of the MORTAR's size (half the element on the big side of a hanging face)
+__device__ inline void brick_fill_mortar(int f, double hx, double hy, double hz, size_t S, int off, int TT, int T,
+                                         double* sj, double* nrm, double* drst_m, double* drst_p, double* hm, double* hp) {
+  const int dir = f >> 1;
+  const double h[3] = {hx, hy, hz};
+  const double J = hx * hy * hz;
+  const double sjv = J * (1. / h[dir]);
+  for (int k = threadIdx.x; k < T; k += blockDim.x) {
+    sj[S + off + k] = sjv;
+    hm[S + off + k] = J / sjv;
+    hp[S + off + k] = J / sjv;
+    for (int d = 0; d < 3; ++d) nrm[3 * S + (size_t)d * TT + off + k] = (d == dir) ? ((f & 1) ? 1. : -1.) : 0.;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        const double v = (i == j) ? 1. / h[i] : 0.;
+        drst_m[9 * S + (size_t)(i + 3 * j) * TT + off + k] = v;
+        drst_p[9 * S + (size_t)(i + 3 * j) * TT + off + k] = v;
+      }
+  }
+}
+
+__global__ __launch_bounds__(64) void brick_mortar_kernel(const SideDesc* __restrict__ sd, int n_sides, const int* __restrict__ elem_dq,
+                                                          double root_len, double ex, double ey, double ez, double* sj, double* nrm,
+                                                          double* drst_m, double* drst_p, double* hm, double* hp) {
+  for (int s = blockIdx.x; s < n_sides; s += gridDim.x) {
+    const SideDesc d = sd[s];
+    if (d.kind == 3) continue;   // hanging side: written by the record kernel
+    const double half = (double)elem_dq[s / 6] / root_len / 2.;
+    const int T = d.NQ * d.NQ;
+    brick_fill_mortar(s % 6, ex * half, ey * half, ez * half, (size_t)d.geom, 0, T, T, sj, nrm, drst_m, drst_p, hm, hp);
+  }
+}
+
+__global__ __launch_bounds__(64) void brick_mortar_hp_kernel(const HpMortar* __restrict__ md, const HpGeomSrc* __restrict__ gs, int n_rec,
+                                                             const int* __restrict__ elem_dq, double root_len, double ex, double ey,
+                                                             double ez, double* sj, double* nrm, double* drst_m, double* drst_p,
+                                                             double* hm, double* hp) {
+  for (int r = blockIdx.x; r < n_rec; r += gridDim.x) {
+    const HpMortar m = md[r];
+    const HpGeomSrc g = gs[r];
+    const double half = (double)elem_dq[m.elem] / root_len / 2. * (m.fm < 1.0 ? 0.5 : 1.0);   // big side: half-size mortar
+    brick_fill_mortar(m.face, ex * half, ey * half, ez * half, (size_t)g.S, g.off, g.Ttot, m.NQ * m.NQ, sj, nrm, drst_m, drst_p, hm, hp);
+  }
+}
+
+void faces_set_geometry_brick(d4est_hip_plan* plan, const int* d_elem_dq, double root_len, const double* extents) {
+  FaceHost& fh = g_face_host[plan];
+  const size_t T = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
+  double* a[6];
+  const size_t mult[6] = {1, 3, 9, 9, 1, 1};
+  for (int i = 0; i < 6; ++i) {
+    HIP_CHECK(hipMalloc(&a[i], mult[i] * T * sizeof(double)));
+    HIP_CHECK(hipMemsetAsync(a[i], 0, mult[i] * T * sizeof(double), plan->stream));
+  }
+  const double ex = extents[1] - extents[0], ey = extents[3] - extents[2], ez = extents[5] - extents[4];
+  const int n_sides = 6 * plan->n_elements;
+  if (fh.hp) {
+    if (fh.n_rec > 0)
+      hipLaunchKernelGGL(brick_mortar_hp_kernel, dim3(std::min(fh.n_rec, 8192)), dim3(64), 0, plan->stream, fh.d_rec, fh.d_gsrc, fh.n_rec,
+                         d_elem_dq, root_len, ex, ey, ez, a[0], a[1], a[2], a[3], a[4], a[5]);
+  } else if (n_sides > 0) {
+    hipLaunchKernelGGL(brick_mortar_kernel, dim3(std::min(n_sides, 8192)), dim3(64), 0, plan->stream, (const SideDesc*)plan->d_side_desc,
+                       n_sides, d_elem_dq, root_len, ex, ey, ez, a[0], a[1], a[2], a[3], a[4], a[5]);
+  }
+  HIP_CHECK(hipGetLastError());
+  faces_set_geometry(plan, a[0], a[1], a[2], a[3], a[4], a[5], /*on_device=*/1);
+  for (int i = 0; i < 6; ++i) HIP_CHECK(hipFree(a[i]));
+}
+
 __global__ __launch_bounds__(256) void robin_setup_kernel(const double* __restrict__ sj, const double* __restrict__ coeff,
                                                           const double* __restrict__ rhs, double* __restrict__ c,
                                                           double* __restrict__ r, size_t n) {

@@ -130,6 +130,8 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
 // mode: 0 mass, 1 galerkin, 2 interpolate / square tensor apply, 3 weighted mass, 4 inverse mass;
 // which: 0 quadrature interpolation, 1 inverse Gauss interpolation, 2 M (1-D mass), 3 M^-1
 void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out, const double* coeff = nullptr, int which = 0);
+void launch_brick_geometry(d4est_hip_plan* plan, const int* d_elem_dq, double root_len, const double* extents);
+void faces_set_geometry_brick(d4est_hip_plan* plan, const int* d_elem_dq, double root_len, const double* extents);
 void launch_dij(d4est_hip_plan* plan, const double* in, double* out, int dir, int transpose);
 void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, double* d2);
 

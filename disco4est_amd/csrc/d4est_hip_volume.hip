@@ -2581,6 +2581,54 @@ void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, 
   HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------
+// Geometric factors of the reference's `brick` geometry generated on the device (brick only):
+// d4est_geometry_brick_DX (src/Geometry/d4est_geometry_brick.c:140-206) is diagonal and constant per element,
+//   dx_d/dr_d = (X1_d - X0_d) (dq / P4EST_ROOT_LEN) / 2,   J = prod_d dx_d/dr_d,   dr_d/dx_d = 1 / (dx_d/dr_d),
+// so J_quad, the symmetric metric and the six affine constants are written directly: no 96 B/node host arrays, no upload.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void brick_metric_kernel(const int* __restrict__ elem_ids, const int* __restrict__ qs_list,
+                                                           int n_bucket, int NQ, const double* __restrict__ wq,
+                                                           const int* __restrict__ elem_dq, double root_len, double ex, double ey, double ez,
+                                                           double* __restrict__ Jq, double* __restrict__ metric,
+                                                           double* __restrict__ affine) {
+  const int NQ3 = NQ * NQ * NQ;
+  for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
+    const int qs = qs_list[ei];
+    const double half = (double)elem_dq[elem_ids[ei]] / root_len / 2.;
+    const double hx = ex * half, hy = ey * half, hz = ez * half;
+    const double J = hx * hy * hz;
+    const double g[6] = {J * ((1. / hx) * (1. / hx)), 0., 0., J * ((1. / hy) * (1. / hy)), 0., J * ((1. / hz) * (1. / hz))};
+    if (threadIdx.x < 6) affine[(size_t)6 * ei + threadIdx.x] = g[threadIdx.x];
+    double* m = metric + (size_t)6 * qs;
+    for (int q = threadIdx.x; q < NQ3; q += blockDim.x) {
+      const int iq = q % NQ, jq = (q / NQ) % NQ, kq = q / (NQ * NQ);
+      const double w3 = wq[kq] * (wq[jq] * wq[iq]);
+      Jq[qs + q] = J;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) m[(size_t)c * NQ3 + q] = w3 * g[c];
+    }
+  }
+}
+
+void launch_brick_geometry(d4est_hip_plan* plan, const int* d_elem_dq, double root_len, const double* extents) {
+  if (!plan->d_metric_affine) {
+    HIP_CHECK(hipMalloc(&plan->d_metric_affine, std::max<size_t>((size_t)6 * plan->n_elements, 1) * sizeof(double)));
+    HIP_CHECK(hipMalloc(&plan->d_nonaffine, std::max<size_t>(plan->buckets.size(), 1) * sizeof(int)));
+  }
+  for (size_t bi = 0; bi < plan->buckets.size(); ++bi) {
+    Bucket& bk = plan->buckets[bi];
+    if (bk.n_elem == 0) continue;
+    const int grid = bk.n_elem < 4096 ? bk.n_elem : 4096;
+    hipLaunchKernelGGL(brick_metric_kernel, dim3(grid), dim3(256), 0, plan->stream, plan->d_elem_ids + bk.elem_offset,
+                       plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.NQ, bk.d_w, d_elem_dq, root_len, extents[1] - extents[0],
+                       extents[3] - extents[2], extents[5] - extents[4], plan->d_J, plan->d_metric,
+                       plan->d_metric_affine + (size_t)6 * bk.elem_offset);
+    bk.affine = true;
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_dij(d4est_hip_plan* plan, const double* in, double* out, int dir, int transpose) {
   if (dir < 0 || dir > 2) D4EST_HIP_ABORT("apply_dij: direction %d", dir);
   if (in == out) D4EST_HIP_ABORT("apply_dij: in and out must not alias");

@@ -100,6 +100,16 @@ int d4est_hip_plan_n_elements(const d4est_hip_plan_t* plan);
  * (6 entries per quadrature node, element-blocked); the inputs are not retained. */
 void d4est_hip_plan_set_geometry(d4est_hip_plan_t* plan, const double* J_quad, const double* rst_xyz_quad, int on_device);
 
+/* Geometric factors generated ON THE DEVICE for the reference's `brick` geometry ([geometry] name = brick, X0..Z1;
+ * src/Geometry/d4est_geometry_brick.c:140-206: dx_d/dr_d = (X1_d - X0_d) (dq / P4EST_ROOT_LEN) / 2, diagonal, constant per element) --
+ * SURVEY.md section 8f rank 4, brick only.  Replaces d4est_hip_plan_set_geometry / _set_mortar_geometry on a brick: no J_quad /
+ * rst_xyz_quad / mortar arrays are formed on the host or uploaded.  elem_dq[e] = the quadrant's side length in p4est integer
+ * coordinates (d4est_element_data_t::dq), root_len = P4EST_ROOT_LEN, extents = {X0, X1, Y0, Y1, Z0, Z1}.  The mortar variant is
+ * called where d4est_hip_plan_set_mortar_geometry would be (after plan_set_faces / plan_set_sipg); hanging faces use the mortar-sized
+ * cell (src/Mesh/d4est_mortars.c:420-470), face_h_type FACE_H_EQ_J_DIV_SJ_QUAD. */
+void d4est_hip_plan_set_geometry_brick(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents);
+void d4est_hip_plan_set_mortar_geometry_brick(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents);
+
 /* ---- volume kernels (device vectors of local_nodes doubles) ---------------------- */
 /* Au = K u : replaces d4est_laplacian_apply_stiffness_matrix (src/dGMath/d4est_laplacian.c:198-234)
  * = loop of d4est_quadrature_apply_stiffness_matrix (src/Quadrature/d4est_quadrature.c:263-382).

@@ -239,3 +239,36 @@ def test_consistency_and_symmetry_at_size(gpu, hiplib, oracle):
     s1, s2 = torch.dot(b, Aa).item(), torch.dot(a, Ab).item()
     assert abs(s1 - s2) <= 1e-11 * max(abs(s1), abs(s2))
     assert torch.dot(a, Aa).item() > 0
+
+
+@pytest.mark.parametrize("kind,level,deg", [("uniform", 2, 3), ("uniform", 1, 7), ("uniform", 1, 9), ("hanging", 1, 2), ("hanging", 2, 4)])
+def test_brick_geometry_on_device(gpu, hiplib, oracle, kind, level, deg):
+    """d4est_hip_plan_set_geometry_brick / _set_mortar_geometry_brick (factors of the brick map generated on the device) give
+    the operator of the array path, i.e. of the oracle fed with host-computed factors."""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    ROOT = 1 << 30
+    if kind == "uniform":
+        m = M.BrickMesh(level, deg)
+        dq = np.full(m.n_elements, ROOT >> level, dtype=np.int32)
+    else:
+        refine = np.zeros(8 ** level, dtype=bool)
+        refine[[0, 5 % (8 ** level), (8 ** level) - 2]] = True
+        m = M.HangingBrickMesh(level, refine, deg)
+        dq = (m.size * (ROOT >> (level + 1))).astype(np.int32)
+    J, rst = m.geometry(None); sides = m.build_sides(None); u = m.field()
+    g = np.sin(sides["bndry_xyz"][0]) + sides["bndry_xyz"][1]
+    ref = oracle.apply_aij(m, J, rst, sides, u, bndry_lobatto=g, penalty_prefactor=6.0, nthreads=8)
+    ext = [0.0, 1.0, 0.0, 1.0, 0.0, 1.0]
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan.set_geometry_brick(dq, float(ROOT), ext)
+    plan.set_faces(sides, 6.0, 0, brick=(dq, float(ROOT), ext))
+    plan.set_dirichlet_values(g)
+    du = _t(u, gpu); out = torch.full_like(du, float("nan"))
+    plan.apply_aij(du, out)
+    assert _rel(out.cpu().numpy(), ref) <= RTOL
+    # mass matrix uses the device-generated J as well
+    Mu = torch.full_like(du, float("nan"))
+    plan.apply_mass_matrix(du, Mu)
+    assert _rel(Mu.cpu().numpy(), oracle.apply_mass(m, J, u)) <= RTOL
+    plan.destroy()
