@@ -994,7 +994,7 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
                                                         const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                         const double* __restrict__ geom, const double* __restrict__ bndry_q,
                                                         const double* __restrict__ robin_c, const double* __restrict__ robin_r,
-                                                        int n_elem) {
+                                                        int n_elem, int xcd_chunk) {
   __shared__ double s_in[6][4][64];   // per wave: 4 term fields on the 8 x 8 grid
   __shared__ double s_tmp[6][4][64];
   __shared__ double s_E[6][64];       // per wave: E of its side, zero-padded to 8 x 8
@@ -1005,17 +1005,21 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
   const int f = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, lo = lane & 7, hi = lane >> 3;
   // persistent workgroups: the descriptors of the NEXT element are requested while this one is computed
+  // XCD-aware element order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the virtual index v is
+  // mapped to element (v % 8) * chunk + v / 8: every XCD walks one contiguous (Morton-local) eighth of the elements and finds
+  // its neighbours' traces in its own L2 more often.  xcd_chunk = 0: identity.
+  auto elem_of = [&](int v) { return xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v; };
   int e = blockIdx.x;
-  ElemDesc edn = ed[e < n_elem ? e : 0];
-  SideDesc dn = sd[6 * (e < n_elem ? e : 0) + f];
+  ElemDesc edn = ed[e < n_elem ? elem_of(e) : 0];
+  SideDesc dn = sd[6 * (e < n_elem ? elem_of(e) : 0) + f];
   for (; e < n_elem; e += gridDim.x) {
     const ElemDesc el = edn;
     const SideDesc d = dn;
     {
       const int en = e + gridDim.x;
       if (en < n_elem) {
-        edn = ed[en];
-        dn = sd[6 * en + f];
+        edn = ed[elem_of(en)];
+        dn = sd[6 * elem_of(en) + f];
       }
     }
     const int N = el.N, N2 = N * N, N3 = N2 * N, NQ = d.NQ, T = NQ * NQ;
@@ -2300,7 +2304,8 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     const int grid = (n + rounds - 1) / rounds;
     hipLaunchKernelGGL(flux_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
                        (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops,
-                       plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n);
+                       plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n,
+                       (n % 8 == 0 && grid % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0);
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     hipLaunchKernelGGL(flux_mfma16_kernel, dim3(std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), 0, plan->stream, trace,
                        ghost_trace, Au, (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
