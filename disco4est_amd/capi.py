@@ -41,6 +41,9 @@ SIGNATURES = {
     "d4est_hip_interpolate": (None, [_vp, _vp, _vp]),
     "d4est_hip_apply_weighted_mass_matrix": (None, [_vp, _vp, _vp, _vp]),
     "d4est_hip_apply_inverse_mass_matrix": (None, [_vp, _vp, _vp]),
+    "d4est_hip_plan_face_nodes": (ctypes.c_int, [_vp]),
+    "d4est_hip_apply_slicer": (None, [_vp, _vp, ctypes.c_int, _vp]),
+    "d4est_hip_apply_lift": (None, [_vp, _vp, ctypes.c_int, _vp]),
     "d4est_hip_apply_dij": (None, [_vp, _vp, ctypes.c_int, _vp]),
     "d4est_hip_apply_dij_transpose": (None, [_vp, _vp, ctypes.c_int, _vp]),
     "d4est_hip_apply_mij": (None, [_vp, _vp, _vp]),
@@ -219,6 +222,14 @@ class Plan:
     def apply_invmij(self, x, out):
         assert x.numel() == self.local_nodes and out.numel() == self.local_nodes
         self.lib.d4est_hip_apply_invmij(self.handle, _ptr(x), _ptr(out))
+
+    def apply_slicer(self, x, face, out_face):
+        assert x.numel() == self.local_nodes and out_face.numel() == self.lib.d4est_hip_plan_face_nodes(self.handle)
+        self.lib.d4est_hip_apply_slicer(self.handle, _ptr(x), int(face), _ptr(out_face))
+
+    def apply_lift(self, x_face, face, out):
+        assert out.numel() == self.local_nodes and x_face.numel() == self.lib.d4est_hip_plan_face_nodes(self.handle)
+        self.lib.d4est_hip_apply_lift(self.handle, _ptr(x_face), int(face), _ptr(out))
 
     def apply_dij(self, x, direction, out, transpose=False):
         assert x.numel() == self.local_nodes and out.numel() == self.local_nodes

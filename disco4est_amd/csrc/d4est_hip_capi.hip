@@ -201,6 +201,7 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   (void)hipFree(plan->d_ns_list);
   (void)hipFree(plan->d_qs_list);
   (void)hipFree(plan->d_J);
+  (void)hipFree(plan->d_face_stride);
   (void)hipFree(plan->d_metric);
   (void)hipFree(plan->d_metric_affine);
   (void)hipFree(plan->d_nonaffine);
@@ -322,6 +323,23 @@ void d4est_hip_apply_mij(d4est_hip_plan_t* plan, const double* in_dev, double* o
 void d4est_hip_apply_invmij(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev) {
   check_plan(plan, "apply_invmij");
   d4est_hip::launch_mass_like(plan, 2, in_dev, out_dev, nullptr, 3);
+}
+
+int d4est_hip_plan_face_nodes(const d4est_hip_plan_t* plan) {
+  check_plan(plan, "plan_face_nodes");
+  long long n = 0;
+  for (int e = 0; e < plan->n_elements; ++e) n += (long long)(plan->deg[e] + 1) * (plan->deg[e] + 1);
+  return (int)n;
+}
+
+void d4est_hip_apply_slicer(d4est_hip_plan_t* plan, const double* in_dev, int face, double* out_face_dev) {
+  check_plan(plan, "apply_slicer");
+  d4est_hip::launch_slicer_lift(plan, in_dev, out_face_dev, face, 0);
+}
+
+void d4est_hip_apply_lift(d4est_hip_plan_t* plan, const double* in_face_dev, int face, double* out_dev) {
+  check_plan(plan, "apply_lift");
+  d4est_hip::launch_slicer_lift(plan, in_face_dev, out_dev, face, 1);
 }
 
 void d4est_hip_apply_dij(d4est_hip_plan_t* plan, const double* in_dev, int dir, double* out_dev) {

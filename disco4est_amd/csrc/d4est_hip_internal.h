@@ -80,6 +80,8 @@ struct d4est_hip_plan {
 
   bool has_geometry = false;
   double* d_J = nullptr;          // local_nodes_quad  (reference layout)
+  int* d_face_stride = nullptr;       // per element: offset of its N^2 face values in a face vector (apply_slicer / apply_lift)
+  int face_nodes = 0;
   double* d_metric = nullptr;
   double* d_metric_affine = nullptr;  // 6 per element (bucket order): J (dr/dx)(dr/dx)^T of node 0
   int* d_nonaffine = nullptr;         // per bucket: set by the precombine kernel when an element is not affine     // 6 * local_nodes_quad, element-blocked: [e][c][n], c in (rr,rs,rt,ss,st,tt)
@@ -132,6 +134,7 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
 void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out, const double* coeff = nullptr, int which = 0);
 void launch_brick_geometry(d4est_hip_plan* plan, const int* d_elem_dq, double root_len, const double* extents);
 void faces_set_geometry_brick(d4est_hip_plan* plan, const int* d_elem_dq, double root_len, const double* extents);
+void launch_slicer_lift(d4est_hip_plan* plan, const double* in, double* out, int face, int lift);
 void launch_dij(d4est_hip_plan* plan, const double* in, double* out, int dir, int transpose);
 void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, double* d2);
 

@@ -2629,6 +2629,50 @@ void launch_brick_geometry(d4est_hip_plan* plan, const int* d_elem_dq, double ro
   HIP_CHECK(hipGetLastError());
 }
 
+// d4est_operators_apply_slicer / _apply_lift (src/dGMath/d4est_operators.c:1521-1582, :1454-1519), batched: the trace of a volume
+// field on face f of every element (N^2 values per element, face axes in increasing order, first axis fastest) and its inverse
+// scatter (zero elsewhere).  Face vectors are element-ordered with stride sum_{e' < e} N_{e'}^2.
+__global__ __launch_bounds__(256) void slicer_lift_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                          const int* __restrict__ elem_ids, const int* __restrict__ ns_list,
+                                                          const int* __restrict__ face_stride, int n_bucket, int N, int face, int lift) {
+  const int dir = face >> 1, fix = (face & 1) ? N - 1 : 0, N2 = N * N, N3 = N2 * N;
+  for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
+    const int ns = ns_list[ei], fs = face_stride[elem_ids[ei]];
+    if (lift) {
+      for (int idx = threadIdx.x; idx < N3; idx += blockDim.x) {
+        const int i = idx % N, j = (idx / N) % N, k = idx / N2;
+        const int pos = dir == 0 ? i : (dir == 1 ? j : k);
+        const int a = dir == 0 ? j : i, b = dir == 2 ? j : k;
+        out[ns + idx] = (pos == fix) ? in[fs + a + N * b] : 0.0;
+      }
+    } else {
+      for (int ab = threadIdx.x; ab < N2; ab += blockDim.x) {
+        const int a = ab % N, b = ab / N;
+        const int v = dir == 0 ? fix + N * (a + N * b) : (dir == 1 ? a + N * (fix + N * b) : a + N * (b + N * fix));
+        out[fs + ab] = in[ns + v];
+      }
+    }
+  }
+}
+
+void launch_slicer_lift(d4est_hip_plan* plan, const double* in, double* out, int face, int lift) {
+  if (face < 0 || face > 5) D4EST_HIP_ABORT("apply_slicer / apply_lift: face %d", face);
+  if (!plan->d_face_stride) {
+    std::vector<int> fs((size_t)plan->n_elements + 1, 0);
+    for (int e = 0; e < plan->n_elements; ++e) fs[e + 1] = fs[e] + (plan->deg[e] + 1) * (plan->deg[e] + 1);
+    plan->face_nodes = fs[plan->n_elements];
+    HIP_CHECK(hipMalloc(&plan->d_face_stride, fs.size() * sizeof(int)));
+    HIP_CHECK(hipMemcpy(plan->d_face_stride, fs.data(), fs.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  for (const Bucket& bk : plan->buckets) {
+    if (bk.n_elem == 0) continue;
+    const int grid = bk.n_elem < 16384 ? bk.n_elem : 16384;
+    hipLaunchKernelGGL(slicer_lift_kernel, dim3(grid), dim3(256), 0, plan->stream, in, out, plan->d_elem_ids + bk.elem_offset,
+                       plan->d_ns_list + bk.elem_offset, plan->d_face_stride, bk.n_elem, bk.N, face, lift);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_dij(d4est_hip_plan* plan, const double* in, double* out, int dir, int transpose) {
   if (dir < 0 || dir > 2) D4EST_HIP_ABORT("apply_dij: direction %d", dir);
   if (in == out) D4EST_HIP_ABORT("apply_dij: in and out must not alias");

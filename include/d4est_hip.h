@@ -140,6 +140,12 @@ void d4est_hip_apply_invmij(d4est_hip_plan_t* plan, const double* in_dev, double
  * (d4est_operators.c:1385-1410, :2259-2284), batched over the plan; in and out must not alias. */
 void d4est_hip_apply_dij(d4est_hip_plan_t* plan, const double* in_dev, int dir, double* out_dev);
 void d4est_hip_apply_dij_transpose(d4est_hip_plan_t* plan, const double* in_dev, int dir, double* out_dev);
+/* Trace of a volume field on face `face` of every element and its inverse scatter: d4est_operators_apply_slicer / _apply_lift
+ * (d4est_operators.c:1521-1582, :1454-1519), batched.  A face vector holds N_e^2 values per element (tangential axes in increasing
+ * order, the first fastest), element e at sum_{e' < e} N_{e'}^2; d4est_hip_plan_face_nodes = its length.  The lift zero-fills. */
+int d4est_hip_plan_face_nodes(const d4est_hip_plan_t* plan);
+void d4est_hip_apply_slicer(d4est_hip_plan_t* plan, const double* in_dev, int face, double* out_face_dev);
+void d4est_hip_apply_lift(d4est_hip_plan_t* plan, const double* in_face_dev, int face, double* out_dev);
 /* dudr_i = D_i u, i = 0..2 : d4est_laplacian_compute_dudr (d4est_laplacian.c:237-282), 3 applies of
  * d4est_operators_apply_dij (d4est_operators.c:1385-1410) per element. */
 void d4est_hip_compute_dudr(d4est_hip_plan_t* plan, const double* u_dev, double* dudr0_dev, double* dudr1_dev, double* dudr2_dev);

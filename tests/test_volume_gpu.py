@@ -210,6 +210,27 @@ def test_weighted_inverse_mass_mij_parity(gpu, hiplib, oracle, level, deg, inc, 
                 fn(src.ctypes.data_as(dp), int(m.deg[e]), direction, dst.ctypes.data_as(dp))
                 ref[s0:s0 + n3] = dst
             assert _rel(o.cpu().numpy(), ref) <= RTOL
+    # d4est_operators_apply_slicer / _apply_lift on every face (bit-exact: pure gathers / scatters)
+    oracle.lib.oracle_apply_slicer.argtypes = [dp, ctypes.c_int, ctypes.c_int, dp]
+    oracle.lib.oracle_apply_lift.argtypes = [dp, ctypes.c_int, ctypes.c_int, dp]
+    nf = plan.lib.d4est_hip_plan_face_nodes(plan.handle)
+    fstride = np.concatenate([[0], np.cumsum((m.deg.astype(np.int64) + 1) ** 2)])
+    assert nf == fstride[-1]
+    for face in range(6):
+        tf = torch.full((nf,), float("nan"), dtype=torch.float64, device=gpu)
+        plan.apply_slicer(du, face, tf)
+        back = torch.full_like(du, float("nan"))
+        plan.apply_lift(tf, face, back)
+        ref_f = np.zeros(nf); ref_b = np.zeros(m.local_nodes)
+        for e in range(m.n_elements):
+            s0, n3, n2 = int(m.nodal_stride[e]), (int(m.deg[e]) + 1) ** 3, (int(m.deg[e]) + 1) ** 2
+            src = np.ascontiguousarray(u[s0:s0 + n3]); fo = np.zeros(n2); vo = np.zeros(n3)
+            oracle.lib.oracle_apply_slicer(src.ctypes.data_as(dp), face, int(m.deg[e]), fo.ctypes.data_as(dp))
+            oracle.lib.oracle_apply_lift(fo.ctypes.data_as(dp), int(m.deg[e]), face, vo.ctypes.data_as(dp))
+            ref_f[fstride[e]:fstride[e] + n2] = fo
+            ref_b[s0:s0 + n3] = vo
+        assert np.array_equal(tf.cpu().numpy(), ref_f)
+        assert np.array_equal(back.cpu().numpy(), ref_b)
     if inc == 0:
         # the inverse mass is Gauss-only in the reference; the tolerance carries the conditioning of V^-1 (grows with p)
         o = torch.full_like(du, float("nan"))
