@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
                                                           const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                           const double* __restrict__ geom, const double* __restrict__ bndry_q,
                                                           const double* __restrict__ robin_c, const double* __restrict__ robin_r,
-                                                          int n_elem) {
+                                                          int n_elem, int xcd_chunk) {
   constexpr int LT = 17;                    // padded row length of a 16 x 16 tile in LDS
   constexpr int TPB = 192;
   __shared__ double s_tile[6][2][16 * LT];  // per face: val, normal field   (rows a, columns b)
@@ -1141,7 +1141,8 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
   double opE[2][4], opD[4];   // E[mi][4 ks + mk] (N x NQ) per face;  D[4 ks + mk][mi]
 #pragma unroll
   for (int i = 0; i < 4; ++i) opE[0][i] = opE[1][i] = opD[i] = 0.0;
-  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+  for (int v = blockIdx.x; v < n_elem; v += gridDim.x) {
+    const int e = xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v;   // XCD-aware element order, see flux_wave_kernel
     const ElemDesc el = ed[e];
     const int N = el.N, N2 = N * N, N3 = N2 * N;
     if (el.offD != cur_offD || N != cur_N) {
@@ -2307,9 +2308,11 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
                        plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n,
                        (n % 8 == 0 && grid % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0);
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
-    hipLaunchKernelGGL(flux_mfma16_kernel, dim3(std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), 0, plan->stream, trace,
+    const int grid16 = std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256));
+    hipLaunchKernelGGL(flux_mfma16_kernel, dim3(grid16), dim3(192), 0, plan->stream, trace,
                        ghost_trace, Au, (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
-                       plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n);
+                       plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n,
+                       (n % 8 == 0 && grid16 % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0);
   } else {
     const size_t lds = generic_lds_bytes(plan);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
