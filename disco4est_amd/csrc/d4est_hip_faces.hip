@@ -861,14 +861,14 @@ __global__ __launch_bounds__(192) void trace_mfma_kernel(const double* __restric
 // face path five times more expensive than the volume kernel at p >= 9.
 __global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
                                                            const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
-                                                           const double* __restrict__ face_ops, int n_elem) {
+                                                           const double* __restrict__ face_ops, int n_elem, int max_n) {
   constexpr int LDM = 34;                  // staging rows: 32 columns (field, b) + padding
   constexpr int UJ = 17, UK = 272;         // padded strides of the LDS copy of u (<= 2-way bank conflicts in all directions)
   constexpr int TPB = 192;
   extern __shared__ __attribute__((aligned(16))) double smem16[];
-  double* s_u = smem16;                    // 16 * UK
+  double* s_u = smem16;                    // max_n * UK (only the k-planes the plan's largest element needs)
   const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* stage = smem16 + 16 * UK + dir * (2 * 16 * LDM);   // per wave: 2 faces x [a (16)][(field, b) 32]
+  double* stage = smem16 + max_n * UK + dir * (2 * 16 * LDM);   // per wave: 2 faces x [a (16)][(field, b) 32]
   const int lane = threadIdx.x & 63;
   const int mi = lane & 15, mk = lane >> 4;
   const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;
@@ -1274,14 +1274,14 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
 __global__ __launch_bounds__(192) void trace_hp_mfma16_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
                                                               const HpMortar* __restrict__ md, const int* __restrict__ side_first,
                                                               const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
-                                                              const double* __restrict__ hp_ops, int n_elem) {
+                                                              const double* __restrict__ hp_ops, int n_elem, int max_n) {
   constexpr int LDM = 34;
   constexpr int UJ = 17, UK = 272;
   constexpr int TPB = 192;
   extern __shared__ __attribute__((aligned(16))) double smem16[];
   double* s_u = smem16;
   const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* stage = smem16 + 16 * UK + dir * (2 * 16 * LDM);
+  double* stage = smem16 + max_n * UK + dir * (2 * 16 * LDM);
   const int lane = threadIdx.x & 63;
   const int mi = lane & 15, mk = lane >> 4;
   const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;
@@ -2242,10 +2242,10 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
   const int n = plan->n_elements;
   if (n == 0) return;
   if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
-    const size_t lds = (size_t)(16 * 272 + 3 * 2 * 16 * 34) * sizeof(double);
+    const size_t lds = (size_t)(fh.hp_max_N * 272 + 3 * 2 * 16 * 34) * sizeof(double);
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(trace_hp_mfma16_kernel, dim3(std::min(n, 4 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), lds, plan->stream, u, trace,
-                       fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, n);
+                       fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, n, fh.hp_max_N);
   } else if (fh.hp) {
     const size_t lds = fh.hp_lds_doubles * sizeof(double);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2267,10 +2267,14 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
                          (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, fh.uni);
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     // p = 8 .. 15: tiled MFMA trace kernel (descriptors with unpadded N x N derivative matrices)
-    const size_t lds = (size_t)(16 * 272 + 3 * 2 * 16 * 34) * sizeof(double);
+    // only local elements are copied to LDS: size the copy of u by the largest LOCAL degree
+    int max_local_n = 1;
+    for (int e = 0; e < plan->n_elements; ++e) max_local_n = std::max(max_local_n, plan->deg[e] + 1);
+    const size_t lds = (size_t)(max_local_n * 272 + 3 * 2 * 16 * 34) * sizeof(double);
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(n, 4 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), lds, plan->stream, u, trace,
-                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n);
+    const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+    hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(n, per_cu * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), lds, plan->stream, u, trace,
+                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n, max_local_n);
   } else {
     const size_t lds = generic_lds_bytes(plan);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
