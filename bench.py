@@ -95,17 +95,19 @@ def main():
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)   # one rank per GPU; the modulo only matters for rehearsals on smaller boxes
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("D4EST_BENCH_BACKEND", "nccl")   # nccl = RCCL over xGMI; "gloo" only to rehearse the N > 1 path on one GPU
         try:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend=backend, device_id=dev) if backend == "nccl" else dist.init_process_group(backend=backend)
         except TypeError:  # older signature without device_id
-            dist.init_process_group(backend="nccl")
+            dist.init_process_group(backend=backend)
         dist.barrier()
     # the library normally travels pre-built; if the sources look newer, rank 0 rebuilds and everybody waits
     if build.needs_build() and rank == 0:
