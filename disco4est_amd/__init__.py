@@ -9,5 +9,6 @@ fails to load, importing :mod:`disco4est_amd.capi` raises.
 """
 from .capi import Plan, Transfer, load_library, table, TABLE  # noqa: F401
 from . import mesh  # noqa: F401
+from .schwarz import Schwarz, SchwarzMetadata  # noqa: F401
 
-__all__ = ["Plan", "Transfer", "load_library", "table", "TABLE", "mesh"]
+__all__ = ["Plan", "Transfer", "Schwarz", "SchwarzMetadata", "load_library", "table", "TABLE", "mesh"]

@@ -16,6 +16,7 @@ SOURCES = [
     "d4est_hip_faces.hip",
     "d4est_hip_solver.hip",
     "d4est_hip_transfer.hip",
+    "d4est_hip_schwarz.hip",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

@@ -61,6 +61,15 @@ SIGNATURES = {
     "d4est_hip_transfer_fine_nodes": (ctypes.c_longlong, [_vp]),
     "d4est_hip_transfer_prolong": (None, [_vp, _vp, _vp]),
     "d4est_hip_transfer_restrict": (None, [_vp, _vp, _vp]),
+    "d4est_hip_schwarz_create": (_vp, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "d4est_hip_schwarz_destroy": (None, [_vp]),
+    "d4est_hip_schwarz_nodal_size": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_schwarz_restricted_nodal_size": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_schwarz_restrict_field": (None, [_vp, _vp, _vp]),
+    "d4est_hip_schwarz_apply_over_subdomains": (None, [_vp, _vp, _vp]),
+    "d4est_hip_schwarz_add_correction": (None, [_vp, _vp, _vp]),
+    "d4est_hip_schwarz_iterate": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_double]),
+    "d4est_hip_schwarz_get_info": (None, [_vp, _vp, _vp]),
     "d4est_hip_plan_set_sipg": (None, [_vp, ctypes.c_double, ctypes.c_int]),
     "d4est_hip_plan_set_mortar_geometry": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "d4est_hip_plan_set_dirichlet_values": (None, [_vp, _vp, ctypes.c_int]),

@@ -1,0 +1,189 @@
+"""Host side of the additive Schwarz smoother.
+
+Mirrors the reference's setup for it:
+  * ``SchwarzMetadata``  <->  d4est_solver_schwarz_metadata_init (src/Solver/d4est_solver_schwarz_metadata.c:186-405, :447-520):
+    one subdomain per local element = the core and every element that shares a face, an edge or a corner with it, sorted by
+    (tree, quadid); per subdomain element the ``faces`` that touch the core and the mirrored ``core_faces``.
+  * ``subdomain_sides``  <->  d4est_solver_schwarz_geometric_data_init (src/Solver/d4est_solver_schwarz_geometric_data.c): the mortar
+    list of every subdomain with its zero_and_skip flags, expressed as the side arrays of a *subdomain plan* (see
+    csrc/d4est_hip_schwarz.hip): neighbours inside the subdomain are the local copies, neighbours outside become ghost sides that the
+    smoother feeds with a zero trace; geometric factors are not copied, the strides alias the mesh's arrays.
+  * ``Schwarz``          <->  d4est_solver_schwarz_t + d4est_solver_schwarz_iterate (src/Solver/d4est_solver_schwarz.c:20-285).
+
+Conforming single-tree, single-rank meshes (``mesh.BrickMesh`` with uniform or mixed degrees).
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+
+_vp = ctypes.c_void_p
+
+
+class SchwarzMetadata:
+    """Flat d4est_solver_schwarz_metadata_t (src/Solver/d4est_solver_schwarz_metadata.h:19-62)."""
+
+    def __init__(self, mesh, sides, num_nodes_overlap):
+        ne = mesh.n_elements
+        if num_nodes_overlap <= 0:
+            raise ValueError("num_nodes_overlap <= 0")                      # d4est_solver_schwarz_metadata.c:166-168
+        if num_nodes_overlap == 1:
+            # overlap_size = 1 - r[deg] = 0: the hat weights (d4est_solver_schwarz_operators.c:27-40) are 0/0 at the element ends
+            raise ValueError("num_nodes_overlap = 1 gives a zero-width weight ramp")
+        if num_nodes_overlap > int(mesh.deg.min()) + 1:
+            raise ValueError("num_nodes_overlap exceeds the minimum mesh degree + 1")   # metadata.h:69-70
+        if "side_hang" in sides and np.any(np.asarray(sides["side_hang"]) != 0):
+            raise NotImplementedError("Schwarz subdomains on hanging faces are not built")
+        nbr = np.asarray(sides["side_nbr"]).reshape(ne, 6)
+        if np.any(nbr <= -2):
+            raise NotImplementedError("Schwarz subdomains across ranks are not built (single-rank meshes only)")
+        self.num_nodes_overlap = int(num_nodes_overlap)
+        self.num_subdomains = ne
+        core_l, elem_l, faces_l = [np.arange(ne)], [np.arange(ne)], [np.full((ne, 3), -1, dtype=np.int32)]
+        for oz in (-1, 0, 1):
+            for oy in (-1, 0, 1):
+                for ox in (-1, 0, 1):
+                    off = (ox, oy, oz)
+                    if off == (0, 0, 0):
+                        continue
+                    idx = np.arange(ne)
+                    valid = np.ones(ne, dtype=bool)
+                    for d in range(3):                       # walk face neighbours direction by direction (conforming mesh)
+                        if off[d] == 0:
+                            continue
+                        nxt = nbr[idx, 2 * d + (1 if off[d] > 0 else 0)]
+                        valid &= nxt >= 0
+                        idx = np.where(valid, nxt, 0)
+                    # faces of the subdomain element that touch the core: the side facing back (ascending like p8est_edge_faces /
+                    # p8est_corner_faces, metadata.c:336-372); an element to the right of the core touches it with its "-" face
+                    fc = [2 * d + (0 if off[d] > 0 else 1) for d in range(3) if off[d] != 0]
+                    fc = fc + [-1] * (3 - len(fc))
+                    sel = np.nonzero(valid)[0]
+                    core_l.append(sel)
+                    elem_l.append(idx[sel])
+                    faces_l.append(np.tile(np.array(fc, dtype=np.int32), (sel.size, 1)))
+        core = np.concatenate(core_l)
+        elem = np.concatenate(elem_l)
+        faces = np.concatenate(faces_l)
+        order = np.lexsort((elem, core))                     # per subdomain sorted by (tree, quadid) = local Morton id (:447-455)
+        core, elem, faces = core[order], elem[order], faces[order]
+        self.sub_first = np.concatenate([[0], np.cumsum(np.bincount(core, minlength=ne))]).astype(np.int32)
+        self.sub_core = core.astype(np.int32)
+        self.sub_elem = elem.astype(np.int32)
+        self.sub_faces = np.ascontiguousarray(faces, dtype=np.int32)
+        self.sub_core_faces = np.where(self.sub_faces >= 0, self.sub_faces ^ 1, -1).astype(np.int32)   # get_mirrored_face (:379-385)
+        self.num_elements = int(elem.size)
+        n1 = mesh.deg[elem].astype(np.int64) + 1
+        res = np.where(self.sub_faces >= 0, self.num_nodes_overlap, n1[:, None])
+        self.elem_restricted_nodal_size = res.prod(axis=1)
+        self.elem_nodal_size = n1 ** 3
+        self.nodal_size = int(self.elem_nodal_size.sum())
+        self.restricted_nodal_size = int(self.elem_restricted_nodal_size.sum())
+
+    def subdomain(self, i):
+        a, b = int(self.sub_first[i]), int(self.sub_first[i + 1])
+        return self.sub_elem[a:b], self.sub_faces[a:b], self.sub_core_faces[a:b]
+
+
+def subdomain_sides(mesh, sides, md):
+    """Side arrays of the subdomain plan (same keys as BrickMesh.build_sides, geometry arrays shared with the mesh)."""
+    ne = mesh.n_elements
+    nv = md.num_elements
+    # position of mesh element e inside subdomain s: binary search in the sorted keys s * ne + e
+    key = md.sub_core.astype(np.int64) * ne + md.sub_elem.astype(np.int64)
+    nbr_mesh = np.asarray(sides["side_nbr"]).reshape(ne, 6)[md.sub_elem]             # (nv, 6) neighbours of the originals
+    want = md.sub_core.astype(np.int64)[:, None] * ne + np.clip(nbr_mesh, 0, None)
+    loc = np.searchsorted(key, want)
+    loc_c = np.clip(loc, 0, nv - 1)
+    inside = (nbr_mesh >= 0) & (key[loc_c] == want)
+    # outside neighbours: one ghost "element" per (deg, deg_quad) pair that occurs; its trace is never computed, only sized
+    dq_pairs = {}
+    ghost_deg, ghost_deg_quad = [], []
+    side_nbr = np.full((nv, 6), -1, dtype=np.int32)
+    side_nbr[inside] = loc_c[inside]
+    out = (nbr_mesh >= 0) & ~inside
+    if out.any():
+        od, oq = mesh.deg[nbr_mesh[out]], mesh.deg_quad[nbr_mesh[out]]
+        codes = np.empty(od.size, dtype=np.int32)
+        for i, (a, b) in enumerate(zip(od.tolist(), oq.tolist())):
+            if (a, b) not in dq_pairs:
+                dq_pairs[(a, b)] = len(ghost_deg)
+                ghost_deg.append(a)
+                ghost_deg_quad.append(b)
+            codes[i] = -(dq_pairs[(a, b)] + 2)
+        side_nbr[out] = codes
+    rep = lambda k: np.asarray(sides[k]).reshape(ne, 6)[md.sub_elem].reshape(-1).astype(np.int32)
+    vs = dict(sides)
+    vs.update(side_nbr=side_nbr.reshape(-1), side_nbr_face=rep("side_nbr_face"), side_reorder=rep("side_reorder"),
+              side_mortar_stride=rep("side_mortar_stride"), side_bndry_stride=rep("side_bndry_stride"),
+              ghost_deg=np.asarray(ghost_deg, dtype=np.int32), ghost_deg_quad=np.asarray(ghost_deg_quad, dtype=np.int32))
+    for k in ("side_hang", "side_sub", "side_nbr4", "side_orientation"):
+        vs.pop(k, None)
+    return vs
+
+
+class Schwarz:
+    """d4est_solver_schwarz_t on the device: metadata + subdomain plan + the native smoother handle."""
+
+    def __init__(self, mesh, sides, J_quad, rst_xyz_quad, num_nodes_overlap, subdomain_iter, subdomain_atol, subdomain_rtol,
+                 penalty_prefactor=10.0, penalty_fcn=0, stream=None):
+        self.lib = capi.load_library()
+        self.metadata = md = SchwarzMetadata(mesh, sides, num_nodes_overlap)
+        self.subdomain_iter, self.subdomain_atol, self.subdomain_rtol = int(subdomain_iter), float(subdomain_atol), float(subdomain_rtol)
+        e = md.sub_elem
+        vdeg, vdegq = mesh.deg[e], mesh.deg_quad[e]
+        vstride = np.concatenate([[0], np.cumsum(md.elem_nodal_size)[:-1]])
+        if md.nodal_size > 0x7fffffff:
+            raise ValueError("field over the subdomains exceeds 32-bit strides")
+        self.plan = capi.Plan(vdeg, vdegq, vstride.astype(np.int32), mesh.quad_stride[e], quad_type=mesh.quad_type, stream=stream)
+        self.plan.set_geometry(J_quad, rst_xyz_quad)                      # the mesh's own arrays: quad_stride aliases them
+        self.plan.set_faces(subdomain_sides(mesh, sides, md), penalty_prefactor, penalty_fcn)
+        self.plan.set_dirichlet_values(None)                              # the correction has homogeneous boundary data
+        self._keep = [capi._iarr(a) for a in (md.sub_first, md.sub_elem, md.sub_faces.reshape(-1), md.sub_core_faces.reshape(-1),
+                                              mesh.deg, mesh.nodal_stride)]
+        k = self._keep
+        self.handle = self.lib.d4est_hip_schwarz_create(self.plan.handle, md.num_subdomains, k[0][1], k[1][1], k[2][1], k[3][1],
+                                                        md.num_nodes_overlap, mesh.n_elements, k[4][1], k[5][1])
+        self.nodal_size = self.lib.d4est_hip_schwarz_nodal_size(self.handle)
+        self.restricted_nodal_size = self.lib.d4est_hip_schwarz_restricted_nodal_size(self.handle)
+        assert self.nodal_size == md.nodal_size and self.restricted_nodal_size == md.restricted_nodal_size
+        self.local_nodes = mesh.local_nodes
+
+    def restrict_field(self, field, out):
+        assert field.numel() == self.local_nodes and out.numel() == self.nodal_size
+        self.lib.d4est_hip_schwarz_restrict_field(self.handle, capi._ptr(field), capi._ptr(out))
+
+    def apply_over_subdomains(self, x, out):
+        assert x.numel() == self.nodal_size and out.numel() == self.nodal_size
+        self.lib.d4est_hip_schwarz_apply_over_subdomains(self.handle, capi._ptr(x), capi._ptr(out))
+
+    def add_correction(self, du, u):
+        assert du.numel() == self.nodal_size and u.numel() == self.local_nodes
+        self.lib.d4est_hip_schwarz_add_correction(self.handle, capi._ptr(du), capi._ptr(u))
+
+    def iterate(self, u, r):
+        """u += Schwarz correction of the residual r (d4est_solver_schwarz_iterate); returns the number of batched CG sweeps"""
+        assert u.numel() == self.local_nodes and r.numel() == self.local_nodes
+        return self.lib.d4est_hip_schwarz_iterate(self.handle, capi._ptr(u), capi._ptr(r), self.subdomain_iter, self.subdomain_atol,
+                                                  self.subdomain_rtol)
+
+    def info(self):
+        it = np.zeros(self.metadata.num_subdomains, dtype=np.int32)
+        res = np.zeros(self.metadata.num_subdomains)
+        self.lib.d4est_hip_schwarz_get_info(self.handle, it.ctypes.data_as(_vp), res.ctypes.data_as(_vp))
+        return it, res
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            self.lib.d4est_hip_schwarz_destroy(self.handle)
+            self.handle = None
+        if getattr(self, "plan", None) is not None:
+            self.plan.destroy()
+            self.plan = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

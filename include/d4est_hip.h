@@ -290,6 +290,48 @@ void d4est_hip_transfer_prolong(d4est_hip_transfer_t* t, const double* x_coarse_
 /* x_coarse = P^T x_fine (d4est_operators_apply_p_prolong_transpose / _hp_prolong_transpose per item; overwrites x_coarse) */
 void d4est_hip_transfer_restrict(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev);
 
+/* ---- additive Schwarz smoother ------------------------------------------------------------
+ * Replaces d4est_solver_schwarz_iterate (src/Solver/d4est_solver_schwarz.c:172-285) with its CG subdomain solver
+ * (src/Solver/d4est_solver_schwarz_subdomain_solver_cg.c:101-249) and the Laplacian subdomain operator
+ * (src/Solver/d4est_solver_schwarz_laplacian_ext.c:167-358), all subdomains of the rank at once.
+ *
+ * Metadata in the reference's terms (src/Solver/d4est_solver_schwarz_metadata.h:19-62), flattened: subdomain i owns the entries
+ * [sub_first[i], sub_first[i+1]) of sub_elem (local element id of each subdomain element, sorted by (tree, quadid) like
+ * d4est_solver_schwarz_metadata.c:447-455), sub_faces[3k..3k+2] (element_metadata.faces: the faces of the subdomain element that
+ * touch the core, -1 = none; all -1 on the core) and sub_core_faces[3k..3k+2] (element_metadata.core_faces, the mirrored faces).
+ * num_nodes_overlap is the [d4est_solver_schwarz] input of that name (1 .. min deg + 1).
+ *
+ * subdomain_plan is a plan whose elements are the subdomain elements in that order (deg / deg_quad of the mesh element; quad_stride
+ * and the mortar strides of the mesh element, so the geometric factors are the mesh's own arrays; neighbours = the copies inside the
+ * same subdomain; a face whose neighbour is outside the subdomain = a ghost side, which the smoother feeds with a zero trace: the
+ * reference's zero_and_skip rule, src/dGMath/d4est_laplacian_flux.c:486-520, :944-962; domain boundary = -1 with homogeneous
+ * Dirichlet data).  disco4est_amd/schwarz.py builds it; the plan stays owned by the caller and must outlive the handle.
+ * Conforming single-rank meshes (hanging faces and off-rank subdomain elements abort in the builder). */
+typedef struct d4est_hip_schwarz d4est_hip_schwarz_t;
+d4est_hip_schwarz_t* d4est_hip_schwarz_create(d4est_hip_plan_t* subdomain_plan, int n_subdomains, const int* sub_first,
+                                              const int* sub_elem, const int* sub_faces, const int* sub_core_faces,
+                                              int num_nodes_overlap, int n_mesh_elements, const int* mesh_deg,
+                                              const int* mesh_nodal_stride);
+void d4est_hip_schwarz_destroy(d4est_hip_schwarz_t* sz);
+/* schwarz_metadata->nodal_size / ->restricted_nodal_size (d4est_solver_schwarz_metadata.c:459-520) */
+long long d4est_hip_schwarz_nodal_size(const d4est_hip_schwarz_t* sz);
+long long d4est_hip_schwarz_restricted_nodal_size(const d4est_hip_schwarz_t* sz);
+/* d4est_solver_schwarz_convert_nodal_field_to_restricted_field_over_subdomains (src/Solver/d4est_solver_schwarz_helpers.c:123-155).
+ * Fields over the subdomains have nodal_size entries (whole elements); the restricted field is stored in place, zero outside the
+ * overlap nodes (restrict-transpose, helpers.c:210-239, is then the identity). */
+void d4est_hip_schwarz_restrict_field(d4est_hip_schwarz_t* sz, const double* field_dev, double* out_over_subdomains_dev);
+/* d4est_solver_schwarz_laplacian_ext_apply_over_subdomain for every subdomain: out = R A R^T in (in must be zero outside the overlap) */
+void d4est_hip_schwarz_apply_over_subdomains(d4est_hip_schwarz_t* sz, const double* in_dev, double* out_dev);
+/* d4est_solver_schwarz_compute_correction + ..._add_corrections (helpers.c:421-451, transfer_ghost_data.c:97-120):
+ * u += sum over subdomains of weights * du, added in ascending subdomain order */
+void d4est_hip_schwarz_add_correction(d4est_hip_schwarz_t* sz, const double* du_over_subdomains_dev, double* u_dev);
+/* d4est_solver_schwarz_iterate: u += correction of the residual r = rhs - A u (both mesh vectors on the device); the three
+ * [d4est_solver_schwarz] CG options as arguments.  Returns the number of batched CG sweeps (= the largest iteration count). */
+int d4est_hip_schwarz_iterate(d4est_hip_schwarz_t* sz, double* u_dev, const double* r_dev, int subdomain_iter, double subdomain_atol,
+                              double subdomain_rtol);
+/* schwarz->subdomain_solve_iterations / _residuals of the last iterate (d4est_solver_schwarz.c:259-260), host arrays of n_subdomains */
+void d4est_hip_schwarz_get_info(d4est_hip_schwarz_t* sz, int* final_iter_host, double* final_res_host);
+
 #ifdef __cplusplus
 }
 #endif

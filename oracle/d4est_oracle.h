@@ -157,6 +157,23 @@ void oracle_cheby_iterate_aux(double* u, const double* rhs, double* Au, double* 
                               int compute_residual_at_end);                     /* d4est_solver_multigrid_smoother_cheby.c:81-176 */
 void oracle_cg_eigs(double* u, const double* rhs, double* Au, int imax, int use_new, double* spectral_bound); /* d4est_solver_cg_eigs.c:116-275 */
 double oracle_gershgorin_bound(const double* alpha_h, const double* beta_h, int imax, int local_nodes, int use_new);
+void oracle_apply_lhs(const double* u, double* Au);   /* the registered operator, homogeneous Dirichlet data */
+void oracle_operator_info(int* n_elements, const int** deg, const int** nodal_stride, int* local_nodes);
+
+/* ---- additive Schwarz smoother (oracle/d4est_oracle_schwarz.c) ----
+ * Subdomain metadata in flat form (Solver/d4est_solver_schwarz_metadata.h:19-62): subdomain i owns the entries
+ * [sub_first[i], sub_first[i+1]) of sub_elem (local element ids, sorted by (tree, quadid) as :447-455 does), sub_faces[3*k..] (faces of
+ * that element touching the core, -1 = none) and sub_core_faces[3*k..] (the mirrored faces of the core). */
+void oracle_schwarz_build_restrictor_1d(double* restrictor_1d, int deg, int restricted_size);  /* d4est_solver_schwarz_operators.c:42-60 */
+void oracle_schwarz_build_weights_1d(double* weights_1d, int deg, int restricted_size);        /* :78-105 */
+int oracle_schwarz_restricted_nodes(const int* faces, int deg, int restricted_size);           /* d4est_solver_schwarz_metadata.c:497-506 */
+void oracle_schwarz_apply_restrictor(const double* in, const int* faces, int deg, int restricted_size, int transpose, double* out); /* :170-262 */
+void oracle_schwarz_apply_weights(const double* in, const int* core_faces, int deg, int restricted_size, double* out);               /* :334-397 */
+void oracle_schwarz_apply_over_subdomain(int n_sub_elements, const int* elem, const int* faces, int restricted_size,
+                                         const double* u_restricted, double* Au_restricted);   /* d4est_solver_schwarz_laplacian_ext.c:167-358 */
+void oracle_schwarz_iterate(int n_subdomains, const int* sub_first, const int* sub_elem, const int* sub_faces,
+                            const int* sub_core_faces, int restricted_size, int subdomain_iter, double subdomain_atol,
+                            double subdomain_rtol, double* u, const double* r, int* final_iter, double* final_res); /* d4est_solver_schwarz.c:172-285 */
 
 #ifdef __cplusplus
 }

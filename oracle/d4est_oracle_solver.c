@@ -47,6 +47,12 @@ void oracle_set_aij_operator(int quad_type, int n_elements, const int* deg, cons
 }
 
 /* apply_lhs: Au = A u with homogeneous Dirichlet data (single rank: no ghosts) */
+static void apply_lhs(const double* u, double* Au);
+void oracle_apply_lhs(const double* u, double* Au) { apply_lhs(u, Au); }
+void oracle_operator_info(int* n_elements, const int** deg, const int** nodal_stride, int* local_nodes) {
+  if (!g_op.set) { fprintf(stderr, "[ORACLE_ABORT] operator not set\n"); abort(); }
+  *n_elements = g_op.n_elements; *deg = g_op.deg; *nodal_stride = g_op.nodal_stride; *local_nodes = g_op.local_nodes;
+}
 static void apply_lhs(const double* u, double* Au) {
   if (!g_op.set) { fprintf(stderr, "[ORACLE_ABORT] operator not set\n"); abort(); }
   double dummy = 0.;

@@ -264,6 +264,49 @@ class Oracle:
         f(P(u), P(np.ascontiguousarray(rhs)), P(Au), imax, use_new, ctypes.byref(bound))
         return bound.value, u
 
+    # ---- additive Schwarz (oracle/d4est_oracle_schwarz.c); operator from set_operator()
+    def schwarz_restrictor_1d(self, deg, rs):
+        R = np.zeros((2, rs, deg + 1))
+        self.lib.oracle_schwarz_build_restrictor_1d(P(R), deg, rs)
+        return R
+
+    def schwarz_weights_1d(self, deg, rs):
+        w = np.zeros(2 * rs + deg + 1)
+        self.lib.oracle_schwarz_build_weights_1d(P(w), deg, rs)
+        return w
+
+    def schwarz_apply_restrictor(self, x, faces, deg, rs, transpose=False):
+        faces = np.ascontiguousarray(faces, dtype=np.int32)
+        n_res = self.lib.oracle_schwarz_restricted_nodes(I(faces), deg, rs)
+        out = np.zeros((deg + 1) ** 3 if transpose else n_res)
+        self.lib.oracle_schwarz_apply_restrictor(P(np.ascontiguousarray(x, dtype=np.float64)), I(faces), deg, rs, int(transpose), P(out))
+        return out
+
+    def schwarz_apply_weights(self, x, core_faces, deg, rs):
+        core_faces = np.ascontiguousarray(core_faces, dtype=np.int32)
+        out = np.zeros_like(x)
+        self.lib.oracle_schwarz_apply_weights(P(np.ascontiguousarray(x, dtype=np.float64)), I(core_faces), deg, rs, P(out))
+        return out
+
+    def schwarz_apply_over_subdomain(self, elem, faces, rs, u_res):
+        elem = np.ascontiguousarray(elem, dtype=np.int32); faces = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1)
+        out = np.zeros_like(u_res)
+        self.lib.oracle_schwarz_apply_over_subdomain(len(elem), I(elem), I(faces), rs, P(np.ascontiguousarray(u_res)), P(out))
+        return out
+
+    def schwarz_iterate(self, md, u, r, subdomain_iter, atol, rtol):
+        """md: flat metadata (sub_first, sub_elem, sub_faces, sub_core_faces, num_nodes_overlap); returns (u_new, final_iter, final_res)"""
+        u = u.copy()
+        n = len(md.sub_first) - 1
+        it = np.zeros(n, dtype=np.int32); res = np.zeros(n)
+        f = self.lib.oracle_schwarz_iterate
+        f.argtypes = [ctypes.c_int, ip, ip, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp, dp, ip, dp]
+        sf = np.ascontiguousarray(md.sub_faces, dtype=np.int32).reshape(-1)
+        sc = np.ascontiguousarray(md.sub_core_faces, dtype=np.int32).reshape(-1)
+        f(n, I(np.ascontiguousarray(md.sub_first, dtype=np.int32)), I(np.ascontiguousarray(md.sub_elem, dtype=np.int32)), I(sf), I(sc),
+          int(md.num_nodes_overlap), int(subdomain_iter), float(atol), float(rtol), P(u), P(np.ascontiguousarray(r)), I(it), P(res))
+        return u, it, res
+
     def compute_dudr(self, mesh, u):
         d = [np.zeros(mesh.local_nodes) for _ in range(3)]
         self.lib.oracle_laplacian_compute_dudr(mesh.n_elements, I(mesh.deg), I(mesh.nodal_stride), P(u), P(d[0]), P(d[1]), P(d[2]))

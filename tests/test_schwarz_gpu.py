@@ -1,0 +1,200 @@
+"""GPU parity tests of the batched additive Schwarz smoother (csrc/d4est_hip_schwarz.hip, disco4est_amd/schwarz.py) against the
+oracle's serial restatement of d4est_solver_schwarz_iterate (oracle/d4est_oracle_schwarz.c).  Tolerances (fp64): the restriction is
+a copy and must be bit-exact; the weighted correction follows the reference's order of additions and is compared at 2e-15 absolute
+on O(1) data (the hat weights come from two independent node tables); the subdomain operator is compared at 1e-12 relative to the largest entry; a whole Schwarz iteration runs several CG iterations per
+subdomain on differently rounded operators, so it is compared at 1e-9."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _setup(level, deg, curved, rs, oracle, iters=200, atol=1e-15, rtol=1e-15, deg_quad_inc=0):
+    from disco4est_amd import mesh as M
+    from disco4est_amd.schwarz import Schwarz
+    m = M.BrickMesh(level, deg, deg_quad_inc=deg_quad_inc)
+    mp = M.SineMap(0.04) if curved else None
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    oracle.set_operator(m, J, rst, sides, 10.0, 0, threads=1)
+    sz = Schwarz(m, sides, J, rst, rs, iters, atol, rtol, 10.0, 0)
+    return m, J, rst, sides, sz
+
+
+def _over_subdomains_to_restricted(oracle, m, md, x, s):
+    """restricted field of subdomain s (reference layout) out of a field over the subdomains"""
+    a, b = int(md.sub_first[s]), int(md.sub_first[s + 1])
+    off = np.concatenate([[0], np.cumsum(md.elem_nodal_size)])
+    return np.concatenate([oracle.schwarz_apply_restrictor(x[off[k]:off[k + 1]], md.sub_faces[k], int(m.deg[md.sub_elem[k]]),
+                                                           md.num_nodes_overlap) for k in range(a, b)])
+
+
+def _restricted_to_over_subdomains(oracle, m, md, xr, s, out):
+    a, b = int(md.sub_first[s]), int(md.sub_first[s + 1])
+    off = np.concatenate([[0], np.cumsum(md.elem_nodal_size)])
+    ro = 0
+    for k in range(a, b):
+        n = int(md.elem_restricted_nodal_size[k])
+        out[off[k]:off[k + 1]] = oracle.schwarz_apply_restrictor(xr[ro:ro + n], md.sub_faces[k], int(m.deg[md.sub_elem[k]]),
+                                                                  md.num_nodes_overlap, transpose=True)
+        ro += n
+
+
+def _mixed(level, lo, hi):
+    n = 8 ** level
+    return lo + (np.arange(n) * 7 % (hi - lo + 1))
+
+
+@pytest.mark.parametrize("level,deg,curved,rs", [(1, 2, False, 2), (2, 3, True, 2), (2, "mixed", True, 3), (2, 4, False, 5)])
+def test_restriction_and_operator_parity(gpu, hiplib, oracle, level, deg, curved, rs):
+    import torch
+    from disco4est_amd import mesh as M
+    if deg == "mixed":
+        deg = _mixed(level, 2, 4)
+    m, J, rst, sides, sz = _setup(level, deg, curved, rs, oracle)
+    md = sz.metadata
+    field = M.splitmix64_uniform(21, m.local_nodes) - 0.5
+    x = torch.full((sz.nodal_size,), float("nan"), dtype=torch.float64, device=gpu)
+    sz.restrict_field(_t(field, gpu), x)
+    xh = x.cpu().numpy()
+    want = np.zeros(sz.nodal_size)
+    for s in range(md.num_subdomains):
+        elem, faces, _ = md.subdomain(s)
+        xr = np.concatenate([oracle.schwarz_apply_restrictor(field[m.nodal_stride[e]:m.nodal_stride[e] + (m.deg[e] + 1) ** 3], f,
+                                                             int(m.deg[e]), rs) for e, f in zip(elem, faces)])
+        _restricted_to_over_subdomains(oracle, m, md, xr, s, want)
+    np.testing.assert_array_equal(xh, want)                      # a copy: bit-exact
+    assert int(np.count_nonzero(want)) == md.restricted_nodal_size
+    Ax = torch.full_like(x, float("nan"))
+    sz.apply_over_subdomains(x, Ax)
+    Axh = Ax.cpu().numpy()
+    scale = np.abs(Axh).max()
+    check = range(md.num_subdomains) if md.num_subdomains <= 8 else (0, 7, 21, 22, 42, 63)
+    for s in check:
+        elem, faces, _ = md.subdomain(s)
+        ref = oracle.schwarz_apply_over_subdomain(elem, faces, rs, _over_subdomains_to_restricted(oracle, m, md, xh, s))
+        got = _over_subdomains_to_restricted(oracle, m, md, Axh, s)
+        assert np.abs(got - ref).max() <= 1e-12 * scale, (s, np.abs(got - ref).max() / scale)
+    # outside the overlap the result is exactly zero (it is a restricted field)
+    chk = np.zeros(sz.nodal_size)
+    for s in range(md.num_subdomains):
+        _restricted_to_over_subdomains(oracle, m, md, _over_subdomains_to_restricted(oracle, m, md, Axh, s), s, chk)
+    np.testing.assert_array_equal(chk, Axh)
+    sz.destroy()
+
+
+@pytest.mark.parametrize("level,deg,rs", [(1, 3, 2), (2, "mixed", 3)])
+def test_correction_parity(gpu, hiplib, oracle, level, deg, rs):
+    import torch
+    from disco4est_amd import mesh as M
+    if deg == "mixed":
+        deg = _mixed(level, 2, 4)
+    m, J, rst, sides, sz = _setup(level, deg, False, rs, oracle)
+    md = sz.metadata
+    du = torch.empty(sz.nodal_size, dtype=torch.float64, device=gpu)
+    sz.restrict_field(_t(M.splitmix64_uniform(31, m.local_nodes) - 0.5, gpu), du)
+    du *= _t(M.splitmix64_uniform(32, sz.nodal_size) + 0.5, gpu)          # different values in every subdomain
+    u0 = M.splitmix64_uniform(33, m.local_nodes)
+    u = _t(u0, gpu)
+    sz.add_correction(du, u)
+    duh = du.cpu().numpy()
+    want = u0.copy()
+    off = np.concatenate([[0], np.cumsum(md.elem_nodal_size)])
+    for k in range(md.num_elements):                 # ascending subdomain, then element: the reference's order of additions
+        e = int(md.sub_elem[k]); p = int(m.deg[e])
+        xr = oracle.schwarz_apply_restrictor(duh[off[k]:off[k + 1]], md.sub_faces[k], p, rs)
+        w = oracle.schwarz_apply_weights(xr, md.sub_core_faces[k], p, rs)
+        want[m.nodal_stride[e]:m.nodal_stride[e] + (p + 1) ** 3] += oracle.schwarz_apply_restrictor(w, md.sub_faces[k], p, rs, transpose=True)
+    np.testing.assert_allclose(u.cpu().numpy(), want, rtol=0, atol=2e-15)      # same order of additions; weights from two table builders
+    # partition of unity: the same du = 1 in every subdomain adds exactly one to u away from the domain boundary
+    if level == 2:
+        ones = torch.empty(sz.nodal_size, dtype=torch.float64, device=gpu)
+        sz.restrict_field(torch.ones(m.local_nodes, dtype=torch.float64, device=gpu), ones)
+        u1 = torch.zeros(m.local_nodes, dtype=torch.float64, device=gpu)
+        sz.add_correction(ones, u1)
+        interior = np.nonzero(np.all((m.ijk >= 1) & (m.ijk <= 2), axis=1))[0]
+        for e in interior:
+            blk = u1.cpu().numpy()[m.nodal_stride[e]:m.nodal_stride[e] + (m.deg[e] + 1) ** 3]
+            np.testing.assert_allclose(blk, 1.0, rtol=0, atol=1e-14)
+    sz.destroy()
+
+
+@pytest.mark.parametrize("level,deg,curved,rs,iters,rtol", [(1, 3, True, 2, 6, 1e-15), (2, 2, False, 2, 60, 3e-2), (2, "mixed", True, 2, 5, 1e-15)])
+def test_iterate_parity(gpu, hiplib, oracle, level, deg, curved, rs, iters, rtol):
+    """one d4est_solver_schwarz_iterate: same correction, same per-subdomain iteration counts and residuals as the serial oracle"""
+    from disco4est_amd import mesh as M
+    if deg == "mixed":
+        deg = _mixed(level, 2, 3)
+    m, J, rst, sides, sz = _setup(level, deg, curved, rs, oracle, iters, 1e-15, rtol)
+    u0 = M.splitmix64_uniform(41, m.local_nodes) - 0.5
+    rhs = M.splitmix64_uniform(42, m.local_nodes) - 0.5
+    r = rhs - oracle.apply_aij(m, J, rst, sides, u0)
+    u_ref, it_ref, res_ref = oracle.schwarz_iterate(sz.metadata, u0, r, iters, 1e-15, rtol)
+    u = _t(u0, gpu)
+    sweeps = sz.iterate(u, _t(r, gpu))
+    it, res = sz.info()
+    assert _rel(u.cpu().numpy() - u0, u_ref - u0) <= 1e-9
+    np.testing.assert_array_equal(it, it_ref)
+    np.testing.assert_allclose(res, res_ref, rtol=1e-6, atol=1e-13 * np.abs(r).max())
+    assert sweeps == min(iters, int(it_ref.max()) + 1)
+    if rtol > 1e-10:
+        assert it_ref.min() < iters                 # the loose tolerance really made subdomains leave their loop early
+    sz.destroy()
+
+
+def test_schwarz_as_a_solver(gpu, hiplib, oracle):
+    """u <- u + Schwarz(rhs - A u) entirely on the device (the loop of d4est_test_schwarz_cubic_new.c:363-470): the residual
+    drops at every iteration; p = 4 on 64 elements, overlap 3"""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    m, J, rst, sides, sz = _setup(2, 4, True, 3, oracle, 60, 1e-15, 1e-8)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan.set_geometry(J, rst)
+    plan.set_faces(sides, 10.0, 0)
+    u_exact = _t(M.splitmix64_uniform(51, m.local_nodes) - 0.5, gpu)
+    rhs = torch.empty_like(u_exact); Au = torch.empty_like(u_exact)
+    plan.apply_aij(u_exact, rhs)
+    u = torch.zeros_like(u_exact)
+    hist = [float(rhs.norm())]
+    for _ in range(5):
+        plan.apply_aij(u, Au)
+        r = rhs - Au
+        sz.iterate(u, r)
+        plan.apply_aij(u, Au)
+        hist.append(float((rhs - Au).norm()))
+    assert all(b < 0.7 * a for a, b in zip(hist[:-1], hist[1:])), hist
+    assert float((u - u_exact).norm()) < 0.1 * float(u_exact.norm())
+    it, res = sz.info()
+    assert it.min() >= 1 and it.max() <= 60 and np.all(np.isfinite(res))
+    sz.destroy()
+
+
+def test_schwarz_p7_subdomains(gpu, hiplib, oracle):
+    """p = 7 (the wave flux kernel + stiffness_wave_eo on the subdomain plan): operator parity on sampled subdomains, one iterate"""
+    import torch
+    from disco4est_amd import mesh as M
+    m, J, rst, sides, sz = _setup(2, 7, False, 4, oracle, 3, 1e-15, 1e-15)
+    md = sz.metadata
+    assert sz.nodal_size == (8 * 8 + 24 * 12 + 24 * 18 + 8 * 27) * 512
+    x = torch.empty(sz.nodal_size, dtype=torch.float64, device=gpu)
+    sz.restrict_field(_t(M.splitmix64_uniform(61, m.local_nodes) - 0.5, gpu), x)
+    Ax = torch.empty_like(x)
+    sz.apply_over_subdomains(x, Ax)
+    xh, Axh = x.cpu().numpy(), Ax.cpu().numpy()
+    scale = np.abs(Axh).max()
+    for s in (0, 21):
+        elem, faces, _ = md.subdomain(s)
+        ref = oracle.schwarz_apply_over_subdomain(elem, faces, 4, _over_subdomains_to_restricted(oracle, m, md, xh, s))
+        assert np.abs(_over_subdomains_to_restricted(oracle, m, md, Axh, s) - ref).max() <= 1e-12 * scale
+    u = torch.zeros(m.local_nodes, dtype=torch.float64, device=gpu)
+    assert sz.iterate(u, _t(M.splitmix64_uniform(62, m.local_nodes) - 0.5, gpu)) == 3
+    assert bool(torch.isfinite(u).all()) and float(u.abs().max()) > 0
+    sz.destroy()
