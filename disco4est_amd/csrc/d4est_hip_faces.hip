@@ -1891,6 +1891,9 @@ void faces_setup(d4est_hip_plan* plan) {
     }
   }
   long long qoff = 0, goff = 0;
+  // D4EST_HIP_TUNE_GHOST_ALIAS: every ghost side reads block 0 (a constant ghost trace, e.g. the zero trace of a Schwarz subdomain plan)
+  const bool ghost_alias = plan->tuning[D4EST_HIP_TUNE_GHOST_ALIAS] > 0 && !hp;
+  long long ghost_alias_len = 0;
   int maxN = 1, maxNQ = 1, max_fld = 1;
   bool fast = true;
   for (int e = 0; e < ne; ++e) maxN = std::max(maxN, plan->deg[e] + 1);
@@ -1958,7 +1961,8 @@ void faces_setup(d4est_hip_plan* plan) {
         gs.u_off = ghost_u_off[g];
         gs.goff = goff;
         gsides.push_back(gs);
-        goff += 4LL * (deg_mq + 1) * (deg_mq + 1);
+        if (ghost_alias) ghost_alias_len = std::max(ghost_alias_len, 4LL * (deg_mq + 1) * (deg_mq + 1));
+        else goff += 4LL * (deg_mq + 1) * (deg_mq + 1);
       }
       sd[s] = d;
       fh.side_deg_m[s] = deg_m;
@@ -1966,7 +1970,7 @@ void faces_setup(d4est_hip_plan* plan) {
       max_fld = std::max(max_fld, std::max(d.NQ * d.NQ, d.NQ * (deg_m + 1)));
       max_fld = std::max(max_fld, d.NQ * (deg_p + 1));
     }
-  plan->ghost_trace_doubles = goff;   // (hanging plans: overwritten by faces_setup_hp)
+  plan->ghost_trace_doubles = ghost_alias ? ghost_alias_len : goff;   // (hanging plans: overwritten by faces_setup_hp)
   max_fld = std::max(max_fld, maxN * maxN);
   fh.fld_stride = max_fld;
   fh.max_N = maxN;
