@@ -52,6 +52,7 @@ SIGNATURES = {
     "d4est_hip_plan_set_faces": (None, [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _c_int_p, _c_int_p]),
     "d4est_hip_plan_set_hanging": (None, [_vp, _vp, _vp, _vp, _vp]),
+    "d4est_hip_plan_set_geometry_numerical": (None, [_vp, _vp, ctypes.c_int]),
     "d4est_hip_plan_set_geometry_brick": (None, [_vp, _vp, ctypes.c_double, _vp]),
     "d4est_hip_plan_set_mortar_geometry_brick": (None, [_vp, _vp, ctypes.c_double, _vp]),
     "d4est_hip_transfer_create": (_vp, [ctypes.c_int, _vp, _vp, _vp]),
@@ -191,6 +192,17 @@ class Plan:
         else:
             assert J_quad.numel() == self.local_nodes_quad and rst_xyz_quad.numel() == 9 * self.local_nodes_quad
             self.lib.d4est_hip_plan_set_geometry(self.handle, _ptr(J_quad), _ptr(rst_xyz_quad), 1)
+
+    def set_geometry_numerical(self, xyz_lobatto):
+        """GEOM_COMPUTE_NUMERICAL volume factors from the nodal coordinates: xyz_lobatto = (x, y, z) arrays of local_nodes entries
+        (numpy) or one torch CUDA tensor of 3*local_nodes entries"""
+        if isinstance(xyz_lobatto, (list, tuple)) or isinstance(xyz_lobatto, np.ndarray):
+            X = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1) for a in xyz_lobatto]))
+            assert X.size == 3 * self.local_nodes
+            self.lib.d4est_hip_plan_set_geometry_numerical(self.handle, X.ctypes.data_as(_vp), 0)
+        else:
+            assert xyz_lobatto.numel() == 3 * self.local_nodes
+            self.lib.d4est_hip_plan_set_geometry_numerical(self.handle, _ptr(xyz_lobatto), 1)
 
     def apply_stiffness_matrix(self, u, Au):
         assert u.numel() == self.local_nodes and Au.numel() == self.local_nodes

@@ -253,6 +253,25 @@ void d4est_hip_plan_set_geometry(d4est_hip_plan_t* plan, const double* J_quad, c
   plan->has_geometry = true;
 }
 
+void d4est_hip_plan_set_geometry_numerical(d4est_hip_plan_t* plan, const double* xyz_lobatto, int on_device) {
+  check_plan(plan, "plan_set_geometry_numerical");
+  if (!xyz_lobatto) D4EST_HIP_ABORT("plan_set_geometry_numerical: NULL coordinate array");
+  const size_t ln = (size_t)plan->local_nodes, nq = (size_t)plan->local_nodes_quad;
+  if (!plan->d_J) HIP_CHECK(hipMalloc(&plan->d_J, std::max<size_t>(nq, 1) * sizeof(double)));
+  if (!plan->d_metric) HIP_CHECK(hipMalloc(&plan->d_metric, std::max<size_t>(6 * nq, 1) * sizeof(double)));
+  const double* d_xyz = xyz_lobatto;
+  double* tmp = nullptr;
+  if (!on_device) {
+    HIP_CHECK(hipMalloc(&tmp, std::max<size_t>(3 * ln, 1) * sizeof(double)));
+    HIP_CHECK(hipMemcpy(tmp, xyz_lobatto, 3 * ln * sizeof(double), hipMemcpyHostToDevice));
+    d_xyz = tmp;
+  }
+  d4est_hip::launch_numerical_geometry(plan, d_xyz);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  if (tmp) HIP_CHECK(hipFree(tmp));
+  plan->has_geometry = true;
+}
+
 static int* upload_elem_dq(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents, const char* who) {
   if (plan->n_elements > 0 && !elem_dq) D4EST_HIP_ABORT("%s: elem_dq is NULL", who);
   if (!extents || !(root_len > 0.) || !(extents[1] > extents[0]) || !(extents[3] > extents[2]) || !(extents[5] > extents[4]))

@@ -133,6 +133,7 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
 // which: 0 quadrature interpolation, 1 inverse Gauss interpolation, 2 M (1-D mass), 3 M^-1
 void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out, const double* coeff = nullptr, int which = 0);
 void launch_brick_geometry(d4est_hip_plan* plan, const int* d_elem_dq, double root_len, const double* extents);
+void launch_numerical_geometry(d4est_hip_plan* plan, const double* d_xyz);
 void faces_set_geometry_brick(d4est_hip_plan* plan, const int* d_elem_dq, double root_len, const double* extents);
 void launch_slicer_lift(d4est_hip_plan* plan, const double* in, double* out, int face, int lift);
 void launch_dij(d4est_hip_plan* plan, const double* in, double* out, int dir, int transpose);

@@ -2685,6 +2685,49 @@ void launch_dij(d4est_hip_plan* plan, const double* in, double* out, int dir, in
   HIP_CHECK(hipGetLastError());
 }
 
+// J and d(rst)/d(xyz) out of d(xyz)/d(rst) at every quadrature node, in place: a[(3 i + j) nq + n] holds dx_i/dr_j on entry and
+// dr_i/dx_j on exit (the reference's rst_xyz_quad layout).  d4est_geometry_compute_jacobian / _drst_dxyz,
+// src/Geometry/d4est_geometry.c:877-976, same cofactor expressions.
+__global__ __launch_bounds__(256) void jacobian_inverse_kernel(double* __restrict__ a, double* __restrict__ jac, size_t nq) {
+  for (size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x; n < nq; n += (size_t)gridDim.x * blockDim.x) {
+    const double xr = a[0 * nq + n], xs = a[1 * nq + n], xt = a[2 * nq + n];
+    const double yr = a[3 * nq + n], ys = a[4 * nq + n], yt = a[5 * nq + n];
+    const double zr = a[6 * nq + n], zs = a[7 * nq + n], zt = a[8 * nq + n];
+    const double J = xr * (ys * zt - zs * yt) - yr * (xs * zt - zs * xt) + zr * (xs * yt - ys * xt);
+    jac[n] = J;
+    a[0 * nq + n] = (ys * zt - zs * yt) / J;    // rx
+    a[1 * nq + n] = -(xs * zt - zs * xt) / J;   // ry
+    a[2 * nq + n] = (xs * yt - ys * xt) / J;    // rz
+    a[3 * nq + n] = -(yr * zt - zr * yt) / J;   // sx
+    a[4 * nq + n] = (xr * zt - zr * xt) / J;    // sy
+    a[5 * nq + n] = -(xr * yt - yr * xt) / J;   // sz
+    a[6 * nq + n] = (yr * zs - zr * ys) / J;    // tx
+    a[7 * nq + n] = -(xr * zs - zr * xs) / J;   // ty
+    a[8 * nq + n] = (xr * ys - yr * xs) / J;    // tz
+  }
+}
+
+// GEOM_COMPUTE_NUMERICAL volume factors (src/Mesh/d4est_mesh.c:2637-2671): dx_d/dr_d1 = interpolate(D_d1 x_d) at the quadrature
+// nodes, then J and the inverse; d_xyz = x | y | z at the Lobatto nodes (3 local_nodes).  Fills plan->d_J and the metric.
+void launch_numerical_geometry(d4est_hip_plan* plan, const double* d_xyz) {
+  const size_t ln = (size_t)plan->local_nodes, nq = (size_t)plan->local_nodes_quad;
+  double *d_dr = nullptr, *d_a = nullptr;
+  HIP_CHECK(hipMalloc(&d_dr, std::max<size_t>(3 * ln, 1) * sizeof(double)));
+  HIP_CHECK(hipMalloc(&d_a, std::max<size_t>(9 * nq, 1) * sizeof(double)));
+  for (int d = 0; d < 3; ++d) {
+    launch_dudr(plan, d_xyz + d * ln, d_dr, d_dr + ln, d_dr + 2 * ln);
+    for (int d1 = 0; d1 < 3; ++d1) launch_mass_like(plan, 2, d_dr + d1 * ln, d_a + (size_t)(3 * d + d1) * nq);
+  }
+  if (nq > 0) {
+    const int grid = (int)std::min<size_t>((nq + 255) / 256, 65536);
+    hipLaunchKernelGGL(jacobian_inverse_kernel, dim3(grid), dim3(256), 0, plan->stream, d_a, plan->d_J, nq);
+    HIP_CHECK(hipGetLastError());
+  }
+  launch_metric_precombine(plan, plan->d_J, d_a);   // synchronises the stream
+  HIP_CHECK(hipFree(d_dr));
+  HIP_CHECK(hipFree(d_a));
+}
+
 void launch_metric_precombine(d4est_hip_plan* plan, const double* d_J, const double* d_rst) {
   if (!plan->d_metric_affine) {
     HIP_CHECK(hipMalloc(&plan->d_metric_affine, std::max<size_t>((size_t)6 * plan->n_elements, 1) * sizeof(double)));

@@ -101,6 +101,12 @@ int d4est_hip_plan_n_elements(const d4est_hip_plan_t* plan);
  * (6 entries per quadrature node, element-blocked); the inputs are not retained. */
 void d4est_hip_plan_set_geometry(d4est_hip_plan_t* plan, const double* J_quad, const double* rst_xyz_quad, int on_device);
 
+/* Volume factors with DX_compute_method = GEOM_COMPUTE_NUMERICAL (src/Mesh/d4est_mesh.c:2637-2671): the caller hands over only the
+ * physical coordinates of the Lobatto nodes, xyz_lobatto = x[local_nodes] | y[local_nodes] | z[local_nodes] (d4est_factors->xyz, any
+ * geometry: cubed sphere, disk, ...; 24 B/node instead of the 80 B per quadrature node of plan_set_geometry); the device forms
+ * dx_d/dr_d1 = interpolate(D_d1 x_d) at the quadrature nodes, J and dr/dx (src/Geometry/d4est_geometry.c:877-976) and the
+ * pre-combined metric.  Mortar factors still come through plan_set_mortar_geometry. */
+void d4est_hip_plan_set_geometry_numerical(d4est_hip_plan_t* plan, const double* xyz_lobatto, int on_device);
 /* Geometric factors generated ON THE DEVICE for the reference's `brick` geometry ([geometry] name = brick, X0..Z1;
  * src/Geometry/d4est_geometry_brick.c:140-206: dx_d/dr_d = (X1_d - X0_d) (dq / P4EST_ROOT_LEN) / 2, diagonal, constant per element) --
  * SURVEY.md section 8f rank 4, brick only.  Replaces d4est_hip_plan_set_geometry / _set_mortar_geometry on a brick: no J_quad /

@@ -850,3 +850,49 @@ void oracle_laplacian_compute_dudr(int n_elements, const int* deg, const int* no
   for (int e = 0; e < n_elements; e++)
     for (int i = 0; i < 3; i++) oracle_apply_dij(&u[nodal_stride[e]], deg[e], i, &d[i][nodal_stride[e]]);
 }
+
+/* ---- GEOM_COMPUTE_NUMERICAL volume factors: Mesh/d4est_mesh.c:2637-2671, Geometry/d4est_geometry.c:877-976 ----
+ * xyz = x | y | z at the Lobatto nodes (local_nodes each); outputs in the reference layout J_quad[quad_stride + n],
+ * rst_xyz_quad[(3 i + j) local_nodes_quad + quad_stride + n] = d r_i / d x_j. */
+void oracle_mesh_compute_geometry_numerical(int quad_type, int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
+                                            const int* quad_stride, int local_nodes, int local_nodes_quad, const double* xyz,
+                                            double* J_quad, double* rst_xyz_quad) {
+  for (int e = 0; e < n_elements; e++) {
+    int N = deg[e] + 1, NQ = deg_quad[e] + 1, volume_nodes = N * N * N, volume_nodes_quad = NQ * NQ * NQ;
+    double* tmp = (double*)malloc(sizeof(double) * volume_nodes);
+    double* xyz_rst_quad[3][3];
+    for (int d = 0; d < 3; d++)
+      for (int d1 = 0; d1 < 3; d1++) {
+        xyz_rst_quad[d][d1] = (double*)malloc(sizeof(double) * volume_nodes_quad);
+        oracle_apply_dij(&xyz[(size_t)d * local_nodes + nodal_stride[e]], deg[e], d1, tmp);
+        oracle_quadrature_interpolate(quad_type, tmp, deg[e], xyz_rst_quad[d][d1], deg_quad[e]);
+      }
+    double* jac = &J_quad[quad_stride[e]];
+    for (int i = 0; i < volume_nodes_quad; i++) { /* d4est_geometry_compute_jacobian */
+      double xr = xyz_rst_quad[0][0][i], xs = xyz_rst_quad[0][1][i], xt = xyz_rst_quad[0][2][i];
+      double yr = xyz_rst_quad[1][0][i], ys = xyz_rst_quad[1][1][i], yt = xyz_rst_quad[1][2][i];
+      double zr = xyz_rst_quad[2][0][i], zs = xyz_rst_quad[2][1][i], zt = xyz_rst_quad[2][2][i];
+      jac[i] = xr * (ys * zt - zs * yt) - yr * (xs * zt - zs * xt) + zr * (xs * yt - ys * xt);
+    }
+    for (int i = 0; i < volume_nodes_quad; i++) { /* d4est_geometry_compute_drst_dxyz */
+      double xr = xyz_rst_quad[0][0][i], xs = xyz_rst_quad[0][1][i], xt = xyz_rst_quad[0][2][i];
+      double yr = xyz_rst_quad[1][0][i], ys = xyz_rst_quad[1][1][i], yt = xyz_rst_quad[1][2][i];
+      double zr = xyz_rst_quad[2][0][i], zs = xyz_rst_quad[2][1][i], zt = xyz_rst_quad[2][2][i];
+      double J = jac[i];
+      double* o = &rst_xyz_quad[quad_stride[e] + i];
+      size_t nq = (size_t)local_nodes_quad;
+      o[0 * nq] = (ys * zt - zs * yt) / (J);   /* rx */
+      o[1 * nq] = -(xs * zt - zs * xt) / (J);  /* ry */
+      o[2 * nq] = (xs * yt - ys * xt) / (J);   /* rz */
+      o[3 * nq] = -(yr * zt - zr * yt) / (J);  /* sx */
+      o[4 * nq] = (xr * zt - zr * xt) / (J);   /* sy */
+      o[5 * nq] = -(xr * yt - yr * xt) / (J);  /* sz */
+      o[6 * nq] = (yr * zs - zr * ys) / (J);   /* tx */
+      o[7 * nq] = -(xr * zs - zr * xs) / (J);  /* ty */
+      o[8 * nq] = (xr * ys - yr * xs) / (J);   /* tz */
+    }
+    for (int d = 0; d < 3; d++)
+      for (int d1 = 0; d1 < 3; d1++) free(xyz_rst_quad[d][d1]);
+    free(tmp);
+  }
+}

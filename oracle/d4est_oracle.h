@@ -146,6 +146,11 @@ void oracle_flux_set_robin(const double* coeff_quad, const double* rhs_quad);
 void oracle_flux_set_hanging(const int* side_hang, const int* side_sub, const int* side_nbr4, const int* side_orientation);
 int oracle_reorient_face_order(int f_m, int f_p, int o, int i);   /* dGMath/d4est_reference.c:84-110 */
 
+/* GEOM_COMPUTE_NUMERICAL volume factors from the nodal coordinates (Mesh/d4est_mesh.c:2637-2671, Geometry/d4est_geometry.c:877-976) */
+void oracle_mesh_compute_geometry_numerical(int quad_type, int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
+                                            const int* quad_stride, int local_nodes, int local_nodes_quad, const double* xyz,
+                                            double* J_quad, double* rst_xyz_quad);
+
 /* ---- smoother inner loops (oracle/d4est_oracle_solver.c) ---- */
 void oracle_set_aij_operator(int quad_type, int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
                              const int* quad_stride, int local_nodes, int local_nodes_quad, const double* J_quad,

@@ -264,6 +264,14 @@ class Oracle:
         f(P(u), P(np.ascontiguousarray(rhs)), P(Au), imax, use_new, ctypes.byref(bound))
         return bound.value, u
 
+    def geometry_numerical(self, mesh, xyz):
+        """(J_quad, rst_xyz_quad) with DX_compute_method = GEOM_COMPUTE_NUMERICAL from xyz = (x, y, z) at the Lobatto nodes"""
+        X = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1) for a in xyz]))
+        J = np.zeros(mesh.local_nodes_quad); rst = np.zeros(9 * mesh.local_nodes_quad)
+        self.lib.oracle_mesh_compute_geometry_numerical(mesh.quad_type, mesh.n_elements, I(mesh.deg), I(mesh.deg_quad), I(mesh.nodal_stride),
+                                                        I(mesh.quad_stride), mesh.local_nodes, mesh.local_nodes_quad, P(X), P(J), P(rst))
+        return J, rst
+
     # ---- additive Schwarz (oracle/d4est_oracle_schwarz.c); operator from set_operator()
     def schwarz_restrictor_1d(self, deg, rs):
         R = np.zeros((2, rs, deg + 1))

@@ -332,3 +332,43 @@ def test_full_size_properties_config2(gpu, hiplib, oracle):
         s = m.nodal_stride[e]
         ref = oracle.apply_stiffness(sub, Je, rste, np.ascontiguousarray(u[s:s + 512]))
         assert _rel(got[s:s + 512], ref) <= RTOL
+
+
+@pytest.mark.parametrize("level,deg,inc", [(1, 3, 0), (2, "mixed", 1), (1, 7, 0), (1, 11, 0)])
+def test_numerical_geometry_on_device(gpu, hiplib, oracle, level, deg, inc):
+    """d4est_hip_plan_set_geometry_numerical (volume factors from the nodal coordinates, GEOM_COMPUTE_NUMERICAL) against the oracle's
+    restatement of d4est_mesh.c:2637-2671: stiffness and mass with the device-made factors equal the oracle's with its own, 1e-12."""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    if deg == "mixed":
+        deg = 2 + (np.arange(8 ** level) % 4)
+    m = M.BrickMesh(level, deg, deg_quad_inc=inc)
+    mp = M.SineMap(0.05)
+    xyz = m.nodal_coords(mp)
+    Jn, rstn = oracle.geometry_numerical(m, xyz)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan.set_geometry_numerical(xyz)
+    u = m.field(mp)
+    du = torch.from_numpy(u).to(gpu)
+    out = torch.empty_like(du)
+    plan.apply_stiffness_matrix(du, out)
+    ref = oracle.apply_stiffness(m, Jn, rstn, u)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    plan.apply_mass_matrix(du, out)
+    ref = oracle.apply_mass(m, Jn, u)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    # device-resident coordinates take the same path
+    plan2 = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan2.set_geometry_numerical(torch.from_numpy(np.concatenate(xyz)).to(gpu))
+    out2 = torch.empty_like(du)
+    plan2.apply_mass_matrix(du, out2)
+    assert torch.equal(out, out2)
+    # the affine brick is still recognised (6 numbers per element instead of the per-node metric)
+    m0 = M.BrickMesh(1, 7)
+    p0 = Plan(m0.deg, m0.deg_quad, m0.nodal_stride, m0.quad_stride, 0)
+    p0.set_geometry_numerical(m0.nodal_coords(None))
+    x0 = torch.from_numpy(m0.field()).to(gpu); y0 = torch.empty_like(x0)
+    p0.apply_stiffness_matrix(x0, y0)
+    J0, rst0 = m0.geometry(None)
+    ref0 = oracle.apply_stiffness(m0, J0, rst0, m0.field())
+    assert np.abs(y0.cpu().numpy() - ref0).max() <= 1e-12 * np.abs(ref0).max()
