@@ -10,7 +10,7 @@ Mirrors the reference's setup for it:
     smoother feeds with a zero trace; geometric factors are not copied, the strides alias the mesh's arrays.
   * ``Schwarz``          <->  d4est_solver_schwarz_t + d4est_solver_schwarz_iterate (src/Solver/d4est_solver_schwarz.c:20-285).
 
-Conforming single-tree, single-rank meshes (``mesh.BrickMesh`` with uniform or mixed degrees).
+Single-tree, single-rank meshes: ``mesh.BrickMesh`` (uniform or mixed degrees) and ``mesh.HangingBrickMesh`` (hanging 1 <-> 4 faces).
 """
 import ctypes
 
@@ -33,36 +33,17 @@ class SchwarzMetadata:
             raise ValueError("num_nodes_overlap = 1 gives a zero-width weight ramp")
         if num_nodes_overlap > int(mesh.deg.min()) + 1:
             raise ValueError("num_nodes_overlap exceeds the minimum mesh degree + 1")   # metadata.h:69-70
-        if "side_hang" in sides and np.any(np.asarray(sides["side_hang"]) != 0):
-            raise NotImplementedError("Schwarz subdomains on hanging faces are not built")
         nbr = np.asarray(sides["side_nbr"]).reshape(ne, 6)
-        if np.any(nbr <= -2):
+        nbr4 = np.asarray(sides["side_nbr4"]) if "side_nbr4" in sides else np.zeros(0, dtype=np.int32)
+        if np.any(nbr <= -2) or np.any(nbr4 <= -2):
             raise NotImplementedError("Schwarz subdomains across ranks are not built (single-rank meshes only)")
         self.num_nodes_overlap = int(num_nodes_overlap)
         self.num_subdomains = ne
-        core_l, elem_l, faces_l = [np.arange(ne)], [np.arange(ne)], [np.full((ne, 3), -1, dtype=np.int32)]
-        for oz in (-1, 0, 1):
-            for oy in (-1, 0, 1):
-                for ox in (-1, 0, 1):
-                    off = (ox, oy, oz)
-                    if off == (0, 0, 0):
-                        continue
-                    idx = np.arange(ne)
-                    valid = np.ones(ne, dtype=bool)
-                    for d in range(3):                       # walk face neighbours direction by direction (conforming mesh)
-                        if off[d] == 0:
-                            continue
-                        nxt = nbr[idx, 2 * d + (1 if off[d] > 0 else 0)]
-                        valid &= nxt >= 0
-                        idx = np.where(valid, nxt, 0)
-                    # faces of the subdomain element that touch the core: the side facing back (ascending like p8est_edge_faces /
-                    # p8est_corner_faces, metadata.c:336-372); an element to the right of the core touches it with its "-" face
-                    fc = [2 * d + (0 if off[d] > 0 else 1) for d in range(3) if off[d] != 0]
-                    fc = fc + [-1] * (3 - len(fc))
-                    sel = np.nonzero(valid)[0]
-                    core_l.append(sel)
-                    elem_l.append(idx[sel])
-                    faces_l.append(np.tile(np.array(fc, dtype=np.int32), (sel.size, 1)))
+        hanging = "side_hang" in sides and np.any(np.asarray(sides["side_hang"]) != 0)
+        if hanging:
+            core_l, elem_l, faces_l = self._corner_neighbours(mesh)
+        else:
+            core_l, elem_l, faces_l = self._walk_neighbours(ne, nbr)
         core = np.concatenate(core_l)
         elem = np.concatenate(elem_l)
         faces = np.concatenate(faces_l)
@@ -80,6 +61,81 @@ class SchwarzMetadata:
         self.elem_nodal_size = n1 ** 3
         self.nodal_size = int(self.elem_nodal_size.sum())
         self.restricted_nodal_size = int(self.elem_restricted_nodal_size.sum())
+
+    @staticmethod
+    def _walk_neighbours(ne, nbr):
+        """conforming mesh: the 26 offsets reached by walking face neighbours direction by direction"""
+        core_l, elem_l, faces_l = [np.arange(ne)], [np.arange(ne)], [np.full((ne, 3), -1, dtype=np.int32)]
+        for oz in (-1, 0, 1):
+            for oy in (-1, 0, 1):
+                for ox in (-1, 0, 1):
+                    off = (ox, oy, oz)
+                    if off == (0, 0, 0):
+                        continue
+                    idx = np.arange(ne)
+                    valid = np.ones(ne, dtype=bool)
+                    for d in range(3):
+                        if off[d] == 0:
+                            continue
+                        nxt = nbr[idx, 2 * d + (1 if off[d] > 0 else 0)]
+                        valid &= nxt >= 0
+                        idx = np.where(valid, nxt, 0)
+                    # faces of the subdomain element that touch the core: the side facing back (ascending like p8est_edge_faces /
+                    # p8est_corner_faces, metadata.c:336-372); an element to the right of the core touches it with its "-" face
+                    fc = [2 * d + (0 if off[d] > 0 else 1) for d in range(3) if off[d] != 0]
+                    fc = fc + [-1] * (3 - len(fc))
+                    sel = np.nonzero(valid)[0]
+                    core_l.append(sel)
+                    elem_l.append(idx[sel])
+                    faces_l.append(np.tile(np.array(fc, dtype=np.int32), (sel.size, 1)))
+        return core_l, elem_l, faces_l
+
+    @staticmethod
+    def _corner_neighbours(mesh):
+        """mesh with hanging faces (HangingBrickMesh: origin / size on the fine grid): p8est_iterate calls the corner callback at
+        every CONFORMAL corner, i.e. a point that is a corner of every element touching it (p8est_iterate.h, p4est_iter_corner_t),
+        and d4est_solver_schwarz_metadata_corner_callback puts every element of that corner into the subdomain of every other one."""
+        ne = mesh.n_elements
+        org, size = np.asarray(mesh.org), np.asarray(mesh.size)
+        nf = int((org + size[:, None]).max())
+        owner = -np.ones((nf, nf, nf), dtype=np.int64)
+        for e in range(ne):
+            o, sz = org[e], int(size[e])
+            owner[o[0]:o[0] + sz, o[1]:o[1] + sz, o[2]:o[2] + sz] = e
+        pairs = set()
+        seen = set()
+        for e in range(ne):
+            for c in range(8):
+                P = org[e] + size[e] * np.array([c & 1, (c >> 1) & 1, (c >> 2) & 1])
+                key = (int(P[0]), int(P[1]), int(P[2]))
+                if key in seen:
+                    continue
+                seen.add(key)
+                touching = set()
+                for q in range(8):
+                    cell = P - np.array([q & 1, (q >> 1) & 1, (q >> 2) & 1])
+                    if np.all(cell >= 0) and np.all(cell < nf):
+                        touching.add(int(owner[cell[0], cell[1], cell[2]]))
+                conformal = all(np.all((P == org[t]) | (P == org[t] + size[t])) for t in touching)
+                if conformal:
+                    for a in touching:
+                        for b in touching:
+                            if a != b:
+                                pairs.add((a, b))
+        core = np.array([a for a, _ in pairs] + list(range(ne)), dtype=np.int64)
+        elem = np.array([b for _, b in pairs] + list(range(ne)), dtype=np.int64)
+        faces = np.full((core.size, 3), -1, dtype=np.int32)
+        for k in range(len(pairs)):
+            c, e = int(core[k]), int(elem[k])
+            fc = []
+            for d in range(3):
+                if org[e][d] == org[c][d] + size[c]:          # e to the right of the core: touches it with its "-" face
+                    fc.append(2 * d)
+                elif org[e][d] + size[e] == org[c][d]:
+                    fc.append(2 * d + 1)
+            assert fc, "two elements of one corner must be separated in at least one direction"
+            faces[k, :len(fc)] = fc
+        return [core], [elem], [faces]
 
     def subdomain(self, i):
         a, b = int(self.sub_first[i]), int(self.sub_first[i + 1])
@@ -118,8 +174,31 @@ def subdomain_sides(mesh, sides, md):
     vs.update(side_nbr=side_nbr.reshape(-1), side_nbr_face=rep("side_nbr_face"), side_reorder=rep("side_reorder"),
               side_mortar_stride=rep("side_mortar_stride"), side_bndry_stride=rep("side_bndry_stride"),
               ghost_deg=np.asarray(ghost_deg, dtype=np.int32), ghost_deg_quad=np.asarray(ghost_deg_quad, dtype=np.int32))
-    for k in ("side_hang", "side_sub", "side_nbr4", "side_orientation"):
-        vs.pop(k, None)
+    if "side_hang" in sides and np.any(np.asarray(sides["side_hang"]) != 0):
+        # hanging faces: the group / neighbour lists are remapped entry by entry the same way (inside: the copy, outside: a zero ghost)
+        n4_mesh = np.asarray(sides["side_nbr4"]).reshape(ne, 24)[md.sub_elem]                       # (nv, 24)
+        want4 = md.sub_core.astype(np.int64)[:, None] * ne + np.clip(n4_mesh, 0, None)
+        loc4 = np.clip(np.searchsorted(key, want4), 0, nv - 1)
+        in4 = (n4_mesh >= 0) & (key[loc4] == want4)
+        n4 = np.full((nv, 24), -1, dtype=np.int32)
+        n4[in4] = loc4[in4]
+        out4 = (n4_mesh >= 0) & ~in4
+        if out4.any():
+            od, oq = mesh.deg[n4_mesh[out4]], mesh.deg_quad[n4_mesh[out4]]
+            codes = np.empty(od.size, dtype=np.int32)
+            for i, (a, b) in enumerate(zip(od.tolist(), oq.tolist())):
+                if (a, b) not in dq_pairs:
+                    dq_pairs[(a, b)] = len(ghost_deg)
+                    ghost_deg.append(a)
+                    ghost_deg_quad.append(b)
+                codes[i] = -(dq_pairs[(a, b)] + 2)
+            n4[out4] = codes
+        vs.update(side_hang=rep("side_hang"), side_sub=rep("side_sub"), side_orientation=rep("side_orientation"),
+                  side_nbr4=n4.reshape(-1), ghost_deg=np.asarray(ghost_deg, dtype=np.int32),
+                  ghost_deg_quad=np.asarray(ghost_deg_quad, dtype=np.int32))
+    else:
+        for k in ("side_hang", "side_sub", "side_nbr4", "side_orientation"):
+            vs.pop(k, None)
     return vs
 
 

@@ -313,7 +313,8 @@ void d4est_hip_transfer_restrict(d4est_hip_transfer_t* t, const double* x_fine_d
  * same subdomain; a face whose neighbour is outside the subdomain = a ghost side, which the smoother feeds with a zero trace: the
  * reference's zero_and_skip rule, src/dGMath/d4est_laplacian_flux.c:486-520, :944-962; domain boundary = -1 with homogeneous
  * Dirichlet data).  disco4est_amd/schwarz.py builds it; the plan stays owned by the caller and must outlive the handle.
- * Conforming single-rank meshes (hanging faces and off-rank subdomain elements abort in the builder). */
+ * Hanging 1 <-> 4 faces: the copies carry the mesh's plan_set_hanging arrays, group / neighbour entries remapped the same way.
+ * Single-rank meshes (off-rank subdomain elements are refused by the builder). */
 typedef struct d4est_hip_schwarz d4est_hip_schwarz_t;
 d4est_hip_schwarz_t* d4est_hip_schwarz_create(d4est_hip_plan_t* subdomain_plan, int n_subdomains, const int* sub_first,
                                               const int* sub_elem, const int* sub_faces, const int* sub_core_faces,

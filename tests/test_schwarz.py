@@ -127,3 +127,82 @@ def test_schwarz_iterations_converge(oracle, level, deg, rs, outer):
         hist.append(np.linalg.norm(rhs - oracle.apply_aij(m, J, rst, sides, u)))
     assert all(b < 0.8 * a for a, b in zip(hist[:-1], hist[1:])), hist
     assert np.linalg.norm(u - u_exact) < (0.3 if outer >= 4 else 0.6) * np.linalg.norm(u_exact)
+
+
+def test_metadata_geometric_builder_agrees_with_walk():
+    """the corner-based builder used for hanging meshes reproduces the face-walk builder on a conforming mesh"""
+    from disco4est_amd import mesh as M
+    from disco4est_amd.schwarz import SchwarzMetadata
+    mh = M.HangingBrickMesh(2, np.zeros(64, dtype=bool), 2)          # nothing refined: conforming, but with origin / size arrays
+    sides = mh.build_sides(None)
+    md = SchwarzMetadata(mh, sides, 2)                                # walk path (no hanging side)
+    c, e, f = SchwarzMetadata._corner_neighbours(mh)
+    order = np.lexsort((e[0], c[0]))
+    np.testing.assert_array_equal(c[0][order], md.sub_core)
+    np.testing.assert_array_equal(e[0][order], md.sub_elem)
+    np.testing.assert_array_equal(f[0][order], md.sub_faces)
+
+
+def _hanging(level, pattern, deg):
+    from disco4est_amd import mesh as M
+    refine = np.zeros(8 ** level, dtype=bool)
+    refine[np.asarray(pattern)] = True
+    n = M.HangingBrickMesh(level, refine, 2).n_elements
+    m = M.HangingBrickMesh(level, refine, deg(n) if callable(deg) else deg)
+    J, rst = m.geometry(None)
+    sides = m.build_sides(None)
+    return m, J, rst, sides
+
+
+def test_metadata_of_hanging_mesh():
+    from disco4est_amd.schwarz import SchwarzMetadata
+    m, _, _, sides = _hanging(1, [0], 2)                              # 8 small elements in one corner + 7 big ones
+    assert m.n_elements == 15
+    md = SchwarzMetadata(m, sides, 2)
+    members = [set(md.subdomain(s)[0].tolist()) for s in range(15)]
+    for s in range(15):
+        assert s in members[s]
+        for e in members[s]:
+            assert s in members[e]                                    # sharing a conformal corner is symmetric
+    # the small element at the domain corner only sees its 7 siblings; the small element at the centre of the brick touches all
+    # seven big elements at the brick's centre point (a corner of all of them)
+    small = np.nonzero(m.size == 1)[0]
+    corner = [e for e in small if np.all(m.org[e] == 0)][0]
+    centre = [e for e in small if np.all(m.org[e] == 1)][0]
+    assert members[corner] == set(small.tolist())
+    assert members[centre] == set(range(15))
+    # a big element never meets the corner small element (only hanging corners in between), but meets the centre one
+    big = np.nonzero(m.size == 2)[0]
+    assert all(corner not in members[b] for b in big) and all(centre in members[b] for b in big)
+    # faces: the big +x neighbour of the refined cell touches a small element of the x = 1 layer with its "-x" face only
+    bx = [b for b in big if tuple(m.org[b]) == (2, 0, 0)][0]
+    e_list, faces, core_faces = md.subdomain(bx)
+    for e, f, cf in zip(e_list, faces, core_faces):
+        if m.size[e] == 1:
+            assert m.org[e][0] == 1 and int(f[0]) == 1 and int(cf[0]) == 0      # small element left of the core: its +x face
+
+
+def test_schwarz_converges_on_hanging_mesh(oracle):
+    """On a hanging face the big element is the side element of FOUR small-core subdomains, each weighted with the full ramp on the
+    big element's slab (the weights are per subdomain element, d4est_solver_schwarz_helpers.c:344-370), so the hats sum to more than
+    one there and the plain stationary iteration over-corrects; as a damped iteration (or a preconditioner) it contracts."""
+    from disco4est_amd import mesh as M
+    from disco4est_amd.schwarz import SchwarzMetadata
+    m, J, rst, sides = _hanging(1, [0, 7], lambda n: 2 + (np.arange(n) % 2))
+    oracle.set_operator(m, J, rst, sides, 10.0, 0, threads=1)
+    try:
+        md = SchwarzMetadata(m, sides, 2)
+        u_exact = M.splitmix64_uniform(3, m.local_nodes) - 0.5
+        rhs = oracle.apply_aij(m, J, rst, sides, u_exact)
+        u = np.zeros(m.local_nodes)
+        hist = [np.linalg.norm(rhs)]
+        for _ in range(3):
+            r = rhs - oracle.apply_aij(m, J, rst, sides, u)
+            oracle.set_hanging(sides)                                  # apply_aij resets the hanging arrays on exit
+            un, it, res = oracle.schwarz_iterate(md, u, r, 300, 1e-15, 1e-10)
+            assert it.max() < 300
+            u = u + 0.5 * (un - u)
+            hist.append(np.linalg.norm(rhs - oracle.apply_aij(m, J, rst, sides, u)))
+        assert all(b < 0.8 * a for a, b in zip(hist[:-1], hist[1:])), hist
+    finally:
+        oracle.set_hanging(None)

@@ -198,3 +198,47 @@ def test_schwarz_p7_subdomains(gpu, hiplib, oracle):
     assert sz.iterate(u, _t(M.splitmix64_uniform(62, m.local_nodes) - 0.5, gpu)) == 3
     assert bool(torch.isfinite(u).all()) and float(u.abs().max()) > 0
     sz.destroy()
+
+
+@pytest.mark.parametrize("pattern,degf,rs,curved", [([0], lambda n: np.full(n, 2), 2, False), ([1, 6], lambda n: 2 + (np.arange(n) % 3), 3, True)])
+def test_schwarz_on_hanging_mesh(gpu, hiplib, oracle, pattern, degf, rs, curved):
+    """subdomains across hanging 1 <-> 4 faces: the subdomain plan carries the hanging-face arrays of the copies (members outside the
+    subdomain are zero ghosts); operator and a whole iterate against the oracle"""
+    import torch
+    from disco4est_amd import mesh as M
+    from disco4est_amd.schwarz import Schwarz
+    refine = np.zeros(8, dtype=bool)
+    refine[pattern] = True
+    n = M.HangingBrickMesh(1, refine, 2).n_elements
+    m = M.HangingBrickMesh(1, refine, degf(n).astype(np.int32))
+    mp = M.SineMap(0.04) if curved else None
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    assert np.any(sides["side_hang"] != 0)
+    oracle.set_operator(m, J, rst, sides, 10.0, 0, threads=1)
+    oracle.set_hanging(sides)
+    try:
+        sz = Schwarz(m, sides, J, rst, rs, 6, 1e-15, 1e-15, 10.0, 0)
+        md = sz.metadata
+        x = torch.empty(sz.nodal_size, dtype=torch.float64, device=gpu)
+        sz.restrict_field(_t(M.splitmix64_uniform(71, m.local_nodes) - 0.5, gpu), x)
+        Ax = torch.empty_like(x)
+        sz.apply_over_subdomains(x, Ax)
+        xh, Axh = x.cpu().numpy(), Ax.cpu().numpy()
+        scale = np.abs(Axh).max()
+        for s in range(md.num_subdomains):
+            elem, faces, _ = md.subdomain(s)
+            ref = oracle.schwarz_apply_over_subdomain(elem, faces, rs, _over_subdomains_to_restricted(oracle, m, md, xh, s))
+            got = _over_subdomains_to_restricted(oracle, m, md, Axh, s)
+            assert np.abs(got - ref).max() <= 1e-12 * scale, (s, np.abs(got - ref).max() / scale)
+        u0 = M.splitmix64_uniform(72, m.local_nodes) - 0.5
+        r = M.splitmix64_uniform(73, m.local_nodes) - 0.5
+        u_ref, it_ref, res_ref = oracle.schwarz_iterate(md, u0, r, 6, 1e-15, 1e-15)
+        u = _t(u0, gpu)
+        sz.iterate(u, _t(r, gpu))
+        it, res = sz.info()
+        assert _rel(u.cpu().numpy() - u0, u_ref - u0) <= 1e-9
+        np.testing.assert_array_equal(it, it_ref)
+        np.testing.assert_allclose(res, res_ref, rtol=1e-6)
+        sz.destroy()
+    finally:
+        oracle.set_hanging(None)
