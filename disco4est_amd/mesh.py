@@ -50,21 +50,31 @@ class BrickMesh:
 
     ``deg`` may be an int or an array of length 8**level (mixed p);
     ``deg_quad_inc`` mirrors [initial_mesh] regionX_deg_quad_inc (src/Mesh/d4est_mesh.c:303-330).
-    ``first``/``count`` select a contiguous Morton range (the shard of one rank).
+    ``first``/``count`` select a contiguous Morton range (the shard of one rank); ``elements`` (global ids, any order) selects an
+    arbitrary element list instead, e.g. a shard followed by its ghost layer (the Schwarz smoother's extended mesh).
     """
 
-    def __init__(self, level, deg, deg_quad_inc=0, quad_type=0, first=0, count=None):
+    def __init__(self, level, deg, deg_quad_inc=0, quad_type=0, first=0, count=None, elements=None):
         self.level = level
         self.quad_type = quad_type
         ijk = morton_order(level)
         total = ijk.shape[0]
         deg_all = np.full(total, deg, dtype=np.int32) if np.isscalar(deg) else np.asarray(deg, dtype=np.int32)
         assert deg_all.size == total
-        count = total - first if count is None else count
+        if elements is None:
+            count = total - first if count is None else count
+            elements = np.arange(first, first + count, dtype=np.int64)
+        else:
+            elements = np.asarray(elements, dtype=np.int64)
+            count = int(elements.size)
+            first = int(elements[0]) if count else 0
+        self.elements = elements                       # global id of every local element
+        self._g2l = -np.ones(total, dtype=np.int64)    # global id -> local index (-1: not on this mesh)
+        self._g2l[elements] = np.arange(count)
         self.global_elements = total
         self.first = first
-        self.ijk = ijk[first:first + count]
-        self.deg = deg_all[first:first + count].copy()
+        self.ijk = ijk[elements]
+        self.deg = deg_all[elements].copy()
         self.deg_quad = (self.deg + deg_quad_inc).astype(np.int32)
         self.n_elements = count
         self.h = 1.0 / (1 << level)
@@ -174,7 +184,7 @@ class BrickMesh:
             g = np.where(inside, lookup[np.clip(c[:, 0], 0, n - 1), np.clip(c[:, 1], 0, n - 1), np.clip(c[:, 2], 0, n - 1)], -1)
             nbr_global[f::6] = g
             side_nbr_face[f::6] = f ^ 1
-        local = (nbr_global >= self.first) & (nbr_global < self.first + ne)
+        local = (nbr_global >= 0) & (self._g2l[np.clip(nbr_global, 0, None)] >= 0)
         ghost_ids = np.unique(nbr_global[(nbr_global >= 0) & ~local])
         ghost_pos = {int(g): i for i, g in enumerate(ghost_ids)}
         for s_ in range(6 * ne):
@@ -182,7 +192,7 @@ class BrickMesh:
             if g < 0:
                 side_nbr[s_] = -1
             elif local[s_]:
-                side_nbr[s_] = g - self.first
+                side_nbr[s_] = self._g2l[g]
             else:
                 side_nbr[s_] = -(ghost_pos[g] + 2)
         ghost_deg = self.deg_global[ghost_ids].astype(np.int32)

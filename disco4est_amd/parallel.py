@@ -88,6 +88,45 @@ class TraceSchedule:
         return blocks[:, 0].copy(), packed, blocks[:, 1].astype(np.int32)
 
 
+class ElementSchedule:
+    """Whole-element exchange lists of one rank for an extended mesh = own elements followed by a ghost layer (global ids
+    ``ghost_gids``): what d4est_ghost_data_exchange moves for the Schwarz smoother's residual (src/Solver/d4est_solver_schwarz.c:197-203)
+    and, run backwards, what d4est_solver_schwarz_transfer_ghost_data_and_add_corrections returns (…_transfer_ghost_data.c:60-176).
+
+    ``needed_by[peer]``: global ids of OWN elements that lie in ``peer``'s ghost layer.  send / recv blocks are (offset, length) into the
+    element-ordered vector of the extended mesh, both ends sorted by global id: no metadata is exchanged.  Same interface as
+    TraceSchedule, so TraceExchange runs it; ``reversed()`` swaps the roles (ghost copies travel back to their owners)."""
+
+    def __init__(self, ext_mesh, n_own, parts, needed_by):
+        owner = owner_of(parts, ext_mesh.global_elements)
+        n3 = (ext_mesh.deg.astype(np.int64) + 1) ** 3
+        send, recv = {}, {}
+        for peer, gids in needed_by.items():
+            for g in sorted(int(v) for v in gids):
+                l = int(ext_mesh._g2l[g])
+                assert 0 <= l < n_own
+                send.setdefault(int(peer), []).append((int(ext_mesh.nodal_stride[l]), int(n3[l])))
+        for l in range(n_own, ext_mesh.n_elements):          # ghost layer, already sorted by global id
+            g = int(ext_mesh.elements[l])
+            recv.setdefault(int(owner[g]), []).append((int(ext_mesh.nodal_stride[l]), int(n3[l])))
+        self._finish(send, recv)
+
+    def _finish(self, send, recv):
+        self.peers = sorted(set(send) | set(recv))
+        arr = lambda d, p: np.array(d.get(p, []), dtype=np.int64).reshape(-1, 2)
+        self.send = {p: arr(send, p) for p in self.peers}
+        self.recv = {p: arr(recv, p) for p in self.peers}
+        self.send_len = {p: int(self.send[p][:, 1].sum()) for p in self.peers}
+        self.recv_len = {p: int(self.recv[p][:, 1].sum()) for p in self.peers}
+
+    def reversed(self):
+        r = ElementSchedule.__new__(ElementSchedule)
+        r._finish({p: [tuple(b) for b in self.recv[p]] for p in self.peers}, {p: [tuple(b) for b in self.send[p]] for p in self.peers})
+        return r
+
+    pack_lists = TraceSchedule.pack_lists
+
+
 class TraceExchange:
     """Runs the schedule: pack (HIP copy_blocks on the plan's stream) -> point-to-point -> unpack.
 

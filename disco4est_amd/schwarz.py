@@ -24,7 +24,10 @@ _vp = ctypes.c_void_p
 class SchwarzMetadata:
     """Flat d4est_solver_schwarz_metadata_t (src/Solver/d4est_solver_schwarz_metadata.h:19-62)."""
 
-    def __init__(self, mesh, sides, num_nodes_overlap):
+    def __init__(self, mesh, sides, num_nodes_overlap, cores=None, sort_key=None):
+        """cores: local indices of the elements that get a subdomain (default: all); on a rank's extended mesh (own elements + ghost
+        layer, see SchwarzShard) these are the own elements.  sort_key: per element, the (tree, quadid) order used inside a subdomain
+        (default: the local index; on an extended mesh the global id)."""
         ne = mesh.n_elements
         if num_nodes_overlap <= 0:
             raise ValueError("num_nodes_overlap <= 0")                      # d4est_solver_schwarz_metadata.c:166-168
@@ -35,11 +38,10 @@ class SchwarzMetadata:
             raise ValueError("num_nodes_overlap exceeds the minimum mesh degree + 1")   # metadata.h:69-70
         nbr = np.asarray(sides["side_nbr"]).reshape(ne, 6)
         nbr4 = np.asarray(sides["side_nbr4"]) if "side_nbr4" in sides else np.zeros(0, dtype=np.int32)
-        if np.any(nbr <= -2) or np.any(nbr4 <= -2):
-            raise NotImplementedError("Schwarz subdomains across ranks are not built (single-rank meshes only)")
-        self.num_nodes_overlap = int(num_nodes_overlap)
-        self.num_subdomains = ne
         hanging = "side_hang" in sides and np.any(np.asarray(sides["side_hang"]) != 0)
+        if (np.any(nbr <= -2) or np.any(nbr4 <= -2)) and (cores is None or hanging):
+            raise NotImplementedError("subdomain elements on other ranks need the extended mesh of SchwarzShard (conforming meshes)")
+        self.num_nodes_overlap = int(num_nodes_overlap)
         if hanging:
             core_l, elem_l, faces_l = self._corner_neighbours(mesh)
         else:
@@ -47,9 +49,19 @@ class SchwarzMetadata:
         core = np.concatenate(core_l)
         elem = np.concatenate(elem_l)
         faces = np.concatenate(faces_l)
-        order = np.lexsort((elem, core))                     # per subdomain sorted by (tree, quadid) = local Morton id (:447-455)
+        if cores is not None:
+            cores = np.asarray(cores, dtype=np.int64)
+            rank_of = -np.ones(ne, dtype=np.int64)
+            rank_of[cores] = np.arange(cores.size)
+            keep = rank_of[core] >= 0
+            core, elem, faces = rank_of[core[keep]], elem[keep], faces[keep]        # core = subdomain index from here on
+        n_sub = ne if cores is None else int(cores.size)
+        self.num_subdomains = n_sub
+        self.cores = np.arange(ne) if cores is None else cores
+        key = elem if sort_key is None else np.asarray(sort_key)[elem]
+        order = np.lexsort((key, core))                      # per subdomain sorted by (tree, quadid) = Morton id (:447-455)
         core, elem, faces = core[order], elem[order], faces[order]
-        self.sub_first = np.concatenate([[0], np.cumsum(np.bincount(core, minlength=ne))]).astype(np.int32)
+        self.sub_first = np.concatenate([[0], np.cumsum(np.bincount(core, minlength=n_sub))]).astype(np.int32)
         self.sub_core = core.astype(np.int32)
         self.sub_elem = elem.astype(np.int32)
         self.sub_faces = np.ascontiguousarray(faces, dtype=np.int32)
@@ -148,19 +160,25 @@ def subdomain_sides(mesh, sides, md):
     nv = md.num_elements
     # position of mesh element e inside subdomain s: binary search in the sorted keys s * ne + e
     key = md.sub_core.astype(np.int64) * ne + md.sub_elem.astype(np.int64)
+    perm = np.argsort(key, kind="stable")
+    skey = key[perm]
+
+    def locate(ref):                                   # ref: (nv, k) mesh element references; -> (inside mask, copy index)
+        want = md.sub_core.astype(np.int64)[:, None] * ne + np.clip(ref, 0, None)
+        pos = np.clip(np.searchsorted(skey, want), 0, nv - 1)
+        return (ref >= 0) & (skey[pos] == want), perm[pos]
+
     nbr_mesh = np.asarray(sides["side_nbr"]).reshape(ne, 6)[md.sub_elem]             # (nv, 6) neighbours of the originals
-    want = md.sub_core.astype(np.int64)[:, None] * ne + np.clip(nbr_mesh, 0, None)
-    loc = np.searchsorted(key, want)
-    loc_c = np.clip(loc, 0, nv - 1)
-    inside = (nbr_mesh >= 0) & (key[loc_c] == want)
-    # outside neighbours: one ghost "element" per (deg, deg_quad) pair that occurs; its trace is never computed, only sized
+    inside, loc_c = locate(nbr_mesh)
+    # outside neighbours: one ghost "element" per (deg, deg_quad) pair that occurs; its trace is never computed, only sized.
+    # A neighbour beyond the mesh's own ghost layer (code <= -2 on an extended mesh) is outside every subdomain.
     dq_pairs = {}
     ghost_deg, ghost_deg_quad = [], []
-    side_nbr = np.full((nv, 6), -1, dtype=np.int32)
-    side_nbr[inside] = loc_c[inside]
-    out = (nbr_mesh >= 0) & ~inside
-    if out.any():
-        od, oq = mesh.deg[nbr_mesh[out]], mesh.deg_quad[nbr_mesh[out]]
+    mesh_ghost_deg, mesh_ghost_degq = np.asarray(sides["ghost_deg"]), np.asarray(sides["ghost_deg_quad"])
+
+    def ghost_codes(ref):
+        od = np.where(ref >= 0, mesh.deg[np.clip(ref, 0, None)], mesh_ghost_deg[np.clip(-(ref + 2), 0, None)] if mesh_ghost_deg.size else 0)
+        oq = np.where(ref >= 0, mesh.deg_quad[np.clip(ref, 0, None)], mesh_ghost_degq[np.clip(-(ref + 2), 0, None)] if mesh_ghost_degq.size else 0)
         codes = np.empty(od.size, dtype=np.int32)
         for i, (a, b) in enumerate(zip(od.tolist(), oq.tolist())):
             if (a, b) not in dq_pairs:
@@ -168,7 +186,13 @@ def subdomain_sides(mesh, sides, md):
                 ghost_deg.append(a)
                 ghost_deg_quad.append(b)
             codes[i] = -(dq_pairs[(a, b)] + 2)
-        side_nbr[out] = codes
+        return codes
+
+    side_nbr = np.full((nv, 6), -1, dtype=np.int32)
+    side_nbr[inside] = loc_c[inside]
+    out = (nbr_mesh != -1) & ~inside
+    if out.any():
+        side_nbr[out] = ghost_codes(nbr_mesh[out])
     rep = lambda k: np.asarray(sides[k]).reshape(ne, 6)[md.sub_elem].reshape(-1).astype(np.int32)
     vs = dict(sides)
     vs.update(side_nbr=side_nbr.reshape(-1), side_nbr_face=rep("side_nbr_face"), side_reorder=rep("side_reorder"),
@@ -177,22 +201,12 @@ def subdomain_sides(mesh, sides, md):
     if "side_hang" in sides and np.any(np.asarray(sides["side_hang"]) != 0):
         # hanging faces: the group / neighbour lists are remapped entry by entry the same way (inside: the copy, outside: a zero ghost)
         n4_mesh = np.asarray(sides["side_nbr4"]).reshape(ne, 24)[md.sub_elem]                       # (nv, 24)
-        want4 = md.sub_core.astype(np.int64)[:, None] * ne + np.clip(n4_mesh, 0, None)
-        loc4 = np.clip(np.searchsorted(key, want4), 0, nv - 1)
-        in4 = (n4_mesh >= 0) & (key[loc4] == want4)
+        in4, loc4 = locate(n4_mesh)
         n4 = np.full((nv, 24), -1, dtype=np.int32)
         n4[in4] = loc4[in4]
-        out4 = (n4_mesh >= 0) & ~in4
+        out4 = (n4_mesh != -1) & ~in4
         if out4.any():
-            od, oq = mesh.deg[n4_mesh[out4]], mesh.deg_quad[n4_mesh[out4]]
-            codes = np.empty(od.size, dtype=np.int32)
-            for i, (a, b) in enumerate(zip(od.tolist(), oq.tolist())):
-                if (a, b) not in dq_pairs:
-                    dq_pairs[(a, b)] = len(ghost_deg)
-                    ghost_deg.append(a)
-                    ghost_deg_quad.append(b)
-                codes[i] = -(dq_pairs[(a, b)] + 2)
-            n4[out4] = codes
+            n4[out4] = ghost_codes(n4_mesh[out4])
         vs.update(side_hang=rep("side_hang"), side_sub=rep("side_sub"), side_orientation=rep("side_orientation"),
                   side_nbr4=n4.reshape(-1), ghost_deg=np.asarray(ghost_deg, dtype=np.int32),
                   ghost_deg_quad=np.asarray(ghost_deg_quad, dtype=np.int32))
@@ -206,9 +220,9 @@ class Schwarz:
     """d4est_solver_schwarz_t on the device: metadata + subdomain plan + the native smoother handle."""
 
     def __init__(self, mesh, sides, J_quad, rst_xyz_quad, num_nodes_overlap, subdomain_iter, subdomain_atol, subdomain_rtol,
-                 penalty_prefactor=10.0, penalty_fcn=0, stream=None):
+                 penalty_prefactor=10.0, penalty_fcn=0, stream=None, cores=None, sort_key=None):
         self.lib = capi.load_library()
-        self.metadata = md = SchwarzMetadata(mesh, sides, num_nodes_overlap)
+        self.metadata = md = SchwarzMetadata(mesh, sides, num_nodes_overlap, cores=cores, sort_key=sort_key)
         self.subdomain_iter, self.subdomain_atol, self.subdomain_rtol = int(subdomain_iter), float(subdomain_atol), float(subdomain_rtol)
         e = md.sub_elem
         vdeg, vdegq = mesh.deg[e], mesh.deg_quad[e]
@@ -267,3 +281,92 @@ class Schwarz:
             self.destroy()
         except Exception:
             pass
+
+
+def ghost_layer(level, parts, rank):
+    """(own global ids, ghost-layer global ids, needed_by) of one rank of a uniform brick: the ghost layer holds every off-rank element
+    that shares a face, an edge or a corner with an own element (P4EST_CONNECT_FULL, src/Mesh/d4est_ghost.c:47); needed_by[peer] =
+    own elements that lie in ``peer``'s ghost layer.  Every rank derives both from the global Morton numbering alone."""
+    from .mesh import morton_order
+    from .parallel import owner_of
+    ijk = morton_order(level)
+    n = 1 << level
+    lookup = np.empty((n, n, n), dtype=np.int64)
+    lookup[ijk[:, 0], ijk[:, 1], ijk[:, 2]] = np.arange(ijk.shape[0])
+    owner = owner_of(parts, ijk.shape[0])
+    first, count = parts[rank]
+    own = np.arange(first, first + count, dtype=np.int64)
+    ghosts, needed_by = set(), {}
+    for oz in (-1, 0, 1):
+        for oy in (-1, 0, 1):
+            for ox in (-1, 0, 1):
+                if (ox, oy, oz) == (0, 0, 0):
+                    continue
+                c = ijk[own] + np.array([ox, oy, oz])
+                ok = np.all((c >= 0) & (c < n), axis=1)
+                g = lookup[c[ok, 0], c[ok, 1], c[ok, 2]]
+                off_rank = owner[g] != rank
+                ghosts.update(g[off_rank].tolist())
+                for peer, mine in zip(owner[g[off_rank]].tolist(), own[ok][off_rank].tolist()):
+                    needed_by.setdefault(peer, set()).add(mine)
+    return own, np.array(sorted(ghosts), dtype=np.int64), needed_by
+
+
+class SchwarzShard:
+    """The smoother on one rank of a sharded (conforming) brick.  The rank's *extended mesh* is its own elements followed by the
+    ghost layer; subdomains exist for the own elements only and may contain ghost-layer elements, whose geometric factors the rank
+    computes itself (as d4est_solver_schwarz_geometric_data_init does for ghost elements) and whose residual arrives by a whole-element
+    exchange; corrections computed for ghost-layer elements travel back to their owners and are added there
+    (d4est_solver_schwarz_transfer_ghost_data_and_add_corrections).  One forward and one backward point-to-point exchange per iterate."""
+
+    def __init__(self, level, deg_global, parts, rank, mapping, num_nodes_overlap, subdomain_iter, subdomain_atol, subdomain_rtol,
+                 transport, device, penalty_prefactor=10.0, penalty_fcn=0, deg_quad_inc=0, quad_type=0, transport_back=None):
+        import torch
+        from .mesh import BrickMesh
+        from .parallel import ElementSchedule, TraceExchange
+        own, ghosts, needed_by = ghost_layer(level, parts, rank)
+        self.n_own = int(own.size)
+        self.mesh = m = BrickMesh(level, deg_global, deg_quad_inc=deg_quad_inc, quad_type=quad_type, elements=np.concatenate([own, ghosts]))
+        J, rst = m.geometry(mapping)
+        sides = m.build_sides(mapping)
+        self.schwarz = Schwarz(m, sides, J, rst, num_nodes_overlap, subdomain_iter, subdomain_atol, subdomain_rtol, penalty_prefactor,
+                               penalty_fcn, cores=np.arange(self.n_own), sort_key=m.elements)
+        self.own_nodes = int(((m.deg[:self.n_own].astype(np.int64) + 1) ** 3).sum())
+        sched = ElementSchedule(m, self.n_own, parts, needed_by)
+        self.forward = TraceExchange(sched, transport, self.schwarz.plan.copy_blocks, device)
+        self.backward = TraceExchange(sched.reversed(), transport_back or transport, self.schwarz.plan.copy_blocks, device)
+        self.r_ext = torch.zeros(m.local_nodes, dtype=torch.float64, device=device)
+        self.u_ext = torch.zeros(m.local_nodes, dtype=torch.float64, device=device)
+        self.back = torch.zeros(m.local_nodes, dtype=torch.float64, device=device)
+
+    # the two halves of an exchange are separate calls so that in-process virtual ranks can be interleaved by the tests
+    def begin_residual_exchange(self, r_own):
+        self.r_ext[:self.own_nodes].copy_(r_own)
+        self.forward.begin(self.r_ext)
+
+    def solve_and_begin_correction_exchange(self):
+        self.forward.end(self.r_ext)
+        self.u_ext.zero_()
+        sweeps = self.schwarz.iterate(self.u_ext, self.r_ext)
+        self.backward.begin(self.u_ext)                       # the ghost-layer part of the correction goes back to the owners
+        return sweeps
+
+    def end_correction_exchange(self, u_own):
+        u_own += self.u_ext[:self.own_nodes]                   # own subdomains first, then the peers' in rank order (fixed order of additions)
+        bw = self.backward
+        bw.transport.finish(bw._pending)
+        bw._pending = None
+        for p in bw.s.peers:                                  # several peers may correct the same own element: one accumulation pass each
+            _, _, _, ro, rp, rl = bw.idx[p]
+            if len(rl) == 0:
+                continue
+            self.back.zero_()
+            bw.copy_blocks(len(rl), bw.recv_buf[p], rp, self.back, ro, rl)
+            u_own += self.back[:self.own_nodes]
+
+    def iterate(self, u_own, r_own):
+        """one d4est_solver_schwarz_iterate on this rank (collective: every rank calls it)"""
+        self.begin_residual_exchange(r_own)
+        sweeps = self.solve_and_begin_correction_exchange()
+        self.end_correction_exchange(u_own)
+        return sweeps

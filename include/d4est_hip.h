@@ -314,7 +314,9 @@ void d4est_hip_transfer_restrict(d4est_hip_transfer_t* t, const double* x_fine_d
  * reference's zero_and_skip rule, src/dGMath/d4est_laplacian_flux.c:486-520, :944-962; domain boundary = -1 with homogeneous
  * Dirichlet data).  disco4est_amd/schwarz.py builds it; the plan stays owned by the caller and must outlive the handle.
  * Hanging 1 <-> 4 faces: the copies carry the mesh's plan_set_hanging arrays, group / neighbour entries remapped the same way.
- * Single-rank meshes (off-rank subdomain elements are refused by the builder). */
+ * Several ranks: the mesh handed over is the rank's EXTENDED mesh (own elements followed by the ghost layer, P4EST_CONNECT_FULL), subdomains
+ * exist for the own elements only; the residual of the ghost-layer elements arrives by a whole-element exchange before schwarz_iterate and
+ * their part of u (the corrections) is sent back to the owners afterwards (disco4est_amd/schwarz.py: SchwarzShard, parallel.ElementSchedule). */
 typedef struct d4est_hip_schwarz d4est_hip_schwarz_t;
 d4est_hip_schwarz_t* d4est_hip_schwarz_create(d4est_hip_plan_t* subdomain_plan, int n_subdomains, const int* sub_first,
                                               const int* sub_elem, const int* sub_faces, const int* sub_core_faces,

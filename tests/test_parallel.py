@@ -182,3 +182,73 @@ def test_trace_exchange_gloo(world, level, deg_spec):
         assert r[1] == "ok", r
     assert sum(r[2] for r in res) > 0          # faces really crossed the partition boundary
     assert all(r[3] >= 1 for r in res)
+
+
+def _worker_elements(rank, world, port, level, deg_spec, q):
+    """whole-element exchange of the Schwarz smoother (forward: residual of the ghost layer; backward: corrections to the owners)"""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from disco4est_amd import mesh as M, parallel as P
+    from disco4est_amd.schwarz import ghost_layer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_global = 8 ** level
+        deg_global = np.array([deg_spec[i % len(deg_spec)] for i in range(n_global)])
+        parts = P.partition_by_dofs(deg_global, world)
+        own, ghosts, needed_by = ghost_layer(level, parts, rank)
+        m = M.BrickMesh(level, deg_global, elements=np.concatenate([own, ghosts]))
+        sched = P.ElementSchedule(m, own.size, parts, needed_by)
+        n3 = (m.deg.astype(np.int64) + 1) ** 3
+        x = np.full(m.local_nodes, np.nan)
+        for l in range(own.size):
+            x[m.nodal_stride[l]:m.nodal_stride[l] + n3[l]] = _encode(int(m.elements[l]), 0, int(n3[l]))
+        ex = P.TraceExchange(sched, P.DistTransport(), _np_copy_blocks, torch.device("cpu"))
+        t = torch.from_numpy(x)
+        ex.begin(t)
+        ex.end(t)
+        for l in range(m.n_elements):          # every ghost-layer element now holds its owner's data
+            np.testing.assert_array_equal(x[m.nodal_stride[l]:m.nodal_stride[l] + n3[l]], _encode(int(m.elements[l]), 0, int(n3[l])))
+        # backward: every ghost copy returns (global id, sender rank); the owner sees one block per peer that holds a copy
+        back = P.TraceExchange(sched.reversed(), P.DistTransport(), _np_copy_blocks, torch.device("cpu"))
+        y = np.full(m.local_nodes, np.nan)
+        for l in range(own.size, m.n_elements):
+            y[m.nodal_stride[l]:m.nodal_stride[l] + n3[l]] = _encode(int(m.elements[l]), rank, int(n3[l]))
+        ty = torch.from_numpy(y)
+        back.begin(ty)
+        back.transport.finish(back._pending)
+        hits = 0
+        for p in back.s.peers:
+            z = np.full(m.local_nodes, np.nan)
+            _, _, _, ro, rp, rl = back.idx[p]
+            _np_copy_blocks(len(rl), back.recv_buf[p], rp, torch.from_numpy(z), ro, rl)
+            for g in needed_by.get(p, ()):
+                l = int(m._g2l[g])
+                np.testing.assert_array_equal(z[m.nodal_stride[l]:m.nodal_stride[l] + n3[l]], _encode(int(g), p, int(n3[l])))
+                hits += 1
+            assert np.isnan(z).sum() == m.local_nodes - sum(int(n3[m._g2l[g]]) for g in needed_by.get(p, ()))
+        q.put((rank, "ok", int(ghosts.size), hits))
+    except Exception as exc:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail", traceback.format_exc(), str(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,level,deg_spec", [(2, 2, [2]), (3, 2, [2, 3])])
+def test_element_exchange_gloo(world, level, deg_spec):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_elements, args=(r, world, port, level, deg_spec, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r
+    assert all(r[2] > 0 and r[3] > 0 for r in res)

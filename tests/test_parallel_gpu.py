@@ -160,3 +160,46 @@ def test_apply_lhs_hooks_single_rank_with_self_exchange(gpu, hiplib, oracle):
     got = Au0.cpu().numpy()
     assert np.abs(got - ref[:m0.local_nodes]).max() <= 1e-12 * np.abs(ref).max()
     assert ex0 is not None
+
+
+@pytest.mark.parametrize("world,level,deg_spec,rs,curved", [(2, 2, [2], 2, False), (3, 2, [2, 3], 2, True), (4, 2, [3], 3, True)])
+def test_schwarz_virtual_ranks_match_single_rank(gpu, hiplib, oracle, world, level, deg_spec, rs, curved):
+    """The Schwarz smoother on a sharded brick: every rank solves the subdomains of its own elements on its extended mesh (own elements
+    + ghost layer), residuals of ghost-layer elements arrive by a whole-element exchange, their corrections travel back and are added
+    by the owners.  The assembled u equals the single-rank smoother's (which the oracle pins) to 1e-10."""
+    import torch
+    from disco4est_amd import mesh as M, parallel as P
+    from disco4est_amd.schwarz import Schwarz, SchwarzShard
+    n_global = 8 ** level
+    deg_global = np.array([deg_spec[i % len(deg_spec)] for i in range(n_global)])
+    mp = M.SineMap(0.04) if curved else None
+    mg = M.BrickMesh(level, deg_global)
+    Jg, rstg = mg.geometry(mp); sg = mg.build_sides(mp)
+    iters = 5
+    single = Schwarz(mg, sg, Jg, rstg, rs, iters, 1e-15, 1e-15)
+    u0 = M.splitmix64_uniform(81, mg.local_nodes) - 0.5
+    r = M.splitmix64_uniform(82, mg.local_nodes) - 0.5
+    u_ref = torch.from_numpy(u0).to(gpu)
+    single.iterate(u_ref, torch.from_numpy(r).to(gpu))
+    u_ref = u_ref.cpu().numpy()
+    oracle.set_operator(mg, Jg, rstg, sg, 10.0, 0, threads=1)
+    u_orc, _, _ = oracle.schwarz_iterate(single.metadata, u0, r, iters, 1e-15, 1e-15)
+    assert np.abs(u_ref - u_orc).max() <= 1e-9 * np.abs(u_orc - u0).max()
+    parts = P.partition_by_dofs(deg_global, world)
+    mb, mb_back = _Mailbox(), _Mailbox()       # in-process stand-in for two message streams (the phases of the virtual ranks interleave)
+    shards = []
+    for rank, (first, count) in enumerate(parts):
+        sh = SchwarzShard(level, deg_global, parts, rank, mp, rs, iters, 1e-15, 1e-15, _LocalTransport(rank, mb), gpu,
+                          transport_back=_LocalTransport(rank, mb_back))
+        lo = int(mg.global_nodal_stride[first]); hi = lo + sh.own_nodes
+        shards.append((sh, torch.from_numpy(u0[lo:hi].copy()).to(gpu), torch.from_numpy(r[lo:hi].copy()).to(gpu), lo, hi))
+        assert sh.mesh.n_elements > count                      # the extended mesh really has a ghost layer
+    for sh, u, rr, lo, hi in shards:
+        sh.begin_residual_exchange(rr)
+    for sh, u, rr, lo, hi in shards:
+        sh.solve_and_begin_correction_exchange()
+    got = np.empty_like(u_ref)
+    for sh, u, rr, lo, hi in shards:
+        sh.end_correction_exchange(u)
+        got[lo:hi] = u.cpu().numpy()
+    assert np.abs(got - u_ref).max() <= 1e-10 * np.abs(u_ref - u0).max()
