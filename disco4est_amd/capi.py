@@ -70,6 +70,7 @@ SIGNATURES = {
     "d4est_hip_schwarz_apply_over_subdomains": (None, [_vp, _vp, _vp]),
     "d4est_hip_schwarz_add_correction": (None, [_vp, _vp, _vp]),
     "d4est_hip_schwarz_iterate": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_double]),
+    "d4est_hip_schwarz_smooth": (None, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]),
     "d4est_hip_schwarz_get_info": (None, [_vp, _vp, _vp]),
     "d4est_hip_plan_set_sipg": (None, [_vp, ctypes.c_double, ctypes.c_int]),
     "d4est_hip_plan_set_mortar_geometry": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int]),

@@ -152,6 +152,7 @@ void faces_destroy(d4est_hip_plan* plan);
 
 // d4est_hip_solver.hip
 void apply_operator(d4est_hip_plan* plan, const double* u, double* Au);
+void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double* r);   // r = rhs - Au
 void launch_copy_blocks(hipStream_t stream, int n_blocks, const double* src, const long long* src_off, double* dst,
                         const long long* dst_off, const int* len);
 void launch_dot(d4est_hip_plan* plan, int n, const double* x, const double* y, double* out_dev);

@@ -429,6 +429,22 @@ int d4est_hip_schwarz_iterate(d4est_hip_schwarz_t* sz, double* u_dev, const doub
   return sweeps;
 }
 
+void d4est_hip_schwarz_smooth(d4est_hip_schwarz_t* sz, d4est_hip_plan_t* mesh_plan, double* u_dev, const double* rhs_dev, double* r_dev,
+                              int smoother_iterations, int subdomain_iter, double subdomain_atol, double subdomain_rtol) {
+  check_schwarz(sz, "schwarz_smooth");
+  if (!mesh_plan || !mesh_plan->has_faces) D4EST_HIP_ABORT("schwarz_smooth: the mesh plan needs its faces (plan_set_faces)");
+  if (mesh_plan->local_nodes != sz->mesh_nodes) D4EST_HIP_ABORT("schwarz_smooth: mesh plan has %d nodes, the smoother's mesh %d", mesh_plan->local_nodes, sz->mesh_nodes);
+  if (mesh_plan->stream != sz->plan->stream) D4EST_HIP_ABORT("schwarz_smooth: the mesh plan and the subdomain plan must use the same stream");
+  // d4est_solver_multigrid_smoother_schwarz, src/Solver/d4est_solver_multigrid_smoother_schwarz.c:98-196; r doubles as the Au scratch
+  for (int i = 0; i < smoother_iterations; ++i) {
+    apply_operator(mesh_plan, u_dev, r_dev);
+    launch_residual(mesh_plan, mesh_plan->local_nodes, rhs_dev, r_dev, r_dev);
+    d4est_hip_schwarz_iterate(sz, u_dev, r_dev, subdomain_iter, subdomain_atol, subdomain_rtol);
+  }
+  apply_operator(mesh_plan, u_dev, r_dev);
+  launch_residual(mesh_plan, mesh_plan->local_nodes, rhs_dev, r_dev, r_dev);
+}
+
 void d4est_hip_schwarz_get_info(d4est_hip_schwarz_t* sz, int* final_iter_host, double* final_res_host) {
   check_schwarz(sz, "schwarz_get_info");
   if (!sz->d_du) D4EST_HIP_ABORT("schwarz_get_info: call schwarz_iterate first");

@@ -172,6 +172,11 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au) {
   launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au);
 }
 
+void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double* r) {
+  if (n > 0) hipLaunchKernelGGL(residual_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, Au, r, (double*)nullptr);
+  HIP_CHECK(hipGetLastError());
+}
+
 void cheby_iterate(d4est_hip_plan* plan, double* u, const double* rhs, double* Au, double* r, int iter, double lmin, double lmax,
                    int compute_residual_at_end) {
   ensure_solver_workspace(plan);

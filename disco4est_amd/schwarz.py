@@ -262,6 +262,13 @@ class Schwarz:
         return self.lib.d4est_hip_schwarz_iterate(self.handle, capi._ptr(u), capi._ptr(r), self.subdomain_iter, self.subdomain_atol,
                                                   self.subdomain_rtol)
 
+    def smooth(self, mesh_plan, u, rhs, r, smoother_iterations):
+        """d4est_solver_multigrid_smoother_schwarz: iterations x { r = rhs - A u; iterate(u, r) }, then r = rhs - A u"""
+        for t in (u, rhs, r):
+            assert t.numel() == self.local_nodes
+        self.lib.d4est_hip_schwarz_smooth(self.handle, mesh_plan.handle, capi._ptr(u), capi._ptr(rhs), capi._ptr(r), int(smoother_iterations),
+                                          self.subdomain_iter, self.subdomain_atol, self.subdomain_rtol)
+
     def info(self):
         it = np.zeros(self.metadata.num_subdomains, dtype=np.int32)
         res = np.zeros(self.metadata.num_subdomains)

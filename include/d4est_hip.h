@@ -339,6 +339,12 @@ void d4est_hip_schwarz_add_correction(d4est_hip_schwarz_t* sz, const double* du_
  * [d4est_solver_schwarz] CG options as arguments.  Returns the number of batched CG sweeps (= the largest iteration count). */
 int d4est_hip_schwarz_iterate(d4est_hip_schwarz_t* sz, double* u_dev, const double* r_dev, int subdomain_iter, double subdomain_atol,
                               double subdomain_rtol);
+/* The multigrid smoother built on it, d4est_solver_multigrid_smoother_schwarz (src/Solver/d4est_solver_multigrid_smoother_schwarz.c:98-196):
+ * smoother_iterations times { r = rhs - A u; schwarz_iterate(u, r) }, then r = rhs - A u.  mesh_plan is the plan of the mesh itself (faces
+ * set, homogeneous Dirichlet data, same stream as the subdomain plan); on several ranks its apply_lhs hooks do the trace exchange, the
+ * whole-element exchanges around schwarz_iterate are the host's (SchwarzShard), so this entry is for one rank. */
+void d4est_hip_schwarz_smooth(d4est_hip_schwarz_t* sz, d4est_hip_plan_t* mesh_plan, double* u_dev, const double* rhs_dev, double* r_dev,
+                              int smoother_iterations, int subdomain_iter, double subdomain_atol, double subdomain_rtol);
 /* schwarz->subdomain_solve_iterations / _residuals of the last iterate (d4est_solver_schwarz.c:259-260), host arrays of n_subdomains */
 void d4est_hip_schwarz_get_info(d4est_hip_schwarz_t* sz, int* final_iter_host, double* final_res_host);
 

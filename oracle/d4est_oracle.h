@@ -179,6 +179,9 @@ void oracle_schwarz_apply_over_subdomain(int n_sub_elements, const int* elem, co
 void oracle_schwarz_iterate(int n_subdomains, const int* sub_first, const int* sub_elem, const int* sub_faces,
                             const int* sub_core_faces, int restricted_size, int subdomain_iter, double subdomain_atol,
                             double subdomain_rtol, double* u, const double* r, int* final_iter, double* final_res); /* d4est_solver_schwarz.c:172-285 */
+void oracle_schwarz_smoother(int n_subdomains, const int* sub_first, const int* sub_elem, const int* sub_faces, const int* sub_core_faces,
+                             int restricted_size, int subdomain_iter, double subdomain_atol, double subdomain_rtol, int iterations,
+                             double* u, const double* rhs, double* r);                 /* d4est_solver_multigrid_smoother_schwarz.c:98-196 */
 
 #ifdef __cplusplus
 }

@@ -232,3 +232,20 @@ void oracle_schwarz_iterate(int n_subdomains, const int* sub_first, const int* s
   }
   free(du_all);
 }
+
+/* d4est_solver_multigrid_smoother_schwarz, Solver/d4est_solver_multigrid_smoother_schwarz.c:98-196 */
+void oracle_schwarz_smoother(int n_subdomains, const int* sub_first, const int* sub_elem, const int* sub_faces, const int* sub_core_faces,
+                             int restricted_size, int subdomain_iter, double subdomain_atol, double subdomain_rtol, int iterations,
+                             double* u, const double* rhs, double* r) {
+  int n_elements, local_nodes;
+  const int *deg, *nodal_stride;
+  oracle_operator_info(&n_elements, &deg, &nodal_stride, &local_nodes);
+  for (int i = 0; i < iterations; i++) {
+    oracle_apply_lhs(u, r);
+    oracle_linalg_vec_xpby(rhs, -1., r, local_nodes);
+    oracle_schwarz_iterate(n_subdomains, sub_first, sub_elem, sub_faces, sub_core_faces, restricted_size, subdomain_iter, subdomain_atol,
+                           subdomain_rtol, u, r, NULL, NULL);
+  }
+  oracle_apply_lhs(u, r);
+  oracle_linalg_vec_xpby(rhs, -1., r, local_nodes);
+}

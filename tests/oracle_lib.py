@@ -315,6 +315,18 @@ class Oracle:
           int(md.num_nodes_overlap), int(subdomain_iter), float(atol), float(rtol), P(u), P(np.ascontiguousarray(r)), I(it), P(res))
         return u, it, res
 
+    def schwarz_smoother(self, md, u, rhs, iterations, subdomain_iter, atol, rtol):
+        """d4est_solver_multigrid_smoother_schwarz: returns (u_new, r = rhs - A u_new)"""
+        u = u.copy(); r = np.zeros_like(u)
+        n = len(md.sub_first) - 1
+        f = self.lib.oracle_schwarz_smoother
+        f.argtypes = [ctypes.c_int, ip, ip, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp, dp]
+        sf = np.ascontiguousarray(md.sub_faces, dtype=np.int32).reshape(-1)
+        sc = np.ascontiguousarray(md.sub_core_faces, dtype=np.int32).reshape(-1)
+        f(n, I(np.ascontiguousarray(md.sub_first, dtype=np.int32)), I(np.ascontiguousarray(md.sub_elem, dtype=np.int32)), I(sf), I(sc),
+          int(md.num_nodes_overlap), int(subdomain_iter), float(atol), float(rtol), int(iterations), P(u), P(np.ascontiguousarray(rhs)), P(r))
+        return u, r
+
     def compute_dudr(self, mesh, u):
         d = [np.zeros(mesh.local_nodes) for _ in range(3)]
         self.lib.oracle_laplacian_compute_dudr(mesh.n_elements, I(mesh.deg), I(mesh.nodal_stride), P(u), P(d[0]), P(d[1]), P(d[2]))

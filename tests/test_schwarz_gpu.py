@@ -242,3 +242,22 @@ def test_schwarz_on_hanging_mesh(gpu, hiplib, oracle, pattern, degf, rs, curved)
         sz.destroy()
     finally:
         oracle.set_hanging(None)
+
+
+def test_multigrid_schwarz_smoother_parity(gpu, hiplib, oracle):
+    """d4est_hip_schwarz_smooth = d4est_solver_multigrid_smoother_schwarz: 3 x { r = rhs - A u; Schwarz iterate }, final residual"""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    m, J, rst, sides, sz = _setup(2, 2, True, 2, oracle, 6, 1e-15, 1e-15)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan.set_geometry(J, rst)
+    plan.set_faces(sides, 10.0, 0)
+    u0 = M.splitmix64_uniform(91, m.local_nodes) - 0.5
+    rhs = M.splitmix64_uniform(92, m.local_nodes) - 0.5
+    u_ref, r_ref = oracle.schwarz_smoother(sz.metadata, u0, rhs, 3, 6, 1e-15, 1e-15)
+    u = _t(u0, gpu); r = torch.full_like(u, float("nan"))
+    sz.smooth(plan, u, _t(rhs, gpu), r, 3)
+    assert _rel(u.cpu().numpy(), u_ref) <= 1e-9
+    assert _rel(r.cpu().numpy(), r_ref) <= 1e-8
+    assert np.linalg.norm(r_ref) < np.linalg.norm(rhs - oracle.apply_aij(m, J, rst, sides, u0))
+    sz.destroy()
