@@ -46,6 +46,6 @@ sz.restrict_field(r, x)
 torch.cuda.synchronize()
 t = time.time()
 for _ in range(10):
-    sz.plan.apply_aij(x, y, sz.plan and torch.zeros(max(sz.plan.ghost_trace_size, 1), dtype=torch.float64, device=dev)) if False else sz.apply_over_subdomains(x, y)
+    sz.apply_over_subdomains(x, y)
 torch.cuda.synchronize()
 print(f"apply_over_subdomains: {(time.time() - t) / 10 * 1e3:.3f} ms")
