@@ -67,6 +67,14 @@ __device__ inline bool in_overlap(const VirtDesc& q, int n, int& i, int& j, int&
   return i >= q.lo[0] && i < q.hi[0] && j >= q.lo[1] && j < q.hi[1] && k >= q.lo[2] && k < q.hi[2];
 }
 
+// n-th restricted node of a copy (x fastest) -> its offset in a field over the subdomains; count = restricted_count(q)
+__device__ inline int restricted_count(const VirtDesc& q) { return (q.hi[0] - q.lo[0]) * (q.hi[1] - q.lo[1]) * (q.hi[2] - q.lo[2]); }
+__device__ inline size_t restricted_offset(const VirtDesc& q, int n) {
+  const int e0 = q.hi[0] - q.lo[0], e1 = q.hi[1] - q.lo[1];
+  const int i = q.lo[0] + n % e0, j = q.lo[1] + (n / e0) % e1, k = q.lo[2] + n / (e0 * e1);
+  return (size_t)q.dst + i + q.N * (j + q.N * k);
+}
+
 // fixed-order sum over the workgroup (same result on every launch)
 __device__ inline double block_sum(double v, double* red) {
   red[threadIdx.x] = v;
@@ -151,10 +159,10 @@ __global__ __launch_bounds__(256) void schwarz_cg_kernel(const VirtDesc* __restr
   double acc = 0.0;
   for (int v = v0; v < v1; ++v) {
     const VirtDesc q = vd[v];
-    const int n3 = q.N * q.N * q.N;
-    for (int n = threadIdx.x; n < n3; n += blockDim.x) {
-      int i, j, k;
-      if (in_overlap(q, n, i, j, k)) acc += d[q.dst + n] * Ad[q.dst + n];
+    const int nr = restricted_count(q);
+    for (int n = threadIdx.x; n < nr; n += blockDim.x) {
+      const size_t o = restricted_offset(q, n);
+      acc += d[o] * Ad[o];
     }
   }
   const double d_dot_Ad = block_sum(acc, red);
@@ -163,29 +171,23 @@ __global__ __launch_bounds__(256) void schwarz_cg_kernel(const VirtDesc* __restr
   acc = 0.0;
   for (int v = v0; v < v1; ++v) {
     const VirtDesc q = vd[v];
-    const int n3 = q.N * q.N * q.N;
-    for (int n = threadIdx.x; n < n3; n += blockDim.x) {
-      int i, j, k;
-      if (in_overlap(q, n, i, j, k)) {
-        const size_t o = (size_t)q.dst + n;
-        du[o] += alpha * d[o];
-        const double rn = r[o] - alpha * Ad[o];
-        r[o] = rn;
-        acc += rn * rn;
-      }
+    const int nr = restricted_count(q);
+    for (int n = threadIdx.x; n < nr; n += blockDim.x) {
+      const size_t o = restricted_offset(q, n);
+      du[o] += alpha * d[o];
+      const double rn = r[o] - alpha * Ad[o];
+      r[o] = rn;
+      acc += rn * rn;
     }
   }
   const double delta_new = block_sum(acc, red);
   const double beta = delta_new / delta_old;
   for (int v = v0; v < v1; ++v) {
     const VirtDesc q = vd[v];
-    const int n3 = q.N * q.N * q.N;
-    for (int n = threadIdx.x; n < n3; n += blockDim.x) {
-      int i, j, k;
-      if (in_overlap(q, n, i, j, k)) {
-        const size_t o = (size_t)q.dst + n;
-        d[o] = r[o] + beta * d[o];
-      }
+    const int nr = restricted_count(q);
+    for (int n = threadIdx.x; n < nr; n += blockDim.x) {
+      const size_t o = restricted_offset(q, n);
+      d[o] = r[o] + beta * d[o];
     }
   }
   if (threadIdx.x == 0) {
