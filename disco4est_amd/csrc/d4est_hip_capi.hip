@@ -31,6 +31,11 @@ void check_plan(const d4est_hip_plan_t* plan, const char* fn) {
   if (!plan) D4EST_HIP_ABORT("%s: NULL plan", fn);
 }
 
+// any change of the plan's state invalidates a captured cheby_iterate graph (D4EST_HIP_TUNE_GRAPH)
+static void drop_graph(d4est_hip_plan_t* plan) {
+  if (plan->cheby_graph) { (void)hipGraphExecDestroy(plan->cheby_graph); plan->cheby_graph = nullptr; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -209,17 +214,20 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   d4est_hip::faces_destroy(plan);
   (void)hipFree(plan->d_work_p); (void)hipFree(plan->d_work_d); (void)hipFree(plan->d_work_r);
   (void)hipFree(plan->d_reduce); (void)hipFree(plan->d_ghost_trace);
+  if (plan->cheby_graph) (void)hipGraphExecDestroy(plan->cheby_graph);
   if (plan->side_stream) { (void)hipStreamDestroy(plan->side_stream); (void)hipEventDestroy(plan->ev_fork); (void)hipEventDestroy(plan->ev_join); }
   delete plan;
 }
 
 void d4est_hip_plan_set_stream(d4est_hip_plan_t* plan, void* hip_stream) {
   check_plan(plan, "plan_set_stream");
+  drop_graph(plan);
   plan->stream = reinterpret_cast<hipStream_t>(hip_stream);
 }
 
 void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value) {
   check_plan(plan, "plan_set_tuning");
+  drop_graph(plan);
   if (key < 0 || key >= D4EST_HIP_TUNE_COUNT) D4EST_HIP_ABORT("plan_set_tuning: unknown key %d", key);
   plan->tuning[key] = value;
 }
@@ -231,6 +239,7 @@ int d4est_hip_plan_n_elements(const d4est_hip_plan_t* plan) { check_plan(plan, "
 
 void d4est_hip_plan_set_geometry(d4est_hip_plan_t* plan, const double* J_quad, const double* rst_xyz_quad, int on_device) {
   check_plan(plan, "plan_set_geometry");
+  drop_graph(plan);
   if (!J_quad || !rst_xyz_quad) D4EST_HIP_ABORT("plan_set_geometry: NULL geometry array");
   const size_t nq = (size_t)plan->local_nodes_quad;
   if (!plan->d_J) HIP_CHECK(hipMalloc(&plan->d_J, std::max<size_t>(nq, 1) * sizeof(double)));
@@ -255,6 +264,7 @@ void d4est_hip_plan_set_geometry(d4est_hip_plan_t* plan, const double* J_quad, c
 
 void d4est_hip_plan_set_geometry_numerical(d4est_hip_plan_t* plan, const double* xyz_lobatto, int on_device) {
   check_plan(plan, "plan_set_geometry_numerical");
+  drop_graph(plan);
   if (!xyz_lobatto) D4EST_HIP_ABORT("plan_set_geometry_numerical: NULL coordinate array");
   const size_t ln = (size_t)plan->local_nodes, nq = (size_t)plan->local_nodes_quad;
   if (!plan->d_J) HIP_CHECK(hipMalloc(&plan->d_J, std::max<size_t>(nq, 1) * sizeof(double)));
@@ -284,6 +294,7 @@ static int* upload_elem_dq(d4est_hip_plan_t* plan, const int* elem_dq, double ro
 
 void d4est_hip_plan_set_geometry_brick(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents) {
   check_plan(plan, "plan_set_geometry_brick");
+  drop_graph(plan);
   int* d_dq = upload_elem_dq(plan, elem_dq, root_len, extents, "plan_set_geometry_brick");
   const size_t nq = (size_t)plan->local_nodes_quad;
   if (!plan->d_J) HIP_CHECK(hipMalloc(&plan->d_J, std::max<size_t>(nq, 1) * sizeof(double)));
@@ -296,6 +307,7 @@ void d4est_hip_plan_set_geometry_brick(d4est_hip_plan_t* plan, const int* elem_d
 
 void d4est_hip_plan_set_mortar_geometry_brick(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents) {
   check_plan(plan, "plan_set_mortar_geometry_brick");
+  drop_graph(plan);
   if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_mortar_geometry_brick: call plan_set_faces first");
   int* d_dq = upload_elem_dq(plan, elem_dq, root_len, extents, "plan_set_mortar_geometry_brick");
   d4est_hip::faces_set_geometry_brick(plan, d_dq, root_len, extents);
@@ -380,6 +392,7 @@ void d4est_hip_plan_set_faces(d4est_hip_plan_t* plan, const int* side_nbr, const
                               const int* side_mortar_stride, const int* side_bndry_stride, int total_mortar_nodes,
                               int total_bndry_nodes, int n_ghost, const int* ghost_deg, const int* ghost_deg_quad) {
   check_plan(plan, "plan_set_faces");
+  drop_graph(plan);
   if (plan->has_faces) D4EST_HIP_ABORT("plan_set_faces: faces already set (build a new plan per mesh)");
   const size_t ns = 6 * (size_t)plan->n_elements;
   if (ns > 0 && (!side_nbr || !side_nbr_face || !side_reorder || !side_mortar_stride || !side_bndry_stride)) D4EST_HIP_ABORT("plan_set_faces: NULL side array");
@@ -403,6 +416,7 @@ void d4est_hip_plan_set_faces(d4est_hip_plan_t* plan, const int* side_nbr, const
 void d4est_hip_plan_set_hanging(d4est_hip_plan_t* plan, const int* side_hang, const int* side_sub, const int* side_nbr4,
                                 const int* side_orientation) {
   check_plan(plan, "plan_set_hanging");
+  drop_graph(plan);
   if (plan->has_faces) D4EST_HIP_ABORT("plan_set_hanging: call before d4est_hip_plan_set_faces");
   const size_t ns = 6 * (size_t)plan->n_elements;
   if (ns > 0 && (!side_hang || !side_sub || !side_nbr4 || !side_orientation)) D4EST_HIP_ABORT("plan_set_hanging: NULL array");
@@ -414,6 +428,7 @@ void d4est_hip_plan_set_hanging(d4est_hip_plan_t* plan, const int* side_hang, co
 
 void d4est_hip_plan_set_sipg(d4est_hip_plan_t* plan, double penalty_prefactor, int penalty_fcn) {
   check_plan(plan, "plan_set_sipg");
+  drop_graph(plan);
   if (penalty_fcn < 0 || penalty_fcn > 3) D4EST_HIP_ABORT("plan_set_sipg: unknown penalty function %d", penalty_fcn);
   if (plan->has_face_geometry) D4EST_HIP_ABORT("plan_set_sipg: call before plan_set_mortar_geometry");
   plan->sipg_prefactor = penalty_prefactor;
@@ -423,18 +438,21 @@ void d4est_hip_plan_set_sipg(d4est_hip_plan_t* plan, double penalty_prefactor, i
 void d4est_hip_plan_set_mortar_geometry(d4est_hip_plan_t* plan, const double* sj, const double* n, const double* drst_dxyz_m,
                                         const double* drst_dxyz_p_porder, const double* hm, const double* hp, int on_device) {
   check_plan(plan, "plan_set_mortar_geometry");
+  drop_graph(plan);
   if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_mortar_geometry: call plan_set_faces first");
   d4est_hip::faces_set_geometry(plan, sj, n, drst_dxyz_m, drst_dxyz_p_porder, hm, hp, on_device);
 }
 
 void d4est_hip_plan_set_dirichlet_values(d4est_hip_plan_t* plan, const double* g_lobatto, int on_device) {
   check_plan(plan, "plan_set_dirichlet_values");
+  drop_graph(plan);
   if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_dirichlet_values: call plan_set_faces first");
   d4est_hip::faces_set_dirichlet(plan, g_lobatto, on_device);
 }
 
 void d4est_hip_plan_set_robin_values(d4est_hip_plan_t* plan, const double* coeff_quad, const double* rhs_quad, int on_device) {
   check_plan(plan, "plan_set_robin_values");
+  drop_graph(plan);
   if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_robin_values: call d4est_hip_plan_set_faces first");
   d4est_hip::faces_set_robin(plan, coeff_quad, rhs_quad, on_device);
 }
@@ -473,6 +491,7 @@ void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const doub
 
 void d4est_hip_plan_set_comm(d4est_hip_plan_t* plan, d4est_hip_exchange_fn exchange, d4est_hip_allreduce_fn allreduce, void* ctx) {
   check_plan(plan, "plan_set_comm");
+  drop_graph(plan);
   plan->exchange_fn = exchange;
   plan->allreduce_fn = allreduce;
   plan->comm_ctx = ctx;

@@ -113,11 +113,14 @@ struct d4est_hip_plan {
   double *d_work_p = nullptr, *d_work_d = nullptr, *d_work_r = nullptr, *d_reduce = nullptr, *d_ghost_trace = nullptr;
   hipStream_t side_stream = nullptr;  // the trace kernel (and the exchange) run here, concurrently with the volume kernel
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // D4EST_HIP_TUNE_GRAPH: the last cheby_iterate call captured as a hipGraph (replayed while the arguments stay the same)
+  hipGraphExec_t cheby_graph = nullptr;
+  struct { const void *u, *rhs, *Au, *r; int iter, flag; double lmin, lmax; hipStream_t stream; } cheby_graph_key = {};
   d4est_hip_exchange_fn exchange_fn = nullptr;
   d4est_hip_allreduce_fn allreduce_fn = nullptr;
   void* comm_ctx = nullptr;
 
-  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
+  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;

@@ -177,9 +177,39 @@ void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const doubl
   HIP_CHECK(hipGetLastError());
 }
 
+static void cheby_iterate_body(d4est_hip_plan* plan, double* u, const double* rhs, double* Au, double* r, int iter, double lmin,
+                               double lmax, int compute_residual_at_end);
+
 void cheby_iterate(d4est_hip_plan* plan, double* u, const double* rhs, double* Au, double* r, int iter, double lmin, double lmax,
                    int compute_residual_at_end) {
   ensure_solver_workspace(plan);
+  // launch-bound meshes: replay the whole loop (iter x {traces, volume, flux, update}) as one hipGraph
+  const bool graph = plan->tuning[D4EST_HIP_TUNE_GRAPH] > 0 && plan->stream != nullptr && !plan->exchange_fn &&
+                     plan->ghost_trace_doubles == 0 && plan->tuning[D4EST_HIP_TUNE_OVERLAP_TRACES] <= 0;
+  if (!graph) {
+    cheby_iterate_body(plan, u, rhs, Au, r, iter, lmin, lmax, compute_residual_at_end);
+    return;
+  }
+  auto& k = plan->cheby_graph_key;
+  const bool same = plan->cheby_graph && k.u == u && k.rhs == rhs && k.Au == Au && k.r == r && k.iter == iter &&
+                    k.flag == compute_residual_at_end && k.lmin == lmin && k.lmax == lmax && k.stream == plan->stream;
+  if (!same) {
+    if (plan->cheby_graph) { HIP_CHECK(hipGraphExecDestroy(plan->cheby_graph)); plan->cheby_graph = nullptr; }
+    if (!plan->has_faces) D4EST_HIP_ABORT("smoother: the plan has no faces (plan_set_faces)");
+    hipGraph_t g = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(plan->stream, hipStreamCaptureModeThreadLocal));
+    cheby_iterate_body(plan, u, rhs, Au, r, iter, lmin, lmax, compute_residual_at_end);
+    HIP_CHECK(hipStreamEndCapture(plan->stream, &g));
+    HIP_CHECK(hipGraphInstantiate(&plan->cheby_graph, g, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphDestroy(g));
+    k.u = u; k.rhs = rhs; k.Au = Au; k.r = r; k.iter = iter; k.flag = compute_residual_at_end; k.lmin = lmin; k.lmax = lmax;
+    k.stream = plan->stream;
+  }
+  HIP_CHECK(hipGraphLaunch(plan->cheby_graph, plan->stream));
+}
+
+static void cheby_iterate_body(d4est_hip_plan* plan, double* u, const double* rhs, double* Au, double* r, int iter, double lmin,
+                               double lmax, int compute_residual_at_end) {
   const int n = plan->local_nodes;
   const double d = (lmax + lmin) * .5, c = (lmax - lmin) * .5;
   double alpha = 0.0, beta = 0.0;

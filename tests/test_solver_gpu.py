@@ -123,3 +123,42 @@ def test_dot_deterministic(gpu, hiplib):
     assert o1.item() == o2.item()
     ref = float(np.dot(x.cpu().numpy(), y.cpu().numpy()))
     assert abs(o1.item() - ref) <= 1e-12 * abs(ref)
+
+
+def test_cheby_iterate_hipgraph_replay(gpu, hiplib, oracle):
+    """tuning key 9: the captured loop gives bit-identical results, is replayed while the arguments stay the same, re-captured when they
+    change, and dropped when the plan changes"""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    m = M.BrickMesh(1, 3)
+    mp = M.SineMap(0.05)
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    stream = torch.cuda.Stream()
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=stream)
+    plan.set_geometry(J, rst)
+    plan.set_faces(sides, 10.0, 0)
+    u0 = M.splitmix64_uniform(11, m.local_nodes)
+    rhs = _t(M.splitmix64_uniform(12, m.local_nodes) - 0.5, gpu)
+
+    def run(iters, lmax):
+        with torch.cuda.stream(stream):
+            u = _t(u0, gpu); Au = torch.empty_like(u); r = torch.full_like(u, float("nan"))
+            for _ in range(2):          # second call: replay (graph) on top of the first call's result
+                plan.cheby_iterate(u, rhs, Au, r, iters, 1.0, lmax, 1)
+            stream.synchronize()
+        return u.cpu().numpy(), r.cpu().numpy()
+
+    plan.set_tuning(9, 0)
+    ref = {k: run(*k) for k in ((4, 30.0), (6, 30.0), (4, 25.0))}
+    plan.set_tuning(9, 1)
+    for k in ((4, 30.0), (6, 30.0), (4, 25.0), (4, 30.0)):
+        got = run(*k)
+        assert np.array_equal(got[0], ref[k][0]) and np.array_equal(got[1], ref[k][1]), k
+    # a change of the plan's data drops the captured graph: new boundary values must show up in the result
+    g = np.ones(int(sides["total_bndry_nodes"]))
+    plan.set_dirichlet_values(g)
+    got = run(4, 30.0)
+    assert not np.array_equal(got[0], ref[(4, 30.0)][0])
+    plan.set_tuning(9, 0)
+    plain = run(4, 30.0)
+    assert np.array_equal(got[0], plain[0])
