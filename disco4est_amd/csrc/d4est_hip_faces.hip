@@ -989,12 +989,16 @@ __global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restr
   }
 }
 
+// FUSE: the Chebyshev update of the element (r = alpha (rhs - Au), p = r + beta p, u += p; cheby_update_kernel, same roundings) runs
+// in the epilogue, where the element's final Au is in registers -- one kernel and one read of Au less per smoother iteration.  u is
+// not an input of this kernel (the faces read traces), so updating it in place is safe.
+template <bool FUSE>
 __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
                                                         double* __restrict__ Au, const SideDesc* __restrict__ sd,
                                                         const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                         const double* __restrict__ geom, const double* __restrict__ bndry_q,
                                                         const double* __restrict__ robin_c, const double* __restrict__ robin_r,
-                                                        int n_elem, int xcd_chunk) {
+                                                        int n_elem, int xcd_chunk, ChebyFuse cf) {
   __shared__ double s_in[6][4][64];   // per wave: 4 term fields on the 8 x 8 grid
   __shared__ double s_tmp[6][4][64];
   __shared__ double s_E[6][64];       // per wave: E of its side, zero-padded to 8 x 8
@@ -1104,7 +1108,17 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
         v = fma(s_D[(N - 1) * 8 + j], s_N[3][i + 8 * k], v);
         v = fma(s_D[k], s_N[4][i + 8 * j], v);
         v = fma(s_D[(N - 1) * 8 + k], s_N[5][i + 8 * j], v);
-        Au[el.ns + idx] = (rep == 0 ? au0 : au1) + v;
+        const double a = (rep == 0 ? au0 : au1) + v;
+        Au[el.ns + idx] = a;
+        if (FUSE) {
+          const size_t o = (size_t)el.ns + idx;
+          const double res = __dadd_rn(cf.rhs[o], __dmul_rn(-1.0, a));
+          const double ri = __dmul_rn(cf.alpha, res);
+          const double pi = __dadd_rn(__dmul_rn(cf.beta, cf.p[o]), ri);
+          cf.r[o] = ri;
+          cf.p[o] = pi;
+          cf.u[o] = __dadd_rn(cf.u[o], pi);
+        }
       }
     }
     __syncthreads();
@@ -2221,10 +2235,10 @@ static void debug_occupancy_once() {
   done = true;
   int nt = -1, nf = -1;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nt, reinterpret_cast<const void*>(trace_wave_kernel), 384, 0);
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, reinterpret_cast<const void*>(flux_wave_kernel), 384, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, reinterpret_cast<const void*>(flux_wave_kernel<false>), 384, 0);
   hipFuncAttributes at{}, af{};
   (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(trace_wave_kernel));
-  (void)hipFuncGetAttributes(&af, reinterpret_cast<const void*>(flux_wave_kernel));
+  (void)hipFuncGetAttributes(&af, reinterpret_cast<const void*>(flux_wave_kernel<false>));
   std::fprintf(stderr, "[d4est_hip] occupancy: trace_wave %d wg/CU (regs %d, lds %zu, scratch %zu) flux_wave %d wg/CU (regs %d, lds %zu, scratch %zu)\n",
                nt, at.numRegs, at.sharedSizeBytes, at.localSizeBytes, nf, af.numRegs, af.sharedSizeBytes, af.localSizeBytes);
 }
@@ -2289,8 +2303,15 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au) {
+// true when launch_flux runs the kernel that can carry the Chebyshev update in its epilogue
+bool flux_can_fuse_update(d4est_hip_plan* plan) {
   FaceHost& fh = g_face_host[plan];
+  return plan->has_faces && plan->n_elements > 0 && !fh.hp && plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0;
+}
+
+void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf) {
+  FaceHost& fh = g_face_host[plan];
+  if (cf && !flux_can_fuse_update(plan)) D4EST_HIP_ABORT("launch_flux: fused update requested on a plan whose flux kernel cannot carry it");
   if (!plan->has_faces || !plan->has_face_geometry) D4EST_HIP_ABORT("apply flux: plan_set_faces / plan_set_mortar_geometry were not called");
   if (plan->n_elements == 0) return;
   if (fh.n_ghost_sides > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost sides but no ghost trace buffer was given", fh.n_ghost_sides);
@@ -2311,10 +2332,16 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     const int resident = face_wg_per_cu() * cus;
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
-    hipLaunchKernelGGL(flux_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
-                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops,
-                       plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n,
-                       (n % 8 == 0 && grid % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0);
+    const int chunk = (n % 8 == 0 && grid % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0;
+    if (cf)
+      hipLaunchKernelGGL(flux_wave_kernel<true>, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
+                         (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops,
+                         plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk, *cf);
+    else
+      hipLaunchKernelGGL(flux_wave_kernel<false>, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
+                         (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops,
+                         plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk,
+                         ChebyFuse{});
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int grid16 = std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256));
     hipLaunchKernelGGL(flux_mfma16_kernel, dim3(grid16), dim3(192), 0, plan->stream, trace,

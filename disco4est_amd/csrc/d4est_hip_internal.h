@@ -120,7 +120,7 @@ struct d4est_hip_plan {
   d4est_hip_allreduce_fn allreduce_fn = nullptr;
   void* comm_ctx = nullptr;
 
-  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
+  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;
@@ -150,11 +150,20 @@ int reorient_face_order(int f_m, int f_p, int o, int i);  // dGMath/d4est_refere
 void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_device);
 void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const double* rhs_quad, int on_device);
 void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost);
-void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au);
+// Chebyshev update carried by the flux kernel's epilogue (flux_wave_kernel<true>): r = alpha (rhs - Au), p = r + beta p, u += p
+struct ChebyFuse {
+  const double* rhs = nullptr;
+  double* p = nullptr;
+  double* u = nullptr;
+  double* r = nullptr;
+  double alpha = 0.0, beta = 0.0;
+};
+bool flux_can_fuse_update(d4est_hip_plan* plan);
+void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf = nullptr);
 void faces_destroy(d4est_hip_plan* plan);
 
 // d4est_hip_solver.hip
-void apply_operator(d4est_hip_plan* plan, const double* u, double* Au);
+void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const ChebyFuse* cf = nullptr);
 void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double* r);   // r = rhs - Au
 void launch_copy_blocks(hipStream_t stream, int n_blocks, const double* src, const long long* src_off, double* dst,
                         const long long* dst_off, const int* len);

@@ -138,7 +138,7 @@ void launch_dot(d4est_hip_plan* plan, int n, const double* x, const double* y, d
 // Fork-join on two streams: the trace kernel (and, through the hooks, the ghost exchange) runs on the plan's side
 // stream while the volume kernel runs on the main stream -- they only share the read-only u -- and the flux kernel
 // joins them.  At config 2 both kernels are latency-structured (~28 us each), so running them side by side hides one.
-void apply_operator(d4est_hip_plan* plan, const double* u, double* Au) {
+void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const ChebyFuse* cf) {
   if (!plan->has_faces) D4EST_HIP_ABORT("smoother: the plan has no faces (plan_set_faces)");
   ensure_solver_workspace(plan);
   const bool has_ghost = plan->ghost_trace_doubles > 0;
@@ -161,7 +161,7 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au) {
     HIP_CHECK(hipEventRecord(plan->ev_join, plan->side_stream));
     launch_stiffness(plan, u, Au);
     HIP_CHECK(hipStreamWaitEvent(main, plan->ev_join, 0));
-    launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au);
+    launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, cf);
     return;
   }
   // with ghost sides the exchange callbacks enqueue on the plan's (single) stream: traces, post, volume, complete, flux
@@ -169,7 +169,7 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au) {
   if (has_ghost) plan->exchange_fn(plan->comm_ctx, 0, plan->d_trace, plan->d_ghost_trace);
   launch_stiffness(plan, u, Au);  // overlaps the exchange: the volume term needs no ghost data
   if (has_ghost) plan->exchange_fn(plan->comm_ctx, 1, plan->d_trace, plan->d_ghost_trace);
-  launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au);
+  launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, cf);
 }
 
 void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double* r) {
@@ -214,13 +214,20 @@ static void cheby_iterate_body(d4est_hip_plan* plan, double* u, const double* rh
   const double d = (lmax + lmin) * .5, c = (lmax - lmin) * .5;
   double alpha = 0.0, beta = 0.0;
   HIP_CHECK(hipMemsetAsync(plan->d_work_p, 0, std::max<size_t>((size_t)n, 1) * sizeof(double), plan->stream));
+  const bool fuse = plan->tuning[D4EST_HIP_TUNE_FUSE_UPDATE] != 0 && flux_can_fuse_update(plan);
   for (int i = 0; i < iter; ++i) {
-    apply_operator(plan, u, Au);
     if (i == 0) alpha = 1. / d;
     else if (i == 1) alpha = 2. * d / (2 * d * d - c * c);
     else alpha = 1. / (d - (alpha * c * c / 4.));
     beta = alpha * d - 1.;
-    if (n > 0) hipLaunchKernelGGL(cheby_update_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, Au, alpha, beta, r, plan->d_work_p, u);
+    if (fuse) {   // the update rides in the flux kernel's epilogue: 3 kernels per iteration instead of 4
+      ChebyFuse cf;
+      cf.rhs = rhs; cf.p = plan->d_work_p; cf.u = u; cf.r = r; cf.alpha = alpha; cf.beta = beta;
+      apply_operator(plan, u, Au, &cf);
+    } else {
+      apply_operator(plan, u, Au);
+      if (n > 0) hipLaunchKernelGGL(cheby_update_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, Au, alpha, beta, r, plan->d_work_p, u);
+    }
   }
   if (compute_residual_at_end == 1) {
     apply_operator(plan, u, Au);

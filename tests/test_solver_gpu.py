@@ -162,3 +162,31 @@ def test_cheby_iterate_hipgraph_replay(gpu, hiplib, oracle):
     plan.set_tuning(9, 0)
     plain = run(4, 30.0)
     assert np.array_equal(got[0], plain[0])
+
+
+@pytest.mark.parametrize("level,deg", [(1, 3), (2, 7), (2, "mixed")])
+def test_cheby_update_fused_into_flux_is_bit_identical(gpu, hiplib, oracle, level, deg):
+    """tuning key 10: the update carried by the flux kernel's epilogue (default where the p <= 7 conforming flux kernel runs) gives
+    exactly the u, r, Au of the separate update kernel"""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    if deg == "mixed":
+        deg = 2 + (np.arange(8 ** level) % 5)
+    m = M.BrickMesh(level, deg)
+    mp = M.SineMap(0.05)
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan.set_geometry(J, rst)
+    plan.set_faces(sides, 10.0, 0)
+    u0 = M.splitmix64_uniform(11, m.local_nodes)
+    rhs = _t(M.splitmix64_uniform(12, m.local_nodes) - 0.5, gpu)
+    out = {}
+    for fuse in (0, 1):
+        plan.set_tuning(10, fuse)
+        for at_end in (0, 1):
+            u = _t(u0, gpu); Au = torch.full_like(u, float("nan")); r = torch.full_like(u, float("nan"))
+            plan.cheby_iterate(u, rhs, Au, r, 5, 1.0, 40.0, at_end)
+            out[(fuse, at_end)] = (u.cpu().numpy(), r.cpu().numpy(), Au.cpu().numpy())
+    for at_end in (0, 1):
+        for a, b in zip(out[(0, at_end)], out[(1, at_end)]):
+            assert np.array_equal(a, b)
