@@ -71,7 +71,7 @@ class TraceSchedule:
                     c = int(sides["side_sub"][s])
                     o = int(sides["side_orientation"][s])
                     sender_sub = c if reorient is None else int(reorient(f, f_p, o, c))
-                my_gid = mesh.first + e
+                my_gid = int(mesh.elements[e]) if hasattr(mesh, "elements") else mesh.first + e
                 ln = int(block_len(s, sub))
                 send.setdefault(peer, []).append((my_gid, f, sub, int(trace_offset(s, sub)), ln))
                 recv.setdefault(peer, []).append((gid, f_p, sender_sub, goff, ln))
