@@ -1136,12 +1136,13 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
 // then the face-local part `val` and the normal term-2 field (whose D^T spreads along the whole normal line) of the six faces
 // are combined into Au_e by all threads from LDS tiles.
 // ---------------------------------------------------------------------------
+template <bool FUSE>   // FUSE: Chebyshev update in the epilogue, see flux_wave_kernel
 __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
                                                           double* __restrict__ Au, const SideDesc* __restrict__ sd,
                                                           const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                           const double* __restrict__ geom, const double* __restrict__ bndry_q,
                                                           const double* __restrict__ robin_c, const double* __restrict__ robin_r,
-                                                          int n_elem, int xcd_chunk) {
+                                                          int n_elem, int xcd_chunk, ChebyFuse cf) {
   constexpr int LT = 17;                    // padded row length of a 16 x 16 tile in LDS
   constexpr int TPB = 192;
   __shared__ double s_tile[6][2][16 * LT];  // per face: val, normal field   (rows a, columns b)
@@ -1273,7 +1274,17 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
       if (j == N - 1) v += s_tile[3][0][i * LT + k];
       if (k == 0) v += s_tile[4][0][i * LT + j];
       if (k == N - 1) v += s_tile[5][0][i * LT + j];
-      Au[el.ns + idx] += v;
+      const size_t o = (size_t)el.ns + idx;
+      const double a = Au[o] + v;
+      Au[o] = a;
+      if (FUSE) {
+        const double res = __dadd_rn(cf.rhs[o], __dmul_rn(-1.0, a));
+        const double ri = __dmul_rn(cf.alpha, res);
+        const double pi = __dadd_rn(__dmul_rn(cf.beta, cf.p[o]), ri);
+        cf.r[o] = ri;
+        cf.p[o] = pi;
+        cf.u[o] = __dadd_rn(cf.u[o], pi);
+      }
     }
     __syncthreads();
   }
@@ -2306,7 +2317,8 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
 // true when launch_flux runs the kernel that can carry the Chebyshev update in its epilogue
 bool flux_can_fuse_update(d4est_hip_plan* plan) {
   FaceHost& fh = g_face_host[plan];
-  return plan->has_faces && plan->n_elements > 0 && !fh.hp && plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0;
+  return plan->has_faces && plan->n_elements > 0 && !fh.hp && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
+         (plan->face_fast || (fh.max_N <= 16 && fh.max_NQ <= 16));
 }
 
 void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf) {
@@ -2344,10 +2356,16 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
                          ChebyFuse{});
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int grid16 = std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256));
-    hipLaunchKernelGGL(flux_mfma16_kernel, dim3(grid16), dim3(192), 0, plan->stream, trace,
-                       ghost_trace, Au, (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
-                       plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n,
-                       (n % 8 == 0 && grid16 % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0);
+    const int chunk16 = (n % 8 == 0 && grid16 % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0;
+    if (cf)
+      hipLaunchKernelGGL(flux_mfma16_kernel<true>, dim3(grid16), dim3(192), 0, plan->stream, trace,
+                         ghost_trace, Au, (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
+                         plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk16, *cf);
+    else
+      hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(grid16), dim3(192), 0, plan->stream, trace,
+                         ghost_trace, Au, (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
+                         plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk16,
+                         ChebyFuse{});
   } else {
     const size_t lds = generic_lds_bytes(plan);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -85,7 +85,7 @@ enum d4est_hip_tuning_key {
   D4EST_HIP_TUNE_AFFINE = 7,             /* 0: always stream the per-node metric (the reference's general path); else (default) buckets whose elements all have a node-independent J (dr/dx)(dr/dx)^T (detected in plan_set_geometry, 4 ulp) rebuild the metric from 6 numbers per element */
   D4EST_HIP_TUNE_GHOST_ALIAS = 8,        /* set before plan_set_faces; 1: all ghost sides of a conforming plan share block 0 of the ghost trace buffer (for a ghost trace that is the same on every side: the zero trace of a Schwarz subdomain plan); compute_ghost_traces is then meaningless */
   D4EST_HIP_TUNE_GRAPH = 9,              /* 1: d4est_hip_cheby_iterate is captured into a hipGraph on its first call and replayed while its arguments (pointers, iteration count, eigenvalue window) stay the same -- for launch-bound meshes (multigrid coarse levels); needs a non-null plan stream and no exchange callback (single rank); default off */
-  D4EST_HIP_TUNE_FUSE_UPDATE = 10,       /* 0: cheby_iterate runs its update as a separate kernel; else (default) the update rides in the epilogue of the p <= 7 conforming flux kernel (same roundings, bit-identical) */
+  D4EST_HIP_TUNE_FUSE_UPDATE = 10,       /* 0: cheby_iterate runs its update as a separate kernel; else (default) on conforming meshes up to p = 15 the update rides in the epilogue of the flux kernel (same roundings, bit-identical) */
   D4EST_HIP_TUNE_COUNT = 11
 };
 void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value);

@@ -164,9 +164,9 @@ def test_cheby_iterate_hipgraph_replay(gpu, hiplib, oracle):
     assert np.array_equal(got[0], plain[0])
 
 
-@pytest.mark.parametrize("level,deg", [(1, 3), (2, 7), (2, "mixed")])
+@pytest.mark.parametrize("level,deg", [(1, 3), (2, 7), (2, "mixed"), (1, 9), (1, 15)])
 def test_cheby_update_fused_into_flux_is_bit_identical(gpu, hiplib, oracle, level, deg):
-    """tuning key 10: the update carried by the flux kernel's epilogue (default where the p <= 7 conforming flux kernel runs) gives
+    """tuning key 10: the update carried by the flux kernel's epilogue (default on conforming meshes up to p = 15) gives
     exactly the u, r, Au of the separate update kernel"""
     import torch
     from disco4est_amd import Plan, mesh as M
