@@ -261,3 +261,28 @@ def test_multigrid_schwarz_smoother_parity(gpu, hiplib, oracle):
     assert _rel(r.cpu().numpy(), r_ref) <= 1e-8
     assert np.linalg.norm(r_ref) < np.linalg.norm(rhs - oracle.apply_aij(m, J, rst, sides, u0))
     sz.destroy()
+
+
+def test_schwarz_with_overintegration(gpu, hiplib, oracle):
+    """deg_quad = deg + 1 (quadrature grid finer than the Lobatto grid): operator over subdomains and one iterate"""
+    import torch
+    from disco4est_amd import mesh as M
+    m, J, rst, sides, sz = _setup(2, 3, True, 2, oracle, 5, 1e-15, 1e-15, deg_quad_inc=1)
+    md = sz.metadata
+    x = torch.empty(sz.nodal_size, dtype=torch.float64, device=gpu)
+    sz.restrict_field(_t(M.splitmix64_uniform(95, m.local_nodes) - 0.5, gpu), x)
+    Ax = torch.empty_like(x)
+    sz.apply_over_subdomains(x, Ax)
+    xh, Axh = x.cpu().numpy(), Ax.cpu().numpy()
+    scale = np.abs(Axh).max()
+    for s in (0, 21, 63):
+        elem, faces, _ = md.subdomain(s)
+        ref = oracle.schwarz_apply_over_subdomain(elem, faces, 2, _over_subdomains_to_restricted(oracle, m, md, xh, s))
+        assert np.abs(_over_subdomains_to_restricted(oracle, m, md, Axh, s) - ref).max() <= 1e-12 * scale
+    u0 = np.zeros(m.local_nodes)
+    r = M.splitmix64_uniform(96, m.local_nodes) - 0.5
+    u_ref, it_ref, _ = oracle.schwarz_iterate(md, u0, r, 5, 1e-15, 1e-15)
+    u = _t(u0, gpu)
+    sz.iterate(u, _t(r, gpu))
+    assert _rel(u.cpu().numpy(), u_ref) <= 1e-9
+    sz.destroy()
