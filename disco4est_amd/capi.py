@@ -62,6 +62,7 @@ SIGNATURES = {
     "d4est_hip_transfer_fine_nodes": (ctypes.c_longlong, [_vp]),
     "d4est_hip_transfer_prolong": (None, [_vp, _vp, _vp]),
     "d4est_hip_transfer_restrict": (None, [_vp, _vp, _vp]),
+    "d4est_hip_transfer_project": (None, [_vp, _vp, _vp]),
     "d4est_hip_schwarz_create": (_vp, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "d4est_hip_schwarz_destroy": (None, [_vp]),
     "d4est_hip_schwarz_nodal_size": (ctypes.c_longlong, [_vp]),
@@ -388,6 +389,11 @@ class Transfer:
     def restrict(self, x_fine, x_coarse):
         assert x_coarse.numel() == self.coarse_nodes and x_fine.numel() == self.fine_nodes
         self.lib.d4est_hip_transfer_restrict(self.handle, _ptr(x_fine), _ptr(x_coarse))
+
+    def project(self, x_fine, x_coarse):
+        """L2 projection onto the coarse space (apply_p_restrict / apply_hp_restrict per item)"""
+        assert x_fine.numel() == self.fine_nodes and x_coarse.numel() == self.coarse_nodes
+        self.lib.d4est_hip_transfer_project(self.handle, _ptr(x_fine), _ptr(x_coarse))
 
     def destroy(self):
         if self.handle:

@@ -24,6 +24,7 @@ struct d4est_hip_transfer {
   long long* d_off = nullptr;  // per (item, child): {coarse offset, fine offset}
   int* d_item_first = nullptr; // per item: index of its first child record (n_items + 1)
   double* d_ops = nullptr;
+  double* d_rops = nullptr;    // the L2-projection operators (p_restrict / hp_restrict) at the same offsets as the prolongations
   hipStream_t stream = nullptr;
 };
 
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(256) void prolong_kernel(const double* __restrict__
   }
 }
 
-// one workgroup per coarse element: sum over its children of P_c^T x_c
+// one workgroup per coarse element: sum over its children of P_c^T x_c (TRANS, ops = prolongations) or of R_c x_c (ops = projections)
+template <bool TRANS>
 __global__ __launch_bounds__(256) void restrict_kernel(const double* __restrict__ xf, double* __restrict__ xc,
                                                        const int* __restrict__ child, const long long* __restrict__ off,
                                                        const int* __restrict__ item_first, const double* __restrict__ ops,
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void restrict_kernel(const double* __restrict_
       const long long fo = off[2 * c + 1];
       for (int i = threadIdx.x; i < Nh * Nh * Nh; i += blockDim.x) a[i] = xf[fo + i];
       __syncthreads();
-      tensor3<true>(ops + d[3], ops + d[4], ops + d[5], Nh, NH, a, b);
+      tensor3<TRANS>(ops + d[3], ops + d[4], ops + d[5], Nh, NH, a, b);
       for (int i = threadIdx.x; i < NH * NH * NH; i += blockDim.x) acc[i] += b[i];   // same thread <-> same entries: no race
       __syncthreads();
     }
@@ -118,7 +120,7 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
   if (n_items < 0 || (n_items > 0 && (!hrefine || !degH || !degh))) D4EST_HIP_ABORT("transfer_create: bad arguments");
   d4est_hip_transfer* t = new d4est_hip_transfer();
   t->n_items = n_items;
-  std::vector<double> ops;
+  std::vector<double> ops, rops;
   std::map<std::pair<int, int>, int> p_index, hp_index;
   auto get_p = [&](int dH, int dh) {
     auto key = std::make_pair(dH, dh);
@@ -127,6 +129,8 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
     std::vector<double> P = Tables1D::p_prolong(dH, dh);   // identity when dH == dh (d4est_operators.c:1114-1118 copies)
     const int o = (int)ops.size();
     ops.insert(ops.end(), P.begin(), P.end());
+    std::vector<double> R = Tables1D::p_restrict(dH, dh);  // (dH+1) x (dh+1), d4est_operators.c:1165-1185
+    rops.insert(rops.end(), R.begin(), R.end());
     p_index[key] = o;
     return o;
   };
@@ -137,6 +141,8 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
     std::vector<double> P = Tables1D::hp_prolong(dH, dh);  // 2 x (dh+1) x (dH+1)
     const int o = (int)ops.size();
     ops.insert(ops.end(), P.begin(), P.end());
+    std::vector<double> R = Tables1D::hp_restrict(dH, dh); // 2 x (dH+1) x (dh+1), d4est_operators.c:1232-1259
+    rops.insert(rops.end(), R.begin(), R.end());
     hp_index[key] = o;
     return o;
   };
@@ -181,12 +187,14 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
   if (!off.empty()) HIP_CHECK(hipMemcpy(t->d_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
   HIP_CHECK(hipMalloc(&t->d_ops, std::max<size_t>(ops.size(), 1) * sizeof(double)));
   if (!ops.empty()) HIP_CHECK(hipMemcpy(t->d_ops, ops.data(), ops.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMalloc(&t->d_rops, std::max<size_t>(rops.size(), 1) * sizeof(double)));
+  if (!rops.empty()) HIP_CHECK(hipMemcpy(t->d_rops, rops.data(), rops.size() * sizeof(double), hipMemcpyHostToDevice));
   return t;
 }
 
 void d4est_hip_transfer_destroy(d4est_hip_transfer_t* t) {
   if (!t) return;
-  (void)hipFree(t->d_child); (void)hipFree(t->d_off); (void)hipFree(t->d_item_first); (void)hipFree(t->d_ops);
+  (void)hipFree(t->d_child); (void)hipFree(t->d_off); (void)hipFree(t->d_item_first); (void)hipFree(t->d_ops); (void)hipFree(t->d_rops);
   delete t;
 }
 
@@ -209,16 +217,29 @@ void d4est_hip_transfer_prolong(d4est_hip_transfer_t* t, const double* x_coarse_
   HIP_CHECK(hipGetLastError());
 }
 
-void d4est_hip_transfer_restrict(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev) {
-  if (!t) D4EST_HIP_ABORT("transfer_restrict: NULL transfer");
+static void launch_restrict(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev, bool project, const char* who) {
+  if (!t) D4EST_HIP_ABORT("%s: NULL transfer", who);
   if (t->n_items == 0) return;
   const int n3 = t->max_n * t->max_n * t->max_n;
   const size_t lds = (size_t)3 * n3 * sizeof(double);
-  if (lds > 160 * 1024) D4EST_HIP_ABORT("transfer_restrict: degree too high for the LDS-resident kernel");
-  if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(d4est_hip::restrict_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(d4est_hip::restrict_kernel, dim3(std::min(t->n_items, 65536)), dim3(256), lds, t->stream, x_fine_dev, x_coarse_dev,
-                     t->d_child, t->d_off, t->d_item_first, t->d_ops, t->n_items, n3);
+  if (lds > 160 * 1024) D4EST_HIP_ABORT("%s: degree too high for the LDS-resident kernel", who);
+  const void* fn = project ? reinterpret_cast<const void*>(d4est_hip::restrict_kernel<false>) : reinterpret_cast<const void*>(d4est_hip::restrict_kernel<true>);
+  if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (project)
+    hipLaunchKernelGGL(d4est_hip::restrict_kernel<false>, dim3(std::min(t->n_items, 65536)), dim3(256), lds, t->stream, x_fine_dev, x_coarse_dev,
+                       t->d_child, t->d_off, t->d_item_first, t->d_rops, t->n_items, n3);
+  else
+    hipLaunchKernelGGL(d4est_hip::restrict_kernel<true>, dim3(std::min(t->n_items, 65536)), dim3(256), lds, t->stream, x_fine_dev, x_coarse_dev,
+                       t->d_child, t->d_off, t->d_item_first, t->d_ops, t->n_items, n3);
   HIP_CHECK(hipGetLastError());
+}
+
+void d4est_hip_transfer_restrict(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev) {
+  launch_restrict(t, x_fine_dev, x_coarse_dev, false, "transfer_restrict");
+}
+
+void d4est_hip_transfer_project(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev) {
+  launch_restrict(t, x_fine_dev, x_coarse_dev, true, "transfer_project");
 }
 
 }  // extern "C"

@@ -298,6 +298,9 @@ long long d4est_hip_transfer_fine_nodes(const d4est_hip_transfer_t* t);
 void d4est_hip_transfer_prolong(d4est_hip_transfer_t* t, const double* x_coarse_dev, double* x_fine_dev);
 /* x_coarse = P^T x_fine (d4est_operators_apply_p_prolong_transpose / _hp_prolong_transpose per item; overwrites x_coarse) */
 void d4est_hip_transfer_restrict(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev);
+/* x_coarse = L2 projection of x_fine (d4est_operators_apply_p_restrict / _hp_restrict per item, src/dGMath/d4est_operators.c:1205-1230,
+ * :1275-1297: M_H^-1 P^T M_h, children summed; the restriction of FIELDS, e.g. of the solution when the mesh is coarsened) */
+void d4est_hip_transfer_project(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev);
 
 /* ---- additive Schwarz smoother ------------------------------------------------------------
  * Replaces d4est_solver_schwarz_iterate (src/Solver/d4est_solver_schwarz.c:172-285) with its CG subdomain solver

@@ -95,3 +95,42 @@ def test_empty_transfer(gpu, hiplib):
     t.prolong(z, z.clone()); t.restrict(z, z.clone())
     torch.cuda.synchronize()
     t.destroy()
+
+
+@pytest.mark.parametrize("seed,n_items,pmax", [(5, 12, 5), (6, 6, 9)])
+def test_projection_parity(gpu, hiplib, oracle, seed, n_items, pmax):
+    """d4est_hip_transfer_project = d4est_operators_apply_p_restrict / _hp_restrict per item (the L2 projection of a field onto the
+    coarse space): parity with the oracle, and project(prolong(x)) = x"""
+    import torch
+    from disco4est_amd import Transfer, mesh as M
+    dp = ctypes.POINTER(ctypes.c_double)
+    ip = ctypes.POINTER(ctypes.c_int)
+    lib = oracle.lib
+    lib.oracle_apply_p_restrict.argtypes = [dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp]
+    lib.oracle_apply_hp_restrict.argtypes = [dp, ip, ctypes.c_int, ctypes.c_int, dp]
+    hrefine, degH, degh = _items(seed, n_items, pmax)
+    t = Transfer(hrefine, degH, degh)
+    xf = M.splitmix64_uniform(seed + 200, t.fine_nodes) - 0.5
+    ref = np.zeros(t.coarse_nodes)
+    co = fo = 0
+    for k in range(n_items):
+        dH = int(degH[k]); nH = (dH + 1) ** 3
+        dh = np.ascontiguousarray(degh[8 * k:8 * k + 8], dtype=np.int32)
+        nc = 8 if hrefine[k] else 1
+        nf = int(sum((int(d) + 1) ** 3 for d in dh[:nc]))
+        src = np.ascontiguousarray(xf[fo:fo + nf]); dst = np.zeros(nH)
+        if nc == 1:
+            lib.oracle_apply_p_restrict(src.ctypes.data_as(dp), int(dh[0]), 3, dH, dst.ctypes.data_as(dp))
+        else:
+            lib.oracle_apply_hp_restrict(src.ctypes.data_as(dp), dh.ctypes.data_as(ip), 3, dH, dst.ctypes.data_as(dp))
+        ref[co:co + nH] = dst
+        co += nH; fo += nf
+    out = torch.full((t.coarse_nodes,), float("nan"), dtype=torch.float64, device=gpu)
+    t.project(torch.from_numpy(xf).to(gpu), out)
+    assert np.abs(out.cpu().numpy() - ref).max() <= RTOL * np.abs(ref).max()
+    xc = torch.from_numpy(M.splitmix64_uniform(seed + 300, t.coarse_nodes) - 0.5).to(gpu)
+    fine = torch.empty(t.fine_nodes, dtype=torch.float64, device=gpu)
+    back = torch.empty_like(xc)
+    t.prolong(xc, fine)
+    t.project(fine, back)
+    assert float((back - xc).abs().max()) <= 1e-11
