@@ -53,12 +53,14 @@ def _mixed(level, lo, hi):
     return lo + (np.arange(n) * 7 % (hi - lo + 1))
 
 
-@pytest.mark.parametrize("level,deg,curved,rs", [(1, 2, False, 2), (2, 3, True, 2), (2, "mixed", True, 3), (2, 4, False, 5)])
+@pytest.mark.parametrize("level,deg,curved,rs", [(1, 2, False, 2), (2, 3, True, 2), (2, "mixed", True, 3), (2, 4, False, 5), (2, "low", True, 2)])
 def test_restriction_and_operator_parity(gpu, hiplib, oracle, level, deg, curved, rs):
     import torch
     from disco4est_amd import mesh as M
     if deg == "mixed":
         deg = _mixed(level, 2, 4)
+    elif deg == "low":
+        deg = _mixed(level, 1, 3)        # p = 1 elements: the overlap covers the whole element
     m, J, rst, sides, sz = _setup(level, deg, curved, rs, oracle)
     md = sz.metadata
     field = M.splitmix64_uniform(21, m.local_nodes) - 0.5
