@@ -296,7 +296,7 @@ class HangingBrickMesh(BrickMesh):
     ``deg`` is an int or an array over the GLOBAL elements; ``first``/``count`` select a contiguous range of the global
     (Morton) element list = the shard of one rank; off-rank face neighbours become ghost elements."""
 
-    def __init__(self, level, refine, deg, deg_quad_inc=0, quad_type=0, first=0, count=None):
+    def __init__(self, level, refine, deg, deg_quad_inc=0, quad_type=0, first=0, count=None, elements=None):
         self.level = level
         self.quad_type = quad_type
         base = morton_order(level)
@@ -317,13 +317,22 @@ class HangingBrickMesh(BrickMesh):
         total = self._org_all.shape[0]
         deg_all = np.full(total, deg, dtype=np.int32) if np.isscalar(deg) else np.asarray(deg, dtype=np.int32)
         assert deg_all.size == total
-        count = total - first if count is None else count
+        if elements is None:
+            count = total - first if count is None else count
+            elements = np.arange(first, first + count, dtype=np.int64)
+        else:                                   # arbitrary element list (a shard followed by its ghost layer)
+            elements = np.asarray(elements, dtype=np.int64)
+            count = int(elements.size)
+            first = int(elements[0]) if count else 0
+        self.elements = elements
+        self._g2l = -np.ones(total, dtype=np.int64)
+        self._g2l[elements] = np.arange(count)
         self.global_elements = total
         self.first = first
         self.n_elements = count
-        self.org = self._org_all[first:first + count]
-        self.size = self._size_all[first:first + count]
-        self.deg = deg_all[first:first + count].copy()
+        self.org = self._org_all[elements]
+        self.size = self._size_all[elements]
+        self.deg = deg_all[elements].copy()
         self.deg_quad = (self.deg + deg_quad_inc).astype(np.int32)
         self.hf = 1.0 / (1 << (level + 1))      # fine grid spacing
         self.h_elem = self.size * self.hf
@@ -409,7 +418,7 @@ class HangingBrickMesh(BrickMesh):
             o, sz = self._org_all[g], self._size_all[g]
             owner[o[0]:o[0] + sz, o[1]:o[1] + sz, o[2]:o[2] + sz] = g
         first = self.first
-        is_local = lambda g: first <= g < first + ne
+        is_local = lambda g: self._g2l[g] >= 0
         # pass 1: global neighbour ids per side
         nbr_g = np.full(6 * ne, -1, dtype=np.int64)
         nbr4_g = np.full(4 * 6 * ne, -1, dtype=np.int64)
@@ -454,9 +463,9 @@ class HangingBrickMesh(BrickMesh):
         # ghosts: every off-rank element referenced
         refd = np.concatenate([nbr_g, nbr4_g])
         refd = refd[refd >= 0]
-        ghost_ids = np.unique(refd[(refd < first) | (refd >= first + ne)])
+        ghost_ids = np.unique(refd[self._g2l[refd] < 0])
         ghost_pos = {int(g): i for i, g in enumerate(ghost_ids)}
-        enc = lambda g: -1 if g < 0 else (int(g) - first if is_local(g) else -(ghost_pos[int(g)] + 2))
+        enc = lambda g: -1 if g < 0 else (int(self._g2l[g]) if is_local(g) else -(ghost_pos[int(g)] + 2))
         side_nbr = np.array([enc(g) for g in nbr_g], dtype=np.int32)
         side_nbr4 = np.array([enc(g) if g >= 0 else -1 for g in nbr4_g], dtype=np.int32)
         side_reorder = np.zeros(6 * ne, dtype=np.int32)
@@ -472,7 +481,7 @@ class HangingBrickMesh(BrickMesh):
         done_group = {}
         for s_ in range(6 * ne):
             e, f = divmod(s_, 6)
-            ge = first + e
+            ge = int(self.elements[e])
             hang = side_hang[s_]
             if hang == 0:
                 g = int(nbr_g[s_])

@@ -39,8 +39,8 @@ class SchwarzMetadata:
         nbr = np.asarray(sides["side_nbr"]).reshape(ne, 6)
         nbr4 = np.asarray(sides["side_nbr4"]) if "side_nbr4" in sides else np.zeros(0, dtype=np.int32)
         hanging = "side_hang" in sides and np.any(np.asarray(sides["side_hang"]) != 0)
-        if (np.any(nbr <= -2) or np.any(nbr4 <= -2)) and (cores is None or hanging):
-            raise NotImplementedError("subdomain elements on other ranks need the extended mesh of SchwarzShard (conforming meshes)")
+        if (np.any(nbr <= -2) or np.any(nbr4 <= -2)) and cores is None:
+            raise NotImplementedError("subdomain elements on other ranks need the extended mesh of SchwarzShard")
         self.num_nodes_overlap = int(num_nodes_overlap)
         if hanging:
             core_l, elem_l, faces_l = self._corner_neighbours(mesh)
@@ -109,8 +109,8 @@ class SchwarzMetadata:
         and d4est_solver_schwarz_metadata_corner_callback puts every element of that corner into the subdomain of every other one."""
         ne = mesh.n_elements
         org, size = np.asarray(mesh.org), np.asarray(mesh.size)
-        nf = int((org + size[:, None]).max())
-        owner = -np.ones((nf, nf, nf), dtype=np.int64)
+        nf = 1 << (mesh.level + 1)
+        owner = -np.ones((nf, nf, nf), dtype=np.int64)     # -1: a cell of an element this (extended) mesh does not hold
         for e in range(ne):
             o, sz = org[e], int(size[e])
             owner[o[0]:o[0] + sz, o[1]:o[1] + sz, o[2]:o[2] + sz] = e
@@ -128,6 +128,8 @@ class SchwarzMetadata:
                     cell = P - np.array([q & 1, (q >> 1) & 1, (q >> 2) & 1])
                     if np.all(cell >= 0) and np.all(cell < nf):
                         touching.add(int(owner[cell[0], cell[1], cell[2]]))
+                if -1 in touching:        # not all elements around P are known (beyond the ghost layer): never a corner of an own element
+                    continue
                 conformal = all(np.all((P == org[t]) | (P == org[t] + size[t])) for t in touching)
                 if conformal:
                     for a in touching:
@@ -319,21 +321,55 @@ def ghost_layer(level, parts, rank):
     return own, np.array(sorted(ghosts), dtype=np.int64), needed_by
 
 
+def ghost_layer_hanging(level, refine, parts, rank):
+    """ghost_layer() for a HangingBrickMesh: every off-rank element whose closed box touches an own element's (faces, edges, corners,
+    hanging or not -- P4EST_CONNECT_FULL); the conformal-corner test of the subdomain builder then sees every element around an own
+    element's corners."""
+    from .mesh import HangingBrickMesh
+    from .parallel import owner_of
+    mg = HangingBrickMesh(level, refine, 1)
+    org, size = mg._org_all, mg._size_all
+    nf = 1 << (level + 1)
+    cell = -np.ones((nf, nf, nf), dtype=np.int64)
+    for g in range(mg.global_elements):
+        o, sz = org[g], int(size[g])
+        cell[o[0]:o[0] + sz, o[1]:o[1] + sz, o[2]:o[2] + sz] = g
+    owner = owner_of(parts, mg.global_elements)
+    first, count = parts[rank]
+    own = np.arange(first, first + count, dtype=np.int64)
+    ghosts, needed_by = set(), {}
+    for g in own:
+        lo = np.maximum(org[g] - 1, 0)
+        hi = np.minimum(org[g] + size[g] + 1, nf)
+        for t in np.unique(cell[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]).tolist():
+            if owner[t] != rank:
+                ghosts.add(t)
+                needed_by.setdefault(int(owner[t]), set()).add(int(g))
+    return own, np.array(sorted(ghosts), dtype=np.int64), needed_by
+
+
 class SchwarzShard:
-    """The smoother on one rank of a sharded (conforming) brick.  The rank's *extended mesh* is its own elements followed by the
-    ghost layer; subdomains exist for the own elements only and may contain ghost-layer elements, whose geometric factors the rank
-    computes itself (as d4est_solver_schwarz_geometric_data_init does for ghost elements) and whose residual arrives by a whole-element
-    exchange; corrections computed for ghost-layer elements travel back to their owners and are added there
-    (d4est_solver_schwarz_transfer_ghost_data_and_add_corrections).  One forward and one backward point-to-point exchange per iterate."""
+    """The smoother on one rank of a sharded brick (``refine=None``: conforming BrickMesh; else a HangingBrickMesh).  The rank's
+    *extended mesh* is its own elements followed by the ghost layer; subdomains exist for the own elements only and may contain
+    ghost-layer elements, whose geometric factors the rank computes itself (as d4est_solver_schwarz_geometric_data_init does for ghost
+    elements) and whose residual arrives by a whole-element exchange; corrections computed for ghost-layer elements travel back to
+    their owners and are added there (d4est_solver_schwarz_transfer_ghost_data_and_add_corrections).  One forward and one backward
+    point-to-point exchange per iterate."""
 
     def __init__(self, level, deg_global, parts, rank, mapping, num_nodes_overlap, subdomain_iter, subdomain_atol, subdomain_rtol,
-                 transport, device, penalty_prefactor=10.0, penalty_fcn=0, deg_quad_inc=0, quad_type=0, transport_back=None):
+                 transport, device, penalty_prefactor=10.0, penalty_fcn=0, deg_quad_inc=0, quad_type=0, transport_back=None, refine=None):
         import torch
-        from .mesh import BrickMesh
+        from .mesh import BrickMesh, HangingBrickMesh
         from .parallel import ElementSchedule, TraceExchange
-        own, ghosts, needed_by = ghost_layer(level, parts, rank)
-        self.n_own = int(own.size)
-        self.mesh = m = BrickMesh(level, deg_global, deg_quad_inc=deg_quad_inc, quad_type=quad_type, elements=np.concatenate([own, ghosts]))
+        if refine is not None:
+            own, ghosts, needed_by = ghost_layer_hanging(level, refine, parts, rank)
+            self.n_own = int(own.size)
+            self.mesh = m = HangingBrickMesh(level, refine, deg_global, deg_quad_inc=deg_quad_inc, quad_type=quad_type,
+                                             elements=np.concatenate([own, ghosts]))
+        else:
+            own, ghosts, needed_by = ghost_layer(level, parts, rank)
+            self.n_own = int(own.size)
+            self.mesh = m = BrickMesh(level, deg_global, deg_quad_inc=deg_quad_inc, quad_type=quad_type, elements=np.concatenate([own, ghosts]))
         J, rst = m.geometry(mapping)
         sides = m.build_sides(mapping)
         self.schwarz = Schwarz(m, sides, J, rst, num_nodes_overlap, subdomain_iter, subdomain_atol, subdomain_rtol, penalty_prefactor,

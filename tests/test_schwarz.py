@@ -206,3 +206,37 @@ def test_schwarz_converges_on_hanging_mesh(oracle):
         assert all(b < 0.8 * a for a, b in zip(hist[:-1], hist[1:])), hist
     finally:
         oracle.set_hanging(None)
+
+
+@pytest.mark.parametrize("world,pattern", [(2, [0, 7]), (3, [1, 2, 4])])
+def test_sharded_metadata_matches_global(world, pattern):
+    """subdomains built on a rank's extended mesh (own elements + ghost layer) of a hanging brick list the same global elements and
+    faces as the single-rank builder"""
+    from disco4est_amd import mesh as M, parallel as P
+    from disco4est_amd.schwarz import SchwarzMetadata, ghost_layer_hanging
+    refine = np.zeros(8, dtype=bool)
+    refine[pattern] = True
+    n = M.HangingBrickMesh(1, refine, 2).n_elements
+    deg = 2 + (np.arange(n) % 2)
+    mg = M.HangingBrickMesh(1, refine, deg)
+    mdg = SchwarzMetadata(mg, mg.build_sides(None), 2)
+    parts = P.partition_by_dofs(deg, world)
+    seen = 0
+    for rank, (first, count) in enumerate(parts):
+        own, ghosts, needed_by = ghost_layer_hanging(1, refine, parts, rank)
+        assert own.size == count and not set(own.tolist()) & set(ghosts.tolist())
+        m = M.HangingBrickMesh(1, refine, deg, elements=np.concatenate([own, ghosts]))
+        md = SchwarzMetadata(m, m.build_sides(None), 2, cores=np.arange(count), sort_key=m.elements)
+        assert md.num_subdomains == count
+        for s in range(count):
+            e, f, cf = md.subdomain(s)
+            eg, fg, cfg = mdg.subdomain(first + s)
+            np.testing.assert_array_equal(m.elements[e], eg)
+            np.testing.assert_array_equal(f, fg)
+            np.testing.assert_array_equal(cf, cfg)
+            seen += 1
+        # every own element a peer needs is really in that peer's ghost layer
+        for peer, mine in needed_by.items():
+            _, pg, _ = ghost_layer_hanging(1, refine, parts, peer)
+            assert set(mine) <= set(pg.tolist())
+    assert seen == n
