@@ -536,6 +536,13 @@ __global__ __launch_bounds__(256) void flux_hp_kernel(const double* __restrict__
 constexpr int kFW = 8;
 
 // out_c(a',b') = sum_{a,b} op[a'][a] op[b'][b] in_c(a,b); lane = a' + 8 b'; result in registers
+// in / tmp are buffers of the calling WAVE only (each wave of flux_wave_kernel owns s_in[f], s_tmp[f]), so the two hand-offs
+// through LDS need a wave-level fence, not a workgroup barrier
+__device__ __forceinline__ void wave_private_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int NF>
 __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/, const double* in /*[NF][64]*/,
                                              double* tmp /*[NF][64]*/, int lane, double* out /*[NF]*/) {
@@ -550,7 +557,7 @@ __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/,
     for (int a = 0; a < kFW; ++a) s = fma(c[a], in[f * 64 + a + 8 * hi], s);
     tmp[f * 64 + lane] = s;
   }
-  __syncthreads();
+  wave_private_lds_fence();
 #pragma unroll
   for (int b = 0; b < kFW; ++b) c[b] = op[hi * 8 + b];
 #pragma unroll
@@ -560,7 +567,7 @@ __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/,
     for (int b = 0; b < kFW; ++b) s = fma(c[b], tmp[f * 64 + lo + 8 * b], s);
     out[f] = s;
   }
-  __syncthreads();
+  wave_private_lds_fence();
 }
 
 __global__ __launch_bounds__(384, 6) void trace_wave_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
