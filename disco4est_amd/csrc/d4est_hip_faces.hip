@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void flux_hp_kernel(const double* __restrict__
 constexpr int kFW = 8;
 
 // out_c(a',b') = sum_{a,b} op[a'][a] op[b'][b] in_c(a,b); lane = a' + 8 b'; result in registers
-// in / tmp are buffers of the calling WAVE only (each wave of flux_wave_kernel owns s_in[f], s_tmp[f]), so the two hand-offs
+// the buffer handed to wave_apply2d belongs to the calling WAVE only (each wave of flux_wave_kernel owns s_in[f]), so its hand-offs
 // through LDS need a wave-level fence, not a workgroup barrier
 __device__ __forceinline__ void wave_private_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -544,19 +544,24 @@ __device__ __forceinline__ void wave_private_lds_fence() {
 }
 
 template <int NF>
-__device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/, const double* in /*[NF][64]*/,
-                                             double* tmp /*[NF][64]*/, int lane, double* out /*[NF]*/) {
+__device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/, double* buf /*[NF][64], overwritten*/, int lane,
+                                             double* out /*[NF]*/) {
+  // both passes work in place: a wave executes in lockstep, so every lane has its row / column in registers before the
+  // (fenced) stores of the pass overwrite the buffer
   const int lo = lane & 7, hi = lane >> 3;
-  double c[kFW];
+  double c[kFW], t[NF];
 #pragma unroll
   for (int a = 0; a < kFW; ++a) c[a] = op[lo * 8 + a];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     double s = 0.0;
 #pragma unroll
-    for (int a = 0; a < kFW; ++a) s = fma(c[a], in[f * 64 + a + 8 * hi], s);
-    tmp[f * 64 + lane] = s;
+    for (int a = 0; a < kFW; ++a) s = fma(c[a], buf[f * 64 + a + 8 * hi], s);
+    t[f] = s;
   }
+  wave_private_lds_fence();
+#pragma unroll
+  for (int f = 0; f < NF; ++f) buf[f * 64 + lane] = t[f];
   wave_private_lds_fence();
 #pragma unroll
   for (int b = 0; b < kFW; ++b) c[b] = op[hi * 8 + b];
@@ -564,7 +569,7 @@ __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/,
   for (int f = 0; f < NF; ++f) {
     double s = 0.0;
 #pragma unroll
-    for (int b = 0; b < kFW; ++b) s = fma(c[b], tmp[f * 64 + lo + 8 * b], s);
+    for (int b = 0; b < kFW; ++b) s = fma(c[b], buf[f * 64 + lo + 8 * b], s);
     out[f] = s;
   }
   wave_private_lds_fence();
@@ -1007,7 +1012,6 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
                                                         const double* __restrict__ robin_c, const double* __restrict__ robin_r,
                                                         int n_elem, int xcd_chunk, ChebyFuse cf) {
   __shared__ double s_in[6][4][64];   // per wave: 4 term fields on the 8 x 8 grid
-  __shared__ double s_tmp[6][4][64];
   __shared__ double s_E[6][64];       // per wave: E of its side, zero-padded to 8 x 8
   __shared__ double s_W[512];         // lifted face-local part: terms 1+3 and the tangential D^T of term 2
   __shared__ double s_N[6][64];       // per side: term 2 of the normal direction (D^T spreads it along the normal lines)
@@ -1083,7 +1087,7 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
     __syncthreads();
     // ---- integrate and project onto the (-) side: 4 fields on the N x N face nodes
     double res[4];
-    wave_apply2d<4>(s_E[f], &s_in[f][0][0], &s_tmp[f][0][0], lane, res);
+    wave_apply2d<4>(s_E[f], &s_in[f][0][0], lane, res);
     // ---- D^T of the two TANGENTIAL term-2 fields stays inside the face: val = t13 + D_a^T t2_a + D_b^T t2_b
     const int dir = f >> 1;
     const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;  // reference directions of the face indices a and b
