@@ -543,6 +543,34 @@ __device__ __forceinline__ void wave_private_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// two-buffer form of wave_apply2d (first pass in -> tmp): one wave-level fence less per pass than the in-place form
+template <int NF>
+__device__ __forceinline__ void wave_apply2d_tmp(const double* op /*[8][8] padded*/, const double* in /*[NF][64]*/,
+                                                 double* tmp /*[NF][64]*/, int lane, double* out /*[NF]*/) {
+  const int lo = lane & 7, hi = lane >> 3;
+  double c[kFW];
+#pragma unroll
+  for (int a = 0; a < kFW; ++a) c[a] = op[lo * 8 + a];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < kFW; ++a) s = fma(c[a], in[f * 64 + a + 8 * hi], s);
+    tmp[f * 64 + lane] = s;
+  }
+  wave_private_lds_fence();
+#pragma unroll
+  for (int b = 0; b < kFW; ++b) c[b] = op[hi * 8 + b];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    double s = 0.0;
+#pragma unroll
+    for (int b = 0; b < kFW; ++b) s = fma(c[b], tmp[f * 64 + lo + 8 * b], s);
+    out[f] = s;
+  }
+  wave_private_lds_fence();
+}
+
 template <int NF>
 __device__ __forceinline__ void wave_apply2d(const double* op /*[8][8] padded*/, double* buf /*[NF][64], overwritten*/, int lane,
                                              double* out /*[NF]*/) {
@@ -1004,7 +1032,10 @@ __global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restr
 // FUSE: the Chebyshev update of the element (r = alpha (rhs - Au), p = r + beta p, u += p; cheby_update_kernel, same roundings) runs
 // in the epilogue, where the element's final Au is in registers -- one kernel and one read of Au less per smoother iteration.  u is
 // not an input of this kernel (the faces read traces), so updating it in place is safe.
-template <bool FUSE>
+// INPLACE: the per-wave operator apply works in place (23 KB of LDS per workgroup instead of 35 KB): faster on a mesh plan (config 2
+// 41.6 -> 36.9 us, level 5 342 -> 316 us), slower on a Schwarz subdomain plan, where a third of the sides read one cached zero block and
+// the kernel is bound by its LDS / issue chain rather than by memory latency (875 -> 962 us on 97 336 copies) -- chosen per plan.
+template <bool FUSE, bool INPLACE>
 __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
                                                         double* __restrict__ Au, const SideDesc* __restrict__ sd,
                                                         const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
@@ -1012,6 +1043,7 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
                                                         const double* __restrict__ robin_c, const double* __restrict__ robin_r,
                                                         int n_elem, int xcd_chunk, ChebyFuse cf) {
   __shared__ double s_in[6][4][64];   // per wave: 4 term fields on the 8 x 8 grid
+  __shared__ double s_tmp[INPLACE ? 1 : 6][INPLACE ? 1 : 4][64];
   __shared__ double s_E[6][64];       // per wave: E of its side, zero-padded to 8 x 8
   __shared__ double s_W[512];         // lifted face-local part: terms 1+3 and the tangential D^T of term 2
   __shared__ double s_N[6][64];       // per side: term 2 of the normal direction (D^T spreads it along the normal lines)
@@ -1087,7 +1119,8 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
     __syncthreads();
     // ---- integrate and project onto the (-) side: 4 fields on the N x N face nodes
     double res[4];
-    wave_apply2d<4>(s_E[f], &s_in[f][0][0], lane, res);
+    if (INPLACE) wave_apply2d<4>(s_E[f], &s_in[f][0][0], lane, res);
+    else wave_apply2d_tmp<4>(s_E[f], &s_in[f][0][0], &s_tmp[INPLACE ? 0 : f][0][0], lane, res);
     // ---- D^T of the two TANGENTIAL term-2 fields stays inside the face: val = t13 + D_a^T t2_a + D_b^T t2_b
     const int dir = f >> 1;
     const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;  // reference directions of the face indices a and b
@@ -2257,10 +2290,10 @@ static void debug_occupancy_once() {
   done = true;
   int nt = -1, nf = -1;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nt, reinterpret_cast<const void*>(trace_wave_kernel), 384, 0);
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, reinterpret_cast<const void*>(flux_wave_kernel<false>), 384, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, reinterpret_cast<const void*>(flux_wave_kernel<false, true>), 384, 0);
   hipFuncAttributes at{}, af{};
   (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(trace_wave_kernel));
-  (void)hipFuncGetAttributes(&af, reinterpret_cast<const void*>(flux_wave_kernel<false>));
+  (void)hipFuncGetAttributes(&af, reinterpret_cast<const void*>(flux_wave_kernel<false, true>));
   std::fprintf(stderr, "[d4est_hip] occupancy: trace_wave %d wg/CU (regs %d, lds %zu, scratch %zu) flux_wave %d wg/CU (regs %d, lds %zu, scratch %zu)\n",
                nt, at.numRegs, at.sharedSizeBytes, at.localSizeBytes, nf, af.numRegs, af.sharedSizeBytes, af.localSizeBytes);
 }
@@ -2356,15 +2389,16 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     const int chunk = (n % 8 == 0 && grid % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0;
-    if (cf)
-      hipLaunchKernelGGL(flux_wave_kernel<true>, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
-                         (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops,
-                         plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk, *cf);
-    else
-      hipLaunchKernelGGL(flux_wave_kernel<false>, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
-                         (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops,
-                         plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk,
-                         ChebyFuse{});
+    const bool subdomain_plan = plan->tuning[D4EST_HIP_TUNE_GHOST_ALIAS] > 0;   // see flux_wave_kernel: INPLACE
+#define D4EST_HIP_LAUNCH_FLUX_WAVE(FUSE_, INPLACE_, CF_)                                                                                 \
+  hipLaunchKernelGGL((flux_wave_kernel<FUSE_, INPLACE_>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,               \
+                     (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom,        \
+                     plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk, CF_)
+    if (cf && subdomain_plan) D4EST_HIP_LAUNCH_FLUX_WAVE(true, false, *cf);
+    else if (cf) D4EST_HIP_LAUNCH_FLUX_WAVE(true, true, *cf);
+    else if (subdomain_plan) D4EST_HIP_LAUNCH_FLUX_WAVE(false, false, ChebyFuse{});
+    else D4EST_HIP_LAUNCH_FLUX_WAVE(false, true, ChebyFuse{});
+#undef D4EST_HIP_LAUNCH_FLUX_WAVE
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int grid16 = std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256));
     const int chunk16 = (n % 8 == 0 && grid16 % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0;
