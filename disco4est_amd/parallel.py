@@ -172,9 +172,19 @@ class DistTransport:
         import torch.distributed as dist
         self.dist = dist
         self.group = group
+        # nccl / RCCL enqueues its transfers behind the current stream; a host-side backend (gloo: CPU tests, single-GPU rehearsals
+        # with device tensors) touches the buffers from the host, so the pack kernels must have finished before the send is posted
+        self.host_side = dist.is_initialized() and dist.get_backend(group) != "nccl"
+
+    def _device_sync(self, bufs):
+        if self.host_side:
+            import torch
+            if any(t.is_cuda for t in bufs.values()):
+                torch.cuda.synchronize()
 
     def start(self, send_buf, recv_buf):
         dist = self.dist
+        self._device_sync(send_buf)
         ops = []
         for p in sorted(recv_buf):
             if recv_buf[p].numel():

@@ -1,0 +1,64 @@
+"""Two real processes (torch.distributed, one rank per process) running the sharded Schwarz smoother and the sharded operator through
+DistTransport; rank 0 compares the assembled result with the single-rank smoother.  Rehearsal on ONE GPU:
+  D4EST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/multiprocess_rehearsal.py
+(on a multi-GPU node the backend is nccl = RCCL and every rank takes its own device)."""
+import os, sys
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from disco4est_amd import mesh as M, parallel as P
+from disco4est_amd.schwarz import Schwarz, SchwarzShard
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
+torch.cuda.set_device(dev)
+dist.init_process_group(backend=os.environ.get("D4EST_BACKEND", "nccl"))
+level, rs, iters = 2, 2, 5
+deg_global = np.array([2 + (i % 2) for i in range(8 ** level)])
+mp = M.SineMap(0.04)
+parts = P.partition_by_dofs(deg_global, world)
+sh = SchwarzShard(level, deg_global, parts, rank, mp, rs, iters, 1e-15, 1e-15, P.DistTransport(), dev)
+mg = M.BrickMesh(level, deg_global)
+u0 = M.splitmix64_uniform(81, mg.local_nodes) - 0.5
+r = M.splitmix64_uniform(82, mg.local_nodes) - 0.5
+first, count = parts[rank]
+lo = int(mg.global_nodal_stride[first]); hi = lo + sh.own_nodes
+u = torch.from_numpy(u0[lo:hi].copy()).to(dev)
+sh.iterate(u, torch.from_numpy(r[lo:hi].copy()).to(dev))
+torch.cuda.synchronize()
+pieces = [None] * world
+dist.all_gather_object(pieces, (lo, hi, u.cpu().numpy()))
+if rank == 0:
+    got = np.empty(mg.local_nodes)
+    for a, b, x in pieces:
+        got[a:b] = x
+    Jg, rstg = mg.geometry(mp); sg = mg.build_sides(mp)
+    single = Schwarz(mg, sg, Jg, rstg, rs, iters, 1e-15, 1e-15)
+    ur = torch.from_numpy(u0).to(dev)
+    single.iterate(ur, torch.from_numpy(r).to(dev))
+    err = np.abs(got - ur.cpu().numpy()).max() / np.abs(ur.cpu().numpy() - u0).max()
+    print("world %d: sharded Schwarz iterate vs single rank: rel err %.2e %s" % (world, err, "ok" if err <= 1e-10 else "MISMATCH"), flush=True)
+# ---- the sharded operator through the C library's exchange hooks (d4est_hip_plan_set_comm -> TraceExchange -> DistTransport)
+from disco4est_amd import Plan
+ms = M.BrickMesh(level, deg_global, first=first, count=count)
+Js, rsts = ms.geometry(mp); ss = ms.build_sides(mp)
+plan = Plan(ms.deg, ms.deg_quad, ms.nodal_stride, ms.quad_stride, 0)
+plan.set_geometry(Js, rsts); plan.set_faces(ss)
+ex = P.attach(plan, ms, ss, parts, P.DistTransport(), dev)
+us = torch.from_numpy(u0[lo:hi].copy()).to(dev); Aus = torch.empty_like(us)
+plan.apply_lhs(us, Aus)
+torch.cuda.synchronize()
+pieces = [None] * world
+dist.all_gather_object(pieces, (lo, hi, Aus.cpu().numpy()))
+if rank == 0:
+    got = np.empty(mg.local_nodes)
+    for a, b, x in pieces:
+        got[a:b] = x
+    pg = Plan(mg.deg, mg.deg_quad, mg.nodal_stride, mg.quad_stride, 0)
+    pg.set_geometry(Jg, rstg); pg.set_faces(sg)
+    ug = torch.from_numpy(u0).to(dev); Aug = torch.empty_like(ug)
+    pg.apply_aij(ug, Aug)
+    err = np.abs(got - Aug.cpu().numpy()).max() / np.abs(Aug.cpu().numpy()).max()
+    print("world %d: sharded apply_lhs vs single rank: rel err %.2e %s" % (world, err, "ok" if err <= 1e-12 else "MISMATCH"), flush=True)
+dist.barrier()
+dist.destroy_process_group()
