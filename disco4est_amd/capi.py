@@ -167,6 +167,7 @@ class Plan:
         self.handle = self.lib.d4est_hip_plan_create(n, self._keep[0][1], self._keep[1][1], self._keep[2][1],
                                                      self._keep[3][1], int(quad_type))
         self.n_elements = n
+        self.torch_stream = None
         self.local_nodes = self.lib.d4est_hip_plan_local_nodes(self.handle)
         self.local_nodes_quad = self.lib.d4est_hip_plan_local_nodes_quad(self.handle)
         if stream is not None:
@@ -175,6 +176,7 @@ class Plan:
     def set_stream(self, stream):
         """stream: a torch.cuda.Stream (its raw hipStream_t is passed through) or an int handle."""
         h = getattr(stream, "cuda_stream", stream)
+        self.torch_stream = stream if hasattr(stream, "cuda_stream") else None   # parallel.attach makes it current around the exchange
         self.lib.d4est_hip_plan_set_stream(self.handle, ctypes.c_void_p(int(h)))
 
     def last_kernel(self):

@@ -272,14 +272,23 @@ def attach(plan, mesh, sides, parts, transport, device):
         h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
         return torch.as_tensor(h, device=device)
 
+    import contextlib
+
+    def on_plan_stream():
+        # the collectives order themselves behind torch's CURRENT stream; the library's kernels run on the plan's stream
+        ts = getattr(plan, "torch_stream", None)
+        return torch.cuda.stream(ts) if ts is not None else contextlib.nullcontext()
+
     def exchange(phase, trace_ptr, ghost_ptr):
-        if phase == 0:
-            ex.begin(view(trace_ptr, n_trace))
-        else:
-            ex.end(view(ghost_ptr, n_ghost))
+        with on_plan_stream():
+            if phase == 0:
+                ex.begin(view(trace_ptr, n_trace))
+            else:
+                ex.end(view(ghost_ptr, n_ghost))
 
     def allreduce(ptr, n):
-        transport.allreduce_sum(view(ptr, n))
+        with on_plan_stream():
+            transport.allreduce_sum(view(ptr, n))
 
     plan.set_comm(exchange if n_ghost > 0 else None, allreduce if hasattr(transport, "allreduce_sum") else None)
     return ex
