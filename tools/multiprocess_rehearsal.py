@@ -60,5 +60,25 @@ if rank == 0:
     pg.apply_aij(ug, Aug)
     err = np.abs(got - Aug.cpu().numpy()).max() / np.abs(Aug.cpu().numpy()).max()
     print("world %d: sharded apply_lhs vs single rank: rel err %.2e %s" % (world, err, "ok" if err <= 1e-12 else "MISMATCH"), flush=True)
+# ---- cg_eigs (three scalar reductions per iteration through the allreduce hook) and five Chebyshev iterations
+rhs_s = torch.from_numpy(r[lo:hi].copy()).to(dev)
+uz = torch.zeros_like(us)
+bound, _ = plan.cg_eigs(uz, rhs_s, Aus, 8)
+uc = torch.from_numpy(u0[lo:hi].copy()).to(dev); rc = torch.empty_like(uc)
+plan.cheby_iterate(uc, rhs_s, Aus, rc, 5, bound / 30.0, bound, 1)
+torch.cuda.synchronize()
+pieces = [None] * world
+dist.all_gather_object(pieces, (lo, hi, uc.cpu().numpy(), bound))
+if rank == 0:
+    got = np.empty(mg.local_nodes)
+    for a, b, x, _ in pieces:
+        got[a:b] = x
+    rg = torch.from_numpy(r).to(dev)
+    bg, _ = pg.cg_eigs(torch.zeros_like(ug), rg, Aug, 8)
+    ucg = torch.from_numpy(u0).to(dev); rcg = torch.empty_like(ucg)
+    pg.cheby_iterate(ucg, rg, Aug, rcg, 5, bg / 30.0, bg, 1)
+    err = np.abs(got - ucg.cpu().numpy()).max() / np.abs(ucg.cpu().numpy()).max()
+    eb = max(abs(p_[3] - bg) for p_ in pieces) / bg
+    print("world %d: sharded cg_eigs bound rel err %.2e, Chebyshev iterate rel err %.2e %s" % (world, eb, err, "ok" if max(eb, err) <= 1e-10 else "MISMATCH"), flush=True)
 dist.barrier()
 dist.destroy_process_group()
