@@ -79,6 +79,7 @@ if rank == 0:
     pg.cheby_iterate(ucg, rg, Aug, rcg, 5, bg / 30.0, bg, 1)
     err = np.abs(got - ucg.cpu().numpy()).max() / np.abs(ucg.cpu().numpy()).max()
     eb = max(abs(p_[3] - bg) for p_ in pieces) / bg
-    print("world %d: sharded cg_eigs bound rel err %.2e, Chebyshev iterate rel err %.2e %s" % (world, eb, err, "ok" if max(eb, err) <= 1e-10 else "MISMATCH"), flush=True)
+    print("world %d: sharded cg_eigs bound %r (single rank %r) rel err %.2e, Chebyshev iterate rel err %.2e %s" % (
+        world, pieces[-1][3], bg, eb, err, "ok" if max(eb, err) <= 1e-10 else "MISMATCH"), flush=True)
 dist.barrier()
 dist.destroy_process_group()
