@@ -13,8 +13,9 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
 torch.cuda.set_device(dev)
 dist.init_process_group(backend=os.environ.get("D4EST_BACKEND", "nccl"))
-level, rs, iters = 2, 2, 5
-deg_global = np.array([2 + (i % 2) for i in range(8 ** level)])
+level, rs, iters = int(os.environ.get("D4EST_LEVEL", 2)), 2, 5
+pmin = int(os.environ.get("D4EST_DEG", 2))
+deg_global = np.array([pmin + (i % 2) for i in range(8 ** level)])
 mp = M.SineMap(0.04)
 parts = P.partition_by_dofs(deg_global, world)
 sh = SchwarzShard(level, deg_global, parts, rank, mp, rs, iters, 1e-15, 1e-15, P.DistTransport(), dev)
