@@ -15,11 +15,20 @@ torch.cuda.set_device(dev)
 dist.init_process_group(backend=os.environ.get("D4EST_BACKEND", "nccl"))
 level, rs, iters = int(os.environ.get("D4EST_LEVEL", 2)), 2, 5
 pmin = int(os.environ.get("D4EST_DEG", 2))
-deg_global = np.array([pmin + (i % 2) for i in range(8 ** level)])
+refine = None
+if os.environ.get("D4EST_HANGING"):          # locally refined brick: hanging faces cross the rank boundaries
+    refine = np.zeros(8 ** level, dtype=bool)
+    refine[[0, 8 ** level // 2 + 1, 8 ** level - 1]] = True
+    n_el = M.HangingBrickMesh(level, refine, 2).n_elements
+    make = lambda deg, **kw: M.HangingBrickMesh(level, refine, deg, **kw)
+else:
+    n_el = 8 ** level
+    make = lambda deg, **kw: M.BrickMesh(level, deg, **kw)
+deg_global = np.array([pmin + (i % 2) for i in range(n_el)], dtype=np.int32)
 mp = M.SineMap(0.04)
 parts = P.partition_by_dofs(deg_global, world)
-sh = SchwarzShard(level, deg_global, parts, rank, mp, rs, iters, 1e-15, 1e-15, P.DistTransport(), dev)
-mg = M.BrickMesh(level, deg_global)
+sh = SchwarzShard(level, deg_global, parts, rank, mp, rs, iters, 1e-15, 1e-15, P.DistTransport(), dev, refine=refine)
+mg = make(deg_global)
 u0 = M.splitmix64_uniform(81, mg.local_nodes) - 0.5
 r = M.splitmix64_uniform(82, mg.local_nodes) - 0.5
 first, count = parts[rank]
@@ -41,7 +50,7 @@ if rank == 0:
     print("world %d: sharded Schwarz iterate vs single rank: rel err %.2e %s" % (world, err, "ok" if err <= 1e-10 else "MISMATCH"), flush=True)
 # ---- the sharded operator through the C library's exchange hooks (d4est_hip_plan_set_comm -> TraceExchange -> DistTransport)
 from disco4est_amd import Plan
-ms = M.BrickMesh(level, deg_global, first=first, count=count)
+ms = make(deg_global, first=first, count=count)
 Js, rsts = ms.geometry(mp); ss = ms.build_sides(mp)
 plan = Plan(ms.deg, ms.deg_quad, ms.nodal_stride, ms.quad_stride, 0)
 plan.set_geometry(Js, rsts); plan.set_faces(ss)
