@@ -83,6 +83,7 @@ SIGNATURES = {
     "d4est_hip_compute_face_traces": (None, [_vp, _vp, _vp]),
     "d4est_hip_apply_flux": (None, [_vp, _vp, _vp, _vp]),
     "d4est_hip_apply_aij": (None, [_vp, _vp, _vp, _vp]),
+    "d4est_hip_plan_set_lhs_coefficient": (None, [_vp, _vp]),
     "d4est_hip_plan_set_comm": (None, [_vp, _vp, _vp, _vp]),
     "d4est_hip_apply_lhs": (None, [_vp, _vp, _vp]),
     "d4est_hip_cheby_iterate": (None, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]),
@@ -330,6 +331,14 @@ class Plan:
         self._cb_ar = self.ALLREDUCE_FN(lambda ctx, p, n: allreduce(p, n)) if allreduce else None
         self.lib.d4est_hip_plan_set_comm(self.handle, ctypes.cast(self._cb_ex, ctypes.c_void_p) if self._cb_ex else None,
                                          ctypes.cast(self._cb_ar, ctypes.c_void_p) if self._cb_ar else None, None)
+
+    def set_lhs_coefficient(self, coeff_quad):
+        """zeroth-order term of apply_lhs (+ V^T W J c V u): a float64 CUDA tensor of local_nodes_quad entries kept alive by the plan,
+        or None for the pure Laplacian"""
+        self._lhs_coeff = coeff_quad
+        if coeff_quad is not None:
+            assert coeff_quad.numel() == self.local_nodes_quad
+        self.lib.d4est_hip_plan_set_lhs_coefficient(self.handle, _ptr(coeff_quad) if coeff_quad is not None else None)
 
     def apply_lhs(self, u, Au):
         self.lib.d4est_hip_apply_lhs(self.handle, _ptr(u), _ptr(Au))

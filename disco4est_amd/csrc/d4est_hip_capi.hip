@@ -212,7 +212,7 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   (void)hipFree(plan->d_nonaffine);
   (void)hipFree(plan->d_scratch);
   d4est_hip::faces_destroy(plan);
-  (void)hipFree(plan->d_work_p); (void)hipFree(plan->d_work_d); (void)hipFree(plan->d_work_r);
+  (void)hipFree(plan->d_work_p); (void)hipFree(plan->d_work_d); (void)hipFree(plan->d_work_r); (void)hipFree(plan->d_work_m);
   (void)hipFree(plan->d_reduce); (void)hipFree(plan->d_ghost_trace);
   if (plan->cheby_graph) (void)hipGraphExecDestroy(plan->cheby_graph);
   if (plan->side_stream) { (void)hipStreamDestroy(plan->side_stream); (void)hipEventDestroy(plan->ev_fork); (void)hipEventDestroy(plan->ev_join); }
@@ -339,6 +339,12 @@ void d4est_hip_apply_weighted_mass_matrix(d4est_hip_plan_t* plan, const double* 
   check_plan(plan, "apply_weighted_mass_matrix");
   if (!coeff_quad_dev) D4EST_HIP_ABORT("apply_weighted_mass_matrix: coeff_quad is NULL");
   d4est_hip::launch_mass_like(plan, 3, u_dev, out_dev, coeff_quad_dev, 0);
+}
+
+void d4est_hip_plan_set_lhs_coefficient(d4est_hip_plan_t* plan, const double* coeff_quad_dev) {
+  check_plan(plan, "plan_set_lhs_coefficient");
+  drop_graph(plan);
+  plan->d_lhs_coeff = coeff_quad_dev;
 }
 
 void d4est_hip_apply_inverse_mass_matrix(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev) {
@@ -481,7 +487,7 @@ void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const doub
   check_plan(plan, "apply_aij");
   if (!plan->has_faces) D4EST_HIP_ABORT("apply_aij: call plan_set_faces first");
   if (!ghost_trace_dev && plan->ghost_trace_doubles == 0) {
-    d4est_hip::apply_operator(plan, u_dev, Au_dev);  // two-stream fork-join of the trace and volume kernels
+    d4est_hip::apply_operator(plan, u_dev, Au_dev, nullptr, false);  // the Laplacian only (no plan_set_lhs_coefficient term)
     return;
   }
   d4est_hip::launch_stiffness(plan, u_dev, Au_dev);

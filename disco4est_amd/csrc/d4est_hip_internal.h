@@ -111,6 +111,8 @@ struct d4est_hip_plan {
 
   // ---- solver workspace / communication hooks (d4est_hip_solver.hip) ----
   double *d_work_p = nullptr, *d_work_d = nullptr, *d_work_r = nullptr, *d_reduce = nullptr, *d_ghost_trace = nullptr;
+  const double* d_lhs_coeff = nullptr;   // optional zeroth-order term of apply_lhs: + V^T W J c V u (caller-owned, quadrature nodes)
+  double* d_work_m = nullptr;            // scratch of that term
   hipStream_t side_stream = nullptr;  // the trace kernel (and the exchange) run here, concurrently with the volume kernel
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // D4EST_HIP_TUNE_GRAPH: the last cheby_iterate call captured as a hipGraph (replayed while the arguments stay the same)
@@ -163,8 +165,10 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
 void faces_destroy(d4est_hip_plan* plan);
 
 // d4est_hip_solver.hip
-void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const ChebyFuse* cf = nullptr);
+// traces, volume term, (exchange), flux; lhs_term: also the optional zeroth-order term of plan_set_lhs_coefficient
+void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const ChebyFuse* cf = nullptr, bool lhs_term = true);
 void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double* r);   // r = rhs - Au
+void add_lhs_mass_term(d4est_hip_plan* plan, const double* u, double* Au);   // Au += V^T W J c V u when a coefficient is set
 void launch_copy_blocks(hipStream_t stream, int n_blocks, const double* src, const long long* src_off, double* dst,
                         const long long* dst_off, const int* len);
 void launch_dot(d4est_hip_plan* plan, int n, const double* x, const double* y, double* out_dev);

@@ -388,6 +388,7 @@ void d4est_hip_schwarz_apply_over_subdomains(d4est_hip_schwarz_t* sz, const doub
   if (sz->n_virtual == 0) return;
   ensure_zero_ghost(sz);
   d4est_hip_apply_aij(sz->plan, in_dev, sz->d_zero_ghost, out_dev);
+  add_lhs_mass_term(sz->plan, in_dev, out_dev);
   hipLaunchKernelGGL(schwarz_mask_kernel, dim3(std::min(sz->n_virtual, 65536)), dim3(256), 0, sz->plan->stream, sz->d_vd, sz->n_virtual,
                      out_dev);
   HIP_CHECK(hipGetLastError());
@@ -422,6 +423,7 @@ int d4est_hip_schwarz_iterate(d4est_hip_schwarz_t* sz, double* u_dev, const doub
     HIP_CHECK(hipStreamSynchronize(st));
     if (n_active == 0) break;  // every subdomain has left its loop
     d4est_hip_apply_aij(sz->plan, sz->d_d, sz->d_zero_ghost, sz->d_Ad);
+    add_lhs_mass_term(sz->plan, sz->d_d, sz->d_Ad);   // zeroth-order term of a linearised problem (plan_set_lhs_coefficient on the subdomain plan)
     hipLaunchKernelGGL(schwarz_cg_kernel, dim3(sz->n_sub), dim3(256), 0, st, sz->d_vd, sz->d_sub_first, sz->d_du, sz->d_r, sz->d_d,
                        sz->d_Ad, sz->d_delta, sz->d_tol, sz->d_active, sz->d_final_iter, sz->d_n_active, it);
     HIP_CHECK(hipGetLastError());

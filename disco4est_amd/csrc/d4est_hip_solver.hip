@@ -39,6 +39,10 @@ __global__ __launch_bounds__(256) void residual_kernel(int n, const double* __re
   }
 }
 
+__global__ __launch_bounds__(256) void add_kernel(int n, const double* __restrict__ x, double* __restrict__ y) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] = __dadd_rn(y[i], x[i]);
+}
+
 // deterministic two-stage dot product: fixed grid, fixed summation tree
 __global__ __launch_bounds__(256) void dot_partial_kernel(int n, const double* __restrict__ x, const double* __restrict__ y,
                                                           double* __restrict__ partial) {
@@ -138,7 +142,7 @@ void launch_dot(d4est_hip_plan* plan, int n, const double* x, const double* y, d
 // Fork-join on two streams: the trace kernel (and, through the hooks, the ghost exchange) runs on the plan's side
 // stream while the volume kernel runs on the main stream -- they only share the read-only u -- and the flux kernel
 // joins them.  At config 2 both kernels are latency-structured (~28 us each), so running them side by side hides one.
-void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const ChebyFuse* cf) {
+void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const ChebyFuse* cf, bool lhs_term) {
   if (!plan->has_faces) D4EST_HIP_ABORT("smoother: the plan has no faces (plan_set_faces)");
   ensure_solver_workspace(plan);
   const bool has_ghost = plan->ghost_trace_doubles > 0;
@@ -160,6 +164,7 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
     plan->stream = main;
     HIP_CHECK(hipEventRecord(plan->ev_join, plan->side_stream));
     launch_stiffness(plan, u, Au);
+    if (lhs_term) add_lhs_mass_term(plan, u, Au);
     HIP_CHECK(hipStreamWaitEvent(main, plan->ev_join, 0));
     launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, cf);
     return;
@@ -168,8 +173,20 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
   launch_traces(plan, u, plan->d_trace, false);
   if (has_ghost) plan->exchange_fn(plan->comm_ctx, 0, plan->d_trace, plan->d_ghost_trace);
   launch_stiffness(plan, u, Au);  // overlaps the exchange: the volume term needs no ghost data
+  if (lhs_term) add_lhs_mass_term(plan, u, Au);  // before the flux kernel, so an update fused into its epilogue sees the whole A u
   if (has_ghost) plan->exchange_fn(plan->comm_ctx, 1, plan->d_trace, plan->d_ghost_trace);
   launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, cf);
+}
+
+// the zeroth-order term of a linearised nonlinear problem (d4est_quadrature_apply_fofufofvlilj per element, added with axpy 1.0:
+// e.g. constant_density_star_apply_jac_add_nonlinear_term, src/Problems/ConstantDensityStar/constant_density_star_fcns.h:528-603)
+void add_lhs_mass_term(d4est_hip_plan* plan, const double* u, double* Au) {
+  if (!plan->d_lhs_coeff || plan->local_nodes == 0) return;
+  const int n = plan->local_nodes;
+  if (!plan->d_work_m) HIP_CHECK(hipMalloc(&plan->d_work_m, (size_t)n * sizeof(double)));
+  launch_mass_like(plan, 3, u, plan->d_work_m, plan->d_lhs_coeff, 0);
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, plan->d_work_m, Au);
+  HIP_CHECK(hipGetLastError());
 }
 
 void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double* r) {

@@ -224,6 +224,13 @@ void d4est_hip_apply_flux(d4est_hip_plan_t* plan, const double* trace_dev, const
  * ghost_trace_dev may be NULL when the plan has no ghost elements. */
 void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const double* ghost_trace_dev, double* Au_dev);
 
+/* Linearised nonlinear problems: the reference's apply_lhs is d4est_laplacian_apply_aij plus, per element,
+ * d4est_quadrature_apply_fofufofvlilj(u_e; f(x, u0)) added with axpy 1.0 (e.g. constant_density_star_apply_jac,
+ * src/Problems/ConstantDensityStar/constant_density_star_fcns.h:777-850 with :528-603).  coeff_quad_dev[local_nodes_quad] = f at
+ * the quadrature nodes (caller-owned device array, read at every apply; re-evaluate it when u0 changes); NULL = pure Laplacian.
+ * The term then is part of d4est_hip_apply_lhs, _cheby_iterate, _cg_eigs and _schwarz_smooth; set on a Schwarz subdomain plan
+ * (same array: the copies' quad_stride alias it) it is part of the subdomain operator.  d4est_hip_apply_aij stays the Laplacian. */
+void d4est_hip_plan_set_lhs_coefficient(d4est_hip_plan_t* plan, const double* coeff_quad_dev);
 /* ---- smoother inner loops (device resident) -----------------------------------------------------------
  * Communication hooks for plans with ghost elements / several ranks (replace the reference's MPI calls:
  * d4est_ghost_data_exchange, src/Mesh/d4est_ghost_data.c:143-256, and sc_allreduce, d4est_solver_cg_eigs.c:181-243).

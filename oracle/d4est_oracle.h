@@ -163,6 +163,7 @@ void oracle_cheby_iterate_aux(double* u, const double* rhs, double* Au, double* 
 void oracle_cg_eigs(double* u, const double* rhs, double* Au, int imax, int use_new, double* spectral_bound); /* d4est_solver_cg_eigs.c:116-275 */
 double oracle_gershgorin_bound(const double* alpha_h, const double* beta_h, int imax, int local_nodes, int use_new);
 void oracle_apply_lhs(const double* u, double* Au);   /* the registered operator, homogeneous Dirichlet data */
+void oracle_set_lhs_coefficient(const double* coeff_quad);   /* + weighted mass term of a linearised nonlinear problem; NULL = off */
 void oracle_operator_info(int* n_elements, const int** deg, const int** nodal_stride, int* local_nodes);
 
 /* ---- additive Schwarz smoother (oracle/d4est_oracle_schwarz.c) ----

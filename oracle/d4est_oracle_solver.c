@@ -49,6 +49,10 @@ void oracle_set_aij_operator(int quad_type, int n_elements, const int* deg, cons
 /* apply_lhs: Au = A u with homogeneous Dirichlet data (single rank: no ghosts) */
 static void apply_lhs(const double* u, double* Au);
 void oracle_apply_lhs(const double* u, double* Au) { apply_lhs(u, Au); }
+/* zeroth-order term of a linearised nonlinear problem: + sum_e d4est_quadrature_apply_fofufofvlilj(u_e; coeff) added with axpy 1.0
+ * (Problems/ConstantDensityStar/constant_density_star_fcns.h:528-603, :777-850); NULL = pure Laplacian */
+static const double* g_lhs_coeff = NULL;
+void oracle_set_lhs_coefficient(const double* coeff_quad) { g_lhs_coeff = coeff_quad; }
 void oracle_operator_info(int* n_elements, const int** deg, const int** nodal_stride, int* local_nodes) {
   if (!g_op.set) { fprintf(stderr, "[ORACLE_ABORT] operator not set\n"); abort(); }
   *n_elements = g_op.n_elements; *deg = g_op.deg; *nodal_stride = g_op.nodal_stride; *local_nodes = g_op.local_nodes;
@@ -61,6 +65,13 @@ static void apply_lhs(const double* u, double* Au) {
                              g_op.side_nbr, g_op.side_nbr_face, g_op.side_reorder, g_op.side_mortar_stride,
                              g_op.side_bndry_stride, g_op.sj, g_op.n, g_op.drst_m, g_op.drst_p, g_op.hm, g_op.hp,
                              g_op.penalty_prefactor, g_op.penalty_fcn, u, &dummy, NULL, Au, g_op.threads);
+  if (g_lhs_coeff) {
+    double* Mu = (double*)malloc(sizeof(double) * (size_t)g_op.local_nodes);
+    oracle_elements_apply_weighted_mass_matrix(g_op.quad_type, g_op.n_elements, g_op.deg, g_op.deg_quad, g_op.nodal_stride, g_op.quad_stride,
+                                               g_op.J_quad, g_lhs_coeff, u, Mu);
+    oracle_linalg_vec_axpy(1.0, Mu, Au, g_op.local_nodes);
+    free(Mu);
+  }
 }
 
 /* Solver/d4est_solver_multigrid_smoother_cheby.c:81-176 */

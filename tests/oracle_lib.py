@@ -238,6 +238,18 @@ class Oracle:
           I(sides["side_reorder"]), I(sides["side_mortar_stride"]), I(sides["side_bndry_stride"]), P(sides["sj"]), P(sides["n"]),
           P(sides["drst_m"]), P(sides["drst_p"]), P(sides["hm"]), P(sides["hp"]), float(penalty_prefactor), int(penalty_fcn), threads)
 
+    def set_lhs_coefficient(self, coeff_quad):
+        """zeroth-order term of the registered operator (None switches it off); the array is kept alive here"""
+        self.lib.oracle_set_lhs_coefficient.argtypes = [dp]
+        self._lhs_coeff = None if coeff_quad is None else np.ascontiguousarray(coeff_quad, dtype=np.float64)
+        self.lib.oracle_set_lhs_coefficient(None if self._lhs_coeff is None else P(self._lhs_coeff))
+
+    def apply_lhs(self, u):
+        out = np.zeros_like(u)
+        self.lib.oracle_apply_lhs.argtypes = [dp, dp]
+        self.lib.oracle_apply_lhs(P(np.ascontiguousarray(u)), P(out))
+        return out
+
     def set_hanging(self, sides):
         """keep the hanging-face arrays of `sides` active for the following calls (None switches back to conforming)"""
         self.lib.oracle_flux_set_hanging.argtypes = [ip, ip, ip, ip]

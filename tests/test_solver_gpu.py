@@ -190,3 +190,51 @@ def test_cheby_update_fused_into_flux_is_bit_identical(gpu, hiplib, oracle, leve
     for at_end in (0, 1):
         for a, b in zip(out[(0, at_end)], out[(1, at_end)]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("level,deg,inc", [(1, 3, 0), (2, 2, 1), (1, 7, 0)])
+def test_lhs_with_zeroth_order_term(gpu, hiplib, oracle, level, deg, inc):
+    """apply_lhs = Laplacian + V^T W J c V u (the Jacobian of the reference's nonlinear problems, e.g. constant_density_star_apply_jac):
+    apply_lhs, the Chebyshev iteration, cg_eigs and the Schwarz smoother with the coefficient set, against the oracle"""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    from disco4est_amd.schwarz import Schwarz
+    m = M.BrickMesh(level, deg, deg_quad_inc=inc)
+    mp = M.SineMap(0.05)
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan.set_geometry(J, rst)
+    plan.set_faces(sides, 10.0, 0)
+    oracle.set_operator(m, J, rst, sides, 10.0, 0, threads=1)
+    coeff = 1.0 + 5.0 * M.splitmix64_uniform(3, m.local_nodes_quad)          # positive: the operator stays SPD
+    dcoeff = _t(coeff, gpu)
+    try:
+        oracle.set_lhs_coefficient(coeff)
+        plan.set_lhs_coefficient(dcoeff)
+        u0 = M.splitmix64_uniform(11, m.local_nodes)
+        rhs = M.splitmix64_uniform(12, m.local_nodes) - 0.5
+        du = _t(u0, gpu); dAu = torch.empty_like(du)
+        plan.apply_lhs(du, dAu)
+        ref = oracle.apply_lhs(u0)
+        assert _rel(dAu.cpu().numpy(), ref) <= 1e-12
+        # really a different operator than the Laplacian
+        plan.apply_aij(du, dAu)
+        assert _rel(dAu.cpu().numpy(), ref) > 1e-6
+        lmax, _ = oracle.cg_eigs(np.zeros(m.local_nodes), rhs, 8)
+        b, _ = plan.cg_eigs(torch.zeros_like(du), _t(rhs, gpu), dAu, 8)
+        assert abs(b - lmax) <= 1e-10 * lmax
+        u_ref, r_ref = oracle.cheby_iterate(u0, rhs, 5, lmax / 30.0, lmax, 1)
+        du = _t(u0, gpu); dr = torch.empty_like(du)
+        plan.cheby_iterate(du, _t(rhs, gpu), dAu, dr, 5, lmax / 30.0, lmax, 1)
+        assert _rel(du.cpu().numpy(), u_ref) <= 1e-11 and _rel(dr.cpu().numpy(), r_ref) <= 1e-10
+        if deg <= 3:
+            sz = Schwarz(m, sides, J, rst, 2, 5, 1e-15, 1e-15)
+            sz.plan.set_lhs_coefficient(dcoeff)                    # the subdomain operator carries the term too
+            u_ref, it_ref, _ = oracle.schwarz_iterate(sz.metadata, u0, rhs, 5, 1e-15, 1e-15)
+            du = _t(u0, gpu)
+            sz.iterate(du, _t(rhs, gpu))
+            assert _rel(du.cpu().numpy() - u0, u_ref - u0) <= 1e-9
+            sz.destroy()
+    finally:
+        oracle.set_lhs_coefficient(None)
+        plan.set_lhs_coefficient(None)
