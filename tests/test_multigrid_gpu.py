@@ -84,3 +84,49 @@ def test_two_grid_cycle_converges(gpu, hiplib, hanging):
     for p in (pf, pc):
         p.destroy()
     T.destroy()
+
+
+def test_two_grid_cycle_with_schwarz_smoother(gpu, hiplib):
+    """the same cycle with the additive Schwarz smoother (d4est_solver_multigrid_smoother_schwarz = d4est_hip_schwarz_smooth) instead of
+    Chebyshev: it is contractive, beats smoothing alone, and leaves r = rhs - A u on exit like the Chebyshev smoother"""
+    import torch
+    from disco4est_amd import Transfer, mesh as M
+    from disco4est_amd.schwarz import Schwarz
+    mp = M.SineMap(0.03)
+    n_el = 64
+    deg_f, deg_c = np.full(n_el, 4), np.full(n_el, 2)
+    mf, mc = M.BrickMesh(2, deg_f), M.BrickMesh(2, deg_c)
+    pf, pc = _level(mf, mp, gpu, 10.0), _level(mc, mp, gpu, 10.0 * 4.0)
+    Jf, rstf = mf.geometry(mp); sf = mf.build_sides(mp)
+    sz = Schwarz(mf, sf, Jf, rstf, 2, 12, 1e-15, 1e-4, 10.0, 0)        # overlap 2, loose subdomain solves (a smoother, not a solver)
+    degh = np.zeros(8 * n_el, dtype=np.int32)
+    degh[0::8] = deg_f
+    T = Transfer(np.zeros(n_el, dtype=np.int32), deg_c.astype(np.int32), degh)
+    vec = lambda n: torch.zeros(n, dtype=torch.float64, device=gpu)
+    x, y, z = mf.nodal_coords(mp)
+    u_exact = torch.from_numpy(np.sin(2.0 * x) * np.cos(1.5 * y) + z * z + 0.02 * (M.splitmix64_uniform(3, mf.local_nodes) - 0.5)).to(gpu)
+    rhs = vec(mf.local_nodes)
+    pf.apply_aij(u_exact, rhs)
+    u, r, Au = vec(mf.local_nodes), vec(mf.local_nodes), vec(mf.local_nodes)
+    rc, ec, Ac, ef = vec(mc.local_nodes), vec(mc.local_nodes), vec(mc.local_nodes), vec(mf.local_nodes)
+    err = lambda v: (v - u_exact).norm().item() / u_exact.norm().item()
+    history = [err(u)]
+    for cycle in range(3):
+        sz.smooth(pf, u, rhs, r, 1)                                    # pre-smoothing; r = rhs - A u on exit
+        pf.apply_aij(u, Au)
+        assert float((r - (rhs - Au)).abs().max()) <= 1e-11 * float(rhs.abs().max())
+        T.restrict(r, rc)
+        ec.zero_()
+        pc.cg_eigs(ec, rc, Ac, 60, 1)
+        T.prolong(ec, ef)
+        u += ef
+        sz.smooth(pf, u, rhs, r, 1)                                    # post-smoothing
+        history.append(err(u))
+    us = vec(mf.local_nodes)
+    sz.smooth(pf, us, rhs, r, 6)                                       # smoothing alone, same number of Schwarz iterations
+    assert all(b < 0.6 * a for a, b in zip(history[:-1], history[1:])), history
+    assert history[-1] < 0.5 * err(us), (history, err(us))
+    sz.destroy()
+    for p in (pf, pc):
+        p.destroy()
+    T.destroy()
