@@ -63,8 +63,16 @@ def cpu_baseline(mesh, J, rst, u, budget_s=12.0):
         t_acc += time.perf_counter() - t0
         reps += 1
     gdofs = sample.local_nodes * reps / t_acc / 1e9
+    # one core, on a smaller slice (compare with the survey-time 3.5 MDoF/s per core of the real reference)
+    one = M.BrickMesh(mesh.level, int(mesh.deg[0]), quad_type=mesh.quad_type, first=0, count=max(1, min(n_sample, int(2.0 / per_elem / cores))))
+    J1, rst1 = one.geometry(None)
+    u1 = np.ascontiguousarray(u[:one.local_nodes])
+    oracle.apply_stiffness(one, J1, rst1, u1, nthreads=1)
+    t0 = time.perf_counter()
+    oracle.apply_stiffness(one, J1, rst1, u1, nthreads=1)
+    gdofs_1 = one.local_nodes / max(time.perf_counter() - t0, 1e-9) / 1e9
     return {
-        "value": gdofs, "unit": "GDoF/s", "cores": cores, "kind": "port",
+        "value": gdofs, "unit": "GDoF/s", "cores": cores, "kind": "port", "value_1_core": gdofs_1,
         "sample": "%d of %d elements (p=%d) of the same brick, %d reps, %d OpenMP threads over elements; "
                   "oracle/d4est_oracle.c (27-pass reference algorithm, naive row-major dgemm, gcc -O3 -march=native)"
                   % (sample.n_elements, mesh.n_elements, int(mesh.deg[0]), reps, cores),
