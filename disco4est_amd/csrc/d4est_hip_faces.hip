@@ -1629,6 +1629,7 @@ struct FaceHost {
   int n_ghost_sides = 0;
   int fld_stride = 0;   // generic kernels: doubles per field buffer
   int max_N = 1, max_NQ = 1;
+  int max_local_N = 1;   // largest deg + 1 among the plan's own elements (sizes the LDS copy of u in trace_mfma16_kernel)
   ElemDesc* d_elem_desc_generic = nullptr;  // offD -> unpadded N x N matrices
 };
 std::map<d4est_hip_plan*, FaceHost> g_face_host;
@@ -2044,6 +2045,8 @@ void faces_setup(d4est_hip_plan* plan) {
   fh.fld_stride = max_fld;
   fh.max_N = maxN;
   fh.max_NQ = maxNQ;
+  fh.max_local_N = 1;
+  for (int e = 0; e < ne; ++e) fh.max_local_N = std::max(fh.max_local_N, plan->deg[e] + 1);
   fh.n_ghost_sides = (int)gsides.size();
   plan->face_fast = fast;
   plan->max_face_lds_doubles = 12 * max_fld + maxN * maxN * maxN + maxN * maxN;
@@ -2316,7 +2319,7 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
   if (n == 0) return;
   if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const size_t lds = (size_t)(fh.hp_max_N * 272 + 3 * 2 * 16 * 34) * sizeof(double);
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(trace_hp_mfma16_kernel, dim3(std::min(n, 4 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), lds, plan->stream, u, trace,
                        fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, n, fh.hp_max_N);
   } else if (fh.hp) {
@@ -2341,10 +2344,9 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     // p = 8 .. 15: tiled MFMA trace kernel (descriptors with unpadded N x N derivative matrices)
     // only local elements are copied to LDS: size the copy of u by the largest LOCAL degree
-    int max_local_n = 1;
-    for (int e = 0; e < plan->n_elements; ++e) max_local_n = std::max(max_local_n, plan->deg[e] + 1);
+    const int max_local_n = fh.max_local_N;   // (cached at set-up: no per-launch walk over the elements)
     const size_t lds = (size_t)(max_local_n * 272 + 3 * 2 * 16 * 34) * sizeof(double);
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
     hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(n, per_cu * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), lds, plan->stream, u, trace,
                        (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n, max_local_n);
