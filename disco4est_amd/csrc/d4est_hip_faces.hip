@@ -2331,13 +2331,15 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
     const bool mfma = plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1;
     // resident workgroups per CU: 8 of the 3-wave MFMA kernel (47 VGPRs, 11.5 KB LDS), 4 of the 6-wave kernel
-    const int resident = (std::getenv("D4EST_HIP_FACE_WG_PER_CU") ? face_wg_per_cu() : (mfma ? 8 : 4)) * cus;
+    static const bool wg_override = std::getenv("D4EST_HIP_FACE_WG_PER_CU") != nullptr;   // environment knobs are read once
+    const int resident = (wg_override ? face_wg_per_cu() : (mfma ? 8 : 4)) * cus;
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     debug_occupancy_once();
+    static const int trace_diag = std::getenv("D4EST_HIP_TRACE_DIAG") ? std::atoi(std::getenv("D4EST_HIP_TRACE_DIAG")) : 0;
     if (mfma)   // auto: MFMA form of the two interpolation passes
       hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
-                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, std::getenv("D4EST_HIP_TRACE_DIAG") ? std::atoi(std::getenv("D4EST_HIP_TRACE_DIAG")) : 0);
+                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, trace_diag);
     else
       hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
                          (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, fh.uni);
@@ -2390,7 +2392,8 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     const int resident = face_wg_per_cu() * cus;
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
-    const int chunk = (n % 8 == 0 && grid % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0;
+    static const bool no_remap = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
+    const int chunk = (n % 8 == 0 && grid % 8 == 0 && !no_remap) ? n / 8 : 0;
     const bool subdomain_plan = plan->tuning[D4EST_HIP_TUNE_GHOST_ALIAS] > 0;   // see flux_wave_kernel: INPLACE
 #define D4EST_HIP_LAUNCH_FLUX_WAVE(FUSE_, INPLACE_, CF_)                                                                                 \
   hipLaunchKernelGGL((flux_wave_kernel<FUSE_, INPLACE_>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,               \
@@ -2403,7 +2406,8 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
 #undef D4EST_HIP_LAUNCH_FLUX_WAVE
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int grid16 = std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256));
-    const int chunk16 = (n % 8 == 0 && grid16 % 8 == 0 && !std::getenv("D4EST_HIP_NO_XCD_REMAP")) ? n / 8 : 0;
+    static const bool no_remap16 = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
+    const int chunk16 = (n % 8 == 0 && grid16 % 8 == 0 && !no_remap16) ? n / 8 : 0;
     if (cf)
       hipLaunchKernelGGL(flux_mfma16_kernel<true>, dim3(grid16), dim3(192), 0, plan->stream, trace,
                          ghost_trace, Au, (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
