@@ -93,6 +93,7 @@ SIGNATURES = {
     "d4est_hip_plan_trace_offset": (ctypes.c_longlong, [_vp, ctypes.c_int]),
     "d4est_hip_plan_side_blocks": (ctypes.c_int, [_vp, ctypes.c_int]),
     "d4est_hip_reorient_face_order": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "d4est_hip_face_reorder_code": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "d4est_hip_plan_trace_offset_sub": (ctypes.c_longlong, [_vp, ctypes.c_int, ctypes.c_int]),
     "d4est_hip_plan_ghost_trace_offset_sub": (ctypes.c_longlong, [_vp, ctypes.c_int, ctypes.c_int]),
     "d4est_hip_plan_trace_block_len_sub": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),

@@ -556,6 +556,11 @@ int d4est_hip_reorient_face_order(int f_m, int f_p, int orientation, int i) {
   return d4est_hip::reorient_face_order(f_m, f_p, orientation, i);
 }
 
+int d4est_hip_face_reorder_code(int f_m, int f_p, int orientation) {
+  if (f_m < 0 || f_m > 5 || f_p < 0 || f_p > 5 || orientation < 0 || orientation > 3) D4EST_HIP_ABORT("face_reorder_code: bad argument");
+  return d4est_hip::face_reorder_code(f_m, f_p, orientation);
+}
+
 int d4est_hip_plan_side_blocks(const d4est_hip_plan_t* plan, int side) {
   check_plan(plan, "plan_side_blocks");
   if (!plan->has_faces || side < 0 || side >= 6 * plan->n_elements) D4EST_HIP_ABORT("plan_side_blocks: side %d", side);

@@ -1654,6 +1654,28 @@ int reorient_face_order(int f_m, int f_p, int o, int i) {
   return perm_to_order[code_to_perm[FToF_code[f_m][f_p]][o]][i];
 }
 
+// The (flip0, flip1, transpose) code d4est_operators_reorient_face_data derives from a tree-boundary face pair
+// (dGMath/d4est_operators.c:2031-2050): p8est's face transform of the pair (lower face number, higher face number, orientation)
+// -- axes of the lower face's tangential directions, the axes they map to, and whether each is reversed
+// (p4est_expand_face_transform: my_axis = ft[0..2], target_axis = ft[3..5], edge_reverse = ft[6..8]).
+int face_reorder_code(int f_m, int f_p, int o) {
+  static const int ref0[6] = {0, 1, 1, 0, 0, 1};   // p8est_face_permutation_refs[0][.]
+  static const int refs[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
+                                 {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
+  const int lo = f_m <= f_p ? f_m : f_p, hi = f_m <= f_p ? f_p : f_m;
+  int my_axis[2], target_axis[2], edge_reverse[2];
+  my_axis[0] = lo < 2 ? 1 : 0;
+  my_axis[1] = lo < 4 ? 2 : 1;
+  const int swap_axes = ref0[lo] ^ ref0[hi] ^ ((o == 0 || o == 3) ? 1 : 0);
+  target_axis[swap_axes] = hi < 2 ? 1 : 0;
+  target_axis[!swap_axes] = hi < 4 ? 2 : 1;
+  const int swap_rev = (refs[lo][hi] == 1);
+  edge_reverse[swap_rev] = o & 1;
+  edge_reverse[!swap_rev] = o >> 1;
+  const int aligned = (my_axis[1] - my_axis[0]) * (target_axis[1] - target_axis[0]) > 0;
+  return edge_reverse[0] | (edge_reverse[1] << 1) | ((!aligned) << 2);
+}
+
 // Mortar records of a mesh with hanging faces (plan->side_hang etc. set by d4est_hip_plan_set_hanging).
 static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
   const int ne = plan->n_elements;

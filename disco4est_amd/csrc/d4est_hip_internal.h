@@ -149,6 +149,7 @@ void faces_setup(d4est_hip_plan* plan);
 void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n, const double* drst_m, const double* drst_p,
                         const double* hm, const double* hp, int on_device);
 int reorient_face_order(int f_m, int f_p, int o, int i);  // dGMath/d4est_reference.c:84-110
+int face_reorder_code(int f_m, int f_p, int o);            // dGMath/d4est_operators.c:2031-2050
 void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_device);
 void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const double* rhs_quad, int on_device);
 void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost);

@@ -277,6 +277,11 @@ int d4est_hip_plan_side_blocks(const d4est_hip_plan_t* plan, int side);
 /* d4est_reference_reorient_face_order (dGMath/d4est_reference.c:84-110), face_dim = 2: index in the (+) side's own order of the
  * sub-face that is i in (-) order */
 int d4est_hip_reorient_face_order(int f_m, int f_p, int orientation, int i);
+/* The side_reorder code of a tree-boundary face pair: what d4est_operators_reorient_face_data derives through
+ * p4est_expand_face_transform(min(f_m, f_p), 6*orientation + max(f_m, f_p)) (dGMath/d4est_operators.c:2031-2050):
+ * flip0 | flip1 << 1 | (not aligned) << 2.  orientation = p4est's tree_to_face[.] / 6 = p4est_iter_face_info_t::orientation
+ * (0 inside a tree).  Lets a C host fill side_reorder without p4est's transform tables. */
+int d4est_hip_face_reorder_code(int f_m, int f_p, int orientation);
 long long d4est_hip_plan_trace_offset_sub(const d4est_hip_plan_t* plan, int side, int sub);
 long long d4est_hip_plan_ghost_trace_offset_sub(const d4est_hip_plan_t* plan, int side, int sub);
 int d4est_hip_plan_trace_block_len_sub(const d4est_hip_plan_t* plan, int side, int sub);

@@ -145,6 +145,8 @@ void oracle_flux_set_robin(const double* coeff_quad, const double* rhs_quad);
  * 4 small sides share one block, as in Mesh/d4est_mesh.c:956-962. */
 void oracle_flux_set_hanging(const int* side_hang, const int* side_sub, const int* side_nbr4, const int* side_orientation);
 int oracle_reorient_face_order(int f_m, int f_p, int o, int i);   /* dGMath/d4est_reference.c:84-110 */
+void oracle_expand_face_transform(int iface, int nface, int ftransform[9]); /* p4est-2.8 src/p4est_connectivity.c:2877-2944 */
+int oracle_face_reorder_code(int f_m, int f_p, int o);             /* dGMath/d4est_operators.c:2031-2050 */
 
 /* GEOM_COMPUTE_NUMERICAL volume factors from the nodal coordinates (Mesh/d4est_mesh.c:2637-2671, Geometry/d4est_geometry.c:877-976) */
 void oracle_mesh_compute_geometry_numerical(int quad_type, int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,

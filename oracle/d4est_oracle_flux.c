@@ -236,6 +236,38 @@ int oracle_reorient_face_order(int f_m, int f_p, int o, int i) {
   return perm_to_order[perm][i];
 }
 
+/* p4est 2.8, src/p4est_connectivity.c:2877-2944 (p4est_expand_face_transform, P4_TO_P8 branch) -- third-party dependency of the
+ * reference (third_party/p4est-2.8.tar.gz, un-vendored); restated from its published algorithm:
+ * ftransform[0..2] = my_axis, [3..5] = target_axis, [6..8] = edge_reverse. */
+void oracle_expand_face_transform(int iface, int nface, int ftransform[9]) {
+  static const int face_permutation_refs[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
+                                                  {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
+  const int target_face = nface % 6, orientation = nface / 6;
+  int reverse;
+  ftransform[0] = iface < 2 ? 1 : 0;
+  ftransform[1] = iface < 4 ? 2 : 1;
+  ftransform[2] = iface / 2;
+  reverse = face_permutation_refs[0][iface] ^ face_permutation_refs[0][target_face] ^ (orientation == 0 || orientation == 3);
+  ftransform[3 + reverse] = target_face < 2 ? 1 : 0;
+  ftransform[3 + !reverse] = target_face < 4 ? 2 : 1;
+  ftransform[5] = target_face / 2;
+  reverse = (face_permutation_refs[iface][target_face] == 1);
+  ftransform[6 + reverse] = (orientation & 1);
+  ftransform[6 + !reverse] = (orientation >> 1);
+  ftransform[8] = 2 * (iface & 1) + (target_face & 1);
+}
+
+/* d4est_operators.c:2031-2050: the (flip0, flip1, !aligned) triple of d4est_operators_reorient_face_data as the code
+ * oracle_reorient_face_data takes */
+int oracle_face_reorder_code(int f_m, int f_p, int o) {
+  int ftransform[9];
+  oracle_expand_face_transform(((f_m <= f_p) ? f_m : f_p), 6 * o + ((f_m <= f_p) ? f_p : f_m), ftransform);
+  int flip0 = ftransform[6];
+  int flip1 = ftransform[7];
+  int aligned = ((ftransform[1] - ftransform[0]) * (ftransform[4] - ftransform[3]) > 0);
+  return flip0 | (flip1 << 1) | ((aligned == 0) << 2);
+}
+
 /* Mesh/d4est_mortars.c:550-598 */
 static void project_side_onto_mortar_space(const double* in_side, int faces_side, const int* deg_side, double* out_mortar,
                                            int faces_mortar, const int* deg_mortar) {
@@ -266,9 +298,17 @@ static void project_mass_mortar_onto_side(const double* in_mortar, int faces_mor
   } else FLUX_ABORT("project_mass_mortar_onto_side");
 }
 
+/* element references: local id >= 0, or -(g + 2) for ghost element g (e_m_is_ghost / d4est_mesh_get_field_on_element,
+ * dGMath/d4est_laplacian_flux.c:513-557, :700-768; a ghost (-) element receives nothing, d4est_laplacian_flux_sipg.c:896-927) */
+static int ref_deg(const flux_ctx_t* c, int r) { return r >= 0 ? c->deg[r] : c->ghost_deg[-(r + 2)]; }
+static int ref_deg_quad(const flux_ctx_t* c, int r) { return r >= 0 ? c->deg_quad[r] : c->ghost_deg_quad[-(r + 2)]; }
+static const double* ref_field(const flux_ctx_t* c, int r, const double* local, const double* ghost) {
+  return r >= 0 ? &local[c->nodal_stride[r]] : &ghost[c->ghost_nodal_stride[-(r + 2)]];
+}
+
 static void flux_interface_general(const flux_ctx_t* c, const int* e_m, int faces_m, int f_m, const int* e_p_oriented, int faces_p,
-                                   int f_p, int orientation, int code, int S, const double* u, double* const dudr_local[3],
-                                   double* Au) {
+                                   int f_p, int orientation, int code, int S, const double* u, const double* u_ghost,
+                                   double* const dudr_local[3], double* const dudr_ghost[3], double* Au) {
   const int faces_mortar = (faces_m > faces_p) ? faces_m : faces_p;
   int e_p[4];
   int deg_m_lobatto[4], deg_m_quad[4], deg_p_lobatto[4], deg_p_quad[4], deg_p_lobatto_porder[4];
@@ -280,13 +320,13 @@ static void flux_interface_general(const flux_ctx_t* c, const int* e_m, int face
   else for (int i = 0; i < 4; i++) e_p[oracle_reorient_face_order(f_m, f_p, orientation, i)] = e_p_oriented[i];
   int total_side_nodes_m_lobatto = 0, total_side_nodes_p_lobatto = 0;
   for (int i = 0; i < faces_m; i++) {                                        /* :277-288 */
-    deg_m_lobatto[i] = c->deg[e_m[i]]; deg_m_quad[i] = c->deg_quad[e_m[i]];
+    deg_m_lobatto[i] = ref_deg(c, e_m[i]); deg_m_quad[i] = ref_deg_quad(c, e_m[i]);
     face_nodes_m_lobatto[i] = (deg_m_lobatto[i] + 1) * (deg_m_lobatto[i] + 1);
     total_side_nodes_m_lobatto += face_nodes_m_lobatto[i];
   }
   for (int i = 0; i < faces_p; i++) {                                        /* :293-305 */
-    deg_p_lobatto[i] = c->deg[e_p_oriented[i]]; deg_p_quad[i] = c->deg_quad[e_p_oriented[i]];
-    deg_p_lobatto_porder[i] = c->deg[e_p[i]];
+    deg_p_lobatto[i] = ref_deg(c, e_p_oriented[i]); deg_p_quad[i] = ref_deg_quad(c, e_p_oriented[i]);
+    deg_p_lobatto_porder[i] = ref_deg(c, e_p[i]);
     face_nodes_p_lobatto[i] = (deg_p_lobatto[i] + 1) * (deg_p_lobatto[i] + 1);
     total_side_nodes_p_lobatto += face_nodes_p_lobatto[i];
   }
@@ -323,12 +363,12 @@ static void flux_interface_general(const flux_ctx_t* c, const int* e_m, int face
   double* tmp = dalloc(total_side_nodes_p_lobatto + 1);
   int stride = 0;
   for (int i = 0; i < faces_m; i++) {                                        /* :513-557 */
-    oracle_apply_slicer(&u[c->nodal_stride[e_m[i]]], f_m, deg_m_lobatto[i], &u_m_on_f_m[stride]);
+    oracle_apply_slicer(ref_field(c, e_m[i], u, u_ghost), f_m, deg_m_lobatto[i], &u_m_on_f_m[stride]);
     stride += face_nodes_m_lobatto[i];
   }
   stride = 0;
   for (int i = 0; i < faces_p; i++) {                                        /* :575-633 */
-    oracle_apply_slicer(&u[c->nodal_stride[e_p_oriented[i]]], f_p, deg_p_lobatto[i], tmp);
+    oracle_apply_slicer(ref_field(c, e_p_oriented[i], u, u_ghost), f_p, deg_p_lobatto[i], tmp);
     oracle_reorient_face_data(tmp, deg_p_lobatto[i], code, &u_p_on_f_p[stride]);
     stride += face_nodes_p_lobatto[i];
   }
@@ -347,12 +387,12 @@ static void flux_interface_general(const flux_ctx_t* c, const int* e_m, int face
     double* b = dalloc(TT);
     stride = 0;
     for (int f = 0; f < faces_m; f++) {                                      /* :700-731 */
-      oracle_apply_slicer(&dudr_local[d][c->nodal_stride[e_m[f]]], f_m, deg_m_lobatto[f], &a_m[stride]);
+      oracle_apply_slicer(ref_field(c, e_m[f], dudr_local[d], dudr_ghost[d]), f_m, deg_m_lobatto[f], &a_m[stride]);
       stride += face_nodes_m_lobatto[f];
     }
     stride = 0;
     for (int f = 0; f < faces_p; f++) {                                      /* :733-768: (+) side in ITS order */
-      oracle_apply_slicer(&dudr_local[d][c->nodal_stride[e_p[f]]], f_p, deg_p_lobatto_porder[f], &a_p[stride]);
+      oracle_apply_slicer(ref_field(c, e_p[f], dudr_local[d], dudr_ghost[d]), f_p, deg_p_lobatto_porder[f], &a_p[stride]);
       stride += (deg_p_lobatto_porder[f] + 1) * (deg_p_lobatto_porder[f] + 1);
     }
     project_side_onto_mortar_space(a_p, faces_p, deg_p_lobatto_porder, b, faces_mortar, deg_mortar_quad_porder);   /* :770-780 */
@@ -427,6 +467,7 @@ static void flux_interface_general(const flux_ctx_t* c, const int* e_m, int face
   stride = 0;
   for (int f = 0; f < faces_m; f++) {                                        /* :770-826, :896-927 */
     const int deg = deg_m_lobatto[f], vn = (deg + 1) * (deg + 1) * (deg + 1);
+    if (e_m[f] < 0) { stride += face_nodes_m_lobatto[f]; continue; }         /* e_m_is_ghost: handled by its owner */
     double* lifted = dalloc(vn); double* dt = dalloc(vn); double* l1 = dalloc(vn); double* l3 = dalloc(vn);
     double* t2sum = dalloc((size_t)3 * vn);
     oracle_apply_lift(&proj1[stride], deg, f_m, l1);
@@ -572,13 +613,17 @@ void oracle_laplacian_apply_aij(int quad_type, int n_elements, const int* deg, c
       else if (g_side_hang && g_side_hang[6 * e + f] == 1) {
         int em[1] = {e};
         flux_interface_general(&c, em, 1, f, &g_side_nbr4[4 * (6 * e + f)], 4, side_nbr_face[6 * e + f], g_side_orientation[6 * e + f],
-                               side_reorder[6 * e + f], side_mortar_stride[6 * e + f], u, dl, Au);
+                               side_reorder[6 * e + f], side_mortar_stride[6 * e + f], u, u_ghost, dl, dg, Au);
       } else if (g_side_hang && g_side_hang[6 * e + f] == 2) {
-        /* the reference's callback handles the 4 hanging elements of the face together: once, at the group's first member */
-        if (g_side_sub[6 * e + f] == 0) {
+        /* the reference's callback handles the 4 hanging elements of the face together: once, here at the group's first LOCAL
+         * member (ghost members are read but receive nothing, Mesh/d4est_mortars.c:655-700) */
+        const int* grp = &g_side_nbr4[4 * (6 * e + f)];
+        int first_local = -1;
+        for (int i = 0; i < 4 && first_local < 0; i++) if (grp[i] >= 0) first_local = grp[i];
+        if (first_local == e) {
           int ep[1] = {side_nbr[6 * e + f]};
-          flux_interface_general(&c, &g_side_nbr4[4 * (6 * e + f)], 4, f, ep, 1, side_nbr_face[6 * e + f], g_side_orientation[6 * e + f],
-                                 side_reorder[6 * e + f], side_mortar_stride[6 * e + f], u, dl, Au);
+          flux_interface_general(&c, grp, 4, f, ep, 1, side_nbr_face[6 * e + f], g_side_orientation[6 * e + f],
+                                 side_reorder[6 * e + f], side_mortar_stride[6 * e + f], u, u_ghost, dl, dg, Au);
         }
       }
       else flux_interface_side(&c, e, f, u, u_ghost, dl, dg, Au);

@@ -1,0 +1,68 @@
+"""Build-container-only script: extracts NUMBERS the reference tabulates into JSON fixtures (data, not source text).
+
+  reference_nodes_weights.json         Gauss-Legendre and Gauss-Lobatto abscissas / weights for n = 1..20, the values the reference's
+                                       operator tables start from (src/dGMath/GL_and_GLL_nodes_and_weights.h:6-4080 gauss, :4082-4652
+                                       lobatto; consumed by d4est_operators.c:727-741, :790-805).  Each `x[i] = <expr>;` is evaluated
+                                       as double arithmetic, exactly what the C compiler does with it.
+  cubed_sphere_7tree_connectivity.json tree_to_tree / tree_to_face of d4est_connectivity_new_sphere_7tree
+                                       (src/Geometry/d4est_connectivity_cubed_sphere.c:41-58).
+
+Run from the repo root:  python tests/golden/make_reference_tables.py   (needs /root/reference; the fixtures are committed).
+"""
+import json
+import os
+import re
+
+REF = "/root/reference/src"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def parse_rule(text, xname, wname, nmax=20):
+    out = {}
+    blocks = re.split(r"if\s*\(\s*n\s*==\s*(\d+)\s*\)", text)
+    for k in range(1, len(blocks) - 1, 2):
+        n = int(blocks[k])
+        if n > nmax or n in out:
+            continue
+        body = blocks[k + 1]
+        x, w = {}, {}
+        for name, idx, expr in re.findall(r"(\w+)\[(\d+)\]\s*=\s*([^;]+);", body):
+            if name not in (xname, wname):
+                continue
+            val = float(eval(expr.replace(" ", ""), {"__builtins__": {}}))
+            (x if name == xname else w)[int(idx)] = val
+        if len(x) == n and len(w) == n:
+            out[n] = {"x": [x[i] for i in range(n)], "w": [w[i] for i in range(n)]}
+    return out
+
+
+def main():
+    src = open(os.path.join(REF, "dGMath", "GL_and_GLL_nodes_and_weights.h")).read()
+    cut = src.index("d4est_operators_lobatto_nodes_and_weights")
+    gauss = parse_rule(src[:cut], "x", "w")
+    lobatto = parse_rule(src[cut:], "xtab", "weight")
+    assert sorted(gauss) == list(range(1, 21)), sorted(gauss)
+    assert sorted(lobatto) == list(range(1, 21)), sorted(lobatto)
+    with open(os.path.join(HERE, "reference_nodes_weights.json"), "w") as fh:
+        json.dump({"source": "src/dGMath/GL_and_GLL_nodes_and_weights.h (numeric values only)",
+                   "gauss": {str(n): gauss[n] for n in sorted(gauss)},
+                   "lobatto": {str(n): lobatto[n] for n in sorted(lobatto)}}, fh, indent=0)
+
+    csrc = open(os.path.join(REF, "Geometry", "d4est_connectivity_cubed_sphere.c")).read()
+    fn = csrc[csrc.index("d4est_connectivity_new_sphere_7tree"):csrc.index("d4est_connectivity_new_sphere_innerouter_shell")]
+
+    def table(name):
+        body = re.search(name + r"\[[^\]]*\]\s*=\s*\{([^}]*)\}", fn).group(1)
+        body = re.sub(r"//[^\n]*", "", body)
+        return [int(v) for v in re.findall(r"-?\d+", body)]
+
+    ttt, ttf = table("tree_to_tree"), table("tree_to_face")
+    assert len(ttt) == 42 and len(ttf) == 42
+    with open(os.path.join(HERE, "cubed_sphere_7tree_connectivity.json"), "w") as fh:
+        json.dump({"source": "src/Geometry/d4est_connectivity_cubed_sphere.c:41-58 (d4est_connectivity_new_sphere_7tree)",
+                   "num_trees": 7, "tree_to_tree": ttt, "tree_to_face": ttf}, fh)
+    print("wrote reference_nodes_weights.json (n = 1..20) and cubed_sphere_7tree_connectivity.json")
+
+
+if __name__ == "__main__":
+    main()
