@@ -328,8 +328,24 @@ class Plan:
 
     def set_comm(self, exchange=None, allreduce=None):
         """exchange(phase, trace_ptr, ghost_trace_ptr), allreduce(scalars_ptr, n): python callables (pointers are ints)"""
-        self._cb_ex = self.EXCHANGE_FN(lambda ctx, ph, a, b: exchange(ph, a, b)) if exchange else None
-        self._cb_ar = self.ALLREDUCE_FN(lambda ctx, p, n: allreduce(p, n)) if allreduce else None
+        def guarded(fn):
+            # ctypes prints and DROPS an exception raised inside a callback; the C caller would carry on with a stale ghost trace
+            # or un-reduced scalars.  A failed exchange aborts the process, like every other failure of the library (D4EST_HIP_ABORT).
+            def call(*args):
+                try:
+                    fn(*args)
+                except BaseException:
+                    import os
+                    import sys
+                    import traceback
+                    sys.stderr.write("[D4EST_HIP_ABORT] exception in a communication callback:\n")
+                    traceback.print_exc()
+                    sys.stderr.flush()
+                    os.abort()
+            return call
+
+        self._cb_ex = self.EXCHANGE_FN(guarded(lambda ctx, ph, a, b: exchange(ph, a, b))) if exchange else None
+        self._cb_ar = self.ALLREDUCE_FN(guarded(lambda ctx, p, n: allreduce(p, n))) if allreduce else None
         self.lib.d4est_hip_plan_set_comm(self.handle, ctypes.cast(self._cb_ex, ctypes.c_void_p) if self._cb_ex else None,
                                          ctypes.cast(self._cb_ar, ctypes.c_void_p) if self._cb_ar else None, None)
 

@@ -355,7 +355,8 @@ struct HpMortar {
   int offEa, offEb;  // (N x NQ) mortar quadrature nodes -> side
   int first, last;   // first / last record of its side
   int gidx;          // scalar index of the mortar's first node in the precombined geometry / boundary arrays (S + off)
-  int pad;
+  int u_shift;       // offset (doubles) from the (+) block to the block whose u field this mortar reads; 0 except on a small side whose
+                     // face pair the reference re-orients non-geometrically (see faces_setup_hp)
   double fm, fp, w2, pad2;
   long long qoff, nbr_qoff;
 };
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(256) void flux_hp_kernel(const double* __restrict__
         }
         const int kp = (m.kind == 0) ? k : reorder_index(m.code, NQ - 1, k % NQ, k / NQ);
         const double um = qm[k];
-        const double up = (m.kind == 0) ? bndry_q[m.gidx + k] : qp[kp];
+        const double up = (m.kind == 0) ? bndry_q[m.gidx + k] : qp[kp + m.u_shift];
         double tm = 0.0, tp = 0.0, am[3];
         for (int i = 0; i < 3; ++i) {
           am[i] = g[i * T + k];
@@ -1528,7 +1529,7 @@ __global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __res
               }
               if (m.kind != 0) {
                 const double* pp = ((m.kind == 2) ? ghost_qtrace : qtrace) + m.nbr_qoff + reorder_index(m.code, NQ - 1, mi, bq);
-                up = pp[0];
+                up = pp[m.u_shift];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) tp += g[(3 + i) * T] * pp[(1 + i) * T];
               } else {
@@ -1675,6 +1676,21 @@ int face_reorder_code(int f_m, int f_p, int o) {
   const int aligned = (my_axis[1] - my_axis[0]) * (target_axis[1] - target_axis[0]) > 0;
   return edge_reverse[0] | (edge_reverse[1] << 1) | ((!aligned) << 2);
 }
+
+// Small side of a hanging face, sub-face c in its own (= (-)) order.  The reference slices the WHOLE big face, re-orients it with the
+// (flip0, flip1, transpose) code and hp-prolongs the result onto child c (dGMath/d4est_laplacian_flux.c:575-657): u on sub-mortar c
+// comes from the big element's own child that the code maps onto c.  The gradient comes from the child
+// d4est_reference_reorient_face_order names (:733-830, :858-900).  The two agree whenever the code is the geometric map between the
+// faces; for a transposed pair with exactly one flip seen from the lower-numbered face (codes 5, 6) the reference's re-orientation is
+// not geometric (forest.reference_reorientation_is_consistent) and they differ -- followed here as the reference computes it.
+static int small_side_u_child(int code, int c) {
+  int ha = (code & 4) ? (c >> 1) : (c & 1), hb = (code & 4) ? (c & 1) : (c >> 1);
+  if (code & 2) hb ^= 1;
+  if (code & 1) ha ^= 1;
+  return ha + 2 * hb;
+}
+static const char* kNonGeometricMsg =
+    "the reference's re-orientation of this tree-face pair is not geometric (transposed with one flip, seen from the lower face)";
 
 // Mortar records of a mesh with hanging faces (plan->side_hang etc. set by d4est_hip_plan_set_hanging).
 static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
@@ -1852,6 +1868,10 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
       m.nbr_qoff = goff;
       plan->rec_goff[r] = goff;
       goff += 4LL * m.NQ * m.NQ;
+      const size_t sg = 6 * (size_t)m.elem + m.face;
+      if (plan->side_hang[sg] == 2 &&
+          small_side_u_child(m.code, plan->side_sub[sg]) != reorient_face_order(m.face, plan->side_nbr_face[sg], plan->side_orientation[sg], plan->side_sub[sg]))
+        D4EST_HIP_ABORT("plan_set_hanging: small side %zu: %s, and the big element is on another rank", sg, kNonGeometricMsg);
       continue;
     }
     if (m.kind == 0) continue;
@@ -1868,6 +1888,14 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
     const HpMortar& mp = rec[side_first[sp] + sub_p];
     if (mp.NQ != m.NQ) D4EST_HIP_ABORT("plan_set_hanging: sides %zu and %zu disagree on the mortar degree", s, sp);
     m.nbr_qoff = mp.qoff;
+    if (hang == 2) {
+      const int sub_u = small_side_u_child(m.code, plan->side_sub[s]);
+      if (sub_u != sub_p) {
+        const HpMortar& mu = rec[side_first[sp] + sub_u];
+        if (mu.NQ != m.NQ) D4EST_HIP_ABORT("plan_set_hanging: small side %zu: %s, and its sub-mortars have different quadrature degrees", s, kNonGeometricMsg);
+        m.u_shift = (int)(mu.qoff - mp.qoff);
+      }
+    }
   }
   plan->local_trace_doubles = qoff;
   plan->ghost_trace_doubles = goff;

@@ -186,7 +186,12 @@ void d4est_hip_plan_set_faces(d4est_hip_plan_t* plan, const int* side_nbr, const
  * sides share ONE block (the same side_mortar_stride), and drst_dxyz_p_porder is stored in the (+) side's sub-face order.
  * Element references (side_nbr, side_nbr4) are local ids or ghost codes -(g + 2), as in side_nbr.  Plans with hanging faces
  * and ghost elements take the ghost traces from the trace exchange (the *_sub block accessors below); d4est_hip_compute_ghost_traces
- * (whole ghost elements) serves conforming plans only. */
+ * (whole ghost elements) serves conforming plans only.
+ * Faces between trees: side_orientation / side_reorder as p4est reports them; every (f_m, f_p, orientation) triple is followed as the
+ * reference computes it.  For transposed pairs with exactly one flip seen from the lower-numbered face (reorder codes 5, 6 -- none in
+ * the reference's own connectivities) d4est_operators_reorient_face_data is not the geometric map; on a SMALL side of such a pair the
+ * reference takes u and du/dx from different children of the big face, which the engine reproduces when the four sub-mortars share one
+ * quadrature degree and the big element is local, and aborts otherwise. */
 void d4est_hip_plan_set_hanging(d4est_hip_plan_t* plan, const int* side_hang, const int* side_sub, const int* side_nbr4,
                                 const int* side_orientation);
 /* SIPG parameters ([flux] sipg_penalty_prefactor, sipg_penalty_fcn; d4est_laplacian_flux_sipg.c:945-1005):

@@ -80,3 +80,26 @@ def test_error_convention_aborts_like_d4est():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
     assert "[D4EST_HIP_ABORT]" in r.stderr and "apply_stiffness_matrix" in r.stderr
+
+
+def test_comm_callback_exception_aborts():
+    """An exception inside the exchange / allreduce hook must not be swallowed by ctypes (the C caller would continue with a stale
+    ghost trace): the process aborts, the library's error convention (D4EST_ABORT, src/Utilities/d4est_util.h:171)."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent('''
+        import sys; sys.path.insert(0, %r)
+        from disco4est_amd import capi
+        P = capi.Plan.__new__(capi.Plan)
+        class L:
+            def d4est_hip_plan_set_comm(self, *a): pass
+        P.lib = L(); P.handle = None
+        def boom(ph, a, b): raise RuntimeError("exchange failed")
+        P.set_comm(boom, None)
+        P._cb_ex(None, 0, None, None)
+        print("survived")
+    ''') % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "survived" not in r.stdout
+    assert "D4EST_HIP_ABORT" in r.stderr and "exchange failed" in r.stderr
