@@ -9,6 +9,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libd4est_hip.so")
+# the reference's own entry points (include/d4est_hip_compat.h): plain C++ on top of the C-ABI, kept in its own library so that
+# loading the engine does not put d4est's symbol names into the process
+COMPAT_LIB = os.path.join(HERE, "libd4est_hip_compat.so")
+COMPAT_SRC = "d4est_hip_compat.cpp"
 SOURCES = [
     "d4est_hip_tables.cpp",
     "d4est_hip_capi.hip",
@@ -32,7 +36,8 @@ def _newest_source_mtime():
 
 
 def needs_build():
-    return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < _newest_source_mtime()
+    newest = _newest_source_mtime()
+    return any((not os.path.exists(l)) or os.path.getmtime(l) < newest for l in (LIB, COMPAT_LIB))
 
 
 def build_library(force=False, verbose=True, jobs=None):
@@ -61,6 +66,11 @@ def build_library(force=False, verbose=True, jobs=None):
     if failed:
         raise RuntimeError("hipcc compilation failed")
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared", os.path.join(CSRC, COMPAT_SRC), "-o", COMPAT_LIB,
+           "-L" + HERE, "-ld4est_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -101,6 +101,16 @@ SIGNATURES = {
     "d4est_hip_plan_trace_block_len": (ctypes.c_int, [_vp, ctypes.c_int]),
     "d4est_hip_vec_dot": (None, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "d4est_hip_apply_stiffness_matrix_host": (None, [_vp, _vp, _vp]),
+    "d4est_hip_apply_aij_host": (None, [_vp, _vp, _vp]),
+    "d4est_hip_apply_lhs_host": (None, [_vp, _vp, _vp]),
+    "d4est_hip_cheby_iterate_host": (None, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]),
+    "d4est_hip_cg_eigs_host": (ctypes.c_double, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _c_double_p]),
+    "d4est_hip_plan_set_jacobian": (None, [_vp, _vp, ctypes.c_int]),
+    "d4est_hip_host_alloc": (_vp, [ctypes.c_size_t]),
+    "d4est_hip_host_free": (None, [_vp]),
+    "d4est_hip_memcpy_h2d_async": (None, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "d4est_hip_memcpy_d2h_async": (None, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "d4est_hip_plan_synchronize": (None, [_vp]),
 }
 
 TABLE = {
@@ -122,6 +132,12 @@ def load_library(path=None):
         raise RuntimeError(
             "libd4est_hip.so not found at %s -- build it with `python -m disco4est_amd.build` "
             "(or __graft_entry__.build()); there is no CPU fallback" % p)
+    # Load order matters in a process that also uses torch: torch ships its own HIP runtime under the same soname as /opt/rocm's.
+    # Whichever is mapped first serves both; torch aborts on the system one, while this library runs on either.  So torch goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing

@@ -214,6 +214,8 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   d4est_hip::faces_destroy(plan);
   (void)hipFree(plan->d_work_p); (void)hipFree(plan->d_work_d); (void)hipFree(plan->d_work_r); (void)hipFree(plan->d_work_m);
   (void)hipFree(plan->d_reduce); (void)hipFree(plan->d_ghost_trace);
+  if (plan->h_stage) (void)hipHostFree(plan->h_stage);
+  for (int i = 0; i < 4; ++i) (void)hipFree(plan->d_host[i]);
   if (plan->cheby_graph) (void)hipGraphExecDestroy(plan->cheby_graph);
   if (plan->side_stream) { (void)hipStreamDestroy(plan->side_stream); (void)hipEventDestroy(plan->ev_fork); (void)hipEventDestroy(plan->ev_join); }
   delete plan;
@@ -598,18 +600,123 @@ void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const
   d4est_hip::launch_dot(plan, n, x_dev, y_dev, result_dev);
 }
 
+// ---- host-pointer entries: persistent mirrors, upload once / download once -------------------------------------------
+static void ensure_host_mirrors(d4est_hip_plan_t* plan) {
+  if (plan->h_stage) return;
+  const size_t bytes = std::max<size_t>((size_t)plan->local_nodes, 1) * sizeof(double);
+  HIP_CHECK(hipHostMalloc((void**)&plan->h_stage, 3 * bytes, hipHostMallocDefault));
+  for (int i = 0; i < 4; ++i) HIP_CHECK(hipMalloc(&plan->d_host[i], bytes));
+}
+// host vector -> pinned slot -> device mirror, asynchronously on the plan's stream
+static void stage_in(d4est_hip_plan_t* plan, int slot, const double* host, double* dev) {
+  const size_t bytes = (size_t)plan->local_nodes * sizeof(double);
+  double* pin = plan->h_stage + (size_t)slot * plan->local_nodes;
+  std::memcpy(pin, host, bytes);
+  HIP_CHECK(hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, plan->stream));
+}
+static void stage_out_begin(d4est_hip_plan_t* plan, int slot, const double* dev) {
+  HIP_CHECK(hipMemcpyAsync(plan->h_stage + (size_t)slot * plan->local_nodes, dev, (size_t)plan->local_nodes * sizeof(double),
+                           hipMemcpyDeviceToHost, plan->stream));
+}
+static void stage_out_end(d4est_hip_plan_t* plan, int slot, double* host) {
+  std::memcpy(host, plan->h_stage + (size_t)slot * plan->local_nodes, (size_t)plan->local_nodes * sizeof(double));
+}
+
 void d4est_hip_apply_stiffness_matrix_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host) {
   check_plan(plan, "apply_stiffness_matrix_host");
-  const size_t bytes = (size_t)plan->local_nodes * sizeof(double);
-  double *du = nullptr, *dAu = nullptr;
-  HIP_CHECK(hipMalloc(&du, std::max<size_t>(bytes, 8)));
-  HIP_CHECK(hipMalloc(&dAu, std::max<size_t>(bytes, 8)));
-  HIP_CHECK(hipMemcpyAsync(du, u_host, bytes, hipMemcpyHostToDevice, plan->stream));
-  d4est_hip::launch_stiffness(plan, du, dAu);
-  HIP_CHECK(hipMemcpyAsync(Au_host, dAu, bytes, hipMemcpyDeviceToHost, plan->stream));
+  if (!u_host || !Au_host) D4EST_HIP_ABORT("apply_stiffness_matrix_host: NULL vector");
+  ensure_host_mirrors(plan);
+  stage_in(plan, 0, u_host, plan->d_host[0]);
+  d4est_hip::launch_stiffness(plan, plan->d_host[0], plan->d_host[2]);
+  stage_out_begin(plan, 1, plan->d_host[2]);
   HIP_CHECK(hipStreamSynchronize(plan->stream));
-  HIP_CHECK(hipFree(du));
-  HIP_CHECK(hipFree(dAu));
+  stage_out_end(plan, 1, Au_host);
+}
+
+void d4est_hip_apply_aij_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host) {
+  check_plan(plan, "apply_aij_host");
+  if (!u_host || !Au_host) D4EST_HIP_ABORT("apply_aij_host: NULL vector");
+  ensure_host_mirrors(plan);
+  stage_in(plan, 0, u_host, plan->d_host[0]);
+  d4est_hip::apply_operator(plan, plan->d_host[0], plan->d_host[2], nullptr, false);
+  stage_out_begin(plan, 1, plan->d_host[2]);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  stage_out_end(plan, 1, Au_host);
+}
+
+void d4est_hip_apply_lhs_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host) {
+  check_plan(plan, "apply_lhs_host");
+  if (!u_host || !Au_host) D4EST_HIP_ABORT("apply_lhs_host: NULL vector");
+  ensure_host_mirrors(plan);
+  stage_in(plan, 0, u_host, plan->d_host[0]);
+  d4est_hip::apply_operator(plan, plan->d_host[0], plan->d_host[2]);
+  stage_out_begin(plan, 1, plan->d_host[2]);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  stage_out_end(plan, 1, Au_host);
+}
+
+void d4est_hip_cheby_iterate_host(d4est_hip_plan_t* plan, double* u_host, const double* rhs_host, double* Au_host, double* r_host,
+                                  int iter, double lmin, double lmax, int compute_residual_at_end) {
+  check_plan(plan, "cheby_iterate_host");
+  if (!u_host || !rhs_host || !r_host) D4EST_HIP_ABORT("cheby_iterate_host: NULL vector");
+  ensure_host_mirrors(plan);
+  stage_in(plan, 0, u_host, plan->d_host[0]);
+  stage_in(plan, 1, rhs_host, plan->d_host[1]);
+  d4est_hip::cheby_iterate(plan, plan->d_host[0], plan->d_host[1], plan->d_host[2], plan->d_host[3], iter, lmin, lmax, compute_residual_at_end);
+  stage_out_begin(plan, 0, plan->d_host[0]);
+  stage_out_begin(plan, 1, plan->d_host[3]);
+  if (Au_host) stage_out_begin(plan, 2, plan->d_host[2]);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  stage_out_end(plan, 0, u_host);
+  stage_out_end(plan, 1, r_host);
+  if (Au_host) stage_out_end(plan, 2, Au_host);
+}
+
+double d4est_hip_cg_eigs_host(d4est_hip_plan_t* plan, double* u_host, const double* rhs_host, double* Au_host, int imax, int use_new,
+                              double* history_host) {
+  check_plan(plan, "cg_eigs_host");
+  if (!u_host || !rhs_host) D4EST_HIP_ABORT("cg_eigs_host: NULL vector");
+  ensure_host_mirrors(plan);
+  stage_in(plan, 0, u_host, plan->d_host[0]);
+  stage_in(plan, 1, rhs_host, plan->d_host[1]);
+  const double bound = d4est_hip::cg_eigs(plan, plan->d_host[0], plan->d_host[1], plan->d_host[2], imax, use_new, history_host);
+  stage_out_begin(plan, 0, plan->d_host[0]);
+  if (Au_host) stage_out_begin(plan, 2, plan->d_host[2]);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  stage_out_end(plan, 0, u_host);
+  if (Au_host) stage_out_end(plan, 2, Au_host);
+  return bound;
+}
+
+void d4est_hip_plan_set_jacobian(d4est_hip_plan_t* plan, const double* J_quad, int on_device) {
+  check_plan(plan, "plan_set_jacobian");
+  drop_graph(plan);
+  if (!J_quad) D4EST_HIP_ABORT("plan_set_jacobian: NULL array");
+  const size_t nq = (size_t)plan->local_nodes_quad;
+  if (!plan->d_J) HIP_CHECK(hipMalloc(&plan->d_J, std::max<size_t>(nq, 1) * sizeof(double)));
+  HIP_CHECK(hipMemcpyAsync(plan->d_J, J_quad, nq * sizeof(double), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, plan->stream));
+  if (!on_device) HIP_CHECK(hipStreamSynchronize(plan->stream));
+}
+
+void* d4est_hip_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+  return p;
+}
+void d4est_hip_host_free(void* ptr_host) {
+  if (ptr_host) HIP_CHECK(hipHostFree(ptr_host));
+}
+void d4est_hip_memcpy_h2d_async(d4est_hip_plan_t* plan, void* dst_dev, const void* src_host, size_t bytes) {
+  check_plan(plan, "memcpy_h2d_async");
+  HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, plan->stream));
+}
+void d4est_hip_memcpy_d2h_async(d4est_hip_plan_t* plan, void* dst_host, const void* src_dev, size_t bytes) {
+  check_plan(plan, "memcpy_d2h_async");
+  HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, plan->stream));
+}
+void d4est_hip_plan_synchronize(d4est_hip_plan_t* plan) {
+  check_plan(plan, "plan_synchronize");
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,332 @@
+// libd4est_hip_compat.so: the reference's own entry points for the hot path (include/d4est_hip_compat.h), implemented on the
+// C-ABI of libd4est_hip.so only -- plain C++, no HIP header: everything device-side goes through d4est_hip.h.
+//
+// Element-level shims: a cached one-element plan per (deg, deg_quad, quadrature type) with persistent pinned staging and device
+// buffers (allocated on first use, never per call); operator-level shims: the whole-mesh plan bound to the p4est pointer.
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "../../include/d4est_hip_compat.h"
+
+#define COMPAT_ABORT(...)                                       \
+  do {                                                          \
+    std::fprintf(stderr, "[D4EST_HIP_ABORT] ");                 \
+    std::fprintf(stderr, __VA_ARGS__);                          \
+    std::fprintf(stderr, " (%s:%d)\n", __FILE__, __LINE__);     \
+    std::abort();                                               \
+  } while (0)
+
+namespace {
+
+struct ElemCtx {
+  d4est_hip_plan_t* plan = nullptr;
+  int N3 = 0, Q3 = 0, N2 = 0, cap = 0;
+  double* h = nullptr;       // pinned: [in cap][out cap][geometry 10 Q3]
+  double* d_in = nullptr;    // cap
+  double* d_out = nullptr;   // 3 cap (dudr-sized outputs are not needed; 1 cap used)
+  double* d_geo = nullptr;   // 10 Q3: J | rst_xyz[3i+j]
+};
+
+std::map<std::tuple<int, int, int>, ElemCtx> g_elem;
+std::map<std::array<int, 10>, d4est_hip_transfer_t*> g_transfer;
+std::map<const void*, d4est_hip_plan_t*> g_bound;
+double* g_tr_h = nullptr;   // pinned staging of the transfer shims
+double* g_tr_d = nullptr;
+size_t g_tr_cap = 0;
+
+int quad_type_of(const d4est_quadrature_t* q) {
+  // d4est_quadrature_t begins with `d4est_quadrature_type_t quad_type` (src/Quadrature/d4est_quadrature.h:117-119)
+  if (!q) return D4EST_HIP_QUAD_LEGENDRE;
+  int t;
+  std::memcpy(&t, q, sizeof(int));
+  if (t == 0) return D4EST_HIP_QUAD_LEGENDRE;     // QUAD_TYPE_GAUSS_LEGENDRE
+  if (t == 1) return D4EST_HIP_QUAD_LOBATTO;      // QUAD_TYPE_GAUSS_LEGENDRE_LOBATTO
+  COMPAT_ABORT("quadrature type %d (compactified rules, disabled in the reference: d4est_quadrature.c:90-105) is not supported", t);
+}
+
+ElemCtx& elem_ctx(int deg, int deg_quad, int quad_type) {
+  auto key = std::make_tuple(deg, deg_quad, quad_type);
+  auto it = g_elem.find(key);
+  if (it != g_elem.end()) return it->second;
+  if (deg < 1 || deg_quad < 1) COMPAT_ABORT("element shim: deg %d / deg_quad %d", deg, deg_quad);
+  ElemCtx c;
+  int zero = 0;
+  c.plan = d4est_hip_plan_create(1, &deg, &deg_quad, &zero, &zero, quad_type);
+  c.N3 = (deg + 1) * (deg + 1) * (deg + 1);
+  c.Q3 = (deg_quad + 1) * (deg_quad + 1) * (deg_quad + 1);
+  c.N2 = (deg + 1) * (deg + 1);
+  c.cap = c.N3 > c.Q3 ? c.N3 : c.Q3;
+  c.h = (double*)d4est_hip_host_alloc(sizeof(double) * ((size_t)2 * c.cap + (size_t)10 * c.Q3));
+  c.d_in = (double*)d4est_hip_malloc(sizeof(double) * c.cap);
+  c.d_out = (double*)d4est_hip_malloc(sizeof(double) * c.cap);
+  c.d_geo = (double*)d4est_hip_malloc(sizeof(double) * (size_t)10 * c.Q3);
+  return g_elem.emplace(key, c).first->second;
+}
+
+void need_dim3(int dim, const char* who) {
+  if (dim != 3) COMPAT_ABORT("%s: dim = %d; the engine replaces the DIM = 3 (d8est) volume applies only", who, dim);
+}
+void need_volume(d4est_quadrature_object_type_t t, const char* who) {
+  if (t != QUAD_OBJECT_VOLUME) COMPAT_ABORT("%s: QUAD_OBJECT_MORTAR objects stay inside the fused face kernels; volume objects only", who);
+}
+
+void upload(ElemCtx& c, const double* src, int n) {
+  std::memcpy(c.h, src, sizeof(double) * n);
+  d4est_hip_memcpy_h2d_async(c.plan, c.d_in, c.h, sizeof(double) * n);
+}
+void download(ElemCtx& c, double* dst, int n) {
+  d4est_hip_memcpy_d2h_async(c.plan, c.h + c.cap, c.d_out, sizeof(double) * n);
+  d4est_hip_plan_synchronize(c.plan);
+  std::memcpy(dst, c.h + c.cap, sizeof(double) * n);
+}
+void upload_jacobian(ElemCtx& c, const double* jac) {
+  double* hg = c.h + 2 * (size_t)c.cap;
+  std::memcpy(hg, jac, sizeof(double) * c.Q3);
+  d4est_hip_memcpy_h2d_async(c.plan, c.d_geo, hg, sizeof(double) * c.Q3);
+  d4est_hip_plan_set_jacobian(c.plan, c.d_geo, 1);
+}
+
+d4est_hip_transfer_t* transfer_of(int hrefine, int degH, const int* degh) {
+  std::array<int, 10> key{};
+  key[0] = hrefine;
+  key[1] = degH;
+  for (int i = 0; i < 8; ++i) key[2 + i] = hrefine ? degh[i] : (i == 0 ? degh[0] : 0);
+  auto it = g_transfer.find(key);
+  if (it != g_transfer.end()) return it->second;
+  int dh[8];
+  for (int i = 0; i < 8; ++i) dh[i] = hrefine ? degh[i] : degh[0];
+  d4est_hip_transfer_t* t = d4est_hip_transfer_create(1, &hrefine, &degH, dh);
+  g_transfer[key] = t;
+  return t;
+}
+
+// coarse / fine staging of the transfer shims: one pinned and one device buffer, grown (rarely) to the largest pair seen
+void transfer_run(d4est_hip_transfer_t* t, int mode, const double* in, double* out) {
+  const size_t nc = (size_t)d4est_hip_transfer_coarse_nodes(t), nf = (size_t)d4est_hip_transfer_fine_nodes(t);
+  if (nc + nf > g_tr_cap) {
+    if (g_tr_h) { d4est_hip_host_free(g_tr_h); d4est_hip_free(g_tr_d); }
+    g_tr_cap = 2 * (nc + nf);
+    g_tr_h = (double*)d4est_hip_host_alloc(sizeof(double) * g_tr_cap);
+    g_tr_d = (double*)d4est_hip_malloc(sizeof(double) * g_tr_cap);
+  }
+  double *dc = g_tr_d, *df = g_tr_d + nc, *hc = g_tr_h, *hf = g_tr_h + nc;
+  if (mode == 0) {            // prolong: coarse -> fine
+    std::memcpy(hc, in, sizeof(double) * nc);
+    d4est_hip_memcpy_h2d(dc, hc, sizeof(double) * nc);
+    d4est_hip_transfer_prolong(t, dc, df);
+    d4est_hip_device_synchronize();
+    d4est_hip_memcpy_d2h(hf, df, sizeof(double) * nf);
+    std::memcpy(out, hf, sizeof(double) * nf);
+  } else {                    // 1: prolong-transpose, 2: L2 projection; fine -> coarse
+    std::memcpy(hf, in, sizeof(double) * nf);
+    d4est_hip_memcpy_h2d(df, hf, sizeof(double) * nf);
+    if (mode == 1) d4est_hip_transfer_restrict(t, df, dc);
+    else d4est_hip_transfer_project(t, df, dc);
+    d4est_hip_device_synchronize();
+    d4est_hip_memcpy_d2h(hc, dc, sizeof(double) * nc);
+    std::memcpy(out, hc, sizeof(double) * nc);
+  }
+}
+
+d4est_hip_plan_t* bound(const void* p4est, const char* who) {
+  auto it = g_bound.find(p4est);
+  if (it == g_bound.end() || !it->second) COMPAT_ABORT("%s: no plan bound to p4est %p (d4est_hip_compat_bind_mesh)", who, p4est);
+  return it->second;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- src/Quadrature/d4est_quadrature.c:263-382 -----------------------------------------------------------------------------
+void d4est_quadrature_apply_stiffness_matrix(d4est_operators_t*, d4est_quadrature_t* d4est_quadrature, d4est_geometry_t*, void*,
+                                             d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t, double* in,
+                                             int deg_lobatto, double* jac_quad, double* rst_xyz[3][3], int deg_quad, double* out) {
+  need_volume(object_type, "d4est_quadrature_apply_stiffness_matrix");
+  ElemCtx& c = elem_ctx(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature));
+  double* hg = c.h + 2 * (size_t)c.cap;
+  std::memcpy(hg, jac_quad, sizeof(double) * c.Q3);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) std::memcpy(hg + (size_t)(1 + 3 * i + j) * c.Q3, rst_xyz[i][j], sizeof(double) * c.Q3);
+  d4est_hip_memcpy_h2d_async(c.plan, c.d_geo, hg, sizeof(double) * (size_t)10 * c.Q3);
+  upload(c, in, c.N3);
+  d4est_hip_plan_set_geometry(c.plan, c.d_geo, c.d_geo + c.Q3, 1);
+  d4est_hip_apply_stiffness_matrix(c.plan, c.d_in, c.d_out);
+  download(c, out, c.N3);
+}
+
+// :385-477
+void d4est_quadrature_apply_mass_matrix(d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t* d4est_quadrature, void*,
+                                        d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t, double* in,
+                                        int deg_lobatto, double* jac_quad, int deg_quad, double* out) {
+  need_volume(object_type, "d4est_quadrature_apply_mass_matrix");
+  ElemCtx& c = elem_ctx(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature));
+  upload_jacobian(c, jac_quad);
+  upload(c, in, c.N3);
+  d4est_hip_apply_mass_matrix(c.plan, c.d_in, c.d_out);
+  download(c, out, c.N3);
+}
+
+// :142-213
+void d4est_quadrature_apply_galerkin_integral(d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t* d4est_quadrature, void*,
+                                              d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t,
+                                              double* in_quad, int deg_lobatto, double* jac_quad, int deg_quad, double* out) {
+  need_volume(object_type, "d4est_quadrature_apply_galerkin_integral");
+  ElemCtx& c = elem_ctx(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature));
+  upload_jacobian(c, jac_quad);
+  upload(c, in_quad, c.Q3);
+  d4est_hip_apply_galerkin_integral(c.plan, c.d_in, c.d_out);
+  download(c, out, c.N3);
+}
+
+// :966-1016
+void d4est_quadrature_interpolate(d4est_operators_t*, d4est_quadrature_t* d4est_quadrature, d4est_geometry_t*, void*,
+                                  d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t, double* u_lobatto_in,
+                                  int deg_lobatto, double* u_quad_out, int deg_quad) {
+  need_volume(object_type, "d4est_quadrature_interpolate");
+  ElemCtx& c = elem_ctx(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature));
+  upload(c, u_lobatto_in, c.N3);
+  d4est_hip_interpolate(c.plan, c.d_in, c.d_out);
+  download(c, u_quad_out, c.Q3);
+}
+
+// :1222-1331 (always Gauss-Legendre, deg_Gauss == deg_Lobatto asserted at :1233)
+void d4est_quadrature_apply_inverse_mass_matrix(d4est_operators_t*, double* in, int deg_Lobatto, double* jac_Gauss, int deg_Gauss, int dim,
+                                                double* out) {
+  need_dim3(dim, "d4est_quadrature_apply_inverse_mass_matrix");
+  ElemCtx& c = elem_ctx(deg_Lobatto, deg_Gauss, D4EST_HIP_QUAD_LEGENDRE);
+  upload_jacobian(c, jac_Gauss);
+  upload(c, in, c.N3);
+  d4est_hip_apply_inverse_mass_matrix(c.plan, c.d_in, c.d_out);
+  download(c, out, c.N3);
+}
+
+// ---- src/dGMath/d4est_operators.c -------------------------------------------------------------------------------------------
+void d4est_operators_apply_dij(d4est_operators_t*, double* in, int dim, int deg, int dir, double* out) {   // :1385-1410
+  need_dim3(dim, "d4est_operators_apply_dij");
+  ElemCtx& c = elem_ctx(deg, deg, D4EST_HIP_QUAD_LEGENDRE);
+  upload(c, in, c.N3);
+  d4est_hip_apply_dij(c.plan, c.d_in, dir, c.d_out);
+  download(c, out, c.N3);
+}
+void d4est_operators_apply_dij_transpose(d4est_operators_t*, double* in, int dim, int deg, int dir, double* out) {   // :2259-2284
+  need_dim3(dim, "d4est_operators_apply_dij_transpose");
+  ElemCtx& c = elem_ctx(deg, deg, D4EST_HIP_QUAD_LEGENDRE);
+  upload(c, in, c.N3);
+  d4est_hip_apply_dij_transpose(c.plan, c.d_in, dir, c.d_out);
+  download(c, out, c.N3);
+}
+void d4est_operators_apply_lift(d4est_operators_t*, double* in, int dim, int deg, int face, double* out) {   // :1454-1519
+  need_dim3(dim, "d4est_operators_apply_lift");
+  ElemCtx& c = elem_ctx(deg, deg, D4EST_HIP_QUAD_LEGENDRE);
+  upload(c, in, c.N2);
+  d4est_hip_apply_lift(c.plan, c.d_in, face, c.d_out);
+  download(c, out, c.N3);
+}
+void d4est_operators_apply_slicer(d4est_operators_t*, double* in, int dim, int face, int deg, double* out) {   // :1521-1582
+  need_dim3(dim, "d4est_operators_apply_slicer");
+  ElemCtx& c = elem_ctx(deg, deg, D4EST_HIP_QUAD_LEGENDRE);
+  upload(c, in, c.N3);
+  d4est_hip_apply_slicer(c.plan, c.d_in, face, c.d_out);
+  download(c, out, c.N2);
+}
+void d4est_operators_apply_mij(d4est_operators_t*, double* in, int dim, int deg, double* out) {   // :891-908
+  need_dim3(dim, "d4est_operators_apply_mij");
+  ElemCtx& c = elem_ctx(deg, deg, D4EST_HIP_QUAD_LEGENDRE);
+  upload(c, in, c.N3);
+  d4est_hip_apply_mij(c.plan, c.d_in, c.d_out);
+  download(c, out, c.N3);
+}
+void d4est_operators_apply_invmij(d4est_operators_t*, double* in, int dim, int deg, double* out) {   // :910-928
+  need_dim3(dim, "d4est_operators_apply_invmij");
+  ElemCtx& c = elem_ctx(deg, deg, D4EST_HIP_QUAD_LEGENDRE);
+  upload(c, in, c.N3);
+  d4est_hip_apply_invmij(c.plan, c.d_in, c.d_out);
+  download(c, out, c.N3);
+}
+void d4est_operators_apply_p_prolong(d4est_operators_t*, double* in, int degH, int dim, int degh, double* out) {   // :1107-1132
+  need_dim3(dim, "d4est_operators_apply_p_prolong");
+  transfer_run(transfer_of(0, degH, &degh), 0, in, out);
+}
+void d4est_operators_apply_hp_prolong(d4est_operators_t*, double* in, int degH, int dim, int* degh, double* out) {   // :1091-1105
+  need_dim3(dim, "d4est_operators_apply_hp_prolong");
+  transfer_run(transfer_of(1, degH, degh), 0, in, out);
+}
+void d4est_operators_apply_p_restrict(d4est_operators_t*, double* in, int degh, int dim, int degH, double* out) {   // :1205-1230
+  need_dim3(dim, "d4est_operators_apply_p_restrict");
+  transfer_run(transfer_of(0, degH, &degh), 2, in, out);
+}
+void d4est_operators_apply_hp_restrict(d4est_operators_t*, double* in, int* degh, int dim, int degH, double* out) {   // :1275-1297
+  need_dim3(dim, "d4est_operators_apply_hp_restrict");
+  transfer_run(transfer_of(1, degH, degh), 2, in, out);
+}
+void d4est_operators_apply_p_prolong_transpose(d4est_operators_t*, double* in, int degh, int dim, int degH, double* out) {   // :1719-1749
+  need_dim3(dim, "d4est_operators_apply_p_prolong_transpose");
+  transfer_run(transfer_of(0, degH, &degh), 1, in, out);
+}
+void d4est_operators_apply_hp_prolong_transpose(d4est_operators_t*, double* in, int* degh, int dim, int degH, double* out) {   // :1689-1717
+  need_dim3(dim, "d4est_operators_apply_hp_prolong_transpose");
+  transfer_run(transfer_of(1, degH, degh), 1, in, out);
+}
+
+// ---- operator / smoother level: the plan bound to the p4est ------------------------------------------------------------------
+void d4est_laplacian_apply_stiffness_matrix(p4est_t* p4est, d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t*, d4est_mesh_data_t*,
+                                            double* u, double* Au, int local_nodes, int which_field) {   // dGMath/d4est_laplacian.c:198-234
+  d4est_hip_plan_t* plan = bound(p4est, "d4est_laplacian_apply_stiffness_matrix");
+  if (local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("d4est_laplacian_apply_stiffness_matrix: local_nodes %d != plan's %d", local_nodes, d4est_hip_plan_local_nodes(plan));
+  d4est_hip_apply_stiffness_matrix_host(plan, u + (size_t)which_field * local_nodes, Au + (size_t)which_field * local_nodes);
+}
+
+void d4est_laplacian_apply_aij(p4est_t* p4est, d4est_ghost_t*, d4est_ghost_data_t*, d4est_elliptic_data_t* d, d4est_laplacian_flux_data_t*,
+                               d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t*, d4est_mesh_data_t*, int which_field) {   // :318-417
+  d4est_hip_plan_t* plan = bound(p4est, "d4est_laplacian_apply_aij");
+  if (!d || d->local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("d4est_laplacian_apply_aij: elliptic data does not match the bound plan");
+  const size_t off = (size_t)which_field * d->local_nodes;   // :364-366: which_field * local_nodes
+  d4est_hip_apply_aij_host(plan, d->u + off, d->Au + off);
+}
+
+void d4est_solver_multigrid_smoother_cheby_iterate_aux(p4est_t* p4est, d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t*,
+                                                       d4est_mesh_data_t*, d4est_ghost_t*, d4est_ghost_data_t*, d4est_elliptic_data_t* vecs,
+                                                       d4est_elliptic_eqns_t*, double* r, int iter, double lmin, double lmax,
+                                                       int /*print_residual_norm*/, int /*mg_level*/, int compute_residual_at_end) {
+  d4est_hip_plan_t* plan = bound(p4est, "d4est_solver_multigrid_smoother_cheby_iterate_aux");
+  if (!vecs || vecs->local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("cheby_iterate_aux: elliptic data does not match the bound plan");
+  d4est_hip_cheby_iterate_host(plan, vecs->u, vecs->rhs, vecs->Au, r, iter, lmin, lmax, compute_residual_at_end);
+}
+
+void cg_eigs(p4est_t* p4est, d4est_elliptic_data_t* vecs, d4est_elliptic_eqns_t*, d4est_ghost_t*, d4est_ghost_data_t*, d4est_operators_t*,
+             d4est_geometry_t*, d4est_quadrature_t*, d4est_mesh_data_t*, int imax, int /*print_spectral_bound_iterations*/, int use_new,
+             double* spectral_bound) {
+  d4est_hip_plan_t* plan = bound(p4est, "cg_eigs");
+  if (!vecs || vecs->local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("cg_eigs: elliptic data does not match the bound plan");
+  const double b = d4est_hip_cg_eigs_host(plan, vecs->u, vecs->rhs, vecs->Au, imax, use_new, nullptr);
+  if (spectral_bound) *spectral_bound = b;
+}
+
+void d4est_hip_compat_bind_mesh(const void* p4est, d4est_hip_plan_t* plan) {
+  if (plan) g_bound[p4est] = plan;
+  else g_bound.erase(p4est);
+}
+d4est_hip_plan_t* d4est_hip_compat_bound_plan(const void* p4est) {
+  auto it = g_bound.find(p4est);
+  return it == g_bound.end() ? nullptr : it->second;
+}
+void d4est_hip_compat_release(void) {
+  for (auto& kv : g_elem) {
+    ElemCtx& c = kv.second;
+    d4est_hip_plan_destroy(c.plan);
+    d4est_hip_host_free(c.h);
+    d4est_hip_free(c.d_in); d4est_hip_free(c.d_out); d4est_hip_free(c.d_geo);
+  }
+  g_elem.clear();
+  for (auto& kv : g_transfer) d4est_hip_transfer_destroy(kv.second);
+  g_transfer.clear();
+  if (g_tr_h) { d4est_hip_host_free(g_tr_h); d4est_hip_free(g_tr_d); g_tr_h = g_tr_d = nullptr; g_tr_cap = 0; }
+}
+
+}  // extern "C"

@@ -127,6 +127,11 @@ struct d4est_hip_plan {
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;
   size_t scratch_doubles = 0;
+
+  // host-pointer entry points (d4est_hip_*_host): persistent pinned staging (3 vectors) and device mirrors u, rhs, Au, r,
+  // allocated once on first use -- no per-call hipMalloc behind d4est's host double* API
+  double* h_stage = nullptr;
+  double* d_host[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace d4est_hip {

@@ -134,8 +134,15 @@ def reference_reorientation_is_consistent(f_m, f_p, orientation):
     (-) face is the higher-numbered one; for the remaining triples (transpose with exactly one flip, seen from the lower face: 36 of
     the 144) out(a, b) = in(flip0(b), flip1(a)) is applied where in(flip1(b), flip0(a)) would be geometric.  The reference's own
     connectivities (cubed sphere: codes 0, 1, 2, 3, 7) never produce such a pair.  The engine follows the reference either way."""
-    code = int(capi.load_library().d4est_hip_face_reorder_code(f_m, f_p, orientation))
-    return not (code in (5, 6) and f_m <= f_p)
+    return not (face_reorder_code(f_m, f_p, orientation) in (5, 6) and f_m <= f_p)
+
+
+def face_reorder_code(f_m, f_p, orientation):
+    """host-side twin of d4est_hip_face_reorder_code (dGMath/d4est_operators.c:2031-2050) for code that must not load the library
+    (test collection); tests/test_forest.py checks the three implementations (this, the library's, the oracle's) against each other"""
+    ft = expand_face_transform(min(f_m, f_p), max(f_m, f_p), orientation)
+    aligned = (ft[1] - ft[0]) * (ft[4] - ft[3]) > 0
+    return ft[6] | (ft[7] << 1) | ((0 if aligned else 1) << 2)
 
 
 def cube_rotations():

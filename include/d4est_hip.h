@@ -293,9 +293,30 @@ int d4est_hip_plan_trace_block_len_sub(const d4est_hip_plan_t* plan, int side, i
 /* deterministic device dot product; result_dev is a device double */
 void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const double* y_dev, double* result_dev);
 
-/* Host-pointer convenience for a drop-in behind d4est's host double* API: copies u to the
- * device, applies, copies Au back (PCIe-inclusive; not the measured path). */
+/* ---- host-pointer entries: the drop-in behind d4est's host double* API (SURVEY.md section 7 "hard part") -----------------------
+ * Every reference caller hands over HOST vectors.  These entries take host pointers, move the data through plan-owned
+ * persistent pinned staging and device mirrors (allocated once on first use -- no per-call hipMalloc), run the device-resident
+ * routine and copy the results back: ONE upload and ONE download per call, however many operator applies happen inside
+ * (a 15-iteration Chebyshev smoother call moves 2 vectors up and 2 down for 16 applies).  They return after the results are
+ * in the host arrays.  PCIe-inclusive: not the measured path. */
 void d4est_hip_apply_stiffness_matrix_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host);
+/* d4est_laplacian_apply_aij on host vectors (the Laplacian alone) / apply_lhs (+ the zeroth-order term, exchange hooks) */
+void d4est_hip_apply_aij_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host);
+void d4est_hip_apply_lhs_host(d4est_hip_plan_t* plan, const double* u_host, double* Au_host);
+/* d4est_hip_cheby_iterate on host vectors: u_host in/out, r_host out; Au_host (optional, may be NULL) receives the last A u */
+void d4est_hip_cheby_iterate_host(d4est_hip_plan_t* plan, double* u_host, const double* rhs_host, double* Au_host, double* r_host,
+                                  int iter, double lmin, double lmax, int compute_residual_at_end);
+/* d4est_hip_cg_eigs on host vectors: u_host in/out (advanced by the CG iterations, as in the reference) */
+double d4est_hip_cg_eigs_host(d4est_hip_plan_t* plan, double* u_host, const double* rhs_host, double* Au_host, int imax, int use_new,
+                              double* history_host);
+/* only J_quad (mass / galerkin / weighted-mass / inverse-mass kernels need no dr/dx) */
+void d4est_hip_plan_set_jacobian(d4est_hip_plan_t* plan, const double* J_quad, int on_device);
+/* pinned host memory and stream-ordered copies for C hosts that keep their own staging */
+void* d4est_hip_host_alloc(size_t bytes);
+void d4est_hip_host_free(void* ptr_host);
+void d4est_hip_memcpy_h2d_async(d4est_hip_plan_t* plan, void* dst_dev, const void* src_host, size_t bytes);
+void d4est_hip_memcpy_d2h_async(d4est_hip_plan_t* plan, void* dst_host, const void* src_dev, size_t bytes);
+void d4est_hip_plan_synchronize(d4est_hip_plan_t* plan);
 
 /* ---- hp-multigrid inter-grid transfer ---------------------------------------------------
  * The V-cycle's restriction / prolongation callbacks (src/Solver/d4est_solver_multigrid_callbacks.h:100-200, :245-330) walk the

@@ -1,0 +1,198 @@
+/* Plain C99 host that calls the hot path through the REFERENCE's OWN PROTOTYPES (include/d4est_hip_compat.h declares them exactly
+ * as src/Quadrature/d4est_quadrature.h:132-141, src/dGMath/d4est_operators.h:69-126, src/dGMath/d4est_laplacian.h:22-24,
+ * src/Solver/d4est_solver_multigrid_smoother_cheby.h:33 and src/Solver/d4est_solver_cg_eigs.h:9 do), host double* in and out, and
+ * compares every result with the CPU oracle (oracle/d4est_oracle.h, test infrastructure).  No Python, no C++, no torch.
+ *
+ * Build / run: tests/test_compat_gpu.py.  Prints one line per check; exit code 0 = all within tolerance.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "d4est_hip_compat.h"
+#include "d4est_oracle.h"
+
+static int n_fail = 0;
+
+static double lcg(unsigned long long* s) {
+  *s = *s * 6364136223846793005ULL + 1442695040888963407ULL;
+  return (double)((*s >> 11) & ((1ULL << 53) - 1)) / 9007199254740992.0;
+}
+
+static void check(const char* what, int p, const double* got, const double* ref, int n, double tol) {
+  double e = 0, s = 0;
+  for (int i = 0; i < n; i++) {
+    if (fabs(got[i] - ref[i]) > e) e = fabs(got[i] - ref[i]);
+    if (fabs(ref[i]) > s) s = fabs(ref[i]);
+  }
+  const double rel = e / (s > 0 ? s : 1);
+  printf("%-34s p=%2d  n=%6d  rel-inf %.2e %s\n", what, p, n, rel, (rel <= tol) ? "" : "FAIL");
+  if (!(rel <= tol)) n_fail++;
+}
+
+static double* vec(int n) { return (double*)calloc((size_t)(n > 0 ? n : 1), sizeof(double)); }
+
+/* a d4est_quadrature_t as the reference lays it out: the first member is the quadrature type (0 legendre, 1 lobatto) */
+typedef struct { int quad_type; void* getters[4]; void* user; void* fns[2]; } fake_quadrature_t;
+
+static void element_level(int p, int pq, int quad_type) {
+  const int N = p + 1, NQ = pq + 1, n3 = N * N * N, q3 = NQ * NQ * NQ, n2 = N * N;
+  unsigned long long seed = 1234567ULL + 31 * p + pq;
+  double *u = vec(n3), *got = vec(n3 > q3 ? n3 : q3), *ref = vec(n3 > q3 ? n3 : q3), *J = vec(q3), *fq = vec(q3);
+  double* rst[3][3];
+  const double* crst[3][3];
+  for (int i = 0; i < n3; i++) u[i] = lcg(&seed) - 0.3;
+  for (int i = 0; i < q3; i++) { J[i] = 0.5 + lcg(&seed); fq[i] = lcg(&seed) - 0.5; }
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      rst[a][b] = vec(q3);
+      for (int i = 0; i < q3; i++) rst[a][b][i] = (a == b ? 2.0 : 0.0) + 0.4 * (lcg(&seed) - 0.5);
+      crst[a][b] = rst[a][b];
+    }
+  fake_quadrature_t fq_t;
+  memset(&fq_t, 0, sizeof(fq_t));
+  fq_t.quad_type = quad_type;
+  d4est_quadrature_t* quad = (d4est_quadrature_t*)&fq_t;
+  char nm[64];
+
+  d4est_quadrature_apply_stiffness_matrix(NULL, quad, NULL, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, u, p, J, rst, pq, got);
+  oracle_quadrature_apply_stiffness_matrix(quad_type, u, p, J, crst, pq, ref);
+  snprintf(nm, sizeof nm, "apply_stiffness_matrix q%d dq%d", quad_type, pq - p); check(nm, p, got, ref, n3, 1e-12);
+  d4est_quadrature_apply_mass_matrix(NULL, NULL, quad, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, u, p, J, pq, got);
+  oracle_quadrature_apply_mass_matrix(quad_type, u, p, J, pq, ref);
+  snprintf(nm, sizeof nm, "apply_mass_matrix q%d dq%d", quad_type, pq - p); check(nm, p, got, ref, n3, 1e-12);
+  d4est_quadrature_apply_galerkin_integral(NULL, NULL, quad, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, fq, p, J, pq, got);
+  oracle_quadrature_apply_galerkin_integral(quad_type, fq, p, J, pq, ref);
+  snprintf(nm, sizeof nm, "apply_galerkin_integral q%d dq%d", quad_type, pq - p); check(nm, p, got, ref, n3, 1e-12);
+  d4est_quadrature_interpolate(NULL, quad, NULL, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, u, p, got, pq);
+  oracle_quadrature_interpolate(quad_type, u, p, ref, pq);
+  snprintf(nm, sizeof nm, "interpolate q%d dq%d", quad_type, pq - p); check(nm, p, got, ref, q3, 1e-12);
+  if (pq == p && quad_type == 0) {
+    d4est_quadrature_apply_inverse_mass_matrix(NULL, u, p, J, pq, 3, got);
+    oracle_quadrature_apply_inverse_mass_matrix(u, p, J, pq, ref);
+    check("apply_inverse_mass_matrix", p, got, ref, n3, 1e-10);
+    for (int d = 0; d < 3; d++) {
+      d4est_operators_apply_dij(NULL, u, 3, p, d, got); oracle_apply_dij(u, p, d, ref);
+      snprintf(nm, sizeof nm, "apply_dij dir %d", d); check(nm, p, got, ref, n3, 1e-12);
+      d4est_operators_apply_dij_transpose(NULL, u, 3, p, d, got); oracle_apply_dij_transpose(u, p, d, ref);
+      snprintf(nm, sizeof nm, "apply_dij_transpose dir %d", d); check(nm, p, got, ref, n3, 1e-12);
+    }
+    for (int f = 0; f < 6; f++) {
+      d4est_operators_apply_slicer(NULL, u, 3, f, p, got); oracle_apply_slicer(u, f, p, ref);
+      snprintf(nm, sizeof nm, "apply_slicer face %d", f); check(nm, p, got, ref, n2, 0.0);
+      d4est_operators_apply_lift(NULL, u, 3, p, f, got); oracle_apply_lift(u, p, f, ref);     /* first N^2 entries of u as face data */
+      snprintf(nm, sizeof nm, "apply_lift face %d", f); check(nm, p, got, ref, n3, 0.0);
+    }
+    d4est_operators_apply_mij(NULL, u, 3, p, got); oracle_apply_mij(u, p, ref); check("apply_mij", p, got, ref, n3, 1e-12);
+    d4est_operators_apply_invmij(NULL, u, 3, p, got); oracle_apply_invmij(u, p, ref); check("apply_invmij", p, got, ref, n3, 1e-10);
+    /* p- and hp-transfer between degree p (coarse) and p+1 / mixed children (fine) */
+    const int ph = p + 1, nh3 = (ph + 1) * (ph + 1) * (ph + 1);
+    double *fine = vec(8 * nh3), *gotf = vec(8 * nh3), *reff = vec(8 * nh3);
+    for (int i = 0; i < 8 * nh3; i++) fine[i] = lcg(&seed) - 0.5;
+    d4est_operators_apply_p_prolong(NULL, u, p, 3, ph, gotf); oracle_apply_p_prolong(u, p, 3, ph, reff); check("apply_p_prolong", p, gotf, reff, nh3, 1e-12);
+    d4est_operators_apply_p_restrict(NULL, fine, ph, 3, p, got); oracle_apply_p_restrict(fine, ph, 3, p, ref); check("apply_p_restrict", p, got, ref, n3, 1e-11);
+    d4est_operators_apply_p_prolong_transpose(NULL, fine, ph, 3, p, got); oracle_apply_p_prolong_transpose(fine, ph, 3, p, ref);
+    check("apply_p_prolong_transpose", p, got, ref, n3, 1e-12);
+    int degh[8], tot = 0;
+    for (int c = 0; c < 8; c++) { degh[c] = p + (c % 2); tot += (degh[c] + 1) * (degh[c] + 1) * (degh[c] + 1); }
+    d4est_operators_apply_hp_prolong(NULL, u, p, 3, degh, gotf); oracle_apply_hp_prolong(u, p, 3, degh, reff); check("apply_hp_prolong", p, gotf, reff, tot, 1e-12);
+    d4est_operators_apply_hp_restrict(NULL, fine, degh, 3, p, got); oracle_apply_hp_restrict(fine, degh, 3, p, ref); check("apply_hp_restrict", p, got, ref, n3, 1e-11);
+    d4est_operators_apply_hp_prolong_transpose(NULL, fine, degh, 3, p, got); oracle_apply_hp_prolong_transpose(fine, degh, 3, p, ref);
+    check("apply_hp_prolong_transpose", p, got, ref, n3, 1e-12);
+    free(fine); free(gotf); free(reff);
+  }
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) free(rst[a][b]);
+  free(u); free(got); free(ref); free(J); free(fq);
+}
+
+/* level-1 brick [0,1]^3, 8 elements in Morton order, degree p: the operator-level entries through a plan bound to a "p4est" */
+static void operator_level(int p) {
+  const int ne = 8, N = p + 1, n3 = N * N * N, n2 = N * N, ln = ne * n3;
+  const double h = 0.5;
+  int deg[8], degq[8], ns[8], qs[8];
+  for (int e = 0; e < ne; e++) { deg[e] = degq[e] = p; ns[e] = qs[e] = e * n3; }
+  /* sides: element e has integer coordinates (e&1, e>>1&1, e>>2&1) */
+  int side_nbr[48], side_nbr_face[48], side_reorder[48], side_mortar_stride[48], side_bndry_stride[48];
+  int total_mortar = 0, total_bndry = 0;
+  for (int e = 0; e < ne; e++)
+    for (int f = 0; f < 6; f++) {
+      const int s = 6 * e + f, d = f / 2, pos = f % 2, c = (e >> d) & 1;
+      side_nbr_face[s] = f ^ 1; side_reorder[s] = 0;
+      side_nbr[s] = (c == pos) ? -1 : (e ^ (1 << d));
+      side_mortar_stride[s] = total_mortar; total_mortar += n2;
+      side_bndry_stride[s] = total_bndry; if (side_nbr[s] == -1) total_bndry += n2;
+    }
+  /* geometric factors, reference layout (affine brick) */
+  double *J = vec(ln), *rst = vec(9 * ln);
+  for (int i = 0; i < ln; i++) { J[i] = h * h * h / 8; for (int a = 0; a < 3; a++) rst[(size_t)(3 * a + a) * ln + i] = 2 / h; }
+  double *sj = vec(total_mortar), *nrm = vec(3 * total_mortar), *dm = vec(9 * total_mortar), *hm = vec(total_mortar);
+  for (int s = 0; s < 48; s++) {
+    const int S = side_mortar_stride[s], f = s % 6, d = f / 2;
+    for (int k = 0; k < n2; k++) {
+      sj[S + k] = h * h / 4; hm[S + k] = h / 2;
+      nrm[3 * S + d * n2 + k] = (f % 2) ? 1.0 : -1.0;
+      for (int a = 0; a < 3; a++) dm[9 * S + (a + 3 * a) * n2 + k] = 2 / h;
+    }
+  }
+  d4est_hip_plan_t* plan = d4est_hip_plan_create(ne, deg, degq, ns, qs, D4EST_HIP_QUAD_LEGENDRE);
+  d4est_hip_plan_set_geometry(plan, J, rst, 0);
+  d4est_hip_plan_set_faces(plan, side_nbr, side_nbr_face, side_reorder, side_mortar_stride, side_bndry_stride, total_mortar, total_bndry, 0, NULL, NULL);
+  d4est_hip_plan_set_sipg(plan, 10.0, 0);
+  d4est_hip_plan_set_mortar_geometry(plan, sj, nrm, dm, dm, hm, hm, 0);
+  int fake_p4est_storage = 0;
+  p4est_t* p4est = (p4est_t*)&fake_p4est_storage;       /* the shims use the pointer as a key only */
+  d4est_hip_compat_bind_mesh(p4est, plan);
+
+  oracle_set_aij_operator(0, ne, deg, degq, ns, qs, ln, ln, J, rst, side_nbr, side_nbr_face, side_reorder, side_mortar_stride,
+                          side_bndry_stride, sj, nrm, dm, dm, hm, hm, 10.0, 0, 1);
+  unsigned long long seed = 99;
+  double *u = vec(ln), *rhs = vec(ln), *Au = vec(ln), *r = vec(ln), *ref = vec(ln), *ur = vec(ln), *Aur = vec(ln), *rr = vec(ln);
+  for (int i = 0; i < ln; i++) { u[i] = lcg(&seed); rhs[i] = lcg(&seed) - 0.5; }
+
+  d4est_laplacian_apply_stiffness_matrix(p4est, NULL, NULL, NULL, NULL, u, Au, ln, 0);
+  oracle_laplacian_apply_stiffness_matrix(0, ne, deg, degq, ns, qs, ln, J, rst, u, ref, 1);
+  check("d4est_laplacian_apply_stiffness_matrix", p, Au, ref, ln, 1e-12);
+
+  d4est_elliptic_data_t vecs;
+  memset(&vecs, 0, sizeof vecs);
+  vecs.local_nodes = ln; vecs.num_of_fields = 1; vecs.u = u; vecs.Au = Au; vecs.rhs = rhs;
+  d4est_laplacian_apply_aij(p4est, NULL, NULL, &vecs, NULL, NULL, NULL, NULL, NULL, 0);
+  oracle_apply_lhs(u, ref);
+  check("d4est_laplacian_apply_aij", p, Au, ref, ln, 1e-12);
+
+  double bound = 0, bound_ref = 0;
+  memcpy(ur, u, sizeof(double) * ln);
+  cg_eigs(p4est, &vecs, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 8, 0, 1, &bound);
+  oracle_cg_eigs(ur, rhs, Aur, 8, 1, &bound_ref);
+  check("cg_eigs: spectral bound", p, &bound, &bound_ref, 1, 1e-10);
+  check("cg_eigs: u after the CG iterations", p, u, ur, ln, 1e-10);
+
+  d4est_solver_multigrid_smoother_cheby_iterate_aux(p4est, NULL, NULL, NULL, NULL, NULL, NULL, &vecs, NULL, r, 7, bound_ref / 30, bound_ref, 0, 0, 1);
+  oracle_cheby_iterate_aux(ur, rhs, Aur, rr, 7, bound_ref / 30, bound_ref, 1);
+  check("cheby_iterate_aux: u", p, u, ur, ln, 1e-11);
+  check("cheby_iterate_aux: r", p, r, rr, ln, 1e-10);
+  check("cheby_iterate_aux: Au", p, Au, Aur, ln, 1e-10);
+
+  d4est_hip_compat_bind_mesh(p4est, NULL);
+  d4est_hip_plan_destroy(plan);
+  free(J); free(rst); free(sj); free(nrm); free(dm); free(hm);
+  free(u); free(rhs); free(Au); free(r); free(ref); free(ur); free(Aur); free(rr);
+}
+
+int main(void) {
+  if (d4est_hip_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 77; }
+  const int ps[] = {2, 3, 7, 8, 11};
+  for (int i = 0; i < 5; i++) {
+    element_level(ps[i], ps[i], 0);
+    element_level(ps[i], ps[i] + 1, 0);
+    element_level(ps[i], ps[i], 1);
+  }
+  /* the cached contexts are reused: a second pass must allocate nothing and give the same answers */
+  element_level(7, 7, 0);
+  operator_level(3);
+  operator_level(7);
+  d4est_hip_compat_release();
+  printf(n_fail ? "MISMATCH (%d)\n" : "ok\n", n_fail);
+  return n_fail ? 1 : 0;
+}
