@@ -21,6 +21,7 @@ SOURCES = [
     "d4est_hip_solver.hip",
     "d4est_hip_transfer.hip",
     "d4est_hip_schwarz.hip",
+    "d4est_hip_comm.hip",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
@@ -65,7 +66,7 @@ def build_library(force=False, verbose=True, jobs=None):
             sys.stderr.write("hipcc failed on %s\n%s\n" % (src, out.decode(errors="replace")))
     if failed:
         raise RuntimeError("hipcc compilation failed")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

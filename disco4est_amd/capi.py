@@ -100,6 +100,19 @@ SIGNATURES = {
     "d4est_hip_plan_ghost_trace_offset": (ctypes.c_longlong, [_vp, ctypes.c_int]),
     "d4est_hip_plan_trace_block_len": (ctypes.c_int, [_vp, ctypes.c_int]),
     "d4est_hip_vec_dot": (None, [_vp, ctypes.c_int, _vp, _vp, _vp]),
+    "d4est_hip_comm_unique_id_bytes": (ctypes.c_int, []),
+    "d4est_hip_comm_get_unique_id": (None, [_vp]),
+    "d4est_hip_comm_create": (_vp, [_vp, ctypes.c_int, ctypes.c_int]),
+    "d4est_hip_comm_destroy": (None, [_vp]),
+    "d4est_hip_comm_rank": (ctypes.c_int, [_vp]),
+    "d4est_hip_comm_size": (ctypes.c_int, [_vp]),
+    "d4est_hip_plan_set_rccl_exchange": (_vp, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "d4est_hip_rccl_exchange_destroy": (None, [_vp]),
+    "d4est_hip_rccl_exchange_count": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_rccl_exchange_send_doubles": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_rccl_exchange_recv_doubles": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_comm_sendrecv": (None, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "d4est_hip_comm_allreduce_sum": (None, [_vp, _vp, _vp, ctypes.c_int]),
     "d4est_hip_apply_stiffness_matrix_host": (None, [_vp, _vp, _vp]),
     "d4est_hip_apply_aij_host": (None, [_vp, _vp, _vp]),
     "d4est_hip_apply_lhs_host": (None, [_vp, _vp, _vp]),

@@ -739,7 +739,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // which share the same lines of u (trace = first / last entry, normal derivative = row 0 / row N-1 of D)
 __global__ __launch_bounds__(192) void trace_mfma_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
                                                          const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
-                                                         const double* __restrict__ face_ops, int n_elem, int diag) {
+                                                         const double* __restrict__ face_ops, int n_elem) {
   constexpr int LDM = 18;                 // padded row length of the 8 x 16 re-shaping buffer (<= 2-way bank conflicts)
   constexpr int UJ = 9, UK = 72;          // padded strides of the LDS copy of u: conflict-free face reads in all three directions
   constexpr int TPB = 192;
@@ -816,21 +816,6 @@ __global__ __launch_bounds__(192) void trace_mfma_kernel(const double* __restric
     }
     cur_N = N;
     __syncthreads();
-    if (diag == 1) {  // DIAGNOSTIC (timing only): memory skeleton of the kernel, no arithmetic
-#pragma unroll
-      for (int s_ = 0; s_ < 2; ++s_) {
-        const SideDesc& d = s_ ? d1 : d0;
-        if (lo < d.NQ && hi < d.NQ) {
-          double* out = qtrace + d.qoff + lo + d.NQ * hi;
-          const int T = d.NQ * d.NQ;
-          const double v = s_u[lane];
-          out[0] = v; out[T] = v; out[2 * T] = v; out[3 * T] = v;
-        }
-      }
-      __syncthreads();
-      el = el_next; d0 = d0_next; d1 = d1_next;
-      continue;
-    }
     // ---- nodal traces and normal derivatives of both faces at lane (a = lo, b = hi): one pass over the line of u
     {
       const int sn = (dir == 0) ? 1 : (dir == 1 ? UJ : UK);
@@ -2386,10 +2371,9 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     debug_occupancy_once();
-    static const int trace_diag = std::getenv("D4EST_HIP_TRACE_DIAG") ? std::atoi(std::getenv("D4EST_HIP_TRACE_DIAG")) : 0;
     if (mfma)   // auto: MFMA form of the two interpolation passes
       hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
-                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, trace_diag);
+                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n);
     else
       hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
                          (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, fh.uni);

@@ -1106,239 +1106,6 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave2_kernel(
   }
 }
 
-// KH > 0: the first KH quadrature planes (kq < KH) of all six metric components are REQUESTED AT ENTRY, right behind the
-// loads of u (6*KH doubles per thread stay in flight / in VGPRs during the forward contractions), so the metric stream
-// starts at t = 0 instead of after the forward phase; the remaining planes are loaded at the quadrature stage.
-// ns_stride >= 0: the bucket's strides are affine (ns = ns0 + ei*ns_stride, the normal case of a uniform-degree bucket),
-// which removes the dependent list load in front of the first load of u.
-template <int N, int NQ, int KH, int G>
-__global__ __launch_bounds__(64, 4) void stiffness_wave3_kernel(
-    const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
-    const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
-    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT, int ns0, int ns_stride,
-    int qs0, int qs_stride) {
-  using C = WaveCfg<N, NQ>;
-  constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
-  constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-
-  const int tid = threadIdx.x;
-  const int slot = tid / PL;
-  const int te = tid - slot * PL;
-  const int a = te % NQ, b = te / NQ;
-  const int ei = blockIdx.x * C::EPB + slot;
-  const bool active = (slot < C::EPB) && (ei < n_bucket);
-  double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
-  double* R1 = R0 + FS;
-  int ns = 0, qs = 0;
-  double mp[6][KH > 0 ? KH : 1];
-  if (active) {
-    if (ns_stride >= 0) {
-      ns = ns0 + ei * ns_stride;
-      qs = qs0 + ei * qs_stride;
-    } else {
-      ns = ns_list[ei];
-      qs = qs_list[ei];
-    }
-    if (C::EPB == 1) {  // one element per wave: the strides are wave-uniform -> scalar base addresses
-      ns = __builtin_amdgcn_readfirstlane(ns);
-      qs = __builtin_amdgcn_readfirstlane(qs);
-    }
-    double ureg[(N3 + PL - 1) / PL];
-#pragma unroll
-    for (int idx = te, c = 0; idx < N3; idx += PL, ++c) ureg[c] = u[ns + idx];
-    if (KH > 0) {
-      const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
-#pragma unroll
-      for (int c = 0; c < 6; ++c)
-#pragma unroll
-        for (int kq = 0; kq < KH; ++kq) mp[c][kq] = m[c * NQ3 + NQ * NQ * kq];
-    }
-#pragma unroll
-    for (int idx = te, c = 0; idx < N3; idx += PL, ++c) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      R0[i + PN * (j + N * k)] = ureg[c];
-    }
-  }
-  __syncthreads();
-
-  // ---- S1: thread (j=a, k=b)
-  {
-    double x[N], br[NQ], gr[NQ];
-    const bool on = active && a < N && b < N;
-    if (on) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-      contract_pair<N, NQ, false, false>(BopT, x, br, GopT, x, gr);
-    }
-    __syncthreads();
-    if (on) {
-#pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) {
-        R0[a + PN * (iq + NQ * b)] = br[iq];
-        R1[a + PN * (iq + NQ * b)] = gr[iq];
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- S2 (thread (iq=a, k=b)) and S3 (thread (iq=a, jq=b))
-  double gr[NQ], gs[NQ], gt[NQ];
-  {
-    double x1[N], x2[N], t1[NQ], t2[NQ], t3[NQ];
-    const bool on2 = active && b < N;
-    if (on2) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        x1[j] = R0[j + PN * (a + NQ * b)];  // B_r u
-        x2[j] = R1[j + PN * (a + NQ * b)];  // G_r u
-      }
-      contract_pair<N, NQ, false, false>(BopT, x2, t1, GopT, x1, t2);  // B_s G_r u | G_s B_r u
-      contract_single<N, NQ, false>(BopT, x1, t3);                      // B_s B_r u
-    }
-    __syncthreads();
-    if (on2) {
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) {  // [jq][iq][k]
-        R0[b + PN * (a + NQ * jq)] = t1[jq];
-        R1[b + PN * (a + NQ * jq)] = t2[jq];
-      }
-    }
-    __syncthreads();
-    if (active) {
-      double y1[N], y2[N];
-#pragma unroll
-      for (int k = 0; k < N; ++k) {
-        y1[k] = R0[k + PN * (a + NQ * b)];
-        y2[k] = R1[k + PN * (a + NQ * b)];
-      }
-      contract_pair<N, NQ, false, false>(BopT, y1, gr, BopT, y2, gs);
-    }
-    __syncthreads();
-    if (on2) {
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t3[jq];
-    }
-    __syncthreads();
-    if (active) {
-      double y3[N];
-#pragma unroll
-      for (int k = 0; k < N; ++k) y3[k] = R0[k + PN * (a + NQ * b)];
-      contract_single<N, NQ, false>(GopT, y3, gt);
-    }
-  }
-
-  // ---- quadrature-point stage: the planes requested at entry first, then the rest in batches of G planes
-  // (6*G loads in flight per batch; the batch is issued as a whole before its first use)
-  if (active) {
-    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
-#pragma unroll
-    for (int kq = 0; kq < KH; ++kq) {
-      const double r = gr[kq], s = gs[kq], t = gt[kq];
-      gr[kq] = mp[0][kq] * r + mp[1][kq] * s + mp[2][kq] * t;
-      gs[kq] = mp[1][kq] * r + mp[3][kq] * s + mp[4][kq] * t;
-      gt[kq] = mp[2][kq] * r + mp[4][kq] * s + mp[5][kq] * t;
-    }
-#pragma unroll
-    for (int k0 = KH; k0 < NQ; k0 += G) {
-      double mq[6][G];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int c = 0; c < 6; ++c)
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-          if (k0 + g < NQ) mq[c][g] = m[c * NQ3 + NQ * NQ * (k0 + g)];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const int kq = k0 + g;
-        if (kq < NQ) {
-          const double r = gr[kq], s = gs[kq], t = gt[kq];
-          gr[kq] = mq[0][g] * r + mq[1][g] * s + mq[2][g] * t;
-          gs[kq] = mq[1][g] * r + mq[3][g] * s + mq[4][g] * t;
-          gt[kq] = mq[2][g] * r + mq[4][g] * s + mq[5][g] * t;
-        }
-      }
-    }
-  }
-
-  // ---- S5 (registers) / S6 (thread (iq=a, k=b))
-  {
-    double ca[N], cb[N], cc[N], ar[N], bs[N];
-    const bool on6 = active && b < N;
-    if (active) {
-      contract_pair<NQ, N, false, false>(Bop, gr, ca, Bop, gs, cb);
-      contract_single<NQ, N, false>(Gop, gt, cc);
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < N; ++k) {  // [k][iq][jq]
-        R0[b + PQ * (a + NQ * k)] = ca[k];
-        R1[b + PQ * (a + NQ * k)] = cb[k];
-      }
-    }
-    __syncthreads();
-    if (on6) {
-      double x[NQ], y[NQ];
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) {
-        x[jq] = R0[jq + PQ * (a + NQ * b)];
-        y[jq] = R1[jq + PQ * (a + NQ * b)];
-      }
-      contract_pair<NQ, N, false, false>(Bop, x, ar, Gop, y, bs);
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = cc[k];
-    }
-    __syncthreads();
-    if (on6) {
-      double z[NQ];
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) z[jq] = R0[jq + PQ * (a + NQ * b)];
-      contract_single<NQ, N, true>(Bop, z, bs);
-    }
-    __syncthreads();
-    if (on6) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) {  // [k][j][iq]
-        R0[a + PQ * (j + N * b)] = ar[j];
-        R1[a + PQ * (j + N * b)] = bs[j];
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- S7: thread (j=a, k=b)
-  {
-    double x[NQ], y[NQ], o[N], o2[N];
-    const bool on = active && a < N && b < N;
-    if (on) {
-#pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) {
-        x[iq] = R0[iq + PQ * (a + N * b)];
-        y[iq] = R1[iq + PQ * (a + N * b)];
-      }
-      contract_pair<NQ, N, false, false>(Gop, x, o, Bop, y, o2);
-    }
-    __syncthreads();
-    if (on) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = o[i] + o2[i];
-    }
-  }
-  __syncthreads();
-  if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      Au[ns + idx] = R0[i + PN * (j + N * k)];
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // EVEN-ODD single-wavefront kernel.  The 1-D operators on symmetric node sets are centro-symmetric
 // (B: B[R-1-r][C-1-c] = B[r][c]) or centro-antisymmetric (G = B D).  With xe = x[c] + x[C-1-c], xo = x[c] - x[C-1-c]
@@ -1686,237 +1453,6 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave_eo_kernel(
       Au[ns + idx] = R0[i + PN * (j + N * k)];
     }
   }
-}
-
-// ABL != 0 are timing-only ablations (wrong results): 1 = no backward contractions, 2 = no forward contractions
-template <int N, int NQ, int ABL>
-__global__ __launch_bounds__(64, 4) void stiffness_wave2_abl_kernel(
-    const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
-    const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
-    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT, int stagger) {
-  if (stagger > 0 && ((blockIdx.x >> 8) & 1)) {  // optional phase stagger, see stiffness_wave_kernel
-    for (int s_ = 0; s_ < stagger; ++s_) __builtin_amdgcn_s_sleep(16);
-  }
-  using C = WaveCfg<N, NQ>;
-  constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
-  constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-
-  const int tid = threadIdx.x;
-  const int slot = tid / PL;
-  const int te = tid - slot * PL;
-  const int a = te % NQ, b = te / NQ;
-  const int ei = blockIdx.x * C::EPB + slot;
-  const bool active = (slot < C::EPB) && (ei < n_bucket);
-  double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
-  double* R1 = R0 + FS;
-  int ns = 0, qs = 0;
-  if (active) {
-    ns = ns_list[ei];
-    qs = qs_list[ei];
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      R0[i + PN * (j + N * k)] = u[ns + idx];
-    }
-  }
-  __syncthreads();
-
-  if (ABL != 2) {
-  // ---- S1: thread (j=a, k=b)
-  {
-    double x[N], br[NQ], gr[NQ];
-    const bool on = active && a < N && b < N;
-    if (on) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-      contract_pair<N, NQ, false, false>(BopT, x, br, GopT, x, gr);
-    }
-    __syncthreads();
-    if (on) {
-#pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) {
-        R0[a + PN * (iq + NQ * b)] = br[iq];
-        R1[a + PN * (iq + NQ * b)] = gr[iq];
-      }
-    }
-  }
-  __syncthreads();
-
-  }
-  // ---- S2 (thread (iq=a, k=b)) and S3 (thread (iq=a, jq=b))
-  double gr[NQ], gs[NQ], gt[NQ];
-  if (ABL == 2) {
-#pragma unroll
-    for (int kq = 0; kq < NQ; ++kq) { gr[kq] = R0[kq + te]; gs[kq] = gr[kq] * 2; gt[kq] = gr[kq] * 3; }
-  } else {
-    double x1[N], x2[N], t1[NQ], t2[NQ], t3[NQ];
-    const bool on2 = active && b < N;
-    if (on2) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        x1[j] = R0[j + PN * (a + NQ * b)];  // B_r u
-        x2[j] = R1[j + PN * (a + NQ * b)];  // G_r u
-      }
-      contract_pair<N, NQ, false, false>(BopT, x2, t1, GopT, x1, t2);  // B_s G_r u | G_s B_r u
-      contract_single<N, NQ, false>(BopT, x1, t3);                      // B_s B_r u
-    }
-    __syncthreads();
-    if (on2) {
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) {  // [jq][iq][k]
-        R0[b + PN * (a + NQ * jq)] = t1[jq];
-        R1[b + PN * (a + NQ * jq)] = t2[jq];
-      }
-    }
-    __syncthreads();
-    if (active) {
-      double y1[N], y2[N];
-#pragma unroll
-      for (int k = 0; k < N; ++k) {
-        y1[k] = R0[k + PN * (a + NQ * b)];
-        y2[k] = R1[k + PN * (a + NQ * b)];
-      }
-      contract_pair<N, NQ, false, false>(BopT, y1, gr, BopT, y2, gs);
-    }
-    __syncthreads();
-    if (on2) {
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t3[jq];
-    }
-    __syncthreads();
-    if (active) {
-      double y3[N];
-#pragma unroll
-      for (int k = 0; k < N; ++k) y3[k] = R0[k + PN * (a + NQ * b)];
-      contract_single<N, NQ, false>(GopT, y3, gt);
-    }
-  }
-
-  // ---- quadrature-point stage
-  if (active) {
-    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
-#pragma unroll
-    for (int kq = 0; kq < NQ; ++kq) {
-      const int q = NQ * NQ * kq;
-      const double m0 = m[q], m1 = m[NQ3 + q], m2 = m[2 * NQ3 + q], m3 = m[3 * NQ3 + q], m4 = m[4 * NQ3 + q], m5 = m[5 * NQ3 + q];
-      const double r = gr[kq], s = gs[kq], t = gt[kq];
-      gr[kq] = m0 * r + m1 * s + m2 * t;
-      gs[kq] = m1 * r + m3 * s + m4 * t;
-      gt[kq] = m2 * r + m4 * s + m5 * t;
-    }
-  }
-
-  if (ABL == 1) {
-    if (active) {
-      double acc = 0.0;
-#pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) acc += gr[kq] + gs[kq] + gt[kq];
-#pragma unroll
-      for (int idx = te; idx < N3; idx += PL) Au[ns + idx] = acc;
-    }
-    return;
-  }
-  // ---- S5 (registers) / S6 (thread (iq=a, k=b))
-  {
-    double ca[N], cb[N], cc[N], ar[N], bs[N];
-    const bool on6 = active && b < N;
-    if (active) {
-      contract_pair<NQ, N, false, false>(Bop, gr, ca, Bop, gs, cb);
-      contract_single<NQ, N, false>(Gop, gt, cc);
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < N; ++k) {  // [k][iq][jq]
-        R0[b + PQ * (a + NQ * k)] = ca[k];
-        R1[b + PQ * (a + NQ * k)] = cb[k];
-      }
-    }
-    __syncthreads();
-    if (on6) {
-      double x[NQ], y[NQ];
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) {
-        x[jq] = R0[jq + PQ * (a + NQ * b)];
-        y[jq] = R1[jq + PQ * (a + NQ * b)];
-      }
-      contract_pair<NQ, N, false, false>(Bop, x, ar, Gop, y, bs);
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = cc[k];
-    }
-    __syncthreads();
-    if (on6) {
-      double z[NQ];
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) z[jq] = R0[jq + PQ * (a + NQ * b)];
-      contract_single<NQ, N, true>(Bop, z, bs);
-    }
-    __syncthreads();
-    if (on6) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) {  // [k][j][iq]
-        R0[a + PQ * (j + N * b)] = ar[j];
-        R1[a + PQ * (j + N * b)] = bs[j];
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- S7: thread (j=a, k=b)
-  {
-    double x[NQ], y[NQ], o[N], o2[N];
-    const bool on = active && a < N && b < N;
-    if (on) {
-#pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) {
-        x[iq] = R0[iq + PQ * (a + N * b)];
-        y[iq] = R1[iq + PQ * (a + N * b)];
-      }
-      contract_pair<NQ, N, false, false>(Gop, x, o, Bop, y, o2);
-    }
-    __syncthreads();
-    if (on) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = o[i] + o2[i];
-    }
-  }
-  __syncthreads();
-  if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      Au[ns + idx] = R0[i + PN * (j + N * k)];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// DIAGNOSTIC (tuning value 9, never selected automatically; results are NOT the stiffness apply):
-// the stiffness kernel's exact memory access pattern with the arithmetic removed -- the streaming floor
-// of "read u, read 6 metric entries per node, write Au" for this thread mapping.
-// ---------------------------------------------------------------------------
-template <int N, int NQ>
-__global__ __launch_bounds__(64, 4) void stiffness_stream_only_kernel(const double* __restrict__ u, double* __restrict__ Au,
-                                                                      const double* __restrict__ metric,
-                                                                      const int* __restrict__ ns_list,
-                                                                      const int* __restrict__ qs_list, int n_bucket) {
-  constexpr int PL = NQ * NQ, EPB = 64 / PL, N3 = N * N * N, NQ3 = NQ * NQ * NQ;
-  const int slot = threadIdx.x / PL, te = threadIdx.x % PL;
-  const int ei = blockIdx.x * EPB + slot;
-  if (slot >= EPB || ei >= n_bucket) return;
-  const int ns = ns_list[ei], qs = qs_list[ei];
-  double acc = 0.0;
-  const double* __restrict__ m = metric + (size_t)6 * qs + te;
-#pragma unroll
-  for (int kq = 0; kq < NQ; ++kq)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) acc += m[c * NQ3 + PL * kq];
-#pragma unroll
-  for (int idx = te; idx < N3; idx += PL) Au[ns + idx] = u[ns + idx] + acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -2366,33 +1902,11 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
         hipLaunchKernelGGL((stiffness_wave_eo_kernel<N, NQ>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
                            plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBf, bk.d_EGf,
                            bk.d_EBb, bk.d_EGb, bk.ns0, bk.ns_stride, bk.qs0, bk.qs_stride);
-    } else if (tw_ == 4 || tw_ == 5 || tw_ == 6 || tw_ == 10) {
-      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave3_kernel<%d,%d> variant %d", N, NQ, tw_);
-#define W3(KH_, G_)                                                                                                              \
-  hipLaunchKernelGGL((stiffness_wave3_kernel<N, NQ, (KH_ < NQ ? KH_ : 0), G_>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric, \
-                     plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, \
-                     bk.d_GT, bk.ns0, bk.ns_stride, bk.qs0, bk.qs_stride)
-      if (tw_ == 4) W3(2, 6);
-      else if (tw_ == 5) W3(2, 3);
-      else if (tw_ == 6) W3(0, 4);
-      else W3(0, 2);
-#undef W3
     } else if (tw_ == 3 || tw_ < 0) {
       std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave2_kernel<%d,%d>", N, NQ);
       hipLaunchKernelGGL((stiffness_wave2_kernel<N, NQ>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
                          plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT,
                          bk.d_GT, stagger);
-    } else if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 7 || plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 8) {
-      if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 7)
-        hipLaunchKernelGGL((stiffness_wave2_abl_kernel<N, NQ, 1>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
-                           plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, bk.d_GT, 0);
-      else
-        hipLaunchKernelGGL((stiffness_wave2_abl_kernel<N, NQ, 2>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
-                           plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G, bk.d_BT, bk.d_GT, 0);
-    } else if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 9) {
-      std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "DIAGNOSTIC stream-only");
-      hipLaunchKernelGGL((stiffness_stream_only_kernel<N, NQ>), dim3(grid), dim3(64), 0, plan->stream, u, Au, plan->d_metric,
-                         plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem);
     } else if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE] == 2 && N % 2 == 0 && NQ % 2 == 0) {
       std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_pair_kernel<%d,%d>", N, NQ);
       if constexpr (N % 2 == 0 && NQ % 2 == 0)

@@ -292,3 +292,88 @@ def attach(plan, mesh, sides, parts, transport, device):
 
     plan.set_comm(exchange if n_ghost > 0 else None, allreduce if hasattr(transport, "allreduce_sum") else None)
     return ex
+
+
+# ---- RCCL transport in C (csrc/d4est_hip_comm.hip): no Python in the per-apply path --------------------------------------------
+class RcclComm:
+    """One RCCL communicator of the library (d4est_hip_comm_create = ncclCommInitRank), one rank per GPU.  The unique id is created on
+    rank 0 and handed to the other ranks by ``broadcast(bytes or None) -> bytes`` (torch.distributed here; MPI_Bcast in a d4est build)."""
+
+    def __init__(self, rank, world, broadcast=None):
+        import ctypes
+        from . import capi
+        self.lib = capi.load_library()
+        n = self.lib.d4est_hip_comm_unique_id_bytes()
+        buf = ctypes.create_string_buffer(n)
+        if rank == 0:
+            self.lib.d4est_hip_comm_get_unique_id(buf)
+        uid = bytes(buf.raw)
+        if world > 1:
+            if broadcast is None:
+                broadcast = torch_broadcast_bytes
+            uid = broadcast(uid if rank == 0 else None)
+        self._uid = ctypes.create_string_buffer(uid, n)
+        self.rank, self.world = rank, world
+        self.handle = self.lib.d4est_hip_comm_create(self._uid, rank, world)
+
+    def destroy(self):
+        if self.handle:
+            self.lib.d4est_hip_comm_destroy(self.handle)
+            self.handle = None
+
+
+def torch_broadcast_bytes(payload):
+    """broadcast a bytes object from rank 0 over the default torch.distributed group"""
+    import torch.distributed as dist
+    box = [payload]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def flatten_schedule(sched):
+    """per-peer block lists of a TraceSchedule / ElementSchedule as the flat arrays d4est_hip_plan_set_rccl_exchange takes"""
+    peers = np.asarray(sched.peers, dtype=np.int32)
+    sf, rf = [0], [0]
+    so, sl, ro, rl = [], [], [], []
+    for p in sched.peers:
+        so.append(sched.send[p][:, 0]); sl.append(sched.send[p][:, 1])
+        ro.append(sched.recv[p][:, 0]); rl.append(sched.recv[p][:, 1])
+        sf.append(sf[-1] + len(sched.send[p])); rf.append(rf[-1] + len(sched.recv[p]))
+    cat = lambda a, dt: np.ascontiguousarray(np.concatenate(a) if a else np.zeros(0), dtype=dt)
+    return (peers, np.asarray(sf, dtype=np.int32), cat(so, np.int64), cat(sl, np.int32),
+            np.asarray(rf, dtype=np.int32), cat(ro, np.int64), cat(rl, np.int32))
+
+
+def schedule_summary(sched):
+    """{peer: (doubles sent, doubles received)}: what the two ends of every pair must agree on before the first exchange"""
+    return {int(p): (int(sched.send_len[p]), int(sched.recv_len[p])) for p in sched.peers}
+
+
+def check_schedules_match(summaries):
+    """summaries[r] = schedule_summary of rank r (all-gathered): rank a sends to b exactly what b expects from a.  A mismatch would
+    hang the grouped ncclSend / ncclRecv round, so it is checked on the host before the transport is wired."""
+    for a, sa in enumerate(summaries):
+        for b, (sent, recvd) in sa.items():
+            back = summaries[b].get(a)
+            if back is None or back[1] != sent or back[0] != recvd:
+                return False, "rank %d <-> %d: %r vs %r" % (a, b, (sent, recvd), back)
+    return True, ""
+
+
+def attach_rccl(plan, mesh, sides, parts, comm):
+    """Wire a Plan (faces set) to the RCCL transport: d4est_hip_plan_set_rccl_exchange.  Returns the exchange handle wrapper."""
+    import ctypes
+    sched = plan_schedule(plan, mesh, sides, parts)
+    peers, sf, so, sl, rf, ro, rl = flatten_schedule(sched)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    h = plan.lib.d4est_hip_plan_set_rccl_exchange(plan.handle, comm.handle, len(peers), vp(peers), vp(sf), vp(so), vp(sl), vp(rf), vp(ro), vp(rl))
+
+    class _Exchange:
+        pass
+    x = _Exchange()
+    x.handle, x.schedule, x.lib = h, sched, plan.lib
+    x.count = lambda: plan.lib.d4est_hip_rccl_exchange_count(h)
+    x.send_doubles = plan.lib.d4est_hip_rccl_exchange_send_doubles(h)
+    x.recv_doubles = plan.lib.d4est_hip_rccl_exchange_recv_doubles(h)
+    x.destroy = lambda: plan.lib.d4est_hip_rccl_exchange_destroy(h)
+    return x

@@ -76,7 +76,7 @@ void d4est_hip_plan_set_stream(d4est_hip_plan_t* plan, void* hip_stream);
 /* Performance knobs (never change results beyond fp64 re-association).  Value -1 (default) = auto. */
 enum d4est_hip_tuning_key {
   D4EST_HIP_TUNE_STIFFNESS_PREFETCH = 0, /* 1: request the metric at kernel entry (deg_quad <= 7), 0: at the point of use */
-  D4EST_HIP_TUNE_STIFFNESS_WAVE = 1,     /* where (deg_quad+1)^2 <= 64: 0 multi-buffer kernel, 1 single-wavefront kernel, 2 two-wavefront kernel with metric prefetch, 3 single-wavefront kernel with pipelined operator loads (auto default for odd N), 4/5/6/10 its metric-batching variants, 11 even-odd single-wavefront kernel (auto default for even N, NQ), 7/8/9 timing-only diagnostics */
+  D4EST_HIP_TUNE_STIFFNESS_WAVE = 1,     /* where (deg_quad+1)^2 <= 64: 0 multi-buffer kernel, 1 single-wavefront kernel, 2 two-wavefront kernel with metric prefetch, 3 single-wavefront kernel with pipelined operator loads (auto default for odd N), 11 even-odd single-wavefront kernel (auto default for even N, NQ); every value computes the same stiffness apply (tests/test_volume_gpu.py) */
   D4EST_HIP_TUNE_STIFFNESS_STAGGER = 2,  /* single-wave kernel: delay (units of 1024 cycles) of every other resident workgroup row */
   D4EST_HIP_TUNE_FLUX_FAST = 3,          /* 0: always the generic flux kernel; else the wave-per-face kernel where all degrees <= 7 */
   D4EST_HIP_TUNE_STIFFNESS_BIGP = 4,     /* p >= 8: 0 three-field kernel, else two-field multi-wave kernel (default) */
@@ -292,6 +292,40 @@ long long d4est_hip_plan_ghost_trace_offset_sub(const d4est_hip_plan_t* plan, in
 int d4est_hip_plan_trace_block_len_sub(const d4est_hip_plan_t* plan, int side, int sub);
 /* deterministic device dot product; result_dev is a device double */
 void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const double* y_dev, double* result_dev);
+
+/* ---- RCCL transport of the ghost exchange (csrc/d4est_hip_comm.hip) --------------------------------------------------------------
+ * The C replacement of d4est_ghost_data_exchange (src/Mesh/d4est_ghost_data.c:143-256) and of the sc_allreduce calls of cg_eigs
+ * (src/Solver/d4est_solver_cg_eigs.c:181-243), one process per GPU, RCCL over xGMI.  librccl is opened at run time.
+ * Communicator: rank 0 calls d4est_hip_comm_get_unique_id, the host broadcasts the d4est_hip_comm_unique_id_bytes() bytes by whatever
+ * it has (MPI_Bcast in a d4est build, torch.distributed in the tests), every rank calls d4est_hip_comm_create (ncclCommInitRank;
+ * collective; the calling thread's current HIP device is the rank's GPU). */
+typedef struct d4est_hip_comm d4est_hip_comm_t;
+typedef struct d4est_hip_rccl_exchange d4est_hip_rccl_exchange_t;
+int d4est_hip_comm_unique_id_bytes(void);
+void d4est_hip_comm_get_unique_id(void* id_out);
+d4est_hip_comm_t* d4est_hip_comm_create(const void* unique_id, int rank, int world);
+void d4est_hip_comm_destroy(d4est_hip_comm_t* comm);
+int d4est_hip_comm_rank(const d4est_hip_comm_t* comm);
+int d4est_hip_comm_size(const d4est_hip_comm_t* comm);
+/* Wire a plan (faces set) to the communicator: installs C exchange / allreduce hooks (no callback into the host language), so that
+ * d4est_hip_apply_lhs, _cheby_iterate, _cg_eigs run on N ranks.  Per neighbouring rank p (peer_rank[p]) the blocks
+ * [send_first[p], send_first[p+1]) of (send_off, send_len): offsets / lengths in doubles into the plan's LOCAL trace buffer
+ * (d4est_hip_plan_trace_offset_sub / _trace_block_len_sub), and [recv_first[p], recv_first[p+1]) of (recv_off, recv_len) into the GHOST
+ * trace buffer (d4est_hip_plan_ghost_trace_offset_sub); both ends list the shared faces in the same canonical order, the totals per
+ * peer pair must agree.  Per apply: one pack kernel, one grouped ncclSend / ncclRecv round on a communication stream (beside the
+ * volume kernel), one unpack kernel.  All arrays are HOST arrays, copied.  The returned object must outlive the plan's use of it. */
+d4est_hip_rccl_exchange_t* d4est_hip_plan_set_rccl_exchange(d4est_hip_plan_t* plan, d4est_hip_comm_t* comm, int n_peers, const int* peer_rank,
+                                                            const int* send_first, const long long* send_off, const int* send_len,
+                                                            const int* recv_first, const long long* recv_off, const int* recv_len);
+void d4est_hip_rccl_exchange_destroy(d4est_hip_rccl_exchange_t* x);
+long long d4est_hip_rccl_exchange_count(const d4est_hip_rccl_exchange_t* x);          /* exchanges posted so far */
+long long d4est_hip_rccl_exchange_send_doubles(const d4est_hip_rccl_exchange_t* x);   /* doubles sent / received per exchange */
+long long d4est_hip_rccl_exchange_recv_doubles(const d4est_hip_rccl_exchange_t* x);
+/* one grouped point-to-point round on already packed device buffers (peer p: send_dev[send_first[p]..send_first[p+1]), likewise
+ * recv), ordered on the plan's stream -- the whole-element exchanges of the Schwarz smoother; and an in-place SUM over ranks */
+void d4est_hip_comm_sendrecv(d4est_hip_comm_t* comm, d4est_hip_plan_t* plan, int n_peers, const int* peer_rank, const double* send_dev,
+                             const long long* send_first, double* recv_dev, const long long* recv_first);
+void d4est_hip_comm_allreduce_sum(d4est_hip_comm_t* comm, d4est_hip_plan_t* plan, double* scalars_dev, int n);
 
 /* ---- host-pointer entries: the drop-in behind d4est's host double* API (SURVEY.md section 7 "hard part") -----------------------
  * Every reference caller hands over HOST vectors.  These entries take host pointers, move the data through plan-owned

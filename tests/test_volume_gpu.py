@@ -63,7 +63,7 @@ def test_stiffness_parity(gpu, hiplib, oracle, level, deg, inc, qt, curved):
 
 
 @pytest.mark.parametrize("deg,inc", [(1, 0), (3, 0), (5, 0), (7, 0), (3, 2), (5, 2), (2, 0), (6, 1)])
-@pytest.mark.parametrize("tune", [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (0, 3)])
+@pytest.mark.parametrize("tune", [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (0, 3), (0, 11)])
 def test_stiffness_kernel_variants(gpu, hiplib, oracle, deg, inc, tune):
     """every tuning variant (3-buffer / prefetch / single-wave / two-wave kernels) gives the oracle's answer"""
     import torch
