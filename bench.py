@@ -2,10 +2,13 @@
 """bench.py -- GDoF/s of the matrix-free 3-D DG stiffness apply (Au = K u), p = 7, fp64.
 
 Contract (see the task statement):  python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; the volume
-stiffness apply is element-independent, so ranks own disjoint Morton shards and the data
-path has NO collective (weak scaling: every rank owns one config-2 brick's worth of
-elements).  A step = one stiffness apply over the rank's whole shard, inputs resident in HBM.
+For N > 1 the driver launches one rank per GPU with torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment); started by hand with --gpus N and no WORLD_SIZE, bench.py launches that command itself and relays its
+output.  The volume stiffness apply is element-independent, so ranks own disjoint Morton shards and the HEADLINE data
+path has NO collective (weak scaling: every rank owns one config-2 brick's worth of elements).  A step = one stiffness
+apply over the rank's whole shard, inputs resident in HBM.  On N > 1 ranks the line also carries, under "secondary",
+the full operator and the Chebyshev iteration on config 2 SPLIT N ways (strong scaling) with the face-trace exchange
+over RCCL in C (csrc/d4est_hip_comm.hip) -- the replacement of d4est_ghost_data_exchange.
 
 Rank 0 prints ONE JSON line on stdout.  Everything else goes to stderr.
 """
@@ -79,6 +82,98 @@ def cpu_baseline(mesh, J, rst, u, budget_s=12.0):
     }
 
 
+def time_region(fn, reps, stream, torch, warm=3):
+    """average milliseconds per call, HIP events on the launch stream"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def brick_plan(level, deg, stream, torch, dev, count=None):
+    """plan of a uniform brick with the geometric factors GENERATED ON THE DEVICE (no 80 B/node host arrays): the big secondaries"""
+    from disco4est_amd import Plan, mesh as M
+    m = M.BrickMesh(level, deg, count=count)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=stream)
+    plan.set_geometry_brick(np.ones(m.n_elements, dtype=np.int32), float(1 << level), [0.0, 1.0, 0.0, 1.0, 0.0, 1.0])
+    plan.set_tuning(7, 0)     # general path: the per-node metric is streamed
+    x = torch.rand(m.local_nodes, dtype=torch.float64, device=dev)
+    return m, plan, x, torch.empty_like(x)
+
+
+def sharded_secondary(args, rank, world, dev, stream, dist, torch):
+    """config 2 split over the ranks (strong scaling): apply_lhs and Chebyshev iterations with the face-trace exchange over RCCL
+    in C; the sharded operator is checked against the same operator applied by ONE rank (rank-count invariance, d4est_test_mpi.sh)."""
+    from disco4est_amd import Plan, mesh as M, parallel as P
+    full = M.BrickMesh(args.level, args.deg)
+    parts = P.partition_by_dofs(full.deg_global, world)
+    first, count = parts[rank]
+    m = M.BrickMesh(args.level, args.deg, first=first, count=count)
+    J, rst = m.geometry(None)
+    sides = m.build_sides(None)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=stream)
+    plan.set_geometry(J, rst)
+    plan.set_tuning(7, 0)
+    plan.set_faces(sides, 10.0, 0)
+    sched = P.plan_schedule(plan, m, sides, parts)
+    summ = [None] * world
+    dist.all_gather_object(summ, P.schedule_summary(sched))
+    ok, why = P.check_schedules_match(summ)
+    if not ok:   # a mismatch would hang the grouped send / receive round: report instead
+        return {"error": "exchange schedules of the ranks do not match: " + why}
+    comm = P.RcclComm(rank, world)
+    x = P.attach_rccl(plan, m, sides, parts, comm)
+    u = torch.from_numpy(m.field(None)).to(dev)      # slice of ONE global field (offset by the shard's position)
+    Au, rhs, r = torch.empty_like(u), torch.zeros_like(u), torch.empty_like(u)
+    plan.apply_lhs(u, Au)
+    torch.cuda.synchronize()
+    # rank-count invariance: gather the sharded A u on rank 0 and compare with the one-rank operator on the whole mesh
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(Au.cpu().numpy(), gathered, dst=0)
+    invariance = None
+    if rank == 0:
+        Jf, rstf = full.geometry(None)
+        pf = Plan(full.deg, full.deg_quad, full.nodal_stride, full.quad_stride, 0, stream=stream)
+        pf.set_geometry(Jf, rstf)
+        pf.set_tuning(7, 0)
+        pf.set_faces(full.build_sides(None), 10.0, 0)
+        uf = torch.from_numpy(full.field(None)).to(dev)
+        ref = torch.empty_like(uf)
+        pf.apply_aij(uf, ref)
+        ref = ref.cpu().numpy()
+        got = np.concatenate(gathered)
+        invariance = float(np.abs(got - ref).max() / np.abs(ref).max())
+        pf.destroy()
+    res = {"rccl_ranks": world, "elements_per_rank": [int(c) for _, c in parts], "exchange_doubles_sent_by_rank0": int(x.send_doubles),
+           "peers_of_rank0": [int(p_) for p_ in sched.peers], "rank_count_invariance_rel_inf": invariance}
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item() / reps * 1e3
+
+    ms = timed(lambda: plan.apply_lhs(u, Au), 50)
+    res["apply_aij_config2_strong"] = {"ms": ms, "GDoF_per_s": full.local_nodes / (ms * 1e-3) / 1e9}
+    ms = timed(lambda: plan.cheby_iterate(u, rhs, Au, r, 5, 1.0, 30.0, 0), 20)
+    res["cheby_5_iterations_config2_strong"] = {"ms": ms, "GDoF_per_s": full.local_nodes * 5 / (ms * 1e-3) / 1e9}
+    res["exchanges_posted"] = int(x.count())
+    x.destroy(); plan.destroy(); comm.destroy()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,14 +188,24 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` by hand: become the launcher (before anything touches the GPU) and relay the ranks' output
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29533")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        log("launching: " + " ".join(cmd))
+        raise SystemExit(subprocess.run(cmd).returncode)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%s but --gpus %d -- refusing to report a line for a different rank count"
+                         % (os.environ.get("WORLD_SIZE", "1"), args.gpus))
+
     import torch
     from disco4est_amd import Plan, build, mesh as M
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)   # one rank per GPU; the modulo only matters for rehearsals on smaller boxes
@@ -253,6 +358,11 @@ def main():
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / reps
                 sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9}
+                # algorithmic bytes of one full operator apply per DoF: u 8 + A u 8 + metric 48 (NQ/N)^3 + the 7 pre-combined face
+                # factors per mortar node of 6 sides; the mortar-node traces are intermediates, not counted
+                bpd_aij = algorithmic_bytes_per_dof(N, NQ) + 6.0 * 7.0 * 8.0 * NQ * NQ / N ** 3
+                sec[name]["algorithmic_bytes_per_dof"] = bpd_aij
+                sec[name]["roofline_frac_hbm"] = bpd_aij * dofs_per_rank * applies / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             # the affine path: same brick, metric rebuilt from 6 numbers per element, 16 B/DoF
             if args.geometry != "sine":
                 plan.set_tuning(7, -1)
@@ -293,6 +403,16 @@ def main():
                                               "kernel": p2.last_kernel()}
                 p2.destroy()
                 del x2, y2
+            # off-cache points (the config-2 working set, 134 MB, sits in the 256 MB Infinity Cache): level 5 at p = 7 (1.07 GB per
+            # apply) and BASELINE config 3 at full size (level 5, p = 11, 56.6 MDoF, 3.6 GB per apply); factors generated on the device
+            for name, level, deg in (("stiffness_p7_level5", 5, 7), ("stiffness_p11_level5_config3", 5, 11)):
+                m2, p2, x2, y2 = brick_plan(level, deg, stream, torch, dev)
+                ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 10, stream, torch)
+                bytes_ = algorithmic_bytes_per_dof(deg + 1, deg + 1) * m2.local_nodes
+                sec[name] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes, "kernel": p2.last_kernel(),
+                             "roofline_frac_hbm": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                p2.destroy()
+                del x2, y2
             # additive Schwarz smoother on the same mesh: one d4est_solver_schwarz_iterate with
             # 10 CG iterations per subdomain (tolerances off), all subdomains batched on the subdomain plan
             if args.geometry != "sine" and mesh.n_elements <= 4096:
@@ -316,6 +436,28 @@ def main():
             out["secondary"] = sec
         except Exception as exc:  # secondary numbers must never break the headline line
             out["secondary"] = {"error": repr(exc)}
+    if world > 1 and not args.no_secondary:
+        # strong-scaling secondaries with the RCCL exchange; a watchdog prints the headline alone if they do not finish
+        import threading
+
+        def give_up():
+            log("rank %d: the sharded secondary did not finish in time; reporting the headline without it" % rank)
+            if rank == 0:
+                out["secondary"] = {"error": "sharded secondary timed out"}
+                out["cpu_baseline"] = None
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(float(os.environ.get("D4EST_BENCH_SECONDARY_TIMEOUT", "240")), give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            sec = sharded_secondary(args, rank, world, dev, stream, dist, torch)
+        except Exception as exc:
+            sec = {"error": repr(exc)}
+        dog.cancel()
+        if rank == 0:
+            out["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(mesh, J, rst, u)
     elif rank == 0:

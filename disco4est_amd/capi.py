@@ -103,6 +103,7 @@ SIGNATURES = {
     "d4est_hip_comm_unique_id_bytes": (ctypes.c_int, []),
     "d4est_hip_comm_get_unique_id": (None, [_vp]),
     "d4est_hip_comm_create": (_vp, [_vp, ctypes.c_int, ctypes.c_int]),
+    "d4est_hip_comm_try_create": (_vp, [_vp, ctypes.c_int, ctypes.c_int]),
     "d4est_hip_comm_destroy": (None, [_vp]),
     "d4est_hip_comm_rank": (ctypes.c_int, [_vp]),
     "d4est_hip_comm_size": (ctypes.c_int, [_vp]),

@@ -155,6 +155,23 @@ d4est_hip_comm_t* d4est_hip_comm_create(const void* unique_id, int rank, int wor
   return c;
 }
 
+// same, but a failing ncclCommInitRank (e.g. two ranks on one GPU) returns NULL instead of aborting: lets a host fall back
+d4est_hip_comm_t* d4est_hip_comm_try_create(const void* unique_id, int rank, int world) {
+  if (!unique_id || world < 1 || rank < 0 || rank >= world) return nullptr;
+  auto* c = new d4est_hip_comm();
+  c->rank = rank;
+  c->world = world;
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof(id));
+  const ncclResult_t r = rccl().CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    std::fprintf(stderr, "[d4est_hip] ncclCommInitRank failed on rank %d of %d: %s\n", rank, world, rccl().GetErrorString(r));
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
 void d4est_hip_comm_destroy(d4est_hip_comm_t* c) {
   if (!c) return;
   if (c->comm) (void)rccl().CommDestroy(c->comm);

@@ -314,7 +314,9 @@ class RcclComm:
             uid = broadcast(uid if rank == 0 else None)
         self._uid = ctypes.create_string_buffer(uid, n)
         self.rank, self.world = rank, world
-        self.handle = self.lib.d4est_hip_comm_create(self._uid, rank, world)
+        self.handle = self.lib.d4est_hip_comm_try_create(self._uid, rank, world)
+        if not self.handle:
+            raise RuntimeError("RCCL communicator could not be created (rank %d of %d)" % (rank, world))
 
     def destroy(self):
         if self.handle:

@@ -304,6 +304,8 @@ typedef struct d4est_hip_rccl_exchange d4est_hip_rccl_exchange_t;
 int d4est_hip_comm_unique_id_bytes(void);
 void d4est_hip_comm_get_unique_id(void* id_out);
 d4est_hip_comm_t* d4est_hip_comm_create(const void* unique_id, int rank, int world);
+/* as above, but returns NULL (and prints the RCCL error) when ncclCommInitRank fails, instead of aborting */
+d4est_hip_comm_t* d4est_hip_comm_try_create(const void* unique_id, int rank, int world);
 void d4est_hip_comm_destroy(d4est_hip_comm_t* comm);
 int d4est_hip_comm_rank(const d4est_hip_comm_t* comm);
 int d4est_hip_comm_size(const d4est_hip_comm_t* comm);
