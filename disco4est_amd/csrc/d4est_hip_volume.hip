@@ -1456,6 +1456,179 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave_eo_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// N = NQ = 16 (p = 15) on the FP64 matrix cores: the whole sum-factorised apply as chains of v_mfma_f64_16x16x4
+// (D[16x16] += A[16x4] B[4x16]; lane l = (q = l >> 4, c = l & 15) holds A[row c][k q], B[k q][col c] and, in register v,
+// D[row 4 v + q][col c]).  Register v of a result tile IS the B operand of k-step v of a following product that sums over
+// the tile's ROW index, so every second contraction takes its input straight from the accumulators:
+//   slab k:  P  = X_k^T B^T      (A = the element's slab, read from global memory as [row j][k i]; B = operator)       rows j
+//            Z  = B P            (A = operator, B = P's registers)                                                  rows j'
+//   LDS round trip ([k][j'][i'], rows padded to 17 doubles, slabs to 272: conflict-free both ways)
+//   t:       T  = B Z[:, column tile]  -> metric multiply in registers (all three gradient components of a node sit in the
+//            same lane and register) -> W = B^T F (B = F's registers)                                               rows k
+//   LDS round trip, in place (a wave overwrites exactly the column tiles it read)
+//   slab k:  E  = W_k B           (A = W read from the LDS as [row j'][k i'], B = operator)                          rows j'
+//            R  = B^T E           (B = E's registers)  -> Au[i][j][k] from the accumulators, 128-byte segments
+// 1024 MFMAs per element, no scalar operator feed, three workgroup barriers; the 16 operator fragments (B, G, natural and
+// transposed) live in 32 VGPRs per lane for the whole kernel.  One element per 512-thread workgroup (8 waves: two slabs and
+// two column tiles each), 102 KB of LDS, persistent over the bucket with the next element's slabs requested as soon as the
+// current ones are consumed.  Why the matrix cores here and not below p = 15: DESIGN.md section 3.
+// ---------------------------------------------------------------------------
+typedef double mfma_d4v __attribute__((ext_vector_type(4)));
+#define D4_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f64_16x16x4f64((a_), (b_), (c_), 0, 0, 0)
+
+struct Mfma16Cfg {
+  static constexpr int JS = 17, KS = 16 * 17, FS = 16 * KS;      // row / slab / field strides of the LDS image (doubles)
+  static constexpr size_t LDS_BYTES = (size_t)3 * FS * sizeof(double);
+};
+
+__global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* __restrict__ u, double* __restrict__ Au,
+                                                                   const double* __restrict__ metric, const int* __restrict__ ns_list,
+                                                                   const int* __restrict__ qs_list, int n_bucket,
+                                                                   const double* __restrict__ Bop, const double* __restrict__ Gop) {
+  constexpr int JS = Mfma16Cfg::JS, KS = Mfma16Cfg::KS, FS = Mfma16Cfg::FS;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
+  // operator fragments: natural = Op[c][4 s + q], transposed = Op[4 s + q][c]  (Op row-major [quadrature node][Lobatto node])
+  double Bn[4], Gn[4], Bt[4], Gt[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    Bn[s] = Bop[c * 16 + 4 * s + q];
+    Gn[s] = Gop[c * 16 + 4 * s + q];
+    Bt[s] = Bop[(4 * s + q) * 16 + c];
+    Gt[s] = Gop[(4 * s + q) * 16 + c];
+  }
+  const mfma_d4v zero = {0.0, 0.0, 0.0, 0.0};
+  // the wave's two slabs of u, as A operands [row j = c][k i = 4 s + q]
+  double xa[2][4];
+  int e = blockIdx.x;
+  if (e < n_bucket) {
+    const double* ue = u + ns_list[e];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xa[h][s] = ue[(4 * s + q) + 16 * c + 256 * (2 * wave + h)];
+  }
+  for (; e < n_bucket; e += gridDim.x) {
+    const int ns = ns_list[e];
+    const double* me = metric + (size_t)6 * qs_list[e];
+    // metric of the wave's first column tile (j' = 2 wave): requested now, used after the forward slab stage
+    double mt[6][4];
+#pragma unroll
+    for (int m = 0; m < 6; ++m)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) mt[m][v] = me[m * 4096 + c + 16 * (2 * wave) + 256 * (4 * v + q)];
+    // ---- forward slab stage: two slabs, interleaved chains
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = 2 * wave + h;
+      mfma_d4v pb = zero, pg = zero;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        pb = D4_MFMA(xa[h][s], Bn[s], pb);
+        pg = D4_MFMA(xa[h][s], Gn[s], pg);
+      }
+      mfma_d4v za = zero, zb = zero, zc = zero;   // za = Bs Br X (-> d/dt), zb = Bs Gr X (-> d/dr), zc = Gs Br X (-> d/ds)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        za = D4_MFMA(Bn[s], pb[s], za);
+        zb = D4_MFMA(Bn[s], pg[s], zb);
+        zc = D4_MFMA(Gn[s], pb[s], zc);
+      }
+      double* z = smem + k * KS + c;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        z[JS * (4 * v + q)] = zb[v];             // field 0: r
+        z[FS + JS * (4 * v + q)] = zc[v];        // field 1: s
+        z[2 * FS + JS * (4 * v + q)] = za[v];    // field 2: t
+      }
+    }
+    // xa is dead from here: the next element's slabs travel during the t and backward stages
+    {
+      const int e_next = e + (int)gridDim.x;
+      if (e_next < n_bucket) {
+        const double* un = u + ns_list[e_next];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) xa[h][s] = un[(4 * s + q) + 16 * c + 256 * (2 * wave + h)];
+      }
+    }
+    __syncthreads();
+    // ---- t stage on the wave's two column tiles (j' = 2 wave, 2 wave + 1): forward, metric, backward, W in place of Z
+    double mt2[6][4];   // the second tile's metric: requested before the first tile's products
+#pragma unroll
+    for (int m = 0; m < 6; ++m)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) mt2[m][v] = me[m * 4096 + c + 16 * (2 * wave + 1) + 256 * (4 * v + q)];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ct = 2 * wave + h;
+      const double* z = smem + JS * ct + c;
+      mfma_d4v tr = zero, ts = zero, tt = zero;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int off = (4 * s + q) * KS;
+        tr = D4_MFMA(Bn[s], z[off], tr);
+        ts = D4_MFMA(Bn[s], z[FS + off], ts);
+        tt = D4_MFMA(Gn[s], z[2 * FS + off], tt);
+      }
+      mfma_d4v fr, fs, ft;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        fr[v] = mt[0][v] * tr[v] + mt[1][v] * ts[v] + mt[2][v] * tt[v];
+        fs[v] = mt[1][v] * tr[v] + mt[3][v] * ts[v] + mt[4][v] * tt[v];
+        ft[v] = mt[2][v] * tr[v] + mt[4][v] * ts[v] + mt[5][v] * tt[v];
+      }
+      if (h == 0) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) mt[m][v] = mt2[m][v];
+      }
+      mfma_d4v wr = zero, ws = zero, wt = zero;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        wr = D4_MFMA(Bt[s], fr[s], wr);
+        ws = D4_MFMA(Bt[s], fs[s], ws);
+        wt = D4_MFMA(Gt[s], ft[s], wt);
+      }
+      double* w = smem + JS * ct + c;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        w[(4 * v + q) * KS] = wr[v];
+        w[FS + (4 * v + q) * KS] = ws[v];
+        w[2 * FS + (4 * v + q) * KS] = wt[v];
+      }
+    }
+    __syncthreads();
+    // ---- backward slab stage
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = 2 * wave + h;
+      const double* w = smem + k * KS + JS * c + q;      // A operand [row j' = c][k i' = 4 s + q]
+      mfma_d4v e1 = zero, e2 = zero, e3 = zero;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        e1 = D4_MFMA(w[4 * s], Gt[s], e1);               // r term: G^T over i'
+        e2 = D4_MFMA(w[FS + 4 * s], Bt[s], e2);          // s term: B^T over i', then G^T over j'
+        e3 = D4_MFMA(w[2 * FS + 4 * s], Bt[s], e3);      // t term: B^T over i'
+      }
+      mfma_d4v e13 = e1 + e3;
+      mfma_d4v r1 = zero, r2 = zero;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        r1 = D4_MFMA(Bt[s], e13[s], r1);
+        r2 = D4_MFMA(Gt[s], e2[s], r2);
+      }
+      double* out = Au + ns + c + 256 * k;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) out[16 * (4 * v + q)] = r1[v] + r2[v];
+    }
+    __syncthreads();   // the next element's forward stage overwrites the image
+  }
+}
+
+// ---------------------------------------------------------------------------
 // mass-like applies (one field):
 //   MODE 0: out = V^T (W J) V in          (mass)            in: nodal, out: nodal
 //   MODE 1: out = V^T (W J) in_quad       (galerkin)        in: quad,  out: nodal
@@ -1927,6 +2100,15 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
   }
 }
 
+static void launch_stiffness_mfma16(d4est_hip_plan* plan, const Bucket& bk, const double* u, double* Au) {
+  std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_mfma16_kernel (512 threads, v_mfma_f64_16x16x4)");
+  set_lds_limit(stiffness_mfma16_kernel, Mfma16Cfg::LDS_BYTES);
+  const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
+  const int grid = bk.n_elem < cus ? bk.n_elem : cus;   // one 102 KB workgroup per CU, persistent over the bucket
+  hipLaunchKernelGGL(stiffness_mfma16_kernel, dim3(grid), dim3(512), Mfma16Cfg::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
+                     plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);
+}
+
 void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   if (!plan->has_geometry) D4EST_HIP_ABORT("apply_stiffness_matrix: d4est_hip_plan_set_geometry was not called");
   for (const Bucket& bk : plan->buckets) {
@@ -1949,6 +2131,8 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
       const bool use_eo = kEven && bk.d_EBf && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0;                  \
       if (kWave && use_wave) {                                               \
         launch_stiffness_wave<N_, (kWave ? NQ_ : N_)>(plan, bk, use_pf, u, Au);                                 \
+      } else if (N_ == 16 && NQ_ == 16 && (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] == 2 || plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] < 0)) { \
+        launch_stiffness_mfma16(plan, bk, u, Au);                                                               \
       } else if (!kWave && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] != 0) {                                  \
         /* p >= 8: multi-wave workgroup, two LDS fields (sequential field hand-off) -> 1.5x the residency */  \
         using W = WaveCfg<N_, NQ_>;                                                                             \

@@ -81,7 +81,7 @@ def test_stiffness_kernel_variants(gpu, hiplib, oracle, deg, inc, tune):
 
 
 @pytest.mark.parametrize("deg,inc", [(8, 0), (9, 0), (11, 0), (15, 0), (8, 1)])
-@pytest.mark.parametrize("bigp", [0, 1])
+@pytest.mark.parametrize("bigp", [0, 1, 2])
 def test_stiffness_high_p_variants(gpu, hiplib, oracle, deg, inc, bigp):
     import torch
     from disco4est_amd import mesh as M
@@ -95,6 +95,31 @@ def test_stiffness_high_p_variants(gpu, hiplib, oracle, deg, inc, bigp):
     du = _t(u, gpu); dAu = torch.full_like(du, float("nan"))
     plan.apply_stiffness_matrix(du, dAu)
     assert _rel(dAu.cpu().numpy(), ref) <= RTOL
+
+
+def test_stiffness_p15_matrix_core_kernel_persistent(gpu, hiplib, oracle):
+    """p = 15 (config 5's degree): the v_mfma_f64_16x16x4 kernel (default at deg = deg_quad = 15) on more elements than CUs -- every
+    workgroup loops over several elements with the next element's slabs in flight -- curved metric, against the oracle."""
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(3, 15, count=300)
+    mp = M.SineMap(0.05)
+    J, rst = m.geometry(mp)
+    u = m.field(mp)
+    ref = oracle.apply_stiffness(m, J, rst, u, nthreads=8)
+    plan = _plan(m, J, rst)
+    du = _t(u, gpu); dAu = torch.full_like(du, float("nan"))
+    plan.apply_stiffness_matrix(du, dAu)
+    assert "mfma16" in plan.last_kernel()
+    got = dAu.cpu().numpy()
+    per_elem = np.abs(got - ref).reshape(300, -1).max(axis=1) / np.abs(ref).reshape(300, -1).max(axis=1)
+    assert per_elem.max() <= RTOL, (int(per_elem.argmax()), per_elem.max())
+    plan.set_tuning(4, 1)           # the vector-ALU kernel stays selectable and agrees
+    dAu2 = torch.full_like(du, float("nan"))
+    plan.apply_stiffness_matrix(du, dAu2)
+    assert "wave_kernel" in plan.last_kernel()
+    assert _rel(dAu2.cpu().numpy(), got) <= RTOL
+    plan.destroy()
 
 
 def test_stiffness_mixed_p_parity(gpu, hiplib, oracle):
