@@ -10,7 +10,8 @@ Mirrors the reference's setup for it:
     smoother feeds with a zero trace; geometric factors are not copied, the strides alias the mesh's arrays.
   * ``Schwarz``          <->  d4est_solver_schwarz_t + d4est_solver_schwarz_iterate (src/Solver/d4est_solver_schwarz.c:20-285).
 
-Single-tree, single-rank meshes: ``mesh.BrickMesh`` (uniform or mixed degrees) and ``mesh.HangingBrickMesh`` (hanging 1 <-> 4 faces).
+Meshes: ``mesh.BrickMesh`` (uniform or mixed degrees), ``mesh.HangingBrickMesh`` (hanging 1 <-> 4 faces) on 1 .. N ranks, and
+``forest.ForestMesh`` (several trees, inter-tree face orientation, hanging faces) on one rank.
 """
 import ctypes
 
@@ -42,7 +43,9 @@ class SchwarzMetadata:
         if (np.any(nbr <= -2) or np.any(nbr4 <= -2)) and cores is None:
             raise NotImplementedError("subdomain elements on other ranks need the extended mesh of SchwarzShard")
         self.num_nodes_overlap = int(num_nodes_overlap)
-        if hanging:
+        if hasattr(mesh, "conn"):        # multi-tree forest (forest.ForestMesh): corners identified through the tree maps
+            core_l, elem_l, faces_l = self._corner_neighbours_forest(mesh)
+        elif hanging:
             core_l, elem_l, faces_l = self._corner_neighbours(mesh)
         else:
             core_l, elem_l, faces_l = self._walk_neighbours(ne, nbr)
@@ -149,6 +152,82 @@ class SchwarzMetadata:
                     fc.append(2 * d + 1)
             assert fc, "two elements of one corner must be separated in at least one direction"
             faces[k, :len(fc)] = fc
+        return [core], [elem], [faces]
+
+    @staticmethod
+    def _corner_neighbours_forest(mesh):
+        """forest.ForestMesh (several trees, inter-tree orientation, optional hanging faces): the corner callback of the reference
+        (d4est_solver_schwarz_metadata_corner_callback, src/Solver/d4est_solver_schwarz_metadata.c:186-405) restated on points.
+        A corner is conformal when it is a corner of every element that touches it; all elements of a conformal corner enter each
+        other's subdomains.  The faces recorded for a subdomain element are in ITS OWN frame (p8est_corner_faces /
+        p8est_edge_faces of its corner / edge): the shared face if the two share a face, else the two faces at the shared edge, else
+        the three faces at the corner."""
+        ne = mesh.n_elements
+        mp = mesh.mapping
+        key = lambda X: tuple(np.round(X * 2 ** 20).astype(np.int64).tolist())
+        corners, mids = {}, set()
+        ckey = [[None] * 8 for _ in range(ne)]
+        mkey = {}
+        lattice = np.array([[a, b, c] for c in (0, 1, 2) for b in (0, 1, 2) for a in (0, 1, 2)], dtype=np.float64) - 1.0   # 27 points
+        for e in range(ne):
+            X = mp.x(int(mesh.tree[e]), mesh._cell_xi(mesh.org[e], mesh.size[e], lattice))
+            for n_, (ref, x) in enumerate(zip(lattice, X)):
+                k = key(x)
+                nz = int(np.sum(ref == 0.0))
+                if nz == 0:
+                    c = int(ref[0] > 0) + 2 * int(ref[1] > 0) + 4 * int(ref[2] > 0)
+                    corners.setdefault(k, []).append((e, c))
+                    ckey[e][c] = k
+                elif nz <= 2:
+                    mids.add(k)                       # edge midpoints and face centres: a hanging node of a smaller neighbour lands here
+                    mkey[(e, n_)] = k
+        def edge_mid_key(e, c, d):                    # midpoint of the edge of e through corner c along direction d
+            ref = np.array([1.0 if (c >> t) & 1 else -1.0 for t in range(3)])
+            ref[d] = 0.0
+            n_ = int((ref[0] + 1) + 3 * (ref[1] + 1) + 9 * (ref[2] + 1))
+            return mkey[(e, n_)]
+        def linked(e, fe, c, fc):                     # face fe of e and face fc of c are the two sides of one (possibly hanging) mesh face
+            k = mesh.face_neighbours(int(mesh.elements[e]), fe)
+            gc = int(mesh.elements[c])
+            if k[0] == "full" or k[0] == "small":
+                return k[1] == gc and k[2] == fc
+            if k[0] == "big":
+                return gc in k[1] and k[2] == fc
+            return False
+        found = {}
+        for P, lst in corners.items():
+            if P in mids:
+                continue                              # a hanging node of somebody: not a conformal corner
+            for (c, kc) in lst:
+                for (e, ke) in lst:
+                    if e == c:
+                        continue
+                    fe = [2 * d + ((ke >> d) & 1) for d in range(3)]
+                    fc = [2 * d + ((kc >> d) & 1) for d in range(3)]
+                    shared_face = [a for a in fe for b in fc if linked(e, a, c, b)]
+                    if shared_face:
+                        faces = (shared_face[0], -1, -1)
+                        rank = 2
+                    else:
+                        faces, rank = None, 0
+                        for de in range(3):           # a shared edge: same far end point, or one is half of the other
+                            Qe = ckey[e][ke ^ (1 << de)]
+                            for dc in range(3):
+                                Qc = ckey[c][kc ^ (1 << dc)]
+                                if Qe == Qc or Qe == edge_mid_key(c, kc, dc) or Qc == edge_mid_key(e, ke, de):
+                                    faces = tuple(sorted(fe[t] for t in range(3) if t != de)) + (-1,)
+                                    rank = 1
+                        if faces is None:
+                            faces = tuple(fe)
+                    old = found.get((c, e))
+                    if old is None or rank > old[1]:
+                        found[(c, e)] = (faces, rank)
+        pairs = sorted(found)
+        core = np.array([a for a, _ in pairs] + list(range(ne)), dtype=np.int64)
+        elem = np.array([b for _, b in pairs] + list(range(ne)), dtype=np.int64)
+        faces = np.full((core.size, 3), -1, dtype=np.int32)
+        for k, pr in enumerate(pairs):
+            faces[k] = found[pr][0]
         return [core], [elem], [faces]
 
     def subdomain(self, i):
