@@ -239,3 +239,69 @@ def test_schwarz_on_multi_tree_meshes(gpu, hiplib, oracle, case):
         sz.destroy()
     finally:
         oracle.set_hanging(None)
+
+
+class _Mailbox:
+    def __init__(self):
+        self.box = {}
+
+
+class _LocalTransport:
+    """in-process stand-in for the point-to-point transport (as in tests/test_parallel_gpu.py)"""
+
+    def __init__(self, rank, mailbox):
+        self.rank, self.mb = rank, mailbox
+
+    def start(self, send_buf, recv_buf):
+        for p, t in send_buf.items():
+            self.mb.box[(self.rank, p)] = t.clone()
+        return recv_buf
+
+    def finish(self, recv_buf):
+        for p, t in recv_buf.items():
+            t.copy_(self.mb.box[(p, self.rank)])
+
+
+@pytest.mark.parametrize("deg,refine,world", [(3, None, 3), (8, None, 2), (2, [0, 0, 1, 0, 0, 0, 1], 4), (4, [1, 0, 0, 0, 0, 1, 0], 3)])
+def test_trace_exchange_through_oriented_and_hanging_tree_faces(gpu, hiplib, oracle, deg, refine, world):
+    """The FACE-TRACE exchange (what travels over RCCL: mortar-node blocks, not ghost elements) between virtual ranks whose boundary
+    runs through tree faces with orientation != 0 and through hanging faces between trees: the receiver re-orients the sender's
+    block, a small side receives the big element's sub-block d4est_reference_reorient_face_order names.  Assembled A u == the
+    one-rank oracle."""
+    import torch
+    from disco4est_amd import Plan, parallel as P
+    conn = F.cubed_sphere_7tree_connectivity()
+    mp = F.CubedSphere7Map(1.0, 2.0)
+    mg = F.ForestMesh(conn, 0, deg, mp, refine=refine)
+    Jg, rstg = mg.geometry(); sg = mg.build_sides(); ug = mg.field()
+    ref = oracle.apply_aij(mg, Jg, rstg, sg, ug, nthreads=8)
+    parts = P.partition_by_dofs(mg.deg_global, world)
+    mb = _Mailbox()
+    ranks, oriented, hanging_cut = [], 0, 0
+    for r, (first, count) in enumerate(parts):
+        m = F.ForestMesh(conn, 0, deg, mp, refine=refine, first=first, count=count)
+        J, rst = m.geometry(); s = m.build_sides()
+        plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+        plan.set_geometry(J, rst); plan.set_faces(s)
+        ex = P.TraceExchange(P.plan_schedule(plan, m, s, parts), _LocalTransport(r, mb), plan.copy_blocks, gpu)
+        oriented += int(((s["side_nbr"] <= -2) & (s["side_reorder"] != 0)).sum())
+        if "side_hang" in s:
+            hanging_cut += int(((s["side_hang"] == 2) & (s["side_nbr"] <= -2)).sum())
+        u = torch.from_numpy(m.field()).to(gpu)
+        tr = torch.empty(plan.trace_size, dtype=torch.float64, device=gpu)
+        gt = torch.full((max(plan.ghost_trace_size, 1),), float("nan"), dtype=torch.float64, device=gpu)
+        ranks.append((m, plan, ex, u, tr, gt))
+    assert oriented > 0 and (refine is None or hanging_cut > 0)
+    for m, plan, ex, u, tr, gt in ranks:
+        plan.compute_face_traces(u, tr)
+        ex.begin(tr)
+    got = np.zeros_like(ref)
+    for m, plan, ex, u, tr, gt in ranks:
+        ex.end(gt)
+        Au = torch.full_like(u, float("nan"))
+        plan.apply_stiffness_matrix(u, Au)
+        plan.apply_flux(tr, gt, Au)
+        got[m.global_nodal_offset:m.global_nodal_offset + m.local_nodes] = Au.cpu().numpy()
+        plan.destroy()
+    assert np.isfinite(got).all()
+    assert _rel(got, ref) <= RTOL
