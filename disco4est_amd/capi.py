@@ -54,6 +54,8 @@ SIGNATURES = {
     "d4est_hip_plan_set_hanging": (None, [_vp, _vp, _vp, _vp, _vp]),
     "d4est_hip_plan_set_geometry_numerical": (None, [_vp, _vp, ctypes.c_int]),
     "d4est_hip_plan_set_geometry_brick": (None, [_vp, _vp, ctypes.c_double, _vp]),
+    "d4est_hip_plan_set_geometry_analytic": (None, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_double]),
+    "d4est_hip_plan_set_mortar_geometry_analytic": (None, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double]),
     "d4est_hip_plan_set_mortar_geometry_brick": (None, [_vp, _vp, ctypes.c_double, _vp]),
     "d4est_hip_transfer_create": (_vp, [ctypes.c_int, _vp, _vp, _vp]),
     "d4est_hip_transfer_destroy": (None, [_vp]),
@@ -263,6 +265,20 @@ class Plan:
         fn = self.lib.d4est_hip_plan_set_mortar_geometry_brick if mortars else self.lib.d4est_hip_plan_set_geometry_brick
         fn(self.handle, dq[1], float(root_len), ex.ctypes.data_as(_vp))
 
+    def set_geometry_analytic(self, geom_type, params, tree, q, dq, root_len, mortars=False, ghost=None):
+        """factors of an analytic tree map generated on the device (geom_type 1 = cubed_sphere_7tree, params = (R0, R1,
+        compactify_inner_shell)); tree / q[n,3] / dq: where every element sits in the forest; mortars=True: the mortar factors
+        (ghost = (tree, q, dq) of the ghost elements)"""
+        pr = np.ascontiguousarray(params, dtype=np.float64)
+        t, qq, d = _iarr(tree), _iarr(np.asarray(q).reshape(-1)), _iarr(dq)
+        if not mortars:
+            self.lib.d4est_hip_plan_set_geometry_analytic(self.handle, int(geom_type), pr.ctypes.data_as(_vp), t[1], qq[1], d[1], float(root_len))
+            return
+        gt, gq, gd = (_iarr(ghost[0]), _iarr(np.asarray(ghost[1]).reshape(-1)), _iarr(ghost[2])) if ghost is not None else \
+            (_iarr(np.zeros(0)), _iarr(np.zeros(0)), _iarr(np.zeros(0)))
+        self.lib.d4est_hip_plan_set_mortar_geometry_analytic(self.handle, int(geom_type), pr.ctypes.data_as(_vp), t[1], qq[1], d[1],
+                                                             gt[1], gq[1], gd[1], float(root_len))
+
     def apply_weighted_mass_matrix(self, u, coeff_quad, out):
         assert u.numel() == self.local_nodes and out.numel() == self.local_nodes
         assert coeff_quad.numel() == self.local_nodes_quad
@@ -299,7 +315,7 @@ class Plan:
         self.lib.d4est_hip_compute_dudr(self.handle, _ptr(u), _ptr(d0), _ptr(d1), _ptr(d2))
 
     # ---- faces
-    def set_faces(self, sides, penalty_prefactor=10.0, penalty_fcn=0, brick=None):
+    def set_faces(self, sides, penalty_prefactor=10.0, penalty_fcn=0, brick=None, analytic=None):
         """sides: the dict of mesh.BrickMesh.build_sides() (reference-layout side list + mortar factors);
         brick = (elem_dq, root_len, extents): generate the mortar factors of the brick geometry on the device instead"""
         keep = [_iarr(sides[k]) for k in ("side_nbr", "side_nbr_face", "side_reorder", "side_mortar_stride", "side_bndry_stride",
@@ -315,6 +331,8 @@ class Plan:
         self.lib.d4est_hip_plan_set_sipg(self.handle, float(penalty_prefactor), int(penalty_fcn))
         if brick is not None:
             self.set_geometry_brick(brick[0], brick[1], brick[2], mortars=True)
+        elif analytic is not None:      # (geom_type, params, tree, q, dq, root_len, ghost)
+            self.set_geometry_analytic(*analytic[:6], mortars=True, ghost=analytic[6])
         else:
             arrs = [np.ascontiguousarray(sides[k], dtype=np.float64) for k in ("sj", "n", "drst_m", "drst_p", "hm", "hp")]
             self.lib.d4est_hip_plan_set_mortar_geometry(self.handle, *[a.ctypes.data_as(_vp) for a in arrs], 0)

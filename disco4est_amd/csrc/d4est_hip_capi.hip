@@ -1,11 +1,13 @@
 // extern "C" entry points of libd4est_hip.so (declared in include/d4est_hip.h):
 // tables, device-memory helpers, plan life cycle and the volume applies.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <utility>
 
 #include "d4est_hip_internal.h"
+#include "d4est_hip_maps.h"
 #include "d4est_hip_tables.h"
 
 using d4est_hip::Bucket;
@@ -315,6 +317,66 @@ void d4est_hip_plan_set_mortar_geometry_brick(d4est_hip_plan_t* plan, const int*
   d4est_hip::faces_set_geometry_brick(plan, d_dq, root_len, extents);
   HIP_CHECK(hipStreamSynchronize(plan->stream));
   HIP_CHECK(hipFree(d_dq));
+}
+
+static d4est_hip::TreeMapParams analytic_params(int geom_type, const double* params, const char* who) {
+  if (geom_type != D4EST_HIP_GEOM_CUBED_SPHERE_7TREE) D4EST_HIP_ABORT("%s: unknown geometry type %d", who, geom_type);
+  if (!params || !(params[0] > 0.) || !(params[1] > params[0])) D4EST_HIP_ABORT("%s: cubed_sphere_7tree needs params = {R0, R1 > R0, compactify_inner_shell}", who);
+  d4est_hip::TreeMapParams P;
+  P.type = geom_type;
+  P.R0 = params[0];
+  P.R1 = params[1];
+  P.compactify = params[2] != 0.;
+  P.Clength = P.R0 / std::sqrt(3.0);
+  return P;
+}
+
+static std::vector<d4est_hip::CellDesc> cells_from(int n, const int* tree, const int* q, const int* dq, int max_tree, const char* who) {
+  std::vector<d4est_hip::CellDesc> c((size_t)std::max(n, 0));
+  for (int e = 0; e < n; ++e) {
+    if (tree[e] < 0 || tree[e] > max_tree || dq[e] <= 0) D4EST_HIP_ABORT("%s: element %d has tree %d / dq %d", who, e, tree[e], dq[e]);
+    c[e].tree = tree[e];
+    c[e].q[0] = q[3 * e]; c[e].q[1] = q[3 * e + 1]; c[e].q[2] = q[3 * e + 2];
+    c[e].dq = dq[e];
+    c[e].face = 0;
+  }
+  return c;
+}
+
+void d4est_hip_plan_set_geometry_analytic(d4est_hip_plan_t* plan, int geom_type, const double* params, const int* elem_tree,
+                                          const int* elem_q, const int* elem_dq, double root_len) {
+  check_plan(plan, "plan_set_geometry_analytic");
+  drop_graph(plan);
+  const d4est_hip::TreeMapParams P = analytic_params(geom_type, params, "plan_set_geometry_analytic");
+  if (plan->n_elements > 0 && (!elem_tree || !elem_q || !elem_dq)) D4EST_HIP_ABORT("plan_set_geometry_analytic: NULL element array");
+  if (!(root_len > 0.)) D4EST_HIP_ABORT("plan_set_geometry_analytic: root_len");
+  std::vector<d4est_hip::CellDesc> cells = cells_from(plan->n_elements, elem_tree, elem_q, elem_dq, 6, "plan_set_geometry_analytic");
+  d4est_hip::CellDesc* d_cells = nullptr;
+  HIP_CHECK(hipMalloc(&d_cells, std::max<size_t>(cells.size(), 1) * sizeof(d4est_hip::CellDesc)));
+  if (!cells.empty()) HIP_CHECK(hipMemcpy(d_cells, cells.data(), cells.size() * sizeof(d4est_hip::CellDesc), hipMemcpyHostToDevice));
+  const size_t nq = (size_t)plan->local_nodes_quad;
+  if (!plan->d_J) HIP_CHECK(hipMalloc(&plan->d_J, std::max<size_t>(nq, 1) * sizeof(double)));
+  if (!plan->d_metric) HIP_CHECK(hipMalloc(&plan->d_metric, std::max<size_t>(6 * nq, 1) * sizeof(double)));
+  d4est_hip::launch_analytic_geometry(plan, P, d_cells, root_len);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  HIP_CHECK(hipFree(d_cells));
+  plan->has_geometry = true;
+}
+
+void d4est_hip_plan_set_mortar_geometry_analytic(d4est_hip_plan_t* plan, int geom_type, const double* params, const int* elem_tree,
+                                                 const int* elem_q, const int* elem_dq, const int* ghost_tree, const int* ghost_q,
+                                                 const int* ghost_dq, double root_len) {
+  check_plan(plan, "plan_set_mortar_geometry_analytic");
+  drop_graph(plan);
+  if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_mortar_geometry_analytic: call plan_set_faces first");
+  const d4est_hip::TreeMapParams P = analytic_params(geom_type, params, "plan_set_mortar_geometry_analytic");
+  if (plan->n_elements > 0 && (!elem_tree || !elem_q || !elem_dq)) D4EST_HIP_ABORT("plan_set_mortar_geometry_analytic: NULL element array");
+  if (plan->n_ghost > 0 && (!ghost_tree || !ghost_q || !ghost_dq)) D4EST_HIP_ABORT("plan_set_mortar_geometry_analytic: NULL ghost array");
+  if (!(root_len > 0.)) D4EST_HIP_ABORT("plan_set_mortar_geometry_analytic: root_len");
+  std::vector<d4est_hip::CellDesc> cells = cells_from(plan->n_elements, elem_tree, elem_q, elem_dq, 6, "plan_set_mortar_geometry_analytic");
+  std::vector<d4est_hip::CellDesc> gcells = cells_from(plan->n_ghost, ghost_tree, ghost_q, ghost_dq, 6, "plan_set_mortar_geometry_analytic");
+  d4est_hip::faces_set_geometry_analytic(plan, P, cells, gcells, root_len);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
 }
 
 void d4est_hip_apply_stiffness_matrix(d4est_hip_plan_t* plan, const double* u_dev, double* Au_dev) {

@@ -23,6 +23,7 @@
 #include <tuple>
 
 #include "d4est_hip_internal.h"
+#include "d4est_hip_maps.h"
 #include "d4est_hip_tables.h"
 
 namespace d4est_hip {
@@ -2263,6 +2264,177 @@ void faces_set_geometry_brick(d4est_hip_plan* plan, const int* d_elem_dq, double
   HIP_CHECK(hipGetLastError());
   faces_set_geometry(plan, a[0], a[1], a[2], a[3], a[4], a[5], /*on_device=*/1);
   for (int i = 0; i < 6; ++i) HIP_CHECK(hipFree(a[i]));
+}
+
+// ---------------------------------------------------------------------------
+// Mortar factors of an analytic tree map on the device (d4est_mesh_compute_mortar_quadrature_quantities with
+// DX_compute_method = GEOM_COMPUTE_ANALYTIC, src/Mesh/d4est_mesh.c:858-1108, src/Mesh/d4est_mortars.c:19-190): one unit per
+// conforming side / per mortar record.  The (-) cell gives sj, n (COMPUTE_NORMAL_USING_JACOBIAN), dr/dx and hm = J/sj at the
+// mortar's quadrature nodes in (-) order; the (+) cell -- evaluated in ITS tree, at ITS nodes -- gives drst_dxyz_p_porder in the
+// (+) side's own node and sub-face order and, re-oriented into (-) order, hp.  On the big side of a hanging face the cells are
+// the half-size virtual children of the element (d4est_mortars_compute_qcoords_on_mortar, :419-468).  The arrays are written in
+// the reference's layout and handed to the same pre-combination as host-supplied factors.
+// ---------------------------------------------------------------------------
+struct MortarUnit {
+  int S, off, off_p, Ttot, NQ, code, boundary, pad;
+  CellDesc m, p;
+};
+
+__device__ inline void face_ref_point(int f, double ta, double tb, double r[3]) {
+  const int dir = f >> 1;
+  r[dir] = (f & 1) ? 1.0 : -1.0;
+  r[dir == 0 ? 1 : 0] = ta;
+  r[dir == 2 ? 1 : 2] = tb;
+}
+
+__global__ __launch_bounds__(64) void analytic_mortar_kernel(const MortarUnit* __restrict__ units, int n_units, TreeMapParams P,
+                                                             double root_len, const double* __restrict__ quad_nodes /* [NQ][24] */,
+                                                             double* sj, double* nrm, double* drst_m, double* drst_p, double* hm, double* hp) {
+  for (int ui = blockIdx.x; ui < n_units; ui += gridDim.x) {
+    const MortarUnit un = units[ui];
+    const int NQ = un.NQ, T = NQ * NQ;
+    const double* t = quad_nodes + 24 * NQ;
+    const size_t S = (size_t)un.S;
+    for (int k = threadIdx.x; k < T; k += blockDim.x) {
+      const int a = k % NQ, b = k / NQ;
+      double r[3], dxdr[3][3], inv[3][3];
+      face_ref_point(un.m.face, t[a], t[b], r);
+      cell_dxdr(P, un.m, root_len, r, dxdr);
+      const double J = invert3(dxdr, inv);
+      const int dir = un.m.face >> 1;
+      const double sgn = (un.m.face & 1) ? 1.0 : -1.0;
+      double v[3], s2 = 0.0;
+      for (int d = 0; d < 3; ++d) { v[d] = sgn * J * inv[dir][d]; s2 += v[d] * v[d]; }
+      const double sjv = sqrt(s2);
+      sj[S + un.off + k] = sjv;
+      hm[S + un.off + k] = J / sjv;
+      for (int d = 0; d < 3; ++d) nrm[3 * S + (size_t)d * un.Ttot + un.off + k] = v[d] / sjv;
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) drst_m[9 * S + (size_t)(i + 3 * j) * un.Ttot + un.off + k] = inv[i][j];
+      if (un.boundary) {
+        hp[S + un.off + k] = J / sjv;
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) drst_p[9 * S + (size_t)(i + 3 * j) * un.Ttot + un.off_p + k] = inv[i][j];
+        continue;
+      }
+      // (+) side, its own node k
+      face_ref_point(un.p.face, t[a], t[b], r);
+      cell_dxdr(P, un.p, root_len, r, dxdr);
+      (void)invert3(dxdr, inv);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) drst_p[9 * S + (size_t)(i + 3 * j) * un.Ttot + un.off_p + k] = inv[i][j];
+      // hp at (-) node k = J/sj of the (+) side at its node reorder(k)
+      const int kp = reorder_index(un.code, NQ - 1, a, b);
+      face_ref_point(un.p.face, t[kp % NQ], t[kp / NQ], r);
+      cell_dxdr(P, un.p, root_len, r, dxdr);
+      const double Jp = invert3(dxdr, inv);
+      const int dirp = un.p.face >> 1;
+      double sp = 0.0;
+      for (int d = 0; d < 3; ++d) sp += (Jp * inv[dirp][d]) * (Jp * inv[dirp][d]);
+      hp[S + un.off + k] = Jp / sqrt(sp);
+    }
+  }
+}
+
+static CellDesc face_child(const CellDesc& c, int face, int child) {
+  // half-size virtual child `child` (z-order on the face) of cell c that touches face `face`
+  CellDesc r = c;
+  const int dir = face >> 1, h = c.dq / 2;
+  const int a0 = dir == 0 ? 1 : 0, a1 = dir == 2 ? 1 : 2;
+  r.dq = h;
+  r.q[a0] += (child & 1) * h;
+  r.q[a1] += (child >> 1) * h;
+  if (face & 1) r.q[dir] += h;
+  r.face = face;
+  return r;
+}
+
+void faces_set_geometry_analytic(d4est_hip_plan* plan, const TreeMapParams& P, const std::vector<CellDesc>& elem,
+                                 const std::vector<CellDesc>& ghost, double root_len) {
+  FaceHost& fh = g_face_host[plan];
+  const int ne = plan->n_elements;
+  auto cell_of = [&](int ref, int face) {
+    if (ref == -1) D4EST_HIP_ABORT("plan_set_mortar_geometry_analytic: boundary reference");
+    CellDesc c;
+    if (ref >= 0) c = elem[ref];
+    else {
+      const int g = -(ref + 2);
+      if (g >= (int)ghost.size()) D4EST_HIP_ABORT("plan_set_mortar_geometry_analytic: ghost element %d has no cell description", g);
+      c = ghost[g];
+    }
+    c.face = face;
+    return c;
+  };
+  std::vector<MortarUnit> units;
+  if (fh.hp) {
+    std::vector<HpMortar> rec((size_t)fh.n_rec);
+    std::vector<HpGeomSrc> gs((size_t)fh.n_rec);
+    HIP_CHECK(hipMemcpy(rec.data(), fh.d_rec, rec.size() * sizeof(HpMortar), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(gs.data(), fh.d_gsrc, gs.size() * sizeof(HpGeomSrc), hipMemcpyDeviceToHost));
+    for (int e = 0; e < ne; ++e)
+      for (int f = 0; f < 6; ++f) {
+        const size_t s = 6 * (size_t)e + f;
+        const int hang = plan->side_hang[s], nbr = plan->side_nbr[s], f_p = plan->side_nbr_face[s], o = plan->side_orientation[s];
+        const int r0 = plan->side_first_rec[s], r1 = plan->side_first_rec[s + 1];
+        for (int r = r0; r < r1; ++r) {
+          MortarUnit u{};
+          u.S = gs[r].S; u.off = gs[r].off; u.off_p = gs[r].off_p; u.Ttot = gs[r].Ttot; u.NQ = rec[r].NQ; u.code = rec[r].code;
+          u.boundary = (rec[r].kind == 0);
+          if (hang == 0) {
+            u.m = cell_of(e, f);
+            u.p = u.boundary ? u.m : cell_of(nbr, f_p);
+          } else if (hang == 1) {
+            const int i = r - r0;
+            u.m = face_child(cell_of(e, f), f, i);
+            u.p = cell_of(plan->side_nbr4[4 * s + i], f_p);
+          } else {
+            const int c = plan->side_sub[s];
+            u.m = cell_of(e, f);
+            u.p = face_child(cell_of(nbr, f_p), f_p, reorient_face_order(f, f_p, o, c));
+          }
+          units.push_back(u);
+        }
+      }
+  } else {
+    std::vector<SideDesc> sd(6 * (size_t)ne);
+    if (!sd.empty()) HIP_CHECK(hipMemcpy(sd.data(), plan->d_side_desc, sd.size() * sizeof(SideDesc), hipMemcpyDeviceToHost));
+    for (size_t s = 0; s < sd.size(); ++s) {
+      MortarUnit u{};
+      const int T = sd[s].NQ * sd[s].NQ;
+      u.S = sd[s].geom; u.off = 0; u.off_p = 0; u.Ttot = T; u.NQ = sd[s].NQ; u.code = sd[s].code; u.boundary = (sd[s].kind == 0);
+      u.m = cell_of((int)(s / 6), (int)(s % 6));
+      u.p = u.boundary ? u.m : cell_of(plan->side_nbr[s], plan->side_nbr_face[s]);
+      units.push_back(u);
+    }
+  }
+  // quadrature nodes of every mortar degree in use
+  std::vector<double> qn((size_t)25 * 24, 0.0);
+  for (const MortarUnit& u : units) {
+    if (u.NQ > 24) D4EST_HIP_ABORT("plan_set_mortar_geometry_analytic: mortar degree %d", u.NQ - 1);
+    if (qn[(size_t)24 * u.NQ + u.NQ - 1] == 0.0 || u.NQ == 1) {
+      std::vector<double> x, w;
+      if (plan->quad_type == QUAD_LEGENDRE) Tables1D::gauss(u.NQ - 1, x, w);
+      else Tables1D::lobatto(u.NQ - 1, x, w);
+      for (int i = 0; i < u.NQ; ++i) qn[(size_t)24 * u.NQ + i] = x[i];
+    }
+  }
+  const size_t T = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
+  double* a[6];
+  const size_t mult[6] = {1, 3, 9, 9, 1, 1};
+  for (int i = 0; i < 6; ++i) {
+    HIP_CHECK(hipMalloc(&a[i], mult[i] * T * sizeof(double)));
+    HIP_CHECK(hipMemsetAsync(a[i], 0, mult[i] * T * sizeof(double), plan->stream));
+  }
+  MortarUnit* d_units = upload_vec(units);
+  double* d_qn = upload_vec(qn);
+  if (!units.empty())
+    hipLaunchKernelGGL(analytic_mortar_kernel, dim3(std::min((int)units.size(), 8192)), dim3(64), 0, plan->stream, d_units, (int)units.size(), P,
+                       root_len, d_qn, a[0], a[1], a[2], a[3], a[4], a[5]);
+  HIP_CHECK(hipGetLastError());
+  faces_set_geometry(plan, a[0], a[1], a[2], a[3], a[4], a[5], /*on_device=*/1);
+  for (int i = 0; i < 6; ++i) HIP_CHECK(hipFree(a[i]));
+  HIP_CHECK(hipFree(d_units));
+  HIP_CHECK(hipFree(d_qn));
 }
 
 __global__ __launch_bounds__(256) void robin_setup_kernel(const double* __restrict__ sj, const double* __restrict__ coeff,

@@ -135,6 +135,11 @@ struct d4est_hip_plan {
 };
 
 namespace d4est_hip {
+struct TreeMapParams;
+struct CellDesc;
+void launch_analytic_geometry(d4est_hip_plan* plan, const TreeMapParams& P, const CellDesc* d_cells, double root_len);
+void faces_set_geometry_analytic(d4est_hip_plan* plan, const TreeMapParams& P, const std::vector<CellDesc>& elem,
+                                 const std::vector<CellDesc>& ghost, double root_len);
 
 // d4est_hip_volume.hip
 void launch_metric_precombine(d4est_hip_plan* plan, const double* d_J, const double* d_rst);

@@ -20,6 +20,8 @@
 #include <algorithm>
 
 #include "d4est_hip_internal.h"
+#include "d4est_hip_maps.h"
+#include "d4est_hip_tables.h"
 
 namespace d4est_hip {
 
@@ -2325,6 +2327,59 @@ void launch_brick_geometry(d4est_hip_plan* plan, const int* d_elem_dq, double ro
     bk.affine = true;
   }
   HIP_CHECK(hipGetLastError());
+}
+
+// Volume factors of an analytic tree map (d4est_hip_maps.h), DX_compute_method = GEOM_COMPUTE_ANALYTIC: per quadrature node
+// dx/dr from the map's Jacobian, J = det, dr/dx = inverse (src/Mesh/d4est_mesh.c:2637-2680, src/Geometry/d4est_geometry.c:877-976),
+// then J and the pre-combined symmetric metric are written directly.
+__global__ __launch_bounds__(256) void analytic_metric_kernel(const int* __restrict__ elem_ids, const int* __restrict__ qs_list, int n_bucket,
+                                                              int NQ, const double* __restrict__ xq, const double* __restrict__ wq,
+                                                              const CellDesc* __restrict__ cells, TreeMapParams P, double root_len,
+                                                              double* __restrict__ Jq, double* __restrict__ metric) {
+  const int NQ3 = NQ * NQ * NQ;
+  for (int ei = blockIdx.x; ei < n_bucket; ei += gridDim.x) {
+    const int qs = qs_list[ei];
+    const CellDesc cell = cells[elem_ids[ei]];
+    double* m = metric + (size_t)6 * qs;
+    for (int n = threadIdx.x; n < NQ3; n += blockDim.x) {
+      const int iq = n % NQ, jq = (n / NQ) % NQ, kq = n / (NQ * NQ);
+      const double r[3] = {xq[iq], xq[jq], xq[kq]};
+      double dxdr[3][3], inv[3][3];
+      cell_dxdr(P, cell, root_len, r, dxdr);
+      const double J = invert3(dxdr, inv);        // inv[i][j] = d r_i / d x_j
+      const double w3 = wq[kq] * (wq[jq] * wq[iq]) * J;
+      Jq[qs + n] = J;
+      int c = 0;
+      for (int a = 0; a < 3; ++a)
+        for (int b = a; b < 3; ++b) {
+          m[(size_t)c * NQ3 + n] = w3 * (inv[a][0] * inv[b][0] + inv[a][1] * inv[b][1] + inv[a][2] * inv[b][2]);
+          ++c;
+        }
+    }
+  }
+}
+
+void launch_analytic_geometry(d4est_hip_plan* plan, const TreeMapParams& P, const CellDesc* d_cells, double root_len) {
+  if (!plan->d_metric_affine) {
+    HIP_CHECK(hipMalloc(&plan->d_metric_affine, std::max<size_t>((size_t)6 * plan->n_elements, 1) * sizeof(double)));
+    HIP_CHECK(hipMalloc(&plan->d_nonaffine, std::max<size_t>(plan->buckets.size(), 1) * sizeof(int)));
+  }
+  for (Bucket& bk : plan->buckets) {
+    if (bk.n_elem == 0) continue;
+    std::vector<double> x, w;
+    if (plan->quad_type == QUAD_LEGENDRE) Tables1D::gauss(bk.deg_quad, x, w);
+    else Tables1D::lobatto(bk.deg_quad, x, w);
+    double* d_x = nullptr;
+    HIP_CHECK(hipMalloc(&d_x, x.size() * sizeof(double)));
+    HIP_CHECK(hipMemcpyAsync(d_x, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, plan->stream));
+    const int grid = bk.n_elem < 4096 ? bk.n_elem : 4096;
+    hipLaunchKernelGGL(analytic_metric_kernel, dim3(grid), dim3(256), 0, plan->stream, plan->d_elem_ids + bk.elem_offset,
+                       plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.NQ, d_x, bk.d_w, d_cells, P, root_len, plan->d_J, plan->d_metric);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(plan->stream));
+    HIP_CHECK(hipFree(d_x));
+    bk.affine = false;      // curved: the metric is streamed
+  }
 }
 
 // d4est_operators_apply_slicer / _apply_lift (src/dGMath/d4est_operators.c:1521-1582, :1454-1519), batched: the trace of a volume

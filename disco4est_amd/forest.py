@@ -692,6 +692,12 @@ class ForestMesh:
             out.update(side_hang=side_hang, side_sub=side_sub, side_nbr4=side_nbr4, side_orientation=side_orientation)
         return out
 
+    def cells(self, global_ids=None):
+        """(tree, q[n,3], dq) of the local elements (or of the given global ids, e.g. sides["ghost_global_ids"]) in units of the fine
+        grid, root length = self.nf: d4est_element_data_t::tree, ::q, ::dq for d4est_hip_plan_set_geometry_analytic"""
+        g = self.elements if global_ids is None else np.asarray(global_ids, dtype=np.int64)
+        return (self._tree_all[g].astype(np.int32), self._org_all[g].astype(np.int32), self._size_all[g].astype(np.int32))
+
     def gather_ghost(self, sides, u_global):
         out = np.empty(sides["ghost_nodes"])
         for i, g in enumerate(sides["ghost_global_ids"]):

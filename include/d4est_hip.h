@@ -119,6 +119,24 @@ void d4est_hip_plan_set_geometry_numerical(d4est_hip_plan_t* plan, const double*
 void d4est_hip_plan_set_geometry_brick(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents);
 void d4est_hip_plan_set_mortar_geometry_brick(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents);
 
+/* Geometric factors of an ANALYTIC tree map generated on the device (DX_compute_method =
+ * GEOM_COMPUTE_ANALYTIC, JAC_compute_method = GEOM_COMPUTE_NUMERICAL as the reference requires, src/Mesh/d4est_mesh.c:2637-2680,
+ * :858-1108): the host hands over only where every element sits in the forest -- d4est_element_data_t::tree, ::q[3], ::dq
+ * (src/Mesh/d4est_element_data.h:13-48), p4est integer coordinates, root_len = P4EST_ROOT_LEN -- instead of 96 B per quadrature node
+ * and 24 doubles per mortar node.  geom_type / params:
+ *   D4EST_HIP_GEOM_CUBED_SPHERE_7TREE  [geometry] name = cubed_sphere_7tree (src/Geometry/d4est_geometry_cubed_sphere.c:498-580,
+ *                                      :1884-1899): params = {R0, R1, compactify_inner_shell}; trees 0..5 wedges, 6 the centre cube
+ * The mortar variant is called where d4est_hip_plan_set_mortar_geometry would be (after plan_set_hanging / plan_set_faces /
+ * plan_set_sipg), needs the same three arrays for the ghost elements (order of ghost_deg), follows faces between trees through
+ * side_reorder / side_orientation and hanging faces through the half-size virtual children of the big element
+ * (src/Mesh/d4est_mortars.c:419-468); face_h_type FACE_H_EQ_J_DIV_SJ_QUAD. */
+#define D4EST_HIP_GEOM_CUBED_SPHERE_7TREE 1
+void d4est_hip_plan_set_geometry_analytic(d4est_hip_plan_t* plan, int geom_type, const double* params, const int* elem_tree,
+                                          const int* elem_q, const int* elem_dq, double root_len);
+void d4est_hip_plan_set_mortar_geometry_analytic(d4est_hip_plan_t* plan, int geom_type, const double* params, const int* elem_tree,
+                                                 const int* elem_q, const int* elem_dq, const int* ghost_tree, const int* ghost_q,
+                                                 const int* ghost_dq, double root_len);
+
 /* ---- volume kernels (device vectors of local_nodes doubles) ---------------------- */
 /* Au = K u : replaces d4est_laplacian_apply_stiffness_matrix (src/dGMath/d4est_laplacian.c:198-234)
  * = loop of d4est_quadrature_apply_stiffness_matrix (src/Quadrature/d4est_quadrature.c:263-382).

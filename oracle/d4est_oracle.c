@@ -896,3 +896,58 @@ void oracle_mesh_compute_geometry_numerical(int quad_type, int n_elements, const
     free(tmp);
   }
 }
+
+/* ---- cubed_sphere_7tree geometry (src/Geometry/d4est_geometry_cubed_sphere.c:498-580): X restated; DX by complex-step
+ * differentiation of X (exact to rounding, no subtractive cancellation) instead of the reference's machine-generated closed
+ * forms (:846-915, :1751-1830) -- an independent check of the chain-rule Jacobian the engine evaluates on the device. */
+#include <complex.h>
+static void cubed_sphere_7tree_X_c(int tree, double R0, double R1, int compactify, const double complex tc[3], double complex xyz[3]) {
+  double complex abc[3];
+  if (tree == 6) {                                    /* centre cube: vertices -1..1, scaled by Clength = R0 / sqrt(3) */
+    double Clength = R0 / sqrt(3.);
+    for (int d = 0; d < 3; d++) xyz[d] = (2. * tc[d] - 1.) * Clength;
+    return;
+  }
+  abc[0] = 2. * tc[0] - 1.;                           /* d4est_geometry_octree_to_vertex on the wedge's vertices [-1,1]^2 x [1,2] */
+  abc[1] = 2. * tc[1] - 1.;
+  abc[2] = tc[2] + 1.;
+  double complex R;
+  if (compactify) {
+    double m = (2. - 1.) / ((1. / R1) - (1. / R0));
+    double t = (1. * R0 - 2. * R1) / (R0 - R1);
+    R = m / (abc[2] - t);
+  } else {
+    R = R0 * (2. - abc[2]) + R1 * (abc[2] - 1.);
+  }
+  double complex p = 2. - abc[2];
+  double complex tanx = ctan(abc[0] * M_PI_4);
+  double complex tany = ctan(abc[1] * M_PI_4);
+  double complex x = p * abc[0] + (1. - p) * tanx;
+  double complex y = p * abc[1] + (1. - p) * tany;
+  double complex q = R / csqrt(1. + (1. - p) * (tanx * tanx + tany * tany) + 2. * p);
+  switch (tree % 6) {
+    case 0: xyz[0] = +q * x; xyz[1] = -q;     xyz[2] = +q * y; break;   /* front */
+    case 1: xyz[0] = +q * x; xyz[1] = +q * y; xyz[2] = +q;     break;   /* top */
+    case 2: xyz[0] = +q * x; xyz[1] = +q;     xyz[2] = -q * y; break;   /* back */
+    case 3: xyz[0] = +q;     xyz[1] = -q * x; xyz[2] = -q * y; break;   /* right */
+    case 4: xyz[0] = -q * y; xyz[1] = -q * x; xyz[2] = -q;     break;   /* bottom */
+    case 5: xyz[0] = -q;     xyz[1] = -q * x; xyz[2] = +q * y; break;   /* left */
+  }
+}
+
+void oracle_cubed_sphere_7tree_X(int tree, double R0, double R1, int compactify, const double tcoords[3], double xyz[3]) {
+  double complex tc[3] = {tcoords[0], tcoords[1], tcoords[2]}, out[3] = {0., 0., 0.};
+  cubed_sphere_7tree_X_c(tree, R0, R1, compactify, tc, out);
+  for (int d = 0; d < 3; d++) xyz[d] = creal(out[d]);
+}
+
+/* dxyz[i][j] = d x_i / d tcoords_j */
+void oracle_cubed_sphere_7tree_DX(int tree, double R0, double R1, int compactify, const double tcoords[3], double dxyz[9]) {
+  const double h = 1e-30;
+  for (int j = 0; j < 3; j++) {
+    double complex tc[3] = {tcoords[0], tcoords[1], tcoords[2]}, out[3] = {0., 0., 0.};
+    tc[j] += h * I;
+    cubed_sphere_7tree_X_c(tree, R0, R1, compactify, tc, out);
+    for (int i = 0; i < 3; i++) dxyz[3 * i + j] = cimag(out[i]) / h;
+  }
+}

@@ -153,6 +153,11 @@ void oracle_mesh_compute_geometry_numerical(int quad_type, int n_elements, const
                                             const int* quad_stride, int local_nodes, int local_nodes_quad, const double* xyz,
                                             double* J_quad, double* rst_xyz_quad);
 
+/* cubed_sphere_7tree map (src/Geometry/d4est_geometry_cubed_sphere.c:498-580) at tree coordinates in [0,1]^3 and its Jacobian by
+ * complex-step differentiation */
+void oracle_cubed_sphere_7tree_X(int tree, double R0, double R1, int compactify, const double tcoords[3], double xyz[3]);
+void oracle_cubed_sphere_7tree_DX(int tree, double R0, double R1, int compactify, const double tcoords[3], double dxyz[9]);
+
 /* ---- smoother inner loops (oracle/d4est_oracle_solver.c) ---- */
 void oracle_set_aij_operator(int quad_type, int n_elements, const int* deg, const int* deg_quad, const int* nodal_stride,
                              const int* quad_stride, int local_nodes, int local_nodes_quad, const double* J_quad,

@@ -234,3 +234,23 @@ def test_rank_count_invariance_through_oriented_faces(oracle):
             got[m.global_nodal_offset:m.global_nodal_offset + m.local_nodes] = Au
         assert n_oriented_ghost > 0
         assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_cubed_sphere_jacobian_chain_rule_vs_complex_step(oracle):
+    """The chain-rule Jacobian of the 7-tree cubed-sphere map (forest.CubedSphere7Map.jacobian here, d4est_hip_maps.h on the device)
+    against the oracle's complex-step derivative of the reference's X (src/Geometry/d4est_geometry_cubed_sphere.c:498-580), and X itself"""
+    import ctypes
+    dp = ctypes.POINTER(ctypes.c_double)
+    xi = np.array([[0.3, 0.6, 0.2], [0.9, 0.1, 0.7], [0.5, 0.5, 1.0], [0.0, 1.0, 0.0]])
+    for comp in (0, 1):
+        mp = F.CubedSphere7Map(1.0, 3.0, compactify=bool(comp))
+        for t in range(7):
+            D = mp.jacobian(t, xi)
+            X = mp.x(t, xi)
+            for k in range(xi.shape[0]):
+                tc = np.ascontiguousarray(xi[k])
+                out, x = np.zeros(9), np.zeros(3)
+                oracle.lib.oracle_cubed_sphere_7tree_DX(t, ctypes.c_double(1.0), ctypes.c_double(3.0), comp, tc.ctypes.data_as(dp), out.ctypes.data_as(dp))
+                oracle.lib.oracle_cubed_sphere_7tree_X(t, ctypes.c_double(1.0), ctypes.c_double(3.0), comp, tc.ctypes.data_as(dp), x.ctypes.data_as(dp))
+                assert np.abs(D[k] - out.reshape(3, 3)).max() <= 2e-14 * max(1.0, np.abs(out).max())
+                assert np.abs(X[k] - x).max() <= 1e-15 * max(1.0, np.abs(x).max())

@@ -305,3 +305,52 @@ def test_trace_exchange_through_oriented_and_hanging_tree_faces(gpu, hiplib, ora
         plan.destroy()
     assert np.isfinite(got).all()
     assert _rel(got, ref) <= RTOL
+
+
+@pytest.mark.parametrize("deg,inc,level,refine,compactify,world", [
+    (3, 0, 1, None, False, 1), (2, 1, 0, [1, 0, 0, 0, 0, 0, 1], True, 1), (7, 0, 0, None, False, 1), (9, 0, 0, [0, 0, 0, 1, 0, 0, 0], False, 1),
+    (15, 0, 0, None, True, 1), (4, 0, 0, [0, 0, 1, 0, 0, 0, 1], False, 3),
+])
+def test_cubed_sphere_factors_generated_on_the_device(gpu, hiplib, oracle, deg, inc, level, refine, compactify, world):
+    """SURVEY section 8f rank 4 for config 5's geometry: volume AND mortar factors of the cubed sphere from the analytic map on the
+    device (d4est_hip_plan_set_geometry_analytic / _set_mortar_geometry_analytic: the host passes tree, q, dq per element) -- through
+    oriented tree faces, hanging faces and ghost elements -- against the oracle fed with the host-computed arrays."""
+    import torch
+    from disco4est_amd import Plan, parallel as P
+    conn = F.cubed_sphere_7tree_connectivity()
+    R0, R1 = 1.0, 2.5
+    mp = F.CubedSphere7Map(R0, R1, compactify)
+    mg = F.ForestMesh(conn, level, deg, mp, refine=refine, deg_quad_inc=inc)
+    parts = P.partition_by_dofs(mg.deg_global, world)
+    ug = mg.field()
+    Jg, rstg = mg.geometry(); sg = mg.build_sides()
+    ref_full = oracle.apply_aij(mg, Jg, rstg, sg, ug, penalty_prefactor=7.5, nthreads=8)
+    mb = _Mailbox()
+    ranks = []
+    for r, (first, count) in enumerate(parts):
+        m = F.ForestMesh(conn, level, deg, mp, refine=refine, deg_quad_inc=inc, first=first, count=count)
+        s = m.build_sides()
+        tree, q, dq = m.cells()
+        params = (R0, R1, float(compactify))
+        plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, m.quad_type)
+        plan.set_geometry_analytic(1, params, tree, q, dq, m.nf)
+        plan.set_faces(s, 7.5, 0, analytic=(1, params, tree, q, dq, m.nf, m.cells(s["ghost_global_ids"])))
+        ex = P.TraceExchange(P.plan_schedule(plan, m, s, parts), _LocalTransport(r, mb), plan.copy_blocks, gpu)
+        du = _t(m.field(), gpu)
+        tr = torch.empty(plan.trace_size, dtype=torch.float64, device=gpu)
+        gt = torch.full((max(plan.ghost_trace_size, 1),), float("nan"), dtype=torch.float64, device=gpu)
+        ranks.append((m, plan, ex, du, tr, gt))
+    for m, plan, ex, du, tr, gt in ranks:
+        plan.compute_face_traces(du, tr)
+        ex.begin(tr)
+    for m, plan, ex, du, tr, gt in ranks:
+        ex.end(gt)
+        dAu = torch.full_like(du, float("nan"))
+        plan.apply_stiffness_matrix(du, dAu)
+        # the volume factors alone: stiffness against the oracle with host arrays
+        J, rst = m.geometry()
+        assert _rel(dAu.cpu().numpy(), oracle.apply_stiffness(m, J, rst, m.field(), nthreads=8)) <= RTOL
+        plan.apply_flux(tr, gt, dAu)
+        sl = slice(m.global_nodal_offset, m.global_nodal_offset + m.local_nodes)
+        assert _rel(dAu.cpu().numpy(), ref_full[sl]) <= RTOL
+        plan.destroy()
