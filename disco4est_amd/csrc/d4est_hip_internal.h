@@ -179,6 +179,7 @@ void faces_destroy(d4est_hip_plan* plan);
 // traces, volume term, (exchange), flux; lhs_term: also the optional zeroth-order term of plan_set_lhs_coefficient
 void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const ChebyFuse* cf = nullptr, bool lhs_term = true);
 void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double* r);   // r = rhs - Au
+void launch_residual_inplace(d4est_hip_plan* plan, int n, const double* rhs, double* r);              // r = rhs - r
 void add_lhs_mass_term(d4est_hip_plan* plan, const double* u, double* Au);   // Au += V^T W J c V u when a coefficient is set
 void launch_copy_blocks(hipStream_t stream, int n_blocks, const double* src, const long long* src_off, double* dst,
                         const long long* dst_off, const int* len);

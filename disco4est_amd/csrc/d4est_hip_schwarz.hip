@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void schwarz_cg_kernel(const VirtDesc* __restr
   __shared__ double red[256];
   const int s = blockIdx.x;
   if (!active[s]) return;
+  if (threadIdx.x == 0) atomicMax(n_active + 1, it + 1);   // this sweep did work: the reference's loop was still running
   const int v0 = sub_first[s], v1 = sub_first[s + 1];
   double acc = 0.0;
   for (int v = v0; v < v1; ++v) {
@@ -248,7 +249,7 @@ static void ensure_workspace(d4est_hip_schwarz* sz) {
   HIP_CHECK(hipMalloc(&sz->d_tol, ns * sizeof(double)));
   HIP_CHECK(hipMalloc(&sz->d_active, ns * sizeof(int)));
   HIP_CHECK(hipMalloc(&sz->d_final_iter, ns * sizeof(int)));
-  HIP_CHECK(hipMalloc(&sz->d_n_active, sizeof(int)));
+  HIP_CHECK(hipMalloc(&sz->d_n_active, 2 * sizeof(int)));   // [0] subdomains still iterating, [1] sweeps in which any did
 }
 
 static void ensure_zero_ghost(d4est_hip_schwarz* sz) {
@@ -411,26 +412,32 @@ int d4est_hip_schwarz_iterate(d4est_hip_schwarz_t* sz, double* u_dev, const doub
   ensure_workspace(sz);
   ensure_zero_ghost(sz);
   hipStream_t st = sz->plan->stream;
-  HIP_CHECK(hipMemsetAsync(sz->d_n_active, 0, sizeof(int), st));
+  HIP_CHECK(hipMemsetAsync(sz->d_n_active, 0, 2 * sizeof(int), st));
   hipLaunchKernelGGL(schwarz_cg_init_kernel, dim3(sz->n_sub), dim3(256), 0, st, sz->d_vd, sz->d_sub_first, r_dev, sz->d_du, sz->d_r,
                      sz->d_d, sz->d_delta, sz->d_tol, sz->d_active, sz->d_final_iter, sz->d_n_active, subdomain_iter, subdomain_atol,
                      subdomain_rtol);
   HIP_CHECK(hipGetLastError());
-  int sweeps = 0;
+  // A subdomain that has met its tolerance is frozen on the device (its workgroup returns at once), so sweeps past the point where
+  // the reference's loops have all broken are no-ops: the host looks at the "still iterating" counter only before the first sweep
+  // and then every 8th, instead of synchronising before every sweep; the number of sweeps that did work is counted on the device.
   for (int it = 0; it < subdomain_iter; ++it) {
-    int n_active = 0;
-    HIP_CHECK(hipMemcpyAsync(&n_active, sz->d_n_active, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (n_active == 0) break;  // every subdomain has left its loop
+    if (it % 8 == 0) {
+      int n_active = 0;
+      HIP_CHECK(hipMemcpyAsync(&n_active, sz->d_n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (n_active == 0) break;  // every subdomain has left its loop
+    }
     d4est_hip_apply_aij(sz->plan, sz->d_d, sz->d_zero_ghost, sz->d_Ad);
     add_lhs_mass_term(sz->plan, sz->d_d, sz->d_Ad);   // zeroth-order term of a linearised problem (plan_set_lhs_coefficient on the subdomain plan)
     hipLaunchKernelGGL(schwarz_cg_kernel, dim3(sz->n_sub), dim3(256), 0, st, sz->d_vd, sz->d_sub_first, sz->d_du, sz->d_r, sz->d_d,
                        sz->d_Ad, sz->d_delta, sz->d_tol, sz->d_active, sz->d_final_iter, sz->d_n_active, it);
     HIP_CHECK(hipGetLastError());
-    ++sweeps;
   }
   d4est_hip_schwarz_add_correction(sz, sz->d_du, u_dev);
-  return sweeps;
+  int counters[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(counters, sz->d_n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return counters[1];
 }
 
 void d4est_hip_schwarz_smooth(d4est_hip_schwarz_t* sz, d4est_hip_plan_t* mesh_plan, double* u_dev, const double* rhs_dev, double* r_dev,
@@ -442,11 +449,11 @@ void d4est_hip_schwarz_smooth(d4est_hip_schwarz_t* sz, d4est_hip_plan_t* mesh_pl
   // d4est_solver_multigrid_smoother_schwarz, src/Solver/d4est_solver_multigrid_smoother_schwarz.c:98-196; r doubles as the Au scratch
   for (int i = 0; i < smoother_iterations; ++i) {
     apply_operator(mesh_plan, u_dev, r_dev);
-    launch_residual(mesh_plan, mesh_plan->local_nodes, rhs_dev, r_dev, r_dev);
+    launch_residual_inplace(mesh_plan, mesh_plan->local_nodes, rhs_dev, r_dev);
     d4est_hip_schwarz_iterate(sz, u_dev, r_dev, subdomain_iter, subdomain_atol, subdomain_rtol);
   }
   apply_operator(mesh_plan, u_dev, r_dev);
-  launch_residual(mesh_plan, mesh_plan->local_nodes, rhs_dev, r_dev, r_dev);
+  launch_residual_inplace(mesh_plan, mesh_plan->local_nodes, rhs_dev, r_dev);
 }
 
 void d4est_hip_schwarz_get_info(d4est_hip_schwarz_t* sz, int* final_iter_host, double* final_res_host) {

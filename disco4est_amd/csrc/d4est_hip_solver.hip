@@ -39,6 +39,11 @@ __global__ __launch_bounds__(256) void residual_kernel(int n, const double* __re
   }
 }
 
+// r = rhs - r, in place (the Schwarz smoother keeps A u in the residual vector): no aliased __restrict__ pair
+__global__ __launch_bounds__(256) void residual_inplace_kernel(int n, const double* __restrict__ rhs, double* __restrict__ r) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) r[i] = __dadd_rn(rhs[i], __dmul_rn(-1.0, r[i]));
+}
+
 __global__ __launch_bounds__(256) void add_kernel(int n, const double* __restrict__ x, double* __restrict__ y) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] = __dadd_rn(y[i], x[i]);
 }
@@ -194,6 +199,11 @@ void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const doubl
   HIP_CHECK(hipGetLastError());
 }
 
+void launch_residual_inplace(d4est_hip_plan* plan, int n, const double* rhs, double* r) {
+  if (n > 0) hipLaunchKernelGGL(residual_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, r);
+  HIP_CHECK(hipGetLastError());
+}
+
 static void cheby_iterate_body(d4est_hip_plan* plan, double* u, const double* rhs, double* Au, double* r, int iter, double lmin,
                                double lmax, int compute_residual_at_end);
 
@@ -213,6 +223,12 @@ void cheby_iterate(d4est_hip_plan* plan, double* u, const double* rhs, double* A
   if (!same) {
     if (plan->cheby_graph) { HIP_CHECK(hipGraphExecDestroy(plan->cheby_graph)); plan->cheby_graph = nullptr; }
     if (!plan->has_faces) D4EST_HIP_ABORT("smoother: the plan has no faces (plan_set_faces)");
+    // every lazy allocation of the operator (scratch of the generic kernels, the work vector of the zeroth-order term, trace buffers)
+    // must exist before the capture starts -- hipMalloc / hipFree are illegal inside it.  One throw-away apply on the solver's own
+    // work vectors takes exactly the code path the captured loop will take; it happens once per captured argument set.
+    HIP_CHECK(hipMemsetAsync(plan->d_work_d, 0, std::max<size_t>((size_t)plan->local_nodes, 1) * sizeof(double), plan->stream));
+    apply_operator(plan, plan->d_work_d, plan->d_work_r);
+    HIP_CHECK(hipStreamSynchronize(plan->stream));
     hipGraph_t g = nullptr;
     HIP_CHECK(hipStreamBeginCapture(plan->stream, hipStreamCaptureModeThreadLocal));
     cheby_iterate_body(plan, u, rhs, Au, r, iter, lmin, lmax, compute_residual_at_end);

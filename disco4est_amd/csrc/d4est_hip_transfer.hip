@@ -177,6 +177,11 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
     co += (long long)(dH + 1) * (dH + 1) * (dH + 1);
   }
   item_first[n_items] = (int)(child.size() / 8);
+  // the restriction / projection kernels keep three fields of max_n^3 doubles in the LDS (160 KB per workgroup): degrees up to 17.
+  // Refused here, once, with the reason -- not at the first restrict call in the middle of a V-cycle.
+  if ((size_t)3 * t->max_n * t->max_n * t->max_n * sizeof(double) > 160 * 1024)
+    D4EST_HIP_ABORT("transfer_create: degree %d exceeds the transfer kernels' limit of 17 (three %d^3 fields do not fit the 160 KB LDS)",
+                    t->max_n - 1, t->max_n);
   t->n_children = item_first[n_items];
   t->coarse_nodes = co;
   t->fine_nodes = fo;

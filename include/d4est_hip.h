@@ -379,7 +379,8 @@ void d4est_hip_plan_synchronize(d4est_hip_plan_t* plan);
  * item k has hrefine[k] = 0 (one fine element of degree degh[8k] <-> coarse element of degree degH[k]; equal degrees copy) or 1
  * (eight children in z-order with degrees degh[8k..8k+7] <-> their parent); d4est's third case (an element that is not coarsened,
  * copied child by child) is hrefine = 0 with degh = degH.  Both vectors are element-ordered and contiguous in item order, like the
- * reference's fine_stride / coarse_stride.  degh >= degH as the reference asserts (d4est_operators.c:379). */
+ * reference's fine_stride / coarse_stride.  degh >= degH as the reference asserts (d4est_operators.c:379).  Degrees up to 17: the
+ * restriction kernels hold three (deg+1)^3 fields in the 160 KB LDS; d4est_hip_transfer_create aborts above that. */
 typedef struct d4est_hip_transfer d4est_hip_transfer_t;
 d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine, const int* degH, const int* degh);
 void d4est_hip_transfer_destroy(d4est_hip_transfer_t* t);
