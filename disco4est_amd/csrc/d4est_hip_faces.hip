@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
           const double res = __dadd_rn(cf.rhs[o], __dmul_rn(-1.0, a));
           const double ri = __dmul_rn(cf.alpha, res);
           const double pi = __dadd_rn(__dmul_rn(cf.beta, cf.p[o]), ri);
-          cf.r[o] = ri;
+          if (cf.r) cf.r[o] = ri;
           cf.p[o] = pi;
           cf.u[o] = __dadd_rn(cf.u[o], pi);
         }
@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
         const double res = __dadd_rn(cf.rhs[o], __dmul_rn(-1.0, a));
         const double ri = __dmul_rn(cf.alpha, res);
         const double pi = __dadd_rn(__dmul_rn(cf.beta, cf.p[o]), ri);
-        cf.r[o] = ri;
+        if (cf.r) cf.r[o] = ri;
         cf.p[o] = pi;
         cf.u[o] = __dadd_rn(cf.u[o], pi);
       }

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void cheby_update_kernel(int n, const double* 
     const double res = __dadd_rn(rhs[i], __dmul_rn(-1.0, Au[i]));
     const double ri = __dmul_rn(alpha, res);
     const double pi = __dadd_rn(__dmul_rn(beta, p[i]), ri);
-    r[i] = ri;
+    if (r) r[i] = ri;
     p[i] = pi;
     u[i] = __dadd_rn(u[i], pi);
   }
@@ -253,13 +253,16 @@ static void cheby_iterate_body(d4est_hip_plan* plan, double* u, const double* rh
     else if (i == 1) alpha = 2. * d / (2 * d * d - c * c);
     else alpha = 1. / (d - (alpha * c * c / 4.));
     beta = alpha * d - 1.;
+    // r = alpha (rhs - A u) is observable only after the LAST iteration, and only when the caller does not ask for the true
+    // residual at the end (which overwrites it): every other iteration skips the store (one vector of HBM writes per iteration)
+    double* r_out = (i == iter - 1 && compute_residual_at_end != 1) ? r : nullptr;
     if (fuse) {   // the update rides in the flux kernel's epilogue: 3 kernels per iteration instead of 4
       ChebyFuse cf;
-      cf.rhs = rhs; cf.p = plan->d_work_p; cf.u = u; cf.r = r; cf.alpha = alpha; cf.beta = beta;
+      cf.rhs = rhs; cf.p = plan->d_work_p; cf.u = u; cf.r = r_out; cf.alpha = alpha; cf.beta = beta;
       apply_operator(plan, u, Au, &cf);
     } else {
       apply_operator(plan, u, Au);
-      if (n > 0) hipLaunchKernelGGL(cheby_update_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, Au, alpha, beta, r, plan->d_work_p, u);
+      if (n > 0) hipLaunchKernelGGL(cheby_update_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, Au, alpha, beta, r_out, plan->d_work_p, u);
     }
   }
   if (compute_residual_at_end == 1) {
