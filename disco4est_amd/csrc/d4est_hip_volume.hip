@@ -1458,7 +1458,8 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave_eo_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// N = NQ = 16 (p = 15) on the FP64 matrix cores: the whole sum-factorised apply as chains of v_mfma_f64_16x16x4
+// N = NQ = 16 (p = 15) on the FP64 matrix cores (N = 13 ... 15 run too, operators zero-padded to 16, but the padding and the idle
+// waves eat the gain -- measured 32 / 47 / 36 GDoF/s against 41 / 46 / 34 of the vector-ALU kernel -- so only p = 15 selects it by itself): the whole sum-factorised apply as chains of v_mfma_f64_16x16x4
 // (D[16x16] += A[16x4] B[4x16]; lane l = (q = l >> 4, c = l & 15) holds A[row c][k q], B[k q][col c] and, in register v,
 // D[row 4 v + q][col c]).  Register v of a result tile IS the B operand of k-step v of a following product that sums over
 // the tile's ROW index, so every second contraction takes its input straight from the accumulators:
@@ -1483,6 +1484,7 @@ struct Mfma16Cfg {
   static constexpr size_t LDS_BYTES = (size_t)3 * FS * sizeof(double);
 };
 
+template <int N>
 __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* __restrict__ u, double* __restrict__ Au,
                                                                    const double* __restrict__ metric, const int* __restrict__ ns_list,
                                                                    const int* __restrict__ qs_list, int n_bucket,
@@ -1494,10 +1496,11 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
   double Bn[4], Gn[4], Bt[4], Gt[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    Bn[s] = Bop[c * 16 + 4 * s + q];
-    Gn[s] = Gop[c * 16 + 4 * s + q];
-    Bt[s] = Bop[(4 * s + q) * 16 + c];
-    Gt[s] = Gop[(4 * s + q) * 16 + c];
+    const bool in = (c < N) && (4 * s + q < N);     // N < 16: operators zero-padded to 16 x 16
+    Bn[s] = in ? Bop[c * N + 4 * s + q] : 0.0;
+    Gn[s] = in ? Gop[c * N + 4 * s + q] : 0.0;
+    Bt[s] = in ? Bop[(4 * s + q) * N + c] : 0.0;
+    Gt[s] = in ? Gop[(4 * s + q) * N + c] : 0.0;
   }
   const mfma_d4v zero = {0.0, 0.0, 0.0, 0.0};
   // the wave's two slabs of u, as A operands [row j = c][k i = 4 s + q]
@@ -1508,7 +1511,8 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) xa[h][s] = ue[(4 * s + q) + 16 * c + 256 * (2 * wave + h)];
+      for (int s = 0; s < 4; ++s)
+        xa[h][s] = (c < N && 4 * s + q < N && 2 * wave + h < N) ? ue[(4 * s + q) + N * c + N * N * (2 * wave + h)] : 0.0;
   }
   for (; e < n_bucket; e += gridDim.x) {
     const int ns = ns_list[e];
@@ -1518,11 +1522,13 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
 #pragma unroll
     for (int m = 0; m < 6; ++m)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) mt[m][v] = me[m * 4096 + c + 16 * (2 * wave) + 256 * (4 * v + q)];
+      for (int v = 0; v < 4; ++v)
+        mt[m][v] = (c < N && 2 * wave < N && 4 * v + q < N) ? me[m * (N * N * N) + c + N * (2 * wave) + N * N * (4 * v + q)] : 0.0;
     // ---- forward slab stage: two slabs, interleaved chains
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = 2 * wave + h;
+      if (k >= N) continue;
       mfma_d4v pb = zero, pg = zero;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -1552,7 +1558,8 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) xa[h][s] = un[(4 * s + q) + 16 * c + 256 * (2 * wave + h)];
+          for (int s = 0; s < 4; ++s)
+            xa[h][s] = (c < N && 4 * s + q < N && 2 * wave + h < N) ? un[(4 * s + q) + N * c + N * N * (2 * wave + h)] : 0.0;
       }
     }
     __syncthreads();
@@ -1561,10 +1568,12 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
 #pragma unroll
     for (int m = 0; m < 6; ++m)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) mt2[m][v] = me[m * 4096 + c + 16 * (2 * wave + 1) + 256 * (4 * v + q)];
+      for (int v = 0; v < 4; ++v)
+        mt2[m][v] = (c < N && 2 * wave + 1 < N && 4 * v + q < N) ? me[m * (N * N * N) + c + N * (2 * wave + 1) + N * N * (4 * v + q)] : 0.0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int ct = 2 * wave + h;
+      if (ct >= N) continue;
       const double* z = smem + JS * ct + c;
       mfma_d4v tr = zero, ts = zero, tt = zero;
 #pragma unroll
@@ -1607,6 +1616,7 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = 2 * wave + h;
+      if (k >= N) continue;
       const double* w = smem + k * KS + JS * c + q;      // A operand [row j' = c][k i' = 4 s + q]
       mfma_d4v e1 = zero, e2 = zero, e3 = zero;
 #pragma unroll
@@ -1622,9 +1632,10 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
         r1 = D4_MFMA(Bt[s], e13[s], r1);
         r2 = D4_MFMA(Gt[s], e2[s], r2);
       }
-      double* out = Au + ns + c + 256 * k;
+      double* out = Au + ns + c + N * N * k;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) out[16 * (4 * v + q)] = r1[v] + r2[v];
+      for (int v = 0; v < 4; ++v)
+        if (c < N && 4 * v + q < N) out[N * (4 * v + q)] = r1[v] + r2[v];
     }
     __syncthreads();   // the next element's forward stage overwrites the image
   }
@@ -2103,12 +2114,18 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
 }
 
 static void launch_stiffness_mfma16(d4est_hip_plan* plan, const Bucket& bk, const double* u, double* Au) {
-  std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_mfma16_kernel (512 threads, v_mfma_f64_16x16x4)");
-  set_lds_limit(stiffness_mfma16_kernel, Mfma16Cfg::LDS_BYTES);
+  std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_mfma16_kernel<%d> (512 threads, v_mfma_f64_16x16x4)", bk.N);
   const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
   const int grid = bk.n_elem < cus ? bk.n_elem : cus;   // one 102 KB workgroup per CU, persistent over the bucket
-  hipLaunchKernelGGL(stiffness_mfma16_kernel, dim3(grid), dim3(512), Mfma16Cfg::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
-                     plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);
+  auto go = [&](auto kern) {
+    set_lds_limit(kern, Mfma16Cfg::LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Mfma16Cfg::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
+                       plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);
+  };
+  if (bk.N == 16) go(stiffness_mfma16_kernel<16>);
+  else if (bk.N == 15) go(stiffness_mfma16_kernel<15>);
+  else if (bk.N == 14) go(stiffness_mfma16_kernel<14>);
+  else go(stiffness_mfma16_kernel<13>);
 }
 
 void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
@@ -2133,7 +2150,7 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
       const bool use_eo = kEven && bk.d_EBf && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0;                  \
       if (kWave && use_wave) {                                               \
         launch_stiffness_wave<N_, (kWave ? NQ_ : N_)>(plan, bk, use_pf, u, Au);                                 \
-      } else if (N_ == 16 && NQ_ == 16 && (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] == 2 || plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] < 0)) { \
+      } else if (N_ >= 13 && N_ <= 16 && NQ_ == N_ && (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] == 2 || (N_ == 16 && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] < 0))) { \
         launch_stiffness_mfma16(plan, bk, u, Au);                                                               \
       } else if (!kWave && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] != 0) {                                  \
         /* p >= 8: multi-wave workgroup, two LDS fields (sequential field hand-off) -> 1.5x the residency */  \

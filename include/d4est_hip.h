@@ -79,7 +79,7 @@ enum d4est_hip_tuning_key {
   D4EST_HIP_TUNE_STIFFNESS_WAVE = 1,     /* where (deg_quad+1)^2 <= 64: 0 multi-buffer kernel, 1 single-wavefront kernel, 2 two-wavefront kernel with metric prefetch, 3 single-wavefront kernel with pipelined operator loads (auto default for odd N), 11 even-odd single-wavefront kernel (auto default for even N, NQ); every value computes the same stiffness apply (tests/test_volume_gpu.py) */
   D4EST_HIP_TUNE_STIFFNESS_STAGGER = 2,  /* single-wave kernel: delay (units of 1024 cycles) of every other resident workgroup row */
   D4EST_HIP_TUNE_FLUX_FAST = 3,          /* 0: always the generic flux kernel; else the wave-per-face kernel where all degrees <= 7 */
-  D4EST_HIP_TUNE_STIFFNESS_BIGP = 4,     /* p >= 8: 0 three-field kernel, 1 two-field multi-wave kernel (default except p = 15), 2 at p = 15 (deg_quad = 15): the FP64 matrix-core kernel (v_mfma_f64_16x16x4; default there) */
+  D4EST_HIP_TUNE_STIFFNESS_BIGP = 4,     /* p >= 8: 0 three-field kernel, 1 two-field multi-wave kernel (default except p = 15), 2 at p = 12 ... 15 (deg_quad = deg): the FP64 matrix-core kernel (v_mfma_f64_16x16x4; default at p = 15, where no padding is needed) */
   D4EST_HIP_TUNE_OVERLAP_TRACES = 5,     /* 1: the trace kernel runs on a side stream beside the volume kernel (default off: the event waits cost more) */
   D4EST_HIP_TUNE_STIFFNESS_EO = 6,       /* multi-buffer / multi-wave kernels: 0 plain contractions, else (default) even-odd contractions where deg+1 and deg_quad+1 are even */
   D4EST_HIP_TUNE_AFFINE = 7,             /* 0: always stream the per-node metric (the reference's general path); else (default) buckets whose elements all have a node-independent J (dr/dx)(dr/dx)^T (detected in plan_set_geometry, 4 ulp) rebuild the metric from 6 numbers per element */

@@ -80,7 +80,7 @@ def test_stiffness_kernel_variants(gpu, hiplib, oracle, deg, inc, tune):
     assert _rel(dAu.cpu().numpy(), ref) <= RTOL
 
 
-@pytest.mark.parametrize("deg,inc", [(8, 0), (9, 0), (11, 0), (15, 0), (8, 1)])
+@pytest.mark.parametrize("deg,inc", [(8, 0), (9, 0), (11, 0), (12, 0), (13, 0), (14, 0), (15, 0), (8, 1)])
 @pytest.mark.parametrize("bigp", [0, 1, 2])
 def test_stiffness_high_p_variants(gpu, hiplib, oracle, deg, inc, bigp):
     import torch
