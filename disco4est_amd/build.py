@@ -15,6 +15,7 @@ COMPAT_LIB = os.path.join(HERE, "libd4est_hip_compat.so")
 COMPAT_SRC = "d4est_hip_compat.cpp"
 SOURCES = [
     "d4est_hip_tables.cpp",
+    "d4est_hip_sides.cpp",
     "d4est_hip_capi.hip",
     "d4est_hip_volume.hip",
     "d4est_hip_faces.hip",

@@ -190,6 +190,20 @@ void d4est_hip_compute_dudr(d4est_hip_plan_t* plan, const double* u_dev, double*
 void d4est_hip_plan_set_faces(d4est_hip_plan_t* plan, const int* side_nbr, const int* side_nbr_face, const int* side_reorder,
                               const int* side_mortar_stride, const int* side_bndry_stride, int total_mortar_nodes,
                               int total_bndry_nodes, int n_ghost, const int* ghost_deg, const int* ghost_deg_quad);
+/* The side arrays of d4est_hip_plan_set_faces / _set_hanging built on the HOST from a p8est connectivity and the list of quadrants
+ * alone -- for hosts without p4est_iterate; a d4est build records the same numbers from its face callback.
+ * tree_to_tree / tree_to_face: p8est connectivity (6 per tree; face + 6 * orientation; a boundary face points at itself).  Local
+ * elements: tree, q (3 per element, p4est integer coordinates in [0, root_len)), dq (side length), deg, deg_quad -- in the rank's element
+ * order; ghost quadrants (the off-rank face neighbours the rank knows) likewise, referenced as -(g + 2).  The mesh must be 2:1
+ * balanced across faces.  Outputs (caller-allocated: 6 n_local ints each, side_nbr4 24 n_local): everything set_faces / set_hanging
+ * take, with mortar strides assigned in side order (the small sides of a hanging face share the block of their group's first local
+ * member, src/Mesh/d4est_mesh.c:956-962) -- to be used with device-generated factors (plan_set_mortar_geometry_brick / _analytic) or
+ * with host arrays laid out by the same strides.  Returns 1 when the mesh has hanging faces (then call plan_set_hanging). */
+int d4est_hip_build_sides(int n_trees, const int* tree_to_tree, const int* tree_to_face, int root_len, int n_local, const int* tree,
+                          const int* q, const int* dq, const int* deg, const int* deg_quad, int n_ghost, const int* ghost_tree,
+                          const int* ghost_q, const int* ghost_dq, const int* ghost_deg_quad, int* side_nbr, int* side_nbr_face,
+                          int* side_reorder, int* side_orientation, int* side_hang, int* side_sub, int* side_nbr4,
+                          int* side_mortar_stride, int* side_bndry_stride, int* total_mortar_nodes, int* total_bndry_nodes);
 /* Non-conforming (hanging, 1 <-> 4) faces of a 2:1 balanced mesh; call BEFORE d4est_hip_plan_set_faces (conforming meshes skip it).
  * HOST int arrays over the sides s = 6*e + f, mirroring the two calls the reference's face iteration makes per hanging face
  * (src/Mesh/d4est_mortars.c:700-803: (e_m[4], faces_m = 4 | e_p[1]) and (e_m[1] | e_p[4], faces_p = 4)):

@@ -254,3 +254,50 @@ def test_cubed_sphere_jacobian_chain_rule_vs_complex_step(oracle):
                 oracle.lib.oracle_cubed_sphere_7tree_X(t, ctypes.c_double(1.0), ctypes.c_double(3.0), comp, tc.ctypes.data_as(dp), x.ctypes.data_as(dp))
                 assert np.abs(D[k] - out.reshape(3, 3)).max() <= 2e-14 * max(1.0, np.abs(out).max())
                 assert np.abs(X[k] - x).max() <= 1e-15 * max(1.0, np.abs(x).max())
+
+
+def _sides_from_c(hiplib, m):
+    """d4est_hip_build_sides on the quadrant list of a ForestMesh shard (ghost quadrants = the shard's ghost elements)"""
+    import ctypes
+    s_py = m.build_sides()
+    tree, q, dq = m.cells()
+    gt, gq, gd = m.cells(s_py["ghost_global_ids"])
+    ne = m.n_elements
+    I = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ins = [I(m.conn.tree_to_tree), I(m.conn.tree_to_face), I(tree), I(q), I(dq), I(m.deg), I(m.deg_quad), I(gt), I(gq), I(gd), I(s_py["ghost_deg_quad"])]
+    out = {k: np.zeros(6 * ne, dtype=np.int32) for k in ("side_nbr", "side_nbr_face", "side_reorder", "side_orientation", "side_hang", "side_sub",
+                                                         "side_mortar_stride", "side_bndry_stride")}
+    out["side_nbr4"] = np.zeros(24 * ne, dtype=np.int32)
+    tm, tb = ctypes.c_int(0), ctypes.c_int(0)
+    hang = hiplib.d4est_hip_build_sides(m.conn.num_trees, vp(ins[0]), vp(ins[1]), m.nf, ne, vp(ins[2]), vp(ins[3]), vp(ins[4]), vp(ins[5]), vp(ins[6]),
+                                        len(gd), vp(ins[7]), vp(ins[8]), vp(ins[9]), vp(ins[10]),
+                                        vp(out["side_nbr"]), vp(out["side_nbr_face"]), vp(out["side_reorder"]), vp(out["side_orientation"]),
+                                        vp(out["side_hang"]), vp(out["side_sub"]), vp(out["side_nbr4"]), vp(out["side_mortar_stride"]),
+                                        vp(out["side_bndry_stride"]), ctypes.byref(tm), ctypes.byref(tb))
+    return s_py, out, hang, tm.value, tb.value
+
+
+def test_c_side_list_builder_matches_the_python_one(hiplib):
+    """d4est_hip_build_sides (the host-side replacement of the p4est_iterate face walk for hosts without p4est) reproduces
+    forest.ForestMesh.build_sides array for array: cubed sphere conforming / hanging / mixed p / shards with ghosts, rotated pairs"""
+    conn = F.cubed_sphere_7tree_connectivity()
+    mp = F.CubedSphere7Map(1.0, 2.0)
+    cases = [F.ForestMesh(conn, 1, 2, mp), F.ForestMesh(conn, 0, 2 + np.arange(7) % 3, mp, deg_quad_inc=1),
+             F.ForestMesh(conn, 0, 3, mp, refine=[1, 0, 0, 1, 0, 0, 1]), F.ForestMesh(conn, 1, 2, mp, first=10, count=30),
+             F.ForestMesh(conn, 0, 2, mp, refine=[0, 0, 1, 0, 0, 0, 1], first=4, count=9)]
+    for trip in [(0, 0, 1), (1, 4, 2), (2, 5, 3), (3, 3, 0), (5, 0, 1)]:
+        c2 = F.Connectivity.rotated_pair(*TRIPLES[trip])
+        cases += [F.ForestMesh(c2, 1, 2, F.TrilinearMap(c2)), F.ForestMesh(c2, 0, 2, F.TrilinearMap(c2), refine=[1, 0]),
+                  F.ForestMesh(c2, 0, 2, F.TrilinearMap(c2), refine=[0, 1])]
+    for m in cases:
+        s_py, s_c, hang, tm, tb = _sides_from_c(hiplib, m)
+        assert hang == int(m.has_hanging())
+        assert tm == s_py["total_mortar_nodes"] and tb == s_py["total_bndry_nodes"]
+        for k in ("side_nbr", "side_nbr_face", "side_reorder", "side_mortar_stride", "side_bndry_stride"):
+            np.testing.assert_array_equal(s_c[k], s_py[k], err_msg=k)
+        if hang:
+            for k in ("side_hang", "side_sub", "side_nbr4", "side_orientation"):
+                np.testing.assert_array_equal(s_c[k], s_py[k], err_msg=k)
+        else:
+            assert not s_c["side_hang"].any()

@@ -354,3 +354,33 @@ def test_cubed_sphere_factors_generated_on_the_device(gpu, hiplib, oracle, deg, 
         sl = slice(m.global_nodal_offset, m.global_nodal_offset + m.local_nodes)
         assert _rel(dAu.cpu().numpy(), ref_full[sl]) <= RTOL
         plan.destroy()
+
+
+@pytest.mark.parametrize("deg,refine", [(3, 1), (7, 0)])
+def test_plain_c_multi_tree_host(gpu, hiplib, oracle, tmp_path, deg, refine):
+    """tests/c/forest_probe.c: the whole config-5 path from plain C99 -- side list built by d4est_hip_build_sides (no p4est), factors
+    generated on the device, host-pointer apply -- and its v.Aw against the oracle on the same mesh built by forest.py."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "disco4est_amd")
+    exe = str(tmp_path / "forest_probe")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "forest_probe.c"), "-L" + lib_dir, "-ld4est_hip", "-lm", "-Wl,-rpath," + lib_dir, "-o", exe])
+    out = subprocess.run([exe, str(deg), str(refine)], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok")
+    vAw = float(re.search(r"v\.Aw = (\S+)", out.stdout).group(1))
+    # the same mesh through forest.py + the oracle (host-computed factors)
+    conn = F.cubed_sphere_7tree_connectivity()
+    ref_mask = np.zeros(56, dtype=bool)
+    if refine:
+        ref_mask[[6 * 8 + 7, 2 * 8 + 0]] = True
+    m0 = F.ForestMesh(conn, 1, deg, F.CubedSphere7Map(1.0, 2.0), refine=ref_mask)
+    d = deg + (np.arange(m0.global_elements) % 3 == 1)
+    m = F.ForestMesh(conn, 1, d, F.CubedSphere7Map(1.0, 2.0), refine=ref_mask)
+    J, rst = m.geometry(); s = m.build_sides()
+    v = M.splitmix64_uniform(1, m.local_nodes); w = M.splitmix64_uniform(2, m.local_nodes)
+    Aw = oracle.apply_aij(m, J, rst, s, w, nthreads=8)
+    assert abs(v @ Aw - vAw) <= 1e-11 * abs(vAw)
