@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--sharded-secondary", action="store_true",
+                    help="N = 1 only: also run the N-rank secondary (RCCL transport, gather, rank-count invariance) on the single rank -- a rehearsal of its code path")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` by hand: become the launcher (before anything touches the GPU) and relay the ranks' output
@@ -200,6 +202,16 @@ def main():
         raise SystemExit("bench.py: WORLD_SIZE=%s but --gpus %d -- refusing to report a line for a different rank count"
                          % (os.environ.get("WORLD_SIZE", "1"), args.gpus))
 
+    # stdout carries exactly ONE line, the JSON result: everything else a library may print there (RCCL's version banner at
+    # communicator creation, for one) is sent to stderr by pointing fd 1 at fd 2 until the line is written
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(obj) + "\n").encode())
+
     import torch
     from disco4est_amd import Plan, build, mesh as M
 
@@ -212,10 +224,13 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.sharded_secondary:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("D4EST_BENCH_BACKEND", "nccl")   # nccl = RCCL over xGMI; "gloo" only to rehearse the N > 1 path on one GPU
         try:
             dist.init_process_group(backend=backend, device_id=dev) if backend == "nccl" else dist.init_process_group(backend=backend)
@@ -436,6 +451,8 @@ def main():
             out["secondary"] = sec
         except Exception as exc:  # secondary numbers must never break the headline line
             out["secondary"] = {"error": repr(exc)}
+    if world == 1 and args.sharded_secondary:
+        out["sharded_rehearsal"] = sharded_secondary(args, rank, world, dev, stream, dist, torch)
     if world > 1 and not args.no_secondary:
         # strong-scaling secondaries with the RCCL exchange; a watchdog prints the headline alone if they do not finish
         import threading
@@ -445,7 +462,7 @@ def main():
             if rank == 0:
                 out["secondary"] = {"error": "sharded secondary timed out"}
                 out["cpu_baseline"] = None
-                print(json.dumps(out), flush=True)
+                emit(out)
             os._exit(0)
 
         dog = threading.Timer(float(os.environ.get("D4EST_BENCH_SECONDARY_TIMEOUT", "240")), give_up)
@@ -463,7 +480,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
