@@ -31,6 +31,7 @@ SIGNATURES = {
     "d4est_hip_plan_set_stream": (None, [_vp, _vp]),
     "d4est_hip_plan_set_tuning": (None, [_vp, ctypes.c_int, ctypes.c_int]),
     "d4est_hip_plan_last_kernel": (ctypes.c_char_p, [_vp]),
+    "d4est_hip_plan_face_path": (ctypes.c_char_p, [_vp]),
     "d4est_hip_plan_local_nodes": (ctypes.c_int, [_vp]),
     "d4est_hip_plan_local_nodes_quad": (ctypes.c_int, [_vp]),
     "d4est_hip_plan_n_elements": (ctypes.c_int, [_vp]),
@@ -217,6 +218,10 @@ class Plan:
 
     def last_kernel(self):
         return self.lib.d4est_hip_plan_last_kernel(self.handle).decode()
+
+    def face_path(self):
+        """'direct' or 'two-phase': which face kernels the full operator runs on this plan."""
+        return self.lib.d4est_hip_plan_face_path(self.handle).decode()
 
     def set_tuning(self, key, value):
         self.lib.d4est_hip_plan_set_tuning(self.handle, int(key), int(value))

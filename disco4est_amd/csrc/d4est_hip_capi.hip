@@ -90,6 +90,9 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
   if (n_elements > 0 && (!deg || !deg_quad || !nodal_stride || !quad_stride)) D4EST_HIP_ABORT("plan_create: NULL element array");
   if (quad_type != D4EST_HIP_QUAD_LEGENDRE && quad_type != D4EST_HIP_QUAD_LOBATTO) D4EST_HIP_ABORT("plan_create: unknown quadrature type %d", quad_type);
   d4est_hip_plan_t* plan = new d4est_hip_plan_t();
+  // D4EST_HIP_FACE_DIRECT = 0 / 1: the default of tuning key D4EST_HIP_TUNE_FACE_DIRECT for plans created from here on (read per
+  // plan: the test suite runs the smoother, forest and Schwarz modules once per face path)
+  if (const char* e_ = std::getenv("D4EST_HIP_FACE_DIRECT")) plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT] = std::atoi(e_);
   plan->n_elements = n_elements;
   plan->quad_type = quad_type;
   {
@@ -237,6 +240,11 @@ void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value) {
 }
 
 const char* d4est_hip_plan_last_kernel(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_last_kernel"); return plan->last_kernel; }
+const char* d4est_hip_plan_face_path(const d4est_hip_plan_t* plan) {
+  check_plan(plan, "plan_face_path");
+  if (!plan->has_faces) D4EST_HIP_ABORT("plan_face_path: call plan_set_faces first");
+  return d4est_hip::direct_active(plan) ? "direct" : "two-phase";
+}
 int d4est_hip_plan_local_nodes(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes"); return plan->local_nodes; }
 int d4est_hip_plan_local_nodes_quad(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes_quad"); return plan->local_nodes_quad; }
 int d4est_hip_plan_n_elements(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_n_elements"); return plan->n_elements; }
@@ -555,6 +563,10 @@ void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const doub
     return;
   }
   d4est_hip::launch_stiffness(plan, u_dev, Au_dev);
+  if (d4est_hip::direct_active(plan)) {   // the caller's ghost traces, the local ones from u inside the kernel
+    d4est_hip::launch_flux_direct(plan, u_dev, ghost_trace_dev, Au_dev);
+    return;
+  }
   d4est_hip::launch_traces(plan, u_dev, plan->d_trace, false);
   d4est_hip::launch_flux(plan, plan->d_trace, ghost_trace_dev, Au_dev);
 }

@@ -1,0 +1,482 @@
+// "Direct" face kernel: the SIPG face terms of a conforming, uniform-degree plan (deg, deg_quad <= 7) WITHOUT the mortar-node
+// trace arrays in between.
+//
+// Replaces, like d4est_hip_faces.hip, d4est_laplacian_flux_interface / _boundary (src/dGMath/d4est_laplacian_flux.c:23-1014) with
+// the SIPG callbacks (src/dGMath/d4est_laplacian_flux_sipg.c:15-942) over d4est_mortars_compute_flux_on_local_elements
+// (src/Mesh/d4est_mortars.c:601-840) -- same numbers, different data flow.
+//
+// The two-phase form (trace kernel -> 4 fields per mortar node -> flux kernel) moves 12 KB of traces per p = 7 element out to HBM
+// and 24 KB back in (own + neighbour), 36 % of the operator's traffic, and both kernels are LDS-bound: six waves per element, each
+// lane re-reading operator rows and data columns from LDS (45 + 70 KB of LDS traffic per element).  Here ONE wavefront owns an
+// element and works in the volume kernel's style:
+//   * a lane owns a whole LINE (8 doubles in registers); the 1-D operators are wave-uniform and arrive as scalar operands;
+//     LDS is only the transposition network between the passes (~450 b64 accesses per lane and element instead of ~1400);
+//   * the (+) side's trace is RECOMPUTED from the neighbour's nodal values u (the normal lines of its face: 4 KB per side, served
+//     by L2 / Infinity Cache -- u is 16 MB at config 2), so no trace is written or read;
+//   * per reference direction d the two faces 2d, 2d+1 give 8 nodal face fields (trace, normal derivative) x (own, neighbour) x 2
+//     = 64 rows = one row per lane:
+//       pass 1 (rows over a):     P = C x, R = CD x                                 (C: side nodes -> mortar quadrature nodes)
+//       pass 2 (columns over b):  u = C P, du/dt_b = CD P, du/dn = C S, du/dt_a = C R   (32 + 32 lanes, two products each)
+//       SIPG terms at the mortar node of the lane (the (+) values through the p4est re-ordering of the face pair)
+//       lift pass 1 (rows over a'):  Y = E A  (D^T E for the field that is differentiated along a)
+//       lift pass 2 (columns over b'): face-local part + the normal term-2 field, which D^T spreads along the normal line
+//     and the element's Au line registers are updated through an LDS accumulator in the three line orientations.
+// Ghost (+) sides read their mortar-node block from the exchanged ghost trace buffer exactly as the two-phase flux kernel does, so
+// multi-rank plans run the trace kernel only to feed the exchange.
+#include <algorithm>
+#include <type_traits>
+
+#include "d4est_hip_internal.h"
+#include "d4est_hip_tables.h"
+#include "d4est_hip_wave.h"
+
+namespace d4est_hip {
+
+struct DirectSide {
+  int kind;            // 0 boundary, 1 interface with a local (+) element, 2 with a ghost (+) element
+  int code;            // flip0 | flip1<<1 | transpose<<2 applied when reading the (+) side
+  int fp;              // face of the (+) element
+  int nbr_ns;          // nodal offset of the (+) element (kind 1)
+  int geom;            // scalar offset of the side's mortar data (7 combined factors at 7*geom; Dirichlet / Robin data at geom)
+  int pad;
+  long long nbr_qoff;  // kind 2: offset of the (+) block in the ghost trace buffer
+};
+
+struct DirectHost {
+  int N = 0, NQ = 0;
+  bool eo = false;
+  int ns0 = 0, ns_stride = 0;
+  DirectSide* d_sides = nullptr;
+  double* d_ops = nullptr;   // C, CD, E, D^T E (plain: transposed; eo: even-odd tables), then rows 0 and N-1 of D
+  double* d_u2 = nullptr;    // second solution vector of the fused Chebyshev update (see cheby_iterate_body)
+};
+
+// y = M x, M (NO x NI): tab = M transposed (NI x NO row-major), or the even-odd table of M when EO (NI, NO even; ANTI: M is
+// centro-antisymmetric) -- see stiffness_wave_eo_kernel for the table layout
+template <int NI, int NO, bool EO, bool ANTI>
+__device__ __forceinline__ void prod(const double* __restrict__ tab, const double* x, double* y) {
+  if constexpr (EO) {
+    constexpr int HC = NI / 2, HR = NO / 2;
+    double xe[HC], xo[HC], ab[NO];
+#pragma unroll
+    for (int c = 0; c < HC; ++c) {
+      xe[c] = x[c] + x[NI - 1 - c];
+      xo[c] = x[c] - x[NI - 1 - c];
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const double* xx = (half == 0) ? (ANTI ? xo : xe) : (ANTI ? xe : xo);
+#pragma unroll
+      for (int c = 0; c < HC; ++c) {
+        sdouble_ptr row = launder(tab + c * NO + half * HR);
+#pragma unroll
+        for (int o = 0; o < HR; ++o) ab[half * HR + o] = (c == 0) ? row[o] * xx[0] : fma(row[o], xx[c], ab[half * HR + o]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+      y[r] = ab[r] + ab[HR + r];
+      y[NO - 1 - r] = ab[r] - ab[HR + r];
+    }
+  } else {
+    contract_n<NI, NO>(tab, x, y);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ double row_dot(const double* __restrict__ drow, const double* x) {
+  sdouble_ptr row = launder(drow);
+  double s = row[0] * x[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) s = fma(row[i], x[i], s);
+  return s;
+}
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int N, int NQ>
+struct DirectCfg {
+  static_assert(NQ >= N && NQ * NQ <= 64, "one wavefront per element: (deg_quad + 1)^2 <= 64");
+  static constexpr int N2 = N * N, N3 = N2 * N, T = NQ * NQ, PN = N | 1;
+  static constexpr int GS = NQ * N + 8, QS = T + 8, YS = N * NQ + 8, VS = N2 + 8;   // padded field strides (bank spread)
+  static constexpr int S_DOUBLES = cmax(cmax(cmax(8 * N2, 8 * GS), cmax(8 * QS, 8 * T)), cmax(8 * YS, 6 * VS));
+  static constexpr int U_DOUBLES = PN * N2;
+  static constexpr int OPSZ = N * NQ;
+};
+
+template <int N, int NQ, bool EO, bool FUSE>
+__global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
+                                                             double* __restrict__ Au, const DirectSide* __restrict__ sides,
+                                                             const double* __restrict__ ops, const double* __restrict__ geom,
+                                                             const double* __restrict__ bndry_q, const double* __restrict__ robin_c,
+                                                             const double* __restrict__ robin_r, int n_elem, int ns0, int ns_stride,
+                                                             int xcd_chunk, DirectFuse cf) {
+  using C = DirectCfg<N, NQ>;
+  constexpr int N2 = C::N2, N3 = C::N3, T = C::T, PN = C::PN, GS = C::GS, QS = C::QS, YS = C::YS, VS = C::VS;
+  __shared__ double s_U[C::U_DOUBLES];   // the element's u (line reads in the three directions), later the Au accumulator
+  __shared__ double s_S[C::S_DOUBLES];   // the transposition buffer of every pass (in place: a wave runs in lockstep)
+  const double* tC = ops;
+  const double* tCD = ops + C::OPSZ;
+  const double* tE = ops + 2 * C::OPSZ;
+  const double* tDtE = ops + 3 * C::OPSZ;
+  const double* dr0 = ops + 4 * C::OPSZ;   // D[0][:], then D[N-1][:]
+  const int lane = threadIdx.x;
+  const int a = lane % NQ, b = lane / NQ;
+  const bool on_q = lane < T, on_m = on_q && a < N && b < N;
+  // XCD-aware element order (workgroups are dealt round-robin to the 8 XCDs, each with its own L2): XCD x walks the x-th contiguous
+  // (Morton-local) eighth of the elements, so a neighbour's u is more often in the reader's L2
+  const int v = blockIdx.x;
+  const int e = xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v;
+  if (e >= n_elem) return;
+  const int ns = __builtin_amdgcn_readfirstlane(ns0 + e * ns_stride);
+  const DirectSide* __restrict__ sd = sides + 6 * (size_t)e;
+
+  // ---- the element's u -> LDS (odd padded line length: conflict-free line reads in all three directions)
+#pragma unroll
+  for (int idx = lane; idx < N3; idx += 64) {
+    const int i = idx % N, j = (idx / N) % N, k = idx / N2;
+    s_U[i + PN * (j + N * k)] = u[ns + idx];
+  }
+  wave_lds_fence();
+  // ---- own nodal face fields: trace and normal derivative at face node (a, b) of the six faces
+  double own_tr[6], own_nd[6];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    double x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int idx = (d == 0) ? i + PN * (a + N * b) : (d == 1 ? a + PN * (i + N * b) : a + PN * (b + N * i));
+      x[i] = on_m ? s_U[idx] : 0.0;
+    }
+    own_tr[2 * d] = x[0];
+    own_tr[2 * d + 1] = x[N - 1];
+    own_nd[2 * d] = row_dot<N>(dr0, x);
+    own_nd[2 * d + 1] = row_dot<N>(dr0 + N, x);
+  }
+  wave_lds_fence();   // s_U is free from here on: it becomes the accumulator of the lifted face terms
+
+  auto dir_body = [&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    constexpr int t0 = (d == 0) ? 1 : 0, t1d = (d == 2) ? 1 : 2;   // reference directions of the face indices a and b
+    DirectSide sh[2] = {sd[2 * d], sd[2 * d + 1]};
+    // ---- nodal fields of the two faces: c = 0..3 trace (own 2d, own 2d+1, nbr 2d, nbr 2d+1), c = 4..7 normal derivative
+    double fld[8] = {own_tr[2 * d], own_tr[2 * d + 1], 0.0, 0.0, own_nd[2 * d], own_nd[2 * d + 1], 0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (sh[h].kind == 1) {
+        // the normal lines of the (+) element's face fp at ITS face node (a, b)
+        const double* __restrict__ up = u + sh[h].nbr_ns;
+        const int dp = sh[h].fp >> 1, hi = sh[h].fp & 1;
+        double y[N];
+        if (on_m) {
+          if (dp == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) y[i] = up[i + N * a + N2 * b];
+          } else if (dp == 1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) y[i] = up[a + N * i + N2 * b];
+          } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) y[i] = up[a + N * b + N2 * i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < N; ++i) y[i] = 0.0;
+        }
+        fld[2 + h] = hi ? y[N - 1] : y[0];
+        fld[6 + h] = row_dot<N>(dr0 + hi * N, y);
+      }
+    }
+    // ---- pass 1: row (c, b) per lane, contract the face index a
+    wave_lds_fence();
+    if (on_m) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s_S[c * N2 + b * N + a] = fld[c];
+    }
+    wave_lds_fence();
+    const bool row_on = lane < 8 * N;
+    const int rc = lane / N, rb = lane % N;
+    double P[NQ], R[NQ];
+    {
+      double x[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = row_on ? s_S[lane * N + i] : 0.0;
+      prod<N, NQ, EO, false>(tC, x, P);
+      prod<N, NQ, EO, true>(tCD, x, R);   // used for the trace rows (c < 4) only
+    }
+    // ---- pass 2: column (c, a') per lane, contract the face index b
+    wave_lds_fence();
+    if (row_on) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) s_S[rc * GS + q * N + rb] = P[q];
+    }
+    wave_lds_fence();
+    const bool col_on = lane < 8 * NQ;
+    const int cc = lane / NQ, aq = lane % NQ;
+    double col[N], col2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) col[i] = col_on ? s_S[cc * GS + aq * N + i] : 0.0;
+    wave_lds_fence();
+    if (row_on && rc < 4) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) s_S[rc * GS + q * N + rb] = R[q];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < N; ++i) col2[i] = (col_on && cc >= 4) ? s_S[(cc - 4) * GS + aq * N + i] : 0.0;
+    double o1[NQ], o2[NQ];
+    prod<N, NQ, EO, false>(tC, col, o1);                  // lanes c < 4: u            lanes c >= 4: du/dn
+    if (cc < 4) prod<N, NQ, EO, true>(tCD, col, o2);      //              du/dt_b
+    else prod<N, NQ, EO, false>(tC, col2, o2);            //                                         du/dt_a
+    // ---- SIPG terms, one face at a time (the mortar values of its two sides go through the buffer)
+    double At[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      wave_lds_fence();
+      if (col_on && (cc & 1) == h) {
+        const int mp = (cc >> 1) & 1;
+        const int dn = mp ? (sh[h].fp >> 1) : d;   // the reference frame of the side that owns the trace
+        const int ta = (dn == 0) ? 1 : 0, tb = (dn == 2) ? 1 : 2;
+        const int c1 = (cc >= 4) ? 1 + dn : 0, c2 = (cc >= 4) ? 1 + ta : 1 + tb;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          s_S[(mp * 4 + c1) * QS + aq + NQ * q] = o1[q];
+          s_S[(mp * 4 + c2) * QS + aq + NQ * q] = o2[q];
+        }
+      }
+      wave_lds_fence();
+      double qm[4] = {0, 0, 0, 0}, qp[4] = {0, 0, 0, 0}, gq[7] = {0, 0, 0, 0, 0, 0, 0};
+      const int kind = sh[h].kind;
+      if (on_q) {
+        const int k = lane;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qm[c] = s_S[c * QS + k];
+        if (kind == 1) {
+          const int kp = reorder_index(sh[h].code, NQ - 1, a, b);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) qp[c] = s_S[(4 + c) * QS + kp];
+        } else if (kind == 2) {
+          const double* __restrict__ p = ghost_qtrace + sh[h].nbr_qoff + reorder_index(sh[h].code, NQ - 1, a, b);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) qp[c] = p[c * T];
+        } else if (robin_c) {
+          qp[0] = robin_r[sh[h].geom + k];
+        } else {
+          qp[0] = bndry_q[sh[h].geom + k];
+        }
+        if (kind == 0 && robin_c) {
+          gq[6] = robin_c[sh[h].geom + k];   // am = ap = 0: no term 1 / term 2 on a Robin side
+        } else {
+          const double* __restrict__ g = geom + (size_t)7 * sh[h].geom + k;
+#pragma unroll
+          for (int c = 0; c < 7; ++c) gq[c] = g[c * T];
+        }
+      }
+      // interface: t1 = -1/2 sj n.(grad u_m + grad u_p), t2_l = -1/2 am_l [u]; boundary: t1 = -sj n.grad u_m, t2_l = -am_l (u - g)
+      // (d4est_laplacian_flux_sipg.c:494-942, :15-336); Robin (:339-489): sj (coeff u_m - rhs) only
+      double t1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t1 += gq[i] * qm[1 + i] + gq[3 + i] * qp[1 + i];   // gq[3..5] = 0 on boundary sides
+      const double jump = qm[0] - qp[0];
+      const double w1 = (kind != 0) ? -0.5 : -1.0;
+      At[h][0] = (kind == 0 && robin_c) ? gq[6] * qm[0] - qp[0] : w1 * t1 + gq[6] * jump;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) At[h][1 + l] = w1 * gq[l] * jump;
+    }
+    // ---- lift pass 1: row (c8 = 4 h + field, b') per lane, contract a'
+    wave_lds_fence();
+    if (on_q) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_S[(4 * h + c) * T + b * NQ + a] = At[h][c];
+    }
+    wave_lds_fence();
+    double Yv[N];
+    {
+      double row[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) row[q] = col_on ? s_S[lane * NQ + q] : 0.0;
+      // the term-2 field along a takes D_a^T on the way:  val = E_b E_a A0 + E_b (D^T E)_a A_t0 + (D^T E)_b E_a A_t1
+      if ((cc & 3) == 1 + t0) prod<NQ, N, EO, true>(tDtE, row, Yv);
+      else prod<NQ, N, EO, false>(tE, row, Yv);
+    }
+    wave_lds_fence();
+    if (col_on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) s_S[cc * YS + i * NQ + aq] = Yv[i];
+    }
+    wave_lds_fence();
+    // ---- lift pass 2: column (h, g, a) per lane: g = 0 face-local part through E, 1 term 2 along b through D^T E, 2 normal term 2
+    const bool v_on = lane < 6 * N;
+    const int vh = lane / (3 * N), vg = (lane / N) % 3, va = lane % N;
+    double Vv[N];
+    {
+      double colq[NQ];
+      const int f1 = (vg == 0) ? 0 : (vg == 1 ? 1 + t1d : 1 + d);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        double t = v_on ? s_S[(4 * vh + f1) * YS + va * NQ + q] : 0.0;
+        if (v_on && vg == 0) t += s_S[(4 * vh + 1 + t0) * YS + va * NQ + q];
+        colq[q] = t;
+      }
+      if (vg == 1) prod<NQ, N, EO, true>(tDtE, colq, Vv);
+      else prod<NQ, N, EO, false>(tE, colq, Vv);
+    }
+    wave_lds_fence();
+    if (v_on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) s_S[(3 * vh + vg) * VS + i * N + va] = Vv[i];
+    }
+    wave_lds_fence();
+    // ---- the element's normal line at face node (a, b): face-local part at its two ends, D^T of the normal term 2 along it
+    double acc[N];
+    if (on_m) {
+      const double val0 = s_S[0 * VS + b * N + a] + s_S[1 * VS + b * N + a], n0 = s_S[2 * VS + b * N + a];
+      const double val1 = s_S[3 * VS + b * N + a] + s_S[4 * VS + b * N + a], n1 = s_S[5 * VS + b * N + a];
+      sdouble_ptr r0 = launder(dr0), r1 = launder(dr0 + N);
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc[i] = fma(r0[i], n0, r1[i] * n1);
+      acc[0] += val0;
+      acc[N - 1] += val1;
+      if constexpr (d == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) s_U[i + PN * (a + N * b)] = acc[i];
+      } else if constexpr (d == 1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) s_U[a + PN * (i + N * b)] += acc[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const size_t o = (size_t)ns + a + N * b + N2 * i;
+          const double au = Au[o] + (s_U[a + PN * (b + N * i)] + acc[i]);
+          Au[o] = au;
+          if constexpr (FUSE) {
+            // the Chebyshev update of the node (cheby_update_kernel, same roundings): u is an INPUT of this kernel (the
+            // neighbours read it), so the new iterate goes to a second vector
+            const double res = __dadd_rn(cf.rhs[o], __dmul_rn(-1.0, au));
+            const double ri = __dmul_rn(cf.alpha, res);
+            const double pi = __dadd_rn(__dmul_rn(cf.beta, cf.p[o]), ri);
+            if (cf.r) cf.r[o] = ri;
+            cf.p[o] = pi;
+            cf.u_out[o] = __dadd_rn(u[o], pi);
+          }
+        }
+      }
+    }
+    wave_lds_fence();
+  };
+  dir_body(std::integral_constant<int, 0>{});
+  dir_body(std::integral_constant<int, 1>{});
+  dir_body(std::integral_constant<int, 2>{});
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static DirectHost* host_of(d4est_hip_plan* plan) { return static_cast<DirectHost*>(plan->direct); }
+
+void direct_destroy(d4est_hip_plan* plan) {
+  DirectHost* dh = host_of(plan);
+  if (!dh) return;
+  (void)hipFree(dh->d_sides);
+  (void)hipFree(dh->d_ops);
+  (void)hipFree(dh->d_u2);
+  delete dh;
+  plan->direct = nullptr;
+}
+
+#define D4EST_HIP_DIRECT_PAIRS(X) X(2, 2) X(3, 3) X(4, 4) X(5, 5) X(6, 6) X(7, 7) X(8, 8) X(2, 3) X(3, 4) X(4, 5) X(3, 6) X(4, 6)
+
+static bool direct_pair_built(int N, int NQ) {
+#define X(N_, NQ_) if (N == N_ && NQ == NQ_) return true;
+  D4EST_HIP_DIRECT_PAIRS(X)
+#undef X
+  return false;
+}
+
+void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, const double* Cm, const double* CDm, const double* Em) {
+  direct_destroy(plan);
+  if (!direct_pair_built(N, NQ)) return;
+  const int ne = plan->n_elements;
+  DirectHost* dh = new DirectHost;
+  dh->N = N; dh->NQ = NQ; dh->ns0 = ns0; dh->ns_stride = ns_stride;
+  dh->eo = (N % 2 == 0) && (NQ % 2 == 0);
+  std::vector<double> Cv(Cm, Cm + (size_t)NQ * N), CDv(CDm, CDm + (size_t)NQ * N), Ev(Em, Em + (size_t)N * NQ);
+  std::vector<double> D = Tables1D::dij(N - 1);
+  std::vector<double> DtE = Tables1D::matmul(Tables1D::transpose(D, N, N), Ev, N, N, NQ);   // (N x NQ)
+  std::vector<double> ops;
+  auto put = [&](const std::vector<double>& M, int R, int Cc, bool anti) {
+    std::vector<double> t = dh->eo ? Tables1D::eo_table(M, R, Cc, anti) : Tables1D::transpose(M, R, Cc);
+    t.resize((size_t)R * Cc, 0.0);
+    ops.insert(ops.end(), t.begin(), t.end());
+  };
+  put(Cv, NQ, N, false);
+  put(CDv, NQ, N, true);
+  put(Ev, N, NQ, false);
+  put(DtE, N, NQ, true);
+  for (int i = 0; i < N; ++i) ops.push_back(D[i]);
+  for (int i = 0; i < N; ++i) ops.push_back(D[(size_t)(N - 1) * N + i]);
+  ops.resize(ops.size() + 16, 0.0);   // slack for whole-row scalar loads
+  HIP_CHECK(hipMalloc(&dh->d_ops, ops.size() * sizeof(double)));
+  HIP_CHECK(hipMemcpy(dh->d_ops, ops.data(), ops.size() * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<DirectSide> sd(6 * (size_t)ne);
+  for (int e = 0; e < ne; ++e)
+    for (int f = 0; f < 6; ++f) {
+      const size_t s = 6 * (size_t)e + f;
+      DirectSide d{};
+      const int nbr = plan->side_nbr[s];
+      d.kind = (nbr == -1) ? 0 : (nbr >= 0 ? 1 : 2);
+      d.code = plan->side_reorder[s];
+      d.fp = (d.kind == 0) ? 0 : plan->side_nbr_face[s];
+      d.nbr_ns = (d.kind == 1) ? plan->nodal_stride[nbr] : 0;
+      d.geom = plan->side_mortar_stride[s];
+      d.nbr_qoff = (d.kind == 2) ? plan->ghost_trace_offset[s] : 0;
+      sd[s] = d;
+    }
+  HIP_CHECK(hipMalloc(&dh->d_sides, std::max<size_t>(sd.size(), 1) * sizeof(DirectSide)));
+  if (!sd.empty()) HIP_CHECK(hipMemcpy(dh->d_sides, sd.data(), sd.size() * sizeof(DirectSide), hipMemcpyHostToDevice));
+  plan->direct = dh;
+}
+
+bool direct_active(const d4est_hip_plan* plan) {
+  return plan->direct != nullptr && plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0;
+}
+
+double* direct_second_vector(d4est_hip_plan* plan) {
+  DirectHost* dh = host_of(plan);
+  if (!dh->d_u2) HIP_CHECK(hipMalloc(&dh->d_u2, std::max<size_t>((size_t)plan->local_nodes, 1) * sizeof(double)));
+  return dh->d_u2;
+}
+
+void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
+                         const double* robin_c, const double* robin_r) {
+  DirectHost* dh = host_of(plan);
+  if (!dh) D4EST_HIP_ABORT("direct face kernel: the plan has no direct tables");
+  if (!plan->has_face_geometry) D4EST_HIP_ABORT("apply flux: plan_set_mortar_geometry was not called");
+  const int n = plan->n_elements;
+  if (n == 0) return;
+  if (plan->ghost_trace_doubles > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has ghost sides but no ghost trace buffer was given");
+  static const bool no_remap = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
+  const int chunk = (n % 8 == 0 && !no_remap) ? n / 8 : 0;
+  bool done = false;
+#define X(N_, NQ_)                                                                                                              \
+  if (!done && dh->N == N_ && dh->NQ == NQ_) {                                                                                  \
+    constexpr bool kEo = (N_ % 2 == 0) && (NQ_ % 2 == 0);                                                                      \
+    if (cf)                                                                                                                     \
+      hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, kEo, true>), dim3(n), dim3(64), 0, plan->stream, u, ghost_trace, Au,     \
+                         dh->d_sides, dh->d_ops, plan->d_face_geom, plan->d_bndry, robin_c, robin_r, n, dh->ns0, dh->ns_stride, \
+                         chunk, *cf);                                                                                           \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, kEo, false>), dim3(n), dim3(64), 0, plan->stream, u, ghost_trace, Au,    \
+                         dh->d_sides, dh->d_ops, plan->d_face_geom, plan->d_bndry, robin_c, robin_r, n, dh->ns0, dh->ns_stride, \
+                         chunk, DirectFuse{});                                                                                  \
+    done = true;                                                                                                                \
+  }
+  D4EST_HIP_DIRECT_PAIRS(X)
+#undef X
+  if (!done) D4EST_HIP_ABORT("direct face kernel: no instance for N = %d, NQ = %d", dh->N, dh->NQ);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace d4est_hip

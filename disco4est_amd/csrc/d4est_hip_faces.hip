@@ -25,6 +25,7 @@
 #include "d4est_hip_internal.h"
 #include "d4est_hip_maps.h"
 #include "d4est_hip_tables.h"
+#include "d4est_hip_wave.h"
 
 namespace d4est_hip {
 
@@ -66,7 +67,6 @@ struct GhostSideDesc {
   long long goff;   // offset of the block in the ghost trace buffer
 };
 
-__host__ __device__ inline int face_fix(int f, int N) { return (f & 1) ? (N - 1) : 0; }
 
 // volume index of face node (a,b) of face f (a fastest; tangential axes in increasing order)
 __device__ inline int face_vol_index(int f, int N, int a, int b) {
@@ -74,14 +74,6 @@ __device__ inline int face_vol_index(int f, int N, int a, int b) {
   if (dir == 0) return fix + N * (a + N * b);
   if (dir == 1) return a + N * (fix + N * b);
   return a + N * (b + N * fix);
-}
-
-__device__ inline int reorder_index(int code, int deg, int a, int b) {
-  // out(a,b) = in(a2,b2) for out = transpose?(flip1?(flip0?(in)))  (dGMath/d4est_operators.c:2044-2081)
-  int a1 = (code & 4) ? b : a, b1 = (code & 4) ? a : b;
-  if (code & 2) b1 = deg - b1;
-  if (code & 1) a1 = deg - a1;
-  return a1 + (deg + 1) * b1;
 }
 
 // value c (0: u, 1..3: du/dr_{c-1}) at face node (a,b) of face f from the element values ue (N^3, x fastest)
@@ -731,10 +723,6 @@ __global__ __launch_bounds__(384, 6) void trace_wave_kernel(const double* __rest
 // ---------------------------------------------------------------------------
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // one workgroup = 3 waves = the three reference directions of one element; wave `dir` serves the two faces 2 dir, 2 dir + 1,
 // which share the same lines of u (trace = first / last entry, normal derivative = row 0 / row N-1 of D)
@@ -2110,6 +2098,15 @@ void faces_setup(d4est_hip_plan* plan) {
       fh.uni.ns0 = edv[0].ns; fh.uni.ns_stride = n3; fh.uni.q0 = sd[0].qoff; fh.uni.q_stride = qs;
     }
   }
+  // the direct kernel (d4est_hip_direct.hip) takes over apply_aij on uniform conforming plans whose sides all see the local degree
+  direct_destroy(plan);
+  if (fh.uni.N > 0) {
+    bool same = true;
+    for (size_t s_ = 0; s_ < ns && same; ++s_) same = (sd[s_].offE == sd[0].offE) && (deg_p_of[s_] == plan->deg[0]) && sd[s_].kind != 3;
+    if (same && sd[0].NQ * sd[0].NQ <= 64 && sd[0].NQ >= fh.uni.N)
+      direct_setup(plan, fh.uni.N, sd[0].NQ, fh.uni.ns0, fh.uni.ns_stride, ops.data() + fh.uni.offC, ops.data() + fh.uni.offCD,
+                   ops.data() + sd[0].offE);
+  }
   ops.resize(ops.size() + 64, 0.0);  // slack: the fast kernels read 64-entry images
   plan->d_elem_desc = upload_vec(edv);
   fh.d_elem_desc_generic = upload_vec(edg);
@@ -2634,7 +2631,13 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   HIP_CHECK(hipGetLastError());
 }
 
+void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf) {
+  FaceHost& fh = g_face_host[plan];
+  launch_direct_faces(plan, u, ghost_trace, Au, cf, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr);
+}
+
 void faces_destroy(d4est_hip_plan* plan) {
+  direct_destroy(plan);
   auto it = g_face_host.find(plan);
   if (it != g_face_host.end()) {
     FaceHost& fh = it->second;

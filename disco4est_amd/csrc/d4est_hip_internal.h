@@ -108,6 +108,7 @@ struct d4est_hip_plan {
   int sipg_penalty_fcn = 0;
   int max_face_lds_doubles = 0;
   bool face_fast = false;  // all sides have N, Np, NQ <= 8: flux_wave_kernel applies
+  void* direct = nullptr;  // DirectHost (d4est_hip_direct.hip): conforming uniform-degree plans, deg_quad <= 7
 
   // ---- solver workspace / communication hooks (d4est_hip_solver.hip) ----
   double *d_work_p = nullptr, *d_work_d = nullptr, *d_work_r = nullptr, *d_reduce = nullptr, *d_ghost_trace = nullptr;
@@ -122,7 +123,7 @@ struct d4est_hip_plan {
   d4est_hip_allreduce_fn allreduce_fn = nullptr;
   void* comm_ctx = nullptr;
 
-  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
+  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;
@@ -168,10 +169,28 @@ struct ChebyFuse {
   const double* rhs = nullptr;
   double* p = nullptr;
   double* u = nullptr;
+  double* u_out = nullptr;   // direct face kernel only: where the new iterate goes (it reads the neighbours' u)
   double* r = nullptr;
   double alpha = 0.0, beta = 0.0;
 };
 bool flux_can_fuse_update(d4est_hip_plan* plan);
+
+// d4est_hip_direct.hip: the face terms straight from u (no trace arrays) on conforming uniform-degree plans
+struct DirectFuse {   // Chebyshev update in the epilogue; the new iterate goes to u_out (the kernel reads the neighbours' u)
+  const double* rhs = nullptr;
+  double* p = nullptr;
+  double* u_out = nullptr;
+  double* r = nullptr;
+  double alpha = 0.0, beta = 0.0;
+};
+void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, const double* C, const double* CD, const double* E);
+void direct_destroy(d4est_hip_plan* plan);
+bool direct_active(const d4est_hip_plan* plan);
+double* direct_second_vector(d4est_hip_plan* plan);
+void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
+                         const double* robin_c, const double* robin_r);
+// the same through the plan's face data (Robin arrays): Au += face terms of u
+void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf = nullptr);
 void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf = nullptr);
 void faces_destroy(d4est_hip_plan* plan);
 

@@ -154,6 +154,26 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
   if (has_ghost && !plan->exchange_fn) D4EST_HIP_ABORT("apply_lhs: plan has ghost sides but no exchange callback (plan_set_comm)");
   // measured: the two cross-stream event waits cost more than the overlap buys (config 2: 119 -> 129 us; 512 elements:
   // 16 -> 44 us), so the fork is opt-in (tuning value 1) and the default is one stream
+  if (direct_active(plan)) {
+    // one-kernel face terms (d4est_hip_direct.hip): both sides' traces come from u inside the kernel; with ghost sides the trace
+    // kernel still runs, to feed the exchange
+    if (has_ghost) {
+      launch_traces(plan, u, plan->d_trace, false);
+      plan->exchange_fn(plan->comm_ctx, 0, plan->d_trace, plan->d_ghost_trace);
+    }
+    launch_stiffness(plan, u, Au);
+    if (lhs_term) add_lhs_mass_term(plan, u, Au);
+    if (has_ghost) plan->exchange_fn(plan->comm_ctx, 1, plan->d_trace, plan->d_ghost_trace);
+    if (cf) {
+      DirectFuse df;
+      df.rhs = cf->rhs; df.p = cf->p; df.u_out = cf->u_out; df.r = cf->r; df.alpha = cf->alpha; df.beta = cf->beta;
+      if (!df.u_out || df.u_out == u) D4EST_HIP_ABORT("apply_operator: the direct face kernel needs a second vector for the fused update");
+      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, &df);
+    } else {
+      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, nullptr);
+    }
+    return;
+  }
   const bool fork = plan->tuning[D4EST_HIP_TUNE_OVERLAP_TRACES] > 0 && !has_ghost;
   if (fork) {
     if (!plan->side_stream) {
@@ -228,6 +248,7 @@ void cheby_iterate(d4est_hip_plan* plan, double* u, const double* rhs, double* A
     // work vectors takes exactly the code path the captured loop will take; it happens once per captured argument set.
     HIP_CHECK(hipMemsetAsync(plan->d_work_d, 0, std::max<size_t>((size_t)plan->local_nodes, 1) * sizeof(double), plan->stream));
     apply_operator(plan, plan->d_work_d, plan->d_work_r);
+    if (direct_active(plan)) (void)direct_second_vector(plan);   // the second iterate vector of the fused update
     HIP_CHECK(hipStreamSynchronize(plan->stream));
     hipGraph_t g = nullptr;
     HIP_CHECK(hipStreamBeginCapture(plan->stream, hipStreamCaptureModeThreadLocal));
@@ -248,6 +269,11 @@ static void cheby_iterate_body(d4est_hip_plan* plan, double* u, const double* rh
   double alpha = 0.0, beta = 0.0;
   HIP_CHECK(hipMemsetAsync(plan->d_work_p, 0, std::max<size_t>((size_t)n, 1) * sizeof(double), plan->stream));
   const bool fuse = plan->tuning[D4EST_HIP_TUNE_FUSE_UPDATE] != 0 && flux_can_fuse_update(plan);
+  // the direct face kernel reads the neighbours' u, so its fused update writes the new iterate to a second vector: the iterates
+  // alternate between the caller's u and a plan-owned one (copied back after an odd number of iterations)
+  const bool pingpong = fuse && direct_active(plan);
+  double* ub = pingpong ? direct_second_vector(plan) : u;
+  double* const u_caller = u;
   for (int i = 0; i < iter; ++i) {
     if (i == 0) alpha = 1. / d;
     else if (i == 1) alpha = 2. * d / (2 * d * d - c * c);
@@ -259,11 +285,21 @@ static void cheby_iterate_body(d4est_hip_plan* plan, double* u, const double* rh
     if (fuse) {   // the update rides in the flux kernel's epilogue: 3 kernels per iteration instead of 4
       ChebyFuse cf;
       cf.rhs = rhs; cf.p = plan->d_work_p; cf.u = u; cf.r = r_out; cf.alpha = alpha; cf.beta = beta;
-      apply_operator(plan, u, Au, &cf);
+      if (pingpong) {
+        cf.u_out = ub;
+        apply_operator(plan, u, Au, &cf);
+        std::swap(u, ub);
+      } else {
+        apply_operator(plan, u, Au, &cf);
+      }
     } else {
       apply_operator(plan, u, Au);
       if (n > 0) hipLaunchKernelGGL(cheby_update_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, Au, alpha, beta, r_out, plan->d_work_p, u);
     }
+  }
+  if (u != u_caller) {   // odd number of ping-pong iterations: the last iterate sits in the plan's vector
+    HIP_CHECK(hipMemcpyAsync(u_caller, u, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, plan->stream));
+    u = u_caller;
   }
   if (compute_residual_at_end == 1) {
     apply_operator(plan, u, Au);

@@ -22,6 +22,7 @@
 #include "d4est_hip_internal.h"
 #include "d4est_hip_maps.h"
 #include "d4est_hip_tables.h"
+#include "d4est_hip_wave.h"
 
 namespace d4est_hip {
 
@@ -40,57 +41,6 @@ struct VolCfg {
   static constexpr int LDS_PER_ELEM = 3 * FS;
   static constexpr size_t LDS_BYTES = (size_t)EPB * LDS_PER_ELEM * sizeof(double);
 };
-
-// The 1-D operator entries are wave-uniform: they are fetched with scalar loads
-// (s_load) and feed v_fma_f64 as SGPR operands.  `launder` hides the pointer's
-// provenance from the optimiser once per operator ROW, so identical loads are not
-// CSE'd across stages (which would keep 128+ doubles live in SGPRs and spill them
-// through v_readlane); each row (<= 16 doubles) lives only for its own FMAs.
-// The laundered pointer is re-typed to the constant address space (4) so the
-// backend keeps emitting s_load_dwordx* for it.
-typedef const double __attribute__((address_space(4))) * sdouble_ptr;
-__device__ __forceinline__ sdouble_ptr launder(const double* p) {
-  unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  asm volatile("" : "+s"(v));
-  return (sdouble_ptr)v;
-}
-
-// y = op x with op (NO x NI) passed TRANSPOSED: opT is NI x NO row-major.  Loop order i-outer so that one scalar
-// row opT[i][0..NO) feeds NO INDEPENDENT FMA chains (a dependent chain per output would serialise on the
-// FP64 FMA latency: measured 39 % issue-stall cycles with the o-outer form, profiles/r01_c_*).
-template <int NI, int NO>
-__device__ __forceinline__ void contract_n(const double* __restrict__ opT, const double* x, double* y) {
-  // outputs in chunks of <= 8: one scalar row chunk is <= 16 SGPRs (longer rows spill SGPRs through v_readlane)
-#pragma unroll
-  for (int o0 = 0; o0 < NO; o0 += 8) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      sdouble_ptr row = launder(opT + i * NO + o0);
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        if (o0 + o < NO) y[o0 + o] = (i == 0) ? row[o] * x[0] : fma(row[o], x[i], y[o0 + o]);
-      }
-    }
-  }
-}
-
-// y (+)= op^T x, op is NI x NO row-major.  Loop order i-outer so that each scalar
-// row op[i][0..NO) is consumed by NO independent FMA chains.
-template <int NI, int NO, bool ACC>
-__device__ __forceinline__ void contract_t(const double* __restrict__ op, const double* x, double* y) {
-#pragma unroll
-  for (int o0 = 0; o0 < NO; o0 += 8) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      sdouble_ptr row = launder(op + i * NO + o0);
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        if (o0 + o < NO) y[o0 + o] = (i == 0 && !ACC) ? row[o] * x[0] : fma(row[o], x[i], y[o0 + o]);
-      }
-    }
-  }
-}
-
 
 // ---- even-odd form of the same contractions (see stiffness_wave_eo_kernel below for the derivation and table layout):
 // tab = EO table of the operator, C/2 rows of R doubles, row = [first half | second half]

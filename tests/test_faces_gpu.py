@@ -5,6 +5,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-12
+# (deg + 1, deg_quad + 1) pairs the direct face kernel is instantiated for (csrc/d4est_hip_direct.hip: D4EST_HIP_DIRECT_PAIRS)
+DIRECT_PAIRS = {(n, n) for n in range(2, 9)} | {(2, 3), (3, 4), (4, 5), (3, 6), (4, 6)}
 
 
 def _t(a, dev):
@@ -44,10 +46,18 @@ def test_apply_aij_parity(gpu, hiplib, oracle, level, deg, inc, curved, fcn):
     plan.set_dirichlet_values(g)
     du = _t(u, gpu)
     dAu = torch.full_like(du, float("nan"))
-    plan.apply_aij(du, dAu)
-    got = dAu.cpu().numpy()
-    assert np.isfinite(got).all()
-    assert _rel(got, ref) <= RTOL
+    # uniform conforming plans up to deg_quad = 7 run the direct face kernel (traces formed from u in place) by default;
+    # tuning key 11 = 0 selects the two-phase kernels: both are held to the oracle
+    assert plan.face_path() == ("direct" if (deg + 1, deg + inc + 1) in DIRECT_PAIRS else "two-phase")
+    for direct in ((1, 0) if plan.face_path() == "direct" else (0,)):
+        plan.set_tuning(11, direct)
+        assert plan.face_path() == ("direct" if direct else "two-phase")
+        dAu.fill_(float("nan"))
+        plan.apply_aij(du, dAu)
+        got = dAu.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert _rel(got, ref) <= RTOL
+    plan.set_tuning(11, -1)
     # homogeneous operator (what apply_lhs uses) after resetting the Dirichlet data
     plan.set_dirichlet_values(None)
     plan.apply_aij(du, dAu)
@@ -75,8 +85,12 @@ def test_apply_aij_robin_parity(gpu, hiplib, oracle, level, deg, inc):
     plan.set_robin_values(coeff, rhs)
     du = _t(u, gpu)
     dAu = torch.full_like(du, float("nan"))
-    plan.apply_aij(du, dAu)
-    assert _rel(dAu.cpu().numpy(), ref) <= RTOL
+    for direct in ((1, 0) if plan.face_path() == "direct" else (0,)):   # both face paths where the direct kernel applies
+        plan.set_tuning(11, direct)
+        dAu.fill_(float("nan"))
+        plan.apply_aij(du, dAu)
+        assert _rel(dAu.cpu().numpy(), ref) <= RTOL
+    plan.set_tuning(11, -1)
     plan.set_robin_values(None, None)
     plan.apply_aij(du, dAu)
     ref0 = oracle.apply_aij(m, J, rst, sides, u, penalty_prefactor=7.5, nthreads=8)
