@@ -146,7 +146,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # D4EST_HIP_LIBRARY: another build of the same library (kernel experiments: tools/build_variant.sh)
+    p = path or os.environ.get("D4EST_HIP_LIBRARY") or LIB_PATH
     if not os.path.exists(p):
         raise RuntimeError(
             "libd4est_hip.so not found at %s -- build it with `python -m disco4est_amd.build` "

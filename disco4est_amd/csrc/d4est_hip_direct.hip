@@ -30,57 +30,88 @@
 #include "d4est_hip_tables.h"
 #include "d4est_hip_wave.h"
 
+// 1: the even-odd products take one scalar operator row per step (32 SGPRs in flight); 0: two rows / two operators per step (64)
+#ifndef D4EST_DIRECT_LEAN_ROWS
+#define D4EST_DIRECT_LEAN_ROWS 1
+#endif
+
 namespace d4est_hip {
 
 struct DirectSide {
-  int kind;            // 0 boundary, 1 interface with a local (+) element, 2 with a ghost (+) element
-  int code;            // flip0 | flip1<<1 | transpose<<2 applied when reading the (+) side
-  int fp;              // face of the (+) element
+  int kcf;             // kind | code << 2 | fp << 5:  kind 0 boundary, 1 interface with a local (+) element, 2 with a ghost (+) element;
+                       // code = flip0 | flip1<<1 | transpose<<2 applied when reading the (+) side; fp = face of the (+) element
   int nbr_ns;          // nodal offset of the (+) element (kind 1)
   int geom;            // scalar offset of the side's mortar data (7 combined factors at 7*geom; Dirichlet / Robin data at geom)
   int pad;
-  long long nbr_qoff;  // kind 2: offset of the (+) block in the ghost trace buffer
 };
+// kind 2 only: offset of the (+) block in the ghost trace buffer, in its own array (read inside the ghost branch)
+typedef long long DirectGhostOff;
 
 struct DirectHost {
   int N = 0, NQ = 0;
   bool eo = false;
   int ns0 = 0, ns_stride = 0;
   DirectSide* d_sides = nullptr;
+  DirectGhostOff* d_ghost_off = nullptr;
   double* d_ops = nullptr;   // C, CD, E, D^T E (plain: transposed; eo: even-odd tables), then rows 0 and N-1 of D
   double* d_u2 = nullptr;    // second solution vector of the fused Chebyshev update (see cheby_iterate_body)
 };
 
 // y = M x, M (NO x NI): tab = M transposed (NI x NO row-major), or the even-odd table of M when EO (NI, NO even; ANTI: M is
-// centro-antisymmetric) -- see stiffness_wave_eo_kernel for the table layout
+// centro-antisymmetric) -- see stiffness_wave_eo_kernel for the table layout.  The EO form feeds its scalar operator rows through
+// the software-pipelined contract_single_eo (two rows in flight, a scheduling barrier per step): left to itself the compiler
+// hoists every row load of a stage and spills hundreds of SGPRs through v_readlane / v_writelane.
 template <int NI, int NO, bool EO, bool ANTI>
 __device__ __forceinline__ void prod(const double* __restrict__ tab, const double* x, double* y) {
   if constexpr (EO) {
-    constexpr int HC = NI / 2, HR = NO / 2;
+    constexpr int HC = NI / 2;
     double xe[HC], xo[HC], ab[NO];
-#pragma unroll
-    for (int c = 0; c < HC; ++c) {
-      xe[c] = x[c] + x[NI - 1 - c];
-      xo[c] = x[c] - x[NI - 1 - c];
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const double* xx = (half == 0) ? (ANTI ? xo : xe) : (ANTI ? xe : xo);
-#pragma unroll
-      for (int c = 0; c < HC; ++c) {
-        sdouble_ptr row = launder(tab + c * NO + half * HR);
-#pragma unroll
-        for (int o = 0; o < HR; ++o) ab[half * HR + o] = (c == 0) ? row[o] * xx[0] : fma(row[o], xx[c], ab[half * HR + o]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < HR; ++r) {
-      y[r] = ab[r] + ab[HR + r];
-      y[NO - 1 - r] = ab[r] - ab[HR + r];
-    }
+    eo_pre<NI>(x, xe, xo);
+#if D4EST_DIRECT_LEAN_ROWS
+    contract_rows_eo<HC, NO, false>(tab, ANTI ? xo : xe, ANTI ? xe : xo, ab);
+#else
+    contract_single_eo<HC, NO, false>(tab, ANTI ? xo : xe, ANTI ? xe : xo, ab);
+#endif
+    eo_post<NO>(ab, y);
   } else {
     contract_n<NI, NO>(tab, x, y);
   }
+}
+
+// yS = S x and yA = A x for a centro-symmetric S and a centro-antisymmetric A on the same input (one pass over x)
+template <int NI, int NO, bool EO>
+__device__ __forceinline__ void prod_pair(const double* __restrict__ tabS, const double* __restrict__ tabA, const double* x, double* yS,
+                                          double* yA) {
+  if constexpr (EO) {
+    constexpr int HC = NI / 2;
+    double xe[HC], xo[HC], abS[NO], abA[NO];
+    eo_pre<NI>(x, xe, xo);
+#if D4EST_DIRECT_LEAN_ROWS
+    contract_rows_eo<HC, NO, false>(tabS, xe, xo, abS);
+    contract_rows_eo<HC, NO, false>(tabA, xo, xe, abA);
+#else
+    contract_pair_eo<HC, NO, false, false>(tabS, xe, xo, abS, tabA, xo, xe, abA);
+#endif
+    eo_post<NO>(abS, yS);
+    eo_post<NO>(abA, yA);
+  } else {
+    contract_n<NI, NO>(tabS, x, yS);
+    contract_n<NI, NO>(tabA, x, yA);
+  }
+}
+
+// LDS read that the backend must not pair into ds_read2_b64: on gfx950 a ds_read2_b64 takes 8 LDS cycles (banks mod 32), two
+// ds_read_b64 take 2 + 2 (MI355X_MICROARCH.md, LDS table); volatile accesses are never combined
+#ifndef D4EST_DIRECT_VOLATILE_LDS
+#define D4EST_DIRECT_VOLATILE_LDS 1
+#endif
+__device__ __forceinline__ double lds_ld(const double* p) {
+#if D4EST_DIRECT_VOLATILE_LDS
+  typedef const volatile double __attribute__((address_space(3))) * lds_cvptr;
+  return *(lds_cvptr)p;
+#else
+  return *p;
+#endif
 }
 
 template <int N>
@@ -94,79 +125,117 @@ __device__ __forceinline__ double row_dot(const double* __restrict__ drow, const
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// LDS layouts of the transposition buffer (doubles).  Every "one line per lane" read walks rows of ODD length (RS, RQ), so the 32
+// lanes of a pass hit 32 different bank pairs; the field strides are = 16 dwords mod 64 banks at N = NQ = 8.
 template <int N, int NQ>
 struct DirectCfg {
   static_assert(NQ >= N && NQ * NQ <= 64, "one wavefront per element: (deg_quad + 1)^2 <= 64");
   static constexpr int N2 = N * N, N3 = N2 * N, T = NQ * NQ, PN = N | 1;
-  static constexpr int GS = NQ * N + 8, QS = T + 8, YS = N * NQ + 8, VS = N2 + 8;   // padded field strides (bank spread)
-  static constexpr int S_DOUBLES = cmax(cmax(cmax(8 * N2, 8 * GS), cmax(8 * QS, 8 * T)), cmax(8 * YS, 6 * VS));
+  static constexpr int RS = N | 1, RQ = NQ | 1;       // padded row lengths: lines over a side index / a mortar index
+  static constexpr int GS = NQ * RS, YS = N * RQ;     // field strides of the pass-1 outputs [c][a'][b] and [c8][a][b']
+  static constexpr int QS = T + 8, VS = N2 + 8;       // mortar values [block][a' + NQ b'], lifted fields [block][a + N b]
+  static constexpr int S_DOUBLES = cmax(cmax(cmax(8 * N * RS, 8 * GS), cmax(8 * QS, 8 * NQ * RQ)), cmax(8 * YS, 6 * VS));
   static constexpr int U_DOUBLES = PN * N2;
   static constexpr int OPSZ = N * NQ;
+  static constexpr bool FULL = (N == 8 && NQ == 8);   // every lane is a face node, a row and a column: no guards
 };
 
+// D4EST_DIRECT_WPB wavefronts = elements per workgroup (each wave works alone; fewer, larger workgroups launch faster: 4096
+// one-wave workgroups take ~10 us to get going at config 2)
+#ifndef D4EST_DIRECT_WPB
+#define D4EST_DIRECT_WPB 4
+#endif
+constexpr int kDirectWPB = D4EST_DIRECT_WPB;
+
 template <int N, int NQ, bool EO, bool FUSE>
-__global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
+__global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
                                                              double* __restrict__ Au, const DirectSide* __restrict__ sides,
+                                                             const DirectGhostOff* __restrict__ ghost_off,
                                                              const double* __restrict__ ops, const double* __restrict__ geom,
                                                              const double* __restrict__ bndry_q, const double* __restrict__ robin_c,
                                                              const double* __restrict__ robin_r, int n_elem, int ns0, int ns_stride,
                                                              int xcd_chunk, DirectFuse cf) {
   using C = DirectCfg<N, NQ>;
-  constexpr int N2 = C::N2, N3 = C::N3, T = C::T, PN = C::PN, GS = C::GS, QS = C::QS, YS = C::YS, VS = C::VS;
-  __shared__ double s_U[C::U_DOUBLES];   // the element's u (line reads in the three directions), later the Au accumulator
-  __shared__ double s_S[C::S_DOUBLES];   // the transposition buffer of every pass (in place: a wave runs in lockstep)
-  const double* tC = ops;
-  const double* tCD = ops + C::OPSZ;
-  const double* tE = ops + 2 * C::OPSZ;
-  const double* tDtE = ops + 3 * C::OPSZ;
-  const double* dr0 = ops + 4 * C::OPSZ;   // D[0][:], then D[N-1][:]
-  const int lane = threadIdx.x;
+  constexpr int N2 = C::N2, N3 = C::N3, T = C::T, PN = C::PN, RS = C::RS, RQ = C::RQ, GS = C::GS, QS = C::QS, YS = C::YS, VS = C::VS;
+  constexpr bool FULL = C::FULL;
+  __shared__ double s_Ua[kDirectWPB][C::U_DOUBLES];   // per wave: the element's u (line reads in the three directions), later the Au accumulator
+#ifndef D4EST_DIRECT_LDS_PAD
+#define D4EST_DIRECT_LDS_PAD 0
+#endif
+  __shared__ double s_Sa[kDirectWPB][C::S_DOUBLES + D4EST_DIRECT_LDS_PAD];   // (pad: occupancy experiments only)   // per wave: the transposition buffer of every pass (in place: a wave runs in lockstep)
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* s_U = s_Ua[wv];
+  double* s_S = s_Sa[wv];
+  // the five tables are addressed from `ops` at every use (one live pointer instead of five: the kernel is short of SGPRs)
+#define tC (ops)
+#define tCD (ops + C::OPSZ)
+#define tE (ops + 2 * C::OPSZ)
+#define tDtE (ops + 3 * C::OPSZ)
+#define dr0 (ops + 4 * C::OPSZ) /* D[0][:], then D[N-1][:] */
+  const int lane = threadIdx.x & 63;   // (the mask tells the compiler the range: without it every lane-indexed loop grows guards)
   const int a = lane % NQ, b = lane / NQ;
-  const bool on_q = lane < T, on_m = on_q && a < N && b < N;
+  const bool on_q = FULL || lane < T, on_m = FULL || (on_q && a < N && b < N);
   // XCD-aware element order (workgroups are dealt round-robin to the 8 XCDs, each with its own L2): XCD x walks the x-th contiguous
   // (Morton-local) eighth of the elements, so a neighbour's u is more often in the reader's L2
   const int v = blockIdx.x;
-  const int e = xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v;
+  const int e = (xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v) * kDirectWPB + wv;   // xcd_chunk in workgroups
   if (e >= n_elem) return;
   const int ns = __builtin_amdgcn_readfirstlane(ns0 + e * ns_stride);
   const DirectSide* __restrict__ sd = sides + 6 * (size_t)e;
 
-  // ---- the element's u -> LDS (odd padded line length: conflict-free line reads in all three directions)
+  // ---- the element's u -> LDS (odd padded line length: conflict-free line reads in all three directions); all loads first
+  {
+    constexpr int UT = (N3 + 63) / 64;
+    double uo[UT];
 #pragma unroll
-  for (int idx = lane; idx < N3; idx += 64) {
-    const int i = idx % N, j = (idx / N) % N, k = idx / N2;
-    s_U[i + PN * (j + N * k)] = u[ns + idx];
+    for (int t = 0; t < UT; ++t) uo[t] = (N3 % 64 == 0 || lane + 64 * t < N3) ? u[ns + lane + 64 * t] : 0.0;
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const int idx = lane + 64 * t;
+      const int i = idx % N, j = (idx / N) % N, k = idx / N2;
+      if (N3 % 64 == 0 || idx < N3) s_U[i + PN * (j + N * k)] = uo[t];
+    }
   }
   wave_lds_fence();
   // ---- own nodal face fields: trace and normal derivative at face node (a, b) of the six faces
   double own_tr[6], own_nd[6];
+  {
+    sdouble_ptr r0 = launder(dr0), r1 = launder(dr0 + N);   // the two rows of D once for the three directions
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    double x[N];
+    for (int d = 0; d < 3; ++d) {
+      double x[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int idx = (d == 0) ? i + PN * (a + N * b) : (d == 1 ? a + PN * (i + N * b) : a + PN * (b + N * i));
-      x[i] = on_m ? s_U[idx] : 0.0;
+      for (int i = 0; i < N; ++i) {
+        const int idx = (d == 0) ? i + PN * (a + N * b) : (d == 1 ? a + PN * (i + N * b) : a + PN * (b + N * i));
+        x[i] = on_m ? lds_ld(&s_U[idx]) : 0.0;
+      }
+      own_tr[2 * d] = x[0];
+      own_tr[2 * d + 1] = x[N - 1];
+      double s0 = r0[0] * x[0], s1 = r1[0] * x[0];
+#pragma unroll
+      for (int i = 1; i < N; ++i) {
+        s0 = fma(r0[i], x[i], s0);
+        s1 = fma(r1[i], x[i], s1);
+      }
+      own_nd[2 * d] = s0;
+      own_nd[2 * d + 1] = s1;
     }
-    own_tr[2 * d] = x[0];
-    own_tr[2 * d + 1] = x[N - 1];
-    own_nd[2 * d] = row_dot<N>(dr0, x);
-    own_nd[2 * d + 1] = row_dot<N>(dr0 + N, x);
   }
   wave_lds_fence();   // s_U is free from here on: it becomes the accumulator of the lifted face terms
 
   auto dir_body = [&](auto dc) {
     constexpr int d = decltype(dc)::value;
     constexpr int t0 = (d == 0) ? 1 : 0, t1d = (d == 2) ? 1 : 2;   // reference directions of the face indices a and b
-    DirectSide sh[2] = {sd[2 * d], sd[2 * d + 1]};
+    const int kcf[2] = {sd[2 * d].kcf, sd[2 * d + 1].kcf};
+    const int sgeom[2] = {sd[2 * d].geom, sd[2 * d + 1].geom};
     // ---- nodal fields of the two faces: c = 0..3 trace (own 2d, own 2d+1, nbr 2d, nbr 2d+1), c = 4..7 normal derivative
     double fld[8] = {own_tr[2 * d], own_tr[2 * d + 1], 0.0, 0.0, own_nd[2 * d], own_nd[2 * d + 1], 0.0, 0.0};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (sh[h].kind == 1) {
+      if ((kcf[h] & 3) == 1) {
         // the normal lines of the (+) element's face fp at ITS face node (a, b)
-        const double* __restrict__ up = u + sh[h].nbr_ns;
-        const int dp = sh[h].fp >> 1, hi = sh[h].fp & 1;
+        const double* __restrict__ up = u + sd[2 * d + h].nbr_ns;
+        const int dp = kcf[h] >> 6, hi = (kcf[h] >> 5) & 1;
         double y[N];
         if (on_m) {
           if (dp == 0) {
@@ -191,43 +260,46 @@ __global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __res
     wave_lds_fence();
     if (on_m) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) s_S[c * N2 + b * N + a] = fld[c];
+      for (int c = 0; c < 8; ++c) s_S[(c * N + b) * RS + a] = fld[c];
     }
     wave_lds_fence();
-    const bool row_on = lane < 8 * N;
+    const bool row_on = FULL || lane < 8 * N;
     const int rc = lane / N, rb = lane % N;
     double P[NQ], R[NQ];
     {
       double x[N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) x[i] = row_on ? s_S[lane * N + i] : 0.0;
-      prod<N, NQ, EO, false>(tC, x, P);
-      prod<N, NQ, EO, true>(tCD, x, R);   // used for the trace rows (c < 4) only
+      for (int i = 0; i < N; ++i) x[i] = row_on ? lds_ld(&s_S[lane * RS + i]) : 0.0;
+      prod_pair<N, NQ, EO>(tC, tCD, x, P, R);   // R = CD x is used for the trace rows (c < 4) only
     }
     // ---- pass 2: column (c, a') per lane, contract the face index b
     wave_lds_fence();
     if (row_on) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) s_S[rc * GS + q * N + rb] = P[q];
+      for (int q = 0; q < NQ; ++q) s_S[rc * GS + q * RS + rb] = P[q];
     }
     wave_lds_fence();
-    const bool col_on = lane < 8 * NQ;
+    const bool col_on = FULL || lane < 8 * NQ;
     const int cc = lane / NQ, aq = lane % NQ;
-    double col[N], col2[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) col[i] = col_on ? s_S[cc * GS + aq * N + i] : 0.0;
-    wave_lds_fence();
-    if (row_on && rc < 4) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) s_S[rc * GS + q * N + rb] = R[q];
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < N; ++i) col2[i] = (col_on && cc >= 4) ? s_S[(cc - 4) * GS + aq * N + i] : 0.0;
     double o1[NQ], o2[NQ];
-    prod<N, NQ, EO, false>(tC, col, o1);                  // lanes c < 4: u            lanes c >= 4: du/dn
-    if (cc < 4) prod<N, NQ, EO, true>(tCD, col, o2);      //              du/dt_b
-    else prod<N, NQ, EO, false>(tC, col2, o2);            //                                         du/dt_a
+    {
+      double col[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) col[i] = col_on ? lds_ld(&s_S[cc * GS + aq * RS + i]) : 0.0;
+      wave_lds_fence();
+      if (row_on && rc < 4) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s_S[rc * GS + q * RS + rb] = R[q];
+      }
+      wave_lds_fence();
+      prod_pair<N, NQ, EO>(tC, tCD, col, o1, o2);   // lanes c < 4: u, du/dt_b        lanes c >= 4: du/dn (o2 replaced below)
+      if (cc >= 4) {
+        double col2[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) col2[i] = col_on ? lds_ld(&s_S[(cc - 4) * GS + aq * RS + i]) : 0.0;
+        prod<N, NQ, EO, false>(tC, col2, o2);       //                                 lanes c >= 4: du/dt_a
+      }
+    }
     // ---- SIPG terms, one face at a time (the mortar values of its two sides go through the buffer)
     double At[2][4];
 #pragma unroll
@@ -235,7 +307,7 @@ __global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __res
       wave_lds_fence();
       if (col_on && (cc & 1) == h) {
         const int mp = (cc >> 1) & 1;
-        const int dn = mp ? (sh[h].fp >> 1) : d;   // the reference frame of the side that owns the trace
+        const int dn = mp ? (kcf[h] >> 6) : d;   // the reference frame of the side that owns the trace
         const int ta = (dn == 0) ? 1 : 0, tb = (dn == 2) ? 1 : 2;
         const int c1 = (cc >= 4) ? 1 + dn : 0, c2 = (cc >= 4) ? 1 + ta : 1 + tb;
 #pragma unroll
@@ -246,28 +318,28 @@ __global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __res
       }
       wave_lds_fence();
       double qm[4] = {0, 0, 0, 0}, qp[4] = {0, 0, 0, 0}, gq[7] = {0, 0, 0, 0, 0, 0, 0};
-      const int kind = sh[h].kind;
+      const int kind = kcf[h] & 3, code = (kcf[h] >> 2) & 7;
       if (on_q) {
         const int k = lane;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) qm[c] = s_S[c * QS + k];
+        for (int c = 0; c < 4; ++c) qm[c] = lds_ld(&s_S[c * QS + k]);
         if (kind == 1) {
-          const int kp = reorder_index(sh[h].code, NQ - 1, a, b);
+          const int kp = reorder_index(code, NQ - 1, a, b);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) qp[c] = s_S[(4 + c) * QS + kp];
+          for (int c = 0; c < 4; ++c) qp[c] = lds_ld(&s_S[(4 + c) * QS + kp]);
         } else if (kind == 2) {
-          const double* __restrict__ p = ghost_qtrace + sh[h].nbr_qoff + reorder_index(sh[h].code, NQ - 1, a, b);
+          const double* __restrict__ p = ghost_qtrace + ghost_off[6 * (size_t)e + 2 * d + h] + reorder_index(code, NQ - 1, a, b);
 #pragma unroll
           for (int c = 0; c < 4; ++c) qp[c] = p[c * T];
         } else if (robin_c) {
-          qp[0] = robin_r[sh[h].geom + k];
+          qp[0] = robin_r[sgeom[h] + k];
         } else {
-          qp[0] = bndry_q[sh[h].geom + k];
+          qp[0] = bndry_q[sgeom[h] + k];
         }
         if (kind == 0 && robin_c) {
-          gq[6] = robin_c[sh[h].geom + k];   // am = ap = 0: no term 1 / term 2 on a Robin side
+          gq[6] = robin_c[sgeom[h] + k];   // am = ap = 0: no term 1 / term 2 on a Robin side
         } else {
-          const double* __restrict__ g = geom + (size_t)7 * sh[h].geom + k;
+          const double* __restrict__ g = geom + (size_t)7 * sgeom[h] + k;
 #pragma unroll
           for (int c = 0; c < 7; ++c) gq[c] = g[c * T];
         }
@@ -289,14 +361,14 @@ __global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __res
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s_S[(4 * h + c) * T + b * NQ + a] = At[h][c];
+        for (int c = 0; c < 4; ++c) s_S[((4 * h + c) * NQ + b) * RQ + a] = At[h][c];
     }
     wave_lds_fence();
     double Yv[N];
     {
       double row[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) row[q] = col_on ? s_S[lane * NQ + q] : 0.0;
+      for (int q = 0; q < NQ; ++q) row[q] = col_on ? lds_ld(&s_S[lane * RQ + q]) : 0.0;
       // the term-2 field along a takes D_a^T on the way:  val = E_b E_a A0 + E_b (D^T E)_a A_t0 + (D^T E)_b E_a A_t1
       if ((cc & 3) == 1 + t0) prod<NQ, N, EO, true>(tDtE, row, Yv);
       else prod<NQ, N, EO, false>(tE, row, Yv);
@@ -304,7 +376,7 @@ __global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __res
     wave_lds_fence();
     if (col_on) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) s_S[cc * YS + i * NQ + aq] = Yv[i];
+      for (int i = 0; i < N; ++i) s_S[cc * YS + i * RQ + aq] = Yv[i];
     }
     wave_lds_fence();
     // ---- lift pass 2: column (h, g, a) per lane: g = 0 face-local part through E, 1 term 2 along b through D^T E, 2 normal term 2
@@ -316,8 +388,8 @@ __global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __res
       const int f1 = (vg == 0) ? 0 : (vg == 1 ? 1 + t1d : 1 + d);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        double t = v_on ? s_S[(4 * vh + f1) * YS + va * NQ + q] : 0.0;
-        if (v_on && vg == 0) t += s_S[(4 * vh + 1 + t0) * YS + va * NQ + q];
+        double t = v_on ? lds_ld(&s_S[(4 * vh + f1) * YS + va * RQ + q]) : 0.0;
+        if (v_on && vg == 0) t += lds_ld(&s_S[(4 * vh + 1 + t0) * YS + va * RQ + q]);
         colq[q] = t;
       }
       if (vg == 1) prod<NQ, N, EO, true>(tDtE, colq, Vv);
@@ -332,8 +404,8 @@ __global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __res
     // ---- the element's normal line at face node (a, b): face-local part at its two ends, D^T of the normal term 2 along it
     double acc[N];
     if (on_m) {
-      const double val0 = s_S[0 * VS + b * N + a] + s_S[1 * VS + b * N + a], n0 = s_S[2 * VS + b * N + a];
-      const double val1 = s_S[3 * VS + b * N + a] + s_S[4 * VS + b * N + a], n1 = s_S[5 * VS + b * N + a];
+      const double val0 = lds_ld(&s_S[0 * VS + b * N + a]) + lds_ld(&s_S[1 * VS + b * N + a]), n0 = lds_ld(&s_S[2 * VS + b * N + a]);
+      const double val1 = lds_ld(&s_S[3 * VS + b * N + a]) + lds_ld(&s_S[4 * VS + b * N + a]), n1 = lds_ld(&s_S[5 * VS + b * N + a]);
       sdouble_ptr r0 = launder(dr0), r1 = launder(dr0 + N);
 #pragma unroll
       for (int i = 0; i < N; ++i) acc[i] = fma(r0[i], n0, r1[i] * n1);
@@ -349,7 +421,7 @@ __global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __res
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           const size_t o = (size_t)ns + a + N * b + N2 * i;
-          const double au = Au[o] + (s_U[a + PN * (b + N * i)] + acc[i]);
+          const double au = Au[o] + (lds_ld(&s_U[a + PN * (b + N * i)]) + acc[i]);
           Au[o] = au;
           if constexpr (FUSE) {
             // the Chebyshev update of the node (cheby_update_kernel, same roundings): u is an INPUT of this kernel (the
@@ -369,6 +441,11 @@ __global__ __launch_bounds__(64, 4) void faces_direct_kernel(const double* __res
   dir_body(std::integral_constant<int, 0>{});
   dir_body(std::integral_constant<int, 1>{});
   dir_body(std::integral_constant<int, 2>{});
+#undef tC
+#undef tCD
+#undef tE
+#undef tDtE
+#undef dr0
 }
 
 // ---------------------------------------------------------------------------
@@ -380,6 +457,7 @@ void direct_destroy(d4est_hip_plan* plan) {
   DirectHost* dh = host_of(plan);
   if (!dh) return;
   (void)hipFree(dh->d_sides);
+  (void)hipFree(dh->d_ghost_off);
   (void)hipFree(dh->d_ops);
   (void)hipFree(dh->d_u2);
   delete dh;
@@ -421,21 +499,24 @@ void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, c
   HIP_CHECK(hipMalloc(&dh->d_ops, ops.size() * sizeof(double)));
   HIP_CHECK(hipMemcpy(dh->d_ops, ops.data(), ops.size() * sizeof(double), hipMemcpyHostToDevice));
   std::vector<DirectSide> sd(6 * (size_t)ne);
+  std::vector<DirectGhostOff> goff(6 * (size_t)ne, 0);
   for (int e = 0; e < ne; ++e)
     for (int f = 0; f < 6; ++f) {
       const size_t s = 6 * (size_t)e + f;
       DirectSide d{};
       const int nbr = plan->side_nbr[s];
-      d.kind = (nbr == -1) ? 0 : (nbr >= 0 ? 1 : 2);
-      d.code = plan->side_reorder[s];
-      d.fp = (d.kind == 0) ? 0 : plan->side_nbr_face[s];
-      d.nbr_ns = (d.kind == 1) ? plan->nodal_stride[nbr] : 0;
+      const int kind = (nbr == -1) ? 0 : (nbr >= 0 ? 1 : 2);
+      const int fp = (kind == 0) ? 0 : plan->side_nbr_face[s];
+      d.kcf = kind | ((plan->side_reorder[s] & 7) << 2) | (fp << 5);
+      d.nbr_ns = (kind == 1) ? plan->nodal_stride[nbr] : 0;
       d.geom = plan->side_mortar_stride[s];
-      d.nbr_qoff = (d.kind == 2) ? plan->ghost_trace_offset[s] : 0;
+      goff[s] = (kind == 2) ? plan->ghost_trace_offset[s] : 0;
       sd[s] = d;
     }
   HIP_CHECK(hipMalloc(&dh->d_sides, std::max<size_t>(sd.size(), 1) * sizeof(DirectSide)));
   if (!sd.empty()) HIP_CHECK(hipMemcpy(dh->d_sides, sd.data(), sd.size() * sizeof(DirectSide), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMalloc(&dh->d_ghost_off, std::max<size_t>(goff.size(), 1) * sizeof(DirectGhostOff)));
+  if (!goff.empty()) HIP_CHECK(hipMemcpy(dh->d_ghost_off, goff.data(), goff.size() * sizeof(DirectGhostOff), hipMemcpyHostToDevice));
   plan->direct = dh;
 }
 
@@ -458,24 +539,35 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
   if (n == 0) return;
   if (plan->ghost_trace_doubles > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has ghost sides but no ghost trace buffer was given");
   static const bool no_remap = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
-  const int chunk = (n % 8 == 0 && !no_remap) ? n / 8 : 0;
+  const int n_wg = (n + kDirectWPB - 1) / kDirectWPB;
+  const int chunk = (n % (8 * kDirectWPB) == 0 && !no_remap) ? n_wg / 8 : 0;
   bool done = false;
 #define X(N_, NQ_)                                                                                                              \
   if (!done && dh->N == N_ && dh->NQ == NQ_) {                                                                                  \
     constexpr bool kEo = (N_ % 2 == 0) && (NQ_ % 2 == 0);                                                                      \
     if (cf)                                                                                                                     \
-      hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, kEo, true>), dim3(n), dim3(64), 0, plan->stream, u, ghost_trace, Au,     \
-                         dh->d_sides, dh->d_ops, plan->d_face_geom, plan->d_bndry, robin_c, robin_r, n, dh->ns0, dh->ns_stride, \
+      hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, kEo, true>), dim3(n_wg), dim3(64 * kDirectWPB), 0, plan->stream, u, ghost_trace, Au,     \
+                         dh->d_sides, dh->d_ghost_off, dh->d_ops, plan->d_face_geom, plan->d_bndry, robin_c, robin_r, n, dh->ns0, dh->ns_stride, \
                          chunk, *cf);                                                                                           \
     else                                                                                                                        \
-      hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, kEo, false>), dim3(n), dim3(64), 0, plan->stream, u, ghost_trace, Au,    \
-                         dh->d_sides, dh->d_ops, plan->d_face_geom, plan->d_bndry, robin_c, robin_r, n, dh->ns0, dh->ns_stride, \
+      hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, kEo, false>), dim3(n_wg), dim3(64 * kDirectWPB), 0, plan->stream, u, ghost_trace, Au,    \
+                         dh->d_sides, dh->d_ghost_off, dh->d_ops, plan->d_face_geom, plan->d_bndry, robin_c, robin_r, n, dh->ns0, dh->ns_stride, \
                          chunk, DirectFuse{});                                                                                  \
     done = true;                                                                                                                \
   }
   D4EST_HIP_DIRECT_PAIRS(X)
 #undef X
   if (!done) D4EST_HIP_ABORT("direct face kernel: no instance for N = %d, NQ = %d", dh->N, dh->NQ);
+  static bool occ_done = false;
+  if (!occ_done && std::getenv("D4EST_HIP_DEBUG_OCC")) {
+    occ_done = true;
+    int nb = -1;
+    hipFuncAttributes at{};
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(faces_direct_kernel<8, 8, true, false>), 64 * kDirectWPB, 0);
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(faces_direct_kernel<8, 8, true, false>));
+    std::fprintf(stderr, "[d4est_hip] occupancy: faces_direct<8,8> %d workgroups of %d waves per CU (regs %d, lds %zu, scratch %zu)\n", nb, kDirectWPB,
+                 at.numRegs, at.sharedSizeBytes, at.localSizeBytes);
+  }
   HIP_CHECK(hipGetLastError());
 }
 
