@@ -243,7 +243,7 @@ const char* d4est_hip_plan_last_kernel(const d4est_hip_plan_t* plan) { check_pla
 const char* d4est_hip_plan_face_path(const d4est_hip_plan_t* plan) {
   check_plan(plan, "plan_face_path");
   if (!plan->has_faces) D4EST_HIP_ABORT("plan_face_path: call plan_set_faces first");
-  return d4est_hip::direct_active(plan) ? "direct" : "two-phase";
+  return d4est_hip::direct_active(plan) ? (d4est_hip::direct_fused_ok(plan) ? "direct+volume" : "direct") : "two-phase";
 }
 int d4est_hip_plan_local_nodes(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes"); return plan->local_nodes; }
 int d4est_hip_plan_local_nodes_quad(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes_quad"); return plan->local_nodes_quad; }
@@ -562,11 +562,13 @@ void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const doub
     d4est_hip::apply_operator(plan, u_dev, Au_dev, nullptr, false);  // the Laplacian only (no plan_set_lhs_coefficient term)
     return;
   }
-  d4est_hip::launch_stiffness(plan, u_dev, Au_dev);
   if (d4est_hip::direct_active(plan)) {   // the caller's ghost traces, the local ones from u inside the kernel
-    d4est_hip::launch_flux_direct(plan, u_dev, ghost_trace_dev, Au_dev);
+    const bool whole = d4est_hip::direct_fused_ok(plan);
+    if (!whole) d4est_hip::launch_stiffness(plan, u_dev, Au_dev);
+    d4est_hip::launch_flux_direct(plan, u_dev, ghost_trace_dev, Au_dev, nullptr, whole ? 1 : 0);
     return;
   }
+  d4est_hip::launch_stiffness(plan, u_dev, Au_dev);
   d4est_hip::launch_traces(plan, u_dev, plan->d_trace, false);
   d4est_hip::launch_flux(plan, plan->d_trace, ghost_trace_dev, Au_dev);
 }

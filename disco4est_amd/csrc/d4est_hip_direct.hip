@@ -147,25 +147,41 @@ struct DirectCfg {
 #endif
 constexpr int kDirectWPB = D4EST_DIRECT_WPB;
 
-template <int N, int NQ, bool EO, bool FUSE>
+// VOL: the volume (stiffness) term of the element is applied by the same wavefront after its face terms and A u is written once --
+// one kernel for the whole operator (u in, A u out: no read-modify-write of A u, one launch).  The face result waits in 8 registers
+// per lane, in the layout of the volume kernel's coalesced store.
+struct DirectVol {
+  const double* metric = nullptr;    // 6 combined metric entries per quadrature node, element-blocked (plan->d_metric)
+  const double* EBf = nullptr;       // even-odd tables of the volume operators (Bucket::d_EBf ...)
+  const double* EGf = nullptr;
+  const double* EBb = nullptr;
+  const double* EGb = nullptr;
+  const double* affine = nullptr;    // AFF: 6 numbers per element
+  const double* wq = nullptr;        // AFF: quadrature weights
+  int qs0 = 0, qs_stride = 0;
+};
+
+template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only, 1 + streamed metric, 2 + affine metric */>
 __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
                                                              double* __restrict__ Au, const DirectSide* __restrict__ sides,
                                                              const DirectGhostOff* __restrict__ ghost_off,
                                                              const double* __restrict__ ops, const double* __restrict__ geom,
                                                              const double* __restrict__ bndry_q, const double* __restrict__ robin_c,
                                                              const double* __restrict__ robin_r, int n_elem, int ns0, int ns_stride,
-                                                             int xcd_chunk, DirectFuse cf) {
+                                                             int xcd_chunk, DirectFuse cf, DirectVol vol) {
   using C = DirectCfg<N, NQ>;
   constexpr int N2 = C::N2, N3 = C::N3, T = C::T, PN = C::PN, RS = C::RS, RQ = C::RQ, GS = C::GS, QS = C::QS, YS = C::YS, VS = C::VS;
   constexpr bool FULL = C::FULL;
-  __shared__ double s_Ua[kDirectWPB][C::U_DOUBLES];   // per wave: the element's u (line reads in the three directions), later the Au accumulator
 #ifndef D4EST_DIRECT_LDS_PAD
 #define D4EST_DIRECT_LDS_PAD 0
 #endif
-  __shared__ double s_Sa[kDirectWPB][C::S_DOUBLES + D4EST_DIRECT_LDS_PAD];   // (pad: occupancy experiments only)   // per wave: the transposition buffer of every pass (in place: a wave runs in lockstep)
+  // per wave: [0, L0) the element's u (line reads in the three directions), later the accumulator of the lifted face terms; [L0, L0 + L1)
+  // the transposition buffer of every pass (in place: a wave runs in lockstep).  With VOL the two halves are the volume kernel's two fields.
+  constexpr int L0 = cmax(C::U_DOUBLES, VOL ? WaveCfg<N, NQ>::FS : 0), L1 = cmax(C::S_DOUBLES, VOL ? WaveCfg<N, NQ>::FS : 0);
+  __shared__ double s_L[kDirectWPB][L0 + L1 + D4EST_DIRECT_LDS_PAD];   // (pad: occupancy experiments only)
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* s_U = s_Ua[wv];
-  double* s_S = s_Sa[wv];
+  double* s_U = s_L[wv];
+  double* s_S = s_L[wv] + L0;
   // the five tables are addressed from `ops` at every use (one live pointer instead of five: the kernel is short of SGPRs)
 #define tC (ops)
 #define tCD (ops + C::OPSZ)
@@ -222,6 +238,10 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
     }
   }
   wave_lds_fence();   // s_U is free from here on: it becomes the accumulator of the lifted face terms
+
+  double facc[N];   // VOL: the element's face terms at (i = a, j = b, k = 0 .. N-1)
+#pragma unroll
+  for (int i = 0; i < N; ++i) facc[i] = 0.0;
 
   auto dir_body = [&](auto dc) {
     constexpr int d = decltype(dc)::value;
@@ -417,6 +437,9 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
       } else if constexpr (d == 1) {
 #pragma unroll
         for (int i = 0; i < N; ++i) s_U[a + PN * (i + N * b)] += acc[i];
+      } else if constexpr (VOL != 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) facc[i] = lds_ld(&s_U[a + PN * (b + N * i)]) + acc[i];
       } else {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -441,6 +464,42 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
   dir_body(std::integral_constant<int, 0>{});
   dir_body(std::integral_constant<int, 1>{});
   dir_body(std::integral_constant<int, 2>{});
+  if constexpr (VOL != 0) {
+    static_assert(VOL == 0 || (N == NQ && N % 2 == 0 && WaveCfg<N, NQ>::EPB == 1), "fused volume term: N = NQ even, one element per wave");
+    // ---- the volume term: u_e -> R0, the even-odd sum-factorised apply (stiffness_wave_eo_kernel's body), A u = volume + faces
+    {
+      constexpr int UT = (N3 + 63) / 64;
+      double uo[UT];
+#pragma unroll
+      for (int t = 0; t < UT; ++t) uo[t] = (N3 % 64 == 0 || lane + 64 * t < N3) ? u[ns + lane + 64 * t] : 0.0;
+#pragma unroll
+      for (int t = 0; t < UT; ++t) {
+        const int idx = lane + 64 * t;
+        const int i = idx % N, j = (idx / N) % N, k = idx / N2;
+        if (N3 % 64 == 0 || idx < N3) s_U[i + PN * (j + N * k)] = uo[t];
+      }
+    }
+    wave_lds_fence();
+    const int qs = __builtin_amdgcn_readfirstlane(vol.qs0 + e * vol.qs_stride);
+    stiffness_wave_eo_element<N, NQ, VOL == 2, false>(s_U, s_S, vol.metric, qs, e, on_q, a, b, vol.EBf, vol.EGf, vol.EBb, vol.EGb,
+                                                      vol.affine, vol.wq);
+    if (on_m) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const size_t o = (size_t)ns + a + N * b + N2 * i;
+        const double au = s_U[a + PN * (b + N * i)] + facc[i];
+        Au[o] = au;
+        if constexpr (FUSE) {   // the Chebyshev update of the node, as in the faces-only form
+          const double res = __dadd_rn(cf.rhs[o], __dmul_rn(-1.0, au));
+          const double ri = __dmul_rn(cf.alpha, res);
+          const double pi = __dadd_rn(__dmul_rn(cf.beta, cf.p[o]), ri);
+          if (cf.r) cf.r[o] = ri;
+          cf.p[o] = pi;
+          cf.u_out[o] = __dadd_rn(u[o], pi);
+        }
+      }
+    }
+  }
 #undef tC
 #undef tCD
 #undef tE
@@ -530,8 +589,27 @@ double* direct_second_vector(d4est_hip_plan* plan) {
   return dh->d_u2;
 }
 
+// the whole operator in one kernel?  conforming uniform plan with the direct tables, N = NQ in {6, 8}, one bucket in element order
+// with affine strides, even-odd volume tables, default volume-kernel tuning
+bool direct_fused_ok(const d4est_hip_plan* plan) {
+  const DirectHost* dh = static_cast<const DirectHost*>(plan->direct);
+  if (!direct_active(plan) || !dh) return false;
+  const int t = plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT];
+  if (!(t < 0 || t == 2)) return false;
+  if (!(dh->N == dh->NQ && (dh->N == 6 || dh->N == 8))) return false;
+  if (!plan->has_geometry || plan->buckets.size() != 1) return false;
+  const Bucket& bk = plan->buckets[0];
+  if (bk.N != dh->N || bk.NQ != dh->NQ || !bk.d_EBf || bk.ns_stride < 0 || bk.qs_stride < 0 || bk.ns0 != dh->ns0 || bk.ns_stride != dh->ns_stride) return false;
+  if (bk.n_elem != plan->n_elements) return false;
+  for (int i = 0; i < plan->n_elements; ++i)
+    if (plan->elem_ids[i] != i) return false;
+  const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
+  return tw < 0 || tw == 11;
+}
+
+// vol_term: 0 the face terms only (Au += ...), 1 the whole operator (Au = volume + faces; direct_fused_ok)
 void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
-                         const double* robin_c, const double* robin_r) {
+                         const double* robin_c, const double* robin_r, int vol_term) {
   DirectHost* dh = host_of(plan);
   if (!dh) D4EST_HIP_ABORT("direct face kernel: the plan has no direct tables");
   if (!plan->has_face_geometry) D4EST_HIP_ABORT("apply flux: plan_set_mortar_geometry was not called");
@@ -541,32 +619,47 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
   static const bool no_remap = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
   const int n_wg = (n + kDirectWPB - 1) / kDirectWPB;
   const int chunk = (n % (8 * kDirectWPB) == 0 && !no_remap) ? n_wg / 8 : 0;
+  DirectVol vol;
+  int vmode = 0;
+  if (vol_term) {
+    if (!direct_fused_ok(plan)) D4EST_HIP_ABORT("direct face kernel: the fused volume term was requested on a plan that cannot take it");
+    const Bucket& bk = plan->buckets[0];
+    vol.metric = plan->d_metric; vol.EBf = bk.d_EBf; vol.EGf = bk.d_EGf; vol.EBb = bk.d_EBb; vol.EGb = bk.d_EGb;
+    vol.qs0 = bk.qs0; vol.qs_stride = bk.qs_stride;
+    const bool aff = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0;
+    if (aff) { vol.affine = plan->d_metric_affine; vol.wq = bk.d_w; }
+    vmode = aff ? 2 : 1;
+    std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::faces_direct_kernel<%d,%d,vol%s> (faces + stiffness_wave_eo body)", dh->N, dh->NQ, aff ? ",affine" : "");
+  }
+  const DirectFuse cfv = cf ? *cf : DirectFuse{};
   bool done = false;
-#define X(N_, NQ_)                                                                                                              \
-  if (!done && dh->N == N_ && dh->NQ == NQ_) {                                                                                  \
-    constexpr bool kEo = (N_ % 2 == 0) && (NQ_ % 2 == 0);                                                                      \
-    if (cf)                                                                                                                     \
-      hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, kEo, true>), dim3(n_wg), dim3(64 * kDirectWPB), 0, plan->stream, u, ghost_trace, Au,     \
-                         dh->d_sides, dh->d_ghost_off, dh->d_ops, plan->d_face_geom, plan->d_bndry, robin_c, robin_r, n, dh->ns0, dh->ns_stride, \
-                         chunk, *cf);                                                                                           \
-    else                                                                                                                        \
-      hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, kEo, false>), dim3(n_wg), dim3(64 * kDirectWPB), 0, plan->stream, u, ghost_trace, Au,    \
-                         dh->d_sides, dh->d_ghost_off, dh->d_ops, plan->d_face_geom, plan->d_bndry, robin_c, robin_r, n, dh->ns0, dh->ns_stride, \
-                         chunk, DirectFuse{});                                                                                  \
-    done = true;                                                                                                                \
+#define D4EST_HIP_DIRECT_GO(N_, NQ_, FUSE_, VOL_)                                                                             \
+  hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, (N_ % 2 == 0) && (NQ_ % 2 == 0), FUSE_, VOL_>), dim3(n_wg), dim3(64 * kDirectWPB), 0,     \
+                     plan->stream, u, ghost_trace, Au, dh->d_sides, dh->d_ghost_off, dh->d_ops, plan->d_face_geom, plan->d_bndry,            \
+                     robin_c, robin_r, n, dh->ns0, dh->ns_stride, chunk, cfv, vol)
+#define X(N_, NQ_)                                                                 \
+  if (!done && dh->N == N_ && dh->NQ == NQ_) {                                     \
+    if constexpr (N_ == NQ_ && (N_ == 6 || N_ == 8)) {                             \
+      if (vmode == 1) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 1); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 1); done = true; } \
+      if (vmode == 2) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 2); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 2); done = true; } \
+    }                                                                              \
+    if (!done) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 0); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 0); done = true; }        \
   }
   D4EST_HIP_DIRECT_PAIRS(X)
 #undef X
+#undef D4EST_HIP_DIRECT_GO
   if (!done) D4EST_HIP_ABORT("direct face kernel: no instance for N = %d, NQ = %d", dh->N, dh->NQ);
   static bool occ_done = false;
   if (!occ_done && std::getenv("D4EST_HIP_DEBUG_OCC")) {
     occ_done = true;
-    int nb = -1;
-    hipFuncAttributes at{};
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(faces_direct_kernel<8, 8, true, false>), 64 * kDirectWPB, 0);
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(faces_direct_kernel<8, 8, true, false>));
-    std::fprintf(stderr, "[d4est_hip] occupancy: faces_direct<8,8> %d workgroups of %d waves per CU (regs %d, lds %zu, scratch %zu)\n", nb, kDirectWPB,
-                 at.numRegs, at.sharedSizeBytes, at.localSizeBytes);
+    int nb = -1, nv = -1;
+    hipFuncAttributes at{}, av{};
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(faces_direct_kernel<8, 8, true, false, 0>), 64 * kDirectWPB, 0);
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(faces_direct_kernel<8, 8, true, false, 0>));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nv, reinterpret_cast<const void*>(faces_direct_kernel<8, 8, true, false, 1>), 64 * kDirectWPB, 0);
+    (void)hipFuncGetAttributes(&av, reinterpret_cast<const void*>(faces_direct_kernel<8, 8, true, false, 1>));
+    std::fprintf(stderr, "[d4est_hip] occupancy: faces_direct<8,8> %d workgroups of %d waves per CU (regs %d, lds %zu, scratch %zu); with the volume term %d (regs %d, lds %zu, scratch %zu)\n",
+                 nb, kDirectWPB, at.numRegs, at.sharedSizeBytes, at.localSizeBytes, nv, av.numRegs, av.sharedSizeBytes, av.localSizeBytes);
   }
   HIP_CHECK(hipGetLastError());
 }

@@ -2631,9 +2631,9 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf) {
+void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf, int vol_term) {
   FaceHost& fh = g_face_host[plan];
-  launch_direct_faces(plan, u, ghost_trace, Au, cf, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr);
+  launch_direct_faces(plan, u, ghost_trace, Au, cf, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, vol_term);
 }
 
 void faces_destroy(d4est_hip_plan* plan) {

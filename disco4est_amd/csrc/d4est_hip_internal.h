@@ -187,10 +187,12 @@ void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, c
 void direct_destroy(d4est_hip_plan* plan);
 bool direct_active(const d4est_hip_plan* plan);
 double* direct_second_vector(d4est_hip_plan* plan);
+bool direct_fused_ok(const d4est_hip_plan* plan);   // the volume term can ride in the same kernel (N = NQ in {6, 8}, one bucket ...)
 void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
-                         const double* robin_c, const double* robin_r);
-// the same through the plan's face data (Robin arrays): Au += face terms of u
-void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf = nullptr);
+                         const double* robin_c, const double* robin_r, int vol_term);
+// the same through the plan's face data (Robin arrays): vol_term = 0: Au += face terms of u; 1: Au = (volume + face terms) of u
+void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf = nullptr,
+                        int vol_term = 0);
 void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf = nullptr);
 void faces_destroy(d4est_hip_plan* plan);
 

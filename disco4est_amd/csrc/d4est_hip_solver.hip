@@ -161,16 +161,20 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
       launch_traces(plan, u, plan->d_trace, false);
       plan->exchange_fn(plan->comm_ctx, 0, plan->d_trace, plan->d_ghost_trace);
     }
-    launch_stiffness(plan, u, Au);
-    if (lhs_term) add_lhs_mass_term(plan, u, Au);
+    // the volume term rides in the same kernel (u in, A u out) unless an exchange is to overlap it or the zeroth-order term sits between
+    const bool whole = !has_ghost && !(lhs_term && plan->d_lhs_coeff) && direct_fused_ok(plan);
+    if (!whole) {
+      launch_stiffness(plan, u, Au);
+      if (lhs_term) add_lhs_mass_term(plan, u, Au);
+    }
     if (has_ghost) plan->exchange_fn(plan->comm_ctx, 1, plan->d_trace, plan->d_ghost_trace);
     if (cf) {
       DirectFuse df;
       df.rhs = cf->rhs; df.p = cf->p; df.u_out = cf->u_out; df.r = cf->r; df.alpha = cf->alpha; df.beta = cf->beta;
       if (!df.u_out || df.u_out == u) D4EST_HIP_ABORT("apply_operator: the direct face kernel needs a second vector for the fused update");
-      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, &df);
+      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, &df, whole ? 1 : 0);
     } else {
-      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, nullptr);
+      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, nullptr, whole ? 1 : 0);
     }
     return;
   }

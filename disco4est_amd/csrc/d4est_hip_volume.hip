@@ -300,16 +300,6 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 // p = 7 lets 16 waves (4 per SIMD) share a CU, which covers config 2 (4096 elements)
 // in a single resident round.
 // ---------------------------------------------------------------------------
-template <int N, int NQ>
-struct WaveCfg {
-  static constexpr int PL = NQ * NQ;
-  static constexpr int EPB = (PL <= 64) ? 64 / PL : 1;
-  static constexpr int THREADS = (PL <= 64) ? 64 : ((PL + 63) / 64) * 64;  // > 64: one element per multi-wave workgroup
-  static constexpr int PN = N | 1, PQ = NQ | 1;
-  static constexpr int FS = NQ * NQ * PQ;
-  static constexpr int LDS_PER_ELEM = 2 * FS;
-  static constexpr size_t LDS_BYTES = (size_t)EPB * LDS_PER_ELEM * sizeof(double);
-};
 
 template <int N, int NQ, bool PF, bool EO = false>
 __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS == 64 ? (PF ? 3 : 4) : 1)) void stiffness_wave_kernel(
@@ -1087,210 +1077,7 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave_eo_kernel(
     }
   }
   __syncthreads();
-
-  // ---- S1: thread (j=a, k=b): B_r u, G_r u
-  {
-    double x[N], xe[HN], xo[HN], br[NQ], gr[NQ];
-    const bool on = active && a < N && b < N;
-    if (on) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
-      eo_pre<N>(x, xe, xo);
-      contract_pair_eo<HN, NQ, false, false>(EBf, xe, xo, br, EGf, xo, xe, gr);
-    }
-    __syncthreads();
-    if (on) {
-      double y[NQ];
-      eo_post<NQ>(br, y);
-#pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) R0[a + PN * (iq + NQ * b)] = y[iq];
-      eo_post<NQ>(gr, y);
-#pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) R1[a + PN * (iq + NQ * b)] = y[iq];
-    }
-  }
-  __syncthreads();
-
-  // ---- S2 (thread (iq=a, k=b)) and S3 (thread (iq=a, jq=b))
-  double gr[NQ], gs[NQ], gt[NQ];
-  {
-    double t3[NQ];
-    const bool on2 = active && b < N;
-    {
-      double x1[N], x2[N], x1e[HN], x1o[HN], x2e[HN], x2o[HN], t1[NQ], t2[NQ];
-      if (on2) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-          x1[j] = R0[j + PN * (a + NQ * b)];  // B_r u
-          x2[j] = R1[j + PN * (a + NQ * b)];  // G_r u
-        }
-        eo_pre<N>(x1, x1e, x1o);
-        eo_pre<N>(x2, x2e, x2o);
-        contract_pair_eo<HN, NQ, false, false>(EBf, x2e, x2o, t1, EGf, x1o, x1e, t2);  // B_s G_r u | G_s B_r u
-        contract_single_eo<HN, NQ, false>(EBf, x1e, x1o, t3);                           // B_s B_r u
-      }
-      __syncthreads();
-      if (on2) {
-        double y[NQ];
-        eo_post<NQ>(t1, y);
-#pragma unroll
-        for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = y[jq];  // [jq][iq][k]
-        eo_post<NQ>(t2, y);
-#pragma unroll
-        for (int jq = 0; jq < NQ; ++jq) R1[b + PN * (a + NQ * jq)] = y[jq];
-      }
-    }
-    __syncthreads();
-    if (active) {
-      double y1[N], y2[N], y1e[HN], y1o[HN], y2e[HN], y2o[HN], ge[NQ], he[NQ];
-#pragma unroll
-      for (int k = 0; k < N; ++k) {
-        y1[k] = R0[k + PN * (a + NQ * b)];
-        y2[k] = R1[k + PN * (a + NQ * b)];
-      }
-      eo_pre<N>(y1, y1e, y1o);
-      eo_pre<N>(y2, y2e, y2o);
-      contract_pair_eo<HN, NQ, false, false>(EBf, y1e, y1o, ge, EBf, y2e, y2o, he);
-      eo_post<NQ>(ge, gr);
-      eo_post<NQ>(he, gs);
-    }
-    __syncthreads();
-    if (on2) {
-      double y[NQ];
-      eo_post<NQ>(t3, y);
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = y[jq];
-    }
-    __syncthreads();
-    if (active) {
-      double y3[N], y3e[HN], y3o[HN], ge[NQ];
-#pragma unroll
-      for (int k = 0; k < N; ++k) y3[k] = R0[k + PN * (a + NQ * b)];
-      eo_pre<N>(y3, y3e, y3o);
-      contract_single_eo<HN, NQ, false>(EGf, y3o, y3e, ge);
-      eo_post<NQ>(ge, gt);
-    }
-  }
-
-  // ---- quadrature-point stage
-  if (active) {
-    if constexpr (AFF) {
-      const double* __restrict__ c = affine + (size_t)6 * ei;
-      const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
-      const double wab = wq[b] * wq[a];
-#pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) {
-        const double w3 = wq[kq] * wab;
-        const double r = w3 * gr[kq], s = w3 * gs[kq], t = w3 * gt[kq];
-        gr[kq] = c0 * r + c1 * s + c2 * t;
-        gs[kq] = c1 * r + c3 * s + c4 * t;
-        gt[kq] = c2 * r + c4 * s + c5 * t;
-      }
-    } else {
-      const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
-#pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) {
-        const int q = NQ * NQ * kq;
-        const double m0 = m[q], m1 = m[NQ3 + q], m2 = m[2 * NQ3 + q], m3 = m[3 * NQ3 + q], m4 = m[4 * NQ3 + q], m5 = m[5 * NQ3 + q];
-        const double r = gr[kq], s = gs[kq], t = gt[kq];
-        gr[kq] = m0 * r + m1 * s + m2 * t;
-        gs[kq] = m1 * r + m3 * s + m4 * t;
-        gt[kq] = m2 * r + m4 * s + m5 * t;
-      }
-    }
-  }
-
-  // ---- S5 (registers) / S6 (thread (iq=a, k=b))
-  {
-    double cc[N], ar[N], bs[N];
-    const bool on6 = active && b < N;
-    {
-      double ca[N], cb[N];
-      if (active) {
-        double re[HQ], ro[HQ], se[HQ], so[HQ], te_[HQ], to[HQ];
-        eo_pre<NQ>(gr, re, ro);
-        eo_pre<NQ>(gs, se, so);
-        eo_pre<NQ>(gt, te_, to);
-        contract_pair_eo<HQ, N, false, false>(EBb, re, ro, ca, EBb, se, so, cb);
-        contract_single_eo<HQ, N, false>(EGb, to, te_, cc);
-      }
-      __syncthreads();
-      if (active) {
-        double y[N];
-        eo_post<N>(ca, y);
-#pragma unroll
-        for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = y[k];  // [k][iq][jq]
-        eo_post<N>(cb, y);
-#pragma unroll
-        for (int k = 0; k < N; ++k) R1[b + PQ * (a + NQ * k)] = y[k];
-      }
-    }
-    __syncthreads();
-    if (on6) {
-      double x[NQ], y[NQ], xe[HQ], xo[HQ], ye[HQ], yo[HQ];
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) {
-        x[jq] = R0[jq + PQ * (a + NQ * b)];
-        y[jq] = R1[jq + PQ * (a + NQ * b)];
-      }
-      eo_pre<NQ>(x, xe, xo);
-      eo_pre<NQ>(y, ye, yo);
-      contract_pair_eo<HQ, N, false, false>(EBb, xe, xo, ar, EGb, yo, ye, bs);
-    }
-    __syncthreads();
-    if (active) {
-      double y[N];
-      eo_post<N>(cc, y);
-#pragma unroll
-      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = y[k];
-    }
-    __syncthreads();
-    if (on6) {
-      double z[NQ], ze[HQ], zo[HQ];
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) z[jq] = R0[jq + PQ * (a + NQ * b)];
-      eo_pre<NQ>(z, ze, zo);
-      contract_single_eo<HQ, N, true>(EBb, ze, zo, bs);  // summed in (a | b) form with G_s^T(...)
-    }
-    __syncthreads();
-    if (on6) {
-      double y[N];
-      eo_post<N>(ar, y);
-#pragma unroll
-      for (int j = 0; j < N; ++j) R0[a + PQ * (j + N * b)] = y[j];  // [k][j][iq]
-      eo_post<N>(bs, y);
-#pragma unroll
-      for (int j = 0; j < N; ++j) R1[a + PQ * (j + N * b)] = y[j];
-    }
-  }
-  __syncthreads();
-
-  // ---- S7: thread (j=a, k=b)
-  {
-    double o[N], o2[N];
-    const bool on = active && a < N && b < N;
-    if (on) {
-      double x[NQ], y[NQ], xe[HQ], xo[HQ], ye[HQ], yo[HQ];
-#pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) {
-        x[iq] = R0[iq + PQ * (a + N * b)];
-        y[iq] = R1[iq + PQ * (a + N * b)];
-      }
-      eo_pre<NQ>(x, xe, xo);
-      eo_pre<NQ>(y, ye, yo);
-      contract_pair_eo<HQ, N, false, false>(EGb, xo, xe, o, EBb, ye, yo, o2);
-    }
-    __syncthreads();
-    if (on) {
-      double y[N];
-#pragma unroll
-      for (int i = 0; i < N; ++i) o[i] += o2[i];
-      eo_post<N>(o, y);
-#pragma unroll
-      for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = y[i];
-    }
-  }
-  __syncthreads();
+  stiffness_wave_eo_element<N, NQ, AFF, true>(R0, R1, metric, qs, ei, active, a, b, EBf, EGf, EBb, EGb, affine, wq);
   if (active) {
 #pragma unroll
     for (int idx = te; idx < N3; idx += PL) {

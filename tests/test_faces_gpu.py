@@ -9,6 +9,19 @@ RTOL = 1e-12
 DIRECT_PAIRS = {(n, n) for n in range(2, 9)} | {(2, 3), (3, 4), (4, 5), (3, 6), (4, 6)}
 
 
+def _expected_face_path(deg, inc):
+    """What apply_aij runs by default: the direct kernel where it is instantiated, with the volume term in it at deg = deg_quad in {5, 7}."""
+    if (deg + 1, deg + inc + 1) not in DIRECT_PAIRS:
+        return "two-phase"
+    return "direct+volume" if inc == 0 and deg in (5, 7) else "direct"
+
+
+def _face_path_values(plan):
+    """Values of tuning key 11 to run a test with: every face path the plan supports (2 whole operator in the direct kernel, 1 direct
+    face kernel + volume kernel, 0 two-phase kernels)."""
+    return {"direct+volume": (2, 1, 0), "direct": (1, 0), "two-phase": (0,)}[plan.face_path()]
+
+
 def _t(a, dev):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -48,10 +61,10 @@ def test_apply_aij_parity(gpu, hiplib, oracle, level, deg, inc, curved, fcn):
     dAu = torch.full_like(du, float("nan"))
     # uniform conforming plans up to deg_quad = 7 run the direct face kernel (traces formed from u in place) by default;
     # tuning key 11 = 0 selects the two-phase kernels: both are held to the oracle
-    assert plan.face_path() == ("direct" if (deg + 1, deg + inc + 1) in DIRECT_PAIRS else "two-phase")
-    for direct in ((1, 0) if plan.face_path() == "direct" else (0,)):
+    assert plan.face_path() == _expected_face_path(deg, inc)
+    for direct in _face_path_values(plan):
         plan.set_tuning(11, direct)
-        assert plan.face_path() == ("direct" if direct else "two-phase")
+        assert plan.face_path() == {2: "direct+volume", 1: "direct", 0: "two-phase"}[direct]
         dAu.fill_(float("nan"))
         plan.apply_aij(du, dAu)
         got = dAu.cpu().numpy()
@@ -85,7 +98,7 @@ def test_apply_aij_robin_parity(gpu, hiplib, oracle, level, deg, inc):
     plan.set_robin_values(coeff, rhs)
     du = _t(u, gpu)
     dAu = torch.full_like(du, float("nan"))
-    for direct in ((1, 0) if plan.face_path() == "direct" else (0,)):   # both face paths where the direct kernel applies
+    for direct in _face_path_values(plan):   # every face path that applies to the plan
         plan.set_tuning(11, direct)
         dAu.fill_(float("nan"))
         plan.apply_aij(du, dAu)
