@@ -378,6 +378,7 @@ def main():
                 bpd_aij = algorithmic_bytes_per_dof(N, NQ) + 6.0 * 7.0 * 8.0 * NQ * NQ / N ** 3
                 sec[name]["algorithmic_bytes_per_dof"] = bpd_aij
                 sec[name]["roofline_frac_hbm"] = bpd_aij * dofs_per_rank * applies / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                sec[name]["face_path"] = plan.face_path()   # "direct+volume": the whole operator in one kernel (u in, A u out)
             # the affine path: same brick, metric rebuilt from 6 numbers per element, 16 B/DoF
             if args.geometry != "sine":
                 plan.set_tuning(7, -1)

@@ -159,6 +159,8 @@ struct DirectVol {
   const double* affine = nullptr;    // AFF: 6 numbers per element
   const double* wq = nullptr;        // AFF: quadrature weights
   int qs0 = 0, qs_stride = 0;
+  const int* qs_list = nullptr;      // quadrature offset per element where the offsets are not affine (qs_stride < 0): a Schwarz
+                                     // subdomain plan, whose element copies alias the mesh's metric
 };
 
 template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only, 1 + streamed metric, 2 + affine metric */>
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
       }
     }
     wave_lds_fence();
-    const int qs = __builtin_amdgcn_readfirstlane(vol.qs0 + e * vol.qs_stride);
+    const int qs = __builtin_amdgcn_readfirstlane(vol.qs_stride >= 0 ? vol.qs0 + e * vol.qs_stride : vol.qs_list[e]);
     stiffness_wave_eo_element<N, NQ, VOL == 2, false>(s_U, s_S, vol.metric, qs, e, on_q, a, b, vol.EBf, vol.EGf, vol.EBb, vol.EGb,
                                                       vol.affine, vol.wq);
     if (on_m) {
@@ -593,18 +595,28 @@ double* direct_second_vector(d4est_hip_plan* plan) {
 // with affine strides, even-odd volume tables, default volume-kernel tuning
 bool direct_fused_ok(const d4est_hip_plan* plan) {
   const DirectHost* dh = static_cast<const DirectHost*>(plan->direct);
-  if (!direct_active(plan) || !dh) return false;
+  static const bool dbg = std::getenv("D4EST_HIP_DEBUG_FUSED") != nullptr;
+  auto no = [&](const char* why) {
+    if (dbg) std::fprintf(stderr, "[d4est_hip] whole-operator kernel not used: %s\n", why);
+    return false;
+  };
+  if (!direct_active(plan) || !dh) return no("no direct face kernel on this plan");
   const int t = plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT];
-  if (!(t < 0 || t == 2)) return false;
-  if (!(dh->N == dh->NQ && (dh->N == 6 || dh->N == 8))) return false;
-  if (!plan->has_geometry || plan->buckets.size() != 1) return false;
+  if (!(t < 0 || t == 2)) return no("tuning key 11");
+  if (!(dh->N == dh->NQ && (dh->N == 6 || dh->N == 8))) return no("deg != deg_quad or not 5 / 7");
+  if (!plan->has_geometry) return no("no geometry yet");
+  if (plan->buckets.size() != 1) return no("more than one (deg, deg_quad) bucket");
   const Bucket& bk = plan->buckets[0];
-  if (bk.N != dh->N || bk.NQ != dh->NQ || !bk.d_EBf || bk.ns_stride < 0 || bk.qs_stride < 0 || bk.ns0 != dh->ns0 || bk.ns_stride != dh->ns_stride) return false;
-  if (bk.n_elem != plan->n_elements) return false;
+  if (bk.N != dh->N || bk.NQ != dh->NQ || !bk.d_EBf) return no("bucket tables");
+  // (the nodal offsets are affine: the direct tables exist only on uniform plans; the bucket keeps affine strides only when the
+  // quadrature offsets are affine too -- not so on a Schwarz subdomain plan, which reads them from the list)
+  if (bk.ns_stride >= 0 && (bk.ns0 != dh->ns0 || bk.ns_stride != dh->ns_stride)) return no("nodal offsets");
+  if (bk.n_elem != plan->n_elements) return no("bucket size");
   for (int i = 0; i < plan->n_elements; ++i)
-    if (plan->elem_ids[i] != i) return false;
+    if (plan->elem_ids[i] != i) return no("bucket order");
   const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
-  return tw < 0 || tw == 11;
+  if (!(tw < 0 || tw == 11)) return no("tuning key 1");
+  return true;
 }
 
 // vol_term: 0 the face terms only (Au += ...), 1 the whole operator (Au = volume + faces; direct_fused_ok)
@@ -625,8 +637,8 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
     if (!direct_fused_ok(plan)) D4EST_HIP_ABORT("direct face kernel: the fused volume term was requested on a plan that cannot take it");
     const Bucket& bk = plan->buckets[0];
     vol.metric = plan->d_metric; vol.EBf = bk.d_EBf; vol.EGf = bk.d_EGf; vol.EBb = bk.d_EBb; vol.EGb = bk.d_EGb;
-    vol.qs0 = bk.qs0; vol.qs_stride = bk.qs_stride;
-    const bool aff = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0;
+    vol.qs0 = bk.qs0; vol.qs_stride = bk.ns_stride >= 0 ? bk.qs_stride : -1; vol.qs_list = plan->d_qs_list + bk.elem_offset;
+    const bool aff = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine;
     if (aff) { vol.affine = plan->d_metric_affine; vol.wq = bk.d_w; }
     vmode = aff ? 2 : 1;
     std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::faces_direct_kernel<%d,%d,vol%s> (faces + stiffness_wave_eo body)", dh->N, dh->NQ, aff ? ",affine" : "");

@@ -29,6 +29,7 @@ md = sz.metadata
 print(f"level {a.level} p={a.deg} overlap {a.overlap}: {md.num_subdomains} subdomains, {md.num_elements} subdomain elements, "
       f"field over subdomains {sz.nodal_size * 8 / 1e6:.1f} MB, restricted {md.restricted_nodal_size * 8 / 1e6:.1f} MB, "
       f"zero ghost trace {sz.plan.ghost_trace_size * 8 / 1e6:.1f} MB; mesh setup {t1 - t0:.1f} s, schwarz setup {t2 - t1:.1f} s")
+print("subdomain plan face path:", sz.plan.face_path())
 u = torch.zeros(m.local_nodes, dtype=torch.float64, device=dev)
 r = torch.from_numpy(M.splitmix64_uniform(1, m.local_nodes) - 0.5).to(dev)
 sz.iterate(u, r)
