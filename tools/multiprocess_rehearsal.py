@@ -24,7 +24,9 @@ if os.environ.get("D4EST_HANGING"):          # locally refined brick: hanging fa
 else:
     n_el = 8 ** level
     make = lambda deg, **kw: M.BrickMesh(level, deg, **kw)
-deg_global = np.array([pmin + (i % 2) for i in range(n_el)], dtype=np.int32)
+# mixed degrees pmin, pmin + 1 (the two-phase face kernels) unless D4EST_UNIFORM is set (one degree: the direct face kernel, with
+# ghost sides fed by the exchange)
+deg_global = np.array([pmin + (0 if os.environ.get("D4EST_UNIFORM") else i % 2) for i in range(n_el)], dtype=np.int32)
 mp = M.SineMap(0.04)
 parts = P.partition_by_dofs(deg_global, world)
 sh = SchwarzShard(level, deg_global, parts, rank, mp, rs, iters, 1e-15, 1e-15, P.DistTransport(), dev, refine=refine)
