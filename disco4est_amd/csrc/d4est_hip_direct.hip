@@ -55,6 +55,8 @@ struct DirectHost {
   DirectGhostOff* d_ghost_off = nullptr;
   double* d_ops = nullptr;   // C, CD, E, D^T E (plain: transposed; eo: even-odd tables), then rows 0 and N-1 of D
   double* d_u2 = nullptr;    // second solution vector of the fused Chebyshev update (see cheby_iterate_body)
+  const int* d_list = nullptr;   // optional list of the elements the kernel works on (not owned; direct_set_element_list)
+  int n_list = 0;
 };
 
 // y = M x, M (NO x NI): tab = M transposed (NI x NO row-major), or the even-odd table of M when EO (NI, NO even; ANTI: M is
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
                                                              const double* __restrict__ ops, const double* __restrict__ geom,
                                                              const double* __restrict__ bndry_q, const double* __restrict__ robin_c,
                                                              const double* __restrict__ robin_r, int n_elem, int ns0, int ns_stride,
-                                                             int xcd_chunk, DirectFuse cf, DirectVol vol) {
+                                                             int xcd_chunk, DirectFuse cf, DirectVol vol, const int* __restrict__ elem_list) {
   using C = DirectCfg<N, NQ>;
   constexpr int N2 = C::N2, N3 = C::N3, T = C::T, PN = C::PN, RS = C::RS, RQ = C::RQ, GS = C::GS, QS = C::QS, YS = C::YS, VS = C::VS;
   constexpr bool FULL = C::FULL;
@@ -196,8 +198,10 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
   // XCD-aware element order (workgroups are dealt round-robin to the 8 XCDs, each with its own L2): XCD x walks the x-th contiguous
   // (Morton-local) eighth of the elements, so a neighbour's u is more often in the reader's L2
   const int v = blockIdx.x;
-  const int e = (xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v) * kDirectWPB + wv;   // xcd_chunk in workgroups
-  if (e >= n_elem) return;
+  const int slot = (xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v) * kDirectWPB + wv;   // xcd_chunk in workgroups
+  if (slot >= n_elem) return;
+  // an element list leaves out elements whose rows the caller forms another way (condensed Schwarz copies); they are still READ as neighbours
+  const int e = elem_list ? __builtin_amdgcn_readfirstlane(elem_list[slot]) : slot;
   const int ns = __builtin_amdgcn_readfirstlane(ns0 + e * ns_stride);
   const DirectSide* __restrict__ sd = sides + 6 * (size_t)e;
 
@@ -585,6 +589,13 @@ bool direct_active(const d4est_hip_plan* plan) {
   return plan->direct != nullptr && plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0;
 }
 
+void direct_set_element_list(d4est_hip_plan* plan, const int* list_dev, int n_list) {
+  DirectHost* dh = host_of(plan);
+  if (!dh) D4EST_HIP_ABORT("direct_set_element_list: the plan has no direct face kernel");
+  dh->d_list = list_dev;
+  dh->n_list = list_dev ? n_list : 0;
+}
+
 double* direct_second_vector(d4est_hip_plan* plan) {
   DirectHost* dh = host_of(plan);
   if (!dh->d_u2) HIP_CHECK(hipMalloc(&dh->d_u2, std::max<size_t>((size_t)plan->local_nodes, 1) * sizeof(double)));
@@ -625,7 +636,7 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
   DirectHost* dh = host_of(plan);
   if (!dh) D4EST_HIP_ABORT("direct face kernel: the plan has no direct tables");
   if (!plan->has_face_geometry) D4EST_HIP_ABORT("apply flux: plan_set_mortar_geometry was not called");
-  const int n = plan->n_elements;
+  const int n = dh->d_list ? dh->n_list : plan->n_elements;
   if (n == 0) return;
   if (plan->ghost_trace_doubles > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has ghost sides but no ghost trace buffer was given");
   static const bool no_remap = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
@@ -648,7 +659,7 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
 #define D4EST_HIP_DIRECT_GO(N_, NQ_, FUSE_, VOL_)                                                                             \
   hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, (N_ % 2 == 0) && (NQ_ % 2 == 0), FUSE_, VOL_>), dim3(n_wg), dim3(64 * kDirectWPB), 0,     \
                      plan->stream, u, ghost_trace, Au, dh->d_sides, dh->d_ghost_off, dh->d_ops, plan->d_face_geom, plan->d_bndry,            \
-                     robin_c, robin_r, n, dh->ns0, dh->ns_stride, chunk, cfv, vol)
+                     robin_c, robin_r, n, dh->ns0, dh->ns_stride, chunk, cfv, vol, dh->d_list)
 #define X(N_, NQ_)                                                                 \
   if (!done && dh->N == N_ && dh->NQ == NQ_) {                                     \
     if constexpr (N_ == NQ_ && (N_ == 6 || N_ == 8)) {                             \

@@ -187,6 +187,9 @@ void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, c
 void direct_destroy(d4est_hip_plan* plan);
 bool direct_active(const d4est_hip_plan* plan);
 double* direct_second_vector(d4est_hip_plan* plan);
+// the direct kernel works on the listed elements only (the others are still read as neighbours); nullptr: every element.  The list
+// (device ints) stays the caller's.  Only while direct_active(plan).
+void direct_set_element_list(d4est_hip_plan* plan, const int* list_dev, int n_list);
 bool direct_fused_ok(const d4est_hip_plan* plan);   // the volume term can ride in the same kernel (N = NQ in {6, 8}, one bucket ...)
 void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
                          const double* robin_c, const double* robin_r, int vol_term);

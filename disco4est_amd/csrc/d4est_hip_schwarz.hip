@@ -56,6 +56,21 @@ struct d4est_hip_schwarz {
   double *d_du = nullptr, *d_r = nullptr, *d_d = nullptr, *d_Ad = nullptr, *d_zero_ghost = nullptr;
   double *d_delta = nullptr, *d_tol = nullptr;
   int *d_active = nullptr, *d_final_iter = nullptr, *d_n_active = nullptr;
+  // flat list of the restricted nodes of every subdomain (field offsets), for the register-resident CG kernel
+  int* d_box_off = nullptr;
+  int* d_box_first = nullptr;        // n_sub + 1
+  int max_box_nodes = 0;
+  // condensed copies (see ensure_condensed): copies with a handful of restricted nodes whose rows of the subdomain operator are kept as
+  // small dense blocks instead of being applied matrix-free
+  std::vector<VirtDesc> h_vd;        // host copy of the copy descriptors
+  int condensed_state = 0;           // 0 not looked at yet, 1 in use, -1 not applicable / switched off
+  int n_cond = 0;
+  void* d_cond = nullptr;            // CondDesc per condensed copy
+  double* d_cond_blocks = nullptr;
+  int* d_keep_list = nullptr;        // the copies that stay matrix-free
+  int n_keep = 0;
+  int* d_cond_off = nullptr;         // per condensed copy: field offsets of its inputs (own restricted nodes first, then the neighbours')
+  long long cond_block_doubles = 0;
 };
 
 namespace d4est_hip {
@@ -201,6 +216,60 @@ __global__ __launch_bounds__(256) void schwarz_cg_kernel(const VirtDesc* __restr
   }
 }
 
+// The same iteration with the subdomain's restricted nodes taken from a flat offset list and d, A d, r held in registers between the
+// three passes (PT nodes per thread): 4 reads + 3 writes per node instead of 8 + 3, and no index arithmetic.  The partial sums are
+// formed over a different split of the nodes than in schwarz_cg_kernel (still a fixed order: same result on every launch).
+template <int PT>
+__global__ __launch_bounds__(256) void schwarz_cg_flat_kernel(const int* __restrict__ box_first, const int* __restrict__ box_off,
+                                                              double* __restrict__ du, double* __restrict__ r, double* __restrict__ d,
+                                                              const double* __restrict__ Ad, double* __restrict__ delta,
+                                                              const double* __restrict__ tol, int* __restrict__ active,
+                                                              int* __restrict__ final_iter, int* __restrict__ n_active, int it) {
+  __shared__ double red[256];
+  const int s = blockIdx.x;
+  if (!active[s]) return;
+  if (threadIdx.x == 0) atomicMax(n_active + 1, it + 1);   // this sweep did work: the reference's loop was still running
+  const int first = box_first[s], cnt = box_first[s + 1] - first;
+  int o[PT];
+  double dv[PT], av[PT], rv[PT];
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < PT; ++j) {
+    const int t = threadIdx.x + 256 * j;
+    o[j] = (t < cnt) ? box_off[first + t] : -1;
+    dv[j] = (o[j] >= 0) ? d[o[j]] : 0.0;
+    av[j] = (o[j] >= 0) ? Ad[o[j]] : 0.0;
+    acc += dv[j] * av[j];
+  }
+  const double d_dot_Ad = block_sum(acc, red);
+  const double delta_old = delta[s];
+  const double alpha = delta_old / d_dot_Ad;
+  acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < PT; ++j) {
+    rv[j] = 0.0;
+    if (o[j] >= 0) {
+      du[o[j]] += alpha * dv[j];
+      rv[j] = r[o[j]] - alpha * av[j];
+      r[o[j]] = rv[j];
+    }
+    acc += rv[j] * rv[j];
+  }
+  const double delta_new = block_sum(acc, red);
+  const double beta = delta_new / delta_old;
+#pragma unroll
+  for (int j = 0; j < PT; ++j)
+    if (o[j] >= 0) d[o[j]] = rv[j] + beta * dv[j];
+  if (threadIdx.x == 0) {
+    delta[s] = delta_new;
+    if (delta_new < tol[s]) {
+      active[s] = 0;
+      final_iter[s] = it;
+      atomicSub(n_active, 1);
+    }
+  }
+}
+
 // u += sum over the subdomains containing the element of (hat weights * du), in ascending subdomain order; one workgroup per mesh element
 __global__ __launch_bounds__(256) void schwarz_correction_kernel(const VirtDesc* __restrict__ vd, const int* __restrict__ mesh_first,
                                                                  const int* __restrict__ mesh_contrib,
@@ -257,6 +326,236 @@ static void ensure_zero_ghost(d4est_hip_schwarz* sz) {
   const size_t g = std::max<size_t>((size_t)sz->plan->ghost_trace_doubles, 1) * sizeof(double);
   HIP_CHECK(hipMalloc(&sz->d_zero_ghost, g));
   HIP_CHECK(hipMemset(sz->d_zero_ghost, 0, g));
+}
+
+// ---------------------------------------------------------------------------
+// Condensed copies.  On a conforming subdomain the 8 corner copies of the 27 carry rs^3 restricted nodes each (8 of 512 at overlap 2,
+// p = 7) and still cost a full element apply -- 30 % of the operator's work for 0.5 % of its unknowns.  The rows of R A R^T that belong
+// to such a copy c touch only c itself and the copies across its faces:
+//     (A d)|c = S_c d|c + sum_f X_{c,f} d|nbr(c,f)          S_c: L_c x L_c,  X_{c,f}: L_c x L_nbr   (L = restricted nodes of a copy)
+// These blocks are read off the matrix-free operator itself, once, by probing it with unit vectors (every copy of a round in
+// parallel: round (f, m) sets restricted node m of every nbr(c, f) and c reads its column of X_{c,f}; the set-up refuses a mesh on which
+// a second neighbour of such a c would be probed in the same round), so they are the SAME numbers the kernels produce, to rounding.  From then on the operator kernel skips
+// the condensed copies (they are still read as neighbours) and one small kernel forms their rows: 6.6 KB per corner copy instead of a
+// 4 KB + 45 KB element apply.  Only copies whose blocks stay under 8 KB are condensed (at overlap 3 the blocks would cost more to
+// stream than the apply they replace).  D4EST_HIP_SCHWARZ_CONDENSE=0 switches it off.
+// ---------------------------------------------------------------------------
+struct CondDesc {
+  int v;          // the condensed copy
+  int L;          // its restricted nodes
+  int nn;         // neighbours inside the subdomain (<= 6)
+  int nb_v[6];    // their copy ids
+  int nb_L[6];    // their restricted node counts
+  int total;      // L + sum nb_L: columns of [S_c | X_{c,0} | ...]
+  long long blk;  // offset of S_c in the block array; X_{c,k} follow in neighbour order, all column-major with leading dimension L
+  long long off;  // offset of the copy's input offsets in the offset array (total ints; the first L are also its output offsets)
+};
+
+// x = unit vectors: restricted node m of the listed copies (x zeroed beforehand)
+__global__ __launch_bounds__(256) void schwarz_probe_set_kernel(const VirtDesc* __restrict__ vd, const int* __restrict__ copies, int n_copies,
+                                                                int m, double* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_copies) return;
+  const VirtDesc q = vd[copies[i]];
+  if (m < restricted_count(q)) x[restricted_offset(q, m)] = 1.0;
+}
+
+// column m of S_c (slot < 0) or of X_{c,slot}: the operator's response at the restricted nodes of c
+__global__ __launch_bounds__(64) void schwarz_probe_get_kernel(const VirtDesc* __restrict__ vd, const CondDesc* __restrict__ cd, int n_cond,
+                                                               int face_slot_of_round, const int* __restrict__ slot_of, int m,
+                                                               const double* __restrict__ y, double* __restrict__ blocks) {
+  const int ci = blockIdx.x;
+  if (ci >= n_cond) return;
+  const CondDesc c = cd[ci];
+  const int slot = face_slot_of_round < 0 ? -1 : slot_of[ci];   // neighbour slot of c probed in this round, -1: none (or the self round)
+  if (face_slot_of_round >= 0 && slot < 0) return;
+  const int Lcol = slot < 0 ? c.L : c.nb_L[slot];
+  if (m >= Lcol) return;
+  long long off = c.blk;
+  if (slot >= 0) {
+    off += (long long)c.L * c.L;
+    for (int k = 0; k < slot; ++k) off += (long long)c.L * c.nb_L[k];
+  }
+  const VirtDesc q = vd[c.v];
+  for (int r = threadIdx.x; r < c.L; r += blockDim.x) blocks[off + (long long)m * c.L + r] = y[restricted_offset(q, r)];
+}
+
+// (A d)|c for every condensed copy: one wavefront per copy.  S_c and the X_{c,k} are ONE column-major L x total matrix; lane
+// t = r + L * part takes row r and the columns m = part, part + P, ... (P = 64 / L parts), so that for every step the wave reads one
+// contiguous run of the block; the P partial sums of a row are added in a fixed order through LDS.
+__global__ __launch_bounds__(64) void schwarz_condensed_apply_kernel(const CondDesc* __restrict__ cd, int n_cond, const int* __restrict__ offs,
+                                                                     const double* __restrict__ blocks, const double* __restrict__ in,
+                                                                     double* __restrict__ out) {
+  __shared__ double s_in[7 * 128];
+  __shared__ double s_part[64];
+  const int ci = blockIdx.x;
+  if (ci >= n_cond) return;
+  const CondDesc c = cd[ci];
+  const int* __restrict__ io = offs + c.off;
+  for (int m = threadIdx.x; m < c.total; m += blockDim.x) s_in[m] = in[io[m]];
+  __syncthreads();
+  const int P = 64 / c.L;                       // L <= 27: P >= 2
+  const int r = threadIdx.x % c.L, part = threadIdx.x / c.L;
+  const double* __restrict__ B = blocks + c.blk + r;
+  double acc = 0.0;
+  if (part < P) {
+#pragma unroll 4
+    for (int m = part; m < c.total; m += P) acc = fma(B[(long long)m * c.L], s_in[m], acc);
+  }
+  s_part[threadIdx.x] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < c.L) {
+    double sum = 0.0;
+    for (int p2 = 0; p2 < P; ++p2) sum += s_part[threadIdx.x + c.L * p2];
+    out[io[threadIdx.x]] = sum;
+  }
+}
+
+static int live_count(const VirtDesc& q) { return (q.hi[0] - q.lo[0]) * (q.hi[1] - q.lo[1]) * (q.hi[2] - q.lo[2]); }
+
+static void ensure_zero_ghost(d4est_hip_schwarz* sz);
+
+static void ensure_condensed(d4est_hip_schwarz* sz) {
+  if (sz->condensed_state != 0) return;
+  sz->condensed_state = -1;
+  d4est_hip_plan* plan = sz->plan;
+  static const char* env = std::getenv("D4EST_HIP_SCHWARZ_CONDENSE");
+  static const bool dbg = std::getenv("D4EST_HIP_DEBUG_FUSED") != nullptr;
+  auto no = [&](const char* why) {
+    if (dbg) std::fprintf(stderr, "[d4est_hip] schwarz: no condensed copies: %s\n", why);
+  };
+  if (env && std::atoi(env) == 0) return no("switched off");
+  if (!direct_active(plan) || !plan->has_face_geometry || !plan->has_geometry || sz->n_virtual == 0) return no("no direct face kernel on the subdomain plan");
+  if (!plan->side_hang.empty()) return no("hanging faces");
+  const int nv = sz->n_virtual;
+  const std::vector<VirtDesc>& vd = sz->h_vd;
+  if ((int)vd.size() != nv) return no("descriptor count");
+  // candidates: few restricted nodes; condensed: candidates whose neighbours are not candidates and whose blocks stay small
+  std::vector<char> cand(nv, 0);
+  for (int v = 0; v < nv; ++v) cand[v] = live_count(vd[v]) <= 27 && live_count(vd[v]) < vd[v].N * vd[v].N * vd[v].N;
+  std::vector<CondDesc> cds;
+  std::vector<int> offs;           // field offsets of every condensed copy's inputs
+  std::vector<int> face_of_slot;   // per condensed copy and slot: the face of c it sits on
+  long long blk = 0;
+  for (int v = 0; v < nv; ++v) {
+    if (!cand[v]) continue;
+    CondDesc c{};
+    c.v = v; c.L = live_count(vd[v]); c.nn = 0; c.blk = blk;
+    bool ok = true;
+    long long doubles = (long long)c.L * c.L;
+    int faces[6];
+    for (int f = 0; f < 6 && ok; ++f) {
+      const int nb = plan->side_nbr[6 * (size_t)v + f];
+      if (nb < 0) continue;
+      if (cand[nb] || live_count(vd[nb]) > 128) { ok = false; break; }
+      faces[c.nn] = f;
+      c.nb_v[c.nn] = nb; c.nb_L[c.nn] = live_count(vd[nb]);
+      doubles += (long long)c.L * c.nb_L[c.nn];
+      ++c.nn;
+    }
+    if (!ok || doubles * 8 > 8192) continue;
+    int total = c.L;
+    for (int k = 0; k < c.nn; ++k) total += c.nb_L[k];
+    if (total > 7 * 128) continue;
+    c.total = total;
+    c.off = (long long)offs.size();
+    auto push_offsets = [&](const VirtDesc& q) {   // restricted_offset on the host
+      const int e0 = q.hi[0] - q.lo[0], e1 = q.hi[1] - q.lo[1], n = live_count(q);
+      for (int i = 0; i < n; ++i) offs.push_back(q.dst + (q.lo[0] + i % e0) + q.N * ((q.lo[1] + (i / e0) % e1) + q.N * (q.lo[2] + i / (e0 * e1))));
+    };
+    push_offsets(vd[v]);
+    for (int k = 0; k < c.nn; ++k) push_offsets(vd[c.nb_v[k]]);
+    for (int k = 0; k < c.nn; ++k) face_of_slot.push_back(faces[k]);
+    for (int k = c.nn; k < 6; ++k) face_of_slot.push_back(-1);
+    cds.push_back(c);
+    blk += doubles;
+  }
+  const int nc = (int)cds.size();
+  if (nc == 0) return no("no copy qualifies");
+  // rounds: round f probes nbr(c, f) of every condensed c.  Refuse if a probed copy is ALSO another neighbour of some condensed copy
+  // (its response would land in the wrong block).
+  std::vector<std::vector<int>> probed(6);
+  std::vector<std::vector<int>> slot_of(6, std::vector<int>(nc, -1));
+  std::vector<char> mark(nv, 0);
+  for (int f = 0; f < 6; ++f) {
+    for (int ci = 0; ci < nc; ++ci)
+      for (int k = 0; k < cds[ci].nn; ++k)
+        if (face_of_slot[6 * (size_t)ci + k] == f) { probed[f].push_back(cds[ci].nb_v[k]); slot_of[f][ci] = k; }
+    for (int e : probed[f]) mark[e] = 1;
+    for (int ci = 0; ci < nc; ++ci) {
+      if (slot_of[f][ci] < 0) continue;   // c takes nothing from this round
+      for (int k = 0; k < cds[ci].nn; ++k)
+        if (face_of_slot[6 * (size_t)ci + k] != f && mark[cds[ci].nb_v[k]]) return no("two neighbours of one condensed copy fall into the same probing round");   // keep the matrix-free rows
+    }
+    for (int e : probed[f]) mark[e] = 0;
+  }
+  // ---- probe
+  ensure_zero_ghost(sz);
+  hipStream_t st = plan->stream;
+  double *x = nullptr, *y = nullptr;
+  const size_t nbytes = std::max<size_t>((size_t)sz->nodal_size, 1) * sizeof(double);
+  HIP_CHECK(hipMalloc(&x, nbytes));
+  HIP_CHECK(hipMalloc(&y, nbytes));
+  CondDesc* d_cd = upload(cds);
+  HIP_CHECK(hipMalloc(&sz->d_cond_blocks, std::max<long long>(blk, 1) * sizeof(double)));
+  std::vector<int> self(nc);
+  int maxL = 0;
+  for (int ci = 0; ci < nc; ++ci) { self[ci] = cds[ci].v; maxL = std::max(maxL, cds[ci].L); }
+  int* d_self = upload(self);
+  for (int m = 0; m < maxL; ++m) {
+    HIP_CHECK(hipMemsetAsync(x, 0, nbytes, st));
+    hipLaunchKernelGGL(schwarz_probe_set_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, sz->d_vd, d_self, nc, m, x);
+    d4est_hip_apply_aij(plan, x, sz->d_zero_ghost, y);
+    hipLaunchKernelGGL(schwarz_probe_get_kernel, dim3(nc), dim3(64), 0, st, sz->d_vd, d_cd, nc, -1, (const int*)nullptr, m, y, sz->d_cond_blocks);
+  }
+  for (int f = 0; f < 6; ++f) {
+    if (probed[f].empty()) continue;
+    int* d_probed = upload(probed[f]);
+    int* d_slot = upload(slot_of[f]);
+    int maxLe = 0;
+    for (int e : probed[f]) maxLe = std::max(maxLe, live_count(vd[e]));
+    const int np = (int)probed[f].size();
+    for (int m = 0; m < maxLe; ++m) {
+      HIP_CHECK(hipMemsetAsync(x, 0, nbytes, st));
+      hipLaunchKernelGGL(schwarz_probe_set_kernel, dim3((np + 255) / 256), dim3(256), 0, st, sz->d_vd, d_probed, np, m, x);
+      d4est_hip_apply_aij(plan, x, sz->d_zero_ghost, y);
+      hipLaunchKernelGGL(schwarz_probe_get_kernel, dim3(nc), dim3(64), 0, st, sz->d_vd, d_cd, nc, f, d_slot, m, y, sz->d_cond_blocks);
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(d_probed); (void)hipFree(d_slot);
+  }
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(st));
+  (void)hipFree(x); (void)hipFree(y); (void)hipFree(d_self);
+  std::vector<char> skip(nv, 0);
+  for (const CondDesc& c : cds) skip[c.v] = 1;
+  std::vector<int> keep;
+  for (int v = 0; v < nv; ++v)
+    if (!skip[v]) keep.push_back(v);
+  sz->d_keep_list = upload(keep);
+  sz->n_keep = (int)keep.size();
+  sz->d_cond_off = upload(offs);
+  sz->d_cond = d_cd;
+  sz->n_cond = nc;
+  sz->cond_block_doubles = blk;
+  sz->condensed_state = 1;
+  if (dbg) std::fprintf(stderr, "[d4est_hip] schwarz: %d of %d copies condensed, %.1f MB of blocks\n", nc, nv, blk * 8e-6);
+}
+
+// A restricted to every subdomain, applied to a field over the subdomains (restricted input: zero outside the overlap)
+static void subdomain_operator(d4est_hip_schwarz* sz, const double* in, double* out) {
+  ensure_condensed(sz);
+  d4est_hip_plan* plan = sz->plan;
+  const bool cond = sz->condensed_state == 1 && direct_active(plan);
+  if (cond) direct_set_element_list(plan, sz->d_keep_list, sz->n_keep);
+  d4est_hip_apply_aij(plan, in, sz->d_zero_ghost, out);
+  if (cond) {
+    direct_set_element_list(plan, nullptr, 0);
+    hipLaunchKernelGGL(schwarz_condensed_apply_kernel, dim3(sz->n_cond), dim3(64), 0, plan->stream, (const CondDesc*)sz->d_cond, sz->n_cond,
+                       sz->d_cond_off, sz->d_cond_blocks, in, out);
+    HIP_CHECK(hipGetLastError());
+  }
+  add_lhs_mass_term(plan, in, out);
 }
 
 }  // namespace d4est_hip
@@ -347,6 +646,26 @@ d4est_hip_schwarz_t* d4est_hip_schwarz_create(d4est_hip_plan_t* subdomain_plan, 
     mN[e] = mesh_deg[e] + 1;
   }
   sz->d_vd = upload(vd);
+  sz->h_vd = vd;
+  {
+    std::vector<int> box_first(n_subdomains + 1, 0), box_off;
+    bool fits = true;   // field offsets are ints in the descriptors already (dst)
+    for (int s_ = 0; s_ < n_subdomains; ++s_) {
+      for (int v = sub_first[s_]; v < sub_first[s_ + 1]; ++v) {
+        const VirtDesc& q = vd[v];
+        const int e0 = q.hi[0] - q.lo[0], e1 = q.hi[1] - q.lo[1], e2 = q.hi[2] - q.lo[2];
+        for (int n = 0; n < e0 * e1 * e2; ++n)
+          box_off.push_back(q.dst + (q.lo[0] + n % e0) + q.N * ((q.lo[1] + (n / e0) % e1) + q.N * (q.lo[2] + n / (e0 * e1))));
+      }
+      if (box_off.size() > (size_t)0x7fffffff) { fits = false; break; }
+      box_first[s_ + 1] = (int)box_off.size();
+      sz->max_box_nodes = std::max(sz->max_box_nodes, box_first[s_ + 1] - box_first[s_]);
+    }
+    if (fits) {
+      sz->d_box_off = upload(box_off);
+      sz->d_box_first = upload(box_first);
+    }
+  }
   sz->d_sub_first = upload(std::vector<int>(sub_first, sub_first + n_subdomains + 1));
   sz->d_mesh_first = upload(first);
   sz->d_mesh_contrib = upload(flat);
@@ -360,7 +679,7 @@ void d4est_hip_schwarz_destroy(d4est_hip_schwarz_t* sz) {
   if (!sz) return;
   void* ptrs[] = {sz->d_vd, sz->d_sub_first, sz->d_mesh_first, sz->d_mesh_contrib, sz->d_mesh_stride, sz->d_mesh_N, sz->d_weights,
                   sz->d_du, sz->d_r, sz->d_d, sz->d_Ad, sz->d_zero_ghost, sz->d_delta, sz->d_tol, sz->d_active, sz->d_final_iter,
-                  sz->d_n_active};
+                  sz->d_n_active, sz->d_cond, sz->d_cond_blocks, sz->d_keep_list, sz->d_cond_off, sz->d_box_off, sz->d_box_first};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete sz;
@@ -388,8 +707,7 @@ void d4est_hip_schwarz_apply_over_subdomains(d4est_hip_schwarz_t* sz, const doub
   check_schwarz(sz, "schwarz_apply_over_subdomains");
   if (sz->n_virtual == 0) return;
   ensure_zero_ghost(sz);
-  d4est_hip_apply_aij(sz->plan, in_dev, sz->d_zero_ghost, out_dev);
-  add_lhs_mass_term(sz->plan, in_dev, out_dev);
+  subdomain_operator(sz, in_dev, out_dev);
   hipLaunchKernelGGL(schwarz_mask_kernel, dim3(std::min(sz->n_virtual, 65536)), dim3(256), 0, sz->plan->stream, sz->d_vd, sz->n_virtual,
                      out_dev);
   HIP_CHECK(hipGetLastError());
@@ -427,10 +745,16 @@ int d4est_hip_schwarz_iterate(d4est_hip_schwarz_t* sz, double* u_dev, const doub
       HIP_CHECK(hipStreamSynchronize(st));
       if (n_active == 0) break;  // every subdomain has left its loop
     }
-    d4est_hip_apply_aij(sz->plan, sz->d_d, sz->d_zero_ghost, sz->d_Ad);
-    add_lhs_mass_term(sz->plan, sz->d_d, sz->d_Ad);   // zeroth-order term of a linearised problem (plan_set_lhs_coefficient on the subdomain plan)
-    hipLaunchKernelGGL(schwarz_cg_kernel, dim3(sz->n_sub), dim3(256), 0, st, sz->d_vd, sz->d_sub_first, sz->d_du, sz->d_r, sz->d_d,
-                       sz->d_Ad, sz->d_delta, sz->d_tol, sz->d_active, sz->d_final_iter, sz->d_n_active, it);
+    subdomain_operator(sz, sz->d_d, sz->d_Ad);   // (+ the zeroth-order term of a linearised problem: plan_set_lhs_coefficient on the subdomain plan)
+    if (sz->d_box_off && sz->max_box_nodes <= 256 * 8)
+      hipLaunchKernelGGL(schwarz_cg_flat_kernel<8>, dim3(sz->n_sub), dim3(256), 0, st, sz->d_box_first, sz->d_box_off, sz->d_du, sz->d_r,
+                         sz->d_d, sz->d_Ad, sz->d_delta, sz->d_tol, sz->d_active, sz->d_final_iter, sz->d_n_active, it);
+    else if (sz->d_box_off && sz->max_box_nodes <= 256 * 16)
+      hipLaunchKernelGGL(schwarz_cg_flat_kernel<16>, dim3(sz->n_sub), dim3(256), 0, st, sz->d_box_first, sz->d_box_off, sz->d_du, sz->d_r,
+                         sz->d_d, sz->d_Ad, sz->d_delta, sz->d_tol, sz->d_active, sz->d_final_iter, sz->d_n_active, it);
+    else
+      hipLaunchKernelGGL(schwarz_cg_kernel, dim3(sz->n_sub), dim3(256), 0, st, sz->d_vd, sz->d_sub_first, sz->d_du, sz->d_r, sz->d_d,
+                         sz->d_Ad, sz->d_delta, sz->d_tol, sz->d_active, sz->d_final_iter, sz->d_n_active, it);
     HIP_CHECK(hipGetLastError());
   }
   d4est_hip_schwarz_add_correction(sz, sz->d_du, u_dev);
