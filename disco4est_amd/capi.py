@@ -72,6 +72,7 @@ SIGNATURES = {
     "d4est_hip_schwarz_destroy": (None, [_vp]),
     "d4est_hip_schwarz_nodal_size": (ctypes.c_longlong, [_vp]),
     "d4est_hip_schwarz_restricted_nodal_size": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_schwarz_condensed_copies": (ctypes.c_int, [_vp]),
     "d4est_hip_schwarz_restrict_field": (None, [_vp, _vp, _vp]),
     "d4est_hip_schwarz_apply_over_subdomains": (None, [_vp, _vp, _vp]),
     "d4est_hip_schwarz_add_correction": (None, [_vp, _vp, _vp]),

@@ -419,7 +419,7 @@ static void ensure_condensed(d4est_hip_schwarz* sz) {
   if (sz->condensed_state != 0) return;
   sz->condensed_state = -1;
   d4est_hip_plan* plan = sz->plan;
-  static const char* env = std::getenv("D4EST_HIP_SCHWARZ_CONDENSE");
+  const char* env = std::getenv("D4EST_HIP_SCHWARZ_CONDENSE");   // (read per smoother object: once, on its first use)
   static const bool dbg = std::getenv("D4EST_HIP_DEBUG_FUSED") != nullptr;
   auto no = [&](const char* why) {
     if (dbg) std::fprintf(stderr, "[d4est_hip] schwarz: no condensed copies: %s\n", why);
@@ -430,15 +430,18 @@ static void ensure_condensed(d4est_hip_schwarz* sz) {
   const int nv = sz->n_virtual;
   const std::vector<VirtDesc>& vd = sz->h_vd;
   if ((int)vd.size() != nv) return no("descriptor count");
-  // candidates: few restricted nodes; condensed: candidates whose neighbours are not candidates and whose blocks stay small
-  std::vector<char> cand(nv, 0);
-  for (int v = 0; v < nv; ++v) cand[v] = live_count(vd[v]) <= 27 && live_count(vd[v]) < vd[v].N * vd[v].N * vd[v].N;
+  // candidates: copies (not cores) with few restricted nodes, fewest first; a candidate is condensed when none of its neighbours is
+  // (condensed copies form an independent set: the rows of one never involve another) and its blocks stay small
+  std::vector<int> order;
+  for (int v = 0; v < nv; ++v)
+    if (live_count(vd[v]) <= 27 && live_count(vd[v]) < vd[v].N * vd[v].N * vd[v].N) order.push_back(v);
+  std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) { return live_count(vd[a_]) < live_count(vd[b_]); });
+  std::vector<char> taken(nv, 0);
   std::vector<CondDesc> cds;
   std::vector<int> offs;           // field offsets of every condensed copy's inputs
   std::vector<int> face_of_slot;   // per condensed copy and slot: the face of c it sits on
   long long blk = 0;
-  for (int v = 0; v < nv; ++v) {
-    if (!cand[v]) continue;
+  for (int v : order) {
     CondDesc c{};
     c.v = v; c.L = live_count(vd[v]); c.nn = 0; c.blk = blk;
     bool ok = true;
@@ -447,7 +450,7 @@ static void ensure_condensed(d4est_hip_schwarz* sz) {
     for (int f = 0; f < 6 && ok; ++f) {
       const int nb = plan->side_nbr[6 * (size_t)v + f];
       if (nb < 0) continue;
-      if (cand[nb] || live_count(vd[nb]) > 128) { ok = false; break; }
+      if (taken[nb] || live_count(vd[nb]) > 128) { ok = false; break; }
       faces[c.nn] = f;
       c.nb_v[c.nn] = nb; c.nb_L[c.nn] = live_count(vd[nb]);
       doubles += (long long)c.L * c.nb_L[c.nn];
@@ -468,6 +471,7 @@ static void ensure_condensed(d4est_hip_schwarz* sz) {
     for (int k = 0; k < c.nn; ++k) face_of_slot.push_back(faces[k]);
     for (int k = c.nn; k < 6; ++k) face_of_slot.push_back(-1);
     cds.push_back(c);
+    taken[v] = 1;
     blk += doubles;
   }
   const int nc = (int)cds.size();
@@ -687,6 +691,12 @@ void d4est_hip_schwarz_destroy(d4est_hip_schwarz_t* sz) {
 
 static void check_schwarz(const d4est_hip_schwarz_t* sz, const char* who) {
   if (!sz || !sz->plan) D4EST_HIP_ABORT("%s: NULL schwarz handle", who);
+}
+
+int d4est_hip_schwarz_condensed_copies(d4est_hip_schwarz_t* sz) {
+  check_schwarz(sz, "schwarz_condensed_copies");
+  ensure_condensed(sz);
+  return sz->condensed_state == 1 ? sz->n_cond : 0;
 }
 
 long long d4est_hip_schwarz_nodal_size(const d4est_hip_schwarz_t* sz) { check_schwarz(sz, "schwarz_nodal_size"); return sz->nodal_size; }

@@ -325,6 +325,10 @@ class Schwarz:
         assert self.nodal_size == md.nodal_size and self.restricted_nodal_size == md.restricted_nodal_size
         self.local_nodes = mesh.local_nodes
 
+    def condensed_copies(self):
+        """element copies whose operator rows are dense blocks (corner copies of conforming one-degree subdomains); 0 = none"""
+        return int(self.lib.d4est_hip_schwarz_condensed_copies(self.handle))
+
     def restrict_field(self, field, out):
         assert field.numel() == self.local_nodes and out.numel() == self.nodal_size
         self.lib.d4est_hip_schwarz_restrict_field(self.handle, capi._ptr(field), capi._ptr(out))

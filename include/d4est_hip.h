@@ -444,6 +444,11 @@ void d4est_hip_schwarz_destroy(d4est_hip_schwarz_t* sz);
 /* schwarz_metadata->nodal_size / ->restricted_nodal_size (d4est_solver_schwarz_metadata.c:459-520) */
 long long d4est_hip_schwarz_nodal_size(const d4est_hip_schwarz_t* sz);
 long long d4est_hip_schwarz_restricted_nodal_size(const d4est_hip_schwarz_t* sz);
+/* How many element copies have their rows of the subdomain operator kept as small dense blocks (read off the matrix-free operator by
+ * probing, once, on first use) instead of being applied element by element: on a conforming one-degree mesh with a small overlap
+ * the corner copies (8 of 27 per subdomain; 8 restricted nodes of 512 at overlap 2, p = 7).  0 when the optimisation does not apply
+ * (mixed degrees, hanging faces, blocks above 8 KB) or is switched off (D4EST_HIP_SCHWARZ_CONDENSE=0); results agree to rounding. */
+int d4est_hip_schwarz_condensed_copies(d4est_hip_schwarz_t* sz);
 /* d4est_solver_schwarz_convert_nodal_field_to_restricted_field_over_subdomains (src/Solver/d4est_solver_schwarz_helpers.c:123-155).
  * Fields over the subdomains have nodal_size entries (whole elements); the restricted field is stored in place, zero outside the
  * overlap nodes (restrict-transpose, helpers.c:210-239, is then the identity). */

@@ -288,3 +288,45 @@ def test_schwarz_with_overintegration(gpu, hiplib, oracle):
     sz.iterate(u, _t(r, gpu))
     assert _rel(u.cpu().numpy(), u_ref) <= 1e-9
     sz.destroy()
+
+
+@pytest.mark.parametrize("level,deg,curved,rs", [(2, 3, True, 2), (1, 7, True, 2), (2, 5, False, 2)])
+def test_condensed_corner_copies(gpu, hiplib, oracle, monkeypatch, level, deg, curved, rs):
+    """Corner copies of conforming one-degree subdomains keep their rows of the subdomain operator as dense blocks probed from the
+    matrix-free operator (csrc/d4est_hip_schwarz.hip: ensure_condensed).  With and without them: the same operator (1e-13), the
+    oracle's operator (1e-12), the same CG iteration counts and the same iterate (1e-10)."""
+    import torch
+    from disco4est_amd import mesh as M
+    from disco4est_amd.schwarz import Schwarz
+    m, J, rst, sides, sz = _setup(level, deg, curved, rs, oracle, 6, 1e-15, 1e-15)
+    md = sz.metadata
+    direct = sz.plan.face_path() != "two-phase"
+    n_cond = sz.condensed_copies()
+    if direct:
+        # every subdomain has one corner copy per corner of its patch: 8 at level 1 (one per subdomain), 27 000-style counts above
+        assert n_cond > 0 and n_cond < md.num_elements
+    else:
+        assert n_cond == 0          # the list-driven operator kernel belongs to the direct face path
+    monkeypatch.setenv("D4EST_HIP_SCHWARZ_CONDENSE", "0")
+    sz0 = Schwarz(m, sides, J, rst, rs, 6, 1e-15, 1e-15, 10.0, 0)
+    assert sz0.condensed_copies() == 0
+    monkeypatch.delenv("D4EST_HIP_SCHWARZ_CONDENSE")
+    x = torch.empty(sz.nodal_size, dtype=torch.float64, device=gpu)
+    sz.restrict_field(_t(M.splitmix64_uniform(71, m.local_nodes) - 0.5, gpu), x)
+    Ax, Ax0 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+    sz.apply_over_subdomains(x, Ax)
+    sz0.apply_over_subdomains(x, Ax0)
+    xh, Axh, Ax0h = x.cpu().numpy(), Ax.cpu().numpy(), Ax0.cpu().numpy()
+    scale = np.abs(Ax0h).max()
+    assert np.isfinite(Axh).all() and np.abs(Axh - Ax0h).max() <= 1e-13 * scale
+    for s in ((0, md.num_subdomains - 1) if md.num_subdomains <= 8 else (0, 21, 42, 63)):
+        elem, faces, _ = md.subdomain(s)
+        ref = oracle.schwarz_apply_over_subdomain(elem, faces, rs, _over_subdomains_to_restricted(oracle, m, md, xh, s))
+        assert np.abs(_over_subdomains_to_restricted(oracle, m, md, Axh, s) - ref).max() <= 1e-12 * scale
+    r = _t(M.splitmix64_uniform(72, m.local_nodes) - 0.5, gpu)
+    u, u0 = torch.zeros(m.local_nodes, dtype=torch.float64, device=gpu), torch.zeros(m.local_nodes, dtype=torch.float64, device=gpu)
+    assert sz.iterate(u, r) == sz0.iterate(u0, r)
+    assert _rel(u.cpu().numpy(), u0.cpu().numpy()) <= 1e-10
+    it, _ = sz.info(); it0, _ = sz0.info()
+    np.testing.assert_array_equal(it, it0)
+    sz.destroy(); sz0.destroy()
