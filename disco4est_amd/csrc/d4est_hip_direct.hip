@@ -585,8 +585,15 @@ void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, c
   plan->direct = dh;
 }
 
+// Below this many elements the chip is far from full and the two-phase kernels win: they put 3 + 6 wavefronts on an element, the
+// direct kernel ONE, whose serial chain then IS the run time (measured, p = 7: 64 elements 16 us two-phase against 23 us in one kernel,
+// 512 elements 25 against 25 -- Chebyshev 30 against 34 --, 4096 elements 83 against 52).  Auto only; tuning values 1 / 2 force it.
+constexpr int kDirectMinElements = 768;
+
 bool direct_active(const d4est_hip_plan* plan) {
-  return plan->direct != nullptr && plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0;
+  const int t = plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT];
+  return plan->direct != nullptr && t != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
+         (t > 0 || plan->n_elements >= kDirectMinElements);
 }
 
 void direct_set_element_list(d4est_hip_plan* plan, const int* list_dev, int n_list) {

@@ -38,24 +38,19 @@ def gpu():
 
 
 # Modules whose GPU tests exercise the full operator through the smoothers, forests, shards or Schwarz: every test in them runs
-# once per face path -- the default (the direct kernel on conforming uniform plans up to deg_quad = 7, with the volume term in it at
-# deg = deg_quad in {5, 7}), the direct kernel for the faces only, and the two-phase kernels (D4EST_HIP_FACE_DIRECT=1 / 0 make tuning
-# key 11 default to that value for the plans the test creates).
+# once per face path -- the direct kernel on conforming uniform plans up to deg_quad = 7 with the volume term in it at deg = deg_quad
+# in {5, 7}, the direct kernel for the faces only, and the two-phase kernels (D4EST_HIP_FACE_DIRECT=2 / 1 / 0 make tuning key 11
+# default to that value for the plans the test creates; left alone, the library would pick the two-phase kernels on these small meshes).
 _BOTH_FACE_PATHS = {"test_forest_gpu", "test_solver_gpu", "test_schwarz_gpu", "test_parallel_gpu", "test_multigrid_gpu"}
 
 
 def pytest_generate_tests(metafunc):
     if metafunc.module.__name__.split(".")[-1] in _BOTH_FACE_PATHS:
         metafunc.fixturenames.append("_face_path")
-        metafunc.parametrize("_face_path", ["default", "direct-faces-only", "two-phase"], indirect=True)
+        metafunc.parametrize("_face_path", ["direct+volume", "direct-faces-only", "two-phase"], indirect=True)
 
 
 @pytest.fixture
 def _face_path(request, monkeypatch):
-    if request.param == "two-phase":
-        monkeypatch.setenv("D4EST_HIP_FACE_DIRECT", "0")
-    elif request.param == "direct-faces-only":
-        monkeypatch.setenv("D4EST_HIP_FACE_DIRECT", "1")
-    else:
-        monkeypatch.delenv("D4EST_HIP_FACE_DIRECT", raising=False)
+    monkeypatch.setenv("D4EST_HIP_FACE_DIRECT", {"direct+volume": "2", "direct-faces-only": "1", "two-phase": "0"}[request.param])
     return request.param

@@ -9,17 +9,20 @@ RTOL = 1e-12
 DIRECT_PAIRS = {(n, n) for n in range(2, 9)} | {(2, 3), (3, 4), (4, 5), (3, 6), (4, 6)}
 
 
-def _expected_face_path(deg, inc):
-    """What apply_aij runs by default: the direct kernel where it is instantiated, with the volume term in it at deg = deg_quad in {5, 7}."""
+def _face_path_values(plan):
+    """Values of tuning key 11 to run a test with: every face path the plan supports (2 whole operator in the direct kernel, 1 direct
+    face kernel + volume kernel, 0 two-phase kernels).  The default picks by size (two-phase below 768 elements), so the tests force."""
+    plan.set_tuning(11, 2)
+    best = plan.face_path()
+    plan.set_tuning(11, -1)
+    return {"direct+volume": (2, 1, 0), "direct": (1, 0), "two-phase": (0,)}[best]
+
+
+def _best_face_path(deg, inc):
+    """What tuning value 2 selects: the direct kernel where it is instantiated, with the volume term in it at deg = deg_quad in {5, 7}."""
     if (deg + 1, deg + inc + 1) not in DIRECT_PAIRS:
         return "two-phase"
     return "direct+volume" if inc == 0 and deg in (5, 7) else "direct"
-
-
-def _face_path_values(plan):
-    """Values of tuning key 11 to run a test with: every face path the plan supports (2 whole operator in the direct kernel, 1 direct
-    face kernel + volume kernel, 0 two-phase kernels)."""
-    return {"direct+volume": (2, 1, 0), "direct": (1, 0), "two-phase": (0,)}[plan.face_path()]
 
 
 def _t(a, dev):
@@ -61,8 +64,10 @@ def test_apply_aij_parity(gpu, hiplib, oracle, level, deg, inc, curved, fcn):
     dAu = torch.full_like(du, float("nan"))
     # uniform conforming plans up to deg_quad = 7 run the direct face kernel (traces formed from u in place) by default;
     # tuning key 11 = 0 selects the two-phase kernels: both are held to the oracle
-    assert plan.face_path() == _expected_face_path(deg, inc)
-    for direct in _face_path_values(plan):
+    assert plan.face_path() == "two-phase"          # a small mesh: the default is the two-phase kernels (see d4est_hip.h, key 11)
+    vals = _face_path_values(plan)
+    assert {2: "direct+volume", 1: "direct", 0: "two-phase"}[vals[0]] == _best_face_path(deg, inc)
+    for direct in vals:
         plan.set_tuning(11, direct)
         assert plan.face_path() == {2: "direct+volume", 1: "direct", 0: "two-phase"}[direct]
         dAu.fill_(float("nan"))
@@ -299,3 +304,26 @@ def test_brick_geometry_on_device(gpu, hiplib, oracle, kind, level, deg):
     plan.apply_mass_matrix(du, Mu)
     assert _rel(Mu.cpu().numpy(), oracle.apply_mass(m, J, u)) <= RTOL
     plan.destroy()
+
+
+def test_default_face_path_follows_the_size(gpu, hiplib, oracle):
+    """Tuning key 11 left alone: the two-phase kernels below 768 elements (several wavefronts per element on a mostly empty chip), the
+    one-wavefront direct kernel from there on; parity of the default on the larger mesh."""
+    import torch
+    from disco4est_amd import mesh as M
+    paths = {}
+    for level in (3, 4):
+        m = M.BrickMesh(level, 1)
+        J, rst = m.geometry(None)
+        sides = m.build_sides(None)
+        plan = _plan(m, J, rst, sides)
+        paths[level] = plan.face_path()
+        if level == 4:
+            u = m.field(None)
+            du = _t(u, gpu)
+            dAu = torch.full_like(du, float("nan"))
+            plan.apply_aij(du, dAu)
+            ref = oracle.apply_aij(m, J, rst, sides, u, nthreads=8)
+            assert _rel(dAu.cpu().numpy(), ref) <= RTOL
+        plan.destroy()
+    assert paths == {3: "two-phase", 4: "direct"}      # 512 and 4096 elements (p = 1: the volume term stays in its own kernel)
