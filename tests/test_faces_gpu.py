@@ -327,3 +327,26 @@ def test_default_face_path_follows_the_size(gpu, hiplib, oracle):
             assert _rel(dAu.cpu().numpy(), ref) <= RTOL
         plan.destroy()
     assert paths == {3: "two-phase", 4: "direct"}      # 512 and 4096 elements (p = 1: the volume term stays in its own kernel)
+
+
+@pytest.mark.parametrize("level,deg,inc", [(1, 3, 0), (1, 7, 0), (1, 4, 1), (1, 5, 0), (1, 9, 0)])
+def test_apply_aij_lobatto_quadrature(gpu, hiplib, oracle, level, deg, inc):
+    """The reference's second quadrature type (Gauss-Lobatto points, Quadrature/d4est_quadrature_lobatto.c) through every face path:
+    the interpolation to the quadrature nodes is the identity at deg_quad = deg, the weights differ."""
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(level, deg, deg_quad_inc=inc, quad_type=1)
+    mp = M.SineMap(0.05)
+    J, rst = m.geometry(mp)
+    sides = m.build_sides(mp)
+    u = m.field(mp)
+    ref = oracle.apply_aij(m, J, rst, sides, u, penalty_prefactor=9.0, nthreads=8)
+    plan = _plan(m, J, rst, sides, 9.0, 0)
+    du = _t(u, gpu)
+    dAu = torch.full_like(du, float("nan"))
+    for direct in _face_path_values(plan):
+        plan.set_tuning(11, direct)
+        dAu.fill_(float("nan"))
+        plan.apply_aij(du, dAu)
+        assert _rel(dAu.cpu().numpy(), ref) <= RTOL, (direct, plan.face_path())
+    plan.destroy()
