@@ -46,6 +46,8 @@ def _plan(m, J, rst, sides, prefactor=10.0, fcn=0):
     (1, 1, 0, True, 0), (1, 2, 0, False, 0), (1, 2, 1, True, 1), (1, 3, 0, True, 0), (2, 3, 0, True, 2),
     (1, 4, 2, True, 3), (1, 5, 0, True, 0), (1, 7, 0, False, 0), (1, 7, 0, True, 0), (1, 7, 1, True, 0),
     (1, 8, 0, True, 0), (1, 11, 0, True, 0), (0, 3, 0, True, 0), (0, 15, 0, True, 0),
+    # over-integrated pairs the direct face kernel is instantiated for: (deg + 1, deg_quad + 1) = (2, 3), (4, 5), (3, 6), (4, 6)
+    (1, 1, 1, True, 0), (1, 3, 1, True, 0), (1, 2, 3, True, 0), (1, 3, 2, True, 0), (1, 6, 0, True, 0),
 ])
 def test_apply_aij_parity(gpu, hiplib, oracle, level, deg, inc, curved, fcn):
     import torch
