@@ -446,7 +446,9 @@ def main():
                 ms = e0.elapsed_time(e1) / 3
                 sec["schwarz_iterate_10_cg"] = {"ms": ms, "subdomains": sz.metadata.num_subdomains,
                                                 "subdomain_elements": sz.metadata.num_elements, "num_nodes_overlap": 2,
-                                                "ms_per_cg_sweep": ms / 10}
+                                                "ms_per_cg_sweep": ms / 10, "face_path": sz.plan.face_path(),
+                                                # corner copies whose operator rows are dense blocks probed from the operator
+                                                "condensed_copies": sz.condensed_copies()}
                 sz.destroy()
                 del us
             out["secondary"] = sec
