@@ -290,6 +290,21 @@ void d4est_laplacian_apply_aij(p4est_t* p4est, d4est_ghost_t*, d4est_ghost_data_
   d4est_hip_apply_aij_host(plan, d->u + off, d->Au + off);
 }
 
+// the reference's second implementation of the same operator (one visit per face, both sides accumulated): same applies here
+void d4est_laplacian_with_opt_apply_stiffness_matrix(p4est_t* p4est, d4est_operators_t* ops, d4est_geometry_t* geom, d4est_quadrature_t* quad,
+                                                     d4est_mesh_data_t* factors, double* u, double* Au, int local_nodes, int which_field) {
+  d4est_laplacian_apply_stiffness_matrix(p4est, ops, geom, quad, factors, u, Au, local_nodes, which_field);   // d4est_laplacian_with_opt.c:145-209
+}
+
+void d4est_laplacian_with_opt_apply_aij(p4est_t* p4est, d4est_ghost_t*, d4est_ghost_data_t*, d4est_elliptic_data_t* d,
+                                        d4est_laplacian_with_opt_flux_data_t*, d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t*,
+                                        d4est_mesh_data_t*, int which_field) {   // d4est_laplacian_with_opt.c
+  d4est_hip_plan_t* plan = bound(p4est, "d4est_laplacian_with_opt_apply_aij");
+  if (!d || d->local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("d4est_laplacian_with_opt_apply_aij: elliptic data does not match the bound plan");
+  const size_t off = (size_t)which_field * d->local_nodes;
+  d4est_hip_apply_aij_host(plan, d->u + off, d->Au + off);
+}
+
 void d4est_solver_multigrid_smoother_cheby_iterate_aux(p4est_t* p4est, d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t*,
                                                        d4est_mesh_data_t*, d4est_ghost_t*, d4est_ghost_data_t*, d4est_elliptic_data_t* vecs,
                                                        d4est_elliptic_eqns_t*, double* r, int iter, double lmin, double lmax,

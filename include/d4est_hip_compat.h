@@ -41,6 +41,7 @@ typedef struct d4est_mesh_data_opaque d4est_mesh_data_t;        /* Mesh/d4est_me
 typedef struct d4est_ghost_opaque d4est_ghost_t;                /* Mesh/d4est_ghost.h */
 typedef struct d4est_ghost_data_opaque d4est_ghost_data_t;      /* Mesh/d4est_ghost_data.h */
 typedef struct d4est_laplacian_flux_data_opaque d4est_laplacian_flux_data_t; /* dGMath/d4est_laplacian_flux.h */
+typedef struct d4est_laplacian_with_opt_flux_data_opaque d4est_laplacian_with_opt_flux_data_t; /* dGMath/d4est_laplacian_with_opt_flux.h */
 typedef int d4est_quadrature_object_type_t;                     /* enum {QUAD_OBJECT_MORTAR, QUAD_OBJECT_VOLUME}, d4est_quadrature.h:16-17 */
 typedef int d4est_quadrature_integrand_type_t;                  /* enum, d4est_quadrature.h:21-29 */
 typedef int d4est_field_type_t;                                 /* enum, Mesh/d4est_field.h */
@@ -104,6 +105,11 @@ void d4est_operators_apply_hp_prolong_transpose(d4est_operators_t *d4est_ops,dou
  *   cg_eigs                                    src/Solver/d4est_solver_cg_eigs.h:9 */
 void d4est_laplacian_apply_stiffness_matrix(p4est_t *p4est,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,double *D4EST_RESTRICT u,double *D4EST_RESTRICT Au,int local_nodes,int which_field);
 void d4est_laplacian_apply_aij(p4est_t *p4est,d4est_ghost_t *d4est_ghost,d4est_ghost_data_t *d4est_ghost_data,d4est_elliptic_data_t *d4est_elliptic_data,d4est_laplacian_flux_data_t *flux_fcn_data,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,int which_field);
+/* the "_with_opt" twins (src/dGMath/d4est_laplacian_with_opt.h:22-23): the reference's second implementation of the SAME operator,
+ * which visits every face once and accumulates into both sides (d4est_laplacian_with_opt_flux_sipg.c:1231-1245); here they are the
+ * same plan-bound applies as the two functions above */
+void d4est_laplacian_with_opt_apply_stiffness_matrix(p4est_t *p4est,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,double *D4EST_RESTRICT u,double *D4EST_RESTRICT Au,int local_nodes,int which_field);
+void d4est_laplacian_with_opt_apply_aij(p4est_t *p4est,d4est_ghost_t *d4est_ghost,d4est_ghost_data_t *d4est_ghost_data,d4est_elliptic_data_t *d4est_elliptic_data,d4est_laplacian_with_opt_flux_data_t *flux_fcn_data,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,int which_field);
 void d4est_solver_multigrid_smoother_cheby_iterate_aux(p4est_t *p4est,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,d4est_ghost_t *d4est_ghost,d4est_ghost_data_t *d4est_ghost_data,d4est_elliptic_data_t *vecs,d4est_elliptic_eqns_t *fcns,double *r,int iter,double lmin,double lmax,int print_residual_norm,int mg_level,int compute_residual_at_end);
 void cg_eigs(p4est_t *p4est,d4est_elliptic_data_t *vecs,d4est_elliptic_eqns_t *fcns,d4est_ghost_t *ghost,d4est_ghost_data_t *ghost_data,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,int imax,int print_spectral_bound_iterations,int use_new,double *spectral_bound);
 #endif /* D4EST_HIP_COMPAT_NO_TYPES */

@@ -161,6 +161,15 @@ static void operator_level(int p) {
   oracle_apply_lhs(u, ref);
   check("d4est_laplacian_apply_aij", p, Au, ref, ln, 1e-12);
 
+  /* the _with_opt twins: the reference's second implementation of the same operator */
+  memset(Au, 0, sizeof(double) * ln);
+  d4est_laplacian_with_opt_apply_aij(p4est, NULL, NULL, &vecs, NULL, NULL, NULL, NULL, NULL, 0);
+  check("d4est_laplacian_with_opt_apply_aij", p, Au, ref, ln, 1e-12);
+  memset(Au, 0, sizeof(double) * ln);
+  d4est_laplacian_with_opt_apply_stiffness_matrix(p4est, NULL, NULL, NULL, NULL, u, Au, ln, 0);
+  oracle_laplacian_apply_stiffness_matrix(0, ne, deg, degq, ns, qs, ln, J, rst, u, ref, 1);
+  check("d4est_laplacian_with_opt_apply_stiffness_matrix", p, Au, ref, ln, 1e-12);
+
   double bound = 0, bound_ref = 0;
   memcpy(ur, u, sizeof(double) * ln);
   cg_eigs(p4est, &vecs, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 8, 0, 1, &bound);

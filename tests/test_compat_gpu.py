@@ -27,7 +27,8 @@ def test_compat_header_is_c99_and_every_declared_symbol_is_exported(hiplib, orac
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = set(re.findall(r"^(?:void|double|int|d4est_hip_plan_t\s*\*)\s*\*?\s*(\w+)\s*\(", text, flags=re.M))
     assert {"d4est_quadrature_apply_stiffness_matrix", "d4est_operators_apply_hp_restrict", "d4est_laplacian_apply_aij", "cg_eigs",
-            "d4est_solver_multigrid_smoother_cheby_iterate_aux", "d4est_hip_compat_bind_mesh"} <= names and len(names) >= 24
+            "d4est_laplacian_with_opt_apply_aij", "d4est_laplacian_with_opt_apply_stiffness_matrix",
+            "d4est_solver_multigrid_smoother_cheby_iterate_aux", "d4est_hip_compat_bind_mesh"} <= names and len(names) >= 26
     lib = ctypes.CDLL(os.path.join(LIBDIR, "libd4est_hip_compat.so"))
     for n in names:
         getattr(lib, n)
