@@ -82,8 +82,9 @@ def cpu_baseline(mesh, J, rst, u, budget_s=12.0):
     }
 
 
-def time_region(fn, reps, stream, torch, warm=3):
-    """average milliseconds per call, HIP events on the launch stream"""
+def time_region(fn, reps, stream, torch, warm=10):
+    """average milliseconds per call, HIP events on the launch stream.  warm: untimed calls first -- the chip's clocks take some tens
+    of back-to-back launches to settle (p = 15, 8192 elements: 588 us on the first call after an idle gap, 470 us from the 35th on)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -361,17 +362,7 @@ def main():
             sec = {}
             for name, fn, applies in (("apply_aij", lambda: plan.apply_aij(du, dAu), 1),
                                       ("cheby_5_iterations", lambda: plan.cheby_iterate(du, rhs, dAu, r, 5, 1.0, 30.0, 0), 5)):
-                for _ in range(3):
-                    fn()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                reps = 30
-                e0.record(stream)
-                for _ in range(reps):
-                    fn()
-                e1.record(stream)
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / reps
+                ms = time_region(fn, 50, stream, torch, warm=10)
                 sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9}
                 # algorithmic bytes of one full operator apply per DoF: u 8 + A u 8 + metric 48 (NQ/N)^3 + the 7 pre-combined face
                 # factors per mortar node of 6 sides; the mortar-node traces are intermediates, not counted
@@ -404,17 +395,7 @@ def main():
                 p2.set_tuning(7, 0)
                 x2 = torch.from_numpy(m2.field()).to(dev)
                 y2 = torch.empty_like(x2)
-                for _ in range(3):
-                    p2.apply_stiffness_matrix(x2, y2)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                reps = 20
-                e0.record(stream)
-                for _ in range(reps):
-                    p2.apply_stiffness_matrix(x2, y2)
-                e1.record(stream)
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / reps
+                ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 40, stream, torch, warm=20)
                 sec["stiffness_p%d" % deg] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes,
                                               "kernel": p2.last_kernel()}
                 p2.destroy()
