@@ -252,3 +252,47 @@ def test_element_exchange_gloo(world, level, deg_spec):
     for r in res:
         assert r[1] == "ok", r
     assert all(r[2] > 0 and r[3] > 0 for r in res)
+
+
+@pytest.mark.parametrize("world,level,deg_spec", [(2, 2, [3]), (4, 2, [2, 3, 4]), (3, 1, [7])])
+def test_schedules_of_all_ranks_agree_and_flatten(world, level, deg_spec):
+    """The N > 1 preflight of bench.py (parallel.schedule_summary / check_schedules_match) and the flat arrays the RCCL transport takes
+    (parallel.flatten_schedule -> d4est_hip_plan_set_rccl_exchange): every pair of ranks agrees on what travels between them, the flat
+    form holds exactly the schedule's blocks, and a tampered summary is caught (it would hang the grouped send / recv round)."""
+    from disco4est_amd import mesh as M, parallel as P
+    n_global = 8 ** level
+    deg_global = np.array([deg_spec[i % len(deg_spec)] for i in range(n_global)])
+    parts = P.partition_by_dofs(deg_global, world)
+    scheds = []
+    for first, count in parts:
+        m = M.BrickMesh(level, deg_global, first=first, count=count)
+        sides = m.build_sides(None)
+        toff, goff, blen = P.side_block_layout(sides)
+        scheds.append(P.TraceSchedule(m, sides, parts, lambda s, b: toff[s], lambda s, b: goff[s], lambda s, b: blen[s]))
+    summaries = [P.schedule_summary(s) for s in scheds]
+    ok, why = P.check_schedules_match(summaries)
+    assert ok, why
+    total_sent = sum(v[0] for s in summaries for v in s.values())
+    total_recv = sum(v[1] for s in summaries for v in s.values())
+    assert total_sent == total_recv > 0
+    for r, sched in enumerate(scheds):
+        peers, sf, so, sl, rf, ro, rl = P.flatten_schedule(sched)
+        assert list(peers) == list(sched.peers) and r not in peers
+        assert sf[0] == 0 and rf[0] == 0 and sf[-1] == len(so) == len(sl) and rf[-1] == len(ro) == len(rl)
+        for i, p in enumerate(peers):
+            assert int(sl[sf[i]:sf[i + 1]].sum()) == summaries[r][int(p)][0]
+            assert int(rl[rf[i]:rf[i + 1]].sum()) == summaries[r][int(p)][1]
+            np.testing.assert_array_equal(so[sf[i]:sf[i + 1]], sched.send[p][:, 0])
+            np.testing.assert_array_equal(ro[rf[i]:rf[i + 1]], sched.recv[p][:, 0])
+        assert so.dtype == np.int64 and sl.dtype == np.int32 and peers.dtype == np.int32
+    # a rank that expects one double more than its peer sends: refused
+    bad = [dict(s) for s in summaries]
+    a = 0
+    b = next(iter(bad[a]))
+    bad[a][b] = (bad[a][b][0], bad[a][b][1] + 1)
+    ok, why = P.check_schedules_match(bad)
+    assert not ok and "rank" in why
+    # a rank missing from its peer's list: refused
+    bad = [dict(s) for s in summaries]
+    del bad[b][a]
+    assert not P.check_schedules_match(bad)[0]
