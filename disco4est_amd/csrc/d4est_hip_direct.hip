@@ -57,6 +57,7 @@ struct DirectHost {
   double* d_u2 = nullptr;    // second solution vector of the fused Chebyshev update (see cheby_iterate_body)
   const int* d_list = nullptr;   // optional list of the elements the kernel works on (not owned; direct_set_element_list)
   int n_list = 0;
+  int order_ok = -1;             // 1: the plan's single bucket lists the elements in order (cached by direct_fused_ok)
 };
 
 // y = M x, M (NO x NI): tab = M transposed (NI x NO row-major), or the even-odd table of M when EO (NI, NO even; ANTI: M is
@@ -630,8 +631,12 @@ bool direct_fused_ok(const d4est_hip_plan* plan) {
   // quadrature offsets are affine too -- not so on a Schwarz subdomain plan, which reads them from the list)
   if (bk.ns_stride >= 0 && (bk.ns0 != dh->ns0 || bk.ns_stride != dh->ns_stride)) return no("nodal offsets");
   if (bk.n_elem != plan->n_elements) return no("bucket size");
-  for (int i = 0; i < plan->n_elements; ++i)
-    if (plan->elem_ids[i] != i) return no("bucket order");
+  if (dh->order_ok < 0) {   // (the bucket order is fixed at plan creation: looked at once, not at every apply)
+    int ok = 1;
+    for (int i = 0; i < plan->n_elements && ok; ++i) ok = (plan->elem_ids[i] == i);
+    const_cast<DirectHost*>(dh)->order_ok = ok;
+  }
+  if (!dh->order_ok) return no("bucket order");
   const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
   if (!(tw < 0 || tw == 11)) return no("tuning key 1");
   return true;
