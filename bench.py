@@ -402,9 +402,11 @@ def main():
                 del x2, y2
             # off-cache points (the config-2 working set, 134 MB, sits in the 256 MB Infinity Cache): level 5 at p = 7 (1.07 GB per
             # apply) and BASELINE config 3 at full size (level 5, p = 11, 56.6 MDoF, 3.6 GB per apply); factors generated on the device
-            for name, level, deg in (("stiffness_p7_level5", 5, 7), ("stiffness_p11_level5_config3", 5, 11)):
-                m2, p2, x2, y2 = brick_plan(level, deg, stream, torch, dev)
-                ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 10, stream, torch)
+            # ... and config 5's degree at a size past the ramp (8192 elements, 33.6 MDoF, 2.1 GB per apply)
+            for name, level, deg, count in (("stiffness_p7_level5", 5, 7, None), ("stiffness_p11_level5_config3", 5, 11, None),
+                                            ("stiffness_p15_8192_elements", 5, 15, 8192)):
+                m2, p2, x2, y2 = brick_plan(level, deg, stream, torch, dev, count=count)
+                ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 10 if count is None else 30, stream, torch, warm=10 if count is None else 30)
                 bytes_ = algorithmic_bytes_per_dof(deg + 1, deg + 1) * m2.local_nodes
                 sec[name] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes, "kernel": p2.last_kernel(),
                              "roofline_frac_hbm": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
