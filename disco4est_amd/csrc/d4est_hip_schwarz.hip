@@ -338,7 +338,8 @@ static void ensure_zero_ghost(d4est_hip_schwarz* sz) {
 // a second neighbour of such a c would be probed in the same round), so they are the SAME numbers the kernels produce, to rounding.  From then on the operator kernel skips
 // the condensed copies (they are still read as neighbours) and one small kernel forms their rows: 6.6 KB per corner copy instead of a
 // 4 KB + 45 KB element apply.  Only copies whose blocks stay under 8 KB are condensed (at overlap 3 the blocks would cost more to
-// stream than the apply they replace).  D4EST_HIP_SCHWARZ_CONDENSE=0 switches it off.
+// stream than the apply they replace).  D4EST_HIP_SCHWARZ_CONDENSE=0 switches it off.  Probing needs a LINEAR operator: the subdomain
+// plan carries homogeneous boundary data (the correction's), as disco4est_amd/schwarz.py sets it.
 // ---------------------------------------------------------------------------
 struct CondDesc {
   int v;          // the condensed copy
