@@ -470,7 +470,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
       for (int i = 0; i < N; ++i) {
         const size_t o = (size_t)ns + a + N * b + N2 * i;
         const double au = s_U[a + PN * (b + N * i)] + facc[i];
-        Au[o] = au;
+        if (!FUSE || !cf.skip_Au_store) Au[o] = au;
         if constexpr (FUSE) {   // the Chebyshev update of the node, as in the faces-only form
           const double res = __dadd_rn(cf.rhs[o], __dmul_rn(-1.0, au));
           const double ri = __dmul_rn(cf.alpha, res);

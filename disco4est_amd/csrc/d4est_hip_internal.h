@@ -170,6 +170,7 @@ struct ChebyFuse {
   double* p = nullptr;
   double* u = nullptr;
   double* u_out = nullptr;   // direct face kernel only: where the new iterate goes (it reads the neighbours' u)
+  int skip_Au_store = 0;     // whole-operator kernel only: A u is consumed by the update and not stored (every iteration but the last)
   double* r = nullptr;
   double alpha = 0.0, beta = 0.0;
 };
@@ -182,6 +183,8 @@ struct DirectFuse {   // Chebyshev update in the epilogue; the new iterate goes 
   double* u_out = nullptr;
   double* r = nullptr;
   double alpha = 0.0, beta = 0.0;
+  int skip_Au_store = 0;   // whole-operator form only: A u feeds the update in registers and is not written
+  int pad = 0;
 };
 void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, const double* C, const double* CD, const double* E);
 void direct_destroy(d4est_hip_plan* plan);

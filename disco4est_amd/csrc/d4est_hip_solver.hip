@@ -171,6 +171,7 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
     if (cf) {
       DirectFuse df;
       df.rhs = cf->rhs; df.p = cf->p; df.u_out = cf->u_out; df.r = cf->r; df.alpha = cf->alpha; df.beta = cf->beta;
+      df.skip_Au_store = (whole && cf->skip_Au_store) ? 1 : 0;
       if (!df.u_out || df.u_out == u) D4EST_HIP_ABORT("apply_operator: the direct face kernel needs a second vector for the fused update");
       launch_flux_direct(plan, u, plan->d_ghost_trace, Au, &df, whole ? 1 : 0);
     } else {
@@ -291,6 +292,9 @@ static void cheby_iterate_body(d4est_hip_plan* plan, double* u, const double* rh
       cf.rhs = rhs; cf.p = plan->d_work_p; cf.u = u; cf.r = r_out; cf.alpha = alpha; cf.beta = beta;
       if (pingpong) {
         cf.u_out = ub;
+        // A u of an iteration is observable only after the last one (the caller's Au holds A u of the last-but-one iterate, as in the
+        // reference, :119-154): the one-kernel operator keeps it in registers in between -- one vector of stores less per iteration
+        cf.skip_Au_store = (i < iter - 1) ? 1 : 0;
         apply_operator(plan, u, Au, &cf);
         std::swap(u, ub);
       } else {
