@@ -437,6 +437,7 @@ def main():
             out["secondary"] = sec
         except Exception as exc:  # secondary numbers must never break the headline line
             out["secondary"] = {"error": repr(exc)}
+    emitted, dog = [False], None
     if world == 1 and args.sharded_secondary:
         out["sharded_rehearsal"] = sharded_secondary(args, rank, world, dev, stream, dist, torch)
     if world > 1 and not args.no_secondary:
@@ -444,10 +445,11 @@ def main():
         import threading
 
         def give_up():
-            log("rank %d: the sharded secondary did not finish in time; reporting the headline without it" % rank)
-            if rank == 0:
+            log("rank %d: the sharded secondary (or the final barrier) did not finish in time; reporting the headline without it" % rank)
+            if rank == 0 and not emitted[0]:
                 out["secondary"] = {"error": "sharded secondary timed out"}
                 out["cpu_baseline"] = None
+                emitted[0] = True
                 emit(out)
             os._exit(0)
 
@@ -458,18 +460,22 @@ def main():
             sec = sharded_secondary(args, rank, world, dev, stream, dist, torch)
         except Exception as exc:
             sec = {"error": repr(exc)}
-        dog.cancel()
+        # the watchdog stays armed through the final barrier: a rank that failed here must not leave its peers (stuck in a collective
+        # of the secondary) and itself (stuck in the barrier) waiting for each other; the result line is written once either way
         if rank == 0:
             out["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(mesh, J, rst, u)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
+    if rank == 0 and not emitted[0]:
+        emitted[0] = True
         emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if dog is not None:
+        dog.cancel()
 
 
 if __name__ == "__main__":
