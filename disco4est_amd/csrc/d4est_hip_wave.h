@@ -211,6 +211,84 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// software-pipelined plain row contractions (two rows in flight; see the stiffness kernels in d4est_hip_volume.hip)
+template <int NI, int NO, bool ACC, int LD = NO>
+__device__ __forceinline__ void contract_single(const double* __restrict__ op, const double* x, double* y);
+
+// yA (+)= sum_i rowA_i * xA[i], yB (+)= sum_i rowB_i * xB[i]; row_i = NO consecutive doubles at op + i*NO
+// (op = the operator TRANSPOSED for y = op x, or the operator itself for y = op^T x)
+template <int NI, int NO, bool ACCA, bool ACCB>
+__device__ __forceinline__ void contract_pair(const double* __restrict__ opA, const double* xA, double* yA,
+                                              const double* __restrict__ opB, const double* xB, double* yB) {
+  double ca[NO], cb[NO], na[NO], nb[NO];
+  {
+    sdouble_ptr ra = launder(opA), rb = launder(opB);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) { ca[o] = ra[o]; cb[o] = rb[o]; }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    if (i + 1 < NI) {
+      sdouble_ptr ra, rb;
+      launder2_after(opA + (i + 1) * NO, opB + (i + 1) * NO, ca[0], cb[0], ra, rb);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) { na[o] = ra[o]; nb[o] = rb[o]; }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      yA[o] = (i == 0 && !ACCA) ? ca[o] * xA[0] : fma(ca[o], xA[i], yA[o]);
+      yB[o] = (i == 0 && !ACCB) ? cb[o] * xB[0] : fma(cb[o], xB[i], yB[o]);
+    }
+    if (i + 1 < NI) {
+#pragma unroll
+      for (int o = 0; o < NO; ++o) { ca[o] = na[o]; cb[o] = nb[o]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the next step's wait/launder asm behind this step's FMAs
+  }
+}
+
+// y (+)= sum_i row_i * x[i], two rows per step
+template <int NI, int NO, bool ACC, int LD>
+__device__ __forceinline__ void contract_single(const double* __restrict__ op, const double* x, double* y) {
+  constexpr int STEPS = (NI + 1) / 2;
+  double c0[NO], c1[NO], n0[NO], n1[NO];
+  {
+    sdouble_ptr r0 = launder(op);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) c0[o] = r0[o];
+    if (NI > 1) {
+      sdouble_ptr r1 = launder(op + LD);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) c1[o] = r1[o];
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int i0 = 2 * st, i1 = 2 * st + 1;
+    if (i0 + 2 < NI) {
+      sdouble_ptr r0, r1;
+      launder2_after(op + (i0 + 2) * LD, op + ((i1 + 2 < NI) ? (i1 + 2) : (i0 + 2)) * LD, c0[0], (i1 < NI) ? c1[0] : c0[0], r0, r1);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) n0[o] = r0[o];
+      if (i1 + 2 < NI) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) n1[o] = r1[o];
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      y[o] = (i0 == 0 && !ACC) ? c0[o] * x[0] : fma(c0[o], x[i0], y[o]);
+      if (i1 < NI) y[o] = fma(c1[o], x[i1], y[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      if (i0 + 2 < NI) c0[o] = n0[o];
+      if (i1 + 2 < NI) c1[o] = n1[o];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // one element per NQ*NQ lanes of a wavefront: LDS image of the single-wavefront volume kernels
 template <int N, int NQ>
 struct WaveCfg {
@@ -445,6 +523,173 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
       eo_post<N>(o, y);
 #pragma unroll
       for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = y[i];
+    }
+  }
+  SYNC();
+}
+
+// ---------------------------------------------------------------------------
+// The same apply with PLAIN contractions (any N <= NQ, NQ * NQ <= 64; the odd degrees): stiffness_wave2_kernel's body.  On entry R0
+// holds u_e as [i + PN (j + N k)]; on exit R0 holds (A u)_e in the same layout.  Bop / Gop: B, G row-major (NQ x N); BopT / GopT: their
+// transposes.
+// ---------------------------------------------------------------------------
+template <int N, int NQ, bool WG_SYNC>
+__device__ __forceinline__ void stiffness_wave2_element(double* R0, double* R1, const double* __restrict__ metric, int qs, bool active,
+                                                        int a, int b, const double* __restrict__ Bop, const double* __restrict__ Gop,
+                                                        const double* __restrict__ BopT, const double* __restrict__ GopT) {
+  using C = WaveCfg<N, NQ>;
+  constexpr int PN = C::PN, PQ = C::PQ;
+  constexpr int NQ3 = NQ * NQ * NQ;
+  auto SYNC = [] {
+    if constexpr (WG_SYNC) __syncthreads();
+    else wave_lds_fence();
+  };
+
+  // ---- S1: thread (j=a, k=b)
+  {
+    double x[N], br[NQ], gr[NQ];
+    const bool on = active && a < N && b < N;
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+      contract_pair<N, NQ, false, false>(BopT, x, br, GopT, x, gr);
+    }
+    SYNC();
+    if (on) {
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        R0[a + PN * (iq + NQ * b)] = br[iq];
+        R1[a + PN * (iq + NQ * b)] = gr[iq];
+      }
+    }
+  }
+  SYNC();
+
+  // ---- S2 (thread (iq=a, k=b)) and S3 (thread (iq=a, jq=b))
+  double gr[NQ], gs[NQ], gt[NQ];
+  {
+    double x1[N], x2[N], t1[NQ], t2[NQ], t3[NQ];
+    const bool on2 = active && b < N;
+    if (on2) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        x1[j] = R0[j + PN * (a + NQ * b)];  // B_r u
+        x2[j] = R1[j + PN * (a + NQ * b)];  // G_r u
+      }
+      contract_pair<N, NQ, false, false>(BopT, x2, t1, GopT, x1, t2);  // B_s G_r u | G_s B_r u
+      contract_single<N, NQ, false>(BopT, x1, t3);                      // B_s B_r u
+    }
+    SYNC();
+    if (on2) {
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) {  // [jq][iq][k]
+        R0[b + PN * (a + NQ * jq)] = t1[jq];
+        R1[b + PN * (a + NQ * jq)] = t2[jq];
+      }
+    }
+    SYNC();
+    if (active) {
+      double y1[N], y2[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        y1[k] = R0[k + PN * (a + NQ * b)];
+        y2[k] = R1[k + PN * (a + NQ * b)];
+      }
+      contract_pair<N, NQ, false, false>(BopT, y1, gr, BopT, y2, gs);
+    }
+    SYNC();
+    if (on2) {
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t3[jq];
+    }
+    SYNC();
+    if (active) {
+      double y3[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) y3[k] = R0[k + PN * (a + NQ * b)];
+      contract_single<N, NQ, false>(GopT, y3, gt);
+    }
+  }
+
+  // ---- quadrature-point stage
+  if (active) {
+    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) {
+      const int q = NQ * NQ * kq;
+      const double m0 = m[q], m1 = m[NQ3 + q], m2 = m[2 * NQ3 + q], m3 = m[3 * NQ3 + q], m4 = m[4 * NQ3 + q], m5 = m[5 * NQ3 + q];
+      const double r = gr[kq], s = gs[kq], t = gt[kq];
+      gr[kq] = m0 * r + m1 * s + m2 * t;
+      gs[kq] = m1 * r + m3 * s + m4 * t;
+      gt[kq] = m2 * r + m4 * s + m5 * t;
+    }
+  }
+
+  // ---- S5 (registers) / S6 (thread (iq=a, k=b))
+  {
+    double ca[N], cb[N], cc[N], ar[N], bs[N];
+    const bool on6 = active && b < N;
+    if (active) {
+      contract_pair<NQ, N, false, false>(Bop, gr, ca, Bop, gs, cb);
+      contract_single<NQ, N, false>(Gop, gt, cc);
+    }
+    SYNC();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {  // [k][iq][jq]
+        R0[b + PQ * (a + NQ * k)] = ca[k];
+        R1[b + PQ * (a + NQ * k)] = cb[k];
+      }
+    }
+    SYNC();
+    if (on6) {
+      double x[NQ], y[NQ];
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) {
+        x[jq] = R0[jq + PQ * (a + NQ * b)];
+        y[jq] = R1[jq + PQ * (a + NQ * b)];
+      }
+      contract_pair<NQ, N, false, false>(Bop, x, ar, Gop, y, bs);
+    }
+    SYNC();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = cc[k];
+    }
+    SYNC();
+    if (on6) {
+      double z[NQ];
+#pragma unroll
+      for (int jq = 0; jq < NQ; ++jq) z[jq] = R0[jq + PQ * (a + NQ * b)];
+      contract_single<NQ, N, true>(Bop, z, bs);
+    }
+    SYNC();
+    if (on6) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {  // [k][j][iq]
+        R0[a + PQ * (j + N * b)] = ar[j];
+        R1[a + PQ * (j + N * b)] = bs[j];
+      }
+    }
+  }
+  SYNC();
+
+  // ---- S7: thread (j=a, k=b)
+  {
+    double x[NQ], y[NQ], o[N], o2[N];
+    const bool on = active && a < N && b < N;
+    if (on) {
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        x[iq] = R0[iq + PQ * (a + N * b)];
+        y[iq] = R1[iq + PQ * (a + N * b)];
+      }
+      contract_pair<NQ, N, false, false>(Gop, x, o, Bop, y, o2);
+    }
+    SYNC();
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = o[i] + o2[i];
     }
   }
   SYNC();

@@ -38,8 +38,7 @@ def gpu():
 
 
 # Modules whose GPU tests exercise the full operator through the smoothers, forests, shards or Schwarz: every test in them runs
-# once per face path -- the direct kernel on conforming uniform plans up to deg_quad = 7 with the volume term in it at deg = deg_quad
-# in {5, 7}, the direct kernel for the faces only, and the two-phase kernels (D4EST_HIP_FACE_DIRECT=2 / 1 / 0 make tuning key 11
+# once per face path -- the direct kernel on conforming uniform plans up to deg_quad = 7 with the volume term in it at deg_quad = deg, the direct kernel for the faces only, and the two-phase kernels (D4EST_HIP_FACE_DIRECT=2 / 1 / 0 make tuning key 11
 # default to that value for the plans the test creates; left alone, the library would pick the two-phase kernels on these small meshes).
 _BOTH_FACE_PATHS = {"test_forest_gpu", "test_solver_gpu", "test_schwarz_gpu", "test_parallel_gpu", "test_multigrid_gpu"}
 

@@ -19,10 +19,10 @@ def _face_path_values(plan):
 
 
 def _best_face_path(deg, inc):
-    """What tuning value 2 selects: the direct kernel where it is instantiated, with the volume term in it at deg = deg_quad in {5, 7}."""
+    """What tuning value 2 selects: the direct kernel where it is instantiated, with the volume term in it at deg_quad = deg."""
     if (deg + 1, deg + inc + 1) not in DIRECT_PAIRS:
         return "two-phase"
-    return "direct+volume" if inc == 0 and deg in (5, 7) else "direct"
+    return "direct+volume" if inc == 0 else "direct"
 
 
 def _t(a, dev):
@@ -328,7 +328,7 @@ def test_default_face_path_follows_the_size(gpu, hiplib, oracle):
             ref = oracle.apply_aij(m, J, rst, sides, u, nthreads=8)
             assert _rel(dAu.cpu().numpy(), ref) <= RTOL
         plan.destroy()
-    assert paths == {3: "two-phase", 4: "direct"}      # 512 and 4096 elements (p = 1: the volume term stays in its own kernel)
+    assert paths == {3: "two-phase", 4: "direct+volume"}      # 512 and 4096 elements
 
 
 @pytest.mark.parametrize("level,deg,inc", [(1, 3, 0), (1, 7, 0), (1, 4, 1), (1, 5, 0), (1, 9, 0)])
