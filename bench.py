@@ -373,16 +373,7 @@ def main():
             # the affine path: same brick, metric rebuilt from 6 numbers per element, 16 B/DoF
             if args.geometry != "sine":
                 plan.set_tuning(7, -1)
-                for _ in range(3):
-                    plan.apply_stiffness_matrix(du, dAu)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                for _ in range(30):
-                    plan.apply_stiffness_matrix(du, dAu)
-                e1.record(stream)
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / 30
+                ms = time_region(lambda: plan.apply_stiffness_matrix(du, dAu), 100, stream, torch, warm=20)
                 sec["stiffness_p%d_affine_path" % args.deg] = {"ms": ms, "GDoF_per_s": dofs_per_rank / (ms * 1e-3) / 1e9,
                                                                 "algorithmic_bytes_per_dof": 16.0, "kernel": plan.last_kernel()}
                 plan.set_tuning(7, 0)
