@@ -52,7 +52,7 @@ struct DirectHost {
   double* d_u2 = nullptr;    // second solution vector of the fused Chebyshev update (see cheby_iterate_body)
   const int* d_list = nullptr;   // optional list of the elements the kernel works on (not owned; direct_set_element_list)
   int n_list = 0;
-  int order_ok = -1;             // 1: the plan's single bucket lists the elements in order (cached by direct_fused_ok)
+  mutable int order_ok = -1;     // 1: the plan's single bucket lists the elements in order (cached by direct_fused_ok)
 };
 
 // y = M x, M (NO x NI): tab = M transposed (NI x NO row-major), or the even-odd table of M when EO (NI, NO even; ANTI: M is
@@ -612,7 +612,7 @@ bool direct_fused_ok(const d4est_hip_plan* plan) {
   if (dh->order_ok < 0) {   // (the bucket order is fixed at plan creation: looked at once, not at every apply)
     int ok = 1;
     for (int i = 0; i < plan->n_elements && ok; ++i) ok = (plan->elem_ids[i] == i);
-    const_cast<DirectHost*>(dh)->order_ok = ok;
+    dh->order_ok = ok;
   }
   if (!dh->order_ok) return no("bucket order");
   const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
