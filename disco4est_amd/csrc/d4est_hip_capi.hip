@@ -142,7 +142,7 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
     bk.d_GT = upload(Tables1D::transpose(G, bk.NQ, bk.N));
     bk.d_DT = upload(Tables1D::transpose(D, bk.N, bk.N));
     bk.d_w = upload(Tables1D::quad_weights(quad_type, bk.deg_quad));
-    if (bk.N % 2 == 0 && bk.NQ % 2 == 0) {
+    {   // even-odd tables: any parity of N, NQ (Tables1D::eo_table)
       bk.d_EBf = upload(Tables1D::eo_table(B, bk.NQ, bk.N, false));
       bk.d_EGf = upload(Tables1D::eo_table(G, bk.NQ, bk.N, true));
       bk.d_EBb = upload(Tables1D::eo_table(Tables1D::transpose(B, bk.NQ, bk.N), bk.N, bk.NQ, false));

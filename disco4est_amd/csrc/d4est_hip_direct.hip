@@ -62,7 +62,7 @@ struct DirectHost {
 template <int NI, int NO, bool EO, bool ANTI>
 __device__ __forceinline__ void prod(const double* __restrict__ tab, const double* x, double* y) {
   if constexpr (EO) {
-    constexpr int HC = NI / 2;
+    constexpr int HC = (NI + 1) / 2;
     double xe[HC], xo[HC], ab[NO];
     eo_pre<NI>(x, xe, xo);
     contract_rows_eo<HC, NO, false>(tab, ANTI ? xo : xe, ANTI ? xe : xo, ab);   // one scalar row per step: 32 SGPRs in flight (the two-row
@@ -78,7 +78,7 @@ template <int NI, int NO, bool EO>
 __device__ __forceinline__ void prod_pair(const double* __restrict__ tabS, const double* __restrict__ tabA, const double* x, double* yS,
                                           double* yA) {
   if constexpr (EO) {
-    constexpr int HC = NI / 2;
+    constexpr int HC = (NI + 1) / 2;
     double xe[HC], xo[HC], abS[NO], abA[NO];
     eo_pre<NI>(x, xe, xo);
     contract_rows_eo<HC, NO, false>(tabS, xe, xo, abS);
@@ -133,8 +133,8 @@ constexpr int kDirectWPB = 4;
 // per lane, in the layout of the volume kernel's coalesced store.
 struct DirectVol {
   const double* metric = nullptr;    // 6 combined metric entries per quadrature node, element-blocked (plan->d_metric)
-  const double* EBf = nullptr;       // even N: even-odd tables of the volume operators (Bucket::d_EBf ...); odd N (VOL = 3): the plain
-  const double* EGf = nullptr;       // tables B, G, B^T, G^T (Bucket::d_B, d_G, d_BT, d_GT) in the same four slots
+  const double* EBf = nullptr;       // even-odd tables of the volume operators (Bucket::d_EBf ...)
+  const double* EGf = nullptr;
   const double* EBb = nullptr;
   const double* EGb = nullptr;
   const double* affine = nullptr;    // AFF: 6 numbers per element
@@ -144,7 +144,7 @@ struct DirectVol {
                                      // subdomain plan, whose element copies alias the mesh's metric
 };
 
-template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 even-odd, streamed metric, 2 even-odd, affine metric, 3 plain (odd N) */>
+template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 streamed metric, 2 affine metric */>
 __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
                                                              double* __restrict__ Au, const DirectSide* __restrict__ sides,
                                                              const DirectGhostOff* __restrict__ ghost_off,
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
   dir_body(std::integral_constant<int, 1>{});
   dir_body(std::integral_constant<int, 2>{});
   if constexpr (VOL != 0) {
-    static_assert(VOL == 0 || (N == NQ && (VOL == 3 || N % 2 == 0)), "fused volume term: N = NQ; the even-odd forms need N even");
+    static_assert(VOL == 0 || N == NQ, "fused volume term: N = NQ");
     // ---- the volume term: u_e -> R0, the even-odd sum-factorised apply (stiffness_wave_eo_kernel's body), A u = volume + faces
     {
       constexpr int UT = (N3 + 63) / 64;
@@ -463,11 +463,8 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
     }
     wave_lds_fence();
     const int qs = __builtin_amdgcn_readfirstlane(vol.qs_stride >= 0 ? vol.qs0 + e * vol.qs_stride : vol.qs_list[e]);
-    if constexpr (VOL == 3)
-      stiffness_wave2_element<N, NQ, false>(s_U, s_S, vol.metric, qs, on_q, a, b, vol.EBf, vol.EGf, vol.EBb, vol.EGb);
-    else
-      stiffness_wave_eo_element<N, NQ, VOL == 2, false>(s_U, s_S, vol.metric, qs, e, on_q, a, b, vol.EBf, vol.EGf, vol.EBb, vol.EGb,
-                                                        vol.affine, vol.wq);
+    stiffness_wave_eo_element<N, NQ, VOL == 2, false>(s_U, s_S, vol.metric, qs, e, on_q, a, b, vol.EBf, vol.EGf, vol.EBb, vol.EGb,
+                                                      vol.affine, vol.wq);
     if (on_m) {
 #pragma unroll
       for (int i = 0; i < N; ++i) {
@@ -523,7 +520,7 @@ void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, c
   const int ne = plan->n_elements;
   DirectHost* dh = new DirectHost;
   dh->N = N; dh->NQ = NQ; dh->ns0 = ns0; dh->ns_stride = ns_stride;
-  dh->eo = (N % 2 == 0) && (NQ % 2 == 0);
+  dh->eo = true;   // the even-odd products take sizes of either parity
   std::vector<double> Cv(Cm, Cm + (size_t)NQ * N), CDv(CDm, CDm + (size_t)NQ * N), Ev(Em, Em + (size_t)N * NQ);
   std::vector<double> D = Tables1D::dij(N - 1);
   std::vector<double> DtE = Tables1D::matmul(Tables1D::transpose(D, N, N), Ev, N, N, NQ);   // (N x NQ)
@@ -604,7 +601,7 @@ bool direct_fused_ok(const d4est_hip_plan* plan) {
   if (!plan->has_geometry) return no("no geometry yet");
   if (plan->buckets.size() != 1) return no("more than one (deg, deg_quad) bucket");
   const Bucket& bk = plan->buckets[0];
-  if (bk.N != dh->N || bk.NQ != dh->NQ || (dh->N % 2 == 0 ? !bk.d_EBf : !(bk.d_B && bk.d_G && bk.d_BT && bk.d_GT))) return no("bucket tables");
+  if (bk.N != dh->N || bk.NQ != dh->NQ || !bk.d_EBf) return no("bucket tables");
   // (the nodal offsets are affine: the direct tables exist only on uniform plans; the bucket keeps affine strides only when the
   // quadrature offsets are affine too -- not so on a Schwarz subdomain plan, which reads them from the list)
   if (bk.ns_stride >= 0 && (bk.ns0 != dh->ns0 || bk.ns_stride != dh->ns_stride)) return no("nodal offsets");
@@ -616,7 +613,7 @@ bool direct_fused_ok(const d4est_hip_plan* plan) {
   }
   if (!dh->order_ok) return no("bucket order");
   const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
-  if (!(tw < 0 || tw == (dh->N % 2 == 0 ? 11 : 3))) return no("tuning key 1");   // the volume kernel whose body rides along must be the selected one
+  if (!(tw < 0 || tw == 11)) return no("tuning key 1");   // the volume kernel whose body rides along must be the selected one
   return true;
 }
 
@@ -638,29 +635,24 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
     if (!direct_fused_ok(plan)) D4EST_HIP_ABORT("direct face kernel: the fused volume term was requested on a plan that cannot take it");
     const Bucket& bk = plan->buckets[0];
     vol.metric = plan->d_metric;
-    if (dh->N % 2 == 0) { vol.EBf = bk.d_EBf; vol.EGf = bk.d_EGf; vol.EBb = bk.d_EBb; vol.EGb = bk.d_EGb; }
-    else { vol.EBf = bk.d_B; vol.EGf = bk.d_G; vol.EBb = bk.d_BT; vol.EGb = bk.d_GT; }   // stiffness_wave2_element(Bop, Gop, BopT, GopT)
+    vol.EBf = bk.d_EBf; vol.EGf = bk.d_EGf; vol.EBb = bk.d_EBb; vol.EGb = bk.d_EGb;
     vol.qs0 = bk.qs0; vol.qs_stride = bk.ns_stride >= 0 ? bk.qs_stride : -1; vol.qs_list = plan->d_qs_list + bk.elem_offset;
-    const bool aff = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine && dh->N % 2 == 0;
+    const bool aff = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine;
     if (aff) { vol.affine = plan->d_metric_affine; vol.wq = bk.d_w; }
-    vmode = (dh->N % 2 != 0) ? 3 : (aff ? 2 : 1);
-    std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::faces_direct_kernel<%d,%d,vol%s> (faces + %s body)", dh->N, dh->NQ, aff ? ",affine" : "",
-                  dh->N % 2 == 0 ? "stiffness_wave_eo" : "stiffness_wave2");
+    vmode = aff ? 2 : 1;
+    std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::faces_direct_kernel<%d,%d,vol%s> (faces + stiffness_wave_eo body)", dh->N, dh->NQ, aff ? ",affine" : "");
   }
   const DirectFuse cfv = cf ? *cf : DirectFuse{};
   bool done = false;
 #define D4EST_HIP_DIRECT_GO(N_, NQ_, FUSE_, VOL_)                                                                             \
-  hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, (N_ % 2 == 0) && (NQ_ % 2 == 0), FUSE_, VOL_>), dim3(n_wg), dim3(64 * kDirectWPB), 0,     \
+  hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, true, FUSE_, VOL_>), dim3(n_wg), dim3(64 * kDirectWPB), 0,     \
                      plan->stream, u, ghost_trace, Au, dh->d_sides, dh->d_ghost_off, dh->d_ops, plan->d_face_geom, plan->d_bndry,            \
                      robin_c, robin_r, n, dh->ns0, dh->ns_stride, chunk, cfv, vol, dh->d_list)
 #define X(N_, NQ_)                                                                 \
   if (!done && dh->N == N_ && dh->NQ == NQ_) {                                     \
-    if constexpr (N_ == NQ_ && N_ % 2 == 0) {                                      \
+    if constexpr (N_ == NQ_) {                                                     \
       if (vmode == 1) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 1); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 1); done = true; } \
       if (vmode == 2) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 2); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 2); done = true; } \
-    }                                                                              \
-    if constexpr (N_ == NQ_ && N_ % 2 != 0) {                                      \
-      if (vmode == 3) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 3); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 3); done = true; } \
     }                                                                              \
     if (!done) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 0); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 0); done = true; }        \
   }

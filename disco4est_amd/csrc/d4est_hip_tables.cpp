@@ -270,14 +270,28 @@ std::vector<double> Tables1D::quad_weights(int quad_type, int deg_quad) {
 }
 
 std::vector<double> Tables1D::eo_table(const std::vector<double>& M, int R, int C, bool antisymmetric) {
-  std::vector<double> T((size_t)(C / 2) * R);
-  for (int c = 0; c < C / 2; ++c)
-    for (int r = 0; r < R / 2; ++r) {
+  // (C + 1) / 2 rows of R doubles.  Row c < C / 2 serves the column pair (c, C - 1 - c): entries [0, (R + 1) / 2) multiply the FIRST
+  // combination of the pair (x_c + x_{C-1-c} for a symmetric M, x_c - x_{C-1-c} for an antisymmetric one) and give a_r (plus, for odd R,
+  // the middle output itself at index R / 2); entries [(R + 1) / 2, R) multiply the other combination and give b_r;
+  // y_r = a_r + b_r, y_{R-1-r} = a_r - b_r.  For odd C the last row serves the middle column (its input enters both parts as it is).
+  const int hc = C / 2, hr = R / 2, rows = (C + 1) / 2, split = (R + 1) / 2;
+  std::vector<double> T((size_t)rows * R, 0.0);
+  for (int c = 0; c < hc; ++c) {
+    for (int r = 0; r < hr; ++r) {
       const double me = 0.5 * (M[(size_t)r * C + c] + M[(size_t)r * C + (C - 1 - c)]);
       const double mo = 0.5 * (M[(size_t)r * C + c] - M[(size_t)r * C + (C - 1 - c)]);
       T[(size_t)c * R + r] = antisymmetric ? mo : me;
-      T[(size_t)c * R + R / 2 + r] = antisymmetric ? me : mo;
+      T[(size_t)c * R + split + r] = antisymmetric ? me : mo;
     }
+    if (R % 2) T[(size_t)c * R + hr] = M[(size_t)hr * C + c];   // middle output row: sum_c M[hr][c] (x_c +- x_{C-1-c})
+  }
+  if (C % 2) {
+    for (int r = 0; r < hr; ++r) {
+      if (antisymmetric) T[(size_t)hc * R + split + r] = M[(size_t)r * C + hc];
+      else T[(size_t)hc * R + r] = M[(size_t)r * C + hc];
+    }
+    if (R % 2 && !antisymmetric) T[(size_t)hc * R + hr] = M[(size_t)hr * C + hc];   // (zero for an antisymmetric M)
+  }
   return T;
 }
 

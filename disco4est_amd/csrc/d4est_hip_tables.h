@@ -41,8 +41,8 @@ struct Tables1D {
   static std::vector<double> transpose(const std::vector<double>& A, int rows, int cols);
   static std::vector<double> matmul(const std::vector<double>& A, const std::vector<double>& B, int m, int l, int n);
   static bool invert(std::vector<double>& A, int n);
-  // even-odd table of a centro-(anti)symmetric operator M (R x C, both even): C/2 rows of R doubles, see
-  // stiffness_wave_eo_kernel in d4est_hip_volume.hip
+  // even-odd table of a centro-(anti)symmetric operator M (R x C, any parities): (C + 1) / 2 rows of R doubles, see
+  // stiffness_wave_eo_kernel in d4est_hip_volume.hip and the comment in the definition
   static std::vector<double> eo_table(const std::vector<double>& M, int R, int C, bool antisymmetric);
 };
 

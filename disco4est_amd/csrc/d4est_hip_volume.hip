@@ -56,43 +56,46 @@ constexpr bool kEoPipelined = ((C > R ? C : R) >= 12) && ((C > R ? C : R) != 16)
 // spills 1000+ SGPRs at N >= 16.
 template <int C, int R, bool ANTI, bool ACC>
 __device__ __forceinline__ void apply_eo(const double* __restrict__ tab, const double* x, double* y) {
-  constexpr int HC = C / 2, HR = R / 2;
+  constexpr int HC = (C + 1) / 2, P1 = (R + 1) / 2, P2 = R / 2;   // table rows; outputs of the first / second input combination
   double xe[HC], xo[HC], ab[R];
   eo_pre<C>(x, xe, xo);
-  const double* xf = ANTI ? xo : xe;  // first half multiplies xe (symmetric) / xo (antisymmetric)
+  const double* xf = ANTI ? xo : xe;  // first part multiplies xe (symmetric) / xo (antisymmetric)
   const double* xs = ANTI ? xe : xo;
   if constexpr (kEoPipelined<C, R>) {
-    constexpr int CH0 = HR < 8 ? HR : 8, CH1 = (HR - 8 > 0) ? (HR - 8 < 8 ? HR - 8 : 8) : 0, CH2 = (HR - 16 > 0) ? HR - 16 : 0;
-    static_assert(HR <= 24, "apply_eo: row halves longer than 24 are not supported");
-    contract_single<HC, CH0, false, R>(tab, xf, ab);
-    if constexpr (CH1 > 0) contract_single<HC, CH1, false, R>(tab + 8, xf, ab + 8);
-    if constexpr (CH2 > 0) contract_single<HC, CH2, false, R>(tab + 16, xf, ab + 16);
-    contract_single<HC, CH0, false, R>(tab + HR, xs, ab + HR);
-    if constexpr (CH1 > 0) contract_single<HC, CH1, false, R>(tab + HR + 8, xs, ab + HR + 8);
-    if constexpr (CH2 > 0) contract_single<HC, CH2, false, R>(tab + HR + 16, xs, ab + HR + 16);
+    static_assert(P1 <= 24, "apply_eo: row parts longer than 24 are not supported");
+    constexpr int A0 = P1 < 8 ? P1 : 8, A1 = (P1 - 8 > 0) ? (P1 - 8 < 8 ? P1 - 8 : 8) : 0, A2 = (P1 - 16 > 0) ? P1 - 16 : 0;
+    constexpr int B0 = P2 < 8 ? P2 : 8, B1 = (P2 - 8 > 0) ? (P2 - 8 < 8 ? P2 - 8 : 8) : 0, B2 = (P2 - 16 > 0) ? P2 - 16 : 0;
+    contract_single<HC, A0, false, R>(tab, xf, ab);
+    if constexpr (A1 > 0) contract_single<HC, A1, false, R>(tab + 8, xf, ab + 8);
+    if constexpr (A2 > 0) contract_single<HC, A2, false, R>(tab + 16, xf, ab + 16);
+    if constexpr (B0 > 0) contract_single<HC, B0, false, R>(tab + P1, xs, ab + P1);
+    if constexpr (B1 > 0) contract_single<HC, B1, false, R>(tab + P1 + 8, xs, ab + P1 + 8);
+    if constexpr (B2 > 0) contract_single<HC, B2, false, R>(tab + P1 + 16, xs, ab + P1 + 16);
   } else {
     // free scheduling: the compiler hoists the row loads (deep memory-level parallelism, at the price of SGPR spills)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const double* xx = half == 0 ? xf : xs;
+      const int len = half == 0 ? P1 : P2;
 #pragma unroll
-      for (int o0 = 0; o0 < HR; o0 += 8) {
+      for (int o0 = 0; o0 < len; o0 += 8) {
 #pragma unroll
         for (int c = 0; c < HC; ++c) {
-          sdouble_ptr row = launder(tab + c * R + half * HR + o0);
+          sdouble_ptr row = launder(tab + c * R + half * P1 + o0);
 #pragma unroll
           for (int o = 0; o < 8; ++o)
-            if (o0 + o < HR) ab[half * HR + o0 + o] = (c == 0) ? row[o] * xx[0] : fma(row[o], xx[c], ab[half * HR + o0 + o]);
+            if (o0 + o < len) ab[half * P1 + o0 + o] = (c == 0) ? row[o] * xx[0] : fma(row[o], xx[c], ab[half * P1 + o0 + o]);
         }
       }
     }
   }
 #pragma unroll
-  for (int r = 0; r < HR; ++r) {
-    const double p = ab[r] + ab[HR + r], m = ab[r] - ab[HR + r];
+  for (int r = 0; r < R / 2; ++r) {
+    const double p = ab[r] + ab[P1 + r], m = ab[r] - ab[P1 + r];
     y[r] = ACC ? y[r] + p : p;
     y[R - 1 - r] = ACC ? y[R - 1 - r] + m : m;
   }
+  if constexpr (R % 2 != 0) y[R / 2] = ACC ? y[R / 2] + ab[R / 2] : ab[R / 2];
 }
 // y = op x (operator given transposed, or as EO table when EO); y (+)= op^T x (operator itself, or EO table of op^T)
 template <int NI, int NO, bool EO, bool ANTI>
@@ -1480,18 +1483,16 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
     (void)cus_;
     const int stagger = ts < 0 ? 0 : ts;
     const int tw_ = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
-    const bool use_affine = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && N % 2 == 0 && NQ % 2 == 0 && bk.d_EBf && (tw_ == 11 || tw_ < 0);
+    const bool use_affine = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && bk.d_EBf && (tw_ == 11 || tw_ < 0);
     if (use_affine) {
       std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_eo_kernel<%d,%d,affine>", N, NQ);
-      if constexpr (N % 2 == 0 && NQ % 2 == 0)
-        hipLaunchKernelGGL((stiffness_wave_eo_kernel<N, NQ, true>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
+      hipLaunchKernelGGL((stiffness_wave_eo_kernel<N, NQ, true>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
                            plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBf, bk.d_EGf,
                            bk.d_EBb, bk.d_EGb, bk.ns0, bk.ns_stride, bk.qs0, bk.qs_stride,
                            plan->d_metric_affine + (size_t)6 * bk.elem_offset, bk.d_w);
-    } else if ((tw_ == 11 || tw_ < 0) && N % 2 == 0 && NQ % 2 == 0 && bk.d_EBf) {
+    } else if ((tw_ == 11 || tw_ < 0) && bk.d_EBf) {
       std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_eo_kernel<%d,%d>", N, NQ);
-      if constexpr (N % 2 == 0 && NQ % 2 == 0)
-        hipLaunchKernelGGL((stiffness_wave_eo_kernel<N, NQ>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
+      hipLaunchKernelGGL((stiffness_wave_eo_kernel<N, NQ>), dim3(grid), dim3(64), W::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
                            plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBf, bk.d_EGf,
                            bk.d_EBb, bk.d_EGb, bk.ns0, bk.ns_stride, bk.qs0, bk.qs_stride);
     } else if (tw_ == 3 || tw_ < 0) {
@@ -1543,7 +1544,7 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
     // the two-buffer wave kernel wins; for larger buckets the 3-buffer kernel with the metric requested
     // at entry streams HBM best.  profiles/r01_*_ab.txt
     const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE], tp = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_PREFETCH];
-    const bool affine_ok = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && bk.N % 2 == 0 && bk.NQ % 2 == 0;
+    const bool affine_ok = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0;
     const bool use_wave = (tw < 0) ? (bk.n_elem <= 8192 || affine_ok) : (tw != 0);
     const bool use_pf = (tp < 0) ? !use_wave : (tp != 0);
 #define X(N_, NQ_)                                                                                              \
@@ -1552,7 +1553,7 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
     if (C::LDS_BYTES <= 160 * 1024) {                                                                           \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                       \
       constexpr bool kWave = (NQ_ * NQ_ <= 64);                                                                 \
-      constexpr bool kEven = (N_ % 2 == 0) && (NQ_ % 2 == 0);                                                   \
+      constexpr bool kEven = true;   /* the even-odd contractions take sizes of either parity */                                                   \
       const bool use_eo = kEven && bk.d_EBf && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0;                  \
       if (kWave && use_wave) {                                               \
         launch_stiffness_wave<N_, (kWave ? NQ_ : N_)>(plan, bk, use_pf, u, Au);                                 \
@@ -1600,7 +1601,7 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   if (!done && bk.N == N_ && bk.NQ == NQ_ && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] != 0) {                \
     using W = WaveCfg<N_, NQ_>;                                                                                 \
     static_assert(W::LDS_BYTES <= 160 * 1024, "two-field kernel does not fit the LDS");                         \
-    constexpr bool kEven = (N_ % 2 == 0) && (NQ_ % 2 == 0);                                                     \
+    constexpr bool kEven = true;   /* the even-odd contractions take sizes of either parity */                                                     \
     const bool use_eo = kEven && bk.d_EBf && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0;                    \
     std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,false,%s> (%d threads)", N_, NQ_, use_eo ? "eo" : "plain", W::THREADS); \
     if (use_eo) {                                                                                               \
@@ -1644,7 +1645,7 @@ static void launch_mass_like_mode(d4est_hip_plan* plan, const double* in, double
     using C = WaveCfg<N_, NQ_>;                                                                                       \
     if (C::LDS_BYTES <= 160 * 1024) {                                                                                 \
       const int grid = (bk.n_elem + C::EPB - 1) / C::EPB;                                                             \
-      constexpr bool kEven = (N_ % 2 == 0) && (NQ_ % 2 == 0);                                                         \
+      constexpr bool kEven = true;   /* the even-odd contractions take sizes of either parity */                                                         \
       if (kEven && which == 0 && bk.d_EBf && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0) {                        \
         set_lds_limit(mass_like_kernel<N_, NQ_, MODE, kEven>, C::LDS_BYTES);                                          \
         hipLaunchKernelGGL((mass_like_kernel<N_, NQ_, MODE, kEven>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, \

@@ -55,6 +55,8 @@ __device__ __forceinline__ void contract_t(const double* __restrict__ op, const 
 }
 
 // ---- even-odd form of the contractions (see stiffness_wave_eo_kernel in d4est_hip_volume.hip for the derivation and table layout)
+// Sizes of either parity: xe / xo have (C + 1) / 2 entries, for odd C the last one of both is the middle input; the accumulated
+// (a | b) row splits at (R + 1) / 2, for odd R its entry R / 2 is the middle output (Tables1D::eo_table).
 template <int C>
 __device__ __forceinline__ void eo_pre(const double* x, double* xe, double* xo) {
 #pragma unroll
@@ -62,14 +64,20 @@ __device__ __forceinline__ void eo_pre(const double* x, double* xe, double* xo) 
     xe[c] = x[c] + x[C - 1 - c];
     xo[c] = x[c] - x[C - 1 - c];
   }
+  if constexpr (C % 2 != 0) {
+    xe[C / 2] = x[C / 2];
+    xo[C / 2] = x[C / 2];
+  }
 }
 template <int R>
 __device__ __forceinline__ void eo_post(const double* ab, double* y) {
+  constexpr int SP = (R + 1) / 2;
 #pragma unroll
   for (int r = 0; r < R / 2; ++r) {
-    y[r] = ab[r] + ab[R / 2 + r];
-    y[R - 1 - r] = ab[r] - ab[R / 2 + r];
+    y[r] = ab[r] + ab[SP + r];
+    y[R - 1 - r] = ab[r] - ab[SP + r];
   }
+  if constexpr (R % 2 != 0) y[R / 2] = ab[R / 2];
 }
 
 __device__ __forceinline__ void sgpr_touch(double v) { asm volatile("" ::"s"(v)); }
@@ -87,7 +95,7 @@ __device__ __forceinline__ void launder2_after(const double* pa, const double* p
 template <int HC, int R, bool ACCA, bool ACCB>
 __device__ __forceinline__ void contract_pair_eo(const double* __restrict__ opA, const double* xfA, const double* xsA, double* yA,
                                                  const double* __restrict__ opB, const double* xfB, const double* xsB, double* yB) {
-  constexpr int HR = R / 2;
+  constexpr int HR = (R + 1) / 2;   // outputs [0, HR) take the first input combination, [HR, R) the second
   double ca[R], cb[R], na[R], nb[R];
   {
     sdouble_ptr ra = launder(opA), rb = launder(opB);
@@ -119,7 +127,7 @@ __device__ __forceinline__ void contract_pair_eo(const double* __restrict__ opA,
 // one operator, two EO rows per step
 template <int HC, int R, bool ACC>
 __device__ __forceinline__ void contract_single_eo(const double* __restrict__ op, const double* xf, const double* xs, double* y) {
-  constexpr int HR = R / 2;
+  constexpr int HR = (R + 1) / 2;   // outputs [0, HR) take the first input combination, [HR, R) the second
   constexpr int STEPS = (HC + 1) / 2;
   double c0[R], c1[R], n0[R], n1[R];
   {
@@ -167,7 +175,7 @@ __device__ __forceinline__ void contract_single_eo(const double* __restrict__ op
 // contract_single_eo), for kernels that are short of SGPRs
 template <int HC, int R, bool ACC>
 __device__ __forceinline__ void contract_rows_eo(const double* __restrict__ op, const double* xf, const double* xs, double* y) {
-  constexpr int HR = R / 2;
+  constexpr int HR = (R + 1) / 2;   // outputs [0, HR) take the first input combination, [HR, R) the second
   double c0[R], n0[R];
   {
     sdouble_ptr r0 = launder(op);
@@ -317,7 +325,7 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
   using C = WaveCfg<N, NQ>;
   constexpr int PN = C::PN, PQ = C::PQ;
   constexpr int NQ3 = NQ * NQ * NQ;
-  constexpr int HN = N / 2, HQ = NQ / 2;
+  constexpr int HN = (N + 1) / 2, HQ = (NQ + 1) / 2;   // rows of the even-odd tables = entries of xe / xo
   auto SYNC = [] {
     if constexpr (WG_SYNC) __syncthreads();
     else wave_lds_fence();
