@@ -46,6 +46,7 @@ struct VolCfg {
 // tab = EO table of the operator, C/2 rows of R doubles, row = [first half | second half]
 // which EO contraction form a (C, R) pair uses: measured on MI355X with tools/sweep_p.py (GDoF/s pipelined | hoisted):
 // p=5 75.6|76.8, 7 81.5|83.1, 9 62.8|63.6, 11 51.1|48.7, 13 44.1|40.9, 15 39.9|46.8, 17 34.1|26.9, 19 38.7|18.5
+// (odd sizes, round 2: threshold 9 / 12 / 14 -> p = 10: 51.9 / 50.5 / 50.7, p = 12: 53.1 / 52.0 / 48.5 GDoF/s: 12 stays)
 template <int C, int R>
 constexpr bool kEoPipelined = ((C > R ? C : R) >= 12) && ((C > R ? C : R) != 16);
 
