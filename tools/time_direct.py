@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from disco4est_amd import Plan, mesh as M
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 deg = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+affine = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 0: general path (the metric is streamed, as the headline does); -1: affine buckets detected
 m = M.BrickMesh(level, deg)
 J, rst = m.geometry(None); sides = m.build_sides(None); u = m.field()
 dev = torch.device("cuda:0")
@@ -19,7 +20,7 @@ def t(fn, reps=30):
 out = {}
 for direct in (0, 1, 2):
     plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=torch.cuda.current_stream())
-    plan.set_geometry(J, rst); plan.set_tuning(7, 0); plan.set_tuning(11, direct); plan.set_faces(sides)
+    plan.set_geometry(J, rst); plan.set_tuning(7, affine); plan.set_tuning(11, direct); plan.set_faces(sides)
     du = torch.from_numpy(u).to(dev); Au = torch.empty_like(du)
     torch.manual_seed(5); rhs = torch.rand_like(du); r = torch.empty_like(du)
     plan.apply_aij(du, Au); torch.cuda.synchronize()
