@@ -352,3 +352,48 @@ def test_apply_aij_lobatto_quadrature(gpu, hiplib, oracle, level, deg, inc):
         plan.apply_aij(du, dAu)
         assert _rel(dAu.cpu().numpy(), ref) <= RTOL, (direct, plan.face_path())
     plan.destroy()
+
+
+def test_face_paths_agree_randomized(gpu, hiplib):
+    """Every face path of a plan gives the same operator (1e-13) and the same Chebyshev iterate (1e-12) on randomly drawn cases:
+    degree, over-integration, quadrature type, map amplitude, penalty function and prefactor, Dirichlet data -- level 2 (64 elements),
+    no oracle in the loop (the paths are held to it one by one above)."""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    rng = np.random.RandomState(20240607)
+    pairs = sorted(DIRECT_PAIRS)
+    for case in range(14):
+        n, nq = pairs[rng.randint(len(pairs))]
+        deg, inc = n - 1, nq - n
+        qt = int(rng.randint(0, 2))
+        m = M.BrickMesh(2, deg, deg_quad_inc=inc, quad_type=qt)
+        mp = M.SineMap(float(rng.uniform(0.0, 0.06)))
+        J, rst = m.geometry(mp)
+        sides = m.build_sides(mp)
+        fcn, pre = int(rng.randint(0, 4)), float(rng.uniform(2.0, 20.0))
+        plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, qt)
+        plan.set_geometry(J, rst)
+        plan.set_faces(sides, pre, fcn)
+        bx = sides["bndry_xyz"]
+        plan.set_dirichlet_values(np.cos(bx[0] + 2 * bx[1]) * bx[2] if rng.randint(0, 2) else None)
+        u = _t(M.splitmix64_uniform(100 + case, m.local_nodes) - 0.5, gpu)
+        rhs = _t(M.splitmix64_uniform(200 + case, m.local_nodes) - 0.5, gpu)
+        res = {}
+        for key11 in _face_path_values(plan):
+            plan.set_tuning(11, key11)
+            Au = torch.full_like(u, float("nan"))
+            plan.apply_aij(u, Au)
+            uc, r = u.clone(), torch.empty_like(u)
+            lam = float(torch.linalg.norm(Au) / torch.linalg.norm(u)) * 4.0
+            if key11 != _face_path_values(plan)[0]:
+                lam = res["lam"]
+            res["lam"] = lam
+            plan.cheby_iterate(uc, rhs, torch.empty_like(u), r, 3 + case % 3, lam / 30.0, lam, case % 2)
+            res[key11] = (Au.cpu().numpy(), uc.cpu().numpy(), r.cpu().numpy())
+        keys = [k for k in res if k != "lam"]
+        assert len(keys) >= 2, (n, nq)
+        ref = res[keys[-1]]          # the two-phase kernels
+        for k in keys[:-1]:
+            assert _rel(res[k][0], ref[0]) <= 1e-13, (case, n, nq, qt, fcn, k)
+            assert _rel(res[k][1], ref[1]) <= 1e-12 and _rel(res[k][2], ref[2]) <= 1e-11, (case, n, nq, k)
+        plan.destroy()
