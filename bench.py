@@ -401,6 +401,13 @@ def main():
                 bytes_ = algorithmic_bytes_per_dof(deg + 1, deg + 1) * m2.local_nodes
                 sec[name] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes, "kernel": p2.last_kernel(),
                              "roofline_frac_hbm": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if deg == 11:
+                    # the same config on the AFFINE path (labelled separately, SURVEY.md section 8d: the brick's metric is constant per
+                    # element and is rebuilt from 6 numbers instead of being streamed: 16 B/DoF, arithmetic-bound)
+                    p2.set_tuning(7, -1)
+                    ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 10, stream, torch)
+                    sec[name + "_affine_path"] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes,
+                                                  "kernel": p2.last_kernel(), "algorithmic_bytes_per_dof": 16.0}
                 p2.destroy()
                 del x2, y2
             # additive Schwarz smoother on the same mesh: one d4est_solver_schwarz_iterate with

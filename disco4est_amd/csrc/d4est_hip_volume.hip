@@ -302,11 +302,14 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 // in a single resident round.
 // ---------------------------------------------------------------------------
 
-template <int N, int NQ, bool PF, bool EO = false>
+template <int N, int NQ, bool PF, bool EO = false, bool AFF = false>
 __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS == 64 ? (PF ? 3 : 4) : 1)) void stiffness_wave_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
-    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT, int stagger) {
+    const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT, int stagger,
+    const double* __restrict__ affine = nullptr, const double* __restrict__ wq = nullptr) {
+  // AFF: affine bucket -- the metric of node (a, b, kq) is rebuilt as (w_a w_b w_kq) * c[0..5] from the element's six
+  // constants (affine + 6 * element) instead of being streamed (16 B/DoF instead of 64: SURVEY.md section 8d "affine path")
   // Phase stagger for single-round grids: when every resident wave starts at once, all waves load u, then all
   // contract, then all stream the metric ... and the memory pipe idles during the arithmetic phases.  Delaying every
   // other resident "row" of workgroups (block id bit 8 = the second batch the dispatcher places on each CU) by about
@@ -424,7 +427,21 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
   }
 
   // ---- quadrature-point stage
-  if (active) {
+  if constexpr (AFF) {
+    if (active) {
+    const double* __restrict__ c = affine + (size_t)6 * ei;
+    const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+    const double wab = wq[b] * wq[a];
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) {
+      const double w3 = wq[kq] * wab;
+      const double r = w3 * gr[kq], s_ = w3 * gs[kq], t = w3 * gt[kq];
+      gr[kq] = c0 * r + c1 * s_ + c2 * t;
+      gs[kq] = c1 * r + c3 * s_ + c4 * t;
+      gt[kq] = c2 * r + c4 * s_ + c5 * t;
+    }
+    }
+  } else if (active) {
     const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq) {
@@ -1546,6 +1563,8 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
     // at entry streams HBM best.  profiles/r01_*_ab.txt
     const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE], tp = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_PREFETCH];
     const bool affine_ok = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0;
+    // multi-wave kernels (p >= 8): the affine bucket's six constants per element, or nullptr = stream the metric
+#define D4EST_AFF_ARGS (affine_ok && plan->d_metric_affine ? plan->d_metric_affine + (size_t)6 * bk.elem_offset : (const double*)nullptr), bk.d_w
     const bool use_wave = (tw < 0) ? (bk.n_elem <= 8192 || affine_ok) : (tw != 0);
     const bool use_pf = (tp < 0) ? !use_wave : (tp != 0);
 #define X(N_, NQ_)                                                                                              \
@@ -1563,12 +1582,19 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
       } else if (!kWave && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] != 0) {                                  \
         /* p >= 8: multi-wave workgroup, two LDS fields (sequential field hand-off) -> 1.5x the residency */  \
         using W = WaveCfg<N_, NQ_>;                                                                             \
-        std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,false,%s> (%d threads)", N_, NQ_, use_eo ? "eo" : "plain", W::THREADS); \
+        std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,false,%s%s> (%d threads)", N_, NQ_, use_eo ? "eo" : "plain", (use_eo && affine_ok && plan->d_metric_affine) ? ",affine" : "", W::THREADS); \
         if (use_eo) {                                                                                           \
+          if (affine_ok && plan->d_metric_affine) {                                                             \
+            set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven, true>, W::LDS_BYTES);                    \
+            hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven, true>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
+                               plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,           \
+                               plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, 0, D4EST_AFF_ARGS); \
+          } else {                                                                                              \
           set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven>, W::LDS_BYTES);                            \
           hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
                              plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
                              plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, 0); \
+          }                                                                                                     \
         } else {                                                                                                \
           set_lds_limit(stiffness_wave_kernel<N_, NQ_, false>, W::LDS_BYTES);                                   \
           hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
@@ -1604,12 +1630,19 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
     static_assert(W::LDS_BYTES <= 160 * 1024, "two-field kernel does not fit the LDS");                         \
     constexpr bool kEven = true;   /* the even-odd contractions take sizes of either parity */                                                     \
     const bool use_eo = kEven && bk.d_EBf && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0;                    \
-    std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,false,%s> (%d threads)", N_, NQ_, use_eo ? "eo" : "plain", W::THREADS); \
+    std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_kernel<%d,%d,false,%s%s> (%d threads)", N_, NQ_, use_eo ? "eo" : "plain", (use_eo && affine_ok && plan->d_metric_affine) ? ",affine" : "", W::THREADS); \
     if (use_eo) {                                                                                               \
+      if (affine_ok && plan->d_metric_affine) {                                                                 \
+        set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven, true>, W::LDS_BYTES);                        \
+        hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven, true>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
+                           plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,               \
+                           plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, 0, D4EST_AFF_ARGS); \
+      } else {                                                                                                  \
       set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven>, W::LDS_BYTES);                                \
       hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
                          plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,                 \
                          plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, 0); \
+      }                                                                                                         \
     } else {                                                                                                    \
       set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, false>, W::LDS_BYTES);                                \
       hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, false>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
@@ -1620,6 +1653,7 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   }
     D4EST_HIP_BIG_PAIRS(X)
 #undef X
+#undef D4EST_AFF_ARGS
     if (!done) {
       std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::generic_volume_kernel (N=%d,NQ=%d)", bk.N, bk.NQ);
       launch_generic(plan, bk, 3, u, Au);
