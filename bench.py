@@ -389,6 +389,11 @@ def main():
                 ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 40, stream, torch, warm=20)
                 sec["stiffness_p%d" % deg] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes,
                                               "kernel": p2.last_kernel()}
+                if deg == 15:   # config 5's degree on the affine path (labelled separately: the brick's metric from 6 numbers per element)
+                    p2.set_tuning(7, -1)
+                    ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 40, stream, torch, warm=20)
+                    sec["stiffness_p15_affine_path"] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes,
+                                                        "kernel": p2.last_kernel(), "algorithmic_bytes_per_dof": 16.0}
                 p2.destroy()
                 del x2, y2
             # off-cache points (the config-2 working set, 134 MB, sits in the 256 MB Infinity Cache): level 5 at p = 7 (1.07 GB per

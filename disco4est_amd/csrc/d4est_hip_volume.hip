@@ -911,11 +911,14 @@ struct Mfma16Cfg {
   static constexpr size_t LDS_BYTES = (size_t)3 * FS * sizeof(double);
 };
 
-template <int N>
+// AFF: affine bucket -- the metric of node (i, j, k) is (w_i w_j w_k) * c[0..5] with the element's six constants (affine + 6 * element)
+template <int N, bool AFF = false>
 __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* __restrict__ u, double* __restrict__ Au,
                                                                    const double* __restrict__ metric, const int* __restrict__ ns_list,
                                                                    const int* __restrict__ qs_list, int n_bucket,
-                                                                   const double* __restrict__ Bop, const double* __restrict__ Gop) {
+                                                                   const double* __restrict__ Bop, const double* __restrict__ Gop,
+                                                                   const double* __restrict__ affine = nullptr,
+                                                                   const double* __restrict__ wq = nullptr) {
   constexpr int JS = Mfma16Cfg::JS, KS = Mfma16Cfg::KS, FS = Mfma16Cfg::FS;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
@@ -943,14 +946,28 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
   }
   for (; e < n_bucket; e += gridDim.x) {
     const int ns = ns_list[e];
-    const double* me = metric + (size_t)6 * qs_list[e];
+    const double* me = metric + (size_t)6 * (AFF ? 0 : qs_list[e]);
     // metric of the wave's first column tile (j' = 2 wave): requested now, used after the forward slab stage
     double mt[6][4];
+    auto tile_metric = [&](int ct, double (*dst)[4]) {
+      if constexpr (AFF) {
+        const double* __restrict__ cc = affine + (size_t)6 * e;
+        const double wcj = (c < N && ct < N) ? wq[c] * wq[ct] : 0.0;
 #pragma unroll
-    for (int m = 0; m < 6; ++m)
+        for (int v = 0; v < 4; ++v) {
+          const double w3 = (4 * v + q < N) ? wcj * wq[4 * v + q] : 0.0;
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        mt[m][v] = (c < N && 2 * wave < N && 4 * v + q < N) ? me[m * (N * N * N) + c + N * (2 * wave) + N * N * (4 * v + q)] : 0.0;
+          for (int m = 0; m < 6; ++m) dst[m][v] = w3 * cc[m];
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            dst[m][v] = (c < N && ct < N && 4 * v + q < N) ? me[m * (N * N * N) + c + N * ct + N * N * (4 * v + q)] : 0.0;
+      }
+    };
+    tile_metric(2 * wave, mt);
     // ---- forward slab stage: two slabs, interleaved chains
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -992,11 +1009,7 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
     __syncthreads();
     // ---- t stage on the wave's two column tiles (j' = 2 wave, 2 wave + 1): forward, metric, backward, W in place of Z
     double mt2[6][4];   // the second tile's metric: requested before the first tile's products
-#pragma unroll
-    for (int m = 0; m < 6; ++m)
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        mt2[m][v] = (c < N && 2 * wave + 1 < N && 4 * v + q < N) ? me[m * (N * N * N) + c + N * (2 * wave + 1) + N * N * (4 * v + q)] : 0.0;
+    tile_metric(2 * wave + 1, mt2);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int ct = 2 * wave + h;
@@ -1539,15 +1552,19 @@ static void launch_stiffness_wave(d4est_hip_plan* plan, const Bucket& bk, bool u
 }
 
 static void launch_stiffness_mfma16(d4est_hip_plan* plan, const Bucket& bk, const double* u, double* Au) {
-  std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_mfma16_kernel<%d> (512 threads, v_mfma_f64_16x16x4)", bk.N);
+  const bool aff = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine && bk.N == 16;
+  std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_mfma16_kernel<%d%s> (512 threads, v_mfma_f64_16x16x4)", bk.N,
+                aff ? ",affine" : "");
   const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
   const int grid = bk.n_elem < cus ? bk.n_elem : cus;   // one 102 KB workgroup per CU, persistent over the bucket
   auto go = [&](auto kern) {
     set_lds_limit(kern, Mfma16Cfg::LDS_BYTES);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Mfma16Cfg::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
-                       plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G);
+                       plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G,
+                       aff ? plan->d_metric_affine + (size_t)6 * bk.elem_offset : (const double*)nullptr, bk.d_w);
   };
-  if (bk.N == 16) go(stiffness_mfma16_kernel<16>);
+  if (aff) go(stiffness_mfma16_kernel<16, true>);
+  else if (bk.N == 16) go(stiffness_mfma16_kernel<16>);
   else if (bk.N == 15) go(stiffness_mfma16_kernel<15>);
   else if (bk.N == 14) go(stiffness_mfma16_kernel<14>);
   else go(stiffness_mfma16_kernel<13>);

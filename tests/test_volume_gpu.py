@@ -270,7 +270,7 @@ def test_weighted_inverse_mass_mij_parity(gpu, hiplib, oracle, level, deg, inc, 
 
 
 @pytest.mark.parametrize("level,deg,inc", [(1, 1, 0), (1, 3, 0), (2, 3, 2), (1, 5, 0), (1, 7, 0), (2, 7, 0), (1, 4, 0), (1, 6, 0),
-                                           (1, 8, 0), (1, 9, 0), (1, 11, 0), (1, 12, 0), (0, 16, 0)])
+                                           (1, 8, 0), (1, 9, 0), (1, 11, 0), (1, 12, 0), (0, 16, 0), (1, 15, 0)])
 def test_affine_path_parity(gpu, hiplib, oracle, level, deg, inc):
     """Affine bricks: the engine rebuilds the metric from 6 numbers per element (tuning key 7 auto); same results as the
     general path and as the oracle.  A curved mesh must NOT be detected as affine; a mesh with ONE curved element neither."""
