@@ -376,6 +376,13 @@ def main():
                 ms = time_region(lambda: plan.apply_stiffness_matrix(du, dAu), 100, stream, torch, warm=20)
                 sec["stiffness_p%d_affine_path" % args.deg] = {"ms": ms, "GDoF_per_s": dofs_per_rank / (ms * 1e-3) / 1e9,
                                                                 "algorithmic_bytes_per_dof": 16.0, "kernel": plan.last_kernel()}
+                # ... and the full operator / the smoother iteration with the affine volume metric (the face factors are still streamed):
+                # what a brick gets when tuning key 7 is left alone; labelled separately like the entry above
+                for name, fn, applies in (("apply_aij_affine_path", lambda: plan.apply_aij(du, dAu), 1),
+                                          ("cheby_5_iterations_affine_path", lambda: plan.cheby_iterate(du, rhs, dAu, r, 5, 1.0, 30.0, 0), 5)):
+                    ms = time_region(fn, 50, stream, torch, warm=10)
+                    sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9, "face_path": plan.face_path(),
+                                 "algorithmic_bytes_per_dof": 16.0 + 6.0 * 7.0 * 8.0 * NQ * NQ / N ** 3}
                 plan.set_tuning(7, 0)
             # stiffness apply at the other degrees SURVEY.md section 8d names (same general path, ~2-8 MDoF each)
             for deg, level, count in ((3, 5, None), (11, 4, None), (15, 4, 2048)):
