@@ -144,6 +144,26 @@ struct DirectVol {
                                      // subdomain plan, whose element copies alias the mesh's metric
 };
 
+#ifndef D4EST_HIP_DIRECT_GEOM_EARLY
+#define D4EST_HIP_DIRECT_GEOM_EARLY 1   /* both faces' geometric factors requested: 0 at their use, 1 before the SIPG loop, 2 with the neighbour lines */
+#endif
+// the seven geometric-factor fields of a side at mortar node k (sj n_l / 2-weighted rows 0..5, penalty row 6), or the Robin coefficient
+template <int T>
+__device__ __forceinline__ void direct_load_geom(double* gq, int kind, bool on, int k, int sgeom, const double* __restrict__ geom,
+                                                 const double* __restrict__ robin_c) {
+#pragma unroll
+  for (int c = 0; c < 7; ++c) gq[c] = 0.0;
+  if (on) {
+    if (kind == 0 && robin_c) {
+      gq[6] = robin_c[sgeom + k];   // am = ap = 0: no term 1 / term 2 on a Robin side
+    } else {
+      const double* __restrict__ g = geom + (size_t)7 * sgeom + k;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) gq[c] = g[c * T];
+    }
+  }
+}
+
 template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 streamed metric, 2 affine metric */>
 __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
                                                              double* __restrict__ Au, const DirectSide* __restrict__ sides,
@@ -232,30 +252,33 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
     const int sgeom[2] = {sd[2 * d].geom, sd[2 * d + 1].geom};
     // ---- nodal fields of the two faces: c = 0..3 trace (own 2d, own 2d+1, nbr 2d, nbr 2d+1), c = 4..7 normal derivative
     double fld[8] = {own_tr[2 * d], own_tr[2 * d + 1], 0.0, 0.0, own_nd[2 * d], own_nd[2 * d + 1], 0.0, 0.0};
+    // the normal lines of the two (+) elements' faces at THEIR face node (a, b): both faces' lines (and, below, both faces' geometric
+    // factors) are requested before the first of them is used -- one memory round trip per direction instead of one per face and array
+    double yy[2][N];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) yy[h][i] = 0.0;
+      if ((kcf[h] & 3) == 1 && on_m) {
+        const double* __restrict__ up = u + sd[2 * d + h].nbr_ns;
+        const int dp = kcf[h] >> 6;
+        const int st = (dp == 0) ? 1 : (dp == 1 ? N : N2);
+        const int o0 = (dp == 0) ? N * a + N2 * b : (dp == 1 ? a + N2 * b : a + N * b);
+#pragma unroll
+        for (int i = 0; i < N; ++i) yy[h][i] = up[o0 + st * i];
+      }
+    }
+#if D4EST_HIP_DIRECT_GEOM_EARLY == 2
+    double gqa[2][7];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) direct_load_geom<T>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], geom, robin_c);
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if ((kcf[h] & 3) == 1) {
-        // the normal lines of the (+) element's face fp at ITS face node (a, b)
-        const double* __restrict__ up = u + sd[2 * d + h].nbr_ns;
-        const int dp = kcf[h] >> 6, hi = (kcf[h] >> 5) & 1;
-        double y[N];
-        if (on_m) {
-          if (dp == 0) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) y[i] = up[i + N * a + N2 * b];
-          } else if (dp == 1) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) y[i] = up[a + N * i + N2 * b];
-          } else {
-#pragma unroll
-            for (int i = 0; i < N; ++i) y[i] = up[a + N * b + N2 * i];
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < N; ++i) y[i] = 0.0;
-        }
-        fld[2 + h] = hi ? y[N - 1] : y[0];
-        fld[6 + h] = row_dot<N>(dr0 + hi * N, y);
+        const int hi = (kcf[h] >> 5) & 1;
+        fld[2 + h] = hi ? yy[h][N - 1] : yy[h][0];
+        fld[6 + h] = row_dot<N>(dr0 + hi * N, yy[h]);
       }
     }
     // ---- pass 1: row (c, b) per lane, contract the face index a
@@ -304,6 +327,11 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
     }
     // ---- SIPG terms, one face at a time (the mortar values of its two sides go through the buffer)
     double At[2][4];
+#if D4EST_HIP_DIRECT_GEOM_EARLY == 1
+    double gqa[2][7];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) direct_load_geom<T>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], geom, robin_c);
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       wave_lds_fence();
@@ -338,14 +366,14 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
         } else {
           qp[0] = bndry_q[sgeom[h] + k];
         }
-        if (kind == 0 && robin_c) {
-          gq[6] = robin_c[sgeom[h] + k];   // am = ap = 0: no term 1 / term 2 on a Robin side
-        } else {
-          const double* __restrict__ g = geom + (size_t)7 * sgeom[h] + k;
-#pragma unroll
-          for (int c = 0; c < 7; ++c) gq[c] = g[c * T];
-        }
+#if D4EST_HIP_DIRECT_GEOM_EARLY == 0
+        direct_load_geom<T>(gq, kind, true, k, sgeom[h], geom, robin_c);
+#endif
       }
+#if D4EST_HIP_DIRECT_GEOM_EARLY != 0
+#pragma unroll
+      for (int c = 0; c < 7; ++c) gq[c] = gqa[h][c];
+#endif
       // interface: t1 = -1/2 sj n.(grad u_m + grad u_p), t2_l = -1/2 am_l [u]; boundary: t1 = -sj n.grad u_m, t2_l = -am_l (u - g)
       // (d4est_laplacian_flux_sipg.c:494-942, :15-336); Robin (:339-489): sj (coeff u_m - rhs) only
       double t1 = 0.0;

@@ -145,11 +145,7 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 
   // ---- load u_e (coalesced) into R0[k][j][i], i fastest, padded PN
   if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      R0[i + PN * (j + N * k)] = u[ns + idx];
-    }
+    load_element_image<N, PL, PN>(R0, u + ns, te);
   }
   // ---- metric prefetch: symmetric (rr,rs,rt,ss,st,tt) at the thread's quadrature column, coalesced along (iq,jq)
   double mreg[PF ? 6 : 1][PF ? NQ : 1];
@@ -284,11 +280,7 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 
   // ---- store Au_e (coalesced)
   if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      Au[ns + idx] = R2[i + PN * (j + N * k)];
-    }
+    store_element_image<N, PL, PN>(Au + ns, R2, te);
   }
 }
 
@@ -302,8 +294,17 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 // in a single resident round.
 // ---------------------------------------------------------------------------
 
+#ifndef D4EST_HIP_METRIC_DEPTH
+#define D4EST_HIP_METRIC_DEPTH 4
+#endif
+#ifndef D4EST_HIP_METRIC_EARLY
+#define D4EST_HIP_METRIC_EARLY 2
+#endif
+#ifndef D4EST_HIP_MW_WAVES
+#define D4EST_HIP_MW_WAVES 4
+#endif
 template <int N, int NQ, bool PF, bool EO = false, bool AFF = false>
-__global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS == 64 ? (PF ? 3 : 4) : 1)) void stiffness_wave_kernel(
+__global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS == 64 ? (PF ? 3 : 4) : ((!AFF && N <= 13) ? D4EST_HIP_MW_WAVES : ((!AFF && N == 14) ? 3 : 1)))) void stiffness_wave_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
     const double* __restrict__ Gop, const double* __restrict__ BopT, const double* __restrict__ GopT, int stagger,
@@ -314,10 +315,12 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
   // contract, then all stream the metric ... and the memory pipe idles during the arithmetic phases.  Delaying every
   // other resident "row" of workgroups (block id bit 8 = the second batch the dispatcher places on each CU) by about
   // one forward phase lets one half's metric stream run under the other half's contractions.
+  using C = WaveCfg<N, NQ>;
+  if constexpr (C::THREADS == 64) {
   if (stagger > 0 && ((blockIdx.x >> 8) & 1)) {
     for (int s_ = 0; s_ < stagger; ++s_) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles per iteration
   }
-  using C = WaveCfg<N, NQ>;
+  }
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
   constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -336,13 +339,15 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     ns = ns_list[ei];
     qs = qs_list[ei];
   }
+  if constexpr (C::THREADS > 64) {
+    // one element per workgroup: the strides are wave-uniform -- scalar registers, so every global access below is
+    // SGPR base + one VGPR lane offset (frees the 64-bit address pairs the per-lane form keeps live at the quadrature stage)
+    ns = __builtin_amdgcn_readfirstlane(ns);
+    qs = __builtin_amdgcn_readfirstlane(qs);
+  }
 
   if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      R0[i + PN * (j + N * k)] = u[ns + idx];
-    }
+    load_element_image<N, PL, PN>(R0, u + ns, te);
   }
   double mreg[PF ? 6 : 1][PF ? NQ : 1];
   if (PF && active) {
@@ -377,6 +382,14 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
 
   // ---- S2 (thread (iq=a, k=b)) interleaved with S3 (thread (iq=a, jq=b)): one field at a time through R0
   double gr[NQ], gs[NQ], gt[NQ];
+  // Multi-wave general path: the thread's 6 NQ metric values are requested MD quadrature planes ahead of their use.  Left to itself
+  // the compiler requests one plane's six values, waits for all of them, multiplies, requests the next: NQ serialised memory
+  // round trips in the middle of the element (12 at p = 11 -- most of an element's lifetime).  The registers for the planes in
+  // flight come from gr and gs, which wait in the (then idle) LDS fields in thread-private slots during this stage.
+  constexpr bool kPark = !PF && !AFF && C::THREADS > 64;
+  constexpr int MD = (D4EST_HIP_METRIC_DEPTH < NQ) ? D4EST_HIP_METRIC_DEPTH : NQ;
+  constexpr int ME = (D4EST_HIP_METRIC_EARLY < MD) ? D4EST_HIP_METRIC_EARLY : MD;   // planes requested before the last forward contraction
+  double mw[kPark ? NQ : 1][6];
   {
     double x1[N], x2[N], t[NQ], y[N];
     const bool on2 = active && b < N;
@@ -422,6 +435,18 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     if (active) {
 #pragma unroll
       for (int k = 0; k < N; ++k) y[k] = R0[k + PN * (a + NQ * b)];
+      if constexpr (kPark) {
+        // R1 is free from here on (every thread read field 2 before the barrier above): the finished line gr waits there, in the
+        // thread's own slots [kq][te] (conflict-free), while the registers it leaves carry metric planes in flight
+#pragma unroll
+        for (int kq = 0; kq < NQ; ++kq) R1[kq * PL + te] = gr[kq];
+        const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+        for (int kq = 0; kq < ME; ++kq)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
+        __builtin_amdgcn_sched_barrier(0);
+      }
       fwd<N, NQ, EO, true>(GopT, y, gt);
     }
   }
@@ -441,8 +466,41 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
       gt[kq] = c2 * r + c4 * s_ + c5 * t;
     }
     }
-  } else if (active) {
+  } else {
+    if constexpr (kPark) __syncthreads();   // every thread has read field 3: R0 is free as well
+    if (active) {
     const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+    if constexpr (kPark) {
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) R0[kq * PL + te] = gs[kq];
+#pragma unroll
+      for (int kq = ME; kq < MD; ++kq)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
+      double rn = R1[te], sn = R0[te];
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) {
+        if (kq + MD < NQ) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) mw[kq + MD][c] = m[c * NQ3 + NQ * NQ * (kq + MD)];
+        }
+        const double r = rn, s = sn, t = gt[kq];
+        if (kq + 1 < NQ) {
+          rn = R1[(kq + 1) * PL + te];
+          sn = R0[(kq + 1) * PL + te];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        R1[kq * PL + te] = mw[kq][0] * r + mw[kq][1] * s + mw[kq][2] * t;
+        R0[kq * PL + te] = mw[kq][1] * r + mw[kq][3] * s + mw[kq][4] * t;
+        gt[kq] = mw[kq][2] * r + mw[kq][4] * s + mw[kq][5] * t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) {
+        gr[kq] = R1[kq * PL + te];
+        gs[kq] = R0[kq * PL + te];
+      }
+    } else {
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq) {
       const int q = NQ * NQ * kq;
@@ -452,6 +510,8 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
       gr[kq] = m0 * r + m1 * s + m2 * t;
       gs[kq] = m1 * r + m3 * s + m4 * t;
       gt[kq] = m2 * r + m4 * s + m5 * t;
+    }
+    }
     }
   }
 
@@ -526,11 +586,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
   }
   __syncthreads();
   if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      Au[ns + idx] = R0[i + PN * (j + N * k)];
-    }
+    store_element_image<N, PL, PN>(Au + ns, R0, te);
   }
 }
 
@@ -801,20 +857,12 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave2_kernel(
   if (active) {
     ns = ns_list[ei];
     qs = qs_list[ei];
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      R0[i + PN * (j + N * k)] = u[ns + idx];
-    }
+    load_element_image<N, PL, PN>(R0, u + ns, te);
   }
   __syncthreads();
   stiffness_wave2_element<N, NQ, true>(R0, R1, metric, qs, active, a, b, Bop, Gop, BopT, GopT);
   if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      Au[ns + idx] = R0[i + PN * (j + N * k)];
-    }
+    store_element_image<N, PL, PN>(Au + ns, R0, te);
   }
 }
 
@@ -867,20 +915,12 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave_eo_kernel(
       ns = __builtin_amdgcn_readfirstlane(ns);
       qs = __builtin_amdgcn_readfirstlane(qs);
     }
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      R0[i + PN * (j + N * k)] = u[ns + idx];
-    }
+    load_element_image<N, PL, PN>(R0, u + ns, te);
   }
   __syncthreads();
   stiffness_wave_eo_element<N, NQ, AFF, true>(R0, R1, metric, qs, ei, active, a, b, EBf, EGf, EBb, EGb, affine, wq);
   if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      Au[ns + idx] = R0[i + PN * (j + N * k)];
-    }
+    store_element_image<N, PL, PN>(Au + ns, R0, te);
   }
 }
 
@@ -1120,11 +1160,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
   double g[NQ];  // values at quadrature nodes along kq for thread (iq=a, jq=b)
   if (MODE != 1) {
     if (active) {
-#pragma unroll
-      for (int idx = te; idx < N3; idx += PL) {
-        const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-        R0[i + PN * (j + N * k)] = in[ns + idx];
-      }
+      load_element_image<N, PL, PN>(R0, in + ns, te);
     }
     __syncthreads();
     if (active && a < N && b < N) {  // r
@@ -1202,11 +1238,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
   }
   __syncthreads();
   if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      out[ns + idx] = R0[i + PN * (j + N * k)];
-    }
+    store_element_image<N, PL, PN>(out + ns, R0, te);
   }
 }
 
@@ -1342,11 +1374,7 @@ __global__ __launch_bounds__((WaveCfg<N, N>::THREADS)) void dudr_kernel(
   int ns = 0;
   if (active) ns = ns_list[ei];
   if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      R0[i + PN * (j + N * k)] = u[ns + idx];
-    }
+    load_element_image<N, PL, PN>(R0, u + ns, te);
   }
   __syncthreads();
   // direction t (dir 2): thread (i=a, j=b), column along k; output coalesced directly
@@ -1372,11 +1400,7 @@ __global__ __launch_bounds__((WaveCfg<N, N>::THREADS)) void dudr_kernel(
   }
   __syncthreads();
   if (active) {
-#pragma unroll
-    for (int idx = te; idx < N3; idx += PL) {
-      const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      d0[ns + idx] = R1[i + PN * (j + N * k)];
-    }
+    store_element_image<N, PL, PN>(d0 + ns, R1, te);
   }
 }
 
@@ -1610,7 +1634,7 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
           set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven>, W::LDS_BYTES);                            \
           hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
                              plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
-                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, 0); \
+                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER] < 0 ? 0 : plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER])); \
           }                                                                                                     \
         } else {                                                                                                \
           set_lds_limit(stiffness_wave_kernel<N_, NQ_, false>, W::LDS_BYTES);                                   \
@@ -1658,7 +1682,7 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
       set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven>, W::LDS_BYTES);                                \
       hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
                          plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,                 \
-                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, 0); \
+                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER] < 0 ? 0 : plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER])); \
       }                                                                                                         \
     } else {                                                                                                    \
       set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, false>, W::LDS_BYTES);                                \

@@ -203,6 +203,37 @@ __device__ __forceinline__ void contract_rows_eo(const double* __restrict__ op, 
   }
 }
 
+// An element's nodal values <-> its LDS image [i + PN (j + N k)], one coalesced pass by the PL lanes `te` of the element.  Written with
+// a compile-time trip count: a `for (idx = te; idx < N3; idx += PL)` loop is not unrolled (its trip count depends on te), and the
+// rolled loop waits for each global load before it requests the next -- N3 / PL serialised memory round trips per element (12 at
+// p = 11).  Here every load is in flight before the first LDS write.
+template <int N, int PL, int PN>
+__device__ __forceinline__ void load_element_image(double* R, const double* __restrict__ src, int te) {
+  constexpr int N3 = N * N * N, NL = (N3 + PL - 1) / PL;
+  double v[NL];
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    const int idx = te + PL * q;
+    v[q] = (N3 % PL == 0 || idx < N3) ? src[idx] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    const int idx = te + PL * q;
+    const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+    if (N3 % PL == 0 || idx < N3) R[i + PN * (j + N * k)] = v[q];
+  }
+}
+template <int N, int PL, int PN>
+__device__ __forceinline__ void store_element_image(double* __restrict__ dst, const double* R, int te) {
+  constexpr int N3 = N * N * N, NL = (N3 + PL - 1) / PL;
+#pragma unroll
+  for (int q = 0; q < NL; ++q) {
+    const int idx = te + PL * q;
+    const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
+    if (N3 % PL == 0 || idx < N3) dst[idx] = R[i + PN * (j + N * k)];
+  }
+}
+
 __host__ __device__ inline int face_fix(int f, int N) { return (f & 1) ? (N - 1) : 0; }
 
 __device__ inline int reorder_index(int code, int deg, int a, int b) {
@@ -316,6 +347,12 @@ struct WaveCfg {
 // WG_SYNC: the hand-offs through LDS use __syncthreads() (the stand-alone kernel: one wave per workgroup) or the wave-level fence
 // (kernels whose workgroup holds several independent waves).
 // ---------------------------------------------------------------------------
+#ifndef D4EST_HIP_WAVE_EO_DEPTH
+#define D4EST_HIP_WAVE_EO_DEPTH 3
+#endif
+#ifndef D4EST_HIP_WAVE_EO_EARLY
+#define D4EST_HIP_WAVE_EO_EARLY 1
+#endif
 template <int N, int NQ, bool AFF, bool WG_SYNC>
 __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1, const double* __restrict__ metric, int qs, int ei,
                                                           bool active, int a, int b, const double* __restrict__ EBf,
@@ -356,6 +393,13 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
 
   // ---- S2 (thread (iq=a, k=b)) and S3 (thread (iq=a, jq=b))
   double gr[NQ], gs[NQ], gt[NQ];
+  // General path of the stand-alone kernel: the 6 NQ metric values of the thread are requested MD quadrature planes ahead of their
+  // use, the first ME of them before the last forward contraction; the scheduling barriers pin "request plane kq + MD, multiply
+  // plane kq" (the compiler's own order drains the queue between small groups: 6-7 dependent memory round trips at p = 7).
+  constexpr bool kPipe = !AFF && WG_SYNC && (D4EST_HIP_WAVE_EO_DEPTH > 0);
+  constexpr int MD = (D4EST_HIP_WAVE_EO_DEPTH < NQ) ? D4EST_HIP_WAVE_EO_DEPTH : NQ;
+  constexpr int ME = (D4EST_HIP_WAVE_EO_EARLY < MD) ? D4EST_HIP_WAVE_EO_EARLY : MD;
+  double mw[kPipe ? NQ : 1][6];
   {
     double t3[NQ];
     const bool on2 = active && b < N;
@@ -409,6 +453,14 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
       double y3[N], y3e[HN], y3o[HN], ge[NQ];
 #pragma unroll
       for (int k = 0; k < N; ++k) y3[k] = R0[k + PN * (a + NQ * b)];
+      if constexpr (kPipe) {
+        const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+        for (int kq = 0; kq < ME; ++kq)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
+        __builtin_amdgcn_sched_barrier(0);
+      }
       eo_pre<N>(y3, y3e, y3o);
       contract_single_eo<HN, NQ, false>(EGf, y3o, y3e, ge);
       eo_post<NQ>(ge, gt);
@@ -428,6 +480,26 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
         gr[kq] = c0 * r + c1 * s + c2 * t;
         gs[kq] = c1 * r + c3 * s + c4 * t;
         gt[kq] = c2 * r + c4 * s + c5 * t;
+      }
+    } else if constexpr (kPipe) {
+      const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
+#pragma unroll
+      for (int kq = ME; kq < MD; ++kq)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) {
+        if (kq + MD < NQ) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) mw[kq + MD][c] = m[c * NQ3 + NQ * NQ * (kq + MD)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double r = gr[kq], s = gs[kq], t = gt[kq];
+        gr[kq] = mw[kq][0] * r + mw[kq][1] * s + mw[kq][2] * t;
+        gs[kq] = mw[kq][1] * r + mw[kq][3] * s + mw[kq][4] * t;
+        gt[kq] = mw[kq][2] * r + mw[kq][4] * s + mw[kq][5] * t;
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
