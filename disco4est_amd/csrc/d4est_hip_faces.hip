@@ -906,7 +906,17 @@ __global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restr
     const ElemDesc el = ed[e];
     const SideDesc d0 = sd[6 * e + 2 * dir], d1 = sd[6 * e + 2 * dir + 1];
     const int N = el.N, N2 = N * N, N3 = N2 * N;
-    for (int t = threadIdx.x; t < N3; t += TPB) s_u[(t % N) + UJ * ((t / N) % N) + UK * (t / N2)] = u[el.ns + t];
+    // (a rolled `for (t = tid; t < N3; t += TPB)` waits for each load in turn: N3 / TPB dependent memory round trips, 21 at p = 15)
+    for (int t0 = threadIdx.x; t0 < N3; t0 += 8 * TPB) {
+      double uv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) uv[c] = (t0 + c * TPB < N3) ? u[el.ns + t0 + c * TPB] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int t = t0 + c * TPB;
+        if (t < N3) s_u[(t % N) + UJ * ((t / N) % N) + UK * (t / N2)] = uv[c];
+      }
+    }
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
       const SideDesc& d = s_ ? d1 : d0;
@@ -1278,7 +1288,28 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
     cur_N = N;
     __syncthreads();
     // ---- Au_e += lift(val_f) + D[fix_f][.] (x) Nrm_f over the six faces
-    for (int idx = threadIdx.x; idx < N3; idx += TPB) {
+    // (Au and the smoother vectors of six nodes per thread are requested before the first is used: the rolled loop waited for its
+    // loads every trip)
+    for (int idx0 = threadIdx.x; idx0 < N3; idx0 += 6 * TPB) {
+      double au_[6], rh_[6], pp_[6], uu_[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int idx = idx0 + c * TPB;
+        au_[c] = rh_[c] = pp_[c] = uu_[c] = 0.0;
+        if (idx < N3) {
+          const size_t o = (size_t)el.ns + idx;
+          au_[c] = Au[o];
+          if (FUSE) {
+            rh_[c] = cf.rhs[o];
+            pp_[c] = cf.p[o];
+            uu_[c] = cf.u[o];
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+      const int idx = idx0 + c * TPB;
+      if (idx >= N3) continue;
       const int i = idx % N, j = (idx / N) % N, k = idx / N2;
       double v = 0.0;
       v = fma(s_Dfix[0][i], s_tile[0][1][j * LT + k], v);
@@ -1294,15 +1325,16 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
       if (k == 0) v += s_tile[4][0][i * LT + j];
       if (k == N - 1) v += s_tile[5][0][i * LT + j];
       const size_t o = (size_t)el.ns + idx;
-      const double a = Au[o] + v;
+      const double a = au_[c] + v;
       Au[o] = a;
       if (FUSE) {
-        const double res = __dadd_rn(cf.rhs[o], __dmul_rn(-1.0, a));
+        const double res = __dadd_rn(rh_[c], __dmul_rn(-1.0, a));
         const double ri = __dmul_rn(cf.alpha, res);
-        const double pi = __dadd_rn(__dmul_rn(cf.beta, cf.p[o]), ri);
+        const double pi = __dadd_rn(__dmul_rn(cf.beta, pp_[c]), ri);
         if (cf.r) cf.r[o] = ri;
         cf.p[o] = pi;
-        cf.u[o] = __dadd_rn(cf.u[o], pi);
+        cf.u[o] = __dadd_rn(uu_[c], pi);
+      }
       }
     }
     __syncthreads();
@@ -1338,7 +1370,17 @@ __global__ __launch_bounds__(192) void trace_hp_mfma16_kernel(const double* __re
   for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
     const ElemDesc el = ed[e];
     const int N = el.N, N2 = N * N, N3 = N2 * N;
-    for (int t = threadIdx.x; t < N3; t += TPB) s_u[(t % N) + UJ * ((t / N) % N) + UK * (t / N2)] = u[el.ns + t];
+    // (a rolled `for (t = tid; t < N3; t += TPB)` waits for each load in turn: N3 / TPB dependent memory round trips, 21 at p = 15)
+    for (int t0 = threadIdx.x; t0 < N3; t0 += 8 * TPB) {
+      double uv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) uv[c] = (t0 + c * TPB < N3) ? u[el.ns + t0 + c * TPB] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int t = t0 + c * TPB;
+        if (t < N3) s_u[(t % N) + UJ * ((t / N) % N) + UK * (t / N2)] = uv[c];
+      }
+    }
     if (el.offD != cur_offD || N != cur_N) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -1553,7 +1595,14 @@ __global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __res
       }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < N3; idx += TPB) {
+    for (int idx0 = threadIdx.x; idx0 < N3; idx0 += 8 * TPB) {
+      double au_[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) au_[c] = (idx0 + c * TPB < N3) ? Au[el.ns + idx0 + c * TPB] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+      const int idx = idx0 + c * TPB;
+      if (idx >= N3) continue;
       const int i = idx % N, j = (idx / N) % N, k = idx / N2;
       double v = 0.0;
       v = fma(s_Dfix[0][i], s_tile[0][1][j * LT + k], v);
@@ -1568,7 +1617,8 @@ __global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __res
       if (j == N - 1) v += s_tile[3][0][i * LT + k];
       if (k == 0) v += s_tile[4][0][i * LT + j];
       if (k == N - 1) v += s_tile[5][0][i * LT + j];
-      Au[el.ns + idx] += v;
+      Au[el.ns + idx] = au_[c] + v;
+      }
     }
     __syncthreads();
   }
