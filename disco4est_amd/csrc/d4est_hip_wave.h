@@ -216,6 +216,12 @@ __device__ __forceinline__ void load_element_image(double* R, const double* __re
     const int idx = te + PL * q;
     v[q] = (N3 % PL == 0 || idx < N3) ? src[idx] : 0.0;
   }
+  if constexpr (PL == N * N) {   // one k-plane per pass: the lane's (i, j) is the same in every plane (no division per load)
+    const int ij = (te % N) + PN * (te / N);
+#pragma unroll
+    for (int q = 0; q < NL; ++q) R[ij + PN * N * q] = v[q];
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < NL; ++q) {
     const int idx = te + PL * q;
@@ -226,6 +232,12 @@ __device__ __forceinline__ void load_element_image(double* R, const double* __re
 template <int N, int PL, int PN>
 __device__ __forceinline__ void store_element_image(double* __restrict__ dst, const double* R, int te) {
   constexpr int N3 = N * N * N, NL = (N3 + PL - 1) / PL;
+  if constexpr (PL == N * N) {
+    const int ij = (te % N) + PN * (te / N);
+#pragma unroll
+    for (int q = 0; q < NL; ++q) dst[te + PL * q] = R[ij + PN * N * q];
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < NL; ++q) {
     const int idx = te + PL * q;
