@@ -164,6 +164,40 @@ __device__ __forceinline__ void direct_load_geom(double* gq, int kind, bool on, 
   }
 }
 
+// The kernel is short of scalar registers (operator rows travel through them): arguments that are needed late -- the smoother's
+// vectors and coefficients, the volume term's tables, the side data pointers -- are NOT referenced as parameters (the compiler loads
+// every referenced parameter at entry and then spills it through v_writelane / v_readlane for the whole kernel) but read from the
+// kernel-argument segment where they are used.  DirectKernargs mirrors the parameter list: explicit arguments sit in the segment in
+// order at their natural alignment, i.e. exactly as the members of this struct (checked against the code object's .args offsets by
+// tests/test_capi.py::test_direct_kernarg_layout).
+struct DirectKernargs {
+  const double* u; const double* ghost_qtrace; double* Au; const DirectSide* sides; const DirectGhostOff* ghost_off;
+  const double* ops; const double* geom; const double* bndry_q; const double* robin_c; const double* robin_r;
+  int n_elem, ns0, ns_stride, xcd_chunk;
+  DirectFuse cf;
+  DirectVol vol;
+  const int* elem_list;
+};
+typedef const DirectKernargs __attribute__((address_space(4))) * direct_kargs_ptr;
+__device__ __forceinline__ direct_kargs_ptr direct_kargs() {
+  unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(v));   // one opaque pointer per use site: the loads below it cannot be hoisted to the kernel entry
+  return (direct_kargs_ptr)v;
+}
+
+__device__ __forceinline__ DirectFuse direct_load_fuse(direct_kargs_ptr K) {
+  DirectFuse c;
+  c.rhs = K->cf.rhs; c.p = K->cf.p; c.u_out = K->cf.u_out; c.r = K->cf.r;
+  c.alpha = K->cf.alpha; c.beta = K->cf.beta; c.skip_Au_store = K->cf.skip_Au_store;
+  return c;
+}
+__device__ __forceinline__ DirectVol direct_load_vol(direct_kargs_ptr K) {
+  DirectVol v;
+  v.metric = K->vol.metric; v.EBf = K->vol.EBf; v.EGf = K->vol.EGf; v.EBb = K->vol.EBb; v.EGb = K->vol.EGb;
+  v.affine = K->vol.affine; v.wq = K->vol.wq; v.qs0 = K->vol.qs0; v.qs_stride = K->vol.qs_stride; v.qs_list = K->vol.qs_list;
+  return v;
+}
+
 template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 streamed metric, 2 affine metric */>
 __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
                                                              double* __restrict__ Au, const DirectSide* __restrict__ sides,
@@ -199,7 +233,6 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
   // an element list leaves out elements whose rows the caller forms another way (condensed Schwarz copies); they are still READ as neighbours
   const int e = elem_list ? __builtin_amdgcn_readfirstlane(elem_list[slot]) : slot;
   const int ns = __builtin_amdgcn_readfirstlane(ns0 + e * ns_stride);
-  const DirectSide* __restrict__ sd = sides + 6 * (size_t)e;
 
   // ---- the element's u -> LDS (odd padded line length: conflict-free line reads in all three directions); all loads first
   {
@@ -248,6 +281,10 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
   auto dir_body = [&](auto dc) {
     constexpr int d = decltype(dc)::value;
     constexpr int t0 = (d == 0) ? 1 : 0, t1d = (d == 2) ? 1 : 2;   // reference directions of the face indices a and b
+    // (late argument loads: see DirectKernargs; the descriptor array is read-only for the kernel's lifetime: constant address
+    // space, so its fields stay scalar loads)
+    typedef const DirectSide __attribute__((address_space(4))) * sside_ptr;
+    const sside_ptr sd = (sside_ptr)(unsigned long long)(direct_kargs()->sides + 6 * (size_t)e);
     const int kcf[2] = {sd[2 * d].kcf, sd[2 * d + 1].kcf};
     const int sgeom[2] = {sd[2 * d].geom, sd[2 * d + 1].geom};
     // ---- nodal fields of the two faces: c = 0..3 trace (own 2d, own 2d+1, nbr 2d, nbr 2d+1), c = 4..7 normal derivative
@@ -271,7 +308,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 2
     double gqa[2][7];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) direct_load_geom<T>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], geom, robin_c);
+    for (int h = 0; h < 2; ++h) direct_load_geom<T>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], direct_kargs()->geom, direct_kargs()->robin_c);
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -327,6 +364,9 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
     }
     // ---- SIPG terms, one face at a time (the mortar values of its two sides go through the buffer)
     double At[2][4];
+    const direct_kargs_ptr K = direct_kargs();
+    const double* __restrict__ geom = K->geom;
+    const double* __restrict__ robin_c = K->robin_c;
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 1
     double gqa[2][7];
 #pragma unroll
@@ -358,13 +398,13 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
 #pragma unroll
           for (int c = 0; c < 4; ++c) qp[c] = lds_ld(&s_S[(4 + c) * QS + kp]);
         } else if (kind == 2) {
-          const double* __restrict__ p = ghost_qtrace + ghost_off[6 * (size_t)e + 2 * d + h] + reorder_index(code, NQ - 1, a, b);
+          const double* __restrict__ p = K->ghost_qtrace + K->ghost_off[6 * (size_t)e + 2 * d + h] + reorder_index(code, NQ - 1, a, b);
 #pragma unroll
           for (int c = 0; c < 4; ++c) qp[c] = p[c * T];
         } else if (robin_c) {
-          qp[0] = robin_r[sgeom[h] + k];
+          qp[0] = K->robin_r[sgeom[h] + k];
         } else {
-          qp[0] = bndry_q[sgeom[h] + k];
+          qp[0] = K->bndry_q[sgeom[h] + k];
         }
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 0
         direct_load_geom<T>(gq, kind, true, k, sgeom[h], geom, robin_c);
@@ -451,20 +491,23 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
 #pragma unroll
         for (int i = 0; i < N; ++i) facc[i] = lds_ld(&s_U[a + PN * (b + N * i)]) + acc[i];
       } else {
+        DirectFuse cfl;
+        if constexpr (FUSE) cfl = direct_load_fuse(direct_kargs());
+        double* __restrict__ Au_ = direct_kargs()->Au;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           const size_t o = (size_t)ns + a + N * b + N2 * i;
-          const double au = Au[o] + (lds_ld(&s_U[a + PN * (b + N * i)]) + acc[i]);
-          Au[o] = au;
+          const double au = Au_[o] + (lds_ld(&s_U[a + PN * (b + N * i)]) + acc[i]);
+          Au_[o] = au;
           if constexpr (FUSE) {
             // the Chebyshev update of the node (cheby_update_kernel, same roundings): u is an INPUT of this kernel (the
             // neighbours read it), so the new iterate goes to a second vector
-            const double res = __dadd_rn(cf.rhs[o], __dmul_rn(-1.0, au));
-            const double ri = __dmul_rn(cf.alpha, res);
-            const double pi = __dadd_rn(__dmul_rn(cf.beta, cf.p[o]), ri);
-            if (cf.r) cf.r[o] = ri;
-            cf.p[o] = pi;
-            cf.u_out[o] = __dadd_rn(u[o], pi);
+            const double res = __dadd_rn(cfl.rhs[o], __dmul_rn(-1.0, au));
+            const double ri = __dmul_rn(cfl.alpha, res);
+            const double pi = __dadd_rn(__dmul_rn(cfl.beta, cfl.p[o]), ri);
+            if (cfl.r) cfl.r[o] = ri;
+            cfl.p[o] = pi;
+            cfl.u_out[o] = __dadd_rn(u[o], pi);
           }
         }
       }
@@ -490,22 +533,28 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
       }
     }
     wave_lds_fence();
-    const int qs = __builtin_amdgcn_readfirstlane(vol.qs_stride >= 0 ? vol.qs0 + e * vol.qs_stride : vol.qs_list[e]);
-    stiffness_wave_eo_element<N, NQ, VOL == 2, false>(s_U, s_S, vol.metric, qs, e, on_q, a, b, vol.EBf, vol.EGf, vol.EBb, vol.EGb,
-                                                      vol.affine, vol.wq);
+    {
+      const DirectVol vl = direct_load_vol(direct_kargs());
+      const int qs = __builtin_amdgcn_readfirstlane(vl.qs_stride >= 0 ? vl.qs0 + e * vl.qs_stride : vl.qs_list[e]);
+      stiffness_wave_eo_element<N, NQ, VOL == 2, false>(s_U, s_S, vl.metric, qs, e, on_q, a, b, vl.EBf, vl.EGf, vl.EBb, vl.EGb,
+                                                        vl.affine, vl.wq);
+    }
     if (on_m) {
+      DirectFuse cfl;
+      if constexpr (FUSE) cfl = direct_load_fuse(direct_kargs());
+      double* __restrict__ Au_ = direct_kargs()->Au;
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const size_t o = (size_t)ns + a + N * b + N2 * i;
         const double au = s_U[a + PN * (b + N * i)] + facc[i];
-        if (!FUSE || !cf.skip_Au_store) Au[o] = au;
+        if (!FUSE || !cfl.skip_Au_store) Au_[o] = au;
         if constexpr (FUSE) {   // the Chebyshev update of the node, as in the faces-only form
-          const double res = __dadd_rn(cf.rhs[o], __dmul_rn(-1.0, au));
-          const double ri = __dmul_rn(cf.alpha, res);
-          const double pi = __dadd_rn(__dmul_rn(cf.beta, cf.p[o]), ri);
-          if (cf.r) cf.r[o] = ri;
-          cf.p[o] = pi;
-          cf.u_out[o] = __dadd_rn(u[o], pi);
+          const double res = __dadd_rn(cfl.rhs[o], __dmul_rn(-1.0, au));
+          const double ri = __dmul_rn(cfl.alpha, res);
+          const double pi = __dadd_rn(__dmul_rn(cfl.beta, cfl.p[o]), ri);
+          if (cfl.r) cfl.r[o] = ri;
+          cfl.p[o] = pi;
+          cfl.u_out[o] = __dadd_rn(u[o], pi);
         }
       }
     }
@@ -704,3 +753,18 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
 }
 
 }  // namespace d4est_hip
+
+// Offsets of DirectKernargs' members in parameter order (tests/test_capi.py compares them with the .args offsets the compiler
+// recorded for faces_direct_kernel in the code object: the late argument loads rely on the two layouts being the same).
+extern "C" __attribute__((visibility("default"))) int d4est_hipi_direct_kernarg_offsets(int* out, int cap) {
+  using K = d4est_hip::DirectKernargs;
+  const int off[] = {(int)offsetof(K, u), (int)offsetof(K, ghost_qtrace), (int)offsetof(K, Au), (int)offsetof(K, sides),
+                     (int)offsetof(K, ghost_off), (int)offsetof(K, ops), (int)offsetof(K, geom), (int)offsetof(K, bndry_q),
+                     (int)offsetof(K, robin_c), (int)offsetof(K, robin_r), (int)offsetof(K, n_elem), (int)offsetof(K, ns0),
+                     (int)offsetof(K, ns_stride), (int)offsetof(K, xcd_chunk), (int)offsetof(K, cf), (int)offsetof(K, vol),
+                     (int)offsetof(K, elem_list)};
+  const int n = (int)(sizeof(off) / sizeof(off[0]));
+  for (int i = 0; i < n && i < cap; ++i) out[i] = off[i];
+  return n;
+}
+

@@ -103,3 +103,42 @@ def test_comm_callback_exception_aborts():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "survived" not in r.stdout
     assert "D4EST_HIP_ABORT" in r.stderr and "exchange failed" in r.stderr
+
+
+def test_direct_kernarg_layout(hiplib, tmp_path):
+    """The whole-operator kernel reads its late arguments from the kernel-argument segment through a struct that mirrors the
+    parameter list (csrc/d4est_hip_direct.hip: DirectKernargs).  The compiler's own record of the argument offsets (.args in
+    the code object's metadata) must agree with the struct for every instantiation."""
+    import ctypes
+    import subprocess
+    from disco4est_amd import build
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-readelf")):
+        pytest.skip("llvm-readelf not found")
+    fn = hiplib.d4est_hipi_direct_kernarg_offsets
+    fn.restype = ctypes.c_int
+    buf = (ctypes.c_int * 32)()
+    n = fn(buf, 32)
+    want = [buf[i] for i in range(n)]
+    assert n == 17 and want[0] == 0
+    fb = str(tmp_path / "fatbin")
+    subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, build.LIB])
+    data = open(fb, "rb").read()
+    starts = [m.start() for m in re.finditer(b"\x7fELF", data)]
+    checked = 0
+    for i, st in enumerate(starts):
+        co = str(tmp_path / ("co%d" % i))
+        open(co, "wb").write(data[st:(starts[i + 1] if i + 1 < len(starts) else len(data))])
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+        if "faces_direct_kernel" not in notes:
+            continue
+        for blk in notes.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            if not name or "faces_direct_kernel" not in name.group(1):
+                continue
+            args = blk.split(".args:")[1].split(".group_segment_fixed_size")[0]
+            offs = [int(o) for o, kind in re.findall(r"\.offset:\s+(\d+)\s+\.size:\s+\d+\s+\.value_kind:\s+(\w+)", args)
+                    if not kind.startswith("hidden")]
+            assert offs == want, (name.group(1), offs, want)
+            checked += 1
+    assert checked >= 20
