@@ -365,7 +365,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     const bool on = active && a < N && b < N;
     if (on) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+      for (int i = 0; i < N; ++i) x[i] = lds_ld(&R0[i + PN * (a + N * b)]);
       fwd<N, NQ, EO, false>(BopT, x, br);
       fwd<N, NQ, EO, true>(GopT, x, gr);
     }
@@ -396,8 +396,8 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     if (on2) {
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        x1[j] = R0[j + PN * (a + NQ * b)];  // B_r u
-        x2[j] = R1[j + PN * (a + NQ * b)];  // G_r u
+        x1[j] = lds_ld(&R0[j + PN * (a + NQ * b)]);  // B_r u
+        x2[j] = lds_ld(&R1[j + PN * (a + NQ * b)]);  // G_r u
       }
     }
     __syncthreads();
@@ -410,7 +410,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     __syncthreads();
     if (active) {
 #pragma unroll
-      for (int k = 0; k < N; ++k) y[k] = R0[k + PN * (a + NQ * b)];
+      for (int k = 0; k < N; ++k) y[k] = lds_ld(&R0[k + PN * (a + NQ * b)]);
       fwd<N, NQ, EO, false>(BopT, y, gr);
     }
     // field 2: G_s B_r u  -> gs = B_t(.)   (goes through R1 so the two transfers overlap)
@@ -422,7 +422,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     __syncthreads();
     if (active) {
 #pragma unroll
-      for (int k = 0; k < N; ++k) y[k] = R1[k + PN * (a + NQ * b)];
+      for (int k = 0; k < N; ++k) y[k] = lds_ld(&R1[k + PN * (a + NQ * b)]);
       fwd<N, NQ, EO, false>(BopT, y, gs);
     }
     // field 3: B_s B_r u  -> gt = G_t(.)
@@ -434,7 +434,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     __syncthreads();
     if (active) {
 #pragma unroll
-      for (int k = 0; k < N; ++k) y[k] = R0[k + PN * (a + NQ * b)];
+      for (int k = 0; k < N; ++k) y[k] = lds_ld(&R0[k + PN * (a + NQ * b)]);
       if constexpr (kPark) {
         // R1 is free from here on (every thread read field 2 before the barrier above): the finished line gr waits there, in the
         // thread's own slots [kq][te] (conflict-free), while the registers it leaves carry metric planes in flight
@@ -477,7 +477,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
       for (int kq = ME; kq < MD; ++kq)
 #pragma unroll
         for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
-      double rn = R1[te], sn = R0[te];
+      double rn = lds_ld(&R1[te]), sn = lds_ld(&R0[te]);
 #pragma unroll
       for (int kq = 0; kq < NQ; ++kq) {
         if (kq + MD < NQ) {
@@ -486,8 +486,8 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
         }
         const double r = rn, s = sn, t = gt[kq];
         if (kq + 1 < NQ) {
-          rn = R1[(kq + 1) * PL + te];
-          sn = R0[(kq + 1) * PL + te];
+          rn = lds_ld(&R1[(kq + 1) * PL + te]);
+          sn = lds_ld(&R0[(kq + 1) * PL + te]);
         }
         __builtin_amdgcn_sched_barrier(0);
         R1[kq * PL + te] = mw[kq][0] * r + mw[kq][1] * s + mw[kq][2] * t;
@@ -497,8 +497,8 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
       }
 #pragma unroll
       for (int kq = 0; kq < NQ; ++kq) {
-        gr[kq] = R1[kq * PL + te];
-        gs[kq] = R0[kq * PL + te];
+        gr[kq] = lds_ld(&R1[kq * PL + te]);
+        gs[kq] = lds_ld(&R0[kq * PL + te]);
       }
     } else {
 #pragma unroll
@@ -529,7 +529,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     __syncthreads();
     if (on6) {
 #pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R0[jq + PQ * (a + NQ * b)]);
       bwd<NQ, N, EO, false, false>(Bop, x, ar);
     }
     if (active) {
@@ -540,7 +540,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     __syncthreads();
     if (on6) {
 #pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) x[jq] = R1[jq + PQ * (a + NQ * b)];
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R1[jq + PQ * (a + NQ * b)]);
       bwd<NQ, N, EO, true, false>(Gop, x, bs);
     }
     if (active) {
@@ -551,7 +551,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     __syncthreads();
     if (on6) {
 #pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R0[jq + PQ * (a + NQ * b)]);
       bwd<NQ, N, EO, false, true>(Bop, x, bs);
     }
     __syncthreads();
@@ -572,8 +572,8 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     if (on) {
 #pragma unroll
       for (int iq = 0; iq < NQ; ++iq) {
-        x[iq] = R0[iq + PQ * (a + N * b)];
-        y[iq] = R1[iq + PQ * (a + N * b)];
+        x[iq] = lds_ld(&R0[iq + PQ * (a + N * b)]);
+        y[iq] = lds_ld(&R1[iq + PQ * (a + N * b)]);
       }
       bwd<NQ, N, EO, true, false>(Gop, x, o);
       bwd<NQ, N, EO, false, true>(Bop, y, o);

@@ -203,6 +203,13 @@ __device__ __forceinline__ void contract_rows_eo(const double* __restrict__ op, 
   }
 }
 
+// LDS read that the backend must not pair into ds_read2_b64: on gfx950 a ds_read2_b64 takes 8 LDS cycles (banks mod 32), two
+// ds_read_b64 take 2 + 2 (MI355X_MICROARCH.md, LDS table); volatile accesses are never combined
+__device__ __forceinline__ double lds_ld(const double* p) {
+  typedef const volatile double __attribute__((address_space(3))) * lds_cvptr;
+  return *(lds_cvptr)p;
+}
+
 // An element's nodal values <-> its LDS image [i + PN (j + N k)], one coalesced pass by the PL lanes `te` of the element.  Written with
 // a compile-time trip count: a `for (idx = te; idx < N3; idx += PL)` loop is not unrolled (its trip count depends on te), and the
 // rolled loop waits for each global load before it requests the next -- N3 / PL serialised memory round trips per element (12 at
@@ -386,7 +393,7 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
     const bool on = active && a < N && b < N;
     if (on) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+      for (int i = 0; i < N; ++i) x[i] = lds_ld(&R0[i + PN * (a + N * b)]);
       eo_pre<N>(x, xe, xo);
       contract_pair_eo<HN, NQ, false, false>(EBf, xe, xo, br, EGf, xo, xe, gr);
     }
@@ -420,8 +427,8 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
       if (on2) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-          x1[j] = R0[j + PN * (a + NQ * b)];  // B_r u
-          x2[j] = R1[j + PN * (a + NQ * b)];  // G_r u
+          x1[j] = lds_ld(&R0[j + PN * (a + NQ * b)]);  // B_r u
+          x2[j] = lds_ld(&R1[j + PN * (a + NQ * b)]);  // G_r u
         }
         eo_pre<N>(x1, x1e, x1o);
         eo_pre<N>(x2, x2e, x2o);
@@ -444,8 +451,8 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
       double y1[N], y2[N], y1e[HN], y1o[HN], y2e[HN], y2o[HN], ge[NQ], he[NQ];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
-        y1[k] = R0[k + PN * (a + NQ * b)];
-        y2[k] = R1[k + PN * (a + NQ * b)];
+        y1[k] = lds_ld(&R0[k + PN * (a + NQ * b)]);
+        y2[k] = lds_ld(&R1[k + PN * (a + NQ * b)]);
       }
       eo_pre<N>(y1, y1e, y1o);
       eo_pre<N>(y2, y2e, y2o);
@@ -464,7 +471,7 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
     if (active) {
       double y3[N], y3e[HN], y3o[HN], ge[NQ];
 #pragma unroll
-      for (int k = 0; k < N; ++k) y3[k] = R0[k + PN * (a + NQ * b)];
+      for (int k = 0; k < N; ++k) y3[k] = lds_ld(&R0[k + PN * (a + NQ * b)]);
       if constexpr (kPipe) {
         const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
 #pragma unroll
@@ -557,8 +564,8 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
       double x[NQ], y[NQ], xe[HQ], xo[HQ], ye[HQ], yo[HQ];
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) {
-        x[jq] = R0[jq + PQ * (a + NQ * b)];
-        y[jq] = R1[jq + PQ * (a + NQ * b)];
+        x[jq] = lds_ld(&R0[jq + PQ * (a + NQ * b)]);
+        y[jq] = lds_ld(&R1[jq + PQ * (a + NQ * b)]);
       }
       eo_pre<NQ>(x, xe, xo);
       eo_pre<NQ>(y, ye, yo);
@@ -575,7 +582,7 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
     if (on6) {
       double z[NQ], ze[HQ], zo[HQ];
 #pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) z[jq] = R0[jq + PQ * (a + NQ * b)];
+      for (int jq = 0; jq < NQ; ++jq) z[jq] = lds_ld(&R0[jq + PQ * (a + NQ * b)]);
       eo_pre<NQ>(z, ze, zo);
       contract_single_eo<HQ, N, true>(EBb, ze, zo, bs);  // summed in (a | b) form with G_s^T(...)
     }
@@ -600,8 +607,8 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
       double x[NQ], y[NQ], xe[HQ], xo[HQ], ye[HQ], yo[HQ];
 #pragma unroll
       for (int iq = 0; iq < NQ; ++iq) {
-        x[iq] = R0[iq + PQ * (a + N * b)];
-        y[iq] = R1[iq + PQ * (a + N * b)];
+        x[iq] = lds_ld(&R0[iq + PQ * (a + N * b)]);
+        y[iq] = lds_ld(&R1[iq + PQ * (a + N * b)]);
       }
       eo_pre<NQ>(x, xe, xo);
       eo_pre<NQ>(y, ye, yo);
