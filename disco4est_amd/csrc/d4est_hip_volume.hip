@@ -162,7 +162,7 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
   if (active && a < N && b < N) {
     double x[N], br[NQ], gr[NQ];
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+    for (int i = 0; i < N; ++i) x[i] = lds_ld(&R0[i + PN * (a + N * b)]);
     fwd<N, NQ, EO, false>(BopT, x, br);
     fwd<N, NQ, EO, true>(GopT, x, gr);
 #pragma unroll
@@ -178,11 +178,11 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
   if (active && b < N) {
     double x[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];
+    for (int j = 0; j < N; ++j) x[j] = lds_ld(&R1[j + PN * (a + NQ * b)]);
     fwd<N, NQ, EO, false>(BopT, x, t_bb);
     fwd<N, NQ, EO, true>(GopT, x, t_gb);
 #pragma unroll
-    for (int j = 0; j < N; ++j) x[j] = R2[j + PN * (a + NQ * b)];
+    for (int j = 0; j < N; ++j) x[j] = lds_ld(&R2[j + PN * (a + NQ * b)]);
     fwd<N, NQ, EO, false>(BopT, x, t_bg);
   }
   __syncthreads();
@@ -202,13 +202,13 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
   if (active) {
     double x[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
+    for (int k = 0; k < N; ++k) x[k] = lds_ld(&R0[k + PN * (a + NQ * b)]);
     fwd<N, NQ, EO, false>(BopT, x, gr);
 #pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = R1[k + PN * (a + NQ * b)];
+    for (int k = 0; k < N; ++k) x[k] = lds_ld(&R1[k + PN * (a + NQ * b)]);
     fwd<N, NQ, EO, false>(BopT, x, gs);
 #pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = R2[k + PN * (a + NQ * b)];
+    for (int k = 0; k < N; ++k) x[k] = lds_ld(&R2[k + PN * (a + NQ * b)]);
     fwd<N, NQ, EO, true>(GopT, x, gt);
 
     // ---- quadrature-point stage: symmetric metric (rr,rs,rt,ss,st,tt), coalesced along (iq,jq)
@@ -245,13 +245,13 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
   if (active && b < N) {
     double x[NQ];
 #pragma unroll
-    for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+    for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R0[jq + PQ * (a + NQ * b)]);
     bwd<NQ, N, EO, false, false>(Bop, x, ar);
 #pragma unroll
-    for (int jq = 0; jq < NQ; ++jq) x[jq] = R1[jq + PQ * (a + NQ * b)];
+    for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R1[jq + PQ * (a + NQ * b)]);
     bwd<NQ, N, EO, true, false>(Gop, x, bs);
 #pragma unroll
-    for (int jq = 0; jq < NQ; ++jq) x[jq] = R2[jq + PQ * (a + NQ * b)];
+    for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R2[jq + PQ * (a + NQ * b)]);
     bwd<NQ, N, EO, false, true>(Bop, x, bs);
   }
   __syncthreads();
@@ -268,10 +268,10 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
   if (active && a < N && b < N) {
     double x[NQ], o[N];
 #pragma unroll
-    for (int iq = 0; iq < NQ; ++iq) x[iq] = R0[iq + PQ * (a + N * b)];
+    for (int iq = 0; iq < NQ; ++iq) x[iq] = lds_ld(&R0[iq + PQ * (a + N * b)]);
     bwd<NQ, N, EO, true, false>(Gop, x, o);
 #pragma unroll
-    for (int iq = 0; iq < NQ; ++iq) x[iq] = R1[iq + PQ * (a + N * b)];
+    for (int iq = 0; iq < NQ; ++iq) x[iq] = lds_ld(&R1[iq + PQ * (a + N * b)]);
     bwd<NQ, N, EO, false, true>(Bop, x, o);
 #pragma unroll
     for (int i = 0; i < N; ++i) R2[i + PN * (a + N * b)] = o[i];
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(128, 4) void stiffness_pair_kernel(
   if (active && a < N && b < N) {
     double x[N], br[HQ], gr[HQ];
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+    for (int i = 0; i < N; ++i) x[i] = lds_ld(&R0[i + PN * (a + N * b)]);
     contract_n_part<N, NQ, HQ>(BopT, q0, x, br);
     contract_n_part<N, NQ, HQ>(GopT, q0, x, gr);
 #pragma unroll
@@ -700,11 +700,11 @@ __global__ __launch_bounds__(128, 4) void stiffness_pair_kernel(
     const bool on2 = active && b < N;
     if (on2) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];
+      for (int j = 0; j < N; ++j) x[j] = lds_ld(&R1[j + PN * (a + NQ * b)]);
       contract_n_part<N, NQ, HQ>(BopT, q0, x, t_bb);
       contract_n_part<N, NQ, HQ>(GopT, q0, x, t_gb);
 #pragma unroll
-      for (int j = 0; j < N; ++j) x[j] = R2[j + PN * (a + NQ * b)];
+      for (int j = 0; j < N; ++j) x[j] = lds_ld(&R2[j + PN * (a + NQ * b)]);
       contract_n_part<N, NQ, HQ>(BopT, q0, x, t_bg);
     }
     __syncthreads();
@@ -724,13 +724,13 @@ __global__ __launch_bounds__(128, 4) void stiffness_pair_kernel(
   if (active) {
     double x[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
+    for (int k = 0; k < N; ++k) x[k] = lds_ld(&R0[k + PN * (a + NQ * b)]);
     contract_n_part<N, NQ, HQ>(BopT, q0, x, fr);
 #pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = R1[k + PN * (a + NQ * b)];
+    for (int k = 0; k < N; ++k) x[k] = lds_ld(&R1[k + PN * (a + NQ * b)]);
     contract_n_part<N, NQ, HQ>(BopT, q0, x, fs);
 #pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = R2[k + PN * (a + NQ * b)];
+    for (int k = 0; k < N; ++k) x[k] = lds_ld(&R2[k + PN * (a + NQ * b)]);
     contract_n_part<N, NQ, HQ>(GopT, q0, x, ft);
 #pragma unroll
     for (int kq = 0; kq < HQ; ++kq) {
@@ -756,13 +756,13 @@ __global__ __launch_bounds__(128, 4) void stiffness_pair_kernel(
     double x[NQ], ca[HN], cb[HN], cc[HN];
     if (active) {
 #pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) x[kq] = R0[kq + PQ * (a + NQ * b)];
+      for (int kq = 0; kq < NQ; ++kq) x[kq] = lds_ld(&R0[kq + PQ * (a + NQ * b)]);
       contract_t_part<NQ, N, HN, false>(Bop, n0, x, ca);
 #pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) x[kq] = R1[kq + PQ * (a + NQ * b)];
+      for (int kq = 0; kq < NQ; ++kq) x[kq] = lds_ld(&R1[kq + PQ * (a + NQ * b)]);
       contract_t_part<NQ, N, HN, false>(Bop, n0, x, cb);
 #pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) x[kq] = R2[kq + PQ * (a + NQ * b)];
+      for (int kq = 0; kq < NQ; ++kq) x[kq] = lds_ld(&R2[kq + PQ * (a + NQ * b)]);
       contract_t_part<NQ, N, HN, false>(Gop, n0, x, cc);
     }
     __syncthreads();
@@ -782,13 +782,13 @@ __global__ __launch_bounds__(128, 4) void stiffness_pair_kernel(
     const bool on6 = active && b < N;
     if (on6) {
 #pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R0[jq + PQ * (a + NQ * b)]);
       contract_t_part<NQ, N, HN, false>(Bop, n0, x, ar);
 #pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) x[jq] = R1[jq + PQ * (a + NQ * b)];
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R1[jq + PQ * (a + NQ * b)]);
       contract_t_part<NQ, N, HN, false>(Gop, n0, x, bs);
 #pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) x[jq] = R2[jq + PQ * (a + NQ * b)];
+      for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R2[jq + PQ * (a + NQ * b)]);
       contract_t_part<NQ, N, HN, true>(Bop, n0, x, bs);
     }
     __syncthreads();
@@ -805,10 +805,10 @@ __global__ __launch_bounds__(128, 4) void stiffness_pair_kernel(
   if (active && a < N && b < N) {
     double x[NQ], o[HN];
 #pragma unroll
-    for (int iq = 0; iq < NQ; ++iq) x[iq] = R0[iq + PQ * (a + N * b)];
+    for (int iq = 0; iq < NQ; ++iq) x[iq] = lds_ld(&R0[iq + PQ * (a + N * b)]);
     contract_t_part<NQ, N, HN, false>(Gop, n0, x, o);
 #pragma unroll
-    for (int iq = 0; iq < NQ; ++iq) x[iq] = R1[iq + PQ * (a + N * b)];
+    for (int iq = 0; iq < NQ; ++iq) x[iq] = lds_ld(&R1[iq + PQ * (a + N * b)]);
     contract_t_part<NQ, N, HN, true>(Bop, n0, x, o);
 #pragma unroll
     for (int i = 0; i < HN; ++i) R2[n0 + i + PN * (a + N * b)] = o[i];
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(128, 4) void stiffness_pair_kernel(
 #pragma unroll
     for (int idx = te + h * PL; idx < N3; idx += 2 * PL) {
       const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-      Au[ns + idx] = R2[i + PN * (j + N * k)];
+      Au[ns + idx] = lds_ld(&R2[i + PN * (j + N * k)]);
     }
   }
 }
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
     if (active && a < N && b < N) {  // r
       double x[N], y[NQ];
 #pragma unroll
-      for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+      for (int i = 0; i < N; ++i) x[i] = lds_ld(&R0[i + PN * (a + N * b)]);
       fwd<N, NQ, EO, false>(BopT, x, y);
 #pragma unroll
       for (int iq = 0; iq < NQ; ++iq) R1[a + PN * (iq + NQ * b)] = y[iq];
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
     if (active && b < N) {  // s
       double x[N], y[NQ];
 #pragma unroll
-      for (int j = 0; j < N; ++j) x[j] = R1[j + PN * (a + NQ * b)];
+      for (int j = 0; j < N; ++j) x[j] = lds_ld(&R1[j + PN * (a + NQ * b)]);
       fwd<N, NQ, EO, false>(BopT, x, y);
 #pragma unroll
       for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = y[jq];
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
     if (active) {  // t
       double x[N];
 #pragma unroll
-      for (int k = 0; k < N; ++k) x[k] = R0[k + PN * (a + NQ * b)];
+      for (int k = 0; k < N; ++k) x[k] = lds_ld(&R0[k + PN * (a + NQ * b)]);
       fwd<N, NQ, EO, false>(BopT, x, g);
     }
   } else if (active) {
@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
   if (active && b < N) {
     double x[NQ], y[N];
 #pragma unroll
-    for (int jq = 0; jq < NQ; ++jq) x[jq] = R0[jq + PQ * (a + NQ * b)];
+    for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R0[jq + PQ * (a + NQ * b)]);
     bwd<NQ, N, EO, false, false>(Bop, x, y);
 #pragma unroll
     for (int j = 0; j < N; ++j) R1[a + PQ * (j + N * b)] = y[j];
@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
   if (active && a < N && b < N) {
     double x[NQ], o[N];
 #pragma unroll
-    for (int iq = 0; iq < NQ; ++iq) x[iq] = R1[iq + PQ * (a + N * b)];
+    for (int iq = 0; iq < NQ; ++iq) x[iq] = lds_ld(&R1[iq + PQ * (a + N * b)]);
     bwd<NQ, N, EO, false, false>(Bop, x, o);
 #pragma unroll
     for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = o[i];
@@ -1381,19 +1381,19 @@ __global__ __launch_bounds__((WaveCfg<N, N>::THREADS)) void dudr_kernel(
   if (active) {
     double x[N], y[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) x[k] = R0[a + PN * (b + N * k)];
+    for (int k = 0; k < N; ++k) x[k] = lds_ld(&R0[a + PN * (b + N * k)]);
     contract_n<N, N>(DopT, x, y);
 #pragma unroll
     for (int k = 0; k < N; ++k) d2[ns + a + N * (b + N * k)] = y[k];
     // direction s (dir 1): thread (i=a, k=b), column along j
 #pragma unroll
-    for (int j = 0; j < N; ++j) x[j] = R0[a + PN * (j + N * b)];
+    for (int j = 0; j < N; ++j) x[j] = lds_ld(&R0[a + PN * (j + N * b)]);
     contract_n<N, N>(DopT, x, y);
 #pragma unroll
     for (int j = 0; j < N; ++j) d1[ns + a + N * (j + N * b)] = y[j];
     // direction r (dir 0): thread (j=a, k=b), column along i -> stage through LDS for a coalesced store
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = R0[i + PN * (a + N * b)];
+    for (int i = 0; i < N; ++i) x[i] = lds_ld(&R0[i + PN * (a + N * b)]);
     contract_n<N, N>(DopT, x, y);
 #pragma unroll
     for (int i = 0; i < N; ++i) R1[i + PN * (a + N * b)] = y[i];
