@@ -300,9 +300,6 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 #ifndef D4EST_HIP_METRIC_EARLY
 #define D4EST_HIP_METRIC_EARLY 2
 #endif
-#ifndef D4EST_HIP_PARK_GS
-#define D4EST_HIP_PARK_GS 1
-#endif
 #ifndef D4EST_HIP_MW_WAVES
 #define D4EST_HIP_MW_WAVES 4
 #endif
@@ -390,7 +387,6 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
   // round trips in the middle of the element (12 at p = 11 -- most of an element's lifetime).  The registers for the planes in
   // flight come from gr and gs, which wait in the (then idle) LDS fields in thread-private slots during this stage.
   constexpr bool kPark = !PF && !AFF && C::THREADS > 64;
-  constexpr bool kParkGs = (D4EST_HIP_PARK_GS != 0);   // gs parked as well (0: only gr -- one barrier and a third of the slot traffic less, 24 VGPRs more)
   constexpr int MD = (D4EST_HIP_METRIC_DEPTH < NQ) ? D4EST_HIP_METRIC_DEPTH : NQ;
   constexpr int ME = (D4EST_HIP_METRIC_EARLY < MD) ? D4EST_HIP_METRIC_EARLY : MD;   // planes requested before the last forward contraction
   double mw[kPark ? NQ : 1][6];
@@ -471,19 +467,17 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     }
     }
   } else {
-    if constexpr (kPark && kParkGs) __syncthreads();   // every thread has read field 3: R0 is free as well
+    if constexpr (kPark) __syncthreads();   // every thread has read field 3: R0 is free as well
     if (active) {
     const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
     if constexpr (kPark) {
 #pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) {
-        if constexpr (kParkGs) R0[kq * PL + te] = gs[kq];
-      }
+      for (int kq = 0; kq < NQ; ++kq) R0[kq * PL + te] = gs[kq];
 #pragma unroll
       for (int kq = ME; kq < MD; ++kq)
 #pragma unroll
         for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
-      double rn = lds_ld(&R1[te]), sn = kParkGs ? lds_ld(&R0[te]) : gs[0];
+      double rn = lds_ld(&R1[te]), sn = lds_ld(&R0[te]);
 #pragma unroll
       for (int kq = 0; kq < NQ; ++kq) {
         if (kq + MD < NQ) {
@@ -493,19 +487,18 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
         const double r = rn, s = sn, t = gt[kq];
         if (kq + 1 < NQ) {
           rn = lds_ld(&R1[(kq + 1) * PL + te]);
-          sn = kParkGs ? lds_ld(&R0[(kq + 1) * PL + te]) : gs[kq + 1];
+          sn = lds_ld(&R0[(kq + 1) * PL + te]);
         }
         __builtin_amdgcn_sched_barrier(0);
         R1[kq * PL + te] = mw[kq][0] * r + mw[kq][1] * s + mw[kq][2] * t;
-        if constexpr (kParkGs) R0[kq * PL + te] = mw[kq][1] * r + mw[kq][3] * s + mw[kq][4] * t;
-        else gs[kq] = mw[kq][1] * r + mw[kq][3] * s + mw[kq][4] * t;
+        R0[kq * PL + te] = mw[kq][1] * r + mw[kq][3] * s + mw[kq][4] * t;
         gt[kq] = mw[kq][2] * r + mw[kq][4] * s + mw[kq][5] * t;
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int kq = 0; kq < NQ; ++kq) {
         gr[kq] = lds_ld(&R1[kq * PL + te]);
-        if constexpr (kParkGs) gs[kq] = lds_ld(&R0[kq * PL + te]);
+        gs[kq] = lds_ld(&R0[kq * PL + te]);
       }
     } else {
 #pragma unroll
