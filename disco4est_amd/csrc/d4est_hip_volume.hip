@@ -925,6 +925,89 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave_eo_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Mixed-degree plans: ONE launch for all buckets with deg_quad = deg <= 7 (one 64-lane workgroup per wave_eo work unit, whatever the
+// degree).  A plan with p = 3 ... 9 scattered over its elements (BASELINE config 4's shape) otherwise pays one launch per bucket, each
+// far too small to fill the chip; side-by-side launches on forked streams cost more in event waits than they overlap.
+// The workgroup looks its bucket up (wave-uniform) and runs that degree's body -- the same code as stiffness_wave_eo_kernel.
+// ---------------------------------------------------------------------------
+struct WaveEoMulti {
+  static constexpr int MAXB = 7;
+  int n = 0;
+  int wg_end[MAXB] = {};       // exclusive prefix of the buckets' workgroup counts
+  int N[MAXB] = {};
+  int n_elem[MAXB] = {};
+  int elem_offset[MAXB] = {};  // into the plan's bucket-ordered ns / qs lists (and 6 doubles per element of the affine constants)
+  const double* EBf[MAXB] = {};
+  const double* EGf[MAXB] = {};
+  const double* EBb[MAXB] = {};
+  const double* EGb[MAXB] = {};
+  const double* wq[MAXB] = {};
+};
+
+template <int N, bool AFF>
+__device__ __forceinline__ void wave_eo_multi_body(double* smem, int wg, const double* __restrict__ u, double* __restrict__ Au,
+                                                   const double* __restrict__ metric, const int* __restrict__ ns_list,
+                                                   const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ EBf,
+                                                   const double* __restrict__ EGf, const double* __restrict__ EBb,
+                                                   const double* __restrict__ EGb, const double* __restrict__ affine,
+                                                   const double* __restrict__ wq) {
+  using C = WaveCfg<N, N>;
+  constexpr int PL = C::PL, PN = C::PN, FS = C::FS;
+  const int tid = threadIdx.x;
+  const int slot = tid / PL;
+  const int te = tid - slot * PL;
+  const int a = te % N, b = te / N;
+  const int ei = wg * C::EPB + slot;
+  const bool active = (slot < C::EPB) && (ei < n_bucket);
+  double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
+  double* R1 = R0 + FS;
+  int ns = 0, qs = 0;
+  if (active) {
+    ns = ns_list[ei];
+    qs = qs_list[ei];
+    if (C::EPB == 1) {
+      ns = __builtin_amdgcn_readfirstlane(ns);
+      qs = __builtin_amdgcn_readfirstlane(qs);
+    }
+    load_element_image<N, PL, PN>(R0, u + ns, te);
+  }
+  __syncthreads();
+  stiffness_wave_eo_element<N, N, AFF, true>(R0, R1, metric, qs, ei, active, a, b, EBf, EGf, EBb, EGb, affine, wq);
+  if (active) {
+    store_element_image<N, PL, PN>(Au + ns, R0, te);
+  }
+}
+
+template <bool AFF>
+__global__ __launch_bounds__(64, 4) void stiffness_wave_eo_multi_kernel(const double* __restrict__ u, double* __restrict__ Au,
+                                                                        const double* __restrict__ metric,
+                                                                        const int* __restrict__ ns_list_all,
+                                                                        const int* __restrict__ qs_list_all,
+                                                                        const double* __restrict__ affine_all, WaveEoMulti A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int blk = blockIdx.x;
+  int bi = 0;
+  while (bi + 1 < A.n && blk >= A.wg_end[bi]) ++bi;   // wave-uniform: a handful of scalar compares
+  const int wg = blk - (bi > 0 ? A.wg_end[bi - 1] : 0);
+  const int off = A.elem_offset[bi], nb = A.n_elem[bi];
+  const double* EBf = A.EBf[bi];
+  const double* EGf = A.EGf[bi];
+  const double* EBb = A.EBb[bi];
+  const double* EGb = A.EGb[bi];
+  const double* wq = A.wq[bi];
+  const double* aff = AFF ? affine_all + (size_t)6 * off : nullptr;
+#define D4EST_CASE(N_)                                                                                                            \
+  case N_:                                                                                                                        \
+    wave_eo_multi_body<N_, AFF>(smem, wg, u, Au, metric, ns_list_all + off, qs_list_all + off, nb, EBf, EGf, EBb, EGb, aff, wq);   \
+    break;
+  switch (A.N[bi]) {
+    D4EST_CASE(2) D4EST_CASE(3) D4EST_CASE(4) D4EST_CASE(5) D4EST_CASE(6) D4EST_CASE(7) D4EST_CASE(8)
+    default: break;
+  }
+#undef D4EST_CASE
+}
+
+// ---------------------------------------------------------------------------
 // N = NQ = 16 (p = 15) on the FP64 matrix cores (N = 13 ... 15 run too, operators zero-padded to 16, but the padding and the idle
 // waves eat the gain -- measured 32 / 47 / 36 GDoF/s against 41 / 46 / 34 of the vector-ALU kernel -- so only p = 15 selects it by itself): the whole sum-factorised apply as chains of v_mfma_f64_16x16x4
 // (D[16x16] += A[16x4] B[4x16]; lane l = (q = l >> 4, c = l & 15) holds A[row c][k q], B[k q][col c] and, in register v,
@@ -1594,10 +1677,55 @@ static void launch_stiffness_mfma16(d4est_hip_plan* plan, const Bucket& bk, cons
   else go(stiffness_mfma16_kernel<13>);
 }
 
+// Mixed-degree plans: the buckets the single-wavefront even-odd kernel would take (deg_quad = deg <= 7, automatic kernel choice) go
+// into ONE launch per metric form (streamed / affine) when there are at least two of them; returns the buckets it covered.
+static unsigned launch_stiffness_multi(d4est_hip_plan* plan, const double* u, double* Au) {
+  const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
+  if (!(tw < 0 || tw == 11) || plan->tuning[D4EST_HIP_TUNE_STIFFNESS_PREFETCH] > 0) return 0u;
+  unsigned covered = 0u;
+  for (int aff = 0; aff < 2; ++aff) {
+    WaveEoMulti A;
+    size_t lds = 0;
+    unsigned mine = 0u;
+    int wgs = 0;
+    for (size_t i = 0; i < plan->buckets.size() && i < 32; ++i) {
+      const Bucket& bk = plan->buckets[i];
+      if (bk.n_elem == 0 || bk.N != bk.NQ || bk.N < 2 || bk.N > 8 || !bk.d_EBf || A.n == WaveEoMulti::MAXB) continue;
+      const bool use_affine = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine;
+      if ((int)use_affine != aff || !(bk.n_elem <= 8192 || use_affine)) continue;   // (larger buckets: the prefetching kernel, see below)
+      size_t l = 0;
+      int epb = 1;
+#define X(N_) if (bk.N == N_) { l = WaveCfg<N_, N_>::LDS_BYTES; epb = WaveCfg<N_, N_>::EPB; }
+      X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#undef X
+      lds = std::max(lds, l);
+      wgs += (bk.n_elem + epb - 1) / epb;
+      const int j = A.n++;
+      A.wg_end[j] = wgs; A.N[j] = bk.N; A.n_elem[j] = bk.n_elem; A.elem_offset[j] = bk.elem_offset;
+      A.EBf[j] = bk.d_EBf; A.EGf[j] = bk.d_EGf; A.EBb[j] = bk.d_EBb; A.EGb[j] = bk.d_EGb; A.wq[j] = bk.d_w;
+      mine |= 1u << i;
+    }
+    if (A.n < 2) continue;
+    std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_wave_eo_multi_kernel<%s> (%d buckets)", aff ? "affine" : "general", A.n);
+    if (aff)
+      hipLaunchKernelGGL((stiffness_wave_eo_multi_kernel<true>), dim3(wgs), dim3(64), lds, plan->stream, u, Au, plan->d_metric, plan->d_ns_list,
+                         plan->d_qs_list, plan->d_metric_affine, A);
+    else
+      hipLaunchKernelGGL((stiffness_wave_eo_multi_kernel<false>), dim3(wgs), dim3(64), lds, plan->stream, u, Au, plan->d_metric, plan->d_ns_list,
+                         plan->d_qs_list, (const double*)nullptr, A);
+    covered |= mine;
+  }
+  return covered;
+}
+
 void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   if (!plan->has_geometry) D4EST_HIP_ABORT("apply_stiffness_matrix: d4est_hip_plan_set_geometry was not called");
+  const unsigned covered = launch_stiffness_multi(plan, u, Au);
+  size_t bucket_index = 0;
   for (const Bucket& bk : plan->buckets) {
+    const size_t this_bucket = bucket_index++;
     if (bk.n_elem == 0) continue;
+    if (this_bucket < 32 && ((covered >> this_bucket) & 1u)) continue;
     bool done = false;
     // auto-tuning (measured on MI355X, p = 7): up to ~2 resident rounds (16 one-wave workgroups per CU)
     // the two-buffer wave kernel wins; for larger buckets the 3-buffer kernel with the metric requested
