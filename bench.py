@@ -444,6 +444,27 @@ def main():
                                                 "condensed_copies": sz.condensed_copies()}
                 sz.destroy()
                 del us
+            # BASELINE config 4's shape in miniature: degrees p = 3 ... 9 scattered over the level-4 brick (1.75 MDoF), general path --
+            # the volume term (the buckets with deg_quad = deg <= 7 in one launch, p = 8, 9 in theirs) and the full operator
+            # (two-phase tiled face kernels: the mesh holds degrees above 7)
+            if args.geometry != "sine":
+                degs = 3 + (np.arange(8 ** 4) * 5) % 7
+                m4 = M.BrickMesh(4, degs)
+                J4, rst4 = m4.geometry(None)
+                p4 = Plan(m4.deg, m4.deg_quad, m4.nodal_stride, m4.quad_stride, 0, stream=stream)
+                p4.set_geometry(J4, rst4)
+                p4.set_tuning(7, 0)
+                p4.set_faces(m4.build_sides(None))
+                x4 = torch.from_numpy(m4.field()).to(dev)
+                y4 = torch.empty_like(x4)
+                ms_s = time_region(lambda: p4.apply_stiffness_matrix(x4, y4), 50, stream, torch, warm=10)
+                ms_a = time_region(lambda: p4.apply_aij(x4, y4), 50, stream, torch, warm=10)
+                sec["mixed_p3_to_9_level4"] = {"dofs": m4.local_nodes, "elements": m4.n_elements, "stiffness_ms": ms_s,
+                                               "stiffness_GDoF_per_s": m4.local_nodes / (ms_s * 1e-3) / 1e9, "apply_aij_ms": ms_a,
+                                               "apply_aij_GDoF_per_s": m4.local_nodes / (ms_a * 1e-3) / 1e9,
+                                               "face_path": p4.face_path()}
+                p4.destroy()
+                del x4, y4
             out["secondary"] = sec
         except Exception as exc:  # secondary numbers must never break the headline line
             out["secondary"] = {"error": repr(exc)}
