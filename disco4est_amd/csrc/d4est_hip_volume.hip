@@ -1214,22 +1214,21 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
 //   MODE 4: out = V^-1 (W J)^-1 V^-T in   (inverse mass, d4est_quadrature.c:1222-1331; Bop = V^-T, BopT = V^-1)
 // ---------------------------------------------------------------------------
 // EO = true: Bop / BopT are the even-odd tables of B^T / B (the symmetric interpolation), see apply_eo
-template <int N, int NQ, int MODE, bool EO = false>
-__global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
-    const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ Jq,
+template <int N, int NQ, int MODE, bool EO>
+__device__ __forceinline__ void mass_like_body(
+    double* smem, int wg, const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ Jq,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list,
     int n_bucket, const double* __restrict__ Bop, const double* __restrict__ BopT, const double* __restrict__ wq,
     const double* __restrict__ coeff) {
   using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ;
   constexpr int N3 = N * N * N;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
 
   const int tid = threadIdx.x;
   const int slot = tid / PL;
   const int te = tid - slot * PL;
   const int a = te % NQ, b = te / NQ;
-  const int ei = blockIdx.x * C::EPB + slot;
+  const int ei = wg * C::EPB + slot;
   const bool active = (slot < C::EPB) && (ei < n_bucket);
   double* R0 = smem + (active ? slot : 0) * C::LDS_PER_ELEM;
   double* R1 = R0 + C::FS;
@@ -1354,6 +1353,44 @@ __device__ void gen_apply(const double* __restrict__ op, int rows, int so, int s
     out[idx] = acc ? out[idx] + s : s;
   }
   __syncthreads();
+}
+
+template <int N, int NQ, int MODE, bool EO = false>
+__global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS)) void mass_like_kernel(
+    const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ Jq,
+    const int* __restrict__ ns_list, const int* __restrict__ qs_list,
+    int n_bucket, const double* __restrict__ Bop, const double* __restrict__ BopT, const double* __restrict__ wq,
+    const double* __restrict__ coeff) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  mass_like_body<N, NQ, MODE, EO>(smem, blockIdx.x, in, out, Jq, ns_list, qs_list, n_bucket, Bop, BopT, wq, coeff);
+}
+
+// Mixed-degree plans: the mass (MODE 0) / weighted mass (MODE 3) applies of all buckets with deg_quad = deg <= 7 in ONE launch
+// (see stiffness_wave_eo_multi_kernel; WaveEoMulti carries EBb / EBf as the two even-odd tables of B)
+template <int MODE>
+__global__ __launch_bounds__(64) void mass_like_multi_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                             const double* __restrict__ Jq, const int* __restrict__ ns_list_all,
+                                                             const int* __restrict__ qs_list_all, const double* __restrict__ coeff,
+                                                             WaveEoMulti A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int blk = blockIdx.x;
+  int bi = 0;
+  while (bi + 1 < A.n && blk >= A.wg_end[bi]) ++bi;
+  const int wg = blk - (bi > 0 ? A.wg_end[bi - 1] : 0);
+  const int off = A.elem_offset[bi], nb = A.n_elem[bi];
+  const double* EBb = A.EBb[bi];
+  const double* EBf = A.EBf[bi];
+  const double* wq = A.wq[bi];
+#define D4EST_CASE(N_)                                                                                                                 \
+  case N_:                                                                                                                             \
+    mass_like_body<N_, N_, MODE, true>(smem, wg, in, out, Jq, ns_list_all + off, qs_list_all + off, nb, EBb, EBf, wq, coeff);          \
+    break;
+  switch (A.N[bi]) {
+    D4EST_CASE(2) D4EST_CASE(3) D4EST_CASE(4) D4EST_CASE(5) D4EST_CASE(6) D4EST_CASE(7) D4EST_CASE(8)
+    default: break;
+  }
+#undef D4EST_CASE
+
 }
 
 __global__ __launch_bounds__(256) void generic_volume_kernel(
@@ -1834,8 +1871,39 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
 // which = 0: the quadrature interpolation B; 1: B^-1 (inverse mass); 2: 1-D mass M; 3: M^-1 (square nodal applies)
 template <int MODE>
 static void launch_mass_like_mode(d4est_hip_plan* plan, const double* in, double* out, const double* coeff, int which) {
+  unsigned covered = 0u;
+  if constexpr (MODE == 0 || MODE == 3) {
+    if (which == 0 && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0) {   // mixed-degree plans: one launch for the deg_quad = deg <= 7 buckets
+      WaveEoMulti A;
+      size_t lds = 0;
+      int wgs = 0;
+      for (size_t i = 0; i < plan->buckets.size() && i < 32; ++i) {
+        const Bucket& bk = plan->buckets[i];
+        if (bk.n_elem == 0 || bk.N != bk.NQ || bk.N < 2 || bk.N > 8 || !bk.d_EBf || A.n == WaveEoMulti::MAXB) continue;
+        size_t l = 0;
+        int epb = 1;
+#define X(N_) if (bk.N == N_) { l = WaveCfg<N_, N_>::LDS_BYTES; epb = WaveCfg<N_, N_>::EPB; }
+        X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#undef X
+        lds = std::max(lds, l);
+        wgs += (bk.n_elem + epb - 1) / epb;
+        const int j = A.n++;
+        A.wg_end[j] = wgs; A.N[j] = bk.N; A.n_elem[j] = bk.n_elem; A.elem_offset[j] = bk.elem_offset;
+        A.EBf[j] = bk.d_EBf; A.EBb[j] = bk.d_EBb; A.wq[j] = bk.d_w;
+        covered |= 1u << i;
+      }
+      if (A.n >= 2)
+        hipLaunchKernelGGL((mass_like_multi_kernel<MODE>), dim3(wgs), dim3(64), lds, plan->stream, in, out, plan->d_J, plan->d_ns_list,
+                           plan->d_qs_list, coeff, A);
+      else
+        covered = 0u;
+    }
+  }
+  size_t bucket_index = 0;
   for (const Bucket& bk : plan->buckets) {
+    const size_t this_bucket = bucket_index++;
     if (bk.n_elem == 0) continue;
+    if (this_bucket < 32 && ((covered >> this_bucket) & 1u)) continue;
     if (which == 1 && bk.N != bk.NQ) D4EST_HIP_ABORT("apply_inverse_mass_matrix needs deg_quad == deg (reference asserts the same, d4est_quadrature.c:1233)");
     const double* op = which == 0 ? bk.d_B : (which == 1 ? bk.d_BinvT : (which == 2 ? bk.d_M : bk.d_Minv));
     const double* opT = which == 0 ? bk.d_BT : (which == 1 ? bk.d_Binv : (which == 2 ? bk.d_MT : bk.d_MinvT));

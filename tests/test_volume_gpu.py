@@ -470,6 +470,20 @@ def test_stiffness_multi_bucket_launch(gpu, hiplib, oracle, curved):
     for e in range(m.n_elements):
         s = m.nodal_stride[e]; n3 = (deg[e] + 1) ** 3
         assert _rel(got[s:s + n3], ref[s:s + n3]) <= 10 * RTOL, (e, deg[e])
+    # the mass and weighted-mass applies of the same plan take the one-launch form too (mass_like_multi_kernel)
+    out = torch.full_like(du, float("nan"))
+    plan.apply_mass_matrix(du, out)
+    refm = oracle.apply_mass(m, J, u)
+    uq = oracle.interpolate(m, u)
+    coeff = 1.0 + uq * uq
+    outw = torch.full_like(du, float("nan"))
+    plan.apply_weighted_mass_matrix(du, _t(coeff, gpu), outw)
+    refw = oracle.apply_weighted_mass(m, J, coeff, u)
+    gm, gw = out.cpu().numpy(), outw.cpu().numpy()
+    for e in range(m.n_elements):
+        s = m.nodal_stride[e]; n3 = (deg[e] + 1) ** 3
+        assert _rel(gm[s:s + n3], refm[s:s + n3]) <= 10 * RTOL, (e, deg[e])
+        assert _rel(gw[s:s + n3], refw[s:s + n3]) <= 10 * RTOL, (e, deg[e])
     # the general path forced on the brick: the streamed-metric form of the same launch
     if not curved:
         plan.set_tuning(7, 0)
