@@ -26,34 +26,12 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "d4est_hip_direct.h"
 #include "d4est_hip_internal.h"
 #include "d4est_hip_tables.h"
 #include "d4est_hip_wave.h"
 
 namespace d4est_hip {
-
-struct DirectSide {
-  int kcf;             // kind | code << 2 | fp << 5:  kind 0 boundary, 1 interface with a local (+) element, 2 with a ghost (+) element;
-                       // code = flip0 | flip1<<1 | transpose<<2 applied when reading the (+) side; fp = face of the (+) element
-  int nbr_ns;          // nodal offset of the (+) element (kind 1)
-  int geom;            // scalar offset of the side's mortar data (7 combined factors at 7*geom; Dirichlet / Robin data at geom)
-  int pad;
-};
-// kind 2 only: offset of the (+) block in the ghost trace buffer, in its own array (read inside the ghost branch)
-typedef long long DirectGhostOff;
-
-struct DirectHost {
-  int N = 0, NQ = 0;
-  bool eo = false;
-  int ns0 = 0, ns_stride = 0;
-  DirectSide* d_sides = nullptr;
-  DirectGhostOff* d_ghost_off = nullptr;
-  double* d_ops = nullptr;   // C, CD, E, D^T E (plain: transposed; eo: even-odd tables), then rows 0 and N-1 of D
-  double* d_u2 = nullptr;    // second solution vector of the fused Chebyshev update (see cheby_iterate_body)
-  const int* d_list = nullptr;   // optional list of the elements the kernel works on (not owned; direct_set_element_list)
-  int n_list = 0;
-  mutable int order_ok = -1;     // 1: the plan's single bucket lists the elements in order (cached by direct_fused_ok)
-};
 
 // y = M x, M (NO x NI): tab = M transposed (NI x NO row-major), or the even-odd table of M when EO (NI, NO even; ANTI: M is
 // centro-antisymmetric) -- see stiffness_wave_eo_kernel for the table layout.  The EO form feeds its scalar operator rows through
@@ -120,22 +98,6 @@ struct DirectCfg {
 // kDirectWPB wavefronts = elements per workgroup (each wave works alone; fewer, larger workgroups launch faster: 4096
 // one-wave workgroups take ~10 us to get going at config 2)
 constexpr int kDirectWPB = 4;
-
-// VOL: the volume (stiffness) term of the element is applied by the same wavefront after its face terms and A u is written once --
-// one kernel for the whole operator (u in, A u out: no read-modify-write of A u, one launch).  The face result waits in 8 registers
-// per lane, in the layout of the volume kernel's coalesced store.
-struct DirectVol {
-  const double* metric = nullptr;    // 6 combined metric entries per quadrature node, element-blocked (plan->d_metric)
-  const double* EBf = nullptr;       // even-odd tables of the volume operators (Bucket::d_EBf ...)
-  const double* EGf = nullptr;
-  const double* EBb = nullptr;
-  const double* EGb = nullptr;
-  const double* affine = nullptr;    // AFF: 6 numbers per element
-  const double* wq = nullptr;        // AFF: quadrature weights
-  int qs0 = 0, qs_stride = 0;
-  const int* qs_list = nullptr;      // quadrature offset per element where the offsets are not affine (qs_stride < 0): a Schwarz
-                                     // subdomain plan, whose element copies alias the mesh's metric
-};
 
 #ifndef D4EST_HIP_DIRECT_GEOM_EARLY
 #define D4EST_HIP_DIRECT_GEOM_EARLY 1   /* both faces' geometric factors requested: 0 at their use, 1 before the SIPG loop, 2 with the neighbour lines */
@@ -581,7 +543,7 @@ static bool direct_pair_built(int N, int NQ) {
 #define X(N_, NQ_) if (N == N_ && NQ == NQ_) return true;
   D4EST_HIP_DIRECT_PAIRS(X)
 #undef X
-  return false;
+  return direct_mw_built(N, NQ);   // deg = deg_quad = 8 ... 15: the multi-wave kernel (d4est_hip_direct_mw.hip)
 }
 
 void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, const double* Cm, const double* CDm, const double* Em) {
@@ -590,6 +552,7 @@ void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, c
   const int ne = plan->n_elements;
   DirectHost* dh = new DirectHost;
   dh->N = N; dh->NQ = NQ; dh->ns0 = ns0; dh->ns_stride = ns_stride;
+  dh->mw = direct_mw_built(N, NQ);
   dh->eo = true;   // the even-odd products take sizes of either parity
   std::vector<double> Cv(Cm, Cm + (size_t)NQ * N), CDv(CDm, CDm + (size_t)NQ * N), Ev(Em, Em + (size_t)N * NQ);
   std::vector<double> D = Tables1D::dij(N - 1);
@@ -682,6 +645,10 @@ bool direct_fused_ok(const d4est_hip_plan* plan) {
     dh->order_ok = ok;
   }
   if (!dh->order_ok) return no("bucket order");
+  if (dh->mw) {
+    if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] == 0) return no("even-odd contractions switched off");
+    return true;
+  }
   const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
   if (!(tw < 0 || tw == 11)) return no("tuning key 1");   // the volume kernel whose body rides along must be the selected one
   return true;
@@ -697,8 +664,9 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
   if (n == 0) return;
   if (plan->ghost_trace_doubles > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has ghost sides but no ghost trace buffer was given");
   static const bool no_remap = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
-  const int n_wg = (n + kDirectWPB - 1) / kDirectWPB;
-  const int chunk = (n % (8 * kDirectWPB) == 0 && !no_remap) ? n_wg / 8 : 0;
+  const int wpb = dh->mw ? 1 : kDirectWPB;
+  const int n_wg = (n + wpb - 1) / wpb;
+  const int chunk = (n % (8 * wpb) == 0 && !no_remap) ? n_wg / 8 : 0;
   DirectVol vol;
   int vmode = 0;
   if (vol_term) {
@@ -710,7 +678,12 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
     const bool aff = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine;
     if (aff) { vol.affine = plan->d_metric_affine; vol.wq = bk.d_w; }
     vmode = aff ? 2 : 1;
-    std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::faces_direct_kernel<%d,%d,vol%s> (faces + stiffness_wave_eo body)", dh->N, dh->NQ, aff ? ",affine" : "");
+    if (dh->mw) std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::operator_mw_kernel<%d,vol%s> (stiffness_wave_kernel body + faces)", dh->N, aff ? ",affine" : "");
+    else std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::faces_direct_kernel<%d,%d,vol%s> (faces + stiffness_wave_eo body)", dh->N, dh->NQ, aff ? ",affine" : "");
+  }
+  if (dh->mw) {
+    launch_direct_mw(plan, dh, u, ghost_trace, Au, cf, robin_c, robin_r, vmode, vol, n, chunk);
+    return;
   }
   const DirectFuse cfv = cf ? *cf : DirectFuse{};
   bool done = false;

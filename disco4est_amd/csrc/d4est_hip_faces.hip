@@ -2136,7 +2136,8 @@ void faces_setup(d4est_hip_plan* plan) {
   }
   // uniform plan? (one degree, one mortar degree, contiguous element and trace strides)
   fh.uni = TraceUniform{};
-  if (fast && ne > 0 && !hp) {
+  TraceUniform un{};
+  if (ne > 0 && !hp) {
     bool uniform = true;
     const int N0 = edv[0].N, n3 = N0 * N0 * N0;
     for (int e = 0; e < ne && uniform; ++e) uniform = (edv[e].N == N0) && (edv[e].ns == edv[0].ns + e * n3);
@@ -2144,18 +2145,19 @@ void faces_setup(d4est_hip_plan* plan) {
     for (size_t s_ = 0; s_ < ns && uniform; ++s_)
       uniform = (sd[s_].NQ == sd[0].NQ) && (sd[s_].offC == sd[0].offC) && (sd[s_].offCD == sd[0].offCD) && (sd[s_].qoff == sd[0].qoff + (long long)s_ * qs);
     if (uniform) {
-      fh.uni.N = N0; fh.uni.NQ = sd[0].NQ; fh.uni.offC = sd[0].offC; fh.uni.offCD = sd[0].offCD; fh.uni.offD = edv[0].offD;
-      fh.uni.ns0 = edv[0].ns; fh.uni.ns_stride = n3; fh.uni.q0 = sd[0].qoff; fh.uni.q_stride = qs;
+      un.N = N0; un.NQ = sd[0].NQ; un.offC = sd[0].offC; un.offCD = sd[0].offCD; un.offD = edv[0].offD;
+      un.ns0 = edv[0].ns; un.ns_stride = n3; un.q0 = sd[0].qoff; un.q_stride = qs;
     }
   }
-  // the direct kernel (d4est_hip_direct.hip) takes over apply_aij on uniform conforming plans whose sides all see the local degree
+  if (fast) fh.uni = un;   // (the uniform forms of the trace kernels exist for N, NQ <= 8 only)
+  // the direct kernels (d4est_hip_direct.hip: one wavefront per element, deg_quad <= 7; d4est_hip_direct_mw.hip: one multi-wave
+  // workgroup per element, deg = deg_quad = 8 ... 15) take over apply_aij on uniform conforming plans whose sides all see the local degree
   direct_destroy(plan);
-  if (fh.uni.N > 0) {
+  if (un.N > 0) {
     bool same = true;
     for (size_t s_ = 0; s_ < ns && same; ++s_) same = (sd[s_].offE == sd[0].offE) && (deg_p_of[s_] == plan->deg[0]) && sd[s_].kind != 3;
-    if (same && sd[0].NQ * sd[0].NQ <= 64 && sd[0].NQ >= fh.uni.N)
-      direct_setup(plan, fh.uni.N, sd[0].NQ, fh.uni.ns0, fh.uni.ns_stride, ops.data() + fh.uni.offC, ops.data() + fh.uni.offCD,
-                   ops.data() + sd[0].offE);
+    if (same && sd[0].NQ >= un.N && (fast ? sd[0].NQ * sd[0].NQ <= 64 : true))
+      direct_setup(plan, un.N, sd[0].NQ, un.ns0, un.ns_stride, ops.data() + un.offC, ops.data() + un.offCD, ops.data() + sd[0].offE);
   }
   ops.resize(ops.size() + 64, 0.0);  // slack: the fast kernels read 64-entry images
   plan->d_elem_desc = upload_vec(edv);

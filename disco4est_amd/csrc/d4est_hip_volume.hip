@@ -23,6 +23,7 @@
 #include "d4est_hip_maps.h"
 #include "d4est_hip_tables.h"
 #include "d4est_hip_wave.h"
+#include "d4est_hip_mwave.h"
 
 namespace d4est_hip {
 
@@ -42,73 +43,6 @@ struct VolCfg {
   static constexpr size_t LDS_BYTES = (size_t)EPB * LDS_PER_ELEM * sizeof(double);
 };
 
-// ---- even-odd form of the same contractions (see stiffness_wave_eo_kernel below for the derivation and table layout):
-// tab = EO table of the operator, C/2 rows of R doubles, row = [first half | second half]
-// which EO contraction form a (C, R) pair uses: measured on MI355X with tools/sweep_p.py (GDoF/s pipelined | hoisted):
-// p=5 75.6|76.8, 7 81.5|83.1, 9 62.8|63.6, 11 51.1|48.7, 13 44.1|40.9, 15 39.9|46.8, 17 34.1|26.9, 19 38.7|18.5
-// (odd sizes, round 2: threshold 9 / 12 / 14 -> p = 10: 51.9 / 50.5 / 50.7, p = 12: 53.1 / 52.0 / 48.5 GDoF/s: 12 stays)
-template <int C, int R>
-constexpr bool kEoPipelined = ((C > R ? C : R) >= 12) && ((C > R ? C : R) != 16);
-
-
-// y (+)= M x for a centro-symmetric (ANTI = false) or centro-antisymmetric (ANTI = true) operator M (R x C, both even).
-// Each half of the EO rows is contracted in chunks of <= 8 outputs by the software-pipelined contract_single (two scalar
-// rows in flight, sched_barrier per step): without the pipelining barriers the compiler hoists every row load to the top and
-// spills 1000+ SGPRs at N >= 16.
-template <int C, int R, bool ANTI, bool ACC>
-__device__ __forceinline__ void apply_eo(const double* __restrict__ tab, const double* x, double* y) {
-  constexpr int HC = (C + 1) / 2, P1 = (R + 1) / 2, P2 = R / 2;   // table rows; outputs of the first / second input combination
-  double xe[HC], xo[HC], ab[R];
-  eo_pre<C>(x, xe, xo);
-  const double* xf = ANTI ? xo : xe;  // first part multiplies xe (symmetric) / xo (antisymmetric)
-  const double* xs = ANTI ? xe : xo;
-  if constexpr (kEoPipelined<C, R>) {
-    static_assert(P1 <= 24, "apply_eo: row parts longer than 24 are not supported");
-    constexpr int A0 = P1 < 8 ? P1 : 8, A1 = (P1 - 8 > 0) ? (P1 - 8 < 8 ? P1 - 8 : 8) : 0, A2 = (P1 - 16 > 0) ? P1 - 16 : 0;
-    constexpr int B0 = P2 < 8 ? P2 : 8, B1 = (P2 - 8 > 0) ? (P2 - 8 < 8 ? P2 - 8 : 8) : 0, B2 = (P2 - 16 > 0) ? P2 - 16 : 0;
-    contract_single<HC, A0, false, R>(tab, xf, ab);
-    if constexpr (A1 > 0) contract_single<HC, A1, false, R>(tab + 8, xf, ab + 8);
-    if constexpr (A2 > 0) contract_single<HC, A2, false, R>(tab + 16, xf, ab + 16);
-    if constexpr (B0 > 0) contract_single<HC, B0, false, R>(tab + P1, xs, ab + P1);
-    if constexpr (B1 > 0) contract_single<HC, B1, false, R>(tab + P1 + 8, xs, ab + P1 + 8);
-    if constexpr (B2 > 0) contract_single<HC, B2, false, R>(tab + P1 + 16, xs, ab + P1 + 16);
-  } else {
-    // free scheduling: the compiler hoists the row loads (deep memory-level parallelism, at the price of SGPR spills)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const double* xx = half == 0 ? xf : xs;
-      const int len = half == 0 ? P1 : P2;
-#pragma unroll
-      for (int o0 = 0; o0 < len; o0 += 8) {
-#pragma unroll
-        for (int c = 0; c < HC; ++c) {
-          sdouble_ptr row = launder(tab + c * R + half * P1 + o0);
-#pragma unroll
-          for (int o = 0; o < 8; ++o)
-            if (o0 + o < len) ab[half * P1 + o0 + o] = (c == 0) ? row[o] * xx[0] : fma(row[o], xx[c], ab[half * P1 + o0 + o]);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < R / 2; ++r) {
-    const double p = ab[r] + ab[P1 + r], m = ab[r] - ab[P1 + r];
-    y[r] = ACC ? y[r] + p : p;
-    y[R - 1 - r] = ACC ? y[R - 1 - r] + m : m;
-  }
-  if constexpr (R % 2 != 0) y[R / 2] = ACC ? y[R / 2] + ab[R / 2] : ab[R / 2];
-}
-// y = op x (operator given transposed, or as EO table when EO); y (+)= op^T x (operator itself, or EO table of op^T)
-template <int NI, int NO, bool EO, bool ANTI>
-__device__ __forceinline__ void fwd(const double* __restrict__ tab, const double* x, double* y) {
-  if constexpr (EO) apply_eo<NI, NO, ANTI, false>(tab, x, y);
-  else contract_n<NI, NO>(tab, x, y);
-}
-template <int NI, int NO, bool EO, bool ANTI, bool ACC>
-__device__ __forceinline__ void bwd(const double* __restrict__ tab, const double* x, double* y) {
-  if constexpr (EO) apply_eo<NI, NO, ANTI, ACC>(tab, x, y);
-  else contract_t<NI, NO, ACC>(tab, x, y);
-}
 
 // ---------------------------------------------------------------------------
 // stiffness:  Au_e = sum_{lp,l} D_lp^T V^T [ M_{lp,l} (V D_l u_e) ]
@@ -294,15 +228,6 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 // in a single resident round.
 // ---------------------------------------------------------------------------
 
-#ifndef D4EST_HIP_METRIC_DEPTH
-#define D4EST_HIP_METRIC_DEPTH 4
-#endif
-#ifndef D4EST_HIP_METRIC_EARLY
-#define D4EST_HIP_METRIC_EARLY 2
-#endif
-#ifndef D4EST_HIP_MW_WAVES
-#define D4EST_HIP_MW_WAVES 4
-#endif
 template <int N, int NQ, bool PF, bool EO = false, bool AFF = false>
 __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS == 64 ? (PF ? 3 : 4) : ((!AFF && N <= 13) ? D4EST_HIP_MW_WAVES : ((!AFF && N == 14) ? 3 : 1)))) void stiffness_wave_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
@@ -321,8 +246,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     for (int s_ = 0; s_ < stagger; ++s_) __builtin_amdgcn_s_sleep(16);  // 16 * 64 cycles per iteration
   }
   }
-  constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ, FS = C::FS;
-  constexpr int N3 = N * N * N, NQ3 = NQ * NQ * NQ;
+  constexpr int PL = C::PL, PN = C::PN, FS = C::FS;
   extern __shared__ __attribute__((aligned(16))) double smem[];
 
   const int tid = threadIdx.x;
@@ -349,242 +273,7 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
   if (active) {
     load_element_image<N, PL, PN>(R0, u + ns, te);
   }
-  double mreg[PF ? 6 : 1][PF ? NQ : 1];
-  if (PF && active) {
-    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
-#pragma unroll
-    for (int kq = 0; kq < NQ; ++kq)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) mreg[c][kq] = m[c * NQ3 + NQ * NQ * kq];
-  }
-  __syncthreads();
-
-  // ---- S1: r-contraction, thread (j=a, k=b); u column -> registers, then R0 <- B u, R1 <- G u as [k][iq][j]
-  {
-    double x[N], br[NQ], gr[NQ];
-    const bool on = active && a < N && b < N;
-    if (on) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) x[i] = lds_ld(&R0[i + PN * (a + N * b)]);
-      fwd<N, NQ, EO, false>(BopT, x, br);
-      fwd<N, NQ, EO, true>(GopT, x, gr);
-    }
-    __syncthreads();
-    if (on) {
-#pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) {
-        R0[a + PN * (iq + NQ * b)] = br[iq];
-        R1[a + PN * (iq + NQ * b)] = gr[iq];
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- S2 (thread (iq=a, k=b)) interleaved with S3 (thread (iq=a, jq=b)): one field at a time through R0
-  double gr[NQ], gs[NQ], gt[NQ];
-  // Multi-wave general path: the thread's 6 NQ metric values are requested MD quadrature planes ahead of their use.  Left to itself
-  // the compiler requests one plane's six values, waits for all of them, multiplies, requests the next: NQ serialised memory
-  // round trips in the middle of the element (12 at p = 11 -- most of an element's lifetime).  The registers for the planes in
-  // flight come from gr and gs, which wait in the (then idle) LDS fields in thread-private slots during this stage.
-  constexpr bool kPark = !PF && !AFF && C::THREADS > 64;
-  constexpr int MD = (D4EST_HIP_METRIC_DEPTH < NQ) ? D4EST_HIP_METRIC_DEPTH : NQ;
-  constexpr int ME = (D4EST_HIP_METRIC_EARLY < MD) ? D4EST_HIP_METRIC_EARLY : MD;   // planes requested before the last forward contraction
-  double mw[kPark ? NQ : 1][6];
-  {
-    double x1[N], x2[N], t[NQ], y[N];
-    const bool on2 = active && b < N;
-    if (on2) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        x1[j] = lds_ld(&R0[j + PN * (a + NQ * b)]);  // B_r u
-        x2[j] = lds_ld(&R1[j + PN * (a + NQ * b)]);  // G_r u
-      }
-    }
-    __syncthreads();
-    // field 1: B_s G_r u  -> gr = B_t(.)
-    if (on2) {
-      fwd<N, NQ, EO, false>(BopT, x2, t);
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < N; ++k) y[k] = lds_ld(&R0[k + PN * (a + NQ * b)]);
-      fwd<N, NQ, EO, false>(BopT, y, gr);
-    }
-    // field 2: G_s B_r u  -> gs = B_t(.)   (goes through R1 so the two transfers overlap)
-    if (on2) {
-      fwd<N, NQ, EO, true>(GopT, x1, t);
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) R1[b + PN * (a + NQ * jq)] = t[jq];
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < N; ++k) y[k] = lds_ld(&R1[k + PN * (a + NQ * b)]);
-      fwd<N, NQ, EO, false>(BopT, y, gs);
-    }
-    // field 3: B_s B_r u  -> gt = G_t(.)
-    if (on2) {
-      fwd<N, NQ, EO, false>(BopT, x1, t);
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) R0[b + PN * (a + NQ * jq)] = t[jq];
-    }
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int k = 0; k < N; ++k) y[k] = lds_ld(&R0[k + PN * (a + NQ * b)]);
-      if constexpr (kPark) {
-        // R1 is free from here on (every thread read field 2 before the barrier above): the finished line gr waits there, in the
-        // thread's own slots [kq][te] (conflict-free), while the registers it leaves carry metric planes in flight
-#pragma unroll
-        for (int kq = 0; kq < NQ; ++kq) R1[kq * PL + te] = gr[kq];
-        const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
-#pragma unroll
-        for (int kq = 0; kq < ME; ++kq)
-#pragma unroll
-          for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      fwd<N, NQ, EO, true>(GopT, y, gt);
-    }
-  }
-
-  // ---- quadrature-point stage
-  if constexpr (AFF) {
-    if (active) {
-    const double* __restrict__ c = affine + (size_t)6 * ei;
-    const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
-    const double wab = wq[b] * wq[a];
-#pragma unroll
-    for (int kq = 0; kq < NQ; ++kq) {
-      const double w3 = wq[kq] * wab;
-      const double r = w3 * gr[kq], s_ = w3 * gs[kq], t = w3 * gt[kq];
-      gr[kq] = c0 * r + c1 * s_ + c2 * t;
-      gs[kq] = c1 * r + c3 * s_ + c4 * t;
-      gt[kq] = c2 * r + c4 * s_ + c5 * t;
-    }
-    }
-  } else {
-    if constexpr (kPark) __syncthreads();   // every thread has read field 3: R0 is free as well
-    if (active) {
-    const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
-    if constexpr (kPark) {
-#pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) R0[kq * PL + te] = gs[kq];
-#pragma unroll
-      for (int kq = ME; kq < MD; ++kq)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
-      double rn = lds_ld(&R1[te]), sn = lds_ld(&R0[te]);
-#pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) {
-        if (kq + MD < NQ) {
-#pragma unroll
-          for (int c = 0; c < 6; ++c) mw[kq + MD][c] = m[c * NQ3 + NQ * NQ * (kq + MD)];
-        }
-        const double r = rn, s = sn, t = gt[kq];
-        if (kq + 1 < NQ) {
-          rn = lds_ld(&R1[(kq + 1) * PL + te]);
-          sn = lds_ld(&R0[(kq + 1) * PL + te]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        R1[kq * PL + te] = mw[kq][0] * r + mw[kq][1] * s + mw[kq][2] * t;
-        R0[kq * PL + te] = mw[kq][1] * r + mw[kq][3] * s + mw[kq][4] * t;
-        gt[kq] = mw[kq][2] * r + mw[kq][4] * s + mw[kq][5] * t;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) {
-        gr[kq] = lds_ld(&R1[kq * PL + te]);
-        gs[kq] = lds_ld(&R0[kq * PL + te]);
-      }
-    } else {
-#pragma unroll
-    for (int kq = 0; kq < NQ; ++kq) {
-      const int q = NQ * NQ * kq;
-      const double m0 = PF ? mreg[0][kq] : m[q], m1 = PF ? mreg[1][kq] : m[NQ3 + q], m2 = PF ? mreg[2][kq] : m[2 * NQ3 + q];
-      const double m3 = PF ? mreg[3][kq] : m[3 * NQ3 + q], m4 = PF ? mreg[4][kq] : m[4 * NQ3 + q], m5 = PF ? mreg[5][kq] : m[5 * NQ3 + q];
-      const double r = gr[kq], s = gs[kq], t = gt[kq];
-      gr[kq] = m0 * r + m1 * s + m2 * t;
-      gs[kq] = m1 * r + m3 * s + m4 * t;
-      gt[kq] = m2 * r + m4 * s + m5 * t;
-    }
-    }
-    }
-  }
-
-  // ---- S5 (thread (iq=a, jq=b), registers) interleaved with S6 (thread (iq=a, k=b)) through R0/R1
-  double ar[N], bs[N];
-  {
-    double c[N], x[NQ];
-    const bool on6 = active && b < N;
-    __syncthreads();
-    if (active) {
-      bwd<NQ, N, EO, false, false>(Bop, gr, c);
-#pragma unroll
-      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = c[k];  // [k][iq][jq]
-    }
-    __syncthreads();
-    if (on6) {
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R0[jq + PQ * (a + NQ * b)]);
-      bwd<NQ, N, EO, false, false>(Bop, x, ar);
-    }
-    if (active) {
-      bwd<NQ, N, EO, false, false>(Bop, gs, c);
-#pragma unroll
-      for (int k = 0; k < N; ++k) R1[b + PQ * (a + NQ * k)] = c[k];
-    }
-    __syncthreads();
-    if (on6) {
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R1[jq + PQ * (a + NQ * b)]);
-      bwd<NQ, N, EO, true, false>(Gop, x, bs);
-    }
-    if (active) {
-      bwd<NQ, N, EO, true, false>(Gop, gt, c);
-#pragma unroll
-      for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = c[k];
-    }
-    __syncthreads();
-    if (on6) {
-#pragma unroll
-      for (int jq = 0; jq < NQ; ++jq) x[jq] = lds_ld(&R0[jq + PQ * (a + NQ * b)]);
-      bwd<NQ, N, EO, false, true>(Bop, x, bs);
-    }
-    __syncthreads();
-    if (on6) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) {  // [k][j][iq]
-        R0[a + PQ * (j + N * b)] = ar[j];
-        R1[a + PQ * (j + N * b)] = bs[j];
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- S7: r-contraction transposed, thread (j=a, k=b)
-  {
-    double x[NQ], y[NQ], o[N];
-    const bool on = active && a < N && b < N;
-    if (on) {
-#pragma unroll
-      for (int iq = 0; iq < NQ; ++iq) {
-        x[iq] = lds_ld(&R0[iq + PQ * (a + N * b)]);
-        y[iq] = lds_ld(&R1[iq + PQ * (a + N * b)]);
-      }
-      bwd<NQ, N, EO, true, false>(Gop, x, o);
-      bwd<NQ, N, EO, false, true>(Bop, y, o);
-    }
-    __syncthreads();
-    if (on) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) R0[i + PN * (a + N * b)] = o[i];
-    }
-  }
-  __syncthreads();
+  stiffness_mw_element<N, NQ, PF, EO, AFF>(R0, R1, metric, qs, ei, active, te, a, b, Bop, Gop, BopT, GopT, affine, wq);
   if (active) {
     store_element_image<N, PL, PN>(Au + ns, R0, te);
   }

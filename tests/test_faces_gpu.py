@@ -5,8 +5,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-12
-# (deg + 1, deg_quad + 1) pairs the direct face kernel is instantiated for (csrc/d4est_hip_direct.hip: D4EST_HIP_DIRECT_PAIRS)
-DIRECT_PAIRS = {(n, n) for n in range(2, 9)} | {(2, 3), (3, 4), (4, 5), (3, 6), (4, 6)}
+# (deg + 1, deg_quad + 1) pairs the direct face kernels are instantiated for (csrc/d4est_hip_direct.hip: D4EST_HIP_DIRECT_PAIRS, one
+# wavefront per element; csrc/d4est_hip_direct_mw.hip: D4EST_HIP_DIRECT_MW_SIZES, one multi-wave workgroup per element, p = 8 ... 15)
+DIRECT_PAIRS = {(n, n) for n in range(2, 17)} | {(2, 3), (3, 4), (4, 5), (3, 6), (4, 6)}
 
 
 def _face_path_values(plan):
