@@ -46,6 +46,40 @@ struct DirectVol {
 };
 
 
+// The direct kernels are short of scalar registers (operator rows travel through them): arguments that are needed late -- the smoother's
+// vectors and coefficients, the volume term's tables, the side data pointers -- are NOT referenced as parameters (the compiler loads
+// every referenced parameter at entry and then spills it through v_writelane / v_readlane for the whole kernel) but read from the
+// kernel-argument segment where they are used.  DirectKernargs mirrors the parameter list: explicit arguments sit in the segment in
+// order at their natural alignment, i.e. exactly as the members of this struct (checked against the code object's .args offsets by
+// tests/test_capi.py::test_direct_kernarg_layout).
+struct DirectKernargs {
+  const double* u; const double* ghost_qtrace; double* Au; const DirectSide* sides; const DirectGhostOff* ghost_off;
+  const double* ops; const double* geom; const double* bndry_q; const double* robin_c; const double* robin_r;
+  int n_elem, ns0, ns_stride, xcd_chunk;
+  DirectFuse cf;
+  DirectVol vol;
+  const int* elem_list;
+};
+typedef const DirectKernargs __attribute__((address_space(4))) * direct_kargs_ptr;
+__device__ __forceinline__ direct_kargs_ptr direct_kargs() {
+  unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(v));   // one opaque pointer per use site: the loads below it cannot be hoisted to the kernel entry
+  return (direct_kargs_ptr)v;
+}
+
+__device__ __forceinline__ DirectFuse direct_load_fuse(direct_kargs_ptr K) {
+  DirectFuse c;
+  c.rhs = K->cf.rhs; c.p = K->cf.p; c.u_out = K->cf.u_out; c.r = K->cf.r;
+  c.alpha = K->cf.alpha; c.beta = K->cf.beta; c.skip_Au_store = K->cf.skip_Au_store;
+  return c;
+}
+__device__ __forceinline__ DirectVol direct_load_vol(direct_kargs_ptr K) {
+  DirectVol v;
+  v.metric = K->vol.metric; v.EBf = K->vol.EBf; v.EGf = K->vol.EGf; v.EBb = K->vol.EBb; v.EGb = K->vol.EGb;
+  v.affine = K->vol.affine; v.wq = K->vol.wq; v.qs0 = K->vol.qs0; v.qs_stride = K->vol.qs_stride; v.qs_list = K->vol.qs_list;
+  return v;
+}
+
 // d4est_hip_direct_mw.hip
 bool direct_mw_built(int N, int NQ);
 void launch_direct_mw(d4est_hip_plan* plan, DirectHost* dh, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,

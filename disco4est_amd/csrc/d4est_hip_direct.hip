@@ -119,40 +119,6 @@ __device__ __forceinline__ void direct_load_geom(double* gq, int kind, bool on, 
   }
 }
 
-// The kernel is short of scalar registers (operator rows travel through them): arguments that are needed late -- the smoother's
-// vectors and coefficients, the volume term's tables, the side data pointers -- are NOT referenced as parameters (the compiler loads
-// every referenced parameter at entry and then spills it through v_writelane / v_readlane for the whole kernel) but read from the
-// kernel-argument segment where they are used.  DirectKernargs mirrors the parameter list: explicit arguments sit in the segment in
-// order at their natural alignment, i.e. exactly as the members of this struct (checked against the code object's .args offsets by
-// tests/test_capi.py::test_direct_kernarg_layout).
-struct DirectKernargs {
-  const double* u; const double* ghost_qtrace; double* Au; const DirectSide* sides; const DirectGhostOff* ghost_off;
-  const double* ops; const double* geom; const double* bndry_q; const double* robin_c; const double* robin_r;
-  int n_elem, ns0, ns_stride, xcd_chunk;
-  DirectFuse cf;
-  DirectVol vol;
-  const int* elem_list;
-};
-typedef const DirectKernargs __attribute__((address_space(4))) * direct_kargs_ptr;
-__device__ __forceinline__ direct_kargs_ptr direct_kargs() {
-  unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(v));   // one opaque pointer per use site: the loads below it cannot be hoisted to the kernel entry
-  return (direct_kargs_ptr)v;
-}
-
-__device__ __forceinline__ DirectFuse direct_load_fuse(direct_kargs_ptr K) {
-  DirectFuse c;
-  c.rhs = K->cf.rhs; c.p = K->cf.p; c.u_out = K->cf.u_out; c.r = K->cf.r;
-  c.alpha = K->cf.alpha; c.beta = K->cf.beta; c.skip_Au_store = K->cf.skip_Au_store;
-  return c;
-}
-__device__ __forceinline__ DirectVol direct_load_vol(direct_kargs_ptr K) {
-  DirectVol v;
-  v.metric = K->vol.metric; v.EBf = K->vol.EBf; v.EGf = K->vol.EGf; v.EBb = K->vol.EBb; v.EGb = K->vol.EGb;
-  v.affine = K->vol.affine; v.wq = K->vol.wq; v.qs0 = K->vol.qs0; v.qs_stride = K->vol.qs_stride; v.qs_list = K->vol.qs_list;
-  return v;
-}
-
 template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 streamed metric, 2 affine metric */>
 __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
                                                              double* __restrict__ Au, const DirectSide* __restrict__ sides,
@@ -601,8 +567,11 @@ constexpr int kDirectMinElements = 768;
 
 bool direct_active(const d4est_hip_plan* plan) {
   const int t = plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT];
-  return plan->direct != nullptr && t != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
-         (t > 0 || plan->n_elements >= kDirectMinElements);
+  const DirectHost* dh = static_cast<const DirectHost*>(plan->direct);
+  // (the multi-wave kernel of p >= 8 puts a whole workgroup on an element and wins at every size measured: 64 elements at p = 11
+  // 29.8 us against 37.5 us two-phase, 512 elements 42 against 59, 4096 elements 220 against 315)
+  return dh != nullptr && t != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
+         (t > 0 || dh->mw || plan->n_elements >= kDirectMinElements);
 }
 
 void direct_set_element_list(d4est_hip_plan* plan, const int* list_dev, int n_list) {

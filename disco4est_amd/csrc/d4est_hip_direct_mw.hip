@@ -61,18 +61,54 @@ struct PassMap {
   __device__ static __forceinline__ int task(int slot) { return slot < nA ? slot : ((slot >= oB && slot < END) ? slot - oB + nA : -1); }
 };
 
-// y = (A or B) x for the line task of this thread; w0 = first slot of the thread's wavefront in this round (wave-uniform)
+#ifndef D4EST_HIP_MWD_ABLATE
+#define D4EST_HIP_MWD_ABLATE 0   /* timing experiments only (wrong results): 1 no line loads, 2 no products, 4 no volume term, 8 no factor loads, 16 no workgroup barriers in the face part */
+#endif
+#if (D4EST_HIP_MWD_ABLATE & 16)
+#define MW_SYNC() wave_lds_fence()
+#else
+#define MW_SYNC() __syncthreads()
+#endif
+#ifndef D4EST_HIP_MWD_WAVES
+#define D4EST_HIP_MWD_WAVES 4
+#endif
+
+// y = M x for a centro-symmetric / -antisymmetric (ANTI) N x N operator in the even-odd form: full table rows through one base pointer
+// (contract_rows_eo_imm: 2-3 scalar instructions per row)
+template <int N, bool ANTI>
+__device__ __forceinline__ void face_prod(const double* __restrict__ tab, const double* x, double* y) {
+  constexpr int HC = (N + 1) / 2;
+  double xe[HC], xo[HC], ab[N];
+  eo_pre<N>(x, xe, xo);
+  contract_rows_eo_imm<HC, N, false>(tab, ANTI ? xo : xe, ANTI ? xe : xo, ab);
+  eo_post<N>(ab, y);
+}
+
+// y = (A or B) x for the line task of this thread; w0 = first slot of the thread's wavefront in this round (wave-uniform: a wavefront
+// that holds tasks of one group issues that product alone, one that straddles the groups issues both and each thread keeps its own)
 template <int N, int nA, int oB, int END, bool ANTI_A, bool ANTI_B>
 __device__ __forceinline__ void pass_product(const double* __restrict__ tabA, const double* __restrict__ tabB, int w0, bool isB,
                                              const double* x, double* y) {
-  const bool hasA = w0 < nA, hasB = (w0 + 64 > oB) && (w0 < END);   // wave-uniform: a wavefront that straddles the groups issues both
+  if constexpr ((D4EST_HIP_MWD_ABLATE & 2) != 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = x[i];
+    return;
+  }
+  const bool hasA = w0 < nA, hasB = (w0 + 64 > oB) && (w0 < END);
+  if (!hasA && !hasB) return;   // no task in this wavefront (its threads' y is never stored)
   double ya[N], yb[N];
+  if (hasA && hasB) {
+    face_prod<N, ANTI_A>(tabA, x, ya);
+    face_prod<N, ANTI_B>(tabB, x, yb);
 #pragma unroll
-  for (int i = 0; i < N; ++i) ya[i] = yb[i] = 0.0;
-  if (hasA) fwd<N, N, true, ANTI_A>(tabA, x, ya);
-  if (hasB) fwd<N, N, true, ANTI_B>(tabB, x, yb);
+    for (int i = 0; i < N; ++i) ya[i] = isB ? yb[i] : ya[i];
+  } else if (hasB) {
+    face_prod<N, ANTI_B>(tabB, x, ya);
+  } else {
+    face_prod<N, ANTI_A>(tabA, x, ya);
+  }
 #pragma unroll
-  for (int i = 0; i < N; ++i) y[i] = isB ? yb[i] : ya[i];
+  for (int i = 0; i < N; ++i) y[i] = ya[i];
 }
 
 template <int N>
@@ -88,11 +124,19 @@ __device__ __forceinline__ double mw_row_dot(const double* __restrict__ drow, co
   return s;
 }
 
-#ifndef D4EST_HIP_MWD_WAVES
-#define D4EST_HIP_MWD_WAVES 4
-#endif
+// task of a thread in a pass, packed: line-in-field | field-or-group index << 8 | group B << 30; -1: none
+template <typename PM, int N, int nA>
+__device__ __forceinline__ int pack_task(int slot) {
+  const int tk = PM::task(slot);
+  if (tk < 0) return -1;
+  const bool isB = tk >= nA;
+  const int l = isB ? tk - nA : tk;
+  return (l % N) | ((l / N) << 8) | (isB ? (1 << 30) : 0);
+}
 
-// VOL: 0 the face terms only (Au += ...), 1 the whole operator with the streamed metric, 2 with the affine metric
+// VOL: 0 the face terms only (Au += ...), 1 the whole operator with the streamed metric, 2 with the affine metric.
+// The parameter list is faces_direct_kernel's (DirectKernargs mirrors it: arguments needed late are read from the kernel-argument
+// segment at their use instead of being held -- and spilled -- in scalar registers for the whole kernel).
 template <int N, bool FUSE, int VOL>
 __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES : (N == 14 ? 3 : 2))) void operator_mw_kernel(
     const double* __restrict__ u, const double* __restrict__ ghost_qtrace, double* __restrict__ Au, const DirectSide* __restrict__ sides,
@@ -104,11 +148,11 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* R0 = smem;            // u_e, then (K u)_e, then the accumulator of the lifted face terms: [i + PN (j + N k)]
   double* S = smem + C::FS;     // second field of the volume term, then the transposition buffer of the face passes
-  const double* tC = ops;
-  const double* tCD = ops + C::OPSZ;
-  const double* tE = ops + 2 * C::OPSZ;
-  const double* tDtE = ops + 3 * C::OPSZ;
-  const double* dr0 = ops + 4 * C::OPSZ;   // D[0][:], then D[N-1][:]
+#define tC (ops)
+#define tCD (ops + C::OPSZ)
+#define tE (ops + 2 * C::OPSZ)
+#define tDtE (ops + 3 * C::OPSZ)
+#define dr0 (ops + 4 * C::OPSZ) /* D[0][:], then D[N-1][:] */
 
   const int te = threadIdx.x;
   const int a = te % N, b = te / N;
@@ -125,146 +169,160 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
   // ---- R0 <- (K u)_e, or the A u the face terms are added to
   if constexpr (VOL != 0) {
     if (on) load_element_image<N, PL, PN>(R0, u + ns, te);
-    const int qs = __builtin_amdgcn_readfirstlane(vol.qs_stride >= 0 ? vol.qs0 + e * vol.qs_stride : vol.qs_list[e]);
-    stiffness_mw_element<N, N, false, true, VOL == 2>(R0, S, vol.metric, qs, e, on, te, a, b, vol.EBb, vol.EGb, vol.EBf, vol.EGf,
-                                                      vol.affine, vol.wq);
+    const DirectVol vl = direct_load_vol(direct_kargs());
+    const int qs = __builtin_amdgcn_readfirstlane(vl.qs_stride >= 0 ? vl.qs0 + e * vl.qs_stride : vl.qs_list[e]);
+    if constexpr ((D4EST_HIP_MWD_ABLATE & 4) == 0)
+      stiffness_mw_element<N, N, false, true, VOL == 2>(R0, S, vl.metric, qs, e, on, te, a, b, vl.EBb, vl.EGb, vl.EBf, vl.EGf,
+                                                        vl.affine, vl.wq);
+    else __syncthreads();
   } else {
-    if (on) load_element_image<N, PL, PN>(R0, Au + ns, te);
+    if (on) load_element_image<N, PL, PN>(R0, direct_kargs()->Au + ns, te);
     __syncthreads();
   }
+
+  // ---- the thread's line tasks in the four passes (the same in every direction; packed: see pack_task)
+  using PM1 = PassMap<TH, 8 * N, 4 * N>;    // C on the 8 nodal fields | C D on the 4 trace fields
+  using PM2 = PassMap<TH, 12 * N, 4 * N>;   // C on P_0..7, R_0..3 | C D on P_0..3
+  using PM3 = PassMap<TH, 6 * N, 2 * N>;    // E on six term fields | D^T E on the two that are differentiated along a
+  using PM4 = PassMap<TH, 4 * N, 2 * N>;    // E: (h, g) = (0,0) (0,2) (1,0) (1,2) | D^T E: (0,1) (1,1)
+  int tk1[PM1::ROUNDS], tk2[PM2::ROUNDS], tk3[PM3::ROUNDS], tk4[PM4::ROUNDS];
+#pragma unroll
+  for (int r = 0; r < PM1::ROUNDS; ++r) tk1[r] = pack_task<PM1, N, 8 * N>(te + r * TH);
+#pragma unroll
+  for (int r = 0; r < PM2::ROUNDS; ++r) tk2[r] = pack_task<PM2, N, 12 * N>(te + r * TH);
+#pragma unroll
+  for (int r = 0; r < PM3::ROUNDS; ++r) tk3[r] = pack_task<PM3, N, 6 * N>(te + r * TH);
+#pragma unroll
+  for (int r = 0; r < PM4::ROUNDS; ++r) tk4[r] = pack_task<PM4, N, 4 * N>(te + r * TH);
+  const int ab_rs = b * RS + a;
 
   auto dir_body = [&](auto dc) {
     constexpr int d = decltype(dc)::value;
     constexpr int t0 = (d == 0) ? 1 : 0, t1d = (d == 2) ? 1 : 2;   // reference directions of the face indices a and b
-    const DirectSide* sd = sides + 6 * (size_t)e + 2 * d;
-    int kcf[2], sgeom[2], nbr_ns[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      kcf[h] = __builtin_amdgcn_readfirstlane(sd[h].kcf);
-      sgeom[h] = __builtin_amdgcn_readfirstlane(sd[h].geom);
-      nbr_ns[h] = __builtin_amdgcn_readfirstlane(sd[h].nbr_ns);
-    }
+    // (the descriptor array is read-only for the kernel's lifetime: constant address space, so its fields are scalar loads)
+    typedef const DirectSide __attribute__((address_space(4))) * sside_ptr;
+    const sside_ptr sd = (sside_ptr)(unsigned long long)(direct_kargs()->sides + 6 * (size_t)e + 2 * d);
+    const int kcf[2] = {sd[0].kcf, sd[1].kcf};
+    const int sgeom[2] = {sd[0].geom, sd[1].geom};
     // ---- nodal fields of the two faces at face node (a, b): c = 0..3 trace (own 2d, own 2d+1, nbr 2d, nbr 2d+1), c = 4..7 normal
     // derivative.  The normal lines of the element and of the two (+) elements (at THEIR face node (a, b)) are requested together.
     double fld[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    {
+    if (on) {
       double xo[N], yy[2][N];
+      const double* __restrict__ up = u + ns;
+      constexpr int st = (d == 0) ? 1 : (d == 1 ? N : N2);
+      const int o0 = (d == 0) ? N * te : (d == 1 ? a + N2 * b : te);   // N a + N2 b = N te;  a + N b = te
 #pragma unroll
-      for (int i = 0; i < N; ++i) xo[i] = yy[0][i] = yy[1][i] = 0.0;
-      if (on) {
-        const double* __restrict__ up = u + ns;
-        constexpr int st = (d == 0) ? 1 : (d == 1 ? N : N2);
-        const int o0 = (d == 0) ? N * a + N2 * b : (d == 1 ? a + N2 * b : a + N * b);
+      for (int i = 0; i < N; ++i) xo[i] = (D4EST_HIP_MWD_ABLATE & 1) ? 1.0 + i : up[o0 + st * i];
 #pragma unroll
-        for (int i = 0; i < N; ++i) xo[i] = up[o0 + st * i];
+      for (int h = 0; h < 2; ++h) {
+        if ((kcf[h] & 3) == 1) {
+          const double* __restrict__ upn = u + sd[h].nbr_ns;
+          const int dp = kcf[h] >> 6;
+          const int stn = (dp == 0) ? 1 : (dp == 1 ? N : N2);
+          const int on0 = (dp == 0) ? N * te : (dp == 1 ? a + N2 * b : te);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if ((kcf[h] & 3) == 1) {
-            const double* __restrict__ upn = u + nbr_ns[h];
-            const int dp = kcf[h] >> 6;
-            const int stn = (dp == 0) ? 1 : (dp == 1 ? N : N2);
-            const int on0 = (dp == 0) ? N * a + N2 * b : (dp == 1 ? a + N2 * b : a + N * b);
-#pragma unroll
-            for (int i = 0; i < N; ++i) yy[h][i] = upn[on0 + stn * i];
-          }
+          for (int i = 0; i < N; ++i) yy[h][i] = (D4EST_HIP_MWD_ABLATE & 1) ? 2.0 + i + stn + on0 : upn[on0 + stn * i];
         }
-        fld[0] = xo[0];
-        fld[1] = xo[N - 1];
-        fld[4] = mw_row_dot<N>(dr0, xo);
-        fld[5] = mw_row_dot<N>(dr0 + N, xo);
+      }
+      fld[0] = xo[0];
+      fld[1] = xo[N - 1];
+      fld[4] = mw_row_dot<N>(dr0, xo);
+      fld[5] = mw_row_dot<N>(dr0 + N, xo);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if ((kcf[h] & 3) == 1) {
-            const int hi = (kcf[h] >> 5) & 1;
-            fld[2 + h] = hi ? yy[h][N - 1] : yy[h][0];
-            fld[6 + h] = mw_row_dot<N>(dr0 + hi * N, yy[h]);
-          }
+      for (int h = 0; h < 2; ++h) {
+        if ((kcf[h] & 3) == 1) {
+          const int hi = (kcf[h] >> 5) & 1;
+          fld[2 + h] = hi ? yy[h][N - 1] : yy[h][0];
+          fld[6 + h] = mw_row_dot<N>(dr0 + hi * N, yy[h]);
         }
       }
     }
     // ---- pass 1: line (field c, b), contract the face index a:  P_c = C x_c (c = 0..7), R_c = C D x_c (trace fields c = 0..3)
-    __syncthreads();   // (the buffer's last readers: the volume term / the previous direction's line update)
+    MW_SYNC();   // (the buffer's last readers: the volume term / the previous direction's line update)
     if (on) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) S[(c * N + b) * RS + a] = fld[c];
+      for (int c = 0; c < 8; ++c) S[c * N * RS + ab_rs] = fld[c];
     }
-    __syncthreads();
+    MW_SYNC();
     {
-      using PM = PassMap<TH, 8 * N, 4 * N>;
-      double x[PM::ROUNDS][N], y[PM::ROUNDS][N];
-      int tk[PM::ROUNDS];
+      double x[PM1::ROUNDS][N], y[PM1::ROUNDS][N];
 #pragma unroll
-      for (int r = 0; r < PM::ROUNDS; ++r) {
-        tk[r] = PM::task(te + r * TH);
-        const int line = tk[r] < 8 * N ? tk[r] : tk[r] - 8 * N;
+      for (int r = 0; r < PM1::ROUNDS; ++r) {   // (threads without a task read line 0: their product goes nowhere)
+        const int in = tk1[r] < 0 ? 0 : (((tk1[r] >> 8) & 0xff) * N + (tk1[r] & 0xff)) * RS;
 #pragma unroll
-        for (int i = 0; i < N; ++i) x[r][i] = tk[r] >= 0 ? lds_ld(&S[line * RS + i]) : 0.0;
+        for (int i = 0; i < N; ++i) x[r][i] = lds_ld(&S[in + i]);
       }
-      __syncthreads();
+      MW_SYNC();
 #pragma unroll
-      for (int r = 0; r < PM::ROUNDS; ++r) {
-        pass_product<N, 8 * N, PM::oB, PM::END, false, true>(tC, tCD, wave0 + r * TH, tk[r] >= 8 * N, x[r], y[r]);
-        if (tk[r] >= 0) {   // output field tk / N (0..7: P_c, 8..11: R_c), line b = tk % N: [field][a'][b]
-          const int fo = tk[r] / N, lb = tk[r] % N;
+      for (int r = 0; r < PM1::ROUNDS; ++r) {
+        const bool isB = (tk1[r] >> 30) & 1;
+        pass_product<N, 8 * N, PM1::oB, PM1::END, false, true>(tC, tCD, wave0 + r * TH, isB, x[r], y[r]);
+        if (tk1[r] >= 0) {   // output field 0..7: P_c, 8..11: R_c; line b: [field][a'][b]
+          const int out = (((tk1[r] >> 8) & 0xff) + (isB ? 8 : 0)) * GS + (tk1[r] & 0xff);
 #pragma unroll
-          for (int q = 0; q < N; ++q) S[fo * GS + q * RS + lb] = y[r][q];
+          for (int q = 0; q < N; ++q) S[out + q * RS] = y[r][q];
         }
       }
     }
-    __syncthreads();
+    MW_SYNC();
     // ---- pass 2: line (field, a'), contract the face index b:  u = C P_c, du/dn = C P_{4+c}, du/dt_a = C R_c | du/dt_b = C D P_c
-    using PM2 = PassMap<TH, 12 * N, 4 * N>;
     double o2[PM2::ROUNDS][N];
-    int tk2[PM2::ROUNDS];
     {
       double x[PM2::ROUNDS][N];
 #pragma unroll
       for (int r = 0; r < PM2::ROUNDS; ++r) {
-        tk2[r] = PM2::task(te + r * TH);
-        const int line = tk2[r] < 12 * N ? tk2[r] : tk2[r] - 12 * N;   // = field * N + a'
+        const int in = tk2[r] < 0 ? 0 : ((tk2[r] >> 8) & 0xff) * GS + (tk2[r] & 0xff) * RS;
 #pragma unroll
-        for (int i = 0; i < N; ++i) x[r][i] = tk2[r] >= 0 ? lds_ld(&S[(line / N) * GS + (line % N) * RS + i]) : 0.0;
+        for (int i = 0; i < N; ++i) x[r][i] = lds_ld(&S[in + i]);
       }
 #pragma unroll
       for (int r = 0; r < PM2::ROUNDS; ++r)
-        pass_product<N, 12 * N, PM2::oB, PM2::END, false, true>(tC, tCD, wave0 + r * TH, tk2[r] >= 12 * N, x[r], o2[r]);
+        pass_product<N, 12 * N, PM2::oB, PM2::END, false, true>(tC, tCD, wave0 + r * TH, (tk2[r] >> 30) & 1, x[r], o2[r]);
     }
     // ---- SIPG terms, one face at a time (the mortar values of its two sides go through the buffer)
     double At[2][4];
     double gqa[2][7];
+    {
+      const direct_kargs_ptr K = direct_kargs();
+      const double* __restrict__ geom_ = K->geom;
+      const double* __restrict__ robin_c_ = K->robin_c;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int c = 0; c < 7; ++c) gqa[h][c] = 0.0;
-      if (on) {
-        const int kind = kcf[h] & 3;
-        if (kind == 0 && robin_c) {
-          gqa[h][6] = robin_c[sgeom[h] + te];   // am = ap = 0: no term 1 / term 2 on a Robin side
-        } else {
-          const double* __restrict__ g = geom + (size_t)7 * sgeom[h] + te;
+        for (int c = 0; c < 7; ++c) gqa[h][c] = 0.0;
+        if (on) {
+          if ((kcf[h] & 3) == 0 && robin_c_) {
+            gqa[h][6] = robin_c_[sgeom[h] + te];   // am = ap = 0: no term 1 / term 2 on a Robin side
+          } else {
+            const double* __restrict__ g = geom_ + (size_t)7 * sgeom[h] + te;
 #pragma unroll
-          for (int c = 0; c < 7; ++c) gqa[h][c] = g[c * T];
+            for (int c = 0; c < 7; ++c) gqa[h][c] = (D4EST_HIP_MWD_ABLATE & 8) ? 0.5 + c : g[c * T];
+          }
         }
       }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      __syncthreads();
+      MW_SYNC();
 #pragma unroll
       for (int r = 0; r < PM2::ROUNDS; ++r) {
         if (tk2[r] >= 0) {
-          const int g = tk2[r] / (4 * N), c = (tk2[r] / N) & 3, aq = tk2[r] % N;   // g: 0 u, 1 du/dn, 2 du/dt_a, 3 du/dt_b
+          // field index f = 0..11 (group A: P_c, P_{4+c}, R_c) or 0..3 (group B: P_c); c = f & 3: (own h0, own h1, nbr h0, nbr h1)
+          const int f = (tk2[r] >> 8) & 0xff, c = f & 3, aq = tk2[r] & 0xff;
+          const int g = ((tk2[r] >> 30) & 1) ? 3 : (f >> 2);   // 0 u, 1 du/dn, 2 du/dt_a, 3 du/dt_b
           if ((c & 1) == h) {
             const int mp = c >> 1;
             const int dn = mp ? (kcf[h] >> 6) : d;   // the reference frame of the side that owns the trace
             const int ta = (dn == 0) ? 1 : 0, tb = (dn == 2) ? 1 : 2;
             const int comp = (g == 0) ? 0 : (g == 1 ? 1 + dn : (g == 2 ? 1 + ta : 1 + tb));
+            const int out = (mp * 4 + comp) * QS + aq;
 #pragma unroll
-            for (int q = 0; q < N; ++q) S[(mp * 4 + comp) * QS + aq + N * q] = o2[r][q];
+            for (int q = 0; q < N; ++q) S[out + N * q] = o2[r][q];
           }
         }
       }
-      __syncthreads();
+      MW_SYNC();
       double qm[4] = {0, 0, 0, 0}, qp[4] = {0, 0, 0, 0};
       const int kind = kcf[h] & 3, code = (kcf[h] >> 2) & 7;
       if (on) {
@@ -276,13 +334,13 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
 #pragma unroll
           for (int c = 0; c < 4; ++c) qp[c] = lds_ld(&S[(4 + c) * QS + kp]);
         } else if (kind == 2) {
-          const double* __restrict__ p = ghost_qtrace + ghost_off[6 * (size_t)e + 2 * d + h] + reorder_index(code, N - 1, a, b);
+          const direct_kargs_ptr K = direct_kargs();
+          const double* __restrict__ p = K->ghost_qtrace + K->ghost_off[6 * (size_t)e + 2 * d + h] + reorder_index(code, N - 1, a, b);
 #pragma unroll
           for (int c = 0; c < 4; ++c) qp[c] = p[c * T];
-        } else if (robin_c) {
-          qp[0] = robin_r[sgeom[h] + k];
         } else {
-          qp[0] = bndry_q[sgeom[h] + k];
+          const direct_kargs_ptr K = direct_kargs();
+          qp[0] = K->robin_c ? K->robin_r[sgeom[h] + k] : K->bndry_q[sgeom[h] + k];
         }
       }
       // interface: t1 = -1/2 sj n.(grad u_m + grad u_p), t2_l = -1/2 am_l [u]; boundary: t1 = -sj n.grad u_m, t2_l = -am_l (u - g)
@@ -292,86 +350,85 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
       for (int i = 0; i < 3; ++i) t1 += gqa[h][i] * qm[1 + i] + gqa[h][3 + i] * qp[1 + i];   // gq[3..5] = 0 on boundary sides
       const double jump = qm[0] - qp[0];
       const double w1 = (kind != 0) ? -0.5 : -1.0;
-      At[h][0] = (kind == 0 && robin_c) ? gqa[h][6] * qm[0] - qp[0] : w1 * t1 + gqa[h][6] * jump;
+      const bool robin = kind == 0 && direct_kargs()->robin_c;
+      At[h][0] = robin ? gqa[h][6] * qm[0] - qp[0] : w1 * t1 + gqa[h][6] * jump;
 #pragma unroll
       for (int l = 0; l < 3; ++l) At[h][1 + l] = w1 * gqa[h][l] * jump;
     }
     // ---- lift pass 1: line (term field 4 h + c, b'), contract a':  E, and D^T E for the term-2 field that is differentiated along a
     // (val = E_b E_a A0 + E_b (D^T E)_a A_t0 + (D^T E)_b E_a A_t1)
-    __syncthreads();
+    MW_SYNC();
     if (on) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) S[((4 * h + c) * N + b) * RS + a] = At[h][c];
+        for (int c = 0; c < 4; ++c) S[(4 * h + c) * N * RS + ab_rs] = At[h][c];
     }
-    __syncthreads();
+    MW_SYNC();
     {
-      using PM = PassMap<TH, 6 * N, 2 * N>;
-      double x[PM::ROUNDS][N], y[PM::ROUNDS][N];
-      int fl[PM::ROUNDS], lb[PM::ROUNDS];
-      bool isB[PM::ROUNDS];
+      double x[PM3::ROUNDS][N], y[PM3::ROUNDS][N];
+      int fl[PM3::ROUNDS];
 #pragma unroll
-      for (int r = 0; r < PM::ROUNDS; ++r) {
-        const int tk = PM::task(te + r * TH);
-        isB[r] = tk >= 6 * N;
-        // group A: the six fields (h, c != 1 + t0); group B: (h, 1 + t0)
-        const int j = (isB[r] ? tk - 6 * N : tk) / N;
-        const int hh = isB[r] ? j : j / 3, rr = j % 3;
-        const int c = isB[r] ? 1 + t0 : rr + (rr >= 1 + t0 ? 1 : 0);
-        fl[r] = tk >= 0 ? 4 * hh + c : -1;
-        lb[r] = (tk >= 0 ? tk : 0) % N;
+      for (int r = 0; r < PM3::ROUNDS; ++r) {
+        // group A: the six fields (h, c != 1 + t0), j = 3 h + rank of c; group B: (h = j, 1 + t0)
+        const int j = (tk3[r] >> 8) & 0xff;
+        const bool isB = (tk3[r] >> 30) & 1;
+        const int hh = isB ? j : (j >= 3 ? 1 : 0), rr = j - 3 * hh;
+        const int c = isB ? 1 + t0 : rr + (rr >= 1 + t0 ? 1 : 0);
+        fl[r] = tk3[r] < 0 ? 0 : 4 * hh + c;
+        const int in = tk3[r] < 0 ? 0 : (fl[r] * N + (tk3[r] & 0xff)) * RS;
 #pragma unroll
-        for (int i = 0; i < N; ++i) x[r][i] = tk >= 0 ? lds_ld(&S[(fl[r] * N + lb[r]) * RS + i]) : 0.0;
+        for (int i = 0; i < N; ++i) x[r][i] = lds_ld(&S[in + i]);
       }
-      __syncthreads();
+      MW_SYNC();
 #pragma unroll
-      for (int r = 0; r < PM::ROUNDS; ++r) {
-        pass_product<N, 6 * N, PM::oB, PM::END, false, true>(tE, tDtE, wave0 + r * TH, isB[r], x[r], y[r]);
-        if (fl[r] >= 0) {   // [field][a][b']
+      for (int r = 0; r < PM3::ROUNDS; ++r) {
+        pass_product<N, 6 * N, PM3::oB, PM3::END, false, true>(tE, tDtE, wave0 + r * TH, (tk3[r] >> 30) & 1, x[r], y[r]);
+        if (tk3[r] >= 0) {   // [field][a][b']
+          const int out = fl[r] * GS + (tk3[r] & 0xff);
 #pragma unroll
-          for (int i = 0; i < N; ++i) S[fl[r] * GS + i * RS + lb[r]] = y[r][i];
+          for (int i = 0; i < N; ++i) S[out + i * RS] = y[r][i];
         }
       }
     }
-    __syncthreads();
+    MW_SYNC();
     // ---- lift pass 2: line (h, g, a), contract b': g = 0 face-local part through E, 1 term 2 along b through D^T E, 2 normal term 2
     {
-      using PM = PassMap<TH, 4 * N, 2 * N>;
-      double x[PM::ROUNDS][N], y[PM::ROUNDS][N];
-      int blk[PM::ROUNDS], la[PM::ROUNDS];
-      bool isB[PM::ROUNDS];
+      double x[PM4::ROUNDS][N], y[PM4::ROUNDS][N];
+      int blk[PM4::ROUNDS];
 #pragma unroll
-      for (int r = 0; r < PM::ROUNDS; ++r) {
-        const int tk = PM::task(te + r * TH);
-        isB[r] = tk >= 4 * N;
-        const int j = (isB[r] ? tk - 4 * N : tk) / N;   // group A: (h, g) = (0,0) (0,2) (1,0) (1,2); group B: (0,1) (1,1)
-        const int vh = isB[r] ? j : j >> 1, vg = isB[r] ? 1 : 2 * (j & 1);
-        la[r] = (tk >= 0 ? tk : 0) % N;
-        blk[r] = tk >= 0 ? 3 * vh + vg : -1;
+      for (int r = 0; r < PM4::ROUNDS; ++r) {
+        const int j = (tk4[r] >> 8) & 0xff, la = tk4[r] & 0xff;
+        const bool isB = (tk4[r] >> 30) & 1;
+        const int vh = isB ? j : j >> 1, vg = isB ? 1 : 2 * (j & 1);
+        blk[r] = 3 * vh + vg;
         const int f1 = (vg == 0) ? 0 : (vg == 1 ? 1 + t1d : 1 + d);
+        const int in = tk4[r] < 0 ? 0 : (4 * vh + f1) * GS + la * RS;
+        const int in2 = (4 * vh + 1 + t0) * GS + la * RS;
+        const bool two = tk4[r] >= 0 && vg == 0;
 #pragma unroll
         for (int q = 0; q < N; ++q) {
-          double t = tk >= 0 ? lds_ld(&S[(4 * vh + f1) * GS + la[r] * RS + q]) : 0.0;
-          if (tk >= 0 && vg == 0) t += lds_ld(&S[(4 * vh + 1 + t0) * GS + la[r] * RS + q]);
+          double t = lds_ld(&S[in + q]);
+          if (two) t += lds_ld(&S[in2 + q]);
           x[r][q] = t;
         }
       }
-      __syncthreads();
+      MW_SYNC();
 #pragma unroll
-      for (int r = 0; r < PM::ROUNDS; ++r) {
-        pass_product<N, 4 * N, PM::oB, PM::END, false, true>(tE, tDtE, wave0 + r * TH, isB[r], x[r], y[r]);
-        if (blk[r] >= 0) {
+      for (int r = 0; r < PM4::ROUNDS; ++r) {
+        pass_product<N, 4 * N, PM4::oB, PM4::END, false, true>(tE, tDtE, wave0 + r * TH, (tk4[r] >> 30) & 1, x[r], y[r]);
+        if (tk4[r] >= 0) {
+          const int out = blk[r] * VS + (tk4[r] & 0xff);
 #pragma unroll
-          for (int i = 0; i < N; ++i) S[blk[r] * VS + i * N + la[r]] = y[r][i];
+          for (int i = 0; i < N; ++i) S[out + i * N] = y[r][i];
         }
       }
     }
-    __syncthreads();
+    MW_SYNC();
     // ---- the element's normal line at face node (a, b): face-local part at its two ends, D^T of the normal term 2 along it
     if (on) {
-      const double val0 = lds_ld(&S[0 * VS + b * N + a]) + lds_ld(&S[1 * VS + b * N + a]), n0 = lds_ld(&S[2 * VS + b * N + a]);
-      const double val1 = lds_ld(&S[3 * VS + b * N + a]) + lds_ld(&S[4 * VS + b * N + a]), n1 = lds_ld(&S[5 * VS + b * N + a]);
+      const double val0 = lds_ld(&S[0 * VS + te]) + lds_ld(&S[1 * VS + te]), n0 = lds_ld(&S[2 * VS + te]);
+      const double val1 = lds_ld(&S[3 * VS + te]) + lds_ld(&S[4 * VS + te]), n1 = lds_ld(&S[5 * VS + te]);
       double acc[N];
 #pragma unroll
       for (int o0 = 0; o0 < N; o0 += 8) {
@@ -382,11 +439,10 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
       }
       acc[0] += val0;
       acc[N - 1] += val1;
+      const int base = (d == 0) ? PN * te : (d == 1 ? a + PN * N * b : a + PN * b);
+      constexpr int str = (d == 0) ? 1 : (d == 1 ? PN : PN * N);
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        const int idx = (d == 0) ? i + PN * (a + N * b) : (d == 1 ? a + PN * (i + N * b) : a + PN * (b + N * i));
-        R0[idx] += acc[i];
-      }
+      for (int i = 0; i < N; ++i) R0[base + str * i] += acc[i];
     }
   };
   dir_body(std::integral_constant<int, 0>{});
@@ -399,7 +455,9 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
   if (on) {
     constexpr int NL = N;   // PL = N^2: one k-plane per pass
     const int ij = (te % N) + PN * (te / N);
+    double* __restrict__ Au_ = direct_kargs()->Au;
     if constexpr (FUSE) {
+      const DirectFuse cfl = direct_load_fuse(direct_kargs());
       constexpr int BT = 4;   // planes per batch: the smoother vectors of a batch are requested before the first is used
 #pragma unroll
       for (int q0 = 0; q0 < NL; q0 += BT) {
@@ -408,8 +466,8 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
         for (int q = 0; q < BT; ++q) {
           if (q0 + q < NL) {
             const size_t o = (size_t)ns + te + PL * (q0 + q);
-            rh[q] = cf.rhs[o];
-            pp[q] = cf.p[o];
+            rh[q] = cfl.rhs[o];
+            pp[q] = cfl.p[o];
             uu[q] = u[o];
           }
         }
@@ -418,21 +476,26 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
           if (q0 + q < NL) {
             const size_t o = (size_t)ns + te + PL * (q0 + q);
             const double au = R0[ij + PN * N * (q0 + q)];
-            if (!cf.skip_Au_store) Au[o] = au;
+            if (!cfl.skip_Au_store) Au_[o] = au;
             const double res = __dadd_rn(rh[q], __dmul_rn(-1.0, au));
-            const double ri = __dmul_rn(cf.alpha, res);
-            const double pi = __dadd_rn(__dmul_rn(cf.beta, pp[q]), ri);
-            if (cf.r) cf.r[o] = ri;
-            cf.p[o] = pi;
-            cf.u_out[o] = __dadd_rn(uu[q], pi);
+            const double ri = __dmul_rn(cfl.alpha, res);
+            const double pi = __dadd_rn(__dmul_rn(cfl.beta, pp[q]), ri);
+            if (cfl.r) cfl.r[o] = ri;
+            cfl.p[o] = pi;
+            cfl.u_out[o] = __dadd_rn(uu[q], pi);
           }
         }
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < NL; ++q) Au[(size_t)ns + te + PL * q] = R0[ij + PN * N * q];
+      for (int q = 0; q < NL; ++q) Au_[(size_t)ns + te + PL * q] = R0[ij + PN * N * q];
     }
   }
+#undef tC
+#undef tCD
+#undef tE
+#undef tDtE
+#undef dr0
 }
 
 }  // namespace

@@ -13,6 +13,16 @@ namespace d4est_hip {
 // (odd sizes, round 2: threshold 9 / 12 / 14 -> p = 10: 51.9 / 50.5 / 50.7, p = 12: 53.1 / 52.0 / 48.5 GDoF/s: 12 stays)
 template <int C, int R>
 constexpr bool kEoPipelined = ((C > R ? C : R) >= 12) && ((C > R ? C : R) != 16);
+// full EO rows through one base pointer with immediate offsets (contract_rows_eo_imm): where a row (R doubles) and its successor fit
+// the scalar registers
+#ifndef D4EST_HIP_EO_ROWS_IMM_MAX
+#define D4EST_HIP_EO_ROWS_IMM_MAX 12
+#endif
+#ifndef D4EST_HIP_EO_ROWS_IMM_MIN
+#define D4EST_HIP_EO_ROWS_IMM_MIN 12
+#endif
+template <int C, int R>
+constexpr bool kEoRowsImm = ((C > R ? C : R) <= D4EST_HIP_EO_ROWS_IMM_MAX) && ((C > R ? C : R) >= D4EST_HIP_EO_ROWS_IMM_MIN);
 
 
 // y (+)= M x for a centro-symmetric (ANTI = false) or centro-antisymmetric (ANTI = true) operator M (R x C, both even).
@@ -26,7 +36,9 @@ __device__ __forceinline__ void apply_eo(const double* __restrict__ tab, const d
   eo_pre<C>(x, xe, xo);
   const double* xf = ANTI ? xo : xe;  // first part multiplies xe (symmetric) / xo (antisymmetric)
   const double* xs = ANTI ? xe : xo;
-  if constexpr (kEoPipelined<C, R>) {
+  if constexpr (kEoRowsImm<C, R>) {
+    contract_rows_eo_imm<HC, R, false>(tab, xf, xs, ab);
+  } else if constexpr (kEoPipelined<C, R>) {
     static_assert(P1 <= 24, "apply_eo: row parts longer than 24 are not supported");
     constexpr int A0 = P1 < 8 ? P1 : 8, A1 = (P1 - 8 > 0) ? (P1 - 8 < 8 ? P1 - 8 : 8) : 0, A2 = (P1 - 16 > 0) ? P1 - 16 : 0;
     constexpr int B0 = P2 < 8 ? P2 : 8, B1 = (P2 - 8 > 0) ? (P2 - 8 < 8 ? P2 - 8 : 8) : 0, B2 = (P2 - 16 > 0) ? P2 - 16 : 0;

@@ -86,15 +86,15 @@ enum d4est_hip_tuning_key {
   D4EST_HIP_TUNE_GHOST_ALIAS = 8,        /* set before plan_set_faces; 1: all ghost sides of a conforming plan share block 0 of the ghost trace buffer (for a ghost trace that is the same on every side: the zero trace of a Schwarz subdomain plan); compute_ghost_traces is then meaningless */
   D4EST_HIP_TUNE_GRAPH = 9,              /* 1: d4est_hip_cheby_iterate is captured into a hipGraph on its first call and replayed while its arguments (pointers, iteration count, eigenvalue window) stay the same -- for launch-bound meshes (multigrid coarse levels); needs a non-null plan stream and no exchange callback (single rank); default off */
   D4EST_HIP_TUNE_FUSE_UPDATE = 10,       /* 0: cheby_iterate runs its update as a separate kernel; else (default) on conforming meshes up to p = 15 the update rides in the epilogue of the flux kernel (same roundings, bit-identical) */
-  D4EST_HIP_TUNE_FACE_DIRECT = 11,       /* 0: apply_aij / apply_lhs / the smoothers always run the two-phase face kernels (traces, then flux); default: conforming plans with one degree, deg_quad <= 7 and at least 768 elements (below that the two-phase kernels, with several wavefronts per element, are faster on the mostly empty chip) run the single-wavefront kernel that forms both sides' traces from u itself (no trace arrays; with ghost sides the trace kernel still feeds the exchange); 1: that kernel for the face terms only, the volume kernel separately, whatever the size; 2: the whole operator in that one kernel where deg_quad = deg (else as 1), whatever the size -- the default picks this form too */
+  D4EST_HIP_TUNE_FACE_DIRECT = 11,       /* 0: apply_aij / apply_lhs / the smoothers always run the two-phase face kernels (traces, then flux); default: conforming plans with one degree, deg_quad <= 7 and at least 768 elements (below that the two-phase kernels, with several wavefronts per element, are faster on the mostly empty chip) run the single-wavefront kernel that forms both sides' traces from u itself (no trace arrays; with ghost sides the trace kernel still feeds the exchange); 1: that kernel for the face terms only, the volume kernel separately, whatever the size; 2: the whole operator in that one kernel where deg_quad = deg (else as 1), whatever the size -- the default picks this form too.  Conforming plans with one degree deg = deg_quad = 8 ... 15 have the multi-wave form of that kernel (one workgroup per element: volume term, then the trace-free face terms; d4est_hip_direct_mw.hip), which is the default at EVERY size; values 0 / 1 / 2 select as above */
   D4EST_HIP_TUNE_COUNT = 12
 };
 void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value);
 /* name of the stiffness kernel the last d4est_hip_apply_stiffness_matrix selected (for reports / profiles) */
 const char* d4est_hip_plan_last_kernel(const d4est_hip_plan_t* plan);
 /* Which face kernels apply_aij / apply_lhs / the smoothers run on this plan (after plan_set_faces, with the current tuning):
- * "direct" (one single-wavefront kernel, traces formed from u in place: conforming plans with one degree, deg_quad <= 7),
- * "direct+volume" (the same kernel also applies the element's volume term and writes A u once: deg_quad = deg <= 7, after
+ * "direct" (one kernel, traces formed from u in place: conforming plans with one degree, deg_quad <= 7 or deg = deg_quad <= 15),
+ * "direct+volume" (the same kernel also applies the element's volume term and writes A u once: deg_quad = deg <= 15, after
  * plan_set_geometry) or "two-phase" (trace kernel, then flux kernel). */
 const char* d4est_hip_plan_face_path(const d4est_hip_plan_t* plan);
 int d4est_hip_plan_local_nodes(const d4est_hip_plan_t* plan);

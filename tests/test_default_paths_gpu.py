@@ -25,18 +25,20 @@ class _LocalTransport:
             t.copy_(self.mb.box[(p, self.rank)])
 
 
-def test_large_shard_default_is_the_direct_kernel_with_exchanged_ghost_sides(gpu, hiplib, oracle, monkeypatch):
-    """level 4, p = 1: 4096 elements in two shards of 2048; apply_lhs and a Chebyshev iteration on rank 0 through the C exchange hooks
-    (rank 1's traces served in-process) against the oracle's single-rank operator"""
+@pytest.mark.parametrize("level,deg", [(4, 1), (1, 9), (2, 11)])
+def test_large_shard_default_is_the_direct_kernel_with_exchanged_ghost_sides(gpu, hiplib, oracle, monkeypatch, level, deg):
+    """level 4, p = 1: 4096 elements in two shards of 2048; apply_lhs on rank 0 through the C exchange hooks (rank 1's traces served
+    in-process) against the oracle's single-rank operator.  p = 9, 11: the multi-wave direct kernel (the default at every size) with
+    ghost (+) sides that read the exchanged mortar-node blocks."""
     import torch
     from disco4est_amd import Plan, mesh as M, parallel as P
     monkeypatch.delenv("D4EST_HIP_FACE_DIRECT", raising=False)
-    level, deg = 4, 1
     deg_global = np.full(8 ** level, deg)
     mg = M.BrickMesh(level, deg_global)
     Jg, rstg = mg.geometry(None); sg = mg.build_sides(None); ug = mg.field()
     ref = oracle.apply_aij(mg, Jg, rstg, sg, ug, nthreads=8)
-    parts = [(0, 2048), (2048, 2048)]
+    half = 8 ** level // 2
+    parts = [(0, half), (half, half)]
     mb = _Mailbox()
     objs = []
     for first, count in parts:

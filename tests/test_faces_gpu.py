@@ -67,7 +67,9 @@ def test_apply_aij_parity(gpu, hiplib, oracle, level, deg, inc, curved, fcn):
     dAu = torch.full_like(du, float("nan"))
     # uniform conforming plans up to deg_quad = 7 run the direct face kernel (traces formed from u in place) by default;
     # tuning key 11 = 0 selects the two-phase kernels: both are held to the oracle
-    assert plan.face_path() == "two-phase"          # a small mesh: the default is the two-phase kernels (see d4est_hip.h, key 11)
+    # a small mesh: up to p = 7 the default is the two-phase kernels (see d4est_hip.h, key 11); the multi-wave whole-operator kernel of
+    # p = 8 ... 15 is the default at every size
+    assert plan.face_path() == ("direct+volume" if (deg >= 8 and inc == 0) else "two-phase")
     vals = _face_path_values(plan)
     assert {2: "direct+volume", 1: "direct", 0: "two-phase"}[vals[0]] == _best_face_path(deg, inc)
     for direct in vals:

@@ -27,7 +27,7 @@ class _LocalTransport:
             t.copy_(self.mb.box[(p, self.rank)])
 
 
-@pytest.mark.parametrize("world,level,deg_spec", [(2, 2, [3]), (3, 2, [2, 3, 4]), (4, 2, [7])])
+@pytest.mark.parametrize("world,level,deg_spec", [(2, 2, [3]), (3, 2, [2, 3, 4]), (4, 2, [7]), (2, 1, [9]), (3, 1, [12])])
 def test_virtual_ranks_match_single_rank(gpu, hiplib, oracle, world, level, deg_spec):
     import torch
     from disco4est_amd import Plan, mesh as M, parallel as P

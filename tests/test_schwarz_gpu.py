@@ -53,7 +53,7 @@ def _mixed(level, lo, hi):
     return lo + (np.arange(n) * 7 % (hi - lo + 1))
 
 
-@pytest.mark.parametrize("level,deg,curved,rs", [(1, 2, False, 2), (2, 3, True, 2), (2, "mixed", True, 3), (2, 4, False, 5), (2, "low", True, 2)])
+@pytest.mark.parametrize("level,deg,curved,rs", [(1, 2, False, 2), (2, 3, True, 2), (2, "mixed", True, 3), (2, 4, False, 5), (2, "low", True, 2), (1, 8, True, 3)])
 def test_restriction_and_operator_parity(gpu, hiplib, oracle, level, deg, curved, rs):
     import torch
     from disco4est_amd import mesh as M
@@ -129,7 +129,7 @@ def test_correction_parity(gpu, hiplib, oracle, level, deg, rs):
     sz.destroy()
 
 
-@pytest.mark.parametrize("level,deg,curved,rs,iters,rtol", [(1, 3, True, 2, 6, 1e-15), (2, 2, False, 2, 60, 3e-2), (2, "mixed", True, 2, 5, 1e-15)])
+@pytest.mark.parametrize("level,deg,curved,rs,iters,rtol", [(1, 3, True, 2, 6, 1e-15), (2, 2, False, 2, 60, 3e-2), (2, "mixed", True, 2, 5, 1e-15), (1, 9, True, 3, 5, 1e-15)])
 def test_iterate_parity(gpu, hiplib, oracle, level, deg, curved, rs, iters, rtol):
     """one d4est_solver_schwarz_iterate: same correction, same per-subdomain iteration counts and residuals as the serial oracle"""
     from disco4est_amd import mesh as M

@@ -26,7 +26,7 @@ def _setup(level, deg, mapping, gpu, oracle):
     return m, plan
 
 
-@pytest.mark.parametrize("level,deg,curved", [(1, 3, True), (1, 7, False), (2, 2, True)])
+@pytest.mark.parametrize("level,deg,curved", [(1, 3, True), (1, 7, False), (2, 2, True), (1, 8, True), (1, 11, True)])
 def test_cheby_iterate_parity(gpu, hiplib, oracle, level, deg, curved):
     import torch
     from disco4est_amd import mesh as M

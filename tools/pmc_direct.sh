@@ -19,7 +19,7 @@ for d in ("p1","p2","p3"):
     for r in csv.DictReader(open(f[0])):
         acc[r["Kernel_Name"][:56]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        if not any(t in k for t in ("faces_direct", "flux_wave", "stiffness_wave_eo", "trace_mfma")): continue
+        if not any(t in k for t in ("faces_direct", "flux_wave", "stiffness_wave", "trace_mfma", "operator_mw", "flux_mfma")): continue
         print(d, k)
         for c, vals in sorted(v.items()):
             print("   %-24s avg %.5g  (n=%d)" % (c, sum(vals)/len(vals), len(vals)))
