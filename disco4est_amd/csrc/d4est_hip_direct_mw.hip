@@ -69,6 +69,9 @@ struct PassMap {
 #else
 #define MW_SYNC() __syncthreads()
 #endif
+#ifndef D4EST_HIP_MWD_GEOM_EARLY
+#define D4EST_HIP_MWD_GEOM_EARLY 0
+#endif
 #ifndef D4EST_HIP_MWD_WAVES
 #define D4EST_HIP_MWD_WAVES 4
 #endif
@@ -204,6 +207,28 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
     const sside_ptr sd = (sside_ptr)(unsigned long long)(direct_kargs()->sides + 6 * (size_t)e + 2 * d);
     const int kcf[2] = {sd[0].kcf, sd[1].kcf};
     const int sgeom[2] = {sd[0].geom, sd[1].geom};
+#if D4EST_HIP_MWD_GEOM_EARLY   /* the two faces' geometric factors are requested before the lines: their HBM latency passes under passes 1 and 2 */
+    double gqa[2][7];
+    {
+      const direct_kargs_ptr K = direct_kargs();
+      const double* __restrict__ geom_ = K->geom;
+      const double* __restrict__ robin_c_ = K->robin_c;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) gqa[h][c] = 0.0;
+        if (on) {
+          if ((kcf[h] & 3) == 0 && robin_c_) {
+            gqa[h][6] = robin_c_[sgeom[h] + te];   // am = ap = 0: no term 1 / term 2 on a Robin side
+          } else {
+            const double* __restrict__ g = geom_ + (size_t)7 * sgeom[h] + te;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) gqa[h][c] = (D4EST_HIP_MWD_ABLATE & 8) ? 0.5 + c : g[c * T];
+          }
+        }
+      }
+    }
+#endif
     // ---- nodal fields of the two faces at face node (a, b): c = 0..3 trace (own 2d, own 2d+1, nbr 2d, nbr 2d+1), c = 4..7 normal
     // derivative.  The normal lines of the element and of the two (+) elements (at THEIR face node (a, b)) are requested together.
     double fld[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -282,6 +307,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
     }
     // ---- SIPG terms, one face at a time (the mortar values of its two sides go through the buffer)
     double At[2][4];
+#if !D4EST_HIP_MWD_GEOM_EARLY
     double gqa[2][7];
     {
       const direct_kargs_ptr K = direct_kargs();
@@ -302,6 +328,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
         }
       }
     }
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       MW_SYNC();
