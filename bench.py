@@ -108,6 +108,105 @@ def brick_plan(level, deg, stream, torch, dev, count=None):
     return m, plan, x, torch.empty_like(x)
 
 
+def full_operator_bytes_per_dof(N, NQ):
+    """algorithmic bytes of one full operator apply per DoF: u 8 + A u 8 + metric 48 (NQ/N)^3 + the 7 pre-combined face factors per
+    mortar node of 6 sides (= 64 + 336 / N at NQ = N); mortar-node traces and the neighbours' u are intermediates, not counted"""
+    return algorithmic_bytes_per_dof(N, NQ) + 6.0 * 7.0 * 8.0 * NQ * NQ / N ** 3
+
+
+def brick_operator_plan(level, deg, stream, torch, dev):
+    """brick_plan + the SIPG faces, every geometric factor generated on the device (general path: per-node metric streamed)"""
+    m, plan, x, y = brick_plan(level, deg, stream, torch, dev)
+    sides = m.build_sides(None, geometry=False)
+    plan.set_faces(sides, 10.0, 0, brick=(np.ones(m.n_elements, dtype=np.int32), float(1 << level), [0.0, 1.0, 0.0, 1.0, 0.0, 1.0]))
+    return m, plan, x, y
+
+
+def gate_operator(name, plan, level, deg, x, y, shards=3):
+    """parity gate of a timed full-operator secondary: A u of the plan's default kernel path against the oracle on 64-element shards cut
+    from the mesh (whole-element ghost data gathered from the global vector); raises if the worst shard exceeds 1e-12"""
+    from disco4est_amd import mesh as M
+    from tests import oracle_lib
+    oracle = oracle_lib.load()
+    plan.apply_aij(x, y)
+    u, got = x.cpu().numpy(), y.cpu().numpy()
+    n = 8 ** level
+    cnt = min(64, n)
+    firsts = sorted({0, ((n // 2 + n // 16) // cnt) * cnt, n - cnt})
+    worst = 0.0
+    for first in firsts[:shards]:
+        sub = M.BrickMesh(level, deg, first=first, count=cnt)
+        Js, rsts = sub.geometry(None); ss = sub.build_sides(None)
+        s0 = sub.global_nodal_offset
+        ref = oracle.apply_aij(sub, Js, rsts, ss, np.ascontiguousarray(u[s0:s0 + sub.local_nodes]),
+                               u_ghost=(sub.gather_ghost(ss, u) if ss["ghost_nodes"] > 0 else None), nthreads=min(os.cpu_count() or 1, 16))
+        worst = max(worst, np.abs(got[s0:s0 + sub.local_nodes] - ref).max() / np.abs(ref).max())
+    log("parity gate %s: A u against the oracle on %d shards of %d elements: rel-inf = %.3e  [%s]" % (name, len(firsts[:shards]), cnt, worst, plan.face_path()))
+    if not worst <= 1e-12:
+        raise RuntimeError("parity gate of %s failed: %.3e" % (name, worst))
+    return worst
+
+
+def eig_window(plan, x, torch, its=12):
+    """(lmin, lmax) for the Chebyshev secondaries: 1.1 x a power-iteration estimate of the largest eigenvalue, and 1/30 of it (the
+    reference's smoother window, d4est_solver_multigrid_smoother_cheby.c:60-76) -- so that the timed iterations contract"""
+    v = torch.rand_like(x); Av = torch.empty_like(x); lam = 1.0
+    for _ in range(its):
+        plan.apply_aij(v, Av)
+        lam = float(torch.linalg.norm(Av) / torch.linalg.norm(v))
+        v = Av / torch.linalg.norm(Av)
+    return 1.1 * lam / 30.0, 1.1 * lam
+
+
+def gate_cheby(name, plan, x, rhs, torch, iters=5, lmin=1.0, lmax=30.0):
+    """parity gate of a timed Chebyshev secondary: the fused loop (update in the operator kernel's epilogue) against the recurrence of
+    d4est_solver_multigrid_smoother_cheby.c:104-154 written out with separate vector operations around the (gated) operator"""
+    uc = x.clone(); r = torch.empty_like(x); Au = torch.empty_like(x)
+    plan.cheby_iterate(uc, rhs, Au, r, iters, lmin, lmax, 0)
+    d, c = (lmax + lmin) / 2, (lmax - lmin) / 2
+    ur = x.clone(); p = torch.zeros_like(x); Aur = torch.empty_like(x); alpha = 0.0
+    for i in range(iters):
+        alpha = 1 / d if i == 0 else (2 * d / (2 * d * d - c * c) if i == 1 else 1 / (d - alpha * c * c / 4))
+        beta = alpha * d - 1
+        plan.apply_aij(ur, Aur)
+        p = alpha * (rhs - Aur) + beta * p
+        ur = ur + p
+    err = float((uc - ur).abs().max() / ur.abs().max())
+    log("parity gate %s: %d fused Chebyshev iterations against the written-out recurrence: rel-inf = %.3e" % (name, iters, err))
+    if not err <= 1e-12:
+        raise RuntimeError("parity gate of %s failed: %.3e" % (name, err))
+    return err
+
+
+def gate_schwarz(torch, dev):
+    """parity gate of the Schwarz secondary: one iterate (10 CG sweeps, tolerances off) on a 64-element p = 7 brick with overlap 2 --
+    the kernels the timed config-2 iterate runs (whole-operator kernel on the subdomain plan, condensed corner copies, flat CG kernel)
+    -- against the serial oracle (oracle/d4est_oracle_schwarz.c): same correction to 1e-9, same per-subdomain iteration counts"""
+    from disco4est_amd import mesh as M
+    from disco4est_amd.schwarz import Schwarz
+    from tests import oracle_lib
+    oracle = oracle_lib.load()
+    m = M.BrickMesh(2, 7)
+    J, rst = m.geometry(None); sides = m.build_sides(None)
+    oracle.set_operator(m, J, rst, sides, 10.0, 0, threads=min(os.cpu_count() or 1, 16))
+    sz = Schwarz(m, sides, J, rst, 2, 10, 1e-300, 1e-300, 10.0, 0)
+    sz.plan.set_tuning(11, 2)    # the timed mesh is large enough for the one-kernel operator by default; this one is forced onto it
+    r = M.splitmix64_uniform(42, m.local_nodes) - 0.5
+    u0 = np.zeros(m.local_nodes)
+    u_ref, it_ref, _ = oracle.schwarz_iterate(sz.metadata, u0, r, 10, 1e-300, 1e-300)
+    u = torch.zeros(m.local_nodes, dtype=torch.float64, device=dev)
+    sz.iterate(u, torch.from_numpy(r).to(dev))
+    it, _ = sz.info()
+    err = float(np.abs(u.cpu().numpy() - u_ref).max() / np.abs(u_ref).max())
+    same = bool(np.array_equal(it, it_ref))
+    log("parity gate schwarz_iterate_10_cg: against the serial oracle on 64 elements: rel-inf = %.3e, iteration counts equal: %s  [%s, %d condensed copies]"
+        % (err, same, sz.plan.face_path(), sz.condensed_copies()))
+    sz.destroy()
+    if not (err <= 1e-9 and same):
+        raise RuntimeError("parity gate of schwarz_iterate_10_cg failed: %.3e" % err)
+    return err
+
+
 def sharded_secondary(args, rank, world, dev, stream, dist, torch):
     """config 2 split over the ranks (strong scaling): apply_lhs and Chebyshev iterations with the face-trace exchange over RCCL
     in C; the sharded operator is checked against the same operator applied by ONE rank (rank-count invariance, d4est_test_mpi.sh)."""
@@ -360,16 +459,28 @@ def main():
             rhs = torch.zeros_like(du)
             r = torch.empty_like(du)
             sec = {}
+            # parity gates BEFORE the numbers (none of them inside a timed region): the operator on the default kernel path of this mesh
+            # against the oracle on 64-element shards, the fused Chebyshev loop against the written-out recurrence
+            gates = {}
+            lmin, lmax = eig_window(plan, du, torch)
+            if not args.no_check:
+                gates["apply_aij"] = gate_operator("apply_aij", plan, args.level, args.deg, du, dAu) if (args.geometry != "sine" and args.deg_quad_inc == 0) else None
+                gates["cheby_5_iterations"] = gate_cheby("cheby_5_iterations", plan, du, rhs, torch, 5, lmin, lmax)
             for name, fn, applies in (("apply_aij", lambda: plan.apply_aij(du, dAu), 1),
-                                      ("cheby_5_iterations", lambda: plan.cheby_iterate(du, rhs, dAu, r, 5, 1.0, 30.0, 0), 5)):
+                                      ("cheby_5_iterations", lambda: plan.cheby_iterate(du, rhs, dAu, r, 5, lmin, lmax, 0), 5)):
                 ms = time_region(fn, 50, stream, torch, warm=10)
                 sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9}
-                # algorithmic bytes of one full operator apply per DoF: u 8 + A u 8 + metric 48 (NQ/N)^3 + the 7 pre-combined face
-                # factors per mortar node of 6 sides; the mortar-node traces are intermediates, not counted
-                bpd_aij = algorithmic_bytes_per_dof(N, NQ) + 6.0 * 7.0 * 8.0 * NQ * NQ / N ** 3
+                bpd_aij = full_operator_bytes_per_dof(N, NQ)
                 sec[name]["algorithmic_bytes_per_dof"] = bpd_aij
                 sec[name]["roofline_frac_hbm"] = bpd_aij * dofs_per_rank * applies / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 sec[name]["face_path"] = plan.face_path()   # "direct+volume": the whole operator in one kernel (u in, A u out)
+                sec[name]["parity_gate_rel_inf"] = gates.get(name)
+            # HBM traffic of one apply_aij from the PMC counters (2 FETCH_SIZE + WRITE_SIZE, profiles/): neighbours' u re-read past the L2
+            try:
+                rec = json.load(open(tf)) if os.path.exists(tf) else {}
+                sec["apply_aij"]["traffic"] = rec.get("apply_aij_level%d_p%d" % (args.level, args.deg), {}).get("hbm_bytes_per_launch")
+            except Exception:
+                sec["apply_aij"]["traffic"] = None
             # the affine path: same brick, metric rebuilt from 6 numbers per element, 16 B/DoF
             if args.geometry != "sine":
                 plan.set_tuning(7, -1)
@@ -379,7 +490,7 @@ def main():
                 # ... and the full operator / the smoother iteration with the affine volume metric (the face factors are still streamed):
                 # what a brick gets when tuning key 7 is left alone; labelled separately like the entry above
                 for name, fn, applies in (("apply_aij_affine_path", lambda: plan.apply_aij(du, dAu), 1),
-                                          ("cheby_5_iterations_affine_path", lambda: plan.cheby_iterate(du, rhs, dAu, r, 5, 1.0, 30.0, 0), 5)):
+                                          ("cheby_5_iterations_affine_path", lambda: plan.cheby_iterate(du, rhs, dAu, r, 5, lmin, lmax, 0), 5)):
                     ms = time_region(fn, 50, stream, torch, warm=10)
                     sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9, "face_path": plan.face_path(),
                                  "algorithmic_bytes_per_dof": 16.0 + 6.0 * 7.0 * 8.0 * NQ * NQ / N ** 3}
@@ -422,10 +533,39 @@ def main():
                                                   "kernel": p2.last_kernel(), "algorithmic_bytes_per_dof": 16.0}
                 p2.destroy()
                 del x2, y2
+            # the FULL operator at the degrees of BASELINE configs 3 and 5: one kernel per apply
+            # (operator_mw_kernel: volume term + trace-free SIPG faces per multi-wave workgroup); geometric factors generated on the
+            # device, general path; each gated against the oracle on 64-element shards before it is timed
+            for name, level, deg, reps in (("apply_aij_p11_level4", 4, 11, 30), ("apply_aij_p11_level5_config3", 5, 11, 8),
+                                           ("apply_aij_p15_level4", 4, 15, 12)):
+                m2, p2, x2, y2 = brick_operator_plan(level, deg, stream, torch, dev)
+                g = None if args.no_check else gate_operator(name, p2, level, deg, x2, y2, shards=2 if level == 5 else 3)
+                ms = time_region(lambda: p2.apply_aij(x2, y2), reps, stream, torch, warm=reps)
+                bpd_aij = full_operator_bytes_per_dof(deg + 1, deg + 1)
+                sec[name] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes, "elements": m2.n_elements,
+                             "algorithmic_bytes_per_dof": bpd_aij,
+                             "roofline_frac_hbm": bpd_aij * m2.local_nodes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "face_path": p2.face_path(), "kernel": p2.last_kernel(), "parity_gate_rel_inf": g}
+                try:
+                    sec[name]["traffic"] = (json.load(open(tf)) if os.path.exists(tf) else {}).get(name, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    sec[name]["traffic"] = None
+                if name == "apply_aij_p11_level4":
+                    rhs2 = torch.zeros_like(x2); r2 = torch.empty_like(x2)
+                    l0, l1 = eig_window(p2, x2, torch)
+                    gc = None if args.no_check else gate_cheby("cheby_5_iterations_p11_level4", p2, x2, rhs2, torch, 5, l0, l1)
+                    ms = time_region(lambda: p2.cheby_iterate(x2, rhs2, y2, r2, 5, l0, l1, 0), 10, stream, torch, warm=5)
+                    sec["cheby_5_iterations_p11_level4"] = {"ms": ms, "GDoF_per_s": 5 * m2.local_nodes / (ms * 1e-3) / 1e9,
+                                                            "algorithmic_bytes_per_dof": bpd_aij, "parity_gate_rel_inf": gc,
+                                                            "roofline_frac_hbm": 5 * bpd_aij * m2.local_nodes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    del rhs2, r2
+                p2.destroy()
+                del x2, y2
             # additive Schwarz smoother on the same mesh: one d4est_solver_schwarz_iterate with
             # 10 CG iterations per subdomain (tolerances off), all subdomains batched on the subdomain plan
             if args.geometry != "sine" and mesh.n_elements <= 4096:
                 from disco4est_amd.schwarz import Schwarz
+                gsz = None if args.no_check else gate_schwarz(torch, dev)
                 sz = Schwarz(mesh, sides, J, rst, 2, 10, 1e-300, 1e-300, 10.0, 0, stream=stream)
                 us = torch.zeros_like(du)
                 sz.iterate(us, du)
@@ -441,7 +581,7 @@ def main():
                                                 "subdomain_elements": sz.metadata.num_elements, "num_nodes_overlap": 2,
                                                 "ms_per_cg_sweep": ms / 10, "face_path": sz.plan.face_path(),
                                                 # corner copies whose operator rows are dense blocks probed from the operator
-                                                "condensed_copies": sz.condensed_copies()}
+                                                "condensed_copies": sz.condensed_copies(), "parity_gate_rel_inf": gsz}
                 sz.destroy()
                 del us
             # BASELINE config 4's shape in miniature: degrees p = 3 ... 9 scattered over the level-4 brick (1.75 MDoF), general path --

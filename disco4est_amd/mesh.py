@@ -158,8 +158,9 @@ class BrickMesh:
 
 
     # -- faces ---------------------------------------------------------------
-    def build_sides(self, mapping=None):
-        """Flat (element, face) side list + mortar geometric factors in the reference's layout.
+    def build_sides(self, mapping=None, geometry=True):
+        """Flat (element, face) side list + mortar geometric factors in the reference's layout (geometry=False: the side list and the
+        strides only -- for plans whose mortar factors are generated on the device, Plan.set_faces(..., brick=...)).
 
         Mirrors what d4est's face iteration and d4est_mesh_compute_mortar_quadrature_quantities produce
         (src/Mesh/d4est_mortars.c:601-803, src/Mesh/d4est_mesh.c:868-1110): for side s = 6*e + f the (+)
@@ -217,6 +218,12 @@ class BrickMesh:
         nb = np.where(bnd, (deg_m.astype(np.int64) + 1) ** 2, 0)
         side_bndry_stride = np.concatenate([[0], np.cumsum(nb)[:-1]]).astype(np.int32)
         total_bndry = int(nb.sum())
+        if not geometry:
+            return dict(side_nbr=side_nbr, side_nbr_face=side_nbr_face, side_reorder=side_reorder,
+                        side_mortar_stride=side_mortar_stride, side_bndry_stride=side_bndry_stride,
+                        total_mortar_nodes=total, total_bndry_nodes=total_bndry,
+                        ghost_global_ids=ghost_ids, ghost_deg=ghost_deg, ghost_deg_quad=ghost_deg_quad,
+                        ghost_nodal_stride=ghost_nodal_stride, ghost_nodes=int(gn3.sum()))
         sj = np.empty(total); hm = np.empty(total); hp = np.empty(total)
         nrm = np.zeros(3 * total); drst_m = np.zeros(9 * total); drst_p = np.zeros(9 * total)
         bndry_xyz = np.zeros((3, total_bndry))
