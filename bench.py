@@ -475,6 +475,30 @@ def main():
                 sec[name]["roofline_frac_hbm"] = bpd_aij * dofs_per_rank * applies / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 sec[name]["face_path"] = plan.face_path()   # "direct+volume": the whole operator in one kernel (u in, A u out)
                 sec[name]["parity_gate_rel_inf"] = gates.get(name)
+            # apply_lhs of a linearised nonlinear problem (BASELINE config 4's operator: Laplacian + V^T W J f'(u0) V u,
+            # constant_density_star_fcns.h:528-603): the zeroth-order term rides in the operator kernel's volume stage (w J c pre-combined
+            # at plan_set_lhs_coefficient: +8 B per node).  Gate: against apply_aij + the separate weighted-mass kernel (each held to the oracle).
+            cq = 1.0 + torch.rand(mesh.local_nodes_quad, dtype=torch.float64, device=dev)
+            plan.set_lhs_coefficient(cq)
+            glhs = None
+            if not args.no_check:
+                ya, yb = torch.empty_like(du), torch.empty_like(du)
+                plan.apply_lhs(du, ya)
+                plan.apply_aij(du, yb)
+                plan.apply_weighted_mass_matrix(du, cq, dAu)
+                glhs = float((ya - (yb + dAu)).abs().max() / ya.abs().max())
+                log("parity gate apply_lhs_with_coefficient: fused zeroth-order term against apply_aij + weighted mass: rel-inf = %.3e" % glhs)
+                if not glhs <= 1e-12:
+                    raise RuntimeError("parity gate of apply_lhs_with_coefficient failed: %.3e" % glhs)
+                del ya, yb
+            ms = time_region(lambda: plan.apply_lhs(du, dAu), 50, stream, torch, warm=10)
+            bpd_lhs = full_operator_bytes_per_dof(N, NQ) + 8.0 * (NQ / N) ** 3
+            sec["apply_lhs_with_coefficient"] = {"ms": ms, "GDoF_per_s": dofs_per_rank / (ms * 1e-3) / 1e9, "algorithmic_bytes_per_dof": bpd_lhs,
+                                                 "roofline_frac_hbm": bpd_lhs * dofs_per_rank / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "vs_apply_aij": ms / sec["apply_aij"]["ms"], "face_path": plan.face_path(),
+                                                 "parity_gate_rel_inf": glhs}
+            plan.set_lhs_coefficient(None)
+            del cq
             # HBM traffic of one apply_aij from the PMC counters (2 FETCH_SIZE + WRITE_SIZE, profiles/): neighbours' u re-read past the L2
             try:
                 rec = json.load(open(tf)) if os.path.exists(tf) else {}

@@ -217,7 +217,7 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   (void)hipFree(plan->d_nonaffine);
   (void)hipFree(plan->d_scratch);
   d4est_hip::faces_destroy(plan);
-  (void)hipFree(plan->d_work_p); (void)hipFree(plan->d_work_d); (void)hipFree(plan->d_work_r); (void)hipFree(plan->d_work_m);
+  (void)hipFree(plan->d_work_p); (void)hipFree(plan->d_work_d); (void)hipFree(plan->d_work_r); (void)hipFree(plan->d_work_m); (void)hipFree(plan->d_lhs_c); (void)hipFree(plan->d_lhs_wjc);
   (void)hipFree(plan->d_reduce); (void)hipFree(plan->d_ghost_trace);
   if (plan->h_stage) (void)hipHostFree(plan->h_stage);
   for (int i = 0; i < 4; ++i) (void)hipFree(plan->d_host[i]);
@@ -272,6 +272,7 @@ void d4est_hip_plan_set_geometry(d4est_hip_plan_t* plan, const double* J_quad, c
     HIP_CHECK(hipFree(tmp_rst));
   }
   plan->has_geometry = true;
+  plan->lhs_wjc_valid = false;
 }
 
 void d4est_hip_plan_set_geometry_numerical(d4est_hip_plan_t* plan, const double* xyz_lobatto, int on_device) {
@@ -292,6 +293,7 @@ void d4est_hip_plan_set_geometry_numerical(d4est_hip_plan_t* plan, const double*
   HIP_CHECK(hipStreamSynchronize(plan->stream));
   if (tmp) HIP_CHECK(hipFree(tmp));
   plan->has_geometry = true;
+  plan->lhs_wjc_valid = false;
 }
 
 static int* upload_elem_dq(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents, const char* who) {
@@ -315,6 +317,7 @@ void d4est_hip_plan_set_geometry_brick(d4est_hip_plan_t* plan, const int* elem_d
   HIP_CHECK(hipStreamSynchronize(plan->stream));
   HIP_CHECK(hipFree(d_dq));
   plan->has_geometry = true;
+  plan->lhs_wjc_valid = false;
 }
 
 void d4est_hip_plan_set_mortar_geometry_brick(d4est_hip_plan_t* plan, const int* elem_dq, double root_len, const double* extents) {
@@ -369,6 +372,7 @@ void d4est_hip_plan_set_geometry_analytic(d4est_hip_plan_t* plan, int geom_type,
   HIP_CHECK(hipStreamSynchronize(plan->stream));
   HIP_CHECK(hipFree(d_cells));
   plan->has_geometry = true;
+  plan->lhs_wjc_valid = false;
 }
 
 void d4est_hip_plan_set_mortar_geometry_analytic(d4est_hip_plan_t* plan, int geom_type, const double* params, const int* elem_tree,
@@ -417,6 +421,12 @@ void d4est_hip_plan_set_lhs_coefficient(d4est_hip_plan_t* plan, const double* co
   check_plan(plan, "plan_set_lhs_coefficient");
   drop_graph(plan);
   plan->d_lhs_coeff = coeff_quad_dev;
+  plan->lhs_wjc_valid = false;
+  if (coeff_quad_dev) {   // the values are CAPTURED here (see d4est_hip.h): a copy for the separate mass kernel, w J c for the fused operator kernels
+    const size_t nq = std::max<size_t>((size_t)plan->local_nodes_quad, 1);
+    if (!plan->d_lhs_c) HIP_CHECK(hipMalloc(&plan->d_lhs_c, nq * sizeof(double)));
+    HIP_CHECK(hipMemcpyAsync(plan->d_lhs_c, coeff_quad_dev, (size_t)plan->local_nodes_quad * sizeof(double), hipMemcpyDeviceToDevice, plan->stream));
+  }
 }
 
 void d4est_hip_apply_inverse_mass_matrix(d4est_hip_plan_t* plan, const double* in_dev, double* out_dev) {

@@ -43,6 +43,7 @@ struct DirectVol {
   int qs0 = 0, qs_stride = 0;
   const int* qs_list = nullptr;      // quadrature offset per element where the offsets are not affine (qs_stride < 0): a Schwarz
                                      // subdomain plan, whose element copies alias the mesh's metric
+  const double* cq = nullptr;        // zeroth-order term (VOL & 4): w J c at the quadrature nodes (ensure_lhs_wjc)
 };
 
 
@@ -77,11 +78,13 @@ __device__ __forceinline__ DirectVol direct_load_vol(direct_kargs_ptr K) {
   DirectVol v;
   v.metric = K->vol.metric; v.EBf = K->vol.EBf; v.EGf = K->vol.EGf; v.EBb = K->vol.EBb; v.EGb = K->vol.EGb;
   v.affine = K->vol.affine; v.wq = K->vol.wq; v.qs0 = K->vol.qs0; v.qs_stride = K->vol.qs_stride; v.qs_list = K->vol.qs_list;
+  v.cq = K->vol.cq;
   return v;
 }
 
 // d4est_hip_direct_mw.hip
 bool direct_mw_built(int N, int NQ);
+// vmode: 0 the face terms only (Au += ...), 1 / 2 the whole operator with the streamed / affine metric, + 4 with the zeroth-order term
 void launch_direct_mw(d4est_hip_plan* plan, DirectHost* dh, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
                       const double* robin_c, const double* robin_r, int vmode, const DirectVol& vol, int n, int chunk);
 

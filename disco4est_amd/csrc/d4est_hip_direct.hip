@@ -119,7 +119,7 @@ __device__ __forceinline__ void direct_load_geom(double* gq, int kind, bool on, 
   }
 }
 
-template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 streamed metric, 2 affine metric */>
+template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 streamed metric, 2 affine metric; + 4: and the zeroth-order term */>
 __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
                                                              double* __restrict__ Au, const DirectSide* __restrict__ sides,
                                                              const DirectGhostOff* __restrict__ ghost_off,
@@ -457,8 +457,8 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
     {
       const DirectVol vl = direct_load_vol(direct_kargs());
       const int qs = __builtin_amdgcn_readfirstlane(vl.qs_stride >= 0 ? vl.qs0 + e * vl.qs_stride : vl.qs_list[e]);
-      stiffness_wave_eo_element<N, NQ, VOL == 2, false>(s_U, s_S, vl.metric, qs, e, on_q, a, b, vl.EBf, vl.EGf, vl.EBb, vl.EGb,
-                                                        vl.affine, vl.wq);
+      stiffness_wave_eo_element<N, NQ, (VOL & 3) == 2, false, (VOL & 4) != 0>(s_U, s_S, vl.metric, qs, e, on_q, a, b, vl.EBf, vl.EGf, vl.EBb,
+                                                                              vl.EGb, vl.affine, vl.wq, vl.cq);
     }
     if (on_m) {
       DirectFuse cfl;
@@ -623,7 +623,8 @@ bool direct_fused_ok(const d4est_hip_plan* plan) {
   return true;
 }
 
-// vol_term: 0 the face terms only (Au += ...), 1 the whole operator (Au = volume + faces; direct_fused_ok)
+// vol_term: 0 the face terms only (Au += ...), 1 the whole operator (Au = volume + faces; direct_fused_ok), 2 the whole operator
+// with the plan's zeroth-order term (plan_set_lhs_coefficient) in its volume stage
 void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
                          const double* robin_c, const double* robin_r, int vol_term) {
   DirectHost* dh = host_of(plan);
@@ -647,6 +648,11 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
     const bool aff = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine;
     if (aff) { vol.affine = plan->d_metric_affine; vol.wq = bk.d_w; }
     vmode = aff ? 2 : 1;
+    if (vol_term == 2) {
+      if (!plan->d_lhs_coeff) D4EST_HIP_ABORT("direct face kernel: the zeroth-order term was requested but no coefficient is set");
+      vol.cq = ensure_lhs_wjc(plan);
+      vmode |= 4;
+    }
     if (dh->mw) std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::operator_mw_kernel<%d,vol%s> (stiffness_wave_kernel body + faces)", dh->N, aff ? ",affine" : "");
     else std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::faces_direct_kernel<%d,%d,vol%s> (faces + stiffness_wave_eo body)", dh->N, dh->NQ, aff ? ",affine" : "");
   }
@@ -665,6 +671,8 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
     if constexpr (N_ == NQ_) {                                                     \
       if (vmode == 1) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 1); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 1); done = true; } \
       if (vmode == 2) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 2); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 2); done = true; } \
+      if (vmode == 5) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 5); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 5); done = true; } \
+      if (vmode == 6) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 6); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 6); done = true; } \
     }                                                                              \
     if (!done) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 0); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 0); done = true; }        \
   }

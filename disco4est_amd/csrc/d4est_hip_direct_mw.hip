@@ -137,7 +137,8 @@ __device__ __forceinline__ int pack_task(int slot) {
   return (l % N) | ((l / N) << 8) | (isB ? (1 << 30) : 0);
 }
 
-// VOL: 0 the face terms only (Au += ...), 1 the whole operator with the streamed metric, 2 with the affine metric.
+// VOL: 0 the face terms only (Au += ...), 1 the whole operator with the streamed metric, 2 with the affine metric; + 4: with the
+// zeroth-order term V^T w J c V u of plan_set_lhs_coefficient in the volume stage.
 // The parameter list is faces_direct_kernel's (DirectKernargs mirrors it: arguments needed late are read from the kernel-argument
 // segment at their use instead of being held -- and spilled -- in scalar registers for the whole kernel).
 template <int N, bool FUSE, int VOL>
@@ -175,8 +176,8 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
     const DirectVol vl = direct_load_vol(direct_kargs());
     const int qs = __builtin_amdgcn_readfirstlane(vl.qs_stride >= 0 ? vl.qs0 + e * vl.qs_stride : vl.qs_list[e]);
     if constexpr ((D4EST_HIP_MWD_ABLATE & 4) == 0)
-      stiffness_mw_element<N, N, false, true, VOL == 2>(R0, S, vl.metric, qs, e, on, te, a, b, vl.EBb, vl.EGb, vl.EBf, vl.EGf,
-                                                        vl.affine, vl.wq);
+      stiffness_mw_element<N, N, false, true, (VOL & 3) == 2, (VOL & 4) != 0>(R0, S, vl.metric, qs, e, on, te, a, b, vl.EBb, vl.EGb, vl.EBf,
+                                                                              vl.EGf, vl.affine, vl.wq, vl.cq);
     else __syncthreads();
   } else {
     if (on) load_element_image<N, PL, PN>(R0, direct_kargs()->Au + ns, te);
@@ -546,7 +547,6 @@ static void mw_set_lds_limit(K kernel, size_t bytes) {
   if (bytes > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
-// vmode: 0 the face terms only (Au += ...), 1 / 2 the whole operator with the streamed / affine metric
 void launch_direct_mw(d4est_hip_plan* plan, DirectHost* dh, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
                       const double* robin_c, const double* robin_r, int vmode, const DirectVol& vol, int n, int chunk) {
   const DirectFuse cfv = cf ? *cf : DirectFuse{};
@@ -562,6 +562,8 @@ void launch_direct_mw(d4est_hip_plan* plan, DirectHost* dh, const double* u, con
   if (!done && dh->N == N_) {                                                                       \
     if (vmode == 1) { if (cf) D4EST_HIP_MW_GO(N_, true, 1); else D4EST_HIP_MW_GO(N_, false, 1); }   \
     else if (vmode == 2) { if (cf) D4EST_HIP_MW_GO(N_, true, 2); else D4EST_HIP_MW_GO(N_, false, 2); } \
+    else if (vmode == 5) { if (cf) D4EST_HIP_MW_GO(N_, true, 5); else D4EST_HIP_MW_GO(N_, false, 5); } \
+    else if (vmode == 6) { if (cf) D4EST_HIP_MW_GO(N_, true, 6); else D4EST_HIP_MW_GO(N_, false, 6); } \
     else { if (cf) D4EST_HIP_MW_GO(N_, true, 0); else D4EST_HIP_MW_GO(N_, false, 0); }              \
     done = true;                                                                                    \
   }

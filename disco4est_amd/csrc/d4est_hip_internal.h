@@ -112,7 +112,10 @@ struct d4est_hip_plan {
 
   // ---- solver workspace / communication hooks (d4est_hip_solver.hip) ----
   double *d_work_p = nullptr, *d_work_d = nullptr, *d_work_r = nullptr, *d_reduce = nullptr, *d_ghost_trace = nullptr;
-  const double* d_lhs_coeff = nullptr;   // optional zeroth-order term of apply_lhs: + V^T W J c V u (caller-owned, quadrature nodes)
+  const double* d_lhs_coeff = nullptr;   // optional zeroth-order term of apply_lhs: + V^T W J c V u (the caller's array; non-null = term on)
+  double* d_lhs_c = nullptr;             // its values as they were at plan_set_lhs_coefficient (plan-owned copy)
+  double* d_lhs_wjc = nullptr;           // w J c at the quadrature nodes (one stream for the operator kernels' volume stage)
+  bool lhs_wjc_valid = false;
   double* d_work_m = nullptr;            // scratch of that term
   hipStream_t side_stream = nullptr;  // the trace kernel (and the exchange) run here, concurrently with the volume kernel
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -208,6 +211,7 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
 void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double* r);   // r = rhs - Au
 void launch_residual_inplace(d4est_hip_plan* plan, int n, const double* rhs, double* r);              // r = rhs - r
 void add_lhs_mass_term(d4est_hip_plan* plan, const double* u, double* Au);   // Au += V^T W J c V u when a coefficient is set
+const double* ensure_lhs_wjc(d4est_hip_plan* plan);   // w J c at the quadrature nodes (formed on first use after the coefficient / geometry changed)
 void launch_copy_blocks(hipStream_t stream, int n_blocks, const double* src, const long long* src_off, double* dst,
                         const long long* dst_off, const int* len);
 void launch_dot(d4est_hip_plan* plan, int n, const double* x, const double* y, double* out_dev);

@@ -98,11 +98,13 @@ __device__ __forceinline__ void bwd(const double* __restrict__ tab, const double
 // On entry the workgroup's threads have written u_e to R0 as [i + PN (j + N k)] (no barrier yet); on exit R0 holds (A u)_e in the same
 // layout, behind a barrier.  R0, R1: WaveCfg<N, NQ>::FS doubles each.  te = thread within the element, (a, b) = (te % NQ, te / NQ);
 // ns-independent: the caller loads and stores the element.  Operator arguments as stiffness_wave_kernel's.
-template <int N, int NQ, bool PF, bool EO, bool AFF>
+// MASS: + V^T [ w J c (V u) ], the zeroth-order term of a linearised nonlinear problem (see stiffness_wave_eo_element, d4est_hip_wave.h)
+template <int N, int NQ, bool PF, bool EO, bool AFF, bool MASS = false>
 __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, const double* __restrict__ metric, int qs, int ei, bool active,
                                                      int te, int a, int b, const double* __restrict__ Bop, const double* __restrict__ Gop,
                                                      const double* __restrict__ BopT, const double* __restrict__ GopT,
-                                                     const double* __restrict__ affine, const double* __restrict__ wq) {
+                                                     const double* __restrict__ affine, const double* __restrict__ wq,
+                                                     const double* __restrict__ cq = nullptr) {
   using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ;
   constexpr int NQ3 = NQ * NQ * NQ;
@@ -139,13 +141,16 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
 
   // ---- S2 (thread (iq=a, k=b)) interleaved with S3 (thread (iq=a, jq=b)): one field at a time through R0
   double gr[NQ], gs[NQ], gt[NQ];
+  double vm[MASS ? NQ : 1];   // MASS: V u, then w J c V u, at the thread's quadrature nodes
   // Multi-wave general path: the thread's 6 NQ metric values are requested MD quadrature planes ahead of their use.  Left to itself
   // the compiler requests one plane's six values, waits for all of them, multiplies, requests the next: NQ serialised memory
   // round trips in the middle of the element (12 at p = 11 -- most of an element's lifetime).  The registers for the planes in
   // flight come from gr and gs, which wait in the (then idle) LDS fields in thread-private slots during this stage.
   constexpr bool kPark = !PF && !AFF && C::THREADS > 64;
-  constexpr int MD = (D4EST_HIP_METRIC_DEPTH < NQ) ? D4EST_HIP_METRIC_DEPTH : NQ;
-  constexpr int ME = (D4EST_HIP_METRIC_EARLY < MD) ? D4EST_HIP_METRIC_EARLY : MD;   // planes requested before the last forward contraction
+  constexpr int MDW = MASS ? 2 : D4EST_HIP_METRIC_DEPTH;   // (the mass term's line takes the registers of two planes in flight)
+  constexpr int MD = (MDW < NQ) ? MDW : NQ;
+  constexpr int MEW = MASS ? 0 : D4EST_HIP_METRIC_EARLY;
+  constexpr int ME = (MEW < MD) ? MEW : MD;   // planes requested before the last forward contraction
   double mw[kPark ? NQ : 1][6];
   {
     double x1[N], x2[N], t[NQ], y[N];
@@ -204,11 +209,33 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
           for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
         __builtin_amdgcn_sched_barrier(0);
       }
-      fwd<N, NQ, EO, true>(GopT, y, gt);
+      if constexpr (!(MASS && kPark)) fwd<N, NQ, EO, true>(GopT, y, gt);
+      if constexpr (MASS && !kPark) fwd<N, NQ, EO, false>(BopT, y, vm);
+    }
+    if constexpr (MASS && kPark) {
+      // the mass term's line needs the registers of gs as well: every thread has read field 3, so R0 is free and gs waits there
+      // BEFORE the last two forward contractions (without the mass term it goes there after them, see the quadrature stage)
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int kq = 0; kq < NQ; ++kq) R0[kq * PL + te] = gs[kq];
+        fwd<N, NQ, EO, true>(GopT, y, gt);
+        fwd<N, NQ, EO, false>(BopT, y, vm);
+      }
     }
   }
 
   // ---- quadrature-point stage
+  if constexpr (MASS) {
+    if (active) {
+      const double* __restrict__ cp = cq + qs + (a + NQ * b);   // w J c, pre-combined (ensure_lhs_wjc)
+      double cv[NQ];
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) cv[kq] = cp[NQ * NQ * kq];
+#pragma unroll
+      for (int kq = 0; kq < NQ; ++kq) vm[kq] *= cv[kq];
+    }
+  }
   if constexpr (AFF) {
     if (active) {
     const double* __restrict__ c = affine + (size_t)6 * ei;
@@ -224,12 +251,14 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
     }
     }
   } else {
-    if constexpr (kPark) __syncthreads();   // every thread has read field 3: R0 is free as well
+    if constexpr (kPark && !MASS) __syncthreads();   // every thread has read field 3: R0 is free as well
     if (active) {
     const double* __restrict__ m = metric + (size_t)6 * qs + (a + NQ * b);
     if constexpr (kPark) {
+      if constexpr (!MASS) {
 #pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) R0[kq * PL + te] = gs[kq];
+        for (int kq = 0; kq < NQ; ++kq) R0[kq * PL + te] = gs[kq];
+      }
 #pragma unroll
       for (int kq = ME; kq < MD; ++kq)
 #pragma unroll
@@ -302,6 +331,7 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
     }
     if (active) {
       bwd<NQ, N, EO, true, false>(Gop, gt, c);
+      if constexpr (MASS) bwd<NQ, N, EO, false, true>(Bop, vm, c);   // both continue through B_s^T B_r^T
 #pragma unroll
       for (int k = 0; k < N; ++k) R0[b + PQ * (a + NQ * k)] = c[k];
     }

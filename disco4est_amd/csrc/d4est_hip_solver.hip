@@ -161,8 +161,11 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
       launch_traces(plan, u, plan->d_trace, false);
       plan->exchange_fn(plan->comm_ctx, 0, plan->d_trace, plan->d_ghost_trace);
     }
-    // the volume term rides in the same kernel (u in, A u out) unless an exchange is to overlap it or the zeroth-order term sits between
-    const bool whole = !has_ghost && !(lhs_term && plan->d_lhs_coeff) && direct_fused_ok(plan);
+    // the volume term rides in the same kernel (u in, A u out) unless an exchange is to overlap it; the zeroth-order term of
+    // plan_set_lhs_coefficient then sits in that kernel's volume stage (vol_term 2)
+    const bool mass = lhs_term && plan->d_lhs_coeff;
+    const bool whole = !has_ghost && direct_fused_ok(plan);
+    const int vterm = whole ? (mass ? 2 : 1) : 0;
     if (!whole) {
       launch_stiffness(plan, u, Au);
       if (lhs_term) add_lhs_mass_term(plan, u, Au);
@@ -173,9 +176,9 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
       df.rhs = cf->rhs; df.p = cf->p; df.u_out = cf->u_out; df.r = cf->r; df.alpha = cf->alpha; df.beta = cf->beta;
       df.skip_Au_store = (whole && cf->skip_Au_store) ? 1 : 0;
       if (!df.u_out || df.u_out == u) D4EST_HIP_ABORT("apply_operator: the direct face kernel needs a second vector for the fused update");
-      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, &df, whole ? 1 : 0);
+      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, &df, vterm);
     } else {
-      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, nullptr, whole ? 1 : 0);
+      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, nullptr, vterm);
     }
     return;
   }
@@ -214,9 +217,38 @@ void add_lhs_mass_term(d4est_hip_plan* plan, const double* u, double* Au) {
   if (!plan->d_lhs_coeff || plan->local_nodes == 0) return;
   const int n = plan->local_nodes;
   if (!plan->d_work_m) HIP_CHECK(hipMalloc(&plan->d_work_m, (size_t)n * sizeof(double)));
-  launch_mass_like(plan, 3, u, plan->d_work_m, plan->d_lhs_coeff, 0);
+  launch_mass_like(plan, 3, u, plan->d_work_m, plan->d_lhs_c, 0);
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, plan->d_work_m, Au);
   HIP_CHECK(hipGetLastError());
+}
+
+// w J c at the quadrature nodes of the elements of one (deg, deg_quad) bucket (elements that alias each other's quadrature block -- the
+// copies of a Schwarz subdomain plan -- write the same values)
+__global__ __launch_bounds__(256) void lhs_wjc_kernel(const int* __restrict__ qs_list, int n_bucket, int NQ, const double* __restrict__ w,
+                                                      const double* __restrict__ J, const double* __restrict__ c, double* __restrict__ wjc) {
+  const int NQ3 = NQ * NQ * NQ;
+  for (int i = blockIdx.x; i < n_bucket; i += gridDim.x) {
+    const int qs = qs_list[i];
+    for (int n = threadIdx.x; n < NQ3; n += blockDim.x) {
+      const int a = n % NQ, b = (n / NQ) % NQ, k = n / (NQ * NQ);
+      wjc[qs + n] = (w[k] * (w[b] * w[a])) * (J[qs + n] * c[qs + n]);
+    }
+  }
+}
+
+const double* ensure_lhs_wjc(d4est_hip_plan* plan) {
+  if (!plan->d_lhs_coeff) D4EST_HIP_ABORT("zeroth-order term: no coefficient is set (plan_set_lhs_coefficient)");
+  if (!plan->has_geometry) D4EST_HIP_ABORT("zeroth-order term: d4est_hip_plan_set_geometry was not called");
+  if (plan->lhs_wjc_valid) return plan->d_lhs_wjc;
+  if (!plan->d_lhs_wjc) HIP_CHECK(hipMalloc(&plan->d_lhs_wjc, std::max<size_t>((size_t)plan->local_nodes_quad, 1) * sizeof(double)));
+  for (const Bucket& bk : plan->buckets) {
+    if (bk.n_elem == 0) continue;
+    hipLaunchKernelGGL(lhs_wjc_kernel, dim3(std::min(bk.n_elem, 8192)), dim3(256), 0, plan->stream, plan->d_qs_list + bk.elem_offset, bk.n_elem,
+                       bk.NQ, bk.d_w, plan->d_J, plan->d_lhs_c, plan->d_lhs_wjc);
+  }
+  HIP_CHECK(hipGetLastError());
+  plan->lhs_wjc_valid = true;
+  return plan->d_lhs_wjc;
 }
 
 void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double* r) {

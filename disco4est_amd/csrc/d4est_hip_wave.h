@@ -408,12 +408,16 @@ struct WaveCfg {
 #ifndef D4EST_HIP_WAVE_EO_EARLY
 #define D4EST_HIP_WAVE_EO_EARLY 1
 #endif
-template <int N, int NQ, bool AFF, bool WG_SYNC>
+// MASS: the zeroth-order term of a linearised nonlinear problem rides along: + V^T [ w J c (V u) ] (d4est_quadrature_apply_fofufofvlilj,
+// src/Quadrature/d4est_quadrature.c:593-774, with the coefficient c = f(x, u0) handed over at the quadrature nodes) -- V u = B_t B_s B_r u
+// costs one more t-contraction of the line B_s B_r u the gradient already forms, the weighted value one more transposed t-contraction
+// summed into the G_t^T term; cq = w J c at the quadrature nodes (pre-combined when the coefficient is set: one stream of 8 B per node).
+template <int N, int NQ, bool AFF, bool WG_SYNC, bool MASS = false>
 __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1, const double* __restrict__ metric, int qs, int ei,
                                                           bool active, int a, int b, const double* __restrict__ EBf,
                                                           const double* __restrict__ EGf, const double* __restrict__ EBb,
                                                           const double* __restrict__ EGb, const double* __restrict__ affine,
-                                                          const double* __restrict__ wq) {
+                                                          const double* __restrict__ wq, const double* __restrict__ cq = nullptr) {
   using C = WaveCfg<N, NQ>;
   constexpr int PN = C::PN, PQ = C::PQ;
   constexpr int NQ3 = NQ * NQ * NQ;
@@ -448,6 +452,8 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
 
   // ---- S2 (thread (iq=a, k=b)) and S3 (thread (iq=a, jq=b))
   double gr[NQ], gs[NQ], gt[NQ];
+  // (MASS: V u at the thread's quadrature nodes waits in R1, in the thread's own slots [kq][te] -- R1 is idle between the last read of
+  // S3 and the first write of S5 -- and is weighted with w J c where the transposed t-contraction takes it: no registers across stages)
   // General path of the stand-alone kernel: the 6 NQ metric values of the thread are requested MD quadrature planes ahead of their
   // use, the first ME of them before the last forward contraction; the scheduling barriers pin "request plane kq + MD, multiply
   // plane kq" (the compiler's own order drains the queue between small groups: 6-7 dependent memory round trips at p = 7).
@@ -517,7 +523,15 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
         __builtin_amdgcn_sched_barrier(0);
       }
       eo_pre<N>(y3, y3e, y3o);
-      contract_single_eo<HN, NQ, false>(EGf, y3o, y3e, ge);
+      if constexpr (MASS) {
+        double he[NQ], vm[NQ];
+        contract_pair_eo<HN, NQ, false, false>(EGf, y3o, y3e, ge, EBf, y3e, y3o, he);
+        eo_post<NQ>(he, vm);
+#pragma unroll
+        for (int kq = 0; kq < NQ; ++kq) R1[kq * C::PL + (a + NQ * b)] = vm[kq];
+      } else {
+        contract_single_eo<HN, NQ, false>(EGf, y3o, y3e, ge);
+      }
       eo_post<NQ>(ge, gt);
     }
   }
@@ -583,6 +597,16 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
         eo_pre<NQ>(gt, te_, to);
         contract_pair_eo<HQ, N, false, false>(EBb, re, ro, ca, EBb, se, so, cb);
         contract_single_eo<HQ, N, false>(EGb, to, te_, cc);
+        if constexpr (MASS) {   // summed in (a | b) form with G_t^T(...): both continue through B_s^T B_r^T
+          const double* __restrict__ cp = cq + qs + (a + NQ * b);
+          double cv[NQ], vm[NQ], me[HQ], mo[HQ];
+#pragma unroll
+          for (int kq = 0; kq < NQ; ++kq) cv[kq] = cp[NQ * NQ * kq];
+#pragma unroll
+          for (int kq = 0; kq < NQ; ++kq) vm[kq] = lds_ld(&R1[kq * C::PL + (a + NQ * b)]) * cv[kq];
+          eo_pre<NQ>(vm, me, mo);
+          contract_single_eo<HQ, N, true>(EBb, me, mo, cc);
+        }
       }
       SYNC();
       if (active) {

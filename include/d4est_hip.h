@@ -270,7 +270,9 @@ void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const doub
 /* Linearised nonlinear problems: the reference's apply_lhs is d4est_laplacian_apply_aij plus, per element,
  * d4est_quadrature_apply_fofufofvlilj(u_e; f(x, u0)) added with axpy 1.0 (e.g. constant_density_star_apply_jac,
  * src/Problems/ConstantDensityStar/constant_density_star_fcns.h:777-850 with :528-603).  coeff_quad_dev[local_nodes_quad] = f at
- * the quadrature nodes (caller-owned device array, read at every apply; re-evaluate it when u0 changes); NULL = pure Laplacian.
+ * the quadrature nodes (device array; its values are CAPTURED by this call -- a plan-owned copy, and w J c pre-combined for the operator
+ * kernels, whose volume stage then carries the term for one extra stream of 8 B per node -- so call it again whenever u0, i.e. f,
+ * changes; the caller's array is not read afterwards); NULL = pure Laplacian.
  * The term then is part of d4est_hip_apply_lhs, _cheby_iterate, _cg_eigs and _schwarz_smooth; set on a Schwarz subdomain plan
  * (same array: the copies' quad_stride alias it) it is part of the subdomain operator.  d4est_hip_apply_aij stays the Laplacian. */
 void d4est_hip_plan_set_lhs_coefficient(d4est_hip_plan_t* plan, const double* coeff_quad_dev);

@@ -192,7 +192,7 @@ def test_cheby_update_fused_into_flux_is_bit_identical(gpu, hiplib, oracle, leve
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("level,deg,inc", [(1, 3, 0), (2, 2, 1), (1, 7, 0)])
+@pytest.mark.parametrize("level,deg,inc", [(1, 3, 0), (2, 2, 1), (1, 7, 0), (1, 6, 0), (1, 8, 0), (1, 11, 0)])
 def test_lhs_with_zeroth_order_term(gpu, hiplib, oracle, level, deg, inc):
     """apply_lhs = Laplacian + V^T W J c V u (the Jacobian of the reference's nonlinear problems, e.g. constant_density_star_apply_jac):
     apply_lhs, the Chebyshev iteration, cg_eigs and the Schwarz smoother with the coefficient set, against the oracle"""
