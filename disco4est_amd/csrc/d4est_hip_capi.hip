@@ -741,6 +741,34 @@ void d4est_hip_apply_lhs_host(d4est_hip_plan_t* plan, const double* u_host, doub
   stage_out_end(plan, 1, Au_host);
 }
 
+void d4est_hip_build_rhs_with_strong_bc(d4est_hip_plan_t* plan, const double* f_dev, int f_on_quad, double* rhs_dev) {
+  check_plan(plan, "build_rhs_with_strong_bc");
+  if (!f_dev || !rhs_dev) D4EST_HIP_ABORT("build_rhs_with_strong_bc: NULL vector");
+  if (!plan->has_faces) D4EST_HIP_ABORT("build_rhs_with_strong_bc: call plan_set_faces first");
+  d4est_hip::ensure_solver_workspace(plan);
+  const size_t bytes = std::max<size_t>((size_t)plan->local_nodes, 1) * sizeof(double);
+  // A(u = 0) with the plan's boundary data: the pure Laplacian, as the reference calls d4est_laplacian_apply_aij (:44)
+  HIP_CHECK(hipMemsetAsync(plan->d_work_d, 0, bytes, plan->stream));
+  d4est_hip::apply_operator(plan, plan->d_work_d, plan->d_work_r, nullptr, false);
+  d4est_hip::launch_mass_like(plan, f_on_quad ? 1 : 0, f_dev, rhs_dev);
+  d4est_hip::launch_residual_inplace_sub(plan, plan->local_nodes, plan->d_work_r, rhs_dev);   // rhs -= A(0)   (d4est_linalg_vec_axpy(-1, ...), :136)
+}
+
+void d4est_hip_build_rhs_with_strong_bc_host(d4est_hip_plan_t* plan, const double* f_host, int f_on_quad, double* rhs_host) {
+  check_plan(plan, "build_rhs_with_strong_bc_host");
+  if (!f_host || !rhs_host) D4EST_HIP_ABORT("build_rhs_with_strong_bc_host: NULL vector");
+  ensure_host_mirrors(plan);
+  const size_t nf = f_on_quad ? (size_t)plan->local_nodes_quad : (size_t)plan->local_nodes;
+  double* d_f = nullptr;   // (once per solve: a transient buffer, the quadrature-node form does not fit the nodal mirrors)
+  HIP_CHECK(hipMalloc(&d_f, std::max<size_t>(nf, 1) * sizeof(double)));
+  HIP_CHECK(hipMemcpyAsync(d_f, f_host, nf * sizeof(double), hipMemcpyHostToDevice, plan->stream));
+  d4est_hip_build_rhs_with_strong_bc(plan, d_f, f_on_quad, plan->d_host[2]);
+  stage_out_begin(plan, 1, plan->d_host[2]);
+  HIP_CHECK(hipStreamSynchronize(plan->stream));
+  stage_out_end(plan, 1, rhs_host);
+  HIP_CHECK(hipFree(d_f));
+}
+
 void d4est_hip_cheby_iterate_host(d4est_hip_plan_t* plan, double* u_host, const double* rhs_host, double* Au_host, double* r_host,
                                   int iter, double lmin, double lmax, int compute_residual_at_end) {
   check_plan(plan, "cheby_iterate_host");

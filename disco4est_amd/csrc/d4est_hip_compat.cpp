@@ -68,6 +68,70 @@ ElemCtx& elem_ctx(int deg, int deg_quad, int quad_type) {
   return g_elem.emplace(key, c).first->second;
 }
 
+// ---- QUAD_OBJECT_MORTAR: the (dim - 1)-dimensional forms of interpolate / apply_mass_matrix / apply_galerkin_integral.  The engine's
+// operator path never needs them (mortar integrals live inside the fused face kernels), but the reference's estimators and mesh update
+// call these entry points with mortar objects (src/Estimators/d4est_estimator_bi.c:85, src/Mesh/d4est_mortars.c), so a build that links
+// this library in front must serve them: a 2-D tensor apply on the host with the engine's own 1-D tables -- compatibility, not speed.
+struct Tab2 { std::vector<double> I, w; int N = 0, NQ = 0; };
+std::map<std::tuple<int, int, int>, Tab2> g_tab2;
+const Tab2& tab2(int deg, int deg_quad, int quad_type) {
+  auto key = std::make_tuple(deg, deg_quad, quad_type);
+  auto it = g_tab2.find(key);
+  if (it != g_tab2.end()) return it->second;
+  Tab2 t;
+  t.N = deg + 1; t.NQ = deg_quad + 1;
+  t.I.resize((size_t)t.NQ * t.N);
+  t.w.resize(t.NQ);
+  // src/Quadrature/d4est_quadrature_legendre.c:22-93 / d4est_quadrature_lobatto.c:23-93: interpolation to and weights of the rule
+  d4est_hip_table(quad_type == D4EST_HIP_QUAD_LOBATTO ? D4EST_HIP_TABLE_P_PROLONG : D4EST_HIP_TABLE_LOBATTO_TO_GAUSS, deg, deg_quad, t.I.data());
+  d4est_hip_table(quad_type == D4EST_HIP_QUAD_LOBATTO ? D4EST_HIP_TABLE_LOBATTO_WEIGHTS : D4EST_HIP_TABLE_GAUSS_WEIGHTS, deg_quad, 0, t.w.data());
+  return g_tab2.emplace(key, t).first->second;
+}
+// out[NQ x NQ] = (I (x) I) in[N x N]  (first index fastest, as d4est_kron_A1A2x_nonsqr: d4est_quadrature.c:1002-1005)
+void interp2(const Tab2& t, const double* in, double* out) {
+  std::vector<double> tmp((size_t)t.NQ * t.N);
+  for (int b = 0; b < t.N; ++b)
+    for (int aq = 0; aq < t.NQ; ++aq) {
+      double s = 0.0;
+      for (int a = 0; a < t.N; ++a) s += t.I[(size_t)aq * t.N + a] * in[a + t.N * b];
+      tmp[aq + (size_t)t.NQ * b] = s;
+    }
+  for (int bq = 0; bq < t.NQ; ++bq)
+    for (int aq = 0; aq < t.NQ; ++aq) {
+      double s = 0.0;
+      for (int b = 0; b < t.N; ++b) s += t.I[(size_t)bq * t.N + b] * tmp[aq + (size_t)t.NQ * b];
+      out[aq + (size_t)t.NQ * bq] = s;
+    }
+}
+// out[N x N] = (I (x) I)^T (w (x) w . jac . in)[NQ x NQ]   (d4est_quadrature.c:185-209, :441-466 with dim = 2)
+void galerkin2(const Tab2& t, const double* in_quad, const double* jac, double* out) {
+  std::vector<double> f((size_t)t.NQ * t.NQ), tmp((size_t)t.N * t.NQ);
+  for (int bq = 0; bq < t.NQ; ++bq)
+    for (int aq = 0; aq < t.NQ; ++aq) f[aq + (size_t)t.NQ * bq] = (t.w[bq] * t.w[aq]) * jac[aq + (size_t)t.NQ * bq] * in_quad[aq + (size_t)t.NQ * bq];
+  for (int bq = 0; bq < t.NQ; ++bq)
+    for (int a = 0; a < t.N; ++a) {
+      double s = 0.0;
+      for (int aq = 0; aq < t.NQ; ++aq) s += t.I[(size_t)aq * t.N + a] * f[aq + (size_t)t.NQ * bq];
+      tmp[a + (size_t)t.N * bq] = s;
+    }
+  for (int b = 0; b < t.N; ++b)
+    for (int a = 0; a < t.N; ++a) {
+      double s = 0.0;
+      for (int bq = 0; bq < t.NQ; ++bq) s += t.I[(size_t)bq * t.N + b] * tmp[a + (size_t)t.N * bq];
+      out[a + (size_t)t.N * b] = s;
+    }
+}
+
+// the apply_lhs callback the operator-level shims stand for (d4est_hip_compat_bind_operator); nullptr: not registered, not checked
+std::map<const void*, d4est_apply_operator_fcn_t> g_bound_lhs;
+void check_fcns(const void* p4est, const d4est_elliptic_eqns_t* fcns, const char* who) {
+  auto it = g_bound_lhs.find(p4est);
+  if (it == g_bound_lhs.end() || !it->second) return;
+  if (!fcns || fcns->apply_lhs != it->second)
+    COMPAT_ABORT("%s: fcns->apply_lhs is not the operator registered for this p4est (d4est_hip_compat_bind_operator): the bound plan applies "
+                 "the Laplacian + its zeroth-order term and would silently stand in for a different operator", who);
+}
+
 void need_dim3(int dim, const char* who) {
   if (dim != 3) COMPAT_ABORT("%s: dim = %d; the engine replaces the DIM = 3 (d8est) volume applies only", who, dim);
 }
@@ -164,6 +228,13 @@ void d4est_quadrature_apply_stiffness_matrix(d4est_operators_t*, d4est_quadratur
 void d4est_quadrature_apply_mass_matrix(d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t* d4est_quadrature, void*,
                                         d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t, double* in,
                                         int deg_lobatto, double* jac_quad, int deg_quad, double* out) {
+  if (object_type == QUAD_OBJECT_MORTAR) {   // dim - 1: V^T W J V in on the face
+    const Tab2& t = tab2(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature));
+    std::vector<double> q((size_t)t.NQ * t.NQ);
+    interp2(t, in, q.data());
+    galerkin2(t, q.data(), jac_quad, out);
+    return;
+  }
   need_volume(object_type, "d4est_quadrature_apply_mass_matrix");
   ElemCtx& c = elem_ctx(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature));
   upload_jacobian(c, jac_quad);
@@ -176,6 +247,10 @@ void d4est_quadrature_apply_mass_matrix(d4est_operators_t*, d4est_geometry_t*, d
 void d4est_quadrature_apply_galerkin_integral(d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t* d4est_quadrature, void*,
                                               d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t,
                                               double* in_quad, int deg_lobatto, double* jac_quad, int deg_quad, double* out) {
+  if (object_type == QUAD_OBJECT_MORTAR) {
+    galerkin2(tab2(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature)), in_quad, jac_quad, out);
+    return;
+  }
   need_volume(object_type, "d4est_quadrature_apply_galerkin_integral");
   ElemCtx& c = elem_ctx(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature));
   upload_jacobian(c, jac_quad);
@@ -188,6 +263,10 @@ void d4est_quadrature_apply_galerkin_integral(d4est_operators_t*, d4est_geometry
 void d4est_quadrature_interpolate(d4est_operators_t*, d4est_quadrature_t* d4est_quadrature, d4est_geometry_t*, void*,
                                   d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t, double* u_lobatto_in,
                                   int deg_lobatto, double* u_quad_out, int deg_quad) {
+  if (object_type == QUAD_OBJECT_MORTAR) {
+    interp2(tab2(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature)), u_lobatto_in, u_quad_out);
+    return;
+  }
   need_volume(object_type, "d4est_quadrature_interpolate");
   ElemCtx& c = elem_ctx(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature));
   upload(c, u_lobatto_in, c.N3);
@@ -204,6 +283,80 @@ void d4est_quadrature_apply_inverse_mass_matrix(d4est_operators_t*, double* in, 
   upload(c, in, c.N3);
   d4est_hip_apply_inverse_mass_matrix(c.plan, c.d_in, c.d_out);
   download(c, out, c.N3);
+}
+
+// ---- the callback-taking mass terms of the nonlinear problems (src/Quadrature/d4est_quadrature.c:593-774, :776-936), which the
+// Problem files call directly (e.g. constant_density_star_fcns.h:407, :575).  The user functions are HOST function pointers evaluated
+// per node, so that part runs on the host: f(x, u) at the quadrature nodes (u interpolated by the shim above), or at the Lobatto nodes
+// and then interpolated (interpolate_f); the integrals are the mass / galerkin shims.  A Newton-Krylov loop should instead evaluate f
+// once per Newton step and hand it over with d4est_hip_plan_set_lhs_coefficient: this is the compatibility path.
+static double compat_identity(double, double, double, double u, void*) { return u; }   // identity_fcn, src/Mesh/d4est_xyz_functions.c:38-48: f(x, u) = u
+
+// product of the two user functions at n nodes: at the quadrature nodes (fields interpolated first) or, with interpolate_f, at the
+// Lobatto nodes and interpolated afterwards; `scale` (may be NULL) multiplies the result node by node (the Jacobian)
+static void fofu_fofv(d4est_operators_t* ops, d4est_geometry_t* geom, d4est_quadrature_t* quad, void* object,
+                      d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t integrand_type, double* u, double* v,
+                      int deg_lobatto, double* xyz_quad[3], int deg_quad, d4est_xyzu_fcn_t fofu_fcn, void* fofu_ctx, d4est_xyzu_fcn_t fofv_fcn,
+                      void* fofv_ctx, int interpolate_f, double* xyz_lobatto[3], const double* scale, std::vector<double>& out) {
+  const int dim = (object_type == QUAD_OBJECT_MORTAR) ? 2 : 3;
+  int nq = 1, nl = 1;
+  for (int i = 0; i < dim; ++i) { nq *= deg_quad + 1; nl *= deg_lobatto + 1; }
+  const bool use_u = (u != nullptr) || (fofu_fcn != nullptr), use_v = (v != nullptr) || (fofv_fcn != nullptr);
+  if (!fofu_fcn) fofu_fcn = compat_identity;
+  if (!fofv_fcn) fofv_fcn = compat_identity;
+  out.assign(nq, 1.0);
+  if (!interpolate_f) {
+    std::vector<double> uq, vq;
+    if (u) { uq.resize(nq); d4est_quadrature_interpolate(ops, quad, geom, object, object_type, integrand_type, u, deg_lobatto, uq.data(), deg_quad); }
+    if (v) { vq.resize(nq); d4est_quadrature_interpolate(ops, quad, geom, object, object_type, integrand_type, v, deg_lobatto, vq.data(), deg_quad); }
+    for (int i = 0; i < nq; ++i) {
+      const double z = (dim == 3) ? xyz_quad[2][i] : 0.0;
+      double f = scale ? scale[i] : 1.0;
+      if (use_u) f *= fofu_fcn(xyz_quad[0][i], xyz_quad[1][i], z, u ? uq[i] : 0.0, fofu_ctx);
+      if (use_v) f *= fofv_fcn(xyz_quad[0][i], xyz_quad[1][i], z, v ? vq[i] : 0.0, fofv_ctx);
+      out[i] = f;
+    }
+  } else {
+    if (!xyz_lobatto) COMPAT_ABORT("interpolate_f == 1, but xyz_lobatto == NULL");
+    std::vector<double> fl(nl, 1.0);
+    for (int i = 0; i < nl; ++i) {
+      const double z = (dim == 3) ? xyz_lobatto[2][i] : 0.0;
+      if (use_u) fl[i] *= fofu_fcn(xyz_lobatto[0][i], xyz_lobatto[1][i], z, u ? u[i] : 0.0, fofu_ctx);
+      if (use_v) fl[i] *= fofv_fcn(xyz_lobatto[0][i], xyz_lobatto[1][i], z, v ? v[i] : 0.0, fofv_ctx);
+    }
+    d4est_quadrature_interpolate(ops, quad, geom, object, object_type, integrand_type, fl.data(), deg_lobatto, out.data(), deg_quad);
+    if (scale)
+      for (int i = 0; i < nq; ++i) out[i] *= scale[i];
+  }
+}
+
+// out = V^T W [J f(x,u) f(x,v)] V vec  (QUAD_APPLY_MATRIX; the dense-matrix form QUAD_COMPUTE_MATRIX is not served)
+void d4est_quadrature_apply_fofufofvlilj(d4est_operators_t* d4est_ops, d4est_geometry_t* d4est_geom, d4est_quadrature_t* d4est_quad, void* object,
+                                         d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t integrand_type,
+                                         double* vec, double* u, double* v, int deg_lobatto, double* xyz_quad[3], double* jac_quad, int deg_quad,
+                                         double* out, d4est_xyzu_fcn_t fofu_fcn, void* fofu_ctx, d4est_xyzu_fcn_t fofv_fcn, void* fofv_ctx,
+                                         d4est_quadrature_apply_or_compute_matrix_t apply_or_compute_matrix, int interpolate_f,
+                                         double* xyz_lobatto[3]) {
+  if (apply_or_compute_matrix != QUAD_APPLY_MATRIX)
+    COMPAT_ABORT("d4est_quadrature_apply_fofufofvlilj: QUAD_COMPUTE_MATRIX (the dense element matrix) is not served; apply it to unit vectors");
+  if (!vec) COMPAT_ABORT("d4est_quadrature_apply_fofufofvlilj: vec == NULL");
+  std::vector<double> fj;
+  fofu_fofv(d4est_ops, d4est_geom, d4est_quad, object, object_type, integrand_type, u, v, deg_lobatto, xyz_quad, deg_quad, fofu_fcn, fofu_ctx,
+            fofv_fcn, fofv_ctx, interpolate_f, xyz_lobatto, jac_quad, fj);
+  d4est_quadrature_apply_mass_matrix(d4est_ops, d4est_geom, d4est_quad, object, object_type, integrand_type, vec, deg_lobatto, fj.data(), deg_quad, out);
+}
+
+// out = V^T W J [f(x,u) f(x,v)]
+void d4est_quadrature_apply_fofufofvlj(d4est_operators_t* d4est_ops, d4est_geometry_t* d4est_geom, d4est_quadrature_t* d4est_quad, void* object,
+                                       d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t integrand_type, double* u,
+                                       double* v, int deg_lobatto, double* jac_quad, double* xyz_quad[3], int deg_quad, double* out,
+                                       d4est_xyzu_fcn_t fofu_fcn, void* fofu_ctx, d4est_xyzu_fcn_t fofv_fcn, void* fofv_ctx, int interpolate_f,
+                                       double* xyz_lobatto[3]) {
+  std::vector<double> f;
+  fofu_fofv(d4est_ops, d4est_geom, d4est_quad, object, object_type, integrand_type, u, v, deg_lobatto, xyz_quad, deg_quad, fofu_fcn, fofu_ctx,
+            fofv_fcn, fofv_ctx, interpolate_f, xyz_lobatto, nullptr, f);
+  d4est_quadrature_apply_galerkin_integral(d4est_ops, d4est_geom, d4est_quad, object, object_type, integrand_type, f.data(), deg_lobatto, jac_quad,
+                                           deg_quad, out);
 }
 
 // ---- src/dGMath/d4est_operators.c -------------------------------------------------------------------------------------------
@@ -307,17 +460,19 @@ void d4est_laplacian_with_opt_apply_aij(p4est_t* p4est, d4est_ghost_t*, d4est_gh
 
 void d4est_solver_multigrid_smoother_cheby_iterate_aux(p4est_t* p4est, d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t*,
                                                        d4est_mesh_data_t*, d4est_ghost_t*, d4est_ghost_data_t*, d4est_elliptic_data_t* vecs,
-                                                       d4est_elliptic_eqns_t*, double* r, int iter, double lmin, double lmax,
+                                                       d4est_elliptic_eqns_t* fcns, double* r, int iter, double lmin, double lmax,
                                                        int /*print_residual_norm*/, int /*mg_level*/, int compute_residual_at_end) {
   d4est_hip_plan_t* plan = bound(p4est, "d4est_solver_multigrid_smoother_cheby_iterate_aux");
+  check_fcns(p4est, fcns, "d4est_solver_multigrid_smoother_cheby_iterate_aux");
   if (!vecs || vecs->local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("cheby_iterate_aux: elliptic data does not match the bound plan");
   d4est_hip_cheby_iterate_host(plan, vecs->u, vecs->rhs, vecs->Au, r, iter, lmin, lmax, compute_residual_at_end);
 }
 
-void cg_eigs(p4est_t* p4est, d4est_elliptic_data_t* vecs, d4est_elliptic_eqns_t*, d4est_ghost_t*, d4est_ghost_data_t*, d4est_operators_t*,
+void cg_eigs(p4est_t* p4est, d4est_elliptic_data_t* vecs, d4est_elliptic_eqns_t* fcns, d4est_ghost_t*, d4est_ghost_data_t*, d4est_operators_t*,
              d4est_geometry_t*, d4est_quadrature_t*, d4est_mesh_data_t*, int imax, int /*print_spectral_bound_iterations*/, int use_new,
              double* spectral_bound) {
   d4est_hip_plan_t* plan = bound(p4est, "cg_eigs");
+  check_fcns(p4est, fcns, "cg_eigs");
   if (!vecs || vecs->local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("cg_eigs: elliptic data does not match the bound plan");
   const double b = d4est_hip_cg_eigs_host(plan, vecs->u, vecs->rhs, vecs->Au, imax, use_new, nullptr);
   if (spectral_bound) *spectral_bound = b;
@@ -325,7 +480,22 @@ void cg_eigs(p4est_t* p4est, d4est_elliptic_data_t* vecs, d4est_elliptic_eqns_t*
 
 void d4est_hip_compat_bind_mesh(const void* p4est, d4est_hip_plan_t* plan) {
   if (plan) g_bound[p4est] = plan;
-  else g_bound.erase(p4est);
+  else { g_bound.erase(p4est); g_bound_lhs.erase(p4est); }
+}
+void d4est_hip_compat_bind_operator(const void* p4est, d4est_apply_operator_fcn_t apply_lhs) {
+  if (apply_lhs) g_bound_lhs[p4est] = apply_lhs;
+  else g_bound_lhs.erase(p4est);
+}
+
+// rhs = M f - A(0) on the bound plan (d4est_laplacian_build_rhs_with_strong_bc, src/dGMath/d4est_laplacian.c:16-140); the caller
+// evaluates the source term with d4est_mesh_init_field and sets the plan's boundary data (see the header)
+void d4est_hip_compat_build_rhs_with_strong_bc(const void* p4est, d4est_elliptic_data_t* prob_vecs, double* rhs, const double* f,
+                                               int init_option, int which_field) {
+  d4est_hip_plan_t* plan = bound(p4est, "d4est_hip_compat_build_rhs_with_strong_bc");
+  if (!prob_vecs || prob_vecs->local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("build_rhs_with_strong_bc: elliptic data does not match the bound plan");
+  // d4est_mesh_init_field_option_t (src/Mesh/d4est_mesh.h:19): INIT_FIELD_NOT_SET = 0, INIT_FIELD_ON_LOBATTO = 1, INIT_FIELD_ON_QUAD = 2
+  if (init_option != 1 && init_option != 2) COMPAT_ABORT("build_rhs_with_strong_bc: init_option %d is not a supported init option (INIT_FIELD_ON_LOBATTO = 1 / INIT_FIELD_ON_QUAD = 2)", init_option);
+  d4est_hip_build_rhs_with_strong_bc_host(plan, f, init_option == 2, rhs + (size_t)which_field * prob_vecs->local_nodes);
 }
 d4est_hip_plan_t* d4est_hip_compat_bound_plan(const void* p4est) {
   auto it = g_bound.find(p4est);

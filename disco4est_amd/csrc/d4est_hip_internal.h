@@ -210,6 +210,8 @@ void faces_destroy(d4est_hip_plan* plan);
 void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const ChebyFuse* cf = nullptr, bool lhs_term = true);
 void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const double* Au, double* r);   // r = rhs - Au
 void launch_residual_inplace(d4est_hip_plan* plan, int n, const double* rhs, double* r);              // r = rhs - r
+void launch_residual_inplace_sub(d4est_hip_plan* plan, int n, const double* a, double* r);            // r = r - a
+void ensure_solver_workspace(d4est_hip_plan* plan);
 void add_lhs_mass_term(d4est_hip_plan* plan, const double* u, double* Au);   // Au += V^T W J c V u when a coefficient is set
 const double* ensure_lhs_wjc(d4est_hip_plan* plan);   // w J c at the quadrature nodes (formed on first use after the coefficient / geometry changed)
 void launch_copy_blocks(hipStream_t stream, int n_blocks, const double* src, const long long* src_off, double* dst,

@@ -256,6 +256,14 @@ void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const doubl
   HIP_CHECK(hipGetLastError());
 }
 
+__global__ __launch_bounds__(256) void sub_inplace_kernel(int n, const double* __restrict__ a, double* __restrict__ r) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) r[i] = r[i] - a[i];
+}
+void launch_residual_inplace_sub(d4est_hip_plan* plan, int n, const double* a, double* r) {
+  if (n > 0) hipLaunchKernelGGL(sub_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, a, r);
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_residual_inplace(d4est_hip_plan* plan, int n, const double* rhs, double* r) {
   if (n > 0) hipLaunchKernelGGL(residual_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, plan->stream, n, rhs, r);
   HIP_CHECK(hipGetLastError());

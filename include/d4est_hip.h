@@ -267,6 +267,16 @@ void d4est_hip_apply_flux(d4est_hip_plan_t* plan, const double* trace_dev, const
  * ghost_trace_dev may be NULL when the plan has no ghost elements. */
 void d4est_hip_apply_aij(d4est_hip_plan_t* plan, const double* u_dev, const double* ghost_trace_dev, double* Au_dev);
 
+/* rhs = M f - A(0): d4est_laplacian_build_rhs_with_strong_bc (src/dGMath/d4est_laplacian.c:16-140), which every Problem calls once per
+ * solve: the source term integrated against the test functions -- f given at the Lobatto nodes (f_on_quad = 0: M f,
+ * d4est_quadrature_apply_mass_matrix per element, INIT_FIELD_ON_LOBATTO) or at the quadrature nodes (f_on_quad = 1: V^T W J f,
+ * d4est_quadrature_apply_galerkin_integral, INIT_FIELD_ON_QUAD) -- minus the Laplacian applied to u = 0 WITH the inhomogeneous boundary
+ * data currently set on the plan (d4est_hip_plan_set_dirichlet_values / _set_robin_values: the reference's
+ * flux_fcn_data_for_build_rhs; reset them to the homogeneous data of apply_lhs afterwards).  Needs plan_set_faces; on plans with ghost
+ * sides the exchange hooks of plan_set_comm.  f_dev / rhs_dev: device arrays; the _host form takes the reference's host vectors. */
+void d4est_hip_build_rhs_with_strong_bc(d4est_hip_plan_t* plan, const double* f_dev, int f_on_quad, double* rhs_dev);
+void d4est_hip_build_rhs_with_strong_bc_host(d4est_hip_plan_t* plan, const double* f_host, int f_on_quad, double* rhs_host);
+
 /* Linearised nonlinear problems: the reference's apply_lhs is d4est_laplacian_apply_aij plus, per element,
  * d4est_quadrature_apply_fofufofvlilj(u_e; f(x, u0)) added with axpy 1.0 (e.g. constant_density_star_apply_jac,
  * src/Problems/ConstantDensityStar/constant_density_star_fcns.h:777-850 with :528-603).  coeff_quad_dev[local_nodes_quad] = f at

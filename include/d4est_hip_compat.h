@@ -17,7 +17,8 @@
  * pinned staging and device buffers: no hipMalloc per call (one set per (deg, deg_quad) pair on first use).  They are the
  * compatibility path, PCIe- and launch-latency bound (tens of microseconds per element); the fast path is a whole-mesh plan
  * (include/d4est_hip.h) bound to the p4est with d4est_hip_compat_bind_mesh, which the operator-level shims use.
- * Volume objects, DIM = 3 only (the reference's d8est build); other `dim` values abort.  Errors abort (D4EST_ABORT convention).
+ * DIM = 3 only (the reference's d8est build); other `dim` values abort.  Volume objects run on the device; QUAD_OBJECT_MORTAR objects of
+ * the quadrature entry points (interpolate, mass, galerkin, the two callback forms) are served on the host.  Errors abort (D4EST_ABORT).
  */
 #ifndef D4EST_HIP_COMPAT_H
 #define D4EST_HIP_COMPAT_H
@@ -45,9 +46,14 @@ typedef struct d4est_laplacian_with_opt_flux_data_opaque d4est_laplacian_with_op
 typedef int d4est_quadrature_object_type_t;                     /* enum {QUAD_OBJECT_MORTAR, QUAD_OBJECT_VOLUME}, d4est_quadrature.h:16-17 */
 typedef int d4est_quadrature_integrand_type_t;                  /* enum, d4est_quadrature.h:21-29 */
 typedef int d4est_field_type_t;                                 /* enum, Mesh/d4est_field.h */
+typedef int d4est_quadrature_apply_or_compute_matrix_t;         /* enum {QUAD_APPLY_MATRIX, QUAD_COMPUTE_MATRIX}, d4est_quadrature.h:19 */
 #define QUAD_OBJECT_MORTAR 0
 #define QUAD_OBJECT_VOLUME 1
 #define QUAD_INTEGRAND_UNKNOWN 5
+#define QUAD_APPLY_MATRIX 0
+#define QUAD_COMPUTE_MATRIX 1
+/* src/Mesh/d4est_xyz_functions.h:27-37 (DIM = 3): f(x, y, z, u, user) */
+typedef double (*d4est_xyzu_fcn_t)(double, double, double, double, void*);
 
 /* src/EllipticSystem/d4est_elliptic_data.h:6-37 (all four vectors are aliases the callee never owns) */
 typedef struct {
@@ -77,6 +83,13 @@ void d4est_quadrature_apply_mass_matrix(d4est_operators_t *d4est_ops,d4est_geome
 void d4est_quadrature_apply_galerkin_integral(d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geometry,d4est_quadrature_t *d4est_quadrature,void *object,d4est_quadrature_object_type_t object_type,d4est_quadrature_integrand_type_t integrand_type,double *in_quad,int deg_lobatto,double *jac_quad,int deg_quad,double *out);
 void d4est_quadrature_interpolate(d4est_operators_t *d4est_ops,d4est_quadrature_t *d4est_quadrature,d4est_geometry_t *d4est_geometry,void *object,d4est_quadrature_object_type_t object_type,d4est_quadrature_integrand_type_t integrand_type,double *u_lobatto_in,int deg_lobatto,double *u_quad_out,int deg_quad);
 void d4est_quadrature_apply_inverse_mass_matrix(d4est_operators_t *d4est_ops,double *in,int deg_Lobatto,double *jac_Gauss,int deg_Gauss,int dim,double *out);
+/* the mass terms of the nonlinear problems with their user callbacks (d4est_quadrature.h:135, :138; d4est_quadrature.c:776-936, :593-774),
+ * called directly by the Problem files (src/Problems/ConstantDensityStar/constant_density_star_fcns.h:407, :575): the callbacks are host
+ * function pointers, evaluated on the host at the quadrature nodes (or, interpolate_f, at the Lobatto nodes), the integrals run through
+ * the shims above.  QUAD_COMPUTE_MATRIX (the dense element matrix) aborts.  interpolate / apply_mass_matrix / apply_galerkin_integral
+ * and these two also serve QUAD_OBJECT_MORTAR objects (dim - 1, on the host), as the reference's estimators and mesh update need. */
+void d4est_quadrature_apply_fofufofvlj(d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,void *object,d4est_quadrature_object_type_t object_type,d4est_quadrature_integrand_type_t integrand_type,double *u,double *v,int deg_lobatto,double *jac_quad,double *xyz_quad[3],int deg_quad,double *out,d4est_xyzu_fcn_t fofu_fcn,void *fofu_ctx,d4est_xyzu_fcn_t fofv_fcn,void *fofv_ctx,int interpolate_f,double *xyz_lobatto[3]);
+void d4est_quadrature_apply_fofufofvlilj(d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,void *object,d4est_quadrature_object_type_t object_type,d4est_quadrature_integrand_type_t integrand_type,double *vec,double *u,double *v,int deg_lobatto,double *xyz_quad[3],double *jac_quad,int deg_quad,double *out,d4est_xyzu_fcn_t fofu_fcn,void *fofu_ctx,d4est_xyzu_fcn_t fofv_fcn,void *fofv_ctx,d4est_quadrature_apply_or_compute_matrix_t apply_or_compute_matrix,int interpolate_f,double *xyz_lobatto[3]);
 
 /* ---- element level: src/dGMath/d4est_operators.h:69-126 -------------------------------------------------------------------- */
 void d4est_operators_apply_dij(d4est_operators_t *d4est_ops,double *D4EST_RESTRICT in,int dim,int deg,int dir,double *D4EST_RESTRICT out);
@@ -101,7 +114,10 @@ void d4est_operators_apply_hp_prolong_transpose(d4est_operators_t *d4est_ops,dou
  *                                              is not read: SIPG parameters and boundary data are the plan's
  *   ..._smoother_cheby_iterate_aux             src/Solver/d4est_solver_multigrid_smoother_cheby.h:33; `fcns` is NOT called: the
  *                                              operator is the bound plan's apply_lhs (Laplacian + the zeroth-order term of
- *                                              d4est_hip_plan_set_lhs_coefficient), the whole loop runs on the device
+ *                                              d4est_hip_plan_set_lhs_coefficient), the whole loop runs on the device.  So that a
+ *                                              caller with a DIFFERENT apply_lhs is not served the wrong operator silently, register
+ *                                              the callback the plan stands for with d4est_hip_compat_bind_operator: the two shims
+ *                                              then abort when fcns->apply_lhs is another function
  *   cg_eigs                                    src/Solver/d4est_solver_cg_eigs.h:9 */
 void d4est_laplacian_apply_stiffness_matrix(p4est_t *p4est,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,double *D4EST_RESTRICT u,double *D4EST_RESTRICT Au,int local_nodes,int which_field);
 void d4est_laplacian_apply_aij(p4est_t *p4est,d4est_ghost_t *d4est_ghost,d4est_ghost_data_t *d4est_ghost_data,d4est_elliptic_data_t *d4est_elliptic_data,d4est_laplacian_flux_data_t *flux_fcn_data,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,int which_field);
@@ -119,6 +135,17 @@ void cg_eigs(p4est_t *p4est,d4est_elliptic_data_t *vecs,d4est_elliptic_eqns_t *f
  * The plan stays owned by the caller. */
 void d4est_hip_compat_bind_mesh(const void* p4est, d4est_hip_plan_t* plan);
 d4est_hip_plan_t* d4est_hip_compat_bound_plan(const void* p4est);
+#ifndef D4EST_HIP_COMPAT_NO_TYPES
+/* the apply_lhs callback whose operator the bound plan applies (e.g. constant_density_star_apply_jac): cheby_iterate_aux / cg_eigs abort
+ * on any other fcns->apply_lhs; NULL removes the registration (then fcns is not looked at) */
+void d4est_hip_compat_bind_operator(const void* p4est, d4est_apply_operator_fcn_t apply_lhs);
+/* d4est_laplacian_build_rhs_with_strong_bc (src/dGMath/d4est_laplacian.c:16-140) on the bound plan: rhs[which_field] = M f - A(0).
+ * The reference's function evaluates the source callback through d4est_mesh_init_field (it needs the p4est and the mesh data, which
+ * the shims cannot read), so the caller does that step -- one call it already has -- and passes the values: f at the Lobatto nodes
+ * (init_option 1 = INIT_FIELD_ON_LOBATTO) or at the quadrature nodes (2 = INIT_FIELD_ON_QUAD; the values of d4est_mesh_init_field_option_t).  Boundary data: set the inhomogeneous
+ * values on the plan first (d4est_hip_plan_set_dirichlet_values), the homogeneous ones afterwards.  INTEGRATION.md section 3. */
+void d4est_hip_compat_build_rhs_with_strong_bc(const void* p4est, d4est_elliptic_data_t* prob_vecs, double* rhs, const double* f, int init_option, int which_field);
+#endif
 /* free the cached one-element plans, transfer objects and staging buffers of the element-level shims */
 void d4est_hip_compat_release(void);
 

@@ -33,6 +33,13 @@ static void check(const char* what, int p, const double* got, const double* ref,
 
 static double* vec(int n) { return (double*)calloc((size_t)(n > 0 ? n : 1), sizeof(double)); }
 
+/* user callbacks of the d4est_xyzu_fcn_t form (src/Mesh/d4est_xyz_functions.h:27-37) */
+static double probe_f(double x, double y, double z, double u, void* ctx) { return 1.0 + x - 0.5 * y + *(double*)ctx * z + u * u; }
+static double probe_g(double x, double y, double z, double v, void* ctx) { return *(double*)ctx + 0.3 * x * y - z + 0.7 * v; }
+/* two apply_lhs callbacks of the d4est_apply_operator_fcn_t form: the registered one and another */
+static void probe_lhs_a(p4est_t* a, d4est_ghost_t* b, d4est_ghost_data_t* c, d4est_elliptic_data_t* d, d4est_operators_t* e, d4est_geometry_t* f,
+                        d4est_quadrature_t* g, d4est_mesh_data_t* h, void* i) { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; }
+
 /* a d4est_quadrature_t as the reference lays it out: the first member is the quadrature type (0 legendre, 1 lobatto) */
 typedef struct { int quad_type; void* getters[4]; void* user; void* fns[2]; } fake_quadrature_t;
 
@@ -68,6 +75,87 @@ static void element_level(int p, int pq, int quad_type) {
   d4est_quadrature_interpolate(NULL, quad, NULL, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, u, p, got, pq);
   oracle_quadrature_interpolate(quad_type, u, p, ref, pq);
   snprintf(nm, sizeof nm, "interpolate q%d dq%d", quad_type, pq - p); check(nm, p, got, ref, q3, 1e-12);
+  /* the callback-taking mass terms (d4est_quadrature.c:593-774, :776-936): user functions f(x, u), g(x, v) on the host; the expected
+   * values are composed from the oracle's interpolate / mass / galerkin with the same functions evaluated here */
+  {
+    double *v = vec(n3), *xyzq[3], *xyzl[3], *uq = vec(q3), *vq = vec(q3), *fj = vec(q3), *fl = vec(n3);
+    for (int i = 0; i < n3; i++) v[i] = lcg(&seed) - 0.5;
+    for (int d = 0; d < 3; d++) {
+      xyzq[d] = vec(q3); xyzl[d] = vec(n3);
+      for (int i = 0; i < q3; i++) xyzq[d][i] = lcg(&seed);
+      for (int i = 0; i < n3; i++) xyzl[d][i] = lcg(&seed);
+    }
+    double ctx[2] = {0.25, 1.5};
+    oracle_quadrature_interpolate(quad_type, u, p, uq, pq);
+    oracle_quadrature_interpolate(quad_type, v, p, vq, pq);
+    /* (1) lilj, both fields and both callbacks, functions at the quadrature nodes */
+    for (int i = 0; i < q3; i++) fj[i] = J[i] * probe_f(xyzq[0][i], xyzq[1][i], xyzq[2][i], uq[i], ctx) * probe_g(xyzq[0][i], xyzq[1][i], xyzq[2][i], vq[i], ctx + 1);
+    oracle_quadrature_apply_mass_matrix(quad_type, u, p, fj, pq, ref);
+    d4est_quadrature_apply_fofufofvlilj(NULL, NULL, quad, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, u, u, v, p, xyzq, J, pq, got, probe_f, ctx,
+                                        probe_g, ctx + 1, QUAD_APPLY_MATRIX, 0, NULL);
+    snprintf(nm, sizeof nm, "apply_fofufofvlilj q%d dq%d", quad_type, pq - p); check(nm, p, got, ref, n3, 1e-12);
+    /* (2) lilj with u only and NO callback: identity_fcn, i.e. the coefficient is u itself (d4est_xyz_functions.c:38-48); v and g absent */
+    for (int i = 0; i < q3; i++) fj[i] = J[i] * uq[i];
+    oracle_quadrature_apply_mass_matrix(quad_type, v, p, fj, pq, ref);
+    d4est_quadrature_apply_fofufofvlilj(NULL, NULL, quad, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, v, u, NULL, p, xyzq, J, pq, got, NULL, NULL,
+                                        NULL, NULL, QUAD_APPLY_MATRIX, 0, NULL);
+    snprintf(nm, sizeof nm, "apply_fofufofvlilj identity q%d dq%d", quad_type, pq - p); check(nm, p, got, ref, n3, 1e-12);
+    /* (3) lilj, interpolate_f: the functions at the Lobatto nodes, the product interpolated, then times J */
+    for (int i = 0; i < n3; i++) fl[i] = probe_f(xyzl[0][i], xyzl[1][i], xyzl[2][i], u[i], ctx);
+    oracle_quadrature_interpolate(quad_type, fl, p, fj, pq);
+    for (int i = 0; i < q3; i++) fj[i] *= J[i];
+    oracle_quadrature_apply_mass_matrix(quad_type, v, p, fj, pq, ref);
+    d4est_quadrature_apply_fofufofvlilj(NULL, NULL, quad, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, v, u, NULL, p, xyzq, J, pq, got, probe_f, ctx,
+                                        NULL, NULL, QUAD_APPLY_MATRIX, 1, xyzl);
+    snprintf(nm, sizeof nm, "apply_fofufofvlilj interp_f q%d dq%d", quad_type, pq - p); check(nm, p, got, ref, n3, 1e-12);
+    /* (4) lj: V^T W J f(x, u) g(x, v), and a callback without a field (u == NULL: the function sees 0) */
+    for (int i = 0; i < q3; i++) fj[i] = probe_f(xyzq[0][i], xyzq[1][i], xyzq[2][i], uq[i], ctx) * probe_g(xyzq[0][i], xyzq[1][i], xyzq[2][i], vq[i], ctx + 1);
+    oracle_quadrature_apply_galerkin_integral(quad_type, fj, p, J, pq, ref);
+    d4est_quadrature_apply_fofufofvlj(NULL, NULL, quad, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, u, v, p, J, xyzq, pq, got, probe_f, ctx, probe_g,
+                                      ctx + 1, 0, NULL);
+    snprintf(nm, sizeof nm, "apply_fofufofvlj q%d dq%d", quad_type, pq - p); check(nm, p, got, ref, n3, 1e-12);
+    for (int i = 0; i < q3; i++) fj[i] = probe_f(xyzq[0][i], xyzq[1][i], xyzq[2][i], 0.0, ctx);
+    oracle_quadrature_apply_galerkin_integral(quad_type, fj, p, J, pq, ref);
+    d4est_quadrature_apply_fofufofvlj(NULL, NULL, quad, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, NULL, NULL, p, J, xyzq, pq, got, probe_f, ctx, NULL,
+                                      NULL, 0, NULL);
+    snprintf(nm, sizeof nm, "apply_fofufofvlj no field q%d dq%d", quad_type, pq - p); check(nm, p, got, ref, n3, 1e-12);
+    /* QUAD_OBJECT_MORTAR (dim - 1, host): interpolate / mass / galerkin against sums written out here from the oracle's 1-D tables */
+    {
+      double *I1 = vec(NQ * N), *w1 = vec(NQ), *q2 = vec(NQ * NQ), *r2 = vec(NQ * NQ > n2 ? NQ * NQ : n2), *g2 = vec(NQ * NQ > n2 ? NQ * NQ : n2);
+      oracle_quad_interp(quad_type, p, pq, I1);
+      oracle_quad_weights(quad_type, pq, w1);
+      for (int bq = 0; bq < NQ; bq++)
+        for (int aq = 0; aq < NQ; aq++) {
+          double s = 0;
+          for (int b = 0; b < N; b++)
+            for (int a = 0; a < N; a++) s += I1[bq * N + b] * I1[aq * N + a] * u[a + N * b];
+          q2[aq + NQ * bq] = s;
+        }
+      d4est_quadrature_interpolate(NULL, quad, NULL, NULL, QUAD_OBJECT_MORTAR, QUAD_INTEGRAND_UNKNOWN, u, p, g2, pq);
+      snprintf(nm, sizeof nm, "interpolate MORTAR q%d dq%d", quad_type, pq - p); check(nm, p, g2, q2, NQ * NQ, 1e-13);
+      for (int b = 0; b < N; b++)
+        for (int a = 0; a < N; a++) {
+          double s = 0;
+          for (int bq = 0; bq < NQ; bq++)
+            for (int aq = 0; aq < NQ; aq++) s += I1[bq * N + b] * I1[aq * N + a] * w1[aq] * w1[bq] * J[aq + NQ * bq] * q2[aq + NQ * bq];
+          r2[a + N * b] = s;
+        }
+      d4est_quadrature_apply_mass_matrix(NULL, NULL, quad, NULL, QUAD_OBJECT_MORTAR, QUAD_INTEGRAND_UNKNOWN, u, p, J, pq, g2);
+      snprintf(nm, sizeof nm, "apply_mass_matrix MORTAR q%d dq%d", quad_type, pq - p); check(nm, p, g2, r2, n2, 1e-13);
+      for (int b = 0; b < N; b++)
+        for (int a = 0; a < N; a++) {
+          double s = 0;
+          for (int bq = 0; bq < NQ; bq++)
+            for (int aq = 0; aq < NQ; aq++) s += I1[bq * N + b] * I1[aq * N + a] * w1[aq] * w1[bq] * J[aq + NQ * bq] * fq[aq + NQ * bq];
+          r2[a + N * b] = s;
+        }
+      d4est_quadrature_apply_galerkin_integral(NULL, NULL, quad, NULL, QUAD_OBJECT_MORTAR, QUAD_INTEGRAND_UNKNOWN, fq, p, J, pq, g2);
+      snprintf(nm, sizeof nm, "apply_galerkin_integral MORTAR q%d dq%d", quad_type, pq - p); check(nm, p, g2, r2, n2, 1e-13);
+      free(I1); free(w1); free(q2); free(r2); free(g2);
+    }
+    for (int d = 0; d < 3; d++) { free(xyzq[d]); free(xyzl[d]); }
+    free(v); free(uq); free(vq); free(fj); free(fl);
+  }
   if (pq == p && quad_type == 0) {
     d4est_quadrature_apply_inverse_mass_matrix(NULL, u, p, J, pq, 3, got);
     oracle_quadrature_apply_inverse_mass_matrix(u, p, J, pq, ref);
@@ -183,14 +271,66 @@ static void operator_level(int p) {
   check("cheby_iterate_aux: r", p, r, rr, ln, 1e-10);
   check("cheby_iterate_aux: Au", p, Au, Aur, ln, 1e-10);
 
+  /* the smoother shims with the operator's callback registered: the matching fcns passes (a mismatch aborts: tests/test_compat_gpu.py) */
+  {
+    d4est_elliptic_eqns_t fcns;
+    memset(&fcns, 0, sizeof fcns);
+    fcns.apply_lhs = probe_lhs_a;
+    d4est_hip_compat_bind_operator(p4est, probe_lhs_a);
+    double b2 = 0;
+    memcpy(u, ur, sizeof(double) * ln);
+    cg_eigs(p4est, &vecs, &fcns, NULL, NULL, NULL, NULL, NULL, NULL, 4, 0, 1, &b2);
+    printf("%-34s p=%2d  registered apply_lhs accepted (bound %.6e)\n", "cg_eigs with fcns", p, b2);
+    d4est_hip_compat_bind_operator(p4est, NULL);
+  }
+  /* d4est_laplacian_build_rhs_with_strong_bc (d4est_laplacian.c:16-140): rhs = M f - A(0) with inhomogeneous Dirichlet data */
+  {
+    double *g = vec(total_bndry), *f = vec(ln), *zero = vec(ln), *A0 = vec(ln), *Mf = vec(ln), *got = vec(ln);
+    for (int i = 0; i < total_bndry; i++) g[i] = lcg(&seed) - 0.5;
+    for (int i = 0; i < ln; i++) f[i] = lcg(&seed) - 0.5;
+    d4est_hip_plan_set_dirichlet_values(plan, g, 0);
+    d4est_hip_compat_build_rhs_with_strong_bc(p4est, &vecs, got, f, 1 /* INIT_FIELD_ON_LOBATTO */, 0);
+    oracle_laplacian_apply_aij(0, ne, deg, degq, ns, qs, ln, ln, J, rst, 0, NULL, NULL, NULL, 0, side_nbr, side_nbr_face, side_reorder,
+                               side_mortar_stride, side_bndry_stride, sj, nrm, dm, dm, hm, hm, 10.0, 0, zero, NULL, g, A0, 1);
+    oracle_laplacian_apply_mass_matrix(0, ne, deg, degq, ns, qs, J, f, Mf, 1);
+    for (int i = 0; i < ln; i++) ref[i] = Mf[i] - A0[i];
+    check("build_rhs_with_strong_bc (lobatto)", p, got, ref, ln, 1e-12);
+    d4est_hip_compat_build_rhs_with_strong_bc(p4est, &vecs, got, f, 2 /* INIT_FIELD_ON_QUAD: deg_quad = deg here, ln quadrature nodes */, 0);
+    for (int e = 0; e < ne; e++) oracle_quadrature_apply_galerkin_integral(0, f + qs[e], p, J + qs[e], p, Mf + ns[e]);
+    for (int i = 0; i < ln; i++) ref[i] = Mf[i] - A0[i];
+    check("build_rhs_with_strong_bc (quad)", p, got, ref, ln, 1e-12);
+    d4est_hip_plan_set_dirichlet_values(plan, NULL, 0);
+    free(g); free(f); free(zero); free(A0); free(Mf); free(got);
+  }
   d4est_hip_compat_bind_mesh(p4est, NULL);
   d4est_hip_plan_destroy(plan);
   free(J); free(rst); free(sj); free(nrm); free(dm); free(hm);
   free(u); free(rhs); free(Au); free(r); free(ref); free(ur); free(Aur); free(rr);
 }
 
-int main(void) {
+static void probe_lhs_b(p4est_t* a, d4est_ghost_t* b, d4est_ghost_data_t* c, d4est_elliptic_data_t* d, d4est_operators_t* e, d4est_geometry_t* f,
+                        d4est_quadrature_t* g, d4est_mesh_data_t* h, void* i) { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; }
+
+int main(int argc, char** argv) {
   if (d4est_hip_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 77; }
+  if (argc > 1 && strcmp(argv[1], "mismatch") == 0) {
+    /* a caller whose apply_lhs is NOT the registered operator must not be served silently: the shim aborts before touching the plan */
+    int key = 0;
+    d4est_elliptic_eqns_t fcns;
+    memset(&fcns, 0, sizeof fcns);
+    fcns.apply_lhs = probe_lhs_b;
+    int one = 1, zero = 0;
+    d4est_hip_plan_t* plan = d4est_hip_plan_create(1, &one, &one, &zero, &zero, D4EST_HIP_QUAD_LEGENDRE);
+    d4est_hip_compat_bind_mesh(&key, plan);
+    d4est_hip_compat_bind_operator(&key, probe_lhs_a);
+    d4est_elliptic_data_t vecs;
+    memset(&vecs, 0, sizeof vecs);
+    vecs.local_nodes = 8;
+    double b = 0;
+    cg_eigs((p4est_t*)&key, &vecs, &fcns, NULL, NULL, NULL, NULL, NULL, NULL, 2, 0, 1, &b);
+    printf("NOT ABORTED\n");
+    return 0;
+  }
   const int ps[] = {2, 3, 7, 8, 11};
   for (int i = 0; i < 5; i++) {
     element_level(ps[i], ps[i], 0);

@@ -28,7 +28,8 @@ def test_compat_header_is_c99_and_every_declared_symbol_is_exported(hiplib, orac
     names = set(re.findall(r"^(?:void|double|int|d4est_hip_plan_t\s*\*)\s*\*?\s*(\w+)\s*\(", text, flags=re.M))
     assert {"d4est_quadrature_apply_stiffness_matrix", "d4est_operators_apply_hp_restrict", "d4est_laplacian_apply_aij", "cg_eigs",
             "d4est_laplacian_with_opt_apply_aij", "d4est_laplacian_with_opt_apply_stiffness_matrix",
-            "d4est_solver_multigrid_smoother_cheby_iterate_aux", "d4est_hip_compat_bind_mesh"} <= names and len(names) >= 26
+            "d4est_solver_multigrid_smoother_cheby_iterate_aux", "d4est_hip_compat_bind_mesh", "d4est_quadrature_apply_fofufofvlilj",
+            "d4est_quadrature_apply_fofufofvlj", "d4est_hip_compat_bind_operator", "d4est_hip_compat_build_rhs_with_strong_bc"} <= names and len(names) >= 30
     lib = ctypes.CDLL(os.path.join(LIBDIR, "libd4est_hip_compat.so"))
     for n in names:
         getattr(lib, n)
@@ -52,4 +53,16 @@ def test_reference_prototypes_from_plain_c_match_oracle(gpu, hiplib, oracle, tmp
     print(out.stdout[-6000:], out.stderr[-2000:])
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert out.stdout.strip().endswith("ok")
-    assert out.stdout.count("rel-inf") >= 240
+    assert out.stdout.count("rel-inf") >= 370
+    for what in ("apply_fofufofvlilj", "apply_fofufofvlj", "MORTAR", "build_rhs_with_strong_bc", "registered apply_lhs accepted"):
+        assert what in out.stdout
+
+
+@pytest.mark.gpu
+def test_smoother_shims_refuse_another_operator(gpu, hiplib, oracle, tmp_path):
+    """cg_eigs / cheby_iterate_aux never call fcns->apply_lhs (the bound plan applies the operator); with the plan's callback registered
+    (d4est_hip_compat_bind_operator) a caller that passes a DIFFERENT apply_lhs is aborted instead of silently served the wrong operator"""
+    exe = _compile(tmp_path, oracle)
+    out = subprocess.run([exe, "mismatch"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "NOT ABORTED" not in out.stdout
+    assert "fcns->apply_lhs is not the operator registered" in out.stderr
