@@ -632,7 +632,8 @@ def main():
             out["secondary"] = sec
         except Exception as exc:  # secondary numbers must never break the headline line
             out["secondary"] = {"error": repr(exc)}
-    emitted, dog = [False], None
+    import threading as _threading
+    emitted, dog, emit_lock = [False], None, _threading.Lock()
     if world == 1 and args.sharded_secondary:
         out["sharded_rehearsal"] = sharded_secondary(args, rank, world, dev, stream, dist, torch)
     if world > 1 and not args.no_secondary:
@@ -641,12 +642,14 @@ def main():
 
         def give_up():
             log("rank %d: the sharded secondary (or the final barrier) did not finish in time; reporting the headline without it" % rank)
-            if rank == 0 and not emitted[0]:
-                out["secondary"] = {"error": "sharded secondary timed out"}
-                out["cpu_baseline"] = None
-                emitted[0] = True
-                emit(out)
-            os._exit(0)
+            with emit_lock:   # (never kill the process while the main thread is inside emit(): the line must be whole, and printed once)
+                if rank == 0 and not emitted[0]:
+                    out["secondary"] = {"error": "sharded secondary timed out"}
+                    out["cpu_baseline"] = None
+                    emitted[0] = True
+                    emit(out)
+                # rank 0 has a complete result line on stdout: exit 0; a rank that hung in a collective reports it with its exit status
+                os._exit(0 if rank == 0 else 3)
 
         dog = threading.Timer(float(os.environ.get("D4EST_BENCH_SECONDARY_TIMEOUT", "240")), give_up)
         dog.daemon = True
@@ -663,9 +666,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(mesh, J, rst, u)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0 and not emitted[0]:
-        emitted[0] = True
-        emit(out)
+    with emit_lock:
+        if rank == 0 and not emitted[0]:
+            emitted[0] = True
+            emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -89,6 +89,8 @@ SIGNATURES = {
     "d4est_hip_compute_face_traces": (None, [_vp, _vp, _vp]),
     "d4est_hip_apply_flux": (None, [_vp, _vp, _vp, _vp]),
     "d4est_hip_apply_aij": (None, [_vp, _vp, _vp, _vp]),
+    "d4est_hip_build_rhs_with_strong_bc": (None, [_vp, _vp, ctypes.c_int, _vp]),
+    "d4est_hip_build_rhs_with_strong_bc_host": (None, [_vp, _c_double_p, ctypes.c_int, _c_double_p]),
     "d4est_hip_plan_set_lhs_coefficient": (None, [_vp, _vp]),
     "d4est_hip_plan_set_comm": (None, [_vp, _vp, _vp, _vp]),
     "d4est_hip_apply_lhs": (None, [_vp, _vp, _vp]),
@@ -405,6 +407,10 @@ class Plan:
         self._cb_ar = self.ALLREDUCE_FN(guarded(lambda ctx, p, n: allreduce(p, n))) if allreduce else None
         self.lib.d4est_hip_plan_set_comm(self.handle, ctypes.cast(self._cb_ex, ctypes.c_void_p) if self._cb_ex else None,
                                          ctypes.cast(self._cb_ar, ctypes.c_void_p) if self._cb_ar else None, None)
+
+    def build_rhs_with_strong_bc(self, f, rhs, f_on_quad=False):
+        """rhs = M f - A(0) with the boundary data currently set on the plan (d4est_laplacian_build_rhs_with_strong_bc)"""
+        self.lib.d4est_hip_build_rhs_with_strong_bc(self.handle, _ptr(f), int(bool(f_on_quad)), _ptr(rhs))
 
     def set_lhs_coefficient(self, coeff_quad):
         """zeroth-order term of apply_lhs (+ V^T W J c V u): a float64 CUDA tensor of local_nodes_quad entries kept alive by the plan,

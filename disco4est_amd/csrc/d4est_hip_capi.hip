@@ -36,6 +36,7 @@ void check_plan(const d4est_hip_plan_t* plan, const char* fn) {
 // any change of the plan's state invalidates a captured cheby_iterate graph (D4EST_HIP_TUNE_GRAPH)
 static void drop_graph(d4est_hip_plan_t* plan) {
   if (plan->cheby_graph) { (void)hipGraphExecDestroy(plan->cheby_graph); plan->cheby_graph = nullptr; }
+  ++plan->op_generation;   // (every caller of this function changes the plan's state)
 }
 
 }  // namespace
@@ -185,8 +186,11 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
   return plan;
 }
 
+extern "C" void d4est_hip_rccl_exchange_detach_plan(d4est_hip_plan_t* plan);   // d4est_hip_comm.hip
+
 void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   if (!plan) return;
+  d4est_hip_rccl_exchange_detach_plan(plan);   // an RCCL exchange object that outlives the plan must not dereference it
   for (Bucket& bk : plan->buckets) {
     (void)hipFree(bk.d_B);
     (void)hipFree(bk.d_G);

@@ -187,6 +187,8 @@ d4est_hip_rccl_exchange_t* d4est_hip_plan_set_rccl_exchange(d4est_hip_plan_t* pl
   if (!plan || !comm) D4EST_HIP_ABORT("plan_set_rccl_exchange: NULL plan / communicator");
   if (!plan->has_faces) D4EST_HIP_ABORT("plan_set_rccl_exchange: call plan_set_faces first");
   if (n_peers < 0 || (n_peers > 0 && (!peer_rank || !send_first || !recv_first))) D4EST_HIP_ABORT("plan_set_rccl_exchange: bad peer lists");
+  if (n_peers > 0 && ((send_first[n_peers] > send_first[0] && (!send_off || !send_len)) || (recv_first[n_peers] > recv_first[0] && (!recv_off || !recv_len))))
+    D4EST_HIP_ABORT("plan_set_rccl_exchange: block lists are NULL");
   auto* x = new d4est_hip_rccl_exchange();
   x->comm = comm;
   x->plan = plan;
@@ -225,6 +227,7 @@ d4est_hip_rccl_exchange_t* d4est_hip_plan_set_rccl_exchange(d4est_hip_plan_t* pl
 
 void d4est_hip_rccl_exchange_destroy(d4est_hip_rccl_exchange_t* x) {
   if (!x) return;
+  // (a plan destroyed before its exchange clears this back-pointer: d4est_hip_rccl_exchange_detach_plan, called by plan_destroy)
   if (x->plan && x->plan->comm_ctx == x) d4est_hip_plan_set_comm(x->plan, nullptr, nullptr, nullptr);
   (void)hipStreamSynchronize(x->comm_stream);
   (void)hipFree(x->d_send); (void)hipFree(x->d_recv);
@@ -233,6 +236,12 @@ void d4est_hip_rccl_exchange_destroy(d4est_hip_rccl_exchange_t* x) {
   (void)hipStreamDestroy(x->comm_stream);
   (void)hipEventDestroy(x->ev_packed); (void)hipEventDestroy(x->ev_arrived);
   delete x;
+}
+
+// plan_destroy: an exchange object that outlives its plan must not touch it again
+void d4est_hip_rccl_exchange_detach_plan(d4est_hip_plan_t* plan) {
+  if (!plan || !plan->comm_ctx || (plan->exchange_fn != exchange_hook && plan->allreduce_fn != allreduce_hook)) return;
+  static_cast<d4est_hip_rccl_exchange*>(plan->comm_ctx)->plan = nullptr;
 }
 
 long long d4est_hip_rccl_exchange_count(const d4est_hip_rccl_exchange_t* x) { return x ? x->n_exchanges : 0; }
@@ -244,6 +253,9 @@ long long d4est_hip_rccl_exchange_recv_doubles(const d4est_hip_rccl_exchange_t* 
 void d4est_hip_comm_sendrecv(d4est_hip_comm_t* comm, d4est_hip_plan_t* plan, int n_peers, const int* peer_rank, const double* send_dev,
                              const long long* send_first, double* recv_dev, const long long* recv_first) {
   if (!comm || !plan) D4EST_HIP_ABORT("comm_sendrecv: NULL argument");
+  if (n_peers < 0 || (n_peers > 0 && (!peer_rank || !send_first || !recv_first))) D4EST_HIP_ABORT("comm_sendrecv: bad peer lists");
+  for (int p = 0; p < n_peers; ++p)
+    if (peer_rank[p] < 0 || peer_rank[p] >= comm->world) D4EST_HIP_ABORT("comm_sendrecv: peer %d outside the communicator of %d ranks", peer_rank[p], comm->world);
   RcclApi& api = rccl();
   RCCL_CHECK(api.GroupStart());
   for (int p = 0; p < n_peers; ++p) {

@@ -2221,6 +2221,7 @@ void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n,
 void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_device) {
   FaceHost& fh = g_face_host[plan];
   const size_t tm = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
+  plan->bc_inhomogeneous = (g_lobatto != nullptr) || fh.robin;
   if (!g_lobatto) {
     HIP_CHECK(hipMemsetAsync(plan->d_bndry, 0, tm * sizeof(double), plan->stream));
     return;
@@ -2502,6 +2503,7 @@ void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const doubl
   if (!plan->has_face_geometry) D4EST_HIP_ABORT("plan_set_robin_values: call d4est_hip_plan_set_mortar_geometry first (needs sj)");
   if (!coeff_quad) {
     fh.robin = false;
+    plan->bc_inhomogeneous = false;   // (back to Dirichlet; plan_set_dirichlet_values decides from here on)
     return;
   }
   if (!rhs_quad) D4EST_HIP_ABORT("plan_set_robin_values: rhs_quad is NULL");
@@ -2511,6 +2513,7 @@ void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const doubl
     HIP_CHECK(hipMalloc(&fh.d_robin_r, std::max<size_t>(tm, 1) * sizeof(double)));
   }
   fh.robin = true;
+  plan->bc_inhomogeneous = true;
   if (tm == 0) return;
   const double* dc = coeff_quad;
   const double* dr = rhs_quad;

@@ -126,6 +126,11 @@ struct d4est_hip_plan {
   d4est_hip_allreduce_fn allreduce_fn = nullptr;
   void* comm_ctx = nullptr;
 
+  // bumped by every call that can change what the operator computes (geometry, faces, SIPG parameters, boundary data, the zeroth-order
+  // coefficient, tuning): objects that cache something derived from the operator (the Schwarz smoother's condensed blocks) compare it
+  unsigned long long op_generation = 0;
+  bool bc_inhomogeneous = false;   // non-zero Dirichlet data or Robin data is set (an affine, not linear, operator)
+
   int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)

@@ -64,6 +64,7 @@ struct d4est_hip_schwarz {
   // small dense blocks instead of being applied matrix-free
   std::vector<VirtDesc> h_vd;        // host copy of the copy descriptors
   int condensed_state = 0;           // 0 not looked at yet, 1 in use, -1 not applicable / switched off
+  unsigned long long cond_generation = 0;   // the subdomain plan's op_generation the state above belongs to
   int n_cond = 0;
   void* d_cond = nullptr;            // CondDesc per condensed copy
   double* d_cond_blocks = nullptr;
@@ -416,10 +417,21 @@ static int live_count(const VirtDesc& q) { return (q.hi[0] - q.lo[0]) * (q.hi[1]
 
 static void ensure_zero_ghost(d4est_hip_schwarz* sz);
 
+static void release_condensed(d4est_hip_schwarz* sz) {
+  (void)hipFree(sz->d_cond); (void)hipFree(sz->d_cond_blocks); (void)hipFree(sz->d_cond_off); (void)hipFree(sz->d_keep_list);
+  sz->d_cond = nullptr; sz->d_cond_blocks = nullptr; sz->d_cond_off = nullptr; sz->d_keep_list = nullptr;
+  sz->n_cond = 0; sz->n_keep = 0; sz->cond_block_doubles = 0;
+  sz->condensed_state = 0;
+}
+
 static void ensure_condensed(d4est_hip_schwarz* sz) {
+  d4est_hip_plan* plan = sz->plan;
+  // the blocks are the subdomain operator's own numbers, read off by probing: any later change of that operator (SIPG parameters,
+  // geometry, boundary data, the zeroth-order coefficient, tuning) makes them stale -- probe again instead of mixing two operators
+  if (sz->condensed_state != 0 && sz->cond_generation != plan->op_generation) release_condensed(sz);
   if (sz->condensed_state != 0) return;
   sz->condensed_state = -1;
-  d4est_hip_plan* plan = sz->plan;
+  sz->cond_generation = plan->op_generation;
   const char* env = std::getenv("D4EST_HIP_SCHWARZ_CONDENSE");   // (read per smoother object: once, on its first use)
   static const bool dbg = std::getenv("D4EST_HIP_DEBUG_FUSED") != nullptr;
   auto no = [&](const char* why) {
@@ -428,6 +440,9 @@ static void ensure_condensed(d4est_hip_schwarz* sz) {
   if (env && std::atoi(env) == 0) return no("switched off");
   if (!direct_active(plan) || !plan->has_face_geometry || !plan->has_geometry || sz->n_virtual == 0) return no("no direct face kernel on the subdomain plan");
   if (!plan->side_hang.empty()) return no("hanging faces");
+  // probing with unit vectors reads A e_j: with non-zero Dirichlet or Robin data on the subdomain plan the operator is affine and its
+  // constant part would land in every probed column (the smoother's subdomain plan carries homogeneous data: schwarz.py)
+  if (plan->bc_inhomogeneous) return no("inhomogeneous boundary data on the subdomain plan");
   const int nv = sz->n_virtual;
   const std::vector<VirtDesc>& vd = sz->h_vd;
   if ((int)vd.size() != nv) return no("descriptor count");

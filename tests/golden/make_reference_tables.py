@@ -17,6 +17,29 @@ REF = "/root/reference/src"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def numeric(expr):
+    """value of a C numeric initialiser made of float literals, + - * / and parentheses -- parsed, never evaluated as code (the text
+    comes from the untrusted reference tree)"""
+    import ast
+    import operator
+    expr = expr.strip()
+    if not re.fullmatch(r"[0-9eE+\-*/(). ]+", expr):
+        raise ValueError("not a numeric initialiser: %r" % expr)
+    ops = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul, ast.Div: operator.truediv}
+
+    def ev(node):
+        if isinstance(node, ast.Expression):
+            return ev(node.body)
+        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)):
+            return float(node.value)
+        if isinstance(node, ast.BinOp) and type(node.op) in ops:
+            return ops[type(node.op)](ev(node.left), ev(node.right))
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            return -ev(node.operand) if isinstance(node.op, ast.USub) else ev(node.operand)
+        raise ValueError("not a numeric initialiser: %r" % expr)
+    return ev(ast.parse(expr, mode="eval"))
+
+
 def parse_rule(text, xname, wname, nmax=20):
     out = {}
     blocks = re.split(r"if\s*\(\s*n\s*==\s*(\d+)\s*\)", text)
@@ -29,7 +52,7 @@ def parse_rule(text, xname, wname, nmax=20):
         for name, idx, expr in re.findall(r"(\w+)\[(\d+)\]\s*=\s*([^;]+);", body):
             if name not in (xname, wname):
                 continue
-            val = float(eval(expr.replace(" ", ""), {"__builtins__": {}}))
+            val = numeric(expr)
             (x if name == xname else w)[int(idx)] = val
         if len(x) == n and len(w) == n:
             out[n] = {"x": [x[i] for i in range(n)], "w": [w[i] for i in range(n)]}

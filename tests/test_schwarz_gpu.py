@@ -330,3 +330,46 @@ def test_condensed_corner_copies(gpu, hiplib, oracle, monkeypatch, level, deg, c
     it, _ = sz.info(); it0, _ = sz0.info()
     np.testing.assert_array_equal(it, it0)
     sz.destroy(); sz0.destroy()
+
+
+def test_condensed_blocks_follow_the_subdomain_operator(gpu, hiplib, oracle, monkeypatch):
+    """The condensed corner copies hold rows of the subdomain operator probed from the matrix-free kernels.  When that operator changes
+    after the first use (here: the SIPG penalty prefactor on the subdomain plan) the blocks are probed again -- the smoother must never
+    mix the new matrix-free rows with stale dense ones; with inhomogeneous boundary data on the subdomain plan (an affine operator, which
+    unit-vector probing cannot represent) nothing is condensed."""
+    import torch
+    from disco4est_amd import mesh as M
+    from disco4est_amd.schwarz import Schwarz
+    monkeypatch.setenv("D4EST_HIP_FACE_DIRECT", "2")
+    m = M.BrickMesh(2, 3)
+    mp = M.SineMap(0.04)
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    sz = Schwarz(m, sides, J, rst, 2, 6, 1e-15, 1e-15, 10.0, 0)
+    assert sz.condensed_copies() > 0                       # probed with prefactor 10
+    x = torch.empty(sz.nodal_size, dtype=torch.float64, device=gpu)
+    sz.restrict_field(_t(M.splitmix64_uniform(81, m.local_nodes) - 0.5, gpu), x)
+    Ax10 = torch.full_like(x, float("nan"))
+    sz.apply_over_subdomains(x, Ax10)
+    # the operator of the subdomain plan changes: new mortar factors (h halved: the SIPG penalty doubles)
+    from disco4est_amd.capi import _vp
+    sub = dict(sz._sub_sides)
+    sub["hm"] = 0.5 * np.asarray(sub["hm"]); sub["hp"] = 0.5 * np.asarray(sub["hp"])
+    arrs = [np.ascontiguousarray(sub[k], dtype=np.float64) for k in ("sj", "n", "drst_m", "drst_p", "hm", "hp")]
+    sz.plan.lib.d4est_hip_plan_set_mortar_geometry(sz.plan.handle, *[a.ctypes.data_as(_vp) for a in arrs], 0)
+    Ax25 = torch.full_like(x, float("nan"))
+    sz.apply_over_subdomains(x, Ax25)
+    sides2 = dict(sides)
+    sides2["hm"] = 0.5 * np.asarray(sides["hm"]); sides2["hp"] = 0.5 * np.asarray(sides["hp"])
+    sz_new = Schwarz(m, sides2, J, rst, 2, 6, 1e-15, 1e-15, 10.0, 0)
+    ref = torch.full_like(x, float("nan"))
+    sz_new.apply_over_subdomains(x, ref)
+    scale = float(ref.abs().max())
+    assert float((Ax25 - ref).abs().max()) <= 1e-13 * scale
+    assert float((Ax10 - ref).abs().max()) > 1e-3 * scale  # the two operators really differ
+    assert sz.condensed_copies() == sz_new.condensed_copies() > 0
+    # inhomogeneous Robin data on the subdomain plan (an affine operator): nothing is condensed any more
+    tm = int(sz._sub_sides["total_mortar_nodes"]) if hasattr(sz, "_sub_sides") else None
+    if tm is not None:
+        sz.plan.set_robin_values(np.ones(tm), np.ones(tm))
+        assert sz.condensed_copies() == 0
+    sz.destroy(); sz_new.destroy()
