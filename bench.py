@@ -270,7 +270,41 @@ def sharded_secondary(args, rank, world, dev, stream, dist, torch):
     ms = timed(lambda: plan.cheby_iterate(u, rhs, Au, r, 5, 1.0, 30.0, 0), 20)
     res["cheby_5_iterations_config2_strong"] = {"ms": ms, "GDoF_per_s": full.local_nodes * 5 / (ms * 1e-3) / 1e9}
     res["exchanges_posted"] = int(x.count())
-    x.destroy(); plan.destroy(); comm.destroy()
+    # roofline entry of the sharded full operator: algorithmic bytes of ONE rank's share per apply over the measured time
+    N = args.deg + 1
+    bpd_aij = full_operator_bytes_per_dof(N, N)
+    res["apply_aij_config2_strong"]["roofline"] = {"bound": "hbm", "achieved": bpd_aij * full.local_nodes / world / (res["apply_aij_config2_strong"]["ms"] * 1e-3) / 1e9,
+                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_dof": bpd_aij}
+    res["apply_aij_config2_strong"]["roofline"]["frac"] = res["apply_aij_config2_strong"]["roofline"]["achieved"] / HBM_PEAK_GBS
+    x.destroy(); plan.destroy()
+    # ---- WEAK scaling of the full operator: one config-2 brick's worth of elements per rank, WITH neighbours -- the domain is the box of
+    # the first `world` level-`level` sub-cubes of the level + 1 Morton sequence (world = 8: the whole level + 1 cube), every rank
+    # owns one sub-cube and exchanges face traces with up to three others
+    try:
+        lvl = args.level + 1
+        per = 8 ** args.level
+        wparts = [(r_ * per, per) for r_ in range(world)]
+        mw_ = M.BrickMesh(lvl, args.deg, first=rank * per, count=per, domain=world * per)
+        Jw, rstw = mw_.geometry(None)
+        sw = mw_.build_sides(None)
+        pw = Plan(mw_.deg, mw_.deg_quad, mw_.nodal_stride, mw_.quad_stride, 0, stream=stream)
+        pw.set_geometry(Jw, rstw)
+        pw.set_tuning(7, 0)
+        pw.set_faces(sw, 10.0, 0)
+        xw = P.attach_rccl(pw, mw_, sw, wparts, comm)
+        uw = torch.from_numpy(mw_.field(None)).to(dev)
+        Auw = torch.empty_like(uw)
+        ms = timed(lambda: pw.apply_lhs(uw, Auw), 50)
+        tot = mw_.local_nodes * world
+        res["apply_aij_config2_weak"] = {"ms": ms, "GDoF_per_s": tot / (ms * 1e-3) / 1e9, "elements_per_rank": per, "face_path": pw.face_path(),
+                                         "exchange_doubles_sent_by_rank0": int(xw.send_doubles),
+                                         "roofline": {"bound": "hbm", "achieved": bpd_aij * mw_.local_nodes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                                      "unit": "GB/s", "frac": bpd_aij * mw_.local_nodes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                      "algorithmic_bytes_per_dof": bpd_aij}}
+        xw.destroy(); pw.destroy()
+    except Exception as exc:
+        res["apply_aij_config2_weak"] = {"error": repr(exc)}
+    comm.destroy()
     return res
 
 

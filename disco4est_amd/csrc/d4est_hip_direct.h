@@ -27,6 +27,9 @@ struct DirectHost {
   int n_list = 0;
   mutable int order_ok = -1;     // 1: the plan's single bucket lists the elements in order (cached by direct_fused_ok)
   bool mw = false;               // N > 8: the multi-wave kernel of d4est_hip_direct_mw.hip serves the plan
+  int* d_bnd_list = nullptr;     // elements with a ghost (+) side, and the others (multi-rank plans; direct_ghost_split)
+  int* d_int_list = nullptr;
+  int n_bnd = 0, n_int = 0;
 };
 
 // VOL: the volume (stiffness) term of the element is applied by the same wavefront after its face terms and A u is written once --

@@ -499,6 +499,7 @@ void direct_destroy(d4est_hip_plan* plan) {
   (void)hipFree(dh->d_ghost_off);
   (void)hipFree(dh->d_ops);
   (void)hipFree(dh->d_u2);
+  (void)hipFree(dh->d_bnd_list); (void)hipFree(dh->d_int_list);
   delete dh;
   plan->direct = nullptr;
 }
@@ -557,7 +558,27 @@ void direct_setup(d4est_hip_plan* plan, int N, int NQ, int ns0, int ns_stride, c
   if (!sd.empty()) HIP_CHECK(hipMemcpy(dh->d_sides, sd.data(), sd.size() * sizeof(DirectSide), hipMemcpyHostToDevice));
   HIP_CHECK(hipMalloc(&dh->d_ghost_off, std::max<size_t>(goff.size(), 1) * sizeof(DirectGhostOff)));
   if (!goff.empty()) HIP_CHECK(hipMemcpy(dh->d_ghost_off, goff.data(), goff.size() * sizeof(DirectGhostOff), hipMemcpyHostToDevice));
+  // elements whose rows need ghost data / need none (a rank without ghosts: everything is interior, the lists stay empty)
+  std::vector<int> bnd, inn;
+  for (int e = 0; e < ne; ++e) {
+    bool g = false;
+    for (int f = 0; f < 6; ++f) g = g || plan->side_nbr[6 * (size_t)e + f] <= -2;
+    (g ? bnd : inn).push_back(e);
+  }
+  if (!bnd.empty()) {
+    dh->n_bnd = (int)bnd.size(); dh->n_int = (int)inn.size();
+    HIP_CHECK(hipMalloc(&dh->d_bnd_list, bnd.size() * sizeof(int)));
+    HIP_CHECK(hipMemcpy(dh->d_bnd_list, bnd.data(), bnd.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc(&dh->d_int_list, std::max<size_t>(inn.size(), 1) * sizeof(int)));
+    if (!inn.empty()) HIP_CHECK(hipMemcpy(dh->d_int_list, inn.data(), inn.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   plan->direct = dh;
+}
+
+void direct_ghost_split(d4est_hip_plan* plan, const int** bnd_list, int* n_bnd, const int** int_list, int* n_int) {
+  DirectHost* dh = host_of(plan);
+  if (!dh) D4EST_HIP_ABORT("direct_ghost_split: the plan has no direct face kernel");
+  *bnd_list = dh->d_bnd_list; *n_bnd = dh->n_bnd; *int_list = dh->d_int_list; *n_int = dh->n_int;
 }
 
 // Below this many elements the chip is far from full and the two-phase kernels win: they put 3 + 6 wavefronts on an element, the
@@ -579,6 +600,11 @@ void direct_set_element_list(d4est_hip_plan* plan, const int* list_dev, int n_li
   if (!dh) D4EST_HIP_ABORT("direct_set_element_list: the plan has no direct face kernel");
   dh->d_list = list_dev;
   dh->n_list = list_dev ? n_list : 0;
+}
+
+bool direct_has_element_list(const d4est_hip_plan* plan) {
+  const DirectHost* dh = static_cast<const DirectHost*>(plan->direct);
+  return dh && dh->d_list != nullptr;
 }
 
 double* direct_second_vector(d4est_hip_plan* plan) {

@@ -728,7 +728,11 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 // which share the same lines of u (trace = first / last entry, normal derivative = row 0 / row N-1 of D)
 __global__ __launch_bounds__(192) void trace_mfma_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
                                                          const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
-                                                         const double* __restrict__ face_ops, int n_elem) {
+                                                         const double* __restrict__ face_ops, int n_elem,
+                                                         const int* __restrict__ elist = nullptr) {
+  // elist: the kernel works on the listed elements only (n_elem = length of the list): the elements with a ghost (+) side, whose traces
+  // feed the exchange while the interior elements' operator kernel forms its traces from u itself (apply_operator)
+  auto EL = [&](int i) { return elist ? elist[i] : i; };
   constexpr int LDM = 18;                 // padded row length of the 8 x 16 re-shaping buffer (<= 2-way bank conflicts)
   constexpr int UJ = 9, UK = 72;          // padded strides of the LDS copy of u: conflict-free face reads in all three directions
   constexpr int TPB = 192;
@@ -745,8 +749,9 @@ __global__ __launch_bounds__(192) void trace_mfma_kernel(const double* __restric
   for (int i = 0; i < kFW; ++i) drow[0][i] = drow[1][i] = 0.0;
   // persistent loop, software-pipelined: descriptors two elements ahead, u (3 values per thread) one element ahead
   int e = blockIdx.x;
-  ElemDesc el = ed[e < n_elem ? e : 0];
-  SideDesc d0 = sd[6 * (e < n_elem ? e : 0) + 2 * dir], d1 = sd[6 * (e < n_elem ? e : 0) + 2 * dir + 1];
+  const int e_first = e < n_elem ? EL(e) : (n_elem > 0 ? EL(0) : 0);
+  ElemDesc el = ed[e_first];
+  SideDesc d0 = sd[6 * e_first + 2 * dir], d1 = sd[6 * e_first + 2 * dir + 1];
   double uv[3] = {0.0, 0.0, 0.0};
   {
     const int n3 = el.N * el.N * el.N;
@@ -757,9 +762,10 @@ __global__ __launch_bounds__(192) void trace_mfma_kernel(const double* __restric
   ElemDesc edn = el;
   SideDesc dn0 = d0, dn1 = d1;
   if (e + (int)gridDim.x < n_elem) {
-    edn = ed[e + gridDim.x];
-    dn0 = sd[6 * (e + gridDim.x) + 2 * dir];
-    dn1 = sd[6 * (e + gridDim.x) + 2 * dir + 1];
+    const int e2 = EL(e + gridDim.x);
+    edn = ed[e2];
+    dn0 = sd[6 * e2 + 2 * dir];
+    dn1 = sd[6 * e2 + 2 * dir + 1];
   }
   for (; e < n_elem; e += gridDim.x) {
     const int N = el.N, N2 = N * N, N3 = N2 * N;
@@ -778,9 +784,10 @@ __global__ __launch_bounds__(192) void trace_mfma_kernel(const double* __restric
         for (int r = 0; r < 3; ++r) uv[r] = ((int)threadIdx.x + TPB * r < n3) ? u[el_next.ns + threadIdx.x + TPB * r] : 0.0;
         const int en2 = en + gridDim.x;
         if (en2 < n_elem) {
-          edn = ed[en2];
-          dn0 = sd[6 * en2 + 2 * dir];
-          dn1 = sd[6 * en2 + 2 * dir + 1];
+          const int e2 = EL(en2);
+          edn = ed[e2];
+          dn0 = sd[6 * e2 + 2 * dir];
+          dn1 = sd[6 * e2 + 2 * dir + 1];
         }
       }
     }
@@ -876,7 +883,8 @@ __global__ __launch_bounds__(192) void trace_mfma_kernel(const double* __restric
 // face path five times more expensive than the volume kernel at p >= 9.
 __global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
                                                            const SideDesc* __restrict__ sd, const ElemDesc* __restrict__ ed,
-                                                           const double* __restrict__ face_ops, int n_elem, int max_n) {
+                                                           const double* __restrict__ face_ops, int n_elem, int max_n,
+                                                           const int* __restrict__ elist = nullptr) {
   constexpr int LDM = 34;                  // staging rows: 32 columns (field, b) + padding
   constexpr int UJ = 17, UK = 272;         // padded strides of the LDS copy of u (<= 2-way bank conflicts in all directions)
   constexpr int TPB = 192;
@@ -902,7 +910,8 @@ __global__ __launch_bounds__(192) void trace_mfma16_kernel(const double* __restr
   // garbage could be NaN)
   for (int i = lane; i < 2 * 16 * LDM; i += 64) stage[i] = 0.0;
   wave_lds_fence();
-  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+  for (int ei = blockIdx.x; ei < n_elem; ei += gridDim.x) {
+    const int e = elist ? elist[ei] : ei;   // (elist: the listed elements only, see trace_mfma_kernel)
     const ElemDesc el = ed[e];
     const SideDesc d0 = sd[6 * e + 2 * dir], d1 = sd[6 * e + 2 * dir + 1];
     const int N = el.N, N2 = N * N, N3 = N2 * N;
@@ -2562,7 +2571,7 @@ static void debug_occupancy_once() {
 
 static size_t generic_lds_bytes(const d4est_hip_plan* plan) { return (size_t)plan->max_face_lds_doubles * sizeof(double); }
 
-void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost) {
+void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost, const int* elist, int n_list) {
   FaceHost& fh = g_face_host[plan];
   if (ghost) {
     if (fh.hp) D4EST_HIP_ABORT("compute_ghost_traces: plans with hanging faces take their ghost traces from the trace exchange (d4est_hip_plan_*_sub offsets), not from whole ghost elements");
@@ -2574,7 +2583,11 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     HIP_CHECK(hipGetLastError());
     return;
   }
-  const int n = plan->n_elements;
+  // elist: only these elements' traces are needed (the tiled MFMA kernels take the list; the other families compute every element)
+  const bool listed = elist && !fh.hp && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
+                      ((plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1) || (!plan->face_fast && fh.max_N <= 16 && fh.max_NQ <= 16));
+  if (!listed) elist = nullptr;
+  const int n = listed ? n_list : plan->n_elements;
   if (n == 0) return;
   if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const size_t lds = (size_t)(fh.hp_max_N * 272 + 3 * 2 * 16 * 34) * sizeof(double);
@@ -2597,7 +2610,7 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     debug_occupancy_once();
     if (mfma)   // auto: MFMA form of the two interpolation passes
       hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
-                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n);
+                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, elist);
     else
       hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
                          (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, fh.uni);
@@ -2609,7 +2622,7 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
     hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(n, per_cu * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), lds, plan->stream, u, trace,
-                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n, max_local_n);
+                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n, max_local_n, elist);
   } else {
     const size_t lds = generic_lds_bytes(plan);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -171,7 +171,7 @@ int reorient_face_order(int f_m, int f_p, int o, int i);  // dGMath/d4est_refere
 int face_reorder_code(int f_m, int f_p, int o);            // dGMath/d4est_operators.c:2031-2050
 void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_device);
 void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const double* rhs_quad, int on_device);
-void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost);
+void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost, const int* elist = nullptr, int n_list = 0);
 // Chebyshev update carried by the flux kernel's epilogue (flux_wave_kernel<true>): r = alpha (rhs - Au), p = r + beta p, u += p
 struct ChebyFuse {
   const double* rhs = nullptr;
@@ -201,7 +201,11 @@ double* direct_second_vector(d4est_hip_plan* plan);
 // the direct kernel works on the listed elements only (the others are still read as neighbours); nullptr: every element.  The list
 // (device ints) stays the caller's.  Only while direct_active(plan).
 void direct_set_element_list(d4est_hip_plan* plan, const int* list_dev, int n_list);
+bool direct_has_element_list(const d4est_hip_plan* plan);
 bool direct_fused_ok(const d4est_hip_plan* plan);   // the volume term can ride in the same kernel (N = NQ in {6, 8}, one bucket ...)
+// the elements with at least one ghost (+) side / with none (device lists; multi-rank plans: boundary traces feed the exchange,
+// the interior elements' operator kernel runs while it is in flight)
+void direct_ghost_split(d4est_hip_plan* plan, const int** bnd_list, int* n_bnd, const int** int_list, int* n_int);
 void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
                          const double* robin_c, const double* robin_r, int vol_term);
 // the same through the plan's face data (Robin arrays): vol_term = 0: Au += face terms of u; 1: Au = (volume + face terms) of u

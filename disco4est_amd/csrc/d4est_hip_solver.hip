@@ -157,29 +157,56 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
   if (direct_active(plan)) {
     // one-kernel face terms (d4est_hip_direct.hip): both sides' traces come from u inside the kernel; with ghost sides the trace
     // kernel still runs, to feed the exchange
+    const bool mass = lhs_term && plan->d_lhs_coeff;
+    const bool fused = direct_fused_ok(plan);
+    auto run = [&](int vterm) {
+      if (cf) {
+        DirectFuse df;
+        df.rhs = cf->rhs; df.p = cf->p; df.u_out = cf->u_out; df.r = cf->r; df.alpha = cf->alpha; df.beta = cf->beta;
+        df.skip_Au_store = (vterm != 0 && cf->skip_Au_store) ? 1 : 0;
+        if (!df.u_out || df.u_out == u) D4EST_HIP_ABORT("apply_operator: the direct face kernel needs a second vector for the fused update");
+        launch_flux_direct(plan, u, plan->d_ghost_trace, Au, &df, vterm);
+      } else {
+        launch_flux_direct(plan, u, plan->d_ghost_trace, Au, nullptr, vterm);
+      }
+    };
+    if (has_ghost && fused && !direct_has_element_list(plan)) {
+      // Several ranks, whole operator in the kernel.  Only the elements with a ghost (+) side need exchanged data -- the reference,
+      // too, packs just its mirror elements (src/Mesh/d4est_ghost_data.c:143-256): the trace kernel runs over THOSE elements to feed
+      // the exchange, the operator kernel over the interior elements runs while the blocks travel, and a second, short launch over
+      // the boundary elements follows the unpack.  Every element still gets its A u (and its fused update) from exactly one launch.
+      const int *bl, *il;
+      int nb, ni;
+      direct_ghost_split(plan, &bl, &nb, &il, &ni);
+      launch_traces(plan, u, plan->d_trace, false, bl, nb);
+      plan->exchange_fn(plan->comm_ctx, 0, plan->d_trace, plan->d_ghost_trace);
+      const int vterm = mass ? 2 : 1;
+      if (ni > 0) {
+        direct_set_element_list(plan, il, ni);
+        run(vterm);
+      }
+      plan->exchange_fn(plan->comm_ctx, 1, plan->d_trace, plan->d_ghost_trace);
+      direct_set_element_list(plan, bl, nb);
+      run(vterm);
+      direct_set_element_list(plan, nullptr, 0);
+      return;
+    }
+    // one-kernel face terms (d4est_hip_direct.hip): both sides' traces come from u inside the kernel; with ghost sides the trace
+    // kernel still runs, to feed the exchange
     if (has_ghost) {
       launch_traces(plan, u, plan->d_trace, false);
       plan->exchange_fn(plan->comm_ctx, 0, plan->d_trace, plan->d_ghost_trace);
     }
     // the volume term rides in the same kernel (u in, A u out) unless an exchange is to overlap it; the zeroth-order term of
     // plan_set_lhs_coefficient then sits in that kernel's volume stage (vol_term 2)
-    const bool mass = lhs_term && plan->d_lhs_coeff;
-    const bool whole = !has_ghost && direct_fused_ok(plan);
+    const bool whole = !has_ghost && fused;
     const int vterm = whole ? (mass ? 2 : 1) : 0;
     if (!whole) {
       launch_stiffness(plan, u, Au);
       if (lhs_term) add_lhs_mass_term(plan, u, Au);
     }
     if (has_ghost) plan->exchange_fn(plan->comm_ctx, 1, plan->d_trace, plan->d_ghost_trace);
-    if (cf) {
-      DirectFuse df;
-      df.rhs = cf->rhs; df.p = cf->p; df.u_out = cf->u_out; df.r = cf->r; df.alpha = cf->alpha; df.beta = cf->beta;
-      df.skip_Au_store = (whole && cf->skip_Au_store) ? 1 : 0;
-      if (!df.u_out || df.u_out == u) D4EST_HIP_ABORT("apply_operator: the direct face kernel needs a second vector for the fused update");
-      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, &df, vterm);
-    } else {
-      launch_flux_direct(plan, u, plan->d_ghost_trace, Au, nullptr, vterm);
-    }
+    run(vterm);
     return;
   }
   const bool fork = plan->tuning[D4EST_HIP_TUNE_OVERLAP_TRACES] > 0 && !has_ghost;

@@ -54,8 +54,11 @@ class BrickMesh:
     arbitrary element list instead, e.g. a shard followed by its ghost layer (the Schwarz smoother's extended mesh).
     """
 
-    def __init__(self, level, deg, deg_quad_inc=0, quad_type=0, first=0, count=None, elements=None):
+    def __init__(self, level, deg, deg_quad_inc=0, quad_type=0, first=0, count=None, elements=None, domain=None):
+        """domain: the computational domain is the first `domain` elements of the level's Morton sequence (default: the whole cube);
+        faces towards the rest of the cube are domain boundary -- a box of 1, 2, 4 ... level-(L-1) sub-cubes for weak-scaling runs"""
         self.level = level
+        self.domain = domain
         self.quad_type = quad_type
         ijk = morton_order(level)
         total = ijk.shape[0]
@@ -183,6 +186,8 @@ class BrickMesh:
             c[:, d] += sgn
             inside = (c[:, d] >= 0) & (c[:, d] < n)
             g = np.where(inside, lookup[np.clip(c[:, 0], 0, n - 1), np.clip(c[:, 1], 0, n - 1), np.clip(c[:, 2], 0, n - 1)], -1)
+            if self.domain is not None:
+                g = np.where(g >= self.domain, -1, g)   # outside the domain: a boundary face
             nbr_global[f::6] = g
             side_nbr_face[f::6] = f ^ 1
         local = (nbr_global >= 0) & (self._g2l[np.clip(nbr_global, 0, None)] >= 0)

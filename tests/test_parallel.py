@@ -296,3 +296,35 @@ def test_schedules_of_all_ranks_agree_and_flatten(world, level, deg_spec):
     bad = [dict(s) for s in summaries]
     del bad[b][a]
     assert not P.check_schedules_match(bad)[0]
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_weak_scaling_domain_of_sub_cubes(world):
+    """bench.py's weak-scaling full-operator secondary: the domain is the box of the first `world` level-L sub-cubes of the level-(L+1)
+    Morton sequence (BrickMesh(domain=...)), one sub-cube per rank; faces towards the rest of the cube are domain boundary.  Every pair
+    of ranks agrees on the exchange, a rank has ghost sides on exactly the faces it shares with owned sub-cubes, and world = 8 is the
+    whole cube."""
+    from disco4est_amd import mesh as M, parallel as P
+    L, deg = 1, 2                       # sub-cubes of 8 elements in the level-2 cube
+    per = 8 ** L
+    parts = [(r * per, per) for r in range(world)]
+    scheds, n_ghost_sides, n_bnd_sides = [], [], []
+    for r in range(world):
+        m = M.BrickMesh(L + 1, deg, first=r * per, count=per, domain=world * per)
+        sides = m.build_sides(None)
+        nbr = np.asarray(sides["side_nbr"])
+        assert not np.any(sides["ghost_global_ids"] >= world * per)      # nothing outside the domain is ever a neighbour
+        n_ghost_sides.append(int((nbr <= -2).sum())); n_bnd_sides.append(int((nbr == -1).sum()))
+        toff, goff, blen = P.side_block_layout(sides)
+        scheds.append(P.TraceSchedule(m, sides, parts, lambda s, b: toff[s], lambda s, b: goff[s], lambda s, b: blen[s]))
+    ok, why = P.check_schedules_match([P.schedule_summary(s) for s in scheds])
+    assert ok, why
+    # sub-cube r sits at the (x, y, z) bits of r; it shares a 2 x 2-element face with r ^ 1, r ^ 2, r ^ 4 where those are in the domain
+    for r in range(world):
+        shared = sum(1 for b in (1, 2, 4) if (r ^ b) < world)
+        assert n_ghost_sides[r] == 4 * shared and n_bnd_sides[r] == 4 * (6 - shared)
+        assert n_ghost_sides[r] + n_bnd_sides[r] == 24                  # the 6 outer faces of a 2 x 2 x 2 sub-cube: 4 sides each
+        assert sorted(scheds[r].peers) == sorted((r ^ b) for b in (1, 2, 4) if (r ^ b) < world)
+    if world == 8:
+        full = M.BrickMesh(L + 1, deg).build_sides(None)
+        assert sum(n_bnd_sides) == int((np.asarray(full["side_nbr"]) == -1).sum())
