@@ -85,14 +85,16 @@ template <bool TRANS>
 __global__ __launch_bounds__(256) void restrict_kernel(const double* __restrict__ xf, double* __restrict__ xc,
                                                        const int* __restrict__ child, const long long* __restrict__ off,
                                                        const int* __restrict__ item_first, const double* __restrict__ ops,
-                                                       int n_items, int max_n3) {
+                                                       int n_items, int max_n3, int acc_in_lds) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* a = smem;
   double* b = smem + max_n3;
-  double* acc = smem + 2 * max_n3;
   for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
     const int c0 = item_first[it], c1 = item_first[it + 1];
     const int NH = child[8 * c0 + 1];
+    // the sum over the children: a third LDS field, or -- p = 18, 19: three fields of 19^3 / 20^3 doubles exceed the 160 KB -- the coarse
+    // element's own entries of the output (every entry is touched by ONE thread only, in program order: no race either way)
+    double* acc = acc_in_lds ? smem + 2 * max_n3 : xc + off[2 * c0];
     for (int i = threadIdx.x; i < NH * NH * NH; i += blockDim.x) acc[i] = 0.0;
     for (int c = c0; c < c1; ++c) {
       const int* d = child + 8 * c;
@@ -104,8 +106,10 @@ __global__ __launch_bounds__(256) void restrict_kernel(const double* __restrict_
       for (int i = threadIdx.x; i < NH * NH * NH; i += blockDim.x) acc[i] += b[i];   // same thread <-> same entries: no race
       __syncthreads();
     }
-    const long long co = off[2 * c0];
-    for (int i = threadIdx.x; i < NH * NH * NH; i += blockDim.x) xc[co + i] = acc[i];
+    if (acc_in_lds) {
+      const long long co = off[2 * c0];
+      for (int i = threadIdx.x; i < NH * NH * NH; i += blockDim.x) xc[co + i] = acc[i];
+    }
     __syncthreads();
   }
 }
@@ -177,10 +181,11 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
     co += (long long)(dH + 1) * (dH + 1) * (dH + 1);
   }
   item_first[n_items] = (int)(child.size() / 8);
-  // the restriction / projection kernels keep three fields of max_n^3 doubles in the LDS (160 KB per workgroup): degrees up to 17.
-  // Refused here, once, with the reason -- not at the first restrict call in the middle of a V-cycle.
-  if ((size_t)3 * t->max_n * t->max_n * t->max_n * sizeof(double) > 160 * 1024)
-    D4EST_HIP_ABORT("transfer_create: degree %d exceeds the transfer kernels' limit of 17 (three %d^3 fields do not fit the 160 KB LDS)",
+  // the kernels keep two fields of max_n^3 doubles in the LDS (the restriction / projection a third one for the sum over the children
+  // up to p = 17; above that the sum lives in the output vector): the reference's degree range p <= 19 (d4est_operators.c:1205-1297) fits.
+  // Anything larger is refused here, once, with the reason -- not at the first restrict call in the middle of a V-cycle.
+  if ((size_t)2 * t->max_n * t->max_n * t->max_n * sizeof(double) > 160 * 1024)
+    D4EST_HIP_ABORT("transfer_create: degree %d exceeds the transfer kernels' limit (two %d^3 fields do not fit the 160 KB LDS)",
                     t->max_n - 1, t->max_n);
   t->n_children = item_first[n_items];
   t->coarse_nodes = co;
@@ -226,16 +231,17 @@ static void launch_restrict(d4est_hip_transfer_t* t, const double* x_fine_dev, d
   if (!t) D4EST_HIP_ABORT("%s: NULL transfer", who);
   if (t->n_items == 0) return;
   const int n3 = t->max_n * t->max_n * t->max_n;
-  const size_t lds = (size_t)3 * n3 * sizeof(double);
+  const int acc_in_lds = ((size_t)3 * n3 * sizeof(double) <= 160 * 1024) ? 1 : 0;
+  const size_t lds = (size_t)(acc_in_lds ? 3 : 2) * n3 * sizeof(double);
   if (lds > 160 * 1024) D4EST_HIP_ABORT("%s: degree too high for the LDS-resident kernel", who);
   const void* fn = project ? reinterpret_cast<const void*>(d4est_hip::restrict_kernel<false>) : reinterpret_cast<const void*>(d4est_hip::restrict_kernel<true>);
   if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (project)
     hipLaunchKernelGGL(d4est_hip::restrict_kernel<false>, dim3(std::min(t->n_items, 65536)), dim3(256), lds, t->stream, x_fine_dev, x_coarse_dev,
-                       t->d_child, t->d_off, t->d_item_first, t->d_rops, t->n_items, n3);
+                       t->d_child, t->d_off, t->d_item_first, t->d_rops, t->n_items, n3, acc_in_lds);
   else
     hipLaunchKernelGGL(d4est_hip::restrict_kernel<true>, dim3(std::min(t->n_items, 65536)), dim3(256), lds, t->stream, x_fine_dev, x_coarse_dev,
-                       t->d_child, t->d_off, t->d_item_first, t->d_ops, t->n_items, n3);
+                       t->d_child, t->d_off, t->d_item_first, t->d_ops, t->n_items, n3, acc_in_lds);
   HIP_CHECK(hipGetLastError());
 }
 

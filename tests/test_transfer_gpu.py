@@ -11,6 +11,14 @@ RTOL = 1e-12
 
 
 def _items(seed, n_items, pmax):
+    if pmax == "p19":   # the top of the reference's degree range (d4est_operators.c:1205-1297): coarse p = 17, 18, fine up to p = 19
+        hrefine = np.array([0, 1, 0], dtype=np.int32)
+        degH = np.array([17, 17, 18], dtype=np.int32)
+        degh = np.zeros(24, dtype=np.int32)
+        degh[0] = 19
+        degh[8:16] = [17, 18, 19, 19, 18, 17, 19, 18]
+        degh[16] = 19
+        return hrefine, degH, degh
     rng = np.random.RandomState(seed)
     hrefine = rng.randint(0, 2, size=n_items).astype(np.int32)
     degH = rng.randint(1, pmax, size=n_items).astype(np.int32)
@@ -60,7 +68,7 @@ def _oracle_transfer(oracle, hrefine, degH, degh, x, prolong):
     return out
 
 
-@pytest.mark.parametrize("seed,n_items,pmax", [(1, 7, 4), (2, 40, 6), (3, 9, 9), (4, 3, 13)])
+@pytest.mark.parametrize("seed,n_items,pmax", [(1, 7, 4), (2, 40, 6), (3, 9, 9), (4, 3, 13), (7, 3, "p19")])
 def test_prolong_restrict_parity(gpu, hiplib, oracle, seed, n_items, pmax):
     import torch
     from disco4est_amd import Transfer, mesh as M
@@ -97,7 +105,7 @@ def test_empty_transfer(gpu, hiplib):
     t.destroy()
 
 
-@pytest.mark.parametrize("seed,n_items,pmax", [(5, 12, 5), (6, 6, 9)])
+@pytest.mark.parametrize("seed,n_items,pmax", [(5, 12, 5), (6, 6, 9), (8, 3, "p19")])
 def test_projection_parity(gpu, hiplib, oracle, seed, n_items, pmax):
     """d4est_hip_transfer_project = d4est_operators_apply_p_restrict / _hp_restrict per item (the L2 projection of a field onto the
     coarse space): parity with the oracle, and project(prolong(x)) = x"""
@@ -133,4 +141,4 @@ def test_projection_parity(gpu, hiplib, oracle, seed, n_items, pmax):
     back = torch.empty_like(xc)
     t.prolong(xc, fine)
     t.project(fine, back)
-    assert float((back - xc).abs().max()) <= 1e-11
+    assert float((back - xc).abs().max()) <= (1e-11 if pmax != "p19" else 1e-9)
