@@ -16,10 +16,10 @@ constexpr bool kEoPipelined = ((C > R ? C : R) >= 12) && ((C > R ? C : R) != 16)
 // full EO rows through one base pointer with immediate offsets (contract_rows_eo_imm): where a row (R doubles) and its successor fit
 // the scalar registers
 #ifndef D4EST_HIP_EO_ROWS_IMM_MAX
-#define D4EST_HIP_EO_ROWS_IMM_MAX 12
+#define D4EST_HIP_EO_ROWS_IMM_MAX 20
 #endif
 #ifndef D4EST_HIP_EO_ROWS_IMM_MIN
-#define D4EST_HIP_EO_ROWS_IMM_MIN 12
+#define D4EST_HIP_EO_ROWS_IMM_MIN 9
 #endif
 template <int C, int R>
 constexpr bool kEoRowsImm = ((C > R ? C : R) <= D4EST_HIP_EO_ROWS_IMM_MAX) && ((C > R ? C : R) >= D4EST_HIP_EO_ROWS_IMM_MIN);
