@@ -91,24 +91,44 @@ __device__ __forceinline__ void launder2_after(const double* pa, const double* p
   rb = (sdouble_ptr)vb;
 }
 
+#ifndef D4EST_HIP_EO_IMM_ROWS
+#define D4EST_HIP_EO_IMM_ROWS 1
+#endif
 // two operators at once, one EO row of each per step: yA (+)= sum_c rowA_c * (xfA[c] | xsA[c]), same for B.  HC = C/2 rows.
 template <int HC, int R, bool ACCA, bool ACCB>
 __device__ __forceinline__ void contract_pair_eo(const double* __restrict__ opA, const double* xfA, const double* xsA, double* yA,
                                                  const double* __restrict__ opB, const double* xfB, const double* xsB, double* yB) {
   constexpr int HR = (R + 1) / 2;   // outputs [0, HR) take the first input combination, [HR, R) the second
   double ca[R], cb[R], na[R], nb[R];
+#if D4EST_HIP_EO_IMM_ROWS   /* the rows through two laundered BASE pointers with immediate offsets (no scalar address arithmetic per row) */
+  unsigned long long bA = reinterpret_cast<unsigned long long>(opA), bB = reinterpret_cast<unsigned long long>(opB);
+  asm volatile("" : "+s"(bA), "+s"(bB));
+  {
+    sdouble_ptr ra = (sdouble_ptr)bA, rb = (sdouble_ptr)bB;
+#pragma unroll
+    for (int o = 0; o < R; ++o) { ca[o] = ra[o]; cb[o] = rb[o]; }
+  }
+#else
   {
     sdouble_ptr ra = launder(opA), rb = launder(opB);
 #pragma unroll
     for (int o = 0; o < R; ++o) { ca[o] = ra[o]; cb[o] = rb[o]; }
   }
+#endif
 #pragma unroll
   for (int i = 0; i < HC; ++i) {
     if (i + 1 < HC) {
+#if D4EST_HIP_EO_IMM_ROWS
+      asm volatile("" : "+s"(bA), "+s"(bB) : "s"(ca[0]), "s"(cb[0]));
+      sdouble_ptr ra = (sdouble_ptr)bA, rb = (sdouble_ptr)bB;
+#pragma unroll
+      for (int o = 0; o < R; ++o) { na[o] = ra[(i + 1) * R + o]; nb[o] = rb[(i + 1) * R + o]; }
+#else
       sdouble_ptr ra, rb;
       launder2_after(opA + (i + 1) * R, opB + (i + 1) * R, ca[0], cb[0], ra, rb);
 #pragma unroll
       for (int o = 0; o < R; ++o) { na[o] = ra[o]; nb[o] = rb[o]; }
+#endif
     }
 #pragma unroll
     for (int o = 0; o < R; ++o) {
@@ -130,6 +150,19 @@ __device__ __forceinline__ void contract_single_eo(const double* __restrict__ op
   constexpr int HR = (R + 1) / 2;   // outputs [0, HR) take the first input combination, [HR, R) the second
   constexpr int STEPS = (HC + 1) / 2;
   double c0[R], c1[R], n0[R], n1[R];
+#if D4EST_HIP_EO_IMM_ROWS
+  unsigned long long bs = reinterpret_cast<unsigned long long>(op);
+  asm volatile("" : "+s"(bs));
+  {
+    sdouble_ptr r0 = (sdouble_ptr)bs;
+#pragma unroll
+    for (int o = 0; o < R; ++o) c0[o] = r0[o];
+    if (HC > 1) {
+#pragma unroll
+      for (int o = 0; o < R; ++o) c1[o] = r0[R + o];
+    }
+  }
+#else
   {
     sdouble_ptr r0 = launder(op);
 #pragma unroll
@@ -140,10 +173,21 @@ __device__ __forceinline__ void contract_single_eo(const double* __restrict__ op
       for (int o = 0; o < R; ++o) c1[o] = r1[o];
     }
   }
+#endif
 #pragma unroll
   for (int st = 0; st < STEPS; ++st) {
     const int i0 = 2 * st, i1 = 2 * st + 1;
     if (i0 + 2 < HC) {
+#if D4EST_HIP_EO_IMM_ROWS
+      asm volatile("" : "+s"(bs) : "s"(c0[0]), "s"((i1 < HC) ? c1[0] : c0[0]));
+      sdouble_ptr r0 = (sdouble_ptr)bs;
+#pragma unroll
+      for (int o = 0; o < R; ++o) n0[o] = r0[(i0 + 2) * R + o];
+      if (i1 + 2 < HC) {
+#pragma unroll
+        for (int o = 0; o < R; ++o) n1[o] = r0[(i1 + 2) * R + o];
+      }
+#else
       sdouble_ptr r0, r1;
       launder2_after(op + (i0 + 2) * R, op + ((i1 + 2 < HC) ? (i1 + 2) : (i0 + 2)) * R, c0[0], (i1 < HC) ? c1[0] : c0[0], r0, r1);
 #pragma unroll
@@ -152,6 +196,7 @@ __device__ __forceinline__ void contract_single_eo(const double* __restrict__ op
 #pragma unroll
         for (int o = 0; o < R; ++o) n1[o] = r1[o];
       }
+#endif
     }
 #pragma unroll
     for (int o = 0; o < R; ++o) {
