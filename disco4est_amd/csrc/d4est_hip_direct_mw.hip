@@ -69,11 +69,18 @@ struct PassMap {
 #else
 #define MW_SYNC() __syncthreads()
 #endif
-#ifndef D4EST_HIP_MWD_GEOM_EARLY
-#define D4EST_HIP_MWD_GEOM_EARLY 0
-#endif
 #ifndef D4EST_HIP_MWD_WAVES
 #define D4EST_HIP_MWD_WAVES 4
+#endif
+// diagnostic build only (-DD4EST_HIP_MWD_STAMPS=1, tools/stamps_mw.py): wave 0 of every workgroup writes s_memtime at the phase
+// boundaries into the buffer handed over as the (otherwise unused) ghost trace argument; never compiled into the product
+#ifndef D4EST_HIP_MWD_STAMPS
+#define D4EST_HIP_MWD_STAMPS 0
+#endif
+#if D4EST_HIP_MWD_STAMPS
+#define MW_STAMP(k) do { if (ghost_qtrace && threadIdx.x == 0) ((unsigned long long*)ghost_qtrace)[(size_t)blockIdx.x * 40 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MW_STAMP(k) do { } while (0)
 #endif
 
 // y = M x for a centro-symmetric / -antisymmetric (ANTI) N x N operator in the even-odd form: full table rows through one base pointer
@@ -169,7 +176,17 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
   if (slot >= n_elem) return;
   const int e = elem_list ? __builtin_amdgcn_readfirstlane(elem_list[slot]) : slot;
   const int ns = __builtin_amdgcn_readfirstlane(ns0 + e * ns_stride);
+  MW_STAMP(0);
 
+  // the six side descriptors now (scalar loads; two dependent round trips -- kernel-argument segment, then the array -- that would
+  // otherwise sit in front of every direction's line loads)
+  int kcf6[6], sgeom6[6], nbr6[6];
+  {
+    typedef const DirectSide __attribute__((address_space(4))) * sside_ptr;
+    const sside_ptr sd = (sside_ptr)(unsigned long long)(sides + 6 * (size_t)e);
+#pragma unroll
+    for (int f = 0; f < 6; ++f) { kcf6[f] = sd[f].kcf; sgeom6[f] = sd[f].geom; nbr6[f] = sd[f].nbr_ns; }
+  }
   // ---- R0 <- (K u)_e, or the A u the face terms are added to
   if constexpr (VOL != 0) {
     if (on) load_element_image<N, PL, PN>(R0, u + ns, te);
@@ -184,6 +201,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
     __syncthreads();
   }
 
+  MW_STAMP(1);
   // ---- the thread's line tasks in the four passes (the same in every direction; packed: see pack_task)
   using PM1 = PassMap<TH, 8 * N, 4 * N>;    // C on the 8 nodal fields | C D on the 4 trace fields
   using PM2 = PassMap<TH, 12 * N, 4 * N>;   // C on P_0..7, R_0..3 | C D on P_0..3
@@ -203,33 +221,8 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
   auto dir_body = [&](auto dc) {
     constexpr int d = decltype(dc)::value;
     constexpr int t0 = (d == 0) ? 1 : 0, t1d = (d == 2) ? 1 : 2;   // reference directions of the face indices a and b
-    // (the descriptor array is read-only for the kernel's lifetime: constant address space, so its fields are scalar loads)
-    typedef const DirectSide __attribute__((address_space(4))) * sside_ptr;
-    const sside_ptr sd = (sside_ptr)(unsigned long long)(direct_kargs()->sides + 6 * (size_t)e + 2 * d);
-    const int kcf[2] = {sd[0].kcf, sd[1].kcf};
-    const int sgeom[2] = {sd[0].geom, sd[1].geom};
-#if D4EST_HIP_MWD_GEOM_EARLY   /* the two faces' geometric factors are requested before the lines: their HBM latency passes under passes 1 and 2 */
-    double gqa[2][7];
-    {
-      const direct_kargs_ptr K = direct_kargs();
-      const double* __restrict__ geom_ = K->geom;
-      const double* __restrict__ robin_c_ = K->robin_c;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int c = 0; c < 7; ++c) gqa[h][c] = 0.0;
-        if (on) {
-          if ((kcf[h] & 3) == 0 && robin_c_) {
-            gqa[h][6] = robin_c_[sgeom[h] + te];   // am = ap = 0: no term 1 / term 2 on a Robin side
-          } else {
-            const double* __restrict__ g = geom_ + (size_t)7 * sgeom[h] + te;
-#pragma unroll
-            for (int c = 0; c < 7; ++c) gqa[h][c] = (D4EST_HIP_MWD_ABLATE & 8) ? 0.5 + c : g[c * T];
-          }
-        }
-      }
-    }
-#endif
+    const int kcf[2] = {kcf6[2 * d], kcf6[2 * d + 1]};
+    const int sgeom[2] = {sgeom6[2 * d], sgeom6[2 * d + 1]};
     // ---- nodal fields of the two faces at face node (a, b): c = 0..3 trace (own 2d, own 2d+1, nbr 2d, nbr 2d+1), c = 4..7 normal
     // derivative.  The normal lines of the element and of the two (+) elements (at THEIR face node (a, b)) are requested together.
     double fld[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -243,7 +236,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if ((kcf[h] & 3) == 1) {
-          const double* __restrict__ upn = u + sd[h].nbr_ns;
+          const double* __restrict__ upn = u + nbr6[2 * d + h];
           const int dp = kcf[h] >> 6;
           const int stn = (dp == 0) ? 1 : (dp == 1 ? N : N2);
           const int on0 = (dp == 0) ? N * te : (dp == 1 ? a + N2 * b : te);
@@ -264,6 +257,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
         }
       }
     }
+    MW_STAMP(2 + 10 * d);   // lines loaded, nodal fields formed
     // ---- pass 1: line (field c, b), contract the face index a:  P_c = C x_c (c = 0..7), R_c = C D x_c (trace fields c = 0..3)
     MW_SYNC();   // (the buffer's last readers: the volume term / the previous direction's line update)
     if (on) {
@@ -280,6 +274,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
         for (int i = 0; i < N; ++i) x[r][i] = lds_ld(&S[in + i]);
       }
       MW_SYNC();
+      MW_STAMP(3 + 10 * d);   // staged, rows read
 #pragma unroll
       for (int r = 0; r < PM1::ROUNDS; ++r) {
         const bool isB = (tk1[r] >> 30) & 1;
@@ -292,23 +287,8 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
       }
     }
     MW_SYNC();
-    // ---- pass 2: line (field, a'), contract the face index b:  u = C P_c, du/dn = C P_{4+c}, du/dt_a = C R_c | du/dt_b = C D P_c
-    double o2[PM2::ROUNDS][N];
-    {
-      double x[PM2::ROUNDS][N];
-#pragma unroll
-      for (int r = 0; r < PM2::ROUNDS; ++r) {
-        const int in = tk2[r] < 0 ? 0 : ((tk2[r] >> 8) & 0xff) * GS + (tk2[r] & 0xff) * RS;
-#pragma unroll
-        for (int i = 0; i < N; ++i) x[r][i] = lds_ld(&S[in + i]);
-      }
-#pragma unroll
-      for (int r = 0; r < PM2::ROUNDS; ++r)
-        pass_product<N, 12 * N, PM2::oB, PM2::END, false, true>(tC, tCD, wave0 + r * TH, (tk2[r] >> 30) & 1, x[r], o2[r]);
-    }
-    // ---- SIPG terms, one face at a time (the mortar values of its two sides go through the buffer)
-    double At[2][4];
-#if !D4EST_HIP_MWD_GEOM_EARLY
+    MW_STAMP(4 + 10 * d);   // pass 1 done
+    // the two faces' geometric factors (HBM) are requested here: their latency passes under the pass-2 products
     double gqa[2][7];
     {
       const direct_kargs_ptr K = direct_kargs();
@@ -329,7 +309,23 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
         }
       }
     }
-#endif
+    // ---- pass 2: line (field, a'), contract the face index b:  u = C P_c, du/dn = C P_{4+c}, du/dt_a = C R_c | du/dt_b = C D P_c
+    double o2[PM2::ROUNDS][N];
+    {
+      double x[PM2::ROUNDS][N];
+#pragma unroll
+      for (int r = 0; r < PM2::ROUNDS; ++r) {
+        const int in = tk2[r] < 0 ? 0 : ((tk2[r] >> 8) & 0xff) * GS + (tk2[r] & 0xff) * RS;
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[r][i] = lds_ld(&S[in + i]);
+      }
+#pragma unroll
+      for (int r = 0; r < PM2::ROUNDS; ++r)
+        pass_product<N, 12 * N, PM2::oB, PM2::END, false, true>(tC, tCD, wave0 + r * TH, (tk2[r] >> 30) & 1, x[r], o2[r]);
+    }
+    MW_STAMP(5 + 10 * d);   // pass 2 products done
+    // ---- SIPG terms, one face at a time (the mortar values of its two sides go through the buffer)
+    double At[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       MW_SYNC();
@@ -383,6 +379,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
 #pragma unroll
       for (int l = 0; l < 3; ++l) At[h][1 + l] = w1 * gqa[h][l] * jump;
     }
+    MW_STAMP(6 + 10 * d);   // SIPG terms of both faces
     // ---- lift pass 1: line (term field 4 h + c, b'), contract a':  E, and D^T E for the term-2 field that is differentiated along a
     // (val = E_b E_a A0 + E_b (D^T E)_a A_t0 + (D^T E)_b E_a A_t1)
     MW_SYNC();
@@ -420,6 +417,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
       }
     }
     MW_SYNC();
+    MW_STAMP(7 + 10 * d);   // lift 1 done
     // ---- lift pass 2: line (h, g, a), contract b': g = 0 face-local part through E, 1 term 2 along b through D^T E, 2 normal term 2
     {
       double x[PM4::ROUNDS][N], y[PM4::ROUNDS][N];
@@ -453,6 +451,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
       }
     }
     MW_SYNC();
+    MW_STAMP(8 + 10 * d);   // lift 2 done
     // ---- the element's normal line at face node (a, b): face-local part at its two ends, D^T of the normal term 2 along it
     if (on) {
       const double val0 = lds_ld(&S[0 * VS + te]) + lds_ld(&S[1 * VS + te]), n0 = lds_ld(&S[2 * VS + te]);
@@ -477,6 +476,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
   dir_body(std::integral_constant<int, 1>{});
   dir_body(std::integral_constant<int, 2>{});
   __syncthreads();
+  MW_STAMP(32);
 
   // ---- A u (and the Chebyshev update of the node: cheby_update_kernel, same roundings; u is an INPUT of this kernel -- the
   // neighbours read it --, so the new iterate goes to a second vector)
@@ -519,6 +519,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
       for (int q = 0; q < NL; ++q) Au_[(size_t)ns + te + PL * q] = R0[ij + PN * N * q];
     }
   }
+  MW_STAMP(33);
 #undef tC
 #undef tCD
 #undef tE
