@@ -148,6 +148,11 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
       bk.d_EGf = upload(Tables1D::eo_table(G, bk.NQ, bk.N, true));
       bk.d_EBb = upload(Tables1D::eo_table(Tables1D::transpose(B, bk.NQ, bk.N), bk.N, bk.NQ, false));
       bk.d_EGb = upload(Tables1D::eo_table(Tables1D::transpose(G, bk.NQ, bk.N), bk.N, bk.NQ, true));
+      if (bk.N == bk.NQ) {
+        std::vector<double> Dq = Tables1D::quad_diff(quad_type, bk.deg_quad);
+        bk.d_EDq = upload(Tables1D::eo_table(Dq, bk.N, bk.N, true));
+        bk.d_EDqT = upload(Tables1D::eo_table(Tables1D::transpose(Dq, bk.N, bk.N), bk.N, bk.N, true));
+      }
     }
     std::vector<double> M = Tables1D::mij(bk.deg), Minv = Tables1D::invmij(bk.deg);
     bk.d_M = upload(M);
@@ -201,6 +206,8 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
     (void)hipFree(bk.d_DT);
     (void)hipFree(bk.d_EBf);
     (void)hipFree(bk.d_EGf);
+    (void)hipFree(bk.d_EDq);
+    (void)hipFree(bk.d_EDqT);
     (void)hipFree(bk.d_EBb);
     (void)hipFree(bk.d_EGb);
     (void)hipFree(bk.d_M);

@@ -47,6 +47,8 @@ struct DirectVol {
   const int* qs_list = nullptr;      // quadrature offset per element where the offsets are not affine (qs_stride < 0): a Schwarz
                                      // subdomain plan, whose element copies alias the mesh's metric
   const double* cq = nullptr;        // zeroth-order term (VOL & 4): w J c at the quadrature nodes (ensure_lhs_wjc)
+  const double* EDq = nullptr;       // multi-wave kernel: even-odd tables of the differentiation matrix on the quadrature nodes and of
+  const double* EDqT = nullptr;      // its transpose (collocated-gradient form of the volume term, stiffness_mw_element_cg)
 };
 
 
@@ -81,7 +83,7 @@ __device__ __forceinline__ DirectVol direct_load_vol(direct_kargs_ptr K) {
   DirectVol v;
   v.metric = K->vol.metric; v.EBf = K->vol.EBf; v.EGf = K->vol.EGf; v.EBb = K->vol.EBb; v.EGb = K->vol.EGb;
   v.affine = K->vol.affine; v.wq = K->vol.wq; v.qs0 = K->vol.qs0; v.qs_stride = K->vol.qs_stride; v.qs_list = K->vol.qs_list;
-  v.cq = K->vol.cq;
+  v.cq = K->vol.cq; v.EDq = K->vol.EDq; v.EDqT = K->vol.EDqT;
   return v;
 }
 

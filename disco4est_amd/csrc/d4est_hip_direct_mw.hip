@@ -192,9 +192,16 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
     if (on) load_element_image<N, PL, PN>(R0, u + ns, te);
     const DirectVol vl = direct_load_vol(direct_kargs());
     const int qs = __builtin_amdgcn_readfirstlane(vl.qs_stride >= 0 ? vl.qs0 + e * vl.qs_stride : vl.qs_list[e]);
-    if constexpr ((D4EST_HIP_MWD_ABLATE & 4) == 0)
+    unsigned long long* st_ = (D4EST_HIP_MWD_STAMPS && ghost_qtrace) ? (unsigned long long*)ghost_qtrace + (size_t)blockIdx.x * 40 + 34 : nullptr;
+    if constexpr ((D4EST_HIP_MWD_ABLATE & 4) == 0) {
+#if D4EST_HIP_MW_COLLOCATED
+      stiffness_mw_element_cg<N, (VOL & 3) == 2, (VOL & 4) != 0>(R0, S, vl.metric, qs, e, on, te, a, b, vl.EBb, vl.EBf, vl.EDq, vl.EDqT, vl.affine,
+                                                                 vl.wq, vl.cq, st_);
+#else
       stiffness_mw_element<N, N, false, true, (VOL & 3) == 2, (VOL & 4) != 0>(R0, S, vl.metric, qs, e, on, te, a, b, vl.EBb, vl.EGb, vl.EBf,
-                                                                              vl.EGf, vl.affine, vl.wq, vl.cq);
+                                                                              vl.EGf, vl.affine, vl.wq, vl.cq, st_);
+#endif
+    }
     else __syncthreads();
   } else {
     if (on) load_element_image<N, PL, PN>(R0, direct_kargs()->Au + ns, te);

@@ -50,6 +50,9 @@ struct Bucket {
   double* d_EGf = nullptr;
   double* d_EBb = nullptr;
   double* d_EGb = nullptr;
+  // N = NQ only: even-odd tables of the differentiation matrix ON the quadrature nodes and of its transpose (collocated-gradient form)
+  double* d_EDq = nullptr;
+  double* d_EDqT = nullptr;
   double* d_M = nullptr;
   double* d_MT = nullptr;
   double* d_Minv = nullptr;

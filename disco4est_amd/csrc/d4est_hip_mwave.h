@@ -92,6 +92,9 @@ __device__ __forceinline__ void bwd(const double* __restrict__ tab, const double
 #ifndef D4EST_HIP_METRIC_EARLY
 #define D4EST_HIP_METRIC_EARLY 2
 #endif
+#ifndef D4EST_HIP_MW_COLLOCATED
+#define D4EST_HIP_MW_COLLOCATED 1   /* deg_quad = deg: the collocated-gradient form (12 instead of 16 one-dimensional products per thread) */
+#endif
 #ifndef D4EST_HIP_MW_WAVES
 #define D4EST_HIP_MW_WAVES 4
 #endif
@@ -104,7 +107,9 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
                                                      int te, int a, int b, const double* __restrict__ Bop, const double* __restrict__ Gop,
                                                      const double* __restrict__ BopT, const double* __restrict__ GopT,
                                                      const double* __restrict__ affine, const double* __restrict__ wq,
-                                                     const double* __restrict__ cq = nullptr) {
+                                                     const double* __restrict__ cq = nullptr, unsigned long long* stamps = nullptr) {
+  // (stamps: diagnostic builds only -- s_memtime at the stage boundaries, tools/stamps_mw.py)
+#define MWE_STAMP(k) do { if (stamps && te == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
   using C = WaveCfg<N, NQ>;
   constexpr int PL = C::PL, PN = C::PN, PQ = C::PQ;
   constexpr int NQ3 = NQ * NQ * NQ;
@@ -139,6 +144,7 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
   }
   __syncthreads();
 
+  MWE_STAMP(0);   // element image + S1
   // ---- S2 (thread (iq=a, k=b)) interleaved with S3 (thread (iq=a, jq=b)): one field at a time through R0
   double gr[NQ], gs[NQ], gt[NQ];
   double vm[MASS ? NQ : 1];   // MASS: V u, then w J c V u, at the thread's quadrature nodes
@@ -225,6 +231,7 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
     }
   }
 
+  MWE_STAMP(1);   // S2 / S3
   // ---- quadrature-point stage
   if constexpr (MASS) {
     if (active) {
@@ -301,6 +308,7 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
     }
   }
 
+  MWE_STAMP(2);   // quadrature stage (the metric stream)
   // ---- S5 (thread (iq=a, jq=b), registers) interleaved with S6 (thread (iq=a, k=b)) through R0/R1
   double ar[N], bs[N];
   {
@@ -352,6 +360,7 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
   }
   __syncthreads();
 
+  MWE_STAMP(3);   // S5 / S6
   // ---- S7: r-contraction transposed, thread (j=a, k=b)
   {
     double x[NQ], y[NQ], o[N];
@@ -372,6 +381,231 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
     }
   }
   __syncthreads();
+  MWE_STAMP(4);   // S7
+#undef MWE_STAMP
+}
+
+// ---------------------------------------------------------------------------
+// The same apply in the COLLOCATED-GRADIENT form, for deg_quad = deg (N = NQ; round 3).  With as many quadrature nodes as Lobatto nodes
+// the interpolation B is square and invertible, so the gradient at the quadrature nodes is the derivative of the interpolant THERE:
+//     (B_t (x) B_s (x) G_r) u = (I (x) I (x) Dq) (B_t (x) B_s (x) B_r) u,     G = B D,  Dq = B D B^-1 = the differentiation matrix ON the
+// quadrature nodes (Tables1D::quad_diff).  One interpolation of u (3 one-dimensional products per thread), three derivatives of it
+// (3), the metric multiply, three transposed derivatives summed into one field (3), one transposed interpolation (3): 12 products per
+// thread instead of the 16 of the form above (8 forward: B_r G_r | B_s G_r, G_s B_r, B_s B_r | B_t B_t G_t; 8 backward) -- the same
+// operator, re-associated (differences at rounding level, held to the oracle by the same tests).  The two gradient lines that are formed
+// by other threads arrive through LDS in exactly the thread-private slots [kq + P te] in which the quadrature stage keeps them while
+// the metric planes are in flight, so the parking of the form above costs nothing here.  V u itself passes through registers (w below):
+// the zeroth-order term (MASS) needs no contraction of its own in either direction.
+// EDq / EDqT: even-odd tables of Dq and of its transpose (centro-antisymmetric); Bop / BopT as above.  On entry R0 holds u_e (no barrier
+// yet); on exit R0 holds (A u)_e behind a barrier.
+// ---------------------------------------------------------------------------
+template <int N, int NQ, bool PF, bool EO>
+inline constexpr bool kMwCollocated = D4EST_HIP_MW_COLLOCATED && N == NQ && EO && !PF && (N * N > 64);
+
+template <int N, bool AFF, bool MASS = false>
+__device__ __forceinline__ void stiffness_mw_element_cg(double* R0, double* R1, const double* __restrict__ metric, int qs, int ei, bool active,
+                                                        int te, int a, int b, const double* __restrict__ Bop, const double* __restrict__ BopT,
+                                                        const double* __restrict__ EDq, const double* __restrict__ EDqT,
+                                                        const double* __restrict__ affine, const double* __restrict__ wq,
+                                                        const double* __restrict__ cq = nullptr, unsigned long long* stamps = nullptr) {
+#define MWE_STAMP(k) do { if (stamps && te == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+  using C = WaveCfg<N, N>;
+  constexpr int P = C::PN;
+  constexpr int N3 = N * N * N;
+  const int line = P * te;   // the thread's private line [kq + P (a + N b)] in either field
+  // ---- F1 (r): thread (j = a, k = b):  R1[j + P (iq + N k)] <- B u
+  __syncthreads();
+  if (active) {
+    double x[N], y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = lds_ld(&R0[i + line]);
+    fwd<N, N, true, false>(BopT, x, y);
+#pragma unroll
+    for (int iq = 0; iq < N; ++iq) R1[a + P * (iq + N * b)] = y[iq];
+  }
+  // ---- F2 (s): thread (iq = a, k = b):  R0[k + P (iq + N jq)] <- B (.)
+  __syncthreads();
+  if (active) {
+    double x[N], y[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] = lds_ld(&R1[j + line]);
+    fwd<N, N, true, false>(BopT, x, y);
+#pragma unroll
+    for (int jq = 0; jq < N; ++jq) R0[b + P * (a + N * jq)] = y[jq];
+  }
+  MWE_STAMP(0);
+  // ---- F3 (t): thread (iq = a, jq = b): w = V u along kq (registers); gt = Dq w; w goes out in the layouts of the s- and r-derivative
+  __syncthreads();
+  double gt[N];
+  double vm[MASS ? N : 1];
+  {
+    double w[N];
+    if (active) {
+      double x[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) x[k] = lds_ld(&R0[k + line]);
+      fwd<N, N, true, false>(BopT, x, w);
+#pragma unroll
+      for (int kq = 0; kq < N; ++kq) R1[a + P * (b + N * kq)] = w[kq];   // r-lines: [iq + P (jq + N kq)]  (R1's readers finished before the barrier above)
+      fwd<N, N, true, true>(EDq, w, gt);
+      if constexpr (MASS) {
+#pragma unroll
+        for (int kq = 0; kq < N; ++kq) vm[kq] = w[kq];
+      }
+    }
+    __syncthreads();   // every thread has read its line of R0  (the barrier is outside the branch: a wavefront may hold idle threads)
+    if (active) {
+#pragma unroll
+      for (int kq = 0; kq < N; ++kq) R0[b + P * (a + N * kq)] = w[kq];   // s-lines: [jq + P (iq + N kq)]
+    }
+  }
+  // ---- F4: thread (iq = a, kq = b): gs line = Dq (s-line);  thread (jq = a, kq = b): gr line = Dq (r-line); both go to the private
+  // slots [kq + P (iq + N jq)] of the threads (iq, jq)
+  __syncthreads();
+  {
+    double z[N], x[N], ys[N], yr[N];
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        z[j] = lds_ld(&R0[j + line]);
+        x[j] = lds_ld(&R1[j + line]);
+      }
+      fwd<N, N, true, true>(EDq, z, ys);
+      fwd<N, N, true, true>(EDq, x, yr);
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        R0[b + P * (a + N * j)] = ys[j];   // gs(iq = a, jq = j, kq = b)  -> [kq + P (iq + N jq)]
+        R1[b + P * (j + N * a)] = yr[j];   // gr(iq = j, jq = a, kq = b)  -> [kq + P (iq + N jq)]
+      }
+    }
+  }
+  __syncthreads();
+  MWE_STAMP(1);
+  // ---- quadrature-point stage: thread (iq = a, jq = b); gs in R0[kq + line], gr in R1[kq + line] (private), gt in registers
+  if constexpr (MASS) {
+    if (active) {
+      const double* __restrict__ cp = cq + qs + (a + N * b);   // w J c, pre-combined (ensure_lhs_wjc)
+      double cv[N];
+#pragma unroll
+      for (int kq = 0; kq < N; ++kq) cv[kq] = cp[N * N * kq];
+#pragma unroll
+      for (int kq = 0; kq < N; ++kq) vm[kq] *= cv[kq];
+    }
+  }
+  if (active) {
+    if constexpr (AFF) {
+      const double* __restrict__ c = affine + (size_t)6 * ei;
+      const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+      const double wab = wq[b] * wq[a];
+#pragma unroll
+      for (int kq = 0; kq < N; ++kq) {
+        const double w3 = wq[kq] * wab;
+        const double r = w3 * lds_ld(&R1[kq + line]), s_ = w3 * lds_ld(&R0[kq + line]), t = w3 * gt[kq];
+        R1[kq + line] = c0 * r + c1 * s_ + c2 * t;
+        R0[kq + line] = c1 * r + c3 * s_ + c4 * t;
+        gt[kq] = c2 * r + c4 * s_ + c5 * t;
+      }
+    } else {
+      constexpr int MDW = MASS ? 2 : D4EST_HIP_METRIC_DEPTH;
+      constexpr int MD = (MDW < N) ? MDW : N;
+      double mw[N][6];
+      const double* __restrict__ m = metric + (size_t)6 * qs + (a + N * b);
+#pragma unroll
+      for (int kq = 0; kq < MD; ++kq)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * N3 + N * N * kq];
+      double rn = lds_ld(&R1[line]), sn = lds_ld(&R0[line]);
+#pragma unroll
+      for (int kq = 0; kq < N; ++kq) {
+        if (kq + MD < N) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) mw[kq + MD][c] = m[c * N3 + N * N * (kq + MD)];
+        }
+        const double r = rn, s = sn, t = gt[kq];
+        if (kq + 1 < N) {
+          rn = lds_ld(&R1[kq + 1 + line]);
+          sn = lds_ld(&R0[kq + 1 + line]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        R1[kq + line] = mw[kq][0] * r + mw[kq][1] * s + mw[kq][2] * t;
+        R0[kq + line] = mw[kq][1] * r + mw[kq][3] * s + mw[kq][4] * t;
+        gt[kq] = mw[kq][2] * r + mw[kq][4] * s + mw[kq][5] * t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  MWE_STAMP(2);
+  // ---- B1: the transposed derivatives.  t: registers.  s / r: the threads (iq, kq) / (jq, kq) take their lines out of the flux fields
+  // (stride P N) and put the result back IN PLACE (each thread rewrites exactly the entries it read)
+  double ft[N];
+  if (active) {
+    bwd<N, N, true, true, false>(EDqT, gt, ft);
+    if constexpr (MASS) {
+#pragma unroll
+      for (int kq = 0; kq < N; ++kq) ft[kq] += vm[kq];
+    }
+  }
+  __syncthreads();
+  {
+    double z[N], x[N], ys[N], yr[N];
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        z[j] = lds_ld(&R0[b + P * (a + N * j)]);   // flux_s(iq = a, jq = j, kq = b)
+        x[j] = lds_ld(&R1[b + P * (j + N * a)]);   // flux_r(iq = j, jq = a, kq = b)
+      }
+      bwd<N, N, true, true, false>(EDqT, z, ys);
+      bwd<N, N, true, true, false>(EDqT, x, yr);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        R0[b + P * (a + N * j)] = ys[j];
+        R1[b + P * (j + N * a)] = yr[j];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- B2 (t^T): thread (iq = a, jq = b): F = ft + (s part) + (r part) along kq;  R?[jq + P (iq + N k)] <- B^T F
+  {
+    double c[N];
+    if (active) {
+      double F[N];
+#pragma unroll
+      for (int kq = 0; kq < N; ++kq) F[kq] = ft[kq] + (lds_ld(&R0[kq + line]) + lds_ld(&R1[kq + line]));
+      bwd<N, N, true, false, false>(Bop, F, c);
+    }
+    __syncthreads();   // every thread has read its private lines
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) R0[b + P * (a + N * k)] = c[k];
+    }
+  }
+  MWE_STAMP(3);
+  // ---- B3 (s^T): thread (iq = a, k = b):  R1[iq + P (j + N k)] <- B^T (.)
+  __syncthreads();
+  if (active) {
+    double x[N], y[N];
+#pragma unroll
+    for (int jq = 0; jq < N; ++jq) x[jq] = lds_ld(&R0[jq + line]);
+    bwd<N, N, true, false, false>(Bop, x, y);
+#pragma unroll
+    for (int j = 0; j < N; ++j) R1[a + P * (j + N * b)] = y[j];
+  }
+  // ---- B4 (r^T): thread (j = a, k = b):  R0[i + P (j + N k)] <- B^T (.)
+  __syncthreads();
+  if (active) {
+    double x[N], o[N];
+#pragma unroll
+    for (int iq = 0; iq < N; ++iq) x[iq] = lds_ld(&R1[iq + line]);
+    bwd<N, N, true, false, false>(Bop, x, o);
+#pragma unroll
+    for (int i = 0; i < N; ++i) R0[i + line] = o[i];
+  }
+  __syncthreads();
+  MWE_STAMP(4);
+#undef MWE_STAMP
 }
 
 }  // namespace d4est_hip

@@ -148,6 +148,30 @@ std::vector<double> Tables1D::dij(int deg) {
   return D;
 }
 
+// Differentiation matrix of the Lagrange basis on the quadrature nodes (barycentric form, as dij on the Lobatto nodes).  With deg_quad =
+// deg it equals B D B^-1 (B = quad_interp, square): the derivative of the interpolant evaluated where it was interpolated to -- the
+// collocated-gradient form of the stiffness apply (stiffness_mw_element_cg).
+std::vector<double> Tables1D::quad_diff(int quad_type, int deg_quad) {
+  std::vector<double> x, w;
+  if (quad_type == QUAD_LEGENDRE) gauss(deg_quad, x, w);
+  else if (quad_type == QUAD_LOBATTO) lobatto(deg_quad, x, w);
+  else { std::fprintf(stderr, "[D4EST_HIP_ABORT] unknown quadrature type %d\n", quad_type); std::abort(); }
+  const int n = deg_quad + 1;
+  std::vector<double> lam = bary_weights(x);
+  std::vector<double> D((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    long double diag = 0.0L;
+    for (int j = 0; j < n; ++j) {
+      if (i == j) continue;
+      long double d = ((long double)lam[j] / (long double)lam[i]) / ((long double)x[i] - (long double)x[j]);
+      D[(size_t)i * n + j] = (double)d;
+      diag -= d;
+    }
+    D[(size_t)i * n + i] = (double)diag;
+  }
+  return D;
+}
+
 std::vector<double> Tables1D::transpose(const std::vector<double>& A, int rows, int cols) {
   std::vector<double> At((size_t)rows * cols);
   for (int i = 0; i < rows; ++i)

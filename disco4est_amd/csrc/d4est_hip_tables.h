@@ -37,6 +37,7 @@ struct Tables1D {
   // quadrature vtable equivalents (Quadrature/d4est_quadrature_legendre.c:22-93, _lobatto.c:23-93)
   static std::vector<double> quad_weights(int quad_type, int deg_quad);
   static std::vector<double> quad_interp(int quad_type, int deg, int deg_quad);  // Nq x N
+  static std::vector<double> quad_diff(int quad_type, int deg_quad);   // Nq x Nq: differentiation matrix ON the quadrature nodes
 
   static std::vector<double> transpose(const std::vector<double>& A, int rows, int cols);
   static std::vector<double> matmul(const std::vector<double>& A, const std::vector<double>& B, int m, int l, int n);

@@ -273,7 +273,10 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
   if (active) {
     load_element_image<N, PL, PN>(R0, u + ns, te);
   }
-  stiffness_mw_element<N, NQ, PF, EO, AFF>(R0, R1, metric, qs, ei, active, te, a, b, Bop, Gop, BopT, GopT, affine, wq);
+  if constexpr (kMwCollocated<N, NQ, PF, EO>)   // Gop / GopT are then the tables of the differentiation matrix on the quadrature nodes
+    stiffness_mw_element_cg<N, AFF, false>(R0, R1, metric, qs, ei, active, te, a, b, Bop, BopT, Gop, GopT, affine, wq, nullptr, nullptr);
+  else
+    stiffness_mw_element<N, NQ, PF, EO, AFF>(R0, R1, metric, qs, ei, active, te, a, b, Bop, Gop, BopT, GopT, affine, wq);
   if (active) {
     store_element_image<N, PL, PN>(Au + ns, R0, te);
   }
@@ -1483,12 +1486,12 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
             set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven, true>, W::LDS_BYTES);                    \
             hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven, true>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
                                plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,           \
-                               plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, 0, D4EST_AFF_ARGS); \
+                               plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDq : bk.d_EGb), bk.d_EBf, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDqT : bk.d_EGf), 0, D4EST_AFF_ARGS); \
           } else {                                                                                              \
           set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven>, W::LDS_BYTES);                            \
           hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
                              plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
-                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER] < 0 ? 0 : plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER])); \
+                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDq : bk.d_EGb), bk.d_EBf, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDqT : bk.d_EGf), (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER] < 0 ? 0 : plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER])); \
           }                                                                                                     \
         } else {                                                                                                \
           set_lds_limit(stiffness_wave_kernel<N_, NQ_, false>, W::LDS_BYTES);                                   \
@@ -1531,12 +1534,12 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
         set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven, true>, W::LDS_BYTES);                        \
         hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven, true>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
                            plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,               \
-                           plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, 0, D4EST_AFF_ARGS); \
+                           plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDq : bk.d_EGb), bk.d_EBf, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDqT : bk.d_EGf), 0, D4EST_AFF_ARGS); \
       } else {                                                                                                  \
       set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven>, W::LDS_BYTES);                                \
       hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
                          plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,                 \
-                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, bk.d_EGb, bk.d_EBf, bk.d_EGf, (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER] < 0 ? 0 : plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER])); \
+                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDq : bk.d_EGb), bk.d_EBf, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDqT : bk.d_EGf), (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER] < 0 ? 0 : plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER])); \
       }                                                                                                         \
     } else {                                                                                                    \
       set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, false>, W::LDS_BYTES);                                \

@@ -21,6 +21,7 @@ for d in range(3):
         names[k + 10 * d] = "dir %d: %s" % (d, nm)
 names[32] = "last line update"; names[33] = "A u stored"
 order = sorted(names)
+vol = {34: "volume: element image + S1", 35: "volume: S2 / S3 (forward s, t)", 36: "volume: quadrature stage (metric stream)", 37: "volume: S5 / S6 (backward t, s)", 38: "volume: S7 (backward r)"}
 t0 = t[:, 0].min()
 print("level %d p %d: %d workgroups; shader cycles (s_memtime), medians over workgroups" % (level, deg, m.n_elements))
 life = np.median(t[:, 33] - t[:, 0])
@@ -28,5 +29,10 @@ prev = 0
 for k in order[1:]:
     dt = np.median(t[:, k] - t[:, prev])
     print("  %-32s %8.0f cycles  (%4.1f %% of the workgroup's %d-cycle lifetime)" % (names[k], dt, 100 * dt / life, life))
+    prev = k
+prev = 0
+for k in sorted(vol):
+    dt = np.median(t[:, k] - t[:, prev])
+    print("  %-44s %8.0f cycles" % (vol[k], dt))
     prev = k
 print("(s_memtime counts shader cycles; the counters of different XCDs have different origins, so only differences inside a workgroup are used)")
