@@ -21,6 +21,7 @@ SOURCES = [
     "d4est_hip_faces.hip",
     "d4est_hip_direct.hip",
     "d4est_hip_direct_mw.hip",
+    "d4est_hip_direct_mw_hi.hip",
     "d4est_hip_solver.hip",
     "d4est_hip_transfer.hip",
     "d4est_hip_schwarz.hip",

@@ -41,6 +41,15 @@ static void drop_graph(d4est_hip_plan_t* plan) {
 
 }  // namespace
 
+// Stream mode (d4est_hip_wave.h, with_ld): on when one apply streams more than fits the 256 MB Infinity Cache with room to spare --
+// metric 48 B per quadrature node + u and A u 16 B per node > 320 MB (measured crossover: p = 12 at 2048 elements, 288 MB, still gains
+// from the cache; p = 13 at 2048 elements, 360 MB, and p = 11 at 4096, 453 MB, gain from streaming) -- or forced by tuning key 12.
+static void update_stream_mode(d4est_hip_plan* plan) {
+  const int t = plan->tuning[D4EST_HIP_TUNE_STREAM];
+  const double bytes = 48.0 * (double)plan->local_nodes_quad + 16.0 * (double)plan->local_nodes;
+  plan->stream_mode = t < 0 ? (bytes > 320.0e6 ? 1 : 0) : (t != 0 ? 1 : 0);
+}
+
 extern "C" {
 
 const char* d4est_hip_version(void) { return "d4est_hip 0.1 (gfx950)"; }
@@ -121,6 +130,7 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
   if (ln > 0x7fffffffLL || lq > 0x7fffffffLL) D4EST_HIP_ABORT("plan_create: local_nodes exceeds 32-bit int (reference strides are int)");
   plan->local_nodes = (int)ln;
   plan->local_nodes_quad = (int)lq;
+  update_stream_mode(plan);
 
   std::vector<int> ids;
   ids.reserve(n_elements);
@@ -248,6 +258,7 @@ void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value) {
   drop_graph(plan);
   if (key < 0 || key >= D4EST_HIP_TUNE_COUNT) D4EST_HIP_ABORT("plan_set_tuning: unknown key %d", key);
   plan->tuning[key] = value;
+  if (key == D4EST_HIP_TUNE_STREAM) update_stream_mode(plan);
 }
 
 const char* d4est_hip_plan_last_kernel(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_last_kernel"); return plan->last_kernel; }

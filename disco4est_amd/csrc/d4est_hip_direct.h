@@ -49,6 +49,7 @@ struct DirectVol {
   const double* cq = nullptr;        // zeroth-order term (VOL & 4): w J c at the quadrature nodes (ensure_lhs_wjc)
   const double* EDq = nullptr;       // multi-wave kernel: even-odd tables of the differentiation matrix on the quadrature nodes and of
   const double* EDqT = nullptr;      // its transpose (collocated-gradient form of the volume term, stiffness_mw_element_cg)
+  int stream = 0;                    // multi-wave kernel: stream mode (plan->stream_mode; with_ld, d4est_hip_wave.h)
 };
 
 
@@ -83,7 +84,7 @@ __device__ __forceinline__ DirectVol direct_load_vol(direct_kargs_ptr K) {
   DirectVol v;
   v.metric = K->vol.metric; v.EBf = K->vol.EBf; v.EGf = K->vol.EGf; v.EBb = K->vol.EBb; v.EGb = K->vol.EGb;
   v.affine = K->vol.affine; v.wq = K->vol.wq; v.qs0 = K->vol.qs0; v.qs_stride = K->vol.qs_stride; v.qs_list = K->vol.qs_list;
-  v.cq = K->vol.cq; v.EDq = K->vol.EDq; v.EDqT = K->vol.EDqT;
+  v.cq = K->vol.cq; v.EDq = K->vol.EDq; v.EDqT = K->vol.EDqT; v.stream = K->vol.stream;
   return v;
 }
 

@@ -671,6 +671,7 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
     vol.metric = plan->d_metric;
     vol.EBf = bk.d_EBf; vol.EGf = bk.d_EGf; vol.EBb = bk.d_EBb; vol.EGb = bk.d_EGb;
     vol.EDq = bk.d_EDq; vol.EDqT = bk.d_EDqT;
+    vol.stream = plan->stream_mode;
     vol.qs0 = bk.qs0; vol.qs_stride = bk.ns_stride >= 0 ? bk.qs_stride : -1; vol.qs_list = plan->d_qs_list + bk.elem_offset;
     const bool aff = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine;
     if (aff) { vol.affine = plan->d_metric_affine; vol.wq = bk.d_w; }

@@ -195,10 +195,10 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
     unsigned long long* st_ = (D4EST_HIP_MWD_STAMPS && ghost_qtrace) ? (unsigned long long*)ghost_qtrace + (size_t)blockIdx.x * 40 + 34 : nullptr;
     if constexpr ((D4EST_HIP_MWD_ABLATE & 4) == 0) {
 #if D4EST_HIP_MW_COLLOCATED
-      stiffness_mw_element_cg<N, (VOL & 3) == 2, (VOL & 4) != 0>(R0, S, vl.metric, qs, e, on, te, a, b, vl.EBb, vl.EBf, vl.EDq, vl.EDqT, vl.affine,
+      stiffness_mw_element_cg<N, (VOL & 3) == 2, (VOL & 4) != 0, (VOL & 8) != 0>(R0, S, vl.metric, qs, e, on, te, a, b, vl.EBb, vl.EBf, vl.EDq, vl.EDqT, vl.affine,
                                                                  vl.wq, vl.cq, st_);
 #else
-      stiffness_mw_element<N, N, false, true, (VOL & 3) == 2, (VOL & 4) != 0>(R0, S, vl.metric, qs, e, on, te, a, b, vl.EBb, vl.EGb, vl.EBf,
+      stiffness_mw_element<N, N, false, true, (VOL & 3) == 2, (VOL & 4) != 0, (VOL & 8) != 0>(R0, S, vl.metric, qs, e, on, te, a, b, vl.EBb, vl.EGb, vl.EBf,
                                                                               vl.EGf, vl.affine, vl.wq, vl.cq, st_);
 #endif
     }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
           } else {
             const double* __restrict__ g = geom_ + (size_t)7 * sgeom[h] + te;
 #pragma unroll
-            for (int c = 0; c < 7; ++c) gqa[h][c] = (D4EST_HIP_MWD_ABLATE & 8) ? 0.5 + c : g[c * T];
+            for (int c = 0; c < 7; ++c) gqa[h][c] = (D4EST_HIP_MWD_ABLATE & 8) ? 0.5 + c : ld_sel<(VOL & 8) != 0>(&g[c * T]);   // (stream mode)
           }
         }
       }
@@ -523,7 +523,10 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < NL; ++q) Au_[(size_t)ns + te + PL * q] = R0[ij + PN * N * q];
+      for (int q = 0; q < NL; ++q) {
+        if constexpr ((VOL & 8) != 0) __builtin_nontemporal_store(R0[ij + PN * N * q], &Au_[(size_t)ns + te + PL * q]);   // stream mode
+        else Au_[(size_t)ns + te + PL * q] = R0[ij + PN * N * q];
+      }
     }
   }
   MW_STAMP(33);
@@ -536,12 +539,24 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
 
 }  // namespace
 
+// The instantiations are spread over two translation units so that the build's longest compile halves: this file holds N = 9 ... 12,
+// d4est_hip_direct_mw_hi.hip includes it with D4EST_HIP_MW_PART = 1 and holds N = 13 ... 16.
+#ifndef D4EST_HIP_MW_PART
+#define D4EST_HIP_MW_PART 0
+#endif
 #ifdef D4EST_HIP_MW_ONLY   /* development builds: one size */
 #define D4EST_HIP_DIRECT_MW_SIZES(X) X(D4EST_HIP_MW_ONLY)
+#define D4EST_HIP_DIRECT_MW_SIZES_HERE(X) X(D4EST_HIP_MW_ONLY)
 #else
 #define D4EST_HIP_DIRECT_MW_SIZES(X) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#if D4EST_HIP_MW_PART == 0
+#define D4EST_HIP_DIRECT_MW_SIZES_HERE(X) X(9) X(10) X(11) X(12)
+#else
+#define D4EST_HIP_DIRECT_MW_SIZES_HERE(X) X(13) X(14) X(15) X(16)
+#endif
 #endif
 
+#if D4EST_HIP_MW_PART == 0
 bool direct_mw_built(int N, int NQ) {
   if (N != NQ) return false;
 #define X(N_) if (N == N_) return true;
@@ -549,16 +564,24 @@ bool direct_mw_built(int N, int NQ) {
 #undef X
   return false;
 }
+bool launch_direct_mw_hi(d4est_hip_plan* plan, DirectHost* dh, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
+                         const double* robin_c, const double* robin_r, int vmode, const DirectVol& vol, int n, int chunk);
+#define D4EST_HIP_MW_LAUNCHER void launch_direct_mw
+#else
+#define D4EST_HIP_MW_LAUNCHER bool launch_direct_mw_hi
+#endif
 
 template <typename K>
 static void mw_set_lds_limit(K kernel, size_t bytes) {
   if (bytes > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
-void launch_direct_mw(d4est_hip_plan* plan, DirectHost* dh, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
+// vmode: VOL of operator_mw_kernel; + 8 (stream mode, plan->stream_mode) exists for the whole operator with the streamed metric (1 -> 9)
+D4EST_HIP_MW_LAUNCHER(d4est_hip_plan* plan, DirectHost* dh, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
                       const double* robin_c, const double* robin_r, int vmode, const DirectVol& vol, int n, int chunk) {
   const DirectFuse cfv = cf ? *cf : DirectFuse{};
   bool done = false;
+  if (vmode == 1 && vol.stream) vmode = 9;
 #define D4EST_HIP_MW_GO(N_, FUSE_, VOL_)                                                                                          \
   do {                                                                                                                             \
     mw_set_lds_limit(operator_mw_kernel<N_, FUSE_, VOL_>, MwCfg<N_>::LDS_BYTES);                                                  \
@@ -569,17 +592,26 @@ void launch_direct_mw(d4est_hip_plan* plan, DirectHost* dh, const double* u, con
 #define X(N_)                                                                                       \
   if (!done && dh->N == N_) {                                                                       \
     if (vmode == 1) { if (cf) D4EST_HIP_MW_GO(N_, true, 1); else D4EST_HIP_MW_GO(N_, false, 1); }   \
+    else if (vmode == 9) { if (cf) D4EST_HIP_MW_GO(N_, true, 9); else D4EST_HIP_MW_GO(N_, false, 9); } \
     else if (vmode == 2) { if (cf) D4EST_HIP_MW_GO(N_, true, 2); else D4EST_HIP_MW_GO(N_, false, 2); } \
     else if (vmode == 5) { if (cf) D4EST_HIP_MW_GO(N_, true, 5); else D4EST_HIP_MW_GO(N_, false, 5); } \
     else if (vmode == 6) { if (cf) D4EST_HIP_MW_GO(N_, true, 6); else D4EST_HIP_MW_GO(N_, false, 6); } \
     else { if (cf) D4EST_HIP_MW_GO(N_, true, 0); else D4EST_HIP_MW_GO(N_, false, 0); }              \
     done = true;                                                                                    \
   }
-  D4EST_HIP_DIRECT_MW_SIZES(X)
+  D4EST_HIP_DIRECT_MW_SIZES_HERE(X)
 #undef X
 #undef D4EST_HIP_MW_GO
+#if D4EST_HIP_MW_PART == 0
+#ifndef D4EST_HIP_MW_ONLY
+  if (!done) done = launch_direct_mw_hi(plan, dh, u, ghost_trace, Au, cf, robin_c, robin_r, vmode, vol, n, chunk);
+#endif
   if (!done) D4EST_HIP_ABORT("multi-wave direct kernel: no instance for N = %d", dh->N);
   HIP_CHECK(hipGetLastError());
+#else
+  if (done) HIP_CHECK(hipGetLastError());
+  return done;
+#endif
 }
 
 }  // namespace d4est_hip

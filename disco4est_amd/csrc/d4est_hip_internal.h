@@ -132,9 +132,10 @@ struct d4est_hip_plan {
   // bumped by every call that can change what the operator computes (geometry, faces, SIPG parameters, boundary data, the zeroth-order
   // coefficient, tuning): objects that cache something derived from the operator (the Schwarz smoother's condensed blocks) compare it
   unsigned long long op_generation = 0;
+  int stream_mode = 0;            // 1: non-temporal metric / factor loads and A u stores (capi: update_stream_mode; kernels: with_ld)
   bool bc_inhomogeneous = false;   // non-zero Dirichlet data or Robin data is set (an affine, not linear, operator)
 
-  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
+  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;

@@ -102,7 +102,7 @@ __device__ __forceinline__ void bwd(const double* __restrict__ tab, const double
 // layout, behind a barrier.  R0, R1: WaveCfg<N, NQ>::FS doubles each.  te = thread within the element, (a, b) = (te % NQ, te / NQ);
 // ns-independent: the caller loads and stores the element.  Operator arguments as stiffness_wave_kernel's.
 // MASS: + V^T [ w J c (V u) ], the zeroth-order term of a linearised nonlinear problem (see stiffness_wave_eo_element, d4est_hip_wave.h)
-template <int N, int NQ, bool PF, bool EO, bool AFF, bool MASS = false>
+template <int N, int NQ, bool PF, bool EO, bool AFF, bool MASS = false, bool NT = false>
 __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, const double* __restrict__ metric, int qs, int ei, bool active,
                                                      int te, int a, int b, const double* __restrict__ Bop, const double* __restrict__ Gop,
                                                      const double* __restrict__ BopT, const double* __restrict__ GopT,
@@ -119,7 +119,7 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) mreg[c][kq] = m[c * NQ3 + NQ * NQ * kq];
+      for (int c = 0; c < 6; ++c) mreg[c][kq] = ld_sel<NT>(&m[c * NQ3 + NQ * NQ * kq]);
   }
   __syncthreads();
 
@@ -212,7 +212,7 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
 #pragma unroll
         for (int kq = 0; kq < ME; ++kq)
 #pragma unroll
-          for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
+          for (int c = 0; c < 6; ++c) mw[kq][c] = ld_sel<NT>(&m[c * NQ3 + NQ * NQ * kq]);
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (!(MASS && kPark)) fwd<N, NQ, EO, true>(GopT, y, gt);
@@ -269,13 +269,13 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
 #pragma unroll
       for (int kq = ME; kq < MD; ++kq)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
+        for (int c = 0; c < 6; ++c) mw[kq][c] = ld_sel<NT>(&m[c * NQ3 + NQ * NQ * kq]);
       double rn = lds_ld(&R1[te]), sn = lds_ld(&R0[te]);
 #pragma unroll
       for (int kq = 0; kq < NQ; ++kq) {
         if (kq + MD < NQ) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) mw[kq + MD][c] = m[c * NQ3 + NQ * NQ * (kq + MD)];
+          for (int c = 0; c < 6; ++c) mw[kq + MD][c] = ld_sel<NT>(&m[c * NQ3 + NQ * NQ * (kq + MD)]);
         }
         const double r = rn, s = sn, t = gt[kq];
         if (kq + 1 < NQ) {
@@ -402,7 +402,7 @@ __device__ __forceinline__ void stiffness_mw_element(double* R0, double* R1, con
 template <int N, int NQ, bool PF, bool EO>
 inline constexpr bool kMwCollocated = D4EST_HIP_MW_COLLOCATED && N == NQ && EO && !PF && (N * N > 64);
 
-template <int N, bool AFF, bool MASS = false>
+template <int N, bool AFF, bool MASS = false, bool NT = false>
 __device__ __forceinline__ void stiffness_mw_element_cg(double* R0, double* R1, const double* __restrict__ metric, int qs, int ei, bool active,
                                                         int te, int a, int b, const double* __restrict__ Bop, const double* __restrict__ BopT,
                                                         const double* __restrict__ EDq, const double* __restrict__ EDqT,
@@ -516,13 +516,13 @@ __device__ __forceinline__ void stiffness_mw_element_cg(double* R0, double* R1, 
 #pragma unroll
       for (int kq = 0; kq < MD; ++kq)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * N3 + N * N * kq];
+        for (int c = 0; c < 6; ++c) mw[kq][c] = ld_sel<NT>(&m[c * N3 + N * N * kq]);
       double rn = lds_ld(&R1[line]), sn = lds_ld(&R0[line]);
 #pragma unroll
       for (int kq = 0; kq < N; ++kq) {
         if (kq + MD < N) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) mw[kq + MD][c] = m[c * N3 + N * N * (kq + MD)];
+          for (int c = 0; c < 6; ++c) mw[kq + MD][c] = ld_sel<NT>(&m[c * N3 + N * N * (kq + MD)]);
         }
         const double r = rn, s = sn, t = gt[kq];
         if (kq + 1 < N) {

@@ -50,7 +50,7 @@ struct VolCfg {
 // PF = true: the thread's 6*NQ metric entries are requested at kernel entry (before the
 // forward contractions) so that HBM latency overlaps the S1-S3 arithmetic; costs 12*NQ VGPRs.
 // EO = true: the four operator arguments are the even-odd tables (Bop = B^T's, Gop = G^T's, BopT = B's, GopT = G's)
-template <int N, int NQ, bool PF, bool EO = false>
+template <int N, int NQ, bool PF, bool EO = false, bool NT = false /* stream mode, d4est_hip_wave.h */>
 __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list,
@@ -88,7 +88,7 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) mreg[c][kq] = m[c * NQ3 + NQ * NQ * kq];
+      for (int c = 0; c < 6; ++c) mreg[c][kq] = ld_sel<NT>(&m[c * NQ3 + NQ * NQ * kq]);
   }
   __syncthreads();
 
@@ -214,7 +214,7 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 
   // ---- store Au_e (coalesced)
   if (active) {
-    store_element_image<N, PL, PN>(Au + ns, R2, te);
+    store_element_image<N, PL, PN, NT>(Au + ns, R2, te);
   }
 }
 
@@ -228,7 +228,7 @@ __global__ __launch_bounds__((VolCfg<N, NQ>::THREADS)) void stiffness_kernel(
 // in a single resident round.
 // ---------------------------------------------------------------------------
 
-template <int N, int NQ, bool PF, bool EO = false, bool AFF = false>
+template <int N, int NQ, bool PF, bool EO = false, bool AFF = false, bool NT = false /* stream mode, d4est_hip_wave.h */>
 __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS == 64 ? (PF ? 3 : 4) : ((!AFF && N <= 13) ? D4EST_HIP_MW_WAVES : ((!AFF && N == 14) ? 3 : 1)))) void stiffness_wave_kernel(
     const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ metric,
     const int* __restrict__ ns_list, const int* __restrict__ qs_list, int n_bucket, const double* __restrict__ Bop,
@@ -274,11 +274,11 @@ __global__ __launch_bounds__((WaveCfg<N, NQ>::THREADS), (WaveCfg<N, NQ>::THREADS
     load_element_image<N, PL, PN>(R0, u + ns, te);
   }
   if constexpr (kMwCollocated<N, NQ, PF, EO>)   // Gop / GopT are then the tables of the differentiation matrix on the quadrature nodes
-    stiffness_mw_element_cg<N, AFF, false>(R0, R1, metric, qs, ei, active, te, a, b, Bop, BopT, Gop, GopT, affine, wq, nullptr, nullptr);
+    stiffness_mw_element_cg<N, AFF, false, NT>(R0, R1, metric, qs, ei, active, te, a, b, Bop, BopT, Gop, GopT, affine, wq);
   else
-    stiffness_mw_element<N, NQ, PF, EO, AFF>(R0, R1, metric, qs, ei, active, te, a, b, Bop, Gop, BopT, GopT, affine, wq);
+    stiffness_mw_element<N, NQ, PF, EO, AFF, false, NT>(R0, R1, metric, qs, ei, active, te, a, b, Bop, Gop, BopT, GopT, affine, wq);
   if (active) {
-    store_element_image<N, PL, PN>(Au + ns, R0, te);
+    store_element_image<N, PL, PN, NT>(Au + ns, R0, te);
   }
 }
 
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
                                                                    const int* __restrict__ qs_list, int n_bucket,
                                                                    const double* __restrict__ Bop, const double* __restrict__ Gop,
                                                                    const double* __restrict__ affine = nullptr,
-                                                                   const double* __restrict__ wq = nullptr) {
+                                                                   const double* __restrict__ wq = nullptr, int stream = 0) {
   constexpr int JS = Mfma16Cfg::JS, KS = Mfma16Cfg::KS, FS = Mfma16Cfg::FS;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
@@ -775,11 +775,13 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
           for (int m = 0; m < 6; ++m) dst[m][v] = w3 * cc[m];
         }
       } else {
+        with_ld(stream != 0, [&](auto ld) {
 #pragma unroll
-        for (int m = 0; m < 6; ++m)
+          for (int m = 0; m < 6; ++m)
 #pragma unroll
-          for (int v = 0; v < 4; ++v)
-            dst[m][v] = (c < N && ct < N && 4 * v + q < N) ? me[m * (N * N * N) + c + N * ct + N * N * (4 * v + q)] : 0.0;
+            for (int v = 0; v < 4; ++v)
+              dst[m][v] = (c < N && ct < N && 4 * v + q < N) ? ld(&me[m * (N * N * N) + c + N * ct + N * N * (4 * v + q)]) : 0.0;
+        });
       }
     };
     tile_metric(2 * wave, mt);
@@ -888,9 +890,17 @@ __global__ __launch_bounds__(512, 1) void stiffness_mfma16_kernel(const double* 
         r2 = D4_MFMA(Gt[s], e2[s], r2);
       }
       double* out = Au + ns + c + N * N * k;
+      if (stream) {
+        D4EST_HIP_STREAM_FENCE();
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (c < N && 4 * v + q < N) out[N * (4 * v + q)] = r1[v] + r2[v];
+        for (int v = 0; v < 4; ++v)
+          if (c < N && 4 * v + q < N) __builtin_nontemporal_store(r1[v] + r2[v], &out[N * (4 * v + q)]);
+        D4EST_HIP_STREAM_FENCE();
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (c < N && 4 * v + q < N) out[N * (4 * v + q)] = r1[v] + r2[v];
+      }
     }
     __syncthreads();   // the next element's forward stage overwrites the image
   }
@@ -1397,7 +1407,7 @@ static void launch_stiffness_mfma16(d4est_hip_plan* plan, const Bucket& bk, cons
     set_lds_limit(kern, Mfma16Cfg::LDS_BYTES);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Mfma16Cfg::LDS_BYTES, plan->stream, u, Au, plan->d_metric,
                        plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_B, bk.d_G,
-                       aff ? plan->d_metric_affine + (size_t)6 * bk.elem_offset : (const double*)nullptr, bk.d_w);
+                       aff ? plan->d_metric_affine + (size_t)6 * bk.elem_offset : (const double*)nullptr, bk.d_w, plan->stream_mode);
   };
   if (aff) go(stiffness_mfma16_kernel<16, true>);
   else if (bk.N == 16) go(stiffness_mfma16_kernel<16>);
@@ -1488,10 +1498,14 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
                                plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,           \
                                plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDq : bk.d_EGb), bk.d_EBf, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDqT : bk.d_EGf), 0, D4EST_AFF_ARGS); \
           } else {                                                                                              \
-          set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven>, W::LDS_BYTES);                            \
-          hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
+          auto go_mw = [&](auto kern) {   /* NT twin: stream mode (plan->stream_mode, d4est_hip_wave.h) */ \
+            set_lds_limit(kern, W::LDS_BYTES); \
+            hipLaunchKernelGGL(kern, dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
                              plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,             \
-                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDq : bk.d_EGb), bk.d_EBf, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDqT : bk.d_EGf), (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER] < 0 ? 0 : plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER])); \
+                             plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDq : bk.d_EGb), bk.d_EBf, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDqT : bk.d_EGf), (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER] < 0 ? 0 : plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER]), (const double*)nullptr, (const double*)nullptr); \
+          }; \
+          if (plan->stream_mode) go_mw(stiffness_wave_kernel<N_, NQ_, false, kEven, false, true>); \
+          else go_mw(stiffness_wave_kernel<N_, NQ_, false, kEven>); \
           }                                                                                                     \
         } else {                                                                                                \
           set_lds_limit(stiffness_wave_kernel<N_, NQ_, false>, W::LDS_BYTES);                                   \
@@ -1512,7 +1526,8 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
           hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, plan->stream, u, Au, plan->d_metric, \
                              plan->d_ns_list + bk.elem_offset, plan->d_qs_list + bk.elem_offset, bk.n_elem, o0, o1, o2, o3); \
         };                                                                                                      \
-        if (pf && use_eo) go(stiffness_kernel<N_, NQ_, kCanPF, kEven>);                                         \
+        if (pf && use_eo && plan->stream_mode) go(stiffness_kernel<N_, NQ_, kCanPF, kEven, true>);              \
+        else if (pf && use_eo) go(stiffness_kernel<N_, NQ_, kCanPF, kEven>);                                    \
         else if (pf) go(stiffness_kernel<N_, NQ_, kCanPF, false>);                                              \
         else if (use_eo) go(stiffness_kernel<N_, NQ_, false, kEven>);                                           \
         else go(stiffness_kernel<N_, NQ_, false, false>);                                                       \
@@ -1536,10 +1551,14 @@ void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
                            plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,               \
                            plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDq : bk.d_EGb), bk.d_EBf, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDqT : bk.d_EGf), 0, D4EST_AFF_ARGS); \
       } else {                                                                                                  \
-      set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, kEven>, W::LDS_BYTES);                                \
-      hipLaunchKernelGGL((stiffness_wave_kernel<N_, NQ_, false, kEven>), dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
+      auto go_mw = [&](auto kern) {   /* NT twin: stream mode (plan->stream_mode, d4est_hip_wave.h) */ \
+        set_lds_limit(kern, W::LDS_BYTES); \
+        hipLaunchKernelGGL(kern, dim3(bk.n_elem), dim3(W::THREADS), W::LDS_BYTES, \
                          plan->stream, u, Au, plan->d_metric, plan->d_ns_list + bk.elem_offset,                 \
-                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDq : bk.d_EGb), bk.d_EBf, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDqT : bk.d_EGf), (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER] < 0 ? 0 : plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER])); \
+                         plan->d_qs_list + bk.elem_offset, bk.n_elem, bk.d_EBb, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDq : bk.d_EGb), bk.d_EBf, (kMwCollocated<N_, NQ_, false, true> ? bk.d_EDqT : bk.d_EGf), (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER] < 0 ? 0 : plan->tuning[D4EST_HIP_TUNE_STIFFNESS_STAGGER]), (const double*)nullptr, (const double*)nullptr); \
+      }; \
+      if (plan->stream_mode) go_mw(stiffness_wave_kernel<N_, NQ_, false, kEven, false, true>); \
+      else go_mw(stiffness_wave_kernel<N_, NQ_, false, kEven>); \
       }                                                                                                         \
     } else {                                                                                                    \
       set_lds_limit(stiffness_wave_kernel<N_, NQ_, false, false>, W::LDS_BYTES);                                \

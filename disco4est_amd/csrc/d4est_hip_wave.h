@@ -286,6 +286,39 @@ __device__ __forceinline__ void contract_rows_eo_imm(const double* __restrict__ 
 
 // LDS read that the backend must not pair into ds_read2_b64: on gfx950 a ds_read2_b64 takes 8 LDS cycles (banks mod 32), two
 // ds_read_b64 take 2 + 2 (MI355X_MICROARCH.md, LDS table); volatile accesses are never combined
+// Stream mode (plan->stream_mode, d4est_hip_internal.h): on plans whose working set does not fit the 256 MB Infinity Cache the data an
+// apply touches exactly once -- the metric and the mortar factors on the way in, A u on the way out -- moves with the non-temporal hint
+// (global_load / global_store ... nt), so that it neither displaces u from the XCD's L2 (the neighbours' lines of the whole-operator
+// kernels come from there) nor allocates cache lines it will not use: level 5, p = 7 stiffness 191 -> 156 us, config 3's full operator
+// +3 %.  On plans that do fit (config 2: 134 MB) the same hint costs 2 ... 19 %, because repeated applies are served from that cache:
+// hence two instantiations (template parameter NT, ld_sel / store_element_image) chosen at launch.  A run-time branch around each
+// batch of loads (with_ld: kept for the matrix-core kernel, whose loads sit outside its pipelined loops) cost the multi-wave kernels
+// 4 % with the switch off -- the branches cut their software-pipelined quadrature loops into basic blocks.
+struct LdPlain {
+  __device__ __forceinline__ double operator()(const double* p) const { return *p; }
+};
+struct LdStream {
+  __device__ __forceinline__ double operator()(const double* p) const { return __builtin_nontemporal_load(p); }
+};
+// (the two empty asm statements keep the optimiser from merging the branches back into one batch of plain loads: it treats loads that
+// differ only in the hint as identical and hoists / sinks them out of the if, dropping the hint)
+#define D4EST_HIP_STREAM_FENCE() asm volatile("; stream mode" ::: "memory")
+template <class F>
+__device__ __forceinline__ void with_ld(bool nt, F&& f) {
+  if (nt) {
+    D4EST_HIP_STREAM_FENCE();
+    f(LdStream{});
+    D4EST_HIP_STREAM_FENCE();
+  } else {
+    f(LdPlain{});
+  }
+}
+template <bool NT>
+__device__ __forceinline__ double ld_sel(const double* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
 __device__ __forceinline__ double lds_ld(const double* p) {
   typedef const volatile double __attribute__((address_space(3))) * lds_cvptr;
   return *(lds_cvptr)p;
@@ -317,20 +350,24 @@ __device__ __forceinline__ void load_element_image(double* R, const double* __re
     if (N3 % PL == 0 || idx < N3) R[i + PN * (j + N * k)] = v[q];
   }
 }
-template <int N, int PL, int PN>
+template <int N, int PL, int PN, bool NT = false>
 __device__ __forceinline__ void store_element_image(double* __restrict__ dst, const double* R, int te) {
   constexpr int N3 = N * N * N, NL = (N3 + PL - 1) / PL;
+  auto put = [](double* p_, double v_) {   // NT: stream mode, see above
+    if constexpr (NT) __builtin_nontemporal_store(v_, p_);
+    else *p_ = v_;
+  };
   if constexpr (PL == N * N) {
     const int ij = (te % N) + PN * (te / N);
 #pragma unroll
-    for (int q = 0; q < NL; ++q) dst[te + PL * q] = R[ij + PN * N * q];
+    for (int q = 0; q < NL; ++q) put(&dst[te + PL * q], R[ij + PN * N * q]);
     return;
   }
 #pragma unroll
   for (int q = 0; q < NL; ++q) {
     const int idx = te + PL * q;
     const int i = idx % N, j = (idx / N) % N, k = idx / (N * N);
-    if (N3 % PL == 0 || idx < N3) dst[idx] = R[i + PN * (j + N * k)];
+    if (N3 % PL == 0 || idx < N3) put(&dst[idx], R[i + PN * (j + N * k)]);
   }
 }
 
@@ -457,7 +494,7 @@ struct WaveCfg {
 // src/Quadrature/d4est_quadrature.c:593-774, with the coefficient c = f(x, u0) handed over at the quadrature nodes) -- V u = B_t B_s B_r u
 // costs one more t-contraction of the line B_s B_r u the gradient already forms, the weighted value one more transposed t-contraction
 // summed into the G_t^T term; cq = w J c at the quadrature nodes (pre-combined when the coefficient is set: one stream of 8 B per node).
-template <int N, int NQ, bool AFF, bool WG_SYNC, bool MASS = false>
+template <int N, int NQ, bool AFF, bool WG_SYNC, bool MASS = false, bool NT = false>
 __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1, const double* __restrict__ metric, int qs, int ei,
                                                           bool active, int a, int b, const double* __restrict__ EBf,
                                                           const double* __restrict__ EGf, const double* __restrict__ EBb,
@@ -564,7 +601,7 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
 #pragma unroll
         for (int kq = 0; kq < ME; ++kq)
 #pragma unroll
-          for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
+          for (int c = 0; c < 6; ++c) mw[kq][c] = ld_sel<NT>(&m[c * NQ3 + NQ * NQ * kq]);
         __builtin_amdgcn_sched_barrier(0);
       }
       eo_pre<N>(y3, y3e, y3o);
@@ -600,13 +637,13 @@ __device__ __forceinline__ void stiffness_wave_eo_element(double* R0, double* R1
 #pragma unroll
       for (int kq = ME; kq < MD; ++kq)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) mw[kq][c] = m[c * NQ3 + NQ * NQ * kq];
+        for (int c = 0; c < 6; ++c) mw[kq][c] = ld_sel<NT>(&m[c * NQ3 + NQ * NQ * kq]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kq = 0; kq < NQ; ++kq) {
         if (kq + MD < NQ) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) mw[kq + MD][c] = m[c * NQ3 + NQ * NQ * (kq + MD)];
+          for (int c = 0; c < 6; ++c) mw[kq + MD][c] = ld_sel<NT>(&m[c * NQ3 + NQ * NQ * (kq + MD)]);
         }
         __builtin_amdgcn_sched_barrier(0);
         const double r = gr[kq], s = gs[kq], t = gt[kq];

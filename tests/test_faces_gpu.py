@@ -400,3 +400,34 @@ def test_face_paths_agree_randomized(gpu, hiplib):
             assert _rel(res[k][0], ref[0]) <= 1e-13, (case, n, nq, qt, fcn, k)
             assert _rel(res[k][1], ref[1]) <= 1e-12 and _rel(res[k][2], ref[2]) <= 1e-11, (case, n, nq, k)
         plan.destroy()
+
+
+@pytest.mark.parametrize("deg", [8, 11, 15])
+def test_stream_mode_whole_operator(gpu, hiplib, oracle, deg):
+    """operator_mw_kernel's stream-mode instantiation (tuning key 12 = 1: non-temporal metric / factor loads and A u stores; the
+    automatic choice takes it from 320 MB per apply): same bits as the plain one, the oracle's numbers, also as a Chebyshev loop."""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    m = M.BrickMesh(1, deg)
+    mp = M.SineMap(0.05)
+    J, rst = m.geometry(mp); sides = m.build_sides(mp); u = m.field(mp)
+    ref = oracle.apply_aij(m, J, rst, sides, u, nthreads=8)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, m.quad_type)
+    plan.set_geometry(J, rst); plan.set_faces(sides, 10.0, 0)
+    assert plan.face_path() == "direct+volume"
+    du = torch.from_numpy(u).to(gpu)
+    outs, its = [], []
+    rhs = torch.from_numpy(M.splitmix64_uniform(7, m.local_nodes) - 0.5).to(gpu)
+    for key in (0, 1):
+        plan.set_tuning(12, key)
+        out = torch.full_like(du, float("nan"))
+        plan.apply_aij(du, out)
+        outs.append(out)
+        uc = du.clone(); r = torch.empty_like(du); Auc = torch.empty_like(du)
+        plan.cheby_iterate(uc, rhs, Auc, r, 3, 1.0, 40.0, 0)
+        its.append((uc, r, Auc))
+    assert torch.equal(outs[0], outs[1])
+    assert all(torch.equal(x, y) for x, y in zip(its[0], its[1]))
+    got = outs[1].cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    plan.destroy()

@@ -492,3 +492,31 @@ def test_stiffness_multi_bucket_launch(gpu, hiplib, oracle, curved):
         assert "general" in plan.last_kernel()
         assert _rel(dAu2.cpu().numpy(), ref) <= RTOL
     plan.destroy()
+
+
+@pytest.mark.parametrize("level,deg,tune", [(1, 5, ((1, 0), (0, 1))), (1, 7, ((1, 0), (0, 1))), (1, 8, ()), (1, 11, ()), (1, 13, ()), (0, 15, ()),
+                                            (0, 17, ())])
+def test_stream_mode_same_numbers(gpu, hiplib, oracle, level, deg, tune):
+    """Tuning key 12 (non-temporal metric loads and A u stores on plans that do not fit the Infinity Cache; automatic by size) only changes
+    cache hints: the NT instantiations of the volume kernels (the prefetching kernel of the large deg_quad <= 7 buckets, the multi-wave
+    kernels, the matrix-core kernel) give the same bits as the plain ones, and the oracle's numbers."""
+    import torch
+    from disco4est_amd import mesh as M
+    m = M.BrickMesh(level, deg)
+    mp = M.SineMap(0.06)
+    J, rst = m.geometry(mp)
+    u = m.field(mp)
+    ref = oracle.apply_stiffness(m, J, rst, u, nthreads=8)
+    plan = _plan(m, J, rst)
+    for k, v in tune:
+        plan.set_tuning(k, v)
+    du = _t(u, gpu)
+    outs = []
+    for key in (0, 1):
+        plan.set_tuning(12, key)
+        out = torch.full_like(du, float("nan"))
+        plan.apply_stiffness_matrix(du, out)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert _rel(outs[1].cpu().numpy(), ref) <= RTOL
+    plan.destroy()
