@@ -82,12 +82,22 @@ def cpu_baseline(mesh, J, rst, u, budget_s=12.0):
     }
 
 
-def time_region(fn, reps, stream, torch, warm=10):
-    """average milliseconds per call, HIP events on the launch stream.  warm: untimed calls first -- the chip's clocks take some tens
-    of back-to-back launches to settle (p = 15, 8192 elements: 588 us on the first call after an idle gap, 470 us from the 35th on)"""
+def time_region(fn, reps, stream, torch, warm=10, settle_s=0.06):
+    """average milliseconds per call, HIP events on the launch stream.  warm: untimed calls first; then more untimed batches until
+    settle_s seconds of back-to-back work have passed -- the chip's clocks take tens of milliseconds of sustained load to settle
+    (p = 15, 8192 elements: 588 us on the first call after an idle gap, 470 us from the 35th on; level 4, p = 11 apply_aij: 212 us in the
+    first 35 calls, 190 us afterwards), and a secondary should report the steady state a smoother loop runs in"""
+    import time
+    t0 = time.perf_counter()
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    for _ in range(50):
+        if time.perf_counter() - t0 >= settle_s:
+            break
+        for _ in range(max(reps, 1)):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(reps):
@@ -587,7 +597,7 @@ def main():
                 y2 = torch.empty_like(x2)
                 ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 40, stream, torch, warm=20)
                 sec["stiffness_p%d" % deg] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes,
-                                              "kernel": p2.last_kernel()}
+                                              "kernel": p2.last_kernel(), "stream_mode": p2.stream_mode()}
                 if deg == 15:   # config 5's degree on the affine path (labelled separately: the brick's metric from 6 numbers per element)
                     p2.set_tuning(7, -1)
                     ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 40, stream, torch, warm=20)
@@ -603,8 +613,9 @@ def main():
                 m2, p2, x2, y2 = brick_plan(level, deg, stream, torch, dev, count=count)
                 ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 10 if count is None else 30, stream, torch, warm=10 if count is None else 30)
                 bytes_ = algorithmic_bytes_per_dof(deg + 1, deg + 1) * m2.local_nodes
+                # stream_mode 1: the plan does not fit the Infinity Cache, so metric loads and A u stores carry the non-temporal hint (tuning key 12)
                 sec[name] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes, "kernel": p2.last_kernel(),
-                             "roofline_frac_hbm": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             "roofline_frac_hbm": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "stream_mode": p2.stream_mode()}
                 if deg == 11:
                     # the same config on the AFFINE path (labelled separately, SURVEY.md section 8d: the brick's metric is constant per
                     # element and is rebuilt from 6 numbers instead of being streamed: 16 B/DoF, arithmetic-bound)
@@ -626,7 +637,7 @@ def main():
                 sec[name] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes, "elements": m2.n_elements,
                              "algorithmic_bytes_per_dof": bpd_aij,
                              "roofline_frac_hbm": bpd_aij * m2.local_nodes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "face_path": p2.face_path(), "kernel": p2.last_kernel(), "parity_gate_rel_inf": g}
+                             "face_path": p2.face_path(), "kernel": p2.last_kernel(), "parity_gate_rel_inf": g, "stream_mode": p2.stream_mode()}
                 try:
                     sec[name]["traffic"] = (json.load(open(tf)) if os.path.exists(tf) else {}).get(name, {}).get("hbm_bytes_per_launch")
                 except Exception:

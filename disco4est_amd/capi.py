@@ -34,6 +34,7 @@ SIGNATURES = {
     "d4est_hip_plan_face_path": (ctypes.c_char_p, [_vp]),
     "d4est_hip_plan_local_nodes": (ctypes.c_int, [_vp]),
     "d4est_hip_plan_local_nodes_quad": (ctypes.c_int, [_vp]),
+    "d4est_hip_plan_stream_mode": (ctypes.c_int, [_vp]),
     "d4est_hip_plan_n_elements": (ctypes.c_int, [_vp]),
     "d4est_hip_plan_set_geometry": (None, [_vp, _vp, _vp, ctypes.c_int]),
     "d4est_hip_apply_stiffness_matrix": (None, [_vp, _vp, _vp]),
@@ -226,6 +227,10 @@ class Plan:
     def face_path(self):
         """'direct' or 'two-phase': which face kernels the full operator runs on this plan."""
         return self.lib.d4est_hip_plan_face_path(self.handle).decode()
+
+    def stream_mode(self):
+        """1 when the large-plan kernels move once-touched data with the non-temporal hint (tuning key 12; automatic from 320 MB per apply)."""
+        return self.lib.d4est_hip_plan_stream_mode(self.handle)
 
     def set_tuning(self, key, value):
         self.lib.d4est_hip_plan_set_tuning(self.handle, int(key), int(value))

@@ -269,6 +269,7 @@ const char* d4est_hip_plan_face_path(const d4est_hip_plan_t* plan) {
 }
 int d4est_hip_plan_local_nodes(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes"); return plan->local_nodes; }
 int d4est_hip_plan_local_nodes_quad(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes_quad"); return plan->local_nodes_quad; }
+int d4est_hip_plan_stream_mode(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_stream_mode"); return plan->stream_mode; }
 int d4est_hip_plan_n_elements(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_n_elements"); return plan->n_elements; }
 
 void d4est_hip_plan_set_geometry(d4est_hip_plan_t* plan, const double* J_quad, const double* rst_xyz_quad, int on_device) {

@@ -100,6 +100,8 @@ const char* d4est_hip_plan_last_kernel(const d4est_hip_plan_t* plan);
 const char* d4est_hip_plan_face_path(const d4est_hip_plan_t* plan);
 int d4est_hip_plan_local_nodes(const d4est_hip_plan_t* plan);
 int d4est_hip_plan_local_nodes_quad(const d4est_hip_plan_t* plan);
+/* 1 when the plan runs in stream mode (tuning key D4EST_HIP_TUNE_STREAM: forced, or chosen from the plan's size), else 0 */
+int d4est_hip_plan_stream_mode(const d4est_hip_plan_t* plan);
 int d4est_hip_plan_n_elements(const d4est_hip_plan_t* plan);
 
 /* Geometric factors in the reference's SoA layout (src/Mesh/d4est_mesh.h:123-169,
