@@ -47,7 +47,8 @@ static void drop_graph(d4est_hip_plan_t* plan) {
 static void update_stream_mode(d4est_hip_plan* plan) {
   const int t = plan->tuning[D4EST_HIP_TUNE_STREAM];
   const double bytes = 48.0 * (double)plan->local_nodes_quad + 16.0 * (double)plan->local_nodes;
-  plan->stream_mode = t < 0 ? (bytes > 320.0e6 ? 1 : 0) : (t != 0 ? 1 : 0);
+  // (elements that alias each other's quadrature block re-read the metric: not a stream)
+  plan->stream_mode = t < 0 ? ((bytes > 320.0e6 && !plan->quad_aliased) ? 1 : 0) : (t != 0 ? 1 : 0);
 }
 
 extern "C" {
@@ -117,7 +118,7 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
 
   // bucket by (deg, deg_quad); keep element order inside a bucket (Morton order of the caller)
   std::map<std::pair<int, int>, std::vector<int>> groups;
-  long long ln = 0, lq = 0;
+  long long ln = 0, lq = 0, sum_q3 = 0;
   for (int e = 0; e < n_elements; ++e) {
     const int p = deg[e], pq = deg_quad[e];
     if (p < 1 || p > Tables1D::kMaxDeg || pq < 1 || pq > Tables1D::kMaxDeg)
@@ -126,10 +127,12 @@ d4est_hip_plan_t* d4est_hip_plan_create(int n_elements, const int* deg, const in
     const long long n3 = (long long)(p + 1) * (p + 1) * (p + 1), q3 = (long long)(pq + 1) * (pq + 1) * (pq + 1);
     ln = std::max(ln, nodal_stride[e] + n3);
     lq = std::max(lq, quad_stride[e] + q3);
+    sum_q3 += q3;
   }
   if (ln > 0x7fffffffLL || lq > 0x7fffffffLL) D4EST_HIP_ABORT("plan_create: local_nodes exceeds 32-bit int (reference strides are int)");
   plan->local_nodes = (int)ln;
   plan->local_nodes_quad = (int)lq;
+  plan->quad_aliased = sum_q3 > lq;   // elements share quadrature blocks (the copies of a Schwarz subdomain plan)
   update_stream_mode(plan);
 
   std::vector<int> ids;

@@ -132,6 +132,7 @@ struct d4est_hip_plan {
   // bumped by every call that can change what the operator computes (geometry, faces, SIPG parameters, boundary data, the zeroth-order
   // coefficient, tuning): objects that cache something derived from the operator (the Schwarz smoother's condensed blocks) compare it
   unsigned long long op_generation = 0;
+  bool quad_aliased = false;      // some elements share a quadrature block (quad_stride repeats)
   int stream_mode = 0;            // 1: non-temporal metric / factor loads and A u stores (capi: update_stream_mode; kernels: with_ld)
   bool bc_inhomogeneous = false;   // non-zero Dirichlet data or Robin data is set (an affine, not linear, operator)
 

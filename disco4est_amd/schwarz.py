@@ -313,6 +313,7 @@ class Schwarz:
         self.plan = capi.Plan(vdeg, vdegq, vstride.astype(np.int32), mesh.quad_stride[e], quad_type=mesh.quad_type, stream=stream)
         self.plan.set_geometry(J_quad, rst_xyz_quad)                      # the mesh's own arrays: quad_stride aliases them
         self.plan.set_tuning(8, 1)                                        # all outside faces read ONE zero trace block
+        self.plan.set_tuning(12, 0)                                       # no stream mode: the copies of an element share its metric, which is therefore re-read
         self._sub_sides = subdomain_sides(mesh, sides, md)
         self.plan.set_faces(self._sub_sides, penalty_prefactor, penalty_fcn)
         self.plan.set_dirichlet_values(None)                              # the correction has homogeneous boundary data
