@@ -82,6 +82,12 @@ def cpu_baseline(mesh, J, rst, u, budget_s=12.0):
     }
 
 
+# bytes per DoF one iteration of the 5-iteration fused Chebyshev loop moves on top of full_operator_bytes_per_dof: + rhs 8 + p read 8 and
+# written 8 + the new iterate 8, - 8 for A u, which is stored in the last iteration only, + (last iteration: A u 8 + r 8; the copy back
+# of the iterate after an odd count 16; the memset of p 8) / 5 = 8  (d4est_hip_solver.hip: cheby_iterate_body)
+CHEBY_VECTOR_BYTES_PER_DOF = 32.0
+
+
 def time_region(fn, reps, stream, torch, warm=10, settle_s=0.06):
     """average milliseconds per call, HIP events on the launch stream.  warm: untimed calls first; then more untimed batches until
     settle_s seconds of back-to-back work have passed -- the chip's clocks take tens of milliseconds of sustained load to settle
@@ -537,7 +543,9 @@ def main():
                                       ("cheby_5_iterations", lambda: plan.cheby_iterate(du, rhs, dAu, r, 5, lmin, lmax, 0), 5)):
                 ms = time_region(fn, 50, stream, torch, warm=10)
                 sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9}
-                bpd_aij = full_operator_bytes_per_dof(N, NQ)
+                # a Chebyshev iteration moves the operator's bytes (A u itself is not stored) plus the smoother's own vectors: rhs read,
+                # p read and written, the new iterate written (u is the operator's input; r is written in the last iteration only)
+                bpd_aij = full_operator_bytes_per_dof(N, NQ) + (CHEBY_VECTOR_BYTES_PER_DOF if applies > 1 else 0.0)
                 sec[name]["algorithmic_bytes_per_dof"] = bpd_aij
                 sec[name]["roofline_frac_hbm"] = bpd_aij * dofs_per_rank * applies / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 sec[name]["face_path"] = plan.face_path()   # "direct+volume": the whole operator in one kernel (u in, A u out)
@@ -647,9 +655,10 @@ def main():
                     l0, l1 = eig_window(p2, x2, torch)
                     gc = None if args.no_check else gate_cheby("cheby_5_iterations_p11_level4", p2, x2, rhs2, torch, 5, l0, l1)
                     ms = time_region(lambda: p2.cheby_iterate(x2, rhs2, y2, r2, 5, l0, l1, 0), 10, stream, torch, warm=5)
+                    bpd_ch = bpd_aij + CHEBY_VECTOR_BYTES_PER_DOF
                     sec["cheby_5_iterations_p11_level4"] = {"ms": ms, "GDoF_per_s": 5 * m2.local_nodes / (ms * 1e-3) / 1e9,
-                                                            "algorithmic_bytes_per_dof": bpd_aij, "parity_gate_rel_inf": gc,
-                                                            "roofline_frac_hbm": 5 * bpd_aij * m2.local_nodes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                                            "algorithmic_bytes_per_dof": bpd_ch, "parity_gate_rel_inf": gc,
+                                                            "roofline_frac_hbm": 5 * bpd_ch * m2.local_nodes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
                     del rhs2, r2
                 p2.destroy()
                 del x2, y2
