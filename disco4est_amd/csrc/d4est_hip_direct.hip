@@ -103,7 +103,7 @@ constexpr int kDirectWPB = 4;
 #define D4EST_HIP_DIRECT_GEOM_EARLY 1   /* both faces' geometric factors requested: 0 at their use, 1 before the SIPG loop, 2 with the neighbour lines */
 #endif
 // the seven geometric-factor fields of a side at mortar node k (sj n_l / 2-weighted rows 0..5, penalty row 6), or the Robin coefficient
-template <int T>
+template <int T, bool NT = false /* stream mode, d4est_hip_wave.h */>
 __device__ __forceinline__ void direct_load_geom(double* gq, int kind, bool on, int k, int sgeom, const double* __restrict__ geom,
                                                  const double* __restrict__ robin_c) {
 #pragma unroll
@@ -114,12 +114,12 @@ __device__ __forceinline__ void direct_load_geom(double* gq, int kind, bool on, 
     } else {
       const double* __restrict__ g = geom + (size_t)7 * sgeom + k;
 #pragma unroll
-      for (int c = 0; c < 7; ++c) gq[c] = g[c * T];
+      for (int c = 0; c < 7; ++c) gq[c] = ld_sel<NT>(&g[c * T]);
     }
   }
 }
 
-template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 streamed metric, 2 affine metric; + 4: and the zeroth-order term */>
+template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 streamed metric, 2 affine metric; + 4: and the zeroth-order term; + 8: stream mode (non-temporal metric / factor loads and A u stores) */>
 __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
                                                              double* __restrict__ Au, const DirectSide* __restrict__ sides,
                                                              const DirectGhostOff* __restrict__ ghost_off,
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 2
     double gqa[2][7];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) direct_load_geom<T>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], direct_kargs()->geom, direct_kargs()->robin_c);
+    for (int h = 0; h < 2; ++h) direct_load_geom<T, (VOL & 8) != 0>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], direct_kargs()->geom, direct_kargs()->robin_c);
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 1
     double gqa[2][7];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) direct_load_geom<T>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], geom, robin_c);
+    for (int h = 0; h < 2; ++h) direct_load_geom<T, (VOL & 8) != 0>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], geom, robin_c);
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
           qp[0] = K->bndry_q[sgeom[h] + k];
         }
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 0
-        direct_load_geom<T>(gq, kind, true, k, sgeom[h], geom, robin_c);
+        direct_load_geom<T, (VOL & 8) != 0>(gq, kind, true, k, sgeom[h], geom, robin_c);
 #endif
       }
 #if D4EST_HIP_DIRECT_GEOM_EARLY != 0
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
     {
       const DirectVol vl = direct_load_vol(direct_kargs());
       const int qs = __builtin_amdgcn_readfirstlane(vl.qs_stride >= 0 ? vl.qs0 + e * vl.qs_stride : vl.qs_list[e]);
-      stiffness_wave_eo_element<N, NQ, (VOL & 3) == 2, false, (VOL & 4) != 0>(s_U, s_S, vl.metric, qs, e, on_q, a, b, vl.EBf, vl.EGf, vl.EBb,
+      stiffness_wave_eo_element<N, NQ, (VOL & 3) == 2, false, (VOL & 4) != 0, (VOL & 8) != 0>(s_U, s_S, vl.metric, qs, e, on_q, a, b, vl.EBf, vl.EGf, vl.EBb,
                                                                               vl.EGb, vl.affine, vl.wq, vl.cq);
     }
     if (on_m) {
@@ -468,7 +468,8 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
       for (int i = 0; i < N; ++i) {
         const size_t o = (size_t)ns + a + N * b + N2 * i;
         const double au = s_U[a + PN * (b + N * i)] + facc[i];
-        if (!FUSE || !cfl.skip_Au_store) Au_[o] = au;
+        if constexpr (!FUSE && (VOL & 8) != 0) __builtin_nontemporal_store(au, &Au_[o]);   // stream mode
+        else if (!FUSE || !cfl.skip_Au_store) Au_[o] = au;
         if constexpr (FUSE) {   // the Chebyshev update of the node, as in the faces-only form
           const double res = __dadd_rn(cfl.rhs[o], __dmul_rn(-1.0, au));
           const double ri = __dmul_rn(cfl.alpha, res);
@@ -681,8 +682,9 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
       vol.cq = ensure_lhs_wjc(plan);
       vmode |= 4;
     }
-    if (dh->mw) std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::operator_mw_kernel<%d,vol%s> (stiffness_wave_kernel body + faces)", dh->N, aff ? ",affine" : "");
-    else std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::faces_direct_kernel<%d,%d,vol%s> (faces + stiffness_wave_eo body)", dh->N, dh->NQ, aff ? ",affine" : "");
+    const char* sm = (!aff && vol_term != 2 && vol.stream) ? ",stream" : "";
+    if (dh->mw) std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::operator_mw_kernel<%d,vol%s%s> (stiffness_wave_kernel body + faces)", dh->N, aff ? ",affine" : "", sm);
+    else std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::faces_direct_kernel<%d,%d,vol%s%s> (faces + stiffness_wave_eo body)", dh->N, dh->NQ, aff ? ",affine" : "", sm);
   }
   if (dh->mw) {
     launch_direct_mw(plan, dh, u, ghost_trace, Au, cf, robin_c, robin_r, vmode, vol, n, chunk);
@@ -690,6 +692,7 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
   }
   const DirectFuse cfv = cf ? *cf : DirectFuse{};
   bool done = false;
+  if (vmode == 1 && vol.stream) vmode = 9;   // stream mode (plan->stream_mode): the twin with non-temporal metric / factor loads and A u stores
 #define D4EST_HIP_DIRECT_GO(N_, NQ_, FUSE_, VOL_)                                                                             \
   hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, true, FUSE_, VOL_>), dim3(n_wg), dim3(64 * kDirectWPB), 0,     \
                      plan->stream, u, ghost_trace, Au, dh->d_sides, dh->d_ghost_off, dh->d_ops, plan->d_face_geom, plan->d_bndry,            \
@@ -698,6 +701,7 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
   if (!done && dh->N == N_ && dh->NQ == NQ_) {                                     \
     if constexpr (N_ == NQ_) {                                                     \
       if (vmode == 1) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 1); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 1); done = true; } \
+      if (vmode == 9) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 9); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 9); done = true; } \
       if (vmode == 2) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 2); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 2); done = true; } \
       if (vmode == 5) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 5); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 5); done = true; } \
       if (vmode == 6) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 6); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 6); done = true; } \

@@ -402,10 +402,11 @@ def test_face_paths_agree_randomized(gpu, hiplib):
         plan.destroy()
 
 
-@pytest.mark.parametrize("deg", [8, 11, 15])
+@pytest.mark.parametrize("deg", [5, 7, 8, 11, 15])
 def test_stream_mode_whole_operator(gpu, hiplib, oracle, deg):
-    """operator_mw_kernel's stream-mode instantiation (tuning key 12 = 1: non-temporal metric / factor loads and A u stores; the
-    automatic choice takes it from 320 MB per apply): same bits as the plain one, the oracle's numbers, also as a Chebyshev loop."""
+    """The stream-mode instantiations of the whole-operator kernels (faces_direct_kernel / operator_mw_kernel with VOL | 8; tuning key
+    12 = 1: non-temporal metric / factor loads and A u stores; the automatic choice takes them from 320 MB per apply): same bits as
+    the plain ones, the oracle's numbers, also as a Chebyshev loop."""
     import torch
     from disco4est_amd import Plan, mesh as M
     m = M.BrickMesh(1, deg)
@@ -413,7 +414,10 @@ def test_stream_mode_whole_operator(gpu, hiplib, oracle, deg):
     J, rst = m.geometry(mp); sides = m.build_sides(mp); u = m.field(mp)
     ref = oracle.apply_aij(m, J, rst, sides, u, nthreads=8)
     plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, m.quad_type)
-    plan.set_geometry(J, rst); plan.set_faces(sides, 10.0, 0)
+    plan.set_geometry(J, rst)
+    plan.set_tuning(7, 0)    # (the streamed-metric form: a brick would otherwise take the affine one, which has no metric stream)
+    plan.set_tuning(11, 2)   # the whole-operator kernel whatever the size
+    plan.set_faces(sides, 10.0, 0)
     assert plan.face_path() == "direct+volume"
     du = torch.from_numpy(u).to(gpu)
     outs, its = [], []
