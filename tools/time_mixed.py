@@ -12,6 +12,7 @@ J, rst = m.geometry(None); sides = m.build_sides(None); u = m.field()
 dev = torch.device("cuda:0")
 plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=torch.cuda.current_stream())
 plan.set_geometry(J, rst); plan.set_tuning(7, 0); plan.set_faces(sides)
+if os.environ.get('D4EST_FORK'): plan.set_tuning(5, int(os.environ['D4EST_FORK']))
 du = torch.from_numpy(u).to(dev); Au = torch.empty_like(du)
 tr = torch.empty(plan.trace_size, dtype=torch.float64, device=dev)
 def t(fn, reps=30):
