@@ -592,7 +592,7 @@ def main():
                                           ("cheby_5_iterations_affine_path", lambda: plan.cheby_iterate(du, rhs, dAu, r, 5, lmin, lmax, 0), 5)):
                     ms = time_region(fn, 50, stream, torch, warm=10)
                     sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9, "face_path": plan.face_path(),
-                                 "algorithmic_bytes_per_dof": 16.0 + 6.0 * 7.0 * 8.0 * NQ * NQ / N ** 3}
+                                 "algorithmic_bytes_per_dof": 16.0 + 6.0 * 7.0 * 8.0 * NQ * NQ / N ** 3 + (CHEBY_VECTOR_BYTES_PER_DOF if applies > 1 else 0.0)}
                 plan.set_tuning(7, 0)
             # stiffness apply at the other degrees SURVEY.md section 8d names (same general path, ~2-8 MDoF each)
             for deg, level, count in ((3, 5, None), (11, 4, None), (15, 4, 2048)):
