@@ -706,6 +706,39 @@ def main():
                                                "face_path": p4.face_path()}
                 p4.destroy()
                 del x4, y4
+            # a locally refined (hanging-face) brick, the mesh class of BASELINE config 4: level 4 with every 64th octant refined
+            # (4544 elements, 336 hanging faces, 19 % of the elements touch one), p = 7, general path.  Plans with hanging faces run
+            # traces + volume + flux; with every degree <= 7 the conforming sides go through the fast conforming face kernels and only
+            # the hanging sides through the mortar-record kernels (tuning key 13).  Gate: that split against the all-records path
+            # (both are held to the oracle by tests/test_faces_gpu.py::test_hp_split_parity / test_apply_aij_hanging_parity)
+            if args.geometry != "sine":
+                refine = np.zeros(8 ** 4, dtype=bool)
+                refine[::64] = True
+                m5 = M.HangingBrickMesh(4, refine, 7)
+                J5, rst5 = m5.geometry(None)
+                s5 = m5.build_sides(None)
+                x5 = torch.from_numpy(m5.field()).to(dev)
+                res5 = {}
+                for key in (0, -1):
+                    p5 = Plan(m5.deg, m5.deg_quad, m5.nodal_stride, m5.quad_stride, 0, stream=stream)
+                    p5.set_geometry(J5, rst5)
+                    p5.set_tuning(7, 0)
+                    p5.set_tuning(13, key)
+                    p5.set_faces(s5)
+                    y5 = torch.empty_like(x5)
+                    ms5 = time_region(lambda: p5.apply_aij(x5, y5), 50, stream, torch, warm=10)
+                    res5[key] = (ms5, y5.clone())
+                    p5.destroy()
+                g5 = float((res5[-1][1] - res5[0][1]).abs().max() / res5[0][1].abs().max())
+                print("parity gate hanging_level4_p7: split face kernels against the mortar-record kernels: rel-inf = %.3e" % g5, file=sys.stderr)
+                if not args.no_check and not g5 <= 1e-12:
+                    raise RuntimeError("hanging_level4_p7: the split face path deviates from the record kernels by %.3e" % g5)
+                sec["hanging_level4_p7"] = {"dofs": m5.local_nodes, "elements": m5.n_elements,
+                                            "hanging_faces": int((np.asarray(s5["side_hang"]) == 1).sum()),
+                                            "apply_aij_ms": res5[-1][0], "apply_aij_GDoF_per_s": m5.local_nodes / (res5[-1][0] * 1e-3) / 1e9,
+                                            "apply_aij_ms_record_kernels_only": res5[0][0], "face_path": "two-phase, conforming sides / hanging sides split",
+                                            "parity_gate_rel_inf_vs_record_kernels": g5}
+                del x5, res5
             out["secondary"] = sec
         except Exception as exc:  # secondary numbers must never break the headline line
             out["secondary"] = {"error": repr(exc)}

@@ -350,7 +350,8 @@ struct HpMortar {
   int gidx;          // scalar index of the mortar's first node in the precombined geometry / boundary arrays (S + off)
   int u_shift;       // offset (doubles) from the (+) block to the block whose u field this mortar reads; 0 except on a small side whose
                      // face pair the reference re-orients non-geometrically (see faces_setup_hp)
-  double fm, fp, w2, pad2;
+  double fm, fp, w2;
+  double hang;       // side_hang of the record's side as a number (0 conforming, 1 big, 2 small): lets the tiled kernels serve the hanging sides only (hp split)
   long long qoff, nbr_qoff;
 };
 
@@ -1067,7 +1068,7 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
     const bool on_m = lo < N && hi < N, on_q = lo < NQ && hi < NQ;
     // ---- every global load of this side up front (independent requests: one memory latency)
     double qm[4] = {0, 0, 0, 0}, qp[4] = {0, 0, 0, 0}, gq[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (on_q) {
+    if (on_q && d.kind != 3) {   // kind 3: a hanging side of an hp-split plan -- its terms come from the mortar-record kernel (all-zero inputs here)
       const int k = lo + NQ * hi;
       const double* m = qtrace + d.qoff + k;
 #pragma unroll
@@ -1359,7 +1360,10 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
 __global__ __launch_bounds__(192) void trace_hp_mfma16_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
                                                               const HpMortar* __restrict__ md, const int* __restrict__ side_first,
                                                               const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
-                                                              const double* __restrict__ hp_ops, int n_elem, int max_n) {
+                                                              const double* __restrict__ hp_ops, int n_elem, int max_n,
+                                                              const int* __restrict__ elist = nullptr, int hang_only = 0) {
+  // elist / hang_only (hp split, launch_traces): the kernel walks the listed elements -- those with a hanging side -- and serves the
+  // records of their HANGING sides only; the conforming sides of the whole mesh are the fast conforming kernel's
   constexpr int LDM = 34;
   constexpr int UJ = 17, UK = 272;
   constexpr int TPB = 192;
@@ -1376,7 +1380,8 @@ __global__ __launch_bounds__(192) void trace_hp_mfma16_kernel(const double* __re
   for (int i = 0; i < 16; ++i) drow[0][i] = drow[1][i] = 0.0;
   for (int i = lane; i < 2 * 16 * LDM; i += 64) stage[i] = 0.0;
   wave_lds_fence();
-  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+  for (int ei = blockIdx.x; ei < n_elem; ei += gridDim.x) {
+    const int e = elist ? elist[ei] : ei;
     const ElemDesc el = ed[e];
     const int N = el.N, N2 = N * N, N3 = N2 * N;
     // (a rolled `for (t = tid; t < N3; t += TPB)` waits for each load in turn: N3 / TPB dependent memory round trips, 21 at p = 15)
@@ -1440,6 +1445,7 @@ __global__ __launch_bounds__(192) void trace_hp_mfma16_kernel(const double* __re
       }
       for (int r_ = side_first[sidx]; r_ < side_first[sidx + 1]; ++r_) {
         const HpMortar m = md[r_];
+        if (hang_only && m.hang == 0.0) continue;   // (wave-uniform)
         const int NQ = m.NQ, T = NQ * NQ;
         double oa[2][4], ob[2][4];   // along a: C, CD ; along b: C, CD   -- OP[row mi][col 4 ks + mk]
 #pragma unroll
@@ -1493,7 +1499,9 @@ __global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __res
                                                              const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                              const double* __restrict__ hp_ops, const double* __restrict__ geom,
                                                              const double* __restrict__ bndry_q, const double* __restrict__ robin_c,
-                                                             const double* __restrict__ robin_r, int n_elem) {
+                                                             const double* __restrict__ robin_r, int n_elem,
+                                                             const int* __restrict__ elist = nullptr, int hang_only = 0) {
+  // elist / hang_only: see trace_hp_mfma16_kernel (the conforming sides' terms were added by the fast conforming flux kernel)
   constexpr int LT = 17;
   constexpr int TPB = 192;
   __shared__ double s_tile[6][2][16 * LT];
@@ -1505,7 +1513,8 @@ __global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __res
   const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;
   int cur_offD = -1, cur_N = -1;
   double opD[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int e = blockIdx.x; e < n_elem; e += gridDim.x) {
+  for (int ei = blockIdx.x; ei < n_elem; ei += gridDim.x) {
+    const int e = elist ? elist[ei] : ei;
     const ElemDesc el = ed[e];
     const int N = el.N, N2 = N * N, N3 = N2 * N;
     if (el.offD != cur_offD || N != cur_N) {
@@ -1524,6 +1533,7 @@ __global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __res
       for (int c = 0; c < 4; ++c) R[c] = mfma_d4{0.0, 0.0, 0.0, 0.0};
       for (int r_ = side_first[sidx]; r_ < side_first[sidx + 1]; ++r_) {
         const HpMortar m = md[r_];
+        if (hang_only && m.hang == 0.0) continue;   // (wave-uniform)
         const int NQ = m.NQ, T = NQ * NQ, KQ = (NQ + 3) >> 2;
         double oea[4], oeb[4];   // E along a / b: E[mi][4 ks + mk]  (N x NQ)
 #pragma unroll
@@ -1648,6 +1658,11 @@ struct FaceHost {
   int* d_elem_first = nullptr;
   int* d_side_first = nullptr;   // first record of side s (6 n_elements + 1 entries)
   int hp_max_N = 1, hp_max_NQ = 1;
+  // hp split (deg, deg_quad <= 7, one rank): the fast conforming kernels serve every conforming side of the mesh, the mortar-record
+  // kernels only the hanging sides of the elements that have one (d_hang_elems)
+  bool hp_split = false;
+  int* d_hang_elems = nullptr;
+  int n_hang_elems = 0;
   double* d_hp_ops = nullptr;
   int hp_fld_stride = 0;
   size_t hp_lds_doubles = 0;
@@ -1833,6 +1848,7 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
         m.first = (i == 0);
         m.last = (i == n_sub - 1);
         m.fm = m.fp = m.w2 = 1.0;
+        m.hang = (double)hang;
         int ep = -1, sub_m = 0;   // (+) element of this mortar; index of the mortar in the face's (-) order
         if (hang == 0) {
           if (nbr != -1 && !valid_ref(nbr)) D4EST_HIP_ABORT("plan_set_faces: side %zu neighbour %d out of range", s, nbr);
@@ -2179,6 +2195,46 @@ void faces_setup(d4est_hip_plan* plan) {
   fh.d_side_bndry_stride = upload_vec(plan->side_bndry_stride);
   fh.d_ghost_sides = upload_vec(gsides);
   if (hp) faces_setup_hp(plan, fh);
+  // ---- hp split.  A mesh with hanging faces is mostly conforming (2:1 interfaces of a locally refined forest): where every degree is
+  // <= 7 the conforming sides go to the fast kernels of the conforming path (one wavefront per face, scalar-operand contractions) and
+  // only the hanging sides to the tiled mortar-record kernels, over the list of elements that have one.  Both families write the same
+  // trace array (offsets of the records: a conforming side's block is its single record's) and add into the same A u.  A hanging
+  // side keeps kind 3 in the conforming descriptors: the fast trace kernel fills its block with a pretend-conforming trace that the
+  // record kernel, launched after it, overwrites (the block is at least as long), the fast flux kernel reads zeros for it.
+  fh.hp_split = false;
+  (void)hipFree(fh.d_hang_elems); fh.d_hang_elems = nullptr; fh.n_hang_elems = 0;
+  if (hp && fast && fh.hp_max_N <= 8 && fh.hp_max_NQ <= 8 && plan->n_ghost == 0 && plan->tuning[D4EST_HIP_TUNE_HP_SPLIT] != 0 &&
+      plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1) {
+    std::vector<int> hang_elems;
+    bool ok = true;
+    for (int e = 0; e < ne && ok; ++e) {
+      bool any = false;
+      for (int f = 0; f < 6; ++f) {
+        const size_t s_ = 6 * (size_t)e + f;
+        SideDesc& d = sd[s_];
+        d.qoff = plan->trace_offset[s_];
+        if (plan->side_hang[s_] != 0) { any = true; continue; }
+        if (d.kind == 1) {
+          const size_t sp = 6 * (size_t)plan->side_nbr[s_] + plan->side_nbr_face[s_];
+          if (plan->side_hang[sp] != 0 || deg_mq_of[sp] != deg_mq_of[s_]) { ok = false; break; }
+          d.nbr_qoff = plan->trace_offset[sp];
+        } else if (d.kind == 2) {
+          ok = false;
+        }
+      }
+      if (any) hang_elems.push_back(e);
+    }
+    // measured (level-4 brick, p = 7, every 64th / 32nd / 16th / 8th octant refined = 19 / 32 / 51 / 73 % of the elements with a hanging
+    // side): apply_aij 201 -> 146, 235 -> 197, 290 -> 266, 401 -> 412 us: the record kernel's cost is per listed element, so past half of
+    // the mesh the split stops paying (tuning value 1 forces it)
+    if (ok && plan->tuning[D4EST_HIP_TUNE_HP_SPLIT] < 0 && 2 * hang_elems.size() > (size_t)ne) ok = false;
+    if (ok) {
+      fh.hp_split = true;
+      fh.n_hang_elems = (int)hang_elems.size();
+      fh.d_hang_elems = upload_vec(hang_elems);
+      if (!sd.empty()) HIP_CHECK(hipMemcpy(plan->d_side_desc, sd.data(), sd.size() * sizeof(SideDesc), hipMemcpyHostToDevice));
+    }
+  }
   const size_t tm = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
   HIP_CHECK(hipMalloc(&plan->d_trace, std::max<size_t>((size_t)plan->local_trace_doubles, 1) * sizeof(double)));
   HIP_CHECK(hipMalloc(&plan->d_bndry, tm * sizeof(double)));  // Dirichlet data at the mortar quadrature nodes, by geom stride
@@ -2589,7 +2645,23 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
   if (!listed) elist = nullptr;
   const int n = listed ? n_list : plan->n_elements;
   if (n == 0) return;
-  if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+  if (fh.hp && fh.hp_split) {
+    // hp split: every conforming side from the fast conforming kernel, then the hanging sides of the elements that have one (the
+    // record kernel overwrites the blocks the first kernel filled for those sides)
+    const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
+    const int resident = 8 * cus;
+    const int rounds = (n + resident - 1) / resident;
+    const int grid = (n + rounds - 1) / rounds;
+    hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
+                       (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, (const int*)nullptr);
+    if (fh.n_hang_elems > 0) {
+      const size_t lds = (size_t)(fh.hp_max_N * 272 + 3 * 2 * 16 * 34) * sizeof(double);
+      if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(trace_hp_mfma16_kernel, dim3(std::min(fh.n_hang_elems, 4 * cus)), dim3(192), lds, plan->stream, u, trace, fh.d_rec,
+                         fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, fh.n_hang_elems, fh.hp_max_N,
+                         (const int*)fh.d_hang_elems, 1);
+    }
+  } else if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const size_t lds = (size_t)(fh.hp_max_N * 272 + 3 * 2 * 16 * 34) * sizeof(double);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(trace_hp_mfma16_kernel, dim3(std::min(n, 4 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), lds, plan->stream, u, trace,
@@ -2647,7 +2719,21 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   if (plan->n_elements == 0) return;
   if (fh.n_ghost_sides > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost sides but no ghost trace buffer was given", fh.n_ghost_sides);
   const int n = plan->n_elements;
-  if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+  if (fh.hp && fh.hp_split) {
+    // hp split (see launch_traces): the conforming sides' terms from the fast kernel, then the hanging sides' from the record kernel
+    const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
+    const int resident = face_wg_per_cu() * cus;
+    const int rounds = (n + resident - 1) / resident;
+    const int grid = (n + rounds - 1) / rounds;
+    hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
+                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom,
+                       plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, 0, ChebyFuse{});
+    if (fh.n_hang_elems > 0)
+      hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(fh.n_hang_elems, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
+                         fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
+                         plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems,
+                         (const int*)fh.d_hang_elems, 1);
+  } else if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
                        fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
                        plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n);
@@ -2712,7 +2798,7 @@ void faces_destroy(d4est_hip_plan* plan) {
     (void)hipFree(fh.d_side_deg_m); (void)hipFree(fh.d_side_deg_p); (void)hipFree(fh.d_side_bndry_stride);
     (void)hipFree(fh.d_ghost_sides); (void)hipFree(fh.d_elem_desc_generic);
     (void)hipFree(fh.d_sj); (void)hipFree(fh.d_robin_c); (void)hipFree(fh.d_robin_r);
-    (void)hipFree(fh.d_rec); (void)hipFree(fh.d_gsrc); (void)hipFree(fh.d_elem_first); (void)hipFree(fh.d_side_first); (void)hipFree(fh.d_hp_ops);
+    (void)hipFree(fh.d_rec); (void)hipFree(fh.d_gsrc); (void)hipFree(fh.d_elem_first); (void)hipFree(fh.d_side_first); (void)hipFree(fh.d_hp_ops); (void)hipFree(fh.d_hang_elems);
     g_face_host.erase(it);
   }
   (void)hipFree(plan->d_elem_desc);

@@ -136,7 +136,7 @@ struct d4est_hip_plan {
   int stream_mode = 0;            // 1: non-temporal metric / factor loads and A u stores (capi: update_stream_mode; kernels: with_ld)
   bool bc_inhomogeneous = false;   // non-zero Dirichlet data or Robin data is set (an affine, not linear, operator)
 
-  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
+  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;

@@ -435,3 +435,49 @@ def test_stream_mode_whole_operator(gpu, hiplib, oracle, deg):
     got = outs[1].cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
     plan.destroy()
+
+
+@pytest.mark.parametrize("level,pattern,deg,inc,mixed,curved,robin", [
+    (1, [0], 2, 0, False, False, False), (1, [0, 5, 6], 2, 0, False, True, False), (1, [3], 3, 1, False, True, True),
+    (1, [1, 2, 4, 7], 2, 0, True, True, False), (1, [0, 7], 4, 0, True, True, False), (2, [0, 9, 21, 42, 63], 2, 1, True, True, True),
+    (1, [6], 7, 0, False, True, False), (2, [5], 5, 0, True, False, False), (2, [0, 63], 6, 1, False, True, False),
+])
+def test_hp_split_parity(gpu, hiplib, oracle, level, pattern, deg, inc, mixed, curved, robin):
+    """Hanging meshes with every degree <= 7 (tuning key 13): the conforming sides through the fast conforming trace / flux kernels, the
+    hanging sides through the mortar-record kernels over the elements that have one -- forced here (the automatic choice takes the
+    split when at most half of the elements have a hanging side) and held to the oracle and to the all-records path (key 13 = 0);
+    the traces the two kernel families leave in the trace array are the same as the record kernels' alone."""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    m = _hanging_mesh(level, pattern, deg, inc, mixed)
+    mp = M.SineMap(0.04) if curved else None
+    J, rst = m.geometry(mp)
+    sides = m.build_sides(mp)
+    u = m.field(mp)
+    bx = sides["bndry_xyz"]
+    g = np.sin(bx[0]) + bx[1] * bx[2]
+    tm = int(sides["total_mortar_nodes"])
+    rb = (0.5 + M.splitmix64_uniform(11, tm), M.splitmix64_uniform(12, tm) - 0.5) if robin else None
+    ref = oracle.apply_aij(m, J, rst, sides, u, bndry_lobatto=None if robin else g, penalty_prefactor=7.5, nthreads=8, robin=rb)
+    du = _t(u, gpu)
+    outs, traces = [], []
+    for key in (0, 1):
+        plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, m.quad_type)
+        plan.set_geometry(J, rst)
+        plan.set_tuning(13, key)
+        plan.set_faces(sides, 7.5, 0)
+        if robin:
+            plan.set_robin_values(*rb)
+        else:
+            plan.set_dirichlet_values(g)
+        out = torch.full_like(du, float("nan"))
+        plan.apply_aij(du, out)
+        outs.append(out.cpu().numpy())
+        tr = torch.full((plan.trace_size,), float("nan"), dtype=torch.float64, device=gpu)
+        plan.compute_face_traces(du, tr)
+        traces.append(tr.cpu().numpy())
+        plan.destroy()
+    assert np.isfinite(outs[1]).all()
+    assert _rel(outs[1], ref) <= RTOL and _rel(outs[0], ref) <= RTOL
+    assert _rel(outs[1], outs[0]) <= 1e-13
+    assert np.isfinite(traces[1]).all() and np.abs(traces[1] - traces[0]).max() <= 1e-13 * max(np.abs(traces[0]).max(), 1.0)

@@ -24,7 +24,9 @@ def _rel(a, b):
 def _plan(m, J, rst, sides, prefactor=10.0, fcn=0, generic=False):
     from disco4est_amd import Plan
     p = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, m.quad_type)
-    if generic:
+    if generic == "split":
+        p.set_tuning(13, 1)    # D4EST_HIP_TUNE_HP_SPLIT = 1: conforming sides through the fast conforming kernels, hanging sides through the record kernels
+    elif generic:
         p.set_tuning(3, 0)     # D4EST_HIP_TUNE_FLUX_FAST = 0: the generic trace / flux kernels
     p.set_geometry(J, rst)
     p.set_faces(sides, prefactor, fcn)
@@ -75,7 +77,7 @@ def test_apply_aij_all_orientations(gpu, hiplib, oracle, deg, generic):
     assert codes == set(range(8))
 
 
-@pytest.mark.parametrize("deg,generic", [(2, False), (2, True), (4, False), (8, False)])
+@pytest.mark.parametrize("deg,generic", [(2, False), (2, True), (4, False), (8, False), (2, "split"), (5, "split")])
 def test_apply_aij_hanging_across_trees(gpu, hiplib, oracle, deg, generic):
     """A hanging (1 <-> 4) face ON the tree boundary, orientation 0..3 (d4est_reference_reorient_face_order), the refined tree on
     either side, mixed p: record kernels (generic and tiled MFMA) against the oracle."""
@@ -107,6 +109,7 @@ def test_apply_aij_hanging_across_trees(gpu, hiplib, oracle, deg, generic):
     (2, 0, 1, None, False, False), (3, 1, 0, None, True, False), (5, 0, 0, [1, 0, 0, 0, 0, 0, 1], False, True),
     (7, 0, 0, None, False, False), (11, 0, 0, None, False, False), (15, 0, 0, None, False, False),
     (15, 0, 0, [0, 0, 0, 1, 0, 0, 0], False, True), (17, 0, 0, None, False, False),
+    (5, 0, 0, [1, 0, 0, 0, 0, 0, 1], "split", True), (3, 1, 0, [0, 0, 1, 0, 0, 0, 0], "split", False),
 ])
 def test_cubed_sphere_apply_aij(gpu, hiplib, oracle, deg, inc, level, refine, generic, compactify):
     """Config 5's mesh class: the reference's 7-tree cubed sphere (curved wedges around a cube; inter-tree codes 1, 2, 3, 7), up to

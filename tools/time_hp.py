@@ -12,7 +12,9 @@ m = M.HangingBrickMesh(level, refine, deg)
 J, rst = m.geometry(None); sides = m.build_sides(None); u = m.field()
 dev = torch.device("cuda:0")
 plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=torch.cuda.current_stream())
-plan.set_geometry(J, rst); plan.set_tuning(7, 0); plan.set_faces(sides)
+plan.set_geometry(J, rst); plan.set_tuning(7, 0)
+if os.environ.get('D4EST_SPLIT'): plan.set_tuning(13, int(os.environ['D4EST_SPLIT']))
+plan.set_faces(sides)
 du = torch.from_numpy(u).to(dev); Au = torch.empty_like(du)
 tr = torch.empty(plan.trace_size, dtype=torch.float64, device=dev)
 def t(fn, reps=20):
@@ -24,6 +26,7 @@ def t(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 hang = int((sides["side_hang"] == 1).sum())
-print("hanging mesh: base level %d p %d: %d elements, %d DoF, %d hanging faces: stiffness %.1f us | traces %.1f us | flux %.1f us | apply_aij %.1f us" % (
-    level, deg, m.n_elements, m.local_nodes, hang, t(lambda: plan.apply_stiffness_matrix(du, Au)),
+he = int((np.asarray(sides["side_hang"]).reshape(-1, 6) != 0).any(axis=1).sum())
+print("hanging mesh (split %s): base level %d p %d: %d elements (%d with a hanging side), %d DoF, %d hanging faces: stiffness %.1f us | traces %.1f us | flux %.1f us | apply_aij %.1f us" % (
+    os.environ.get('D4EST_SPLIT', 'auto'), level, deg, m.n_elements, he, m.local_nodes, hang, t(lambda: plan.apply_stiffness_matrix(du, Au)),
     t(lambda: plan.compute_face_traces(du, tr)), t(lambda: plan.apply_flux(tr, None, Au)), t(lambda: plan.apply_aij(du, Au))))
