@@ -350,7 +350,7 @@ struct HpMortar {
   int gidx;          // scalar index of the mortar's first node in the precombined geometry / boundary arrays (S + off)
   int u_shift;       // offset (doubles) from the (+) block to the block whose u field this mortar reads; 0 except on a small side whose
                      // face pair the reference re-orients non-geometrically (see faces_setup_hp)
-  double fm, fp, w2;
+  double fm, fp, w2; // hanging-face factors (set-up only: face_geom_hp_kernel folds them into the geometric factors; w2 = fm)
   double hang;       // side_hang of the record's side as a number (0 conforming, 1 big, 2 small): lets the tiled kernels serve the hanging sides only (hp split)
   long long qoff, nbr_qoff;
 };
@@ -438,8 +438,11 @@ __global__ __launch_bounds__(64) void face_geom_hp_kernel(const HpMortar* __rest
           // (+) side factors are stored in the (+) side's sub-mortar order and orientation (d4est_laplacian_flux.c:858-900)
           if (m.kind != 0) ap += sn[x] * drst_p[9 * S + (size_t)(i + 3 * x) * TT + g.off_p + kp];
         }
-        geom[7 * (size_t)m.gidx + (size_t)i * T + k] = am;
-        geom[7 * (size_t)m.gidx + (size_t)(3 + i) * T + k] = ap;
+        // the hanging-face factors of the reference (d4est_laplacian_flux.c:907-915: x 0.5 on the big element's gradient and term 2 on
+        // its half-size mortars, x 0.5 on the big element's gradient seen from a small side) are folded in here -- exact scalings --,
+        // so that a record's SIPG terms read like a conforming side's and a small side can go to the conforming flux kernel (hp split)
+        geom[7 * (size_t)m.gidx + (size_t)i * T + k] = m.fm * am;
+        geom[7 * (size_t)m.gidx + (size_t)(3 + i) * T + k] = m.fp * ap;
       }
       const double hmk = hm[S + g.off + k], hpk = (m.kind == 0) ? hmk : hp[S + g.off + k];
       geom[7 * (size_t)m.gidx + (size_t)6 * T + k] = sjk * sipg_penalty(fcn, g.deg_m, hmk, (m.kind == 0) ? g.deg_m : g.deg_p, hpk, prefactor);
@@ -489,8 +492,8 @@ __global__ __launch_bounds__(256) void flux_hp_kernel(const double* __restrict__
         }
         const double jump = um - up;
         const double w1 = (m.kind != 0) ? -0.5 : -1.0;
-        A[k] = w1 * (m.fm * tm + m.fp * tp) + g[6 * T + k] * jump;
-        for (int l = 0; l < 3; ++l) A[(1 + l) * fld_stride + k] = w1 * m.w2 * am[l] * jump;
+        A[k] = w1 * (tm + tp) + g[6 * T + k] * jump;   // (fm, fp, w2: folded into the factors by face_geom_hp_kernel)
+        for (int l = 0; l < 3; ++l) A[(1 + l) * fld_stride + k] = w1 * am[l] * jump;
       }
       __syncthreads();
       apply2d_ab(hp_ops + m.offEa, hp_ops + m.offEb, N, NQ, A, tmp, R, 4, fld_stride, fld_stride, fld_stride, !m.first);
@@ -1572,10 +1575,10 @@ __global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __res
               }
               const double jump = um - up;
               const double w1 = (m.kind != 0) ? -0.5 : -1.0;
-              A[0][ks] = w1 * (m.fm * tm + m.fp * tp) + g[6 * T] * jump;
-              A[1][ks] = w1 * m.w2 * am[t0] * jump;
-              A[2][ks] = w1 * m.w2 * am[t1d] * jump;
-              A[3][ks] = w1 * m.w2 * am[dir] * jump;
+              A[0][ks] = w1 * (tm + tp) + g[6 * T] * jump;   // (fm, fp, w2: folded into the factors by face_geom_hp_kernel)
+              A[1][ks] = w1 * am[t0] * jump;
+              A[2][ks] = w1 * am[t1d] * jump;
+              A[3][ks] = w1 * am[dir] * jump;
             }
           }
         }
@@ -1663,6 +1666,7 @@ struct FaceHost {
   bool hp_split = false;
   int* d_hang_elems = nullptr;
   int n_hang_elems = 0;
+  std::vector<HpMortar> rec_host;   // host copy of the records (set-up of the split)
   double* d_hp_ops = nullptr;
   int hp_fld_stride = 0;
   size_t hp_lds_doubles = 0;
@@ -1956,6 +1960,7 @@ static void faces_setup_hp(d4est_hip_plan* plan, FaceHost& fh) {
   fh.hp_lds_doubles = (size_t)12 * max_fld + (size_t)maxN * maxN * maxN + (size_t)maxN * maxN;
   if (fh.hp_lds_doubles * sizeof(double) > 160 * 1024) D4EST_HIP_ABORT("hanging-face kernels need %zu LDS doubles", fh.hp_lds_doubles);
   fh.d_rec = upload_vec(rec);
+  fh.rec_host = rec;
   fh.d_gsrc = upload_vec(gsrc);
   fh.d_elem_first = upload_vec(elem_first);
   {
@@ -2073,7 +2078,9 @@ void faces_setup(d4est_hip_plan* plan) {
     for (int f = 0; f < 6; ++f) {
       const size_t s = 6 * (size_t)e + f;
       const bool hanging = hp && plan->side_hang[s] != 0;
-      const int nbr = hanging ? -1 : plan->side_nbr[s];   // hanging sides are served by the mortar records only
+      // hanging sides are served by the mortar records (descriptor kind 3); a SMALL side still gets the degrees of its mortar with the
+      // big element, so that the hp split can hand it to the conforming kernels (one mortar, p-prolongation only: it is one of theirs)
+      const int nbr = hanging ? ((plan->side_hang[s] == 2 && plan->side_nbr[s] >= 0) ? plan->side_nbr[s] : -1) : plan->side_nbr[s];
       const int deg_m = plan->deg[e], degq_m = plan->deg_quad[e];
       int deg_p = deg_m, degq_p = degq_m;
       if (nbr >= 0) {
@@ -2086,7 +2093,7 @@ void faces_setup(d4est_hip_plan* plan) {
         deg_p = plan->ghost_deg[g];
         degq_p = plan->ghost_deg_quad[g];
       }
-      deg_mq_of[s] = (nbr == -1) ? degq_m : std::max(degq_m, degq_p);
+      deg_mq_of[s] = (nbr == -1) ? degq_m : std::max(degq_m, degq_p);   // (max: also d4est's rule for a hanging face's mortars)
       deg_p_of[s] = deg_p;
       const long long T = (long long)(deg_mq_of[s] + 1) * (deg_mq_of[s] + 1);
       plan->trace_offset[s] = qoff;
@@ -2206,6 +2213,7 @@ void faces_setup(d4est_hip_plan* plan) {
   if (hp && fast && fh.hp_max_N <= 8 && fh.hp_max_NQ <= 8 && plan->n_ghost == 0 && plan->tuning[D4EST_HIP_TUNE_HP_SPLIT] != 0 &&
       plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1) {
     std::vector<int> hang_elems;
+    std::vector<HpMortar> rec = fh.rec_host;
     bool ok = true;
     for (int e = 0; e < ne && ok; ++e) {
       bool any = false;
@@ -2213,7 +2221,21 @@ void faces_setup(d4est_hip_plan* plan) {
         const size_t s_ = 6 * (size_t)e + f;
         SideDesc& d = sd[s_];
         d.qoff = plan->trace_offset[s_];
-        if (plan->side_hang[s_] != 0) { any = true; continue; }
+        const int hang = plan->side_hang[s_];
+        if (hang == 2) {
+          // a small side: ONE mortar, its own trace p-prolonged to the mortar nodes, the (+) block = the big element's sub-mortar, the
+          // hanging factor folded into the geometric factors -- to the conforming kernels it is an ordinary interior side (unless
+          // the reference's non-geometric re-orientation shifts the block it reads u from: those stay with the record kernel)
+          HpMortar& m = rec[plan->side_first_rec[s_]];
+          if (m.kind == 1 && m.u_shift == 0 && m.NQ == d.NQ && plan->side_first_rec[s_ + 1] == plan->side_first_rec[s_] + 1) {
+            d.kind = 1;
+            d.geom = m.gidx;
+            d.nbr_qoff = m.nbr_qoff;
+            m.hang = 0.0;   // (the record kernel skips it)
+            continue;
+          }
+        }
+        if (hang != 0) { any = true; continue; }
         if (d.kind == 1) {
           const size_t sp = 6 * (size_t)plan->side_nbr[s_] + plan->side_nbr_face[s_];
           if (plan->side_hang[sp] != 0 || deg_mq_of[sp] != deg_mq_of[s_]) { ok = false; break; }
@@ -2224,15 +2246,16 @@ void faces_setup(d4est_hip_plan* plan) {
       }
       if (any) hang_elems.push_back(e);
     }
-    // measured (level-4 brick, p = 7, every 64th / 32nd / 16th / 8th octant refined = 19 / 32 / 51 / 73 % of the elements with a hanging
-    // side): apply_aij 201 -> 146, 235 -> 197, 290 -> 266, 401 -> 412 us: the record kernel's cost is per listed element, so past half of
-    // the mesh the split stops paying (tuning value 1 forces it)
+    // measured (level-4 brick, p = 7, every 64th / 32nd / 16th / 8th / 3rd octant refined): apply_aij 203 -> 139, 236 -> 170, 292 -> 210,
+    // 402 -> 292, 661 -> 448 us.  The record kernel's cost is per listed element (those with a BIG hanging side, or a small side the
+    // conforming kernels cannot take): should they ever be more than half of the mesh, the split is not taken (tuning value 1 forces it)
     if (ok && plan->tuning[D4EST_HIP_TUNE_HP_SPLIT] < 0 && 2 * hang_elems.size() > (size_t)ne) ok = false;
     if (ok) {
       fh.hp_split = true;
       fh.n_hang_elems = (int)hang_elems.size();
       fh.d_hang_elems = upload_vec(hang_elems);
       if (!sd.empty()) HIP_CHECK(hipMemcpy(plan->d_side_desc, sd.data(), sd.size() * sizeof(SideDesc), hipMemcpyHostToDevice));
+      if (!rec.empty()) HIP_CHECK(hipMemcpy(fh.d_rec, rec.data(), rec.size() * sizeof(HpMortar), hipMemcpyHostToDevice));
     }
   }
   const size_t tm = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
