@@ -1661,7 +1661,7 @@ struct FaceHost {
   int* d_elem_first = nullptr;
   int* d_side_first = nullptr;   // first record of side s (6 n_elements + 1 entries)
   int hp_max_N = 1, hp_max_NQ = 1;
-  // hp split (deg, deg_quad <= 7, one rank): the fast conforming kernels serve every conforming side of the mesh, the mortar-record
+  // hp split (deg, deg_quad <= 7): the fast conforming kernels serve every conforming (and small hanging) side of the mesh, the mortar-record
   // kernels only the hanging sides of the elements that have one (d_hang_elems)
   bool hp_split = false;
   int* d_hang_elems = nullptr;
@@ -2080,7 +2080,7 @@ void faces_setup(d4est_hip_plan* plan) {
       const bool hanging = hp && plan->side_hang[s] != 0;
       // hanging sides are served by the mortar records (descriptor kind 3); a SMALL side still gets the degrees of its mortar with the
       // big element, so that the hp split can hand it to the conforming kernels (one mortar, p-prolongation only: it is one of theirs)
-      const int nbr = hanging ? ((plan->side_hang[s] == 2 && plan->side_nbr[s] >= 0) ? plan->side_nbr[s] : -1) : plan->side_nbr[s];
+      const int nbr = hanging ? ((plan->side_hang[s] == 2 && plan->side_nbr[s] != -1) ? plan->side_nbr[s] : -1) : plan->side_nbr[s];
       const int deg_m = plan->deg[e], degq_m = plan->deg_quad[e];
       int deg_p = deg_m, degq_p = degq_m;
       if (nbr >= 0) {
@@ -2210,7 +2210,7 @@ void faces_setup(d4est_hip_plan* plan) {
   // record kernel, launched after it, overwrites (the block is at least as long), the fast flux kernel reads zeros for it.
   fh.hp_split = false;
   (void)hipFree(fh.d_hang_elems); fh.d_hang_elems = nullptr; fh.n_hang_elems = 0;
-  if (hp && fast && fh.hp_max_N <= 8 && fh.hp_max_NQ <= 8 && plan->n_ghost == 0 && plan->tuning[D4EST_HIP_TUNE_HP_SPLIT] != 0 &&
+  if (hp && fast && fh.hp_max_N <= 8 && fh.hp_max_NQ <= 8 && plan->tuning[D4EST_HIP_TUNE_HP_SPLIT] != 0 &&
       plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1) {
     std::vector<int> hang_elems;
     std::vector<HpMortar> rec = fh.rec_host;
@@ -2227,8 +2227,8 @@ void faces_setup(d4est_hip_plan* plan) {
           // hanging factor folded into the geometric factors -- to the conforming kernels it is an ordinary interior side (unless
           // the reference's non-geometric re-orientation shifts the block it reads u from: those stay with the record kernel)
           HpMortar& m = rec[plan->side_first_rec[s_]];
-          if (m.kind == 1 && m.u_shift == 0 && m.NQ == d.NQ && plan->side_first_rec[s_ + 1] == plan->side_first_rec[s_] + 1) {
-            d.kind = 1;
+          if ((m.kind == 1 || m.kind == 2) && m.u_shift == 0 && m.NQ == d.NQ && plan->side_first_rec[s_ + 1] == plan->side_first_rec[s_] + 1) {
+            d.kind = m.kind;   // (2: the big element is a ghost -- its sub-mortar block arrives in the ghost trace buffer at the record's offset)
             d.geom = m.gidx;
             d.nbr_qoff = m.nbr_qoff;
             m.hang = 0.0;   // (the record kernel skips it)
@@ -2241,7 +2241,10 @@ void faces_setup(d4est_hip_plan* plan) {
           if (plan->side_hang[sp] != 0 || deg_mq_of[sp] != deg_mq_of[s_]) { ok = false; break; }
           d.nbr_qoff = plan->trace_offset[sp];
         } else if (d.kind == 2) {
-          ok = false;
+          // a conforming side against a ghost: the exchanged block sits where the side's (single) record expects it
+          const HpMortar& m = rec[plan->side_first_rec[s_]];
+          if (m.kind != 2 || m.NQ != d.NQ || m.u_shift != 0) { ok = false; break; }
+          d.nbr_qoff = m.nbr_qoff;
         }
       }
       if (any) hang_elems.push_back(e);

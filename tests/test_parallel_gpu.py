@@ -71,11 +71,14 @@ def test_virtual_ranks_match_single_rank(gpu, hiplib, oracle, world, level, deg_
     assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("split", [-1, 0, 1])
 @pytest.mark.parametrize("world,level,pattern,deg_spec", [(2, 1, [0, 5, 6], [2]), (3, 1, [1, 2, 4, 7], [2, 3]), (4, 2, [0, 9, 21, 42, 63], [3]),
                                                           (3, 1, [3, 6], [7]), (2, 1, [2], [9])])
-def test_virtual_ranks_hanging_mesh(gpu, hiplib, oracle, world, level, pattern, deg_spec):
+def test_virtual_ranks_hanging_mesh(gpu, hiplib, oracle, world, level, pattern, deg_spec, split):
     """Hanging (1 <-> 4) faces ACROSS rank boundaries: a big side sends one block per sub-mortar to the owners of its four small
-    neighbours, a small side receives the big element's sub-block that faces it; the assembled operator equals the single-rank one."""
+    neighbours, a small side receives the big element's sub-block that faces it; the assembled operator equals the single-rank one.
+    split: tuning key 13 -- automatic, every side through the record kernels, or (degrees <= 7) the conforming and small sides through
+    the fast conforming kernels, ghost (+) sides included."""
     import torch
     from disco4est_amd import Plan, mesh as M, parallel as P
     refine = np.zeros(8 ** level, dtype=bool)
@@ -94,7 +97,7 @@ def test_virtual_ranks_hanging_mesh(gpu, hiplib, oracle, world, level, pattern, 
         m = M.HangingBrickMesh(level, refine, deg_global, first=first, count=count)
         J, rst = m.geometry(mp); s = m.build_sides(mp)
         plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
-        plan.set_geometry(J, rst); plan.set_faces(s)
+        plan.set_geometry(J, rst); plan.set_tuning(13, split); plan.set_faces(s)
         sched = P.plan_schedule(plan, m, s, parts)
         # the host-side layout formula used by the CPU-only tests is the library's layout
         nblk, off, goff, ln, n_trace, n_ghost = P.side_block_layout_hp(m, s)
