@@ -2751,9 +2751,11 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     const int resident = face_wg_per_cu() * cus;
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
+    static const bool no_remap_s = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
+    const int chunk_s = (n % 8 == 0 && grid % 8 == 0 && !no_remap_s) ? n / 8 : 0;   // XCD-aware element order, as on conforming plans
     hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
                        (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom,
-                       plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, 0, ChebyFuse{});
+                       plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk_s, ChebyFuse{});
     if (fh.n_hang_elems > 0)
       hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(fh.n_hang_elems, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
                          fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
