@@ -686,7 +686,7 @@ def main():
                 sz.destroy()
                 del us
             # BASELINE config 4's shape in miniature: degrees p = 3 ... 9 scattered over the level-4 brick (1.75 MDoF), general path --
-            # the volume term (the buckets with deg_quad = deg <= 7 in one launch, p = 8, 9 in theirs) and the full operator
+            # the volume term (the buckets with deg_quad = deg <= 7 in one launch, p = 8, 9 in a second one) and the full operator
             # (two-phase tiled face kernels: the mesh holds degrees above 7)
             if args.geometry != "sine":
                 degs = 3 + (np.arange(8 ** 4) * 5) % 7

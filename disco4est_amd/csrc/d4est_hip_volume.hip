@@ -699,6 +699,59 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave_eo_multi_kernel(const do
 #undef D4EST_CASE
 }
 
+// Mixed-degree plans, p = 8 ... 12: the buckets whose multi-wave kernels have the same workgroup size (N = 9, 10: 128 threads; N = 11,
+// 12, 13: 192) in ONE launch, like stiffness_wave_eo_multi_kernel for p <= 7 -- a workgroup looks its bucket up and runs that degree's
+// body (stiffness_wave_kernel's: collocated-gradient form, streamed metric).  Small buckets (585 elements each on the p = 3 ... 9 mesh of
+// the bench) no longer queue behind each other: 13 + 15 us -> one launch.  WaveEoMulti: EGb / EGf carry the tables of Dq / Dq^T.
+template <int N, bool NT>
+__device__ __forceinline__ void mw_multi_body(double* smem, int ei, const double* __restrict__ u, double* __restrict__ Au,
+                                              const double* __restrict__ metric, const int* __restrict__ ns_list, const int* __restrict__ qs_list,
+                                              int n_bucket, const double* __restrict__ EBb, const double* __restrict__ EBf,
+                                              const double* __restrict__ EDq, const double* __restrict__ EDqT) {
+  using C = WaveCfg<N, N>;
+  constexpr int PL = C::PL, PN = C::PN;
+  const int te = threadIdx.x;
+  const int a = te % N, b = te / N;
+  const bool active = (te < PL) && (ei < n_bucket);
+  double* R0 = smem;
+  double* R1 = R0 + C::FS;
+  int ns = 0, qs = 0;
+  if (ei < n_bucket) {
+    ns = __builtin_amdgcn_readfirstlane(ns_list[ei]);
+    qs = __builtin_amdgcn_readfirstlane(qs_list[ei]);
+  }
+  if (active) load_element_image<N, PL, PN>(R0, u + ns, te);
+  stiffness_mw_element_cg<N, false, false, NT>(R0, R1, metric, qs, ei, active, te, a, b, EBb, EBf, EDq, EDqT, nullptr, nullptr);
+  if (active) store_element_image<N, PL, PN, NT>(Au + ns, R0, te);
+}
+
+template <int THREADS, bool NT>
+__global__ __launch_bounds__(THREADS, D4EST_HIP_MW_WAVES) void stiffness_mw_multi_kernel(const double* __restrict__ u, double* __restrict__ Au,
+                                                                                        const double* __restrict__ metric,
+                                                                                        const int* __restrict__ ns_list_all,
+                                                                                        const int* __restrict__ qs_list_all, WaveEoMulti A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int blk = blockIdx.x;
+  int bi = 0;
+  while (bi + 1 < A.n && blk >= A.wg_end[bi]) ++bi;   // wave-uniform
+  const int ei = blk - (bi > 0 ? A.wg_end[bi - 1] : 0);
+  const int off = A.elem_offset[bi], nb = A.n_elem[bi];
+  const double* EBf = A.EBf[bi];
+  const double* EDqT = A.EGf[bi];
+  const double* EBb = A.EBb[bi];
+  const double* EDq = A.EGb[bi];
+#define D4EST_CASE(N_)                                                                                                  \
+  case N_:                                                                                                              \
+    if constexpr (WaveCfg<N_, N_>::THREADS == THREADS)                                                                  \
+      mw_multi_body<N_, NT>(smem, ei, u, Au, metric, ns_list_all + off, qs_list_all + off, nb, EBb, EBf, EDq, EDqT);    \
+    break;
+  switch (A.N[bi]) {
+    D4EST_CASE(9) D4EST_CASE(10) D4EST_CASE(11) D4EST_CASE(12) D4EST_CASE(13)
+    default: break;
+  }
+#undef D4EST_CASE
+}
+
 // ---------------------------------------------------------------------------
 // N = NQ = 16 (p = 15) on the FP64 matrix cores (N = 13 ... 15 run too, operators zero-padded to 16, but the padding and the idle
 // waves eat the gain -- measured 32 / 47 / 36 GDoF/s against 41 / 46 / 34 of the vector-ALU kernel -- so only p = 15 selects it by itself): the whole sum-factorised apply as chains of v_mfma_f64_16x16x4
@@ -1457,9 +1510,45 @@ static unsigned launch_stiffness_multi(d4est_hip_plan* plan, const double* u, do
   return covered;
 }
 
+// ... and the p = 8 ... 12 buckets of such a plan by workgroup size (stiffness_mw_multi_kernel): general path, automatic kernel choice
+static unsigned launch_stiffness_multi_mw(d4est_hip_plan* plan, const double* u, double* Au) {
+  if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] >= 0 && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] != 1) return 0u;
+  if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] == 0) return 0u;
+  unsigned covered = 0u;
+  for (int threads = 128; threads <= 192; threads += 64) {
+    WaveEoMulti A;
+    size_t lds = 0;
+    unsigned mine = 0u;
+    int wgs = 0;
+    for (size_t i = 0; i < plan->buckets.size() && i < 32; ++i) {
+      const Bucket& bk = plan->buckets[i];
+      if (bk.n_elem == 0 || bk.N != bk.NQ || bk.N < 9 || bk.N > 13 || !bk.d_EDq || A.n == WaveEoMulti::MAXB) continue;
+      if (bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine) continue;   // (affine buckets keep their kernel)
+      const int th = ((bk.N * bk.N + 63) / 64) * 64;
+      if (th != threads) continue;
+      lds = std::max(lds, (size_t)2 * bk.N * bk.N * (bk.N | 1) * sizeof(double));
+      wgs += bk.n_elem;
+      const int j = A.n++;
+      A.wg_end[j] = wgs; A.N[j] = bk.N; A.n_elem[j] = bk.n_elem; A.elem_offset[j] = bk.elem_offset;
+      A.EBf[j] = bk.d_EBf; A.EGf[j] = bk.d_EDqT; A.EBb[j] = bk.d_EBb; A.EGb[j] = bk.d_EDq; A.wq[j] = bk.d_w;
+      mine |= 1u << i;
+    }
+    if (A.n < 2) continue;
+    std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_mw_multi_kernel<%d> (%d buckets)", threads, A.n);
+    auto go = [&](auto kern) {
+      set_lds_limit(kern, lds);
+      hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), lds, plan->stream, u, Au, plan->d_metric, plan->d_ns_list, plan->d_qs_list, A);
+    };
+    if (threads == 128) { if (plan->stream_mode) go(stiffness_mw_multi_kernel<128, true>); else go(stiffness_mw_multi_kernel<128, false>); }
+    else { if (plan->stream_mode) go(stiffness_mw_multi_kernel<192, true>); else go(stiffness_mw_multi_kernel<192, false>); }
+    covered |= mine;
+  }
+  return covered;
+}
+
 void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   if (!plan->has_geometry) D4EST_HIP_ABORT("apply_stiffness_matrix: d4est_hip_plan_set_geometry was not called");
-  const unsigned covered = launch_stiffness_multi(plan, u, Au);
+  const unsigned covered = launch_stiffness_multi(plan, u, Au) | launch_stiffness_multi_mw(plan, u, Au);
   size_t bucket_index = 0;
   for (const Bucket& bk : plan->buckets) {
     const size_t this_bucket = bucket_index++;
