@@ -415,20 +415,30 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
         DirectFuse cfl;
         if constexpr (FUSE) cfl = direct_load_fuse(direct_kargs());
         double* __restrict__ Au_ = direct_kargs()->Au;
+        // every load of the epilogue first (A u, and the smoother's rhs, p, u of the N nodes of this lane): one memory round trip instead
+        // of two or three per node -- the stores to p / the new iterate may alias the loads as far as the compiler knows, so a loop that
+        // loads inside ran 3 N dependent round trips (config 2: +14 us per Chebyshev iteration)
+        double av[N], rh[FUSE ? N : 1], pp[FUSE ? N : 1], uu[FUSE ? N : 1];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           const size_t o = (size_t)ns + a + N * b + N2 * i;
-          const double au = Au_[o] + (lds_ld(&s_U[a + PN * (b + N * i)]) + acc[i]);
+          av[i] = Au_[o];
+          if constexpr (FUSE) { rh[i] = cfl.rhs[o]; pp[i] = cfl.p[o]; uu[i] = u[o]; }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const size_t o = (size_t)ns + a + N * b + N2 * i;
+          const double au = av[i] + (lds_ld(&s_U[a + PN * (b + N * i)]) + acc[i]);
           Au_[o] = au;
           if constexpr (FUSE) {
             // the Chebyshev update of the node (cheby_update_kernel, same roundings): u is an INPUT of this kernel (the
             // neighbours read it), so the new iterate goes to a second vector
-            const double res = __dadd_rn(cfl.rhs[o], __dmul_rn(-1.0, au));
+            const double res = __dadd_rn(rh[i], __dmul_rn(-1.0, au));
             const double ri = __dmul_rn(cfl.alpha, res);
-            const double pi = __dadd_rn(__dmul_rn(cfl.beta, cfl.p[o]), ri);
+            const double pi = __dadd_rn(__dmul_rn(cfl.beta, pp[i]), ri);
             if (cfl.r) cfl.r[o] = ri;
             cfl.p[o] = pi;
-            cfl.u_out[o] = __dadd_rn(u[o], pi);
+            cfl.u_out[o] = __dadd_rn(uu[i], pi);
           }
         }
       }
@@ -464,6 +474,14 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
       DirectFuse cfl;
       if constexpr (FUSE) cfl = direct_load_fuse(direct_kargs());
       double* __restrict__ Au_ = direct_kargs()->Au;
+      double rh[FUSE ? N : 1], pp[FUSE ? N : 1], uu[FUSE ? N : 1];   // the smoother's loads first, all of them: see the faces-only form above
+      if constexpr (FUSE) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const size_t o = (size_t)ns + a + N * b + N2 * i;
+          rh[i] = cfl.rhs[o]; pp[i] = cfl.p[o]; uu[i] = u[o];
+        }
+      }
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const size_t o = (size_t)ns + a + N * b + N2 * i;
@@ -471,12 +489,12 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
         if constexpr (!FUSE && (VOL & 8) != 0) __builtin_nontemporal_store(au, &Au_[o]);   // stream mode
         else if (!FUSE || !cfl.skip_Au_store) Au_[o] = au;
         if constexpr (FUSE) {   // the Chebyshev update of the node, as in the faces-only form
-          const double res = __dadd_rn(cfl.rhs[o], __dmul_rn(-1.0, au));
+          const double res = __dadd_rn(rh[i], __dmul_rn(-1.0, au));
           const double ri = __dmul_rn(cfl.alpha, res);
-          const double pi = __dadd_rn(__dmul_rn(cfl.beta, cfl.p[o]), ri);
+          const double pi = __dadd_rn(__dmul_rn(cfl.beta, pp[i]), ri);
           if (cfl.r) cfl.r[o] = ri;
           cfl.p[o] = pi;
-          cfl.u_out[o] = __dadd_rn(u[o], pi);
+          cfl.u_out[o] = __dadd_rn(uu[i], pi);
         }
       }
     }
