@@ -37,13 +37,21 @@ namespace d4est_hip {
 // centro-antisymmetric) -- see stiffness_wave_eo_kernel for the table layout.  The EO form feeds its scalar operator rows through
 // the software-pipelined contract_single_eo (two rows in flight, a scheduling barrier per step): left to itself the compiler
 // hoists every row load of a stage and spills hundreds of SGPRs through v_readlane / v_writelane.
+#ifndef D4EST_HIP_DIRECT_IMM_ROWS
+#define D4EST_HIP_DIRECT_IMM_ROWS 1   /* 1 (default; config 2 apply_aij -3 %, Schwarz sweep -1 %, 11 % fewer scalar instructions): the operator rows through one laundered base pointer with immediate offsets (contract_rows_eo_imm) */
+#endif
+#if D4EST_HIP_DIRECT_IMM_ROWS
+#define D4EST_DIRECT_ROWS contract_rows_eo_imm
+#else
+#define D4EST_DIRECT_ROWS contract_rows_eo
+#endif
 template <int NI, int NO, bool EO, bool ANTI>
 __device__ __forceinline__ void prod(const double* __restrict__ tab, const double* x, double* y) {
   if constexpr (EO) {
     constexpr int HC = (NI + 1) / 2;
     double xe[HC], xo[HC], ab[NO];
     eo_pre<NI>(x, xe, xo);
-    contract_rows_eo<HC, NO, false>(tab, ANTI ? xo : xe, ANTI ? xe : xo, ab);   // one scalar row per step: 32 SGPRs in flight (the two-row
+    D4EST_DIRECT_ROWS<HC, NO, false>(tab, ANTI ? xo : xe, ANTI ? xe : xo, ab);   // one scalar row per step: 32 SGPRs in flight (the two-row
                                                                                 // form of the volume kernel measures the same here and needs 64)
     eo_post<NO>(ab, y);
   } else {
@@ -59,8 +67,8 @@ __device__ __forceinline__ void prod_pair(const double* __restrict__ tabS, const
     constexpr int HC = (NI + 1) / 2;
     double xe[HC], xo[HC], abS[NO], abA[NO];
     eo_pre<NI>(x, xe, xo);
-    contract_rows_eo<HC, NO, false>(tabS, xe, xo, abS);
-    contract_rows_eo<HC, NO, false>(tabA, xo, xe, abA);
+    D4EST_DIRECT_ROWS<HC, NO, false>(tabS, xe, xo, abS);
+    D4EST_DIRECT_ROWS<HC, NO, false>(tabA, xo, xe, abA);
     eo_post<NO>(abS, yS);
     eo_post<NO>(abA, yA);
   } else {
