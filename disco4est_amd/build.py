@@ -24,6 +24,7 @@ SOURCES = [
     "d4est_hip_direct_mw_hi.hip",
     "d4est_hip_solver.hip",
     "d4est_hip_transfer.hip",
+    "d4est_hip_mgmatrix.hip",
     "d4est_hip_schwarz.hip",
     "d4est_hip_comm.hip",
 ]

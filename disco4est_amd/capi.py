@@ -93,6 +93,13 @@ SIGNATURES = {
     "d4est_hip_build_rhs_with_strong_bc": (None, [_vp, _vp, ctypes.c_int, _vp]),
     "d4est_hip_build_rhs_with_strong_bc_host": (None, [_vp, _c_double_p, ctypes.c_int, _c_double_p]),
     "d4est_hip_plan_set_lhs_coefficient": (None, [_vp, _vp]),
+    "d4est_hip_plan_matrix_nodes": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_compute_weighted_mass_blocks": (None, [_vp, _vp, _vp]),
+    "d4est_hip_plan_set_lhs_element_blocks": (None, [_vp, _vp, _vp]),
+    "d4est_hip_plan_set_lhs_galerkin_chain": (None, [_vp, ctypes.c_int, _vp, _vp]),
+    "d4est_hip_transfer_fine_matrix_nodes": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_transfer_coarse_matrix_nodes": (ctypes.c_longlong, [_vp]),
+    "d4est_hip_transfer_galerkin_blocks": (None, [_vp, _vp, _vp, ctypes.c_int]),
     "d4est_hip_plan_set_comm": (None, [_vp, _vp, _vp, _vp]),
     "d4est_hip_apply_lhs": (None, [_vp, _vp, _vp]),
     "d4est_hip_cheby_iterate": (None, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]),
@@ -418,12 +425,41 @@ class Plan:
         self.lib.d4est_hip_build_rhs_with_strong_bc(self.handle, _ptr(f), int(bool(f_on_quad)), _ptr(rhs))
 
     def set_lhs_coefficient(self, coeff_quad):
-        """zeroth-order term of apply_lhs (+ V^T W J c V u): a float64 CUDA tensor of local_nodes_quad entries kept alive by the plan,
-        or None for the pure Laplacian"""
+        """zeroth-order term of apply_lhs (+ V^T W J c V u): a float64 CUDA tensor of local_nodes_quad entries, or None for the pure
+        Laplacian.  The VALUES ARE CAPTURED by this call (a plan-owned copy; the tensor is not read afterwards): call it again after
+        every change of u0.  The tensor must be complete on the plan's stream (or the device synchronised) when this is called."""
         self._lhs_coeff = coeff_quad
         if coeff_quad is not None:
             assert coeff_quad.numel() == self.local_nodes_quad
         self.lib.d4est_hip_plan_set_lhs_coefficient(self.handle, _ptr(coeff_quad) if coeff_quad is not None else None)
+
+    # ---- the multigrid matrix operator: the zeroth-order term on coarse levels (d4est_solver_multigrid_matrix_operator.c)
+    def matrix_nodes(self):
+        """d4est_mesh_get_local_matrix_nodes: sum of (deg+1)^6"""
+        return self.lib.d4est_hip_plan_matrix_nodes(self.handle)
+
+    def compute_weighted_mass_blocks(self, coeff_quad, blocks):
+        """QUAD_COMPUTE_MATRIX for every element: blocks = V^T (W J coeff) V, dense, consecutive (coeff_quad None: the mass matrix)"""
+        assert blocks.numel() == self.matrix_nodes()
+        self.lib.d4est_hip_compute_weighted_mass_blocks(self.handle, _ptr(coeff_quad) if coeff_quad is not None else None, _ptr(blocks))
+
+    def set_lhs_element_blocks(self, blocks, block_offset=None):
+        """zeroth-order term of apply_lhs as dense element blocks (read at every apply: the tensor is kept alive here); block_offset:
+        per-element offsets in doubles (a Schwarz subdomain plan: the mesh element's block) or None = consecutive"""
+        self._lhs_blocks = blocks
+        off = None
+        if block_offset is not None:
+            off = np.ascontiguousarray(block_offset, dtype=np.int64)
+            assert off.size == self.n_elements
+        self.lib.d4est_hip_plan_set_lhs_element_blocks(self.handle, _ptr(blocks) if blocks is not None else None,
+                                                       off.ctypes.data_as(_vp) if off is not None else None)
+
+    def set_lhs_galerkin_chain(self, transfers, fine_plan):
+        """zeroth-order term as the Galerkin chain T_0^T .. T_k^T (V^T W J c V)_fine T_k .. T_0 (transfers[0] starts at this plan's
+        level; fine_plan carries the coefficient); transfers = [] switches it off"""
+        self._lhs_chain = (list(transfers), fine_plan)
+        arr = (ctypes.c_void_p * max(len(transfers), 1))(*[t.handle for t in transfers])
+        self.lib.d4est_hip_plan_set_lhs_galerkin_chain(self.handle, len(transfers), arr, fine_plan.handle if fine_plan is not None else None)
 
     def apply_lhs(self, u, Au):
         self.lib.d4est_hip_apply_lhs(self.handle, _ptr(u), _ptr(Au))
@@ -485,6 +521,13 @@ class Transfer:
     def restrict(self, x_fine, x_coarse):
         assert x_coarse.numel() == self.coarse_nodes and x_fine.numel() == self.fine_nodes
         self.lib.d4est_hip_transfer_restrict(self.handle, _ptr(x_fine), _ptr(x_coarse))
+
+    def galerkin_blocks(self, fine_blocks, coarse_blocks, literal_window=False):
+        """coarse block k = sum over the item's children of P^T M P (the multigrid matrix operator's restriction callback);
+        literal_window: the reference's arithmetic to the letter on items with eight children (d4est_operators.c:651)"""
+        assert fine_blocks.numel() == self.lib.d4est_hip_transfer_fine_matrix_nodes(self.handle)
+        assert coarse_blocks.numel() == self.lib.d4est_hip_transfer_coarse_matrix_nodes(self.handle)
+        self.lib.d4est_hip_transfer_galerkin_blocks(self.handle, _ptr(fine_blocks), _ptr(coarse_blocks), int(bool(literal_window)))
 
     def project(self, x_fine, x_coarse):
         """L2 projection onto the coarse space (apply_p_restrict / apply_hp_restrict per item)"""

@@ -37,6 +37,9 @@ void check_plan(const d4est_hip_plan_t* plan, const char* fn) {
 static void drop_graph(d4est_hip_plan_t* plan) {
   if (plan->cheby_graph) { (void)hipGraphExecDestroy(plan->cheby_graph); plan->cheby_graph = nullptr; }
   ++plan->op_generation;   // (every caller of this function changes the plan's state)
+  // w J c of the fused operator kernels is derived from J and the coefficient: every setter that can change either comes through here
+  // (plan_set_jacobian included), so the cached stream can never outlive its inputs
+  plan->lhs_wjc_valid = false;
 }
 
 }  // namespace
@@ -242,6 +245,8 @@ void d4est_hip_plan_destroy(d4est_hip_plan_t* plan) {
   (void)hipFree(plan->d_scratch);
   d4est_hip::faces_destroy(plan);
   (void)hipFree(plan->d_work_p); (void)hipFree(plan->d_work_d); (void)hipFree(plan->d_work_r); (void)hipFree(plan->d_work_m); (void)hipFree(plan->d_lhs_c); (void)hipFree(plan->d_lhs_wjc);
+  (void)hipFree(plan->d_lhs_block_off);
+  d4est_hip::lhs_chain_destroy(plan);
   (void)hipFree(plan->d_reduce); (void)hipFree(plan->d_ghost_trace);
   if (plan->h_stage) (void)hipHostFree(plan->h_stage);
   for (int i = 0; i < 4; ++i) (void)hipFree(plan->d_host[i]);
@@ -448,6 +453,10 @@ void d4est_hip_plan_set_lhs_coefficient(d4est_hip_plan_t* plan, const double* co
   drop_graph(plan);
   plan->d_lhs_coeff = coeff_quad_dev;
   plan->lhs_wjc_valid = false;
+  if (coeff_quad_dev) {   // one form of the zeroth-order term at a time: the coefficient replaces element blocks / a Galerkin chain
+    plan->d_lhs_blocks = nullptr;
+    d4est_hip::lhs_chain_destroy(plan);
+  }
   if (coeff_quad_dev) {   // the values are CAPTURED here (see d4est_hip.h): a copy for the separate mass kernel, w J c for the fused operator kernels
     const size_t nq = std::max<size_t>((size_t)plan->local_nodes_quad, 1);
     if (!plan->d_lhs_c) HIP_CHECK(hipMalloc(&plan->d_lhs_c, nq * sizeof(double)));

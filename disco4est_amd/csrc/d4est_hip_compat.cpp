@@ -310,7 +310,7 @@ static void fofu_fofv(d4est_operators_t* ops, d4est_geometry_t* geom, d4est_quad
     if (u) { uq.resize(nq); d4est_quadrature_interpolate(ops, quad, geom, object, object_type, integrand_type, u, deg_lobatto, uq.data(), deg_quad); }
     if (v) { vq.resize(nq); d4est_quadrature_interpolate(ops, quad, geom, object, object_type, integrand_type, v, deg_lobatto, vq.data(), deg_quad); }
     for (int i = 0; i < nq; ++i) {
-      const double z = (dim == 3) ? xyz_quad[2][i] : 0.0;
+      const double z = xyz_quad[2][i];   // d8est build: z is always passed (d4est_quadrature.c:660-690 under #if P4EST_DIM==3), mortar objects included
       double f = scale ? scale[i] : 1.0;
       if (use_u) f *= fofu_fcn(xyz_quad[0][i], xyz_quad[1][i], z, u ? uq[i] : 0.0, fofu_ctx);
       if (use_v) f *= fofv_fcn(xyz_quad[0][i], xyz_quad[1][i], z, v ? vq[i] : 0.0, fofv_ctx);
@@ -320,7 +320,7 @@ static void fofu_fofv(d4est_operators_t* ops, d4est_geometry_t* geom, d4est_quad
     if (!xyz_lobatto) COMPAT_ABORT("interpolate_f == 1, but xyz_lobatto == NULL");
     std::vector<double> fl(nl, 1.0);
     for (int i = 0; i < nl; ++i) {
-      const double z = (dim == 3) ? xyz_lobatto[2][i] : 0.0;
+      const double z = xyz_lobatto[2][i];
       if (use_u) fl[i] *= fofu_fcn(xyz_lobatto[0][i], xyz_lobatto[1][i], z, u ? u[i] : 0.0, fofu_ctx);
       if (use_v) fl[i] *= fofv_fcn(xyz_lobatto[0][i], xyz_lobatto[1][i], z, v ? v[i] : 0.0, fofv_ctx);
     }
@@ -330,20 +330,52 @@ static void fofu_fofv(d4est_operators_t* ops, d4est_geometry_t* geom, d4est_quad
   }
 }
 
-// out = V^T W [J f(x,u) f(x,v)] V vec  (QUAD_APPLY_MATRIX; the dense-matrix form QUAD_COMPUTE_MATRIX is not served)
+// :1143-1186: the dense element matrix, column i = the mass apply of the i-th unit vector (d4est_linalg_set_column).  Volume objects: all
+// columns of the one-element plan in one device call (d4est_hip_compute_weighted_mass_blocks); mortar objects (dim - 1): on the host
+void d4est_quadrature_compute_mass_matrix(d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t* d4est_quadrature, void*,
+                                          d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t, int deg_lobatto,
+                                          double* jac_quad, int deg_quad, double* out) {
+  if (object_type == QUAD_OBJECT_MORTAR) {
+    const Tab2& t = tab2(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature));
+    const int n = t.N * t.N;
+    std::vector<double> u((size_t)n, 0.0), q((size_t)t.NQ * t.NQ), Mu((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      u[i] = 1.0;
+      interp2(t, u.data(), q.data());
+      galerkin2(t, q.data(), jac_quad, Mu.data());
+      for (int r = 0; r < n; ++r) out[(size_t)r * n + i] = Mu[r];
+      u[i] = 0.0;
+    }
+    return;
+  }
+  need_volume(object_type, "d4est_quadrature_compute_mass_matrix");
+  ElemCtx& c = elem_ctx(deg_lobatto, deg_quad, quad_type_of(d4est_quadrature));
+  upload_jacobian(c, jac_quad);
+  const size_t nn = (size_t)c.N3 * c.N3;
+  double* d_blk = (double*)d4est_hip_malloc(sizeof(double) * nn);
+  d4est_hip_compute_weighted_mass_blocks(c.plan, nullptr, d_blk);
+  d4est_hip_memcpy_d2h(out, d_blk, sizeof(double) * nn);
+  d4est_hip_free(d_blk);
+}
+
+// out = V^T W [J f(x,u) f(x,v)] V vec (QUAD_APPLY_MATRIX), or the dense element matrix of that operator (QUAD_COMPUTE_MATRIX: what
+// d4est_solver_multigrid_matrix_setup_fofufofvlilj_operator asks for per element, Solver/d4est_solver_multigrid_matrix_operator.c:215-238)
 void d4est_quadrature_apply_fofufofvlilj(d4est_operators_t* d4est_ops, d4est_geometry_t* d4est_geom, d4est_quadrature_t* d4est_quad, void* object,
                                          d4est_quadrature_object_type_t object_type, d4est_quadrature_integrand_type_t integrand_type,
                                          double* vec, double* u, double* v, int deg_lobatto, double* xyz_quad[3], double* jac_quad, int deg_quad,
                                          double* out, d4est_xyzu_fcn_t fofu_fcn, void* fofu_ctx, d4est_xyzu_fcn_t fofv_fcn, void* fofv_ctx,
                                          d4est_quadrature_apply_or_compute_matrix_t apply_or_compute_matrix, int interpolate_f,
                                          double* xyz_lobatto[3]) {
-  if (apply_or_compute_matrix != QUAD_APPLY_MATRIX)
-    COMPAT_ABORT("d4est_quadrature_apply_fofufofvlilj: QUAD_COMPUTE_MATRIX (the dense element matrix) is not served; apply it to unit vectors");
-  if (!vec) COMPAT_ABORT("d4est_quadrature_apply_fofufofvlilj: vec == NULL");
+  if (apply_or_compute_matrix != QUAD_APPLY_MATRIX && apply_or_compute_matrix != QUAD_COMPUTE_MATRIX)
+    COMPAT_ABORT("d4est_quadrature_apply_fofufofvlilj: Not a supported option");   // d4est_quadrature.c:762
+  if (apply_or_compute_matrix == QUAD_APPLY_MATRIX && !vec) COMPAT_ABORT("d4est_quadrature_apply_fofufofvlilj: vec == NULL");
   std::vector<double> fj;
   fofu_fofv(d4est_ops, d4est_geom, d4est_quad, object, object_type, integrand_type, u, v, deg_lobatto, xyz_quad, deg_quad, fofu_fcn, fofu_ctx,
             fofv_fcn, fofv_ctx, interpolate_f, xyz_lobatto, jac_quad, fj);
-  d4est_quadrature_apply_mass_matrix(d4est_ops, d4est_geom, d4est_quad, object, object_type, integrand_type, vec, deg_lobatto, fj.data(), deg_quad, out);
+  if (apply_or_compute_matrix == QUAD_APPLY_MATRIX)
+    d4est_quadrature_apply_mass_matrix(d4est_ops, d4est_geom, d4est_quad, object, object_type, integrand_type, vec, deg_lobatto, fj.data(), deg_quad, out);
+  else
+    d4est_quadrature_compute_mass_matrix(d4est_ops, d4est_geom, d4est_quad, object, object_type, integrand_type, deg_lobatto, fj.data(), deg_quad, out);
 }
 
 // out = V^T W J [f(x,u) f(x,v)]
@@ -417,6 +449,40 @@ void d4est_operators_apply_p_restrict(d4est_operators_t*, double* in, int degh, 
 void d4est_operators_apply_hp_restrict(d4est_operators_t*, double* in, int* degh, int dim, int degH, double* out) {   // :1275-1297
   need_dim3(dim, "d4est_operators_apply_hp_restrict");
   transfer_run(transfer_of(1, degH, degh), 2, in, out);
+}
+// :572-605: the dense prolongation (sum_i (degh_i+1)^3) x (degH+1)^3, column i = P e_i
+void d4est_operators_compute_prolong_matrix(d4est_operators_t* ops, int degH, int dim, int* degh, int children, double* prolong_mat) {
+  need_dim3(dim, "d4est_operators_compute_prolong_matrix");
+  if (children != 1 && children != 8) COMPAT_ABORT("d4est_operators_compute_prolong_matrix: children = %d", children);
+  const size_t nH = (size_t)(degH + 1) * (degH + 1) * (degH + 1);
+  size_t nh = 0;
+  for (int i = 0; i < children; ++i) nh += (size_t)(degh[i] + 1) * (degh[i] + 1) * (degh[i] + 1);
+  std::vector<double> u(nH, 0.0), Mu(nh);
+  for (size_t i = 0; i < nH; ++i) {
+    u[i] = 1.0;
+    if (children == 8) d4est_operators_apply_hp_prolong(ops, u.data(), degH, dim, degh, Mu.data());
+    else d4est_operators_apply_p_prolong(ops, u.data(), degH, dim, degh[0], Mu.data());
+    for (size_t r = 0; r < nh; ++r) prolong_mat[r * nH + i] = Mu[r];
+    u[i] = 0.0;
+  }
+}
+// :608-667: PT_mat_P = sum_i P_i^T mat_i P_i on the device (d4est_hip_transfer_galerkin_blocks of a one-item transfer).  With eight
+// children the reference's own arithmetic reads a window of the transposed stacked prolongation as the left factor (:651), which is not
+// P_i^T; D4EST_HIP_REFERENCE_PT_WINDOW=1 in the environment reproduces that to the letter, the default is the Galerkin product
+void d4est_operators_compute_PT_mat_P(d4est_operators_t*, double* mat, int degH, int dim, int* degh, int children, double* PT_mat_P) {
+  need_dim3(dim, "d4est_operators_compute_PT_mat_P");
+  if (children != 1 && children != 8) COMPAT_ABORT("d4est_operators_compute_PT_mat_P: children = %d", children);
+  static const bool literal = std::getenv("D4EST_HIP_REFERENCE_PT_WINDOW") != nullptr && std::atoi(std::getenv("D4EST_HIP_REFERENCE_PT_WINDOW")) != 0;
+  d4est_hip_transfer_t* t = transfer_of(children == 8 ? 1 : 0, degH, degh);
+  const size_t nf = (size_t)d4est_hip_transfer_fine_matrix_nodes(t), nc = (size_t)d4est_hip_transfer_coarse_matrix_nodes(t);
+  double* d_f = (double*)d4est_hip_malloc(sizeof(double) * nf);
+  double* d_c = (double*)d4est_hip_malloc(sizeof(double) * nc);
+  d4est_hip_memcpy_h2d(d_f, mat, sizeof(double) * nf);
+  d4est_hip_transfer_galerkin_blocks(t, d_f, d_c, literal ? 1 : 0);
+  d4est_hip_device_synchronize();
+  d4est_hip_memcpy_d2h(PT_mat_P, d_c, sizeof(double) * nc);
+  d4est_hip_free(d_f);
+  d4est_hip_free(d_c);
 }
 void d4est_operators_apply_p_prolong_transpose(d4est_operators_t*, double* in, int degh, int dim, int degH, double* out) {   // :1719-1749
   need_dim3(dim, "d4est_operators_apply_p_prolong_transpose");

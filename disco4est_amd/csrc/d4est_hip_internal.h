@@ -120,6 +120,11 @@ struct d4est_hip_plan {
   double* d_lhs_wjc = nullptr;           // w J c at the quadrature nodes (one stream for the operator kernels' volume stage)
   bool lhs_wjc_valid = false;
   double* d_work_m = nullptr;            // scratch of that term
+  // the same term on a coarse multigrid level (d4est_hip_mgmatrix.hip): dense element blocks (the caller's array; non-null = this form
+  // is on) with one offset per element, or the Galerkin chain through transfer objects up to a fine plan's coefficient
+  const double* d_lhs_blocks = nullptr;
+  long long* d_lhs_block_off = nullptr;
+  void* lhs_chain = nullptr;             // d4est_hip::LhsChain
   hipStream_t side_stream = nullptr;  // the trace kernel (and the exchange) run here, concurrently with the volume kernel
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // D4EST_HIP_TUNE_GRAPH: the last cheby_iterate call captured as a hipGraph (replayed while the arguments stay the same)
@@ -226,7 +231,14 @@ void launch_residual(d4est_hip_plan* plan, int n, const double* rhs, const doubl
 void launch_residual_inplace(d4est_hip_plan* plan, int n, const double* rhs, double* r);              // r = rhs - r
 void launch_residual_inplace_sub(d4est_hip_plan* plan, int n, const double* a, double* r);            // r = r - a
 void ensure_solver_workspace(d4est_hip_plan* plan);
-void add_lhs_mass_term(d4est_hip_plan* plan, const double* u, double* Au);   // Au += V^T W J c V u when a coefficient is set
+void add_lhs_mass_term(d4est_hip_plan* plan, const double* u, double* Au);   // Au += the plan's zeroth-order term, whichever form is set
+// d4est_hip_mgmatrix.hip: the term as dense element blocks / as a Galerkin chain (multigrid matrix operator)
+void add_lhs_blocks_term(d4est_hip_plan* plan, const double* u, double* Au);
+void add_lhs_chain_term(d4est_hip_plan* plan, const double* u, double* Au);
+void lhs_chain_destroy(d4est_hip_plan* plan);
+// the term has a form that the fused operator kernels do not carry (blocks or chain): the volume kernel runs on its own and the term
+// is added before the flux kernel
+inline bool lhs_extra_term(const d4est_hip_plan* plan) { return plan->d_lhs_blocks != nullptr || plan->lhs_chain != nullptr; }
 const double* ensure_lhs_wjc(d4est_hip_plan* plan);   // w J c at the quadrature nodes (formed on first use after the coefficient / geometry changed)
 void launch_copy_blocks(hipStream_t stream, int n_blocks, const double* src, const long long* src_off, double* dst,
                         const long long* dst_off, const int* len);

@@ -158,7 +158,9 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
     // one-kernel face terms (d4est_hip_direct.hip): both sides' traces come from u inside the kernel; with ghost sides the trace
     // kernel still runs, to feed the exchange
     const bool mass = lhs_term && plan->d_lhs_coeff;
-    const bool fused = direct_fused_ok(plan);
+    // a zeroth-order term held as dense element blocks or as a Galerkin chain (coarse multigrid levels) is not part of the fused
+    // kernels' volume stage: volume kernel, the term, then the face kernel
+    const bool fused = direct_fused_ok(plan) && !(lhs_term && lhs_extra_term(plan));
     auto run = [&](int vterm) {
       if (cf) {
         DirectFuse df;
@@ -241,6 +243,9 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
 // the zeroth-order term of a linearised nonlinear problem (d4est_quadrature_apply_fofufofvlilj per element, added with axpy 1.0:
 // e.g. constant_density_star_apply_jac_add_nonlinear_term, src/Problems/ConstantDensityStar/constant_density_star_fcns.h:528-603)
 void add_lhs_mass_term(d4est_hip_plan* plan, const double* u, double* Au) {
+  // on a coarse multigrid level the reference adds the Galerkin-restricted term instead (constant_density_star_fcns.h:806-850)
+  if (plan->d_lhs_blocks) { add_lhs_blocks_term(plan, u, Au); return; }
+  if (plan->lhs_chain) { add_lhs_chain_term(plan, u, Au); return; }
   if (!plan->d_lhs_coeff || plan->local_nodes == 0) return;
   const int n = plan->local_nodes;
   if (!plan->d_work_m) HIP_CHECK(hipMalloc(&plan->d_work_m, (size_t)n * sizeof(double)));

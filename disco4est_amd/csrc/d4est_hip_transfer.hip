@@ -15,51 +15,9 @@
 
 #include "d4est_hip_internal.h"
 #include "d4est_hip_tables.h"
-
-struct d4est_hip_transfer {
-  int n_items = 0, n_children = 0;
-  long long coarse_nodes = 0, fine_nodes = 0;
-  int max_n = 1;
-  int* d_child = nullptr;      // per (item, child): 8 ints {item, NH, Nh, off_x, off_y, off_z, first child of item?, n children of item}
-  long long* d_off = nullptr;  // per (item, child): {coarse offset, fine offset}
-  int* d_item_first = nullptr; // per item: index of its first child record (n_items + 1)
-  double* d_ops = nullptr;
-  double* d_rops = nullptr;    // the L2-projection operators (p_restrict / hp_restrict) at the same offsets as the prolongations
-  hipStream_t stream = nullptr;
-};
+#include "d4est_hip_transfer.h"
 
 namespace d4est_hip {
-
-// out (n_out^3) = (Az (x) Ay (x) Ax) in (n_in^3), A* given as n_out x n_in (TRANS = false) or applied transposed
-// (A* is n_in x n_out, TRANS = true).  in/out/tmp are LDS arrays of >= max(n_in, n_out)^3 doubles.
-template <bool TRANS>
-__device__ inline void tensor3(const double* __restrict__ Ax, const double* __restrict__ Ay, const double* __restrict__ Az, int n_in,
-                               int n_out, double* a, double* b) {
-  // x: a [n_in z][n_in y][n_in x] -> b [z][y][n_out]
-  for (int idx = threadIdx.x; idx < n_in * n_in * n_out; idx += blockDim.x) {
-    const int o = idx % n_out, r = idx / n_out;
-    double s = 0.0;
-    for (int i = 0; i < n_in; ++i) s = fma(TRANS ? Ax[i * n_out + o] : Ax[o * n_in + i], a[r * n_in + i], s);
-    b[r * n_out + o] = s;
-  }
-  __syncthreads();
-  // y: b [z][n_in y][n_out x] -> a [z][n_out][n_out]
-  for (int idx = threadIdx.x; idx < n_in * n_out * n_out; idx += blockDim.x) {
-    const int x = idx % n_out, o = (idx / n_out) % n_out, z = idx / (n_out * n_out);
-    double s = 0.0;
-    for (int i = 0; i < n_in; ++i) s = fma(TRANS ? Ay[i * n_out + o] : Ay[o * n_in + i], b[(z * n_in + i) * n_out + x], s);
-    a[(z * n_out + o) * n_out + x] = s;
-  }
-  __syncthreads();
-  // z: a [n_in z][n_out][n_out] -> b [n_out][n_out][n_out]
-  for (int idx = threadIdx.x; idx < n_out * n_out * n_out; idx += blockDim.x) {
-    const int xy = idx % (n_out * n_out), o = idx / (n_out * n_out);
-    double s = 0.0;
-    for (int i = 0; i < n_in; ++i) s = fma(TRANS ? Az[i * n_out + o] : Az[o * n_in + i], a[i * n_out * n_out + xy], s);
-    b[idx] = s;
-  }
-  __syncthreads();
-}
 
 // one workgroup per fine element
 __global__ __launch_bounds__(256) void prolong_kernel(const double* __restrict__ xc, double* __restrict__ xf,
@@ -151,8 +109,11 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
     return o;
   };
   std::vector<int> child, item_first(n_items + 1, 0);
-  std::vector<long long> off;
-  long long co = 0, fo = 0;
+  std::vector<long long> off, moff, coff;
+  long long co = 0, fo = 0, fm = 0, cm = 0, wk = 0;
+  t->h_hrefine.assign(hrefine, hrefine + n_items);
+  t->h_degH.assign(degH, degH + n_items);
+  t->h_degh.assign(degh, degh + 8 * (size_t)n_items);
   for (int it = 0; it < n_items; ++it) {
     item_first[it] = (int)(child.size() / 8);
     const int dH = degH[it];
@@ -175,11 +136,23 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
       child.insert(child.end(), rec, rec + 8);
       off.push_back(co);
       off.push_back(fo);
+      // dense element blocks of the multigrid matrix operator: consecutive, (deg+1)^3 x (deg+1)^3 each, in the same traversal order
+      // (fine_matrix_stride / coarse_matrix_stride of Solver/d4est_solver_multigrid_matrix_operator.c:19-46)
+      const long long nh3 = (long long)nh * nh * nh, nH3 = (long long)nH * nH * nH;
+      moff.push_back(fm);
+      moff.push_back(wk);
+      fm += nh3 * nh3;
+      wk += nh3 * nH3;
       fo += (long long)nh * nh * nh;
       t->max_n = std::max(t->max_n, std::max(nH, nh));
     }
+    coff.push_back(cm);
+    cm += (long long)(dH + 1) * (dH + 1) * (dH + 1) * (dH + 1) * (dH + 1) * (dH + 1);
     co += (long long)(dH + 1) * (dH + 1) * (dH + 1);
   }
+  t->fine_matrix_nodes = fm;
+  t->coarse_matrix_nodes = cm;
+  t->work_doubles = wk;
   item_first[n_items] = (int)(child.size() / 8);
   // the kernels keep two fields of max_n^3 doubles in the LDS (the restriction / projection a third one for the sum over the children
   // up to p = 17; above that the sum lives in the output vector): the reference's degree range p <= 19 (d4est_operators.c:1205-1297) fits.
@@ -193,8 +166,10 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
   auto up_i = [](const std::vector<int>& v) { int* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(int))); if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice)); return d; };
   t->d_child = up_i(child);
   t->d_item_first = up_i(item_first);
-  HIP_CHECK(hipMalloc(&t->d_off, std::max<size_t>(off.size(), 1) * sizeof(long long)));
-  if (!off.empty()) HIP_CHECK(hipMemcpy(t->d_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
+  auto up_l = [](const std::vector<long long>& v) { long long* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(long long))); if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(long long), hipMemcpyHostToDevice)); return d; };
+  t->d_off = up_l(off);
+  t->d_moff = up_l(moff);
+  t->d_coff = up_l(coff);
   HIP_CHECK(hipMalloc(&t->d_ops, std::max<size_t>(ops.size(), 1) * sizeof(double)));
   if (!ops.empty()) HIP_CHECK(hipMemcpy(t->d_ops, ops.data(), ops.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_CHECK(hipMalloc(&t->d_rops, std::max<size_t>(rops.size(), 1) * sizeof(double)));
@@ -205,6 +180,7 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
 void d4est_hip_transfer_destroy(d4est_hip_transfer_t* t) {
   if (!t) return;
   (void)hipFree(t->d_child); (void)hipFree(t->d_off); (void)hipFree(t->d_item_first); (void)hipFree(t->d_ops); (void)hipFree(t->d_rops);
+  (void)hipFree(t->d_moff); (void)hipFree(t->d_coff); (void)hipFree(t->d_work); (void)hipFree(t->d_window); (void)hipFree(t->d_woff);
   delete t;
 }
 

@@ -327,6 +327,13 @@ class Schwarz:
         assert self.nodal_size == md.nodal_size and self.restricted_nodal_size == md.restricted_nodal_size
         self.local_nodes = mesh.local_nodes
 
+    def set_lhs_element_blocks(self, blocks, mesh):
+        """the zeroth-order term of a coarse multigrid level (dense element blocks, consecutive in the MESH's element order) as part of
+        the subdomain operator: copy k of mesh element e reads e's block"""
+        n3 = (mesh.deg.astype(np.int64) + 1) ** 3
+        off = np.concatenate([[0], np.cumsum(n3 * n3)[:-1]])
+        self.plan.set_lhs_element_blocks(blocks, None if blocks is None else off[self.metadata.sub_elem])
+
     def condensed_copies(self):
         """element copies whose operator rows are dense blocks (corner copies of conforming one-degree subdomains); 0 = none"""
         return int(self.lib.d4est_hip_schwarz_condensed_copies(self.handle))

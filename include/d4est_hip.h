@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 typedef struct d4est_hip_plan d4est_hip_plan_t;
+typedef struct d4est_hip_transfer d4est_hip_transfer_t;   /* hp-multigrid inter-grid transfer, see below */
 
 /* quadrature types (reference: [quadrature] name = legendre | lobatto,
  * src/Quadrature/d4est_quadrature_legendre.c:6-20, d4est_quadrature_lobatto.c:6-21) */
@@ -290,6 +291,37 @@ void d4est_hip_build_rhs_with_strong_bc_host(d4est_hip_plan_t* plan, const doubl
  * The term then is part of d4est_hip_apply_lhs, _cheby_iterate, _cg_eigs and _schwarz_smooth; set on a Schwarz subdomain plan
  * (same array: the copies' quad_stride alias it) it is part of the subdomain operator.  d4est_hip_apply_aij stays the Laplacian. */
 void d4est_hip_plan_set_lhs_coefficient(d4est_hip_plan_t* plan, const double* coeff_quad_dev);
+/* ---- the multigrid MATRIX OPERATOR: the zeroth-order term on the coarse levels (csrc/d4est_hip_mgmatrix.hip) -------------------------
+ * With use_matrix_operator = 1 (e.g. constant_density_star_mgpc_newton_petsc.c:591-602) the reference holds the term
+ * V^T W J f(x, u0) V as ONE DENSE BLOCK PER ELEMENT on the finest level (d4est_solver_multigrid_matrix_setup_fofufofvlilj_operator,
+ * src/Solver/d4est_solver_multigrid_matrix_operator.c:160-245: d4est_quadrature_apply_fofufofvlilj with QUAD_COMPUTE_MATRIX), restricts
+ * the blocks level by level with the Galerkin product  sum_children P_c^T M_c P_c  (the restriction callback :6-48 ->
+ * d4est_operators_compute_PT_mat_P, src/dGMath/d4est_operators.c:608-667), and the smoother's apply_lhs on every level below the finest
+ * adds M_e u_e per element (constant_density_star_apply_jac_add_nonlinear_term_using_matrix,
+ * src/Problems/ConstantDensityStar/constant_density_star_fcns.h:485-527, selected at :806-850 when matrix_op->matrix != matrix_at0).
+ * Block layout = the reference's matrix_op->matrix: element e's (deg_e+1)^3 x (deg_e+1)^3 row-major block, blocks consecutive in
+ * element order (d4est_mesh_get_local_matrix_nodes doubles in all).
+ * The plan carries the term in ONE of three forms (each setter replaces the others; NULL switches its own form off):
+ *   d4est_hip_plan_set_lhs_coefficient     the coefficient field (finest level; fused into the operator kernels)
+ *   d4est_hip_plan_set_lhs_element_blocks  dense blocks (the reference's coarse-level form; 8 (deg+1)^3 bytes per DoF per apply)
+ *   d4est_hip_plan_set_lhs_galerkin_chain  the same Galerkin operator applied matrix-free through the transfer objects and the FINE
+ *                                          plan's coefficient: T_0^T .. T_{k-1}^T (V^T W J c V) T_{k-1} .. T_0 u -- 8 bytes per fine
+ *                                          quadrature node per apply instead of the blocks (cheaper than blocks while
+ *                                          fine quadrature nodes < (deg+1)^6 coarse entries, i.e. for up to two h-levels at equal p)
+ * all three are part of d4est_hip_apply_lhs, _cheby_iterate, _cg_eigs; coefficient and blocks also of the Schwarz subdomain operator
+ * (on a subdomain plan pass block_offset_host: the block of copy k is the block of its mesh element). */
+/* d4est_mesh_get_local_matrix_nodes: sum over the elements of (deg+1)^6 */
+long long d4est_hip_plan_matrix_nodes(const d4est_hip_plan_t* plan);
+/* QUAD_COMPUTE_MATRIX for every element (d4est_quadrature.c:748-760, :1143-1186: the weighted mass matrix applied to the unit vectors,
+ * column by column): blocks_dev[d4est_hip_plan_matrix_nodes] = V^T (W J coeff) V per element; coeff_quad_dev == NULL: the mass matrix */
+void d4est_hip_compute_weighted_mass_blocks(d4est_hip_plan_t* plan, const double* coeff_quad_dev, double* blocks_dev);
+/* blocks_dev stays the caller's (read at every apply); block_offset_host (n_elements, in doubles) or NULL = consecutive */
+void d4est_hip_plan_set_lhs_element_blocks(d4est_hip_plan_t* plan, const double* blocks_dev, const long long* block_offset_host);
+/* transfers[0]: this plan's level <-> the next finer level, ..., transfers[n-1]: <-> fine_plan's level; fine_plan has its geometry and
+ * its coefficient (d4est_hip_plan_set_lhs_coefficient) set; the objects stay the caller's and must outlive the plan's use of them;
+ * n_transfers = 0 switches the form off.  Runs on this plan's stream. */
+void d4est_hip_plan_set_lhs_galerkin_chain(d4est_hip_plan_t* plan, int n_transfers, d4est_hip_transfer_t* const* transfers,
+                                           d4est_hip_plan_t* fine_plan);
 /* ---- smoother inner loops (device resident) -----------------------------------------------------------
  * Communication hooks for plans with ghost elements / several ranks (replace the reference's MPI calls:
  * d4est_ghost_data_exchange, src/Mesh/d4est_ghost_data.c:143-256, and sc_allreduce, d4est_solver_cg_eigs.c:181-243).
@@ -417,7 +449,6 @@ void d4est_hip_plan_synchronize(d4est_hip_plan_t* plan);
  * copied child by child) is hrefine = 0 with degh = degH.  Both vectors are element-ordered and contiguous in item order, like the
  * reference's fine_stride / coarse_stride.  degh >= degH as the reference asserts (d4est_operators.c:379).  Degrees up to 17: the
  * restriction kernels hold three (deg+1)^3 fields in the 160 KB LDS; d4est_hip_transfer_create aborts above that. */
-typedef struct d4est_hip_transfer d4est_hip_transfer_t;
 d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine, const int* degH, const int* degh);
 void d4est_hip_transfer_destroy(d4est_hip_transfer_t* t);
 void d4est_hip_transfer_set_stream(d4est_hip_transfer_t* t, void* hip_stream);
@@ -430,6 +461,18 @@ void d4est_hip_transfer_restrict(d4est_hip_transfer_t* t, const double* x_fine_d
 /* x_coarse = L2 projection of x_fine (d4est_operators_apply_p_restrict / _hp_restrict per item, src/dGMath/d4est_operators.c:1205-1230,
  * :1275-1297: M_H^-1 P^T M_h, children summed; the restriction of FIELDS, e.g. of the solution when the mesh is coarsened) */
 void d4est_hip_transfer_project(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev);
+
+/* The restriction of the multigrid matrix operator's element blocks through this transfer's item list (the restriction callback of
+ * src/Solver/d4est_solver_multigrid_matrix_operator.c:6-48 for every coarse element): coarse block k = sum_c P_c^T M_c P_c over the item's
+ * children (d4est_operators_compute_PT_mat_P, src/dGMath/d4est_operators.c:608-667); blocks consecutive in traversal order on both grids
+ * (fine_matrix_stride / coarse_matrix_stride); an item that is a copy (hrefine 0, degh = degH) copies its block.
+ * literal_window = 0: the Galerkin product as written above.  literal_window = 1: the reference's arithmetic to the letter -- at :651 it
+ * takes child c's left factor as a window of the transposed STACKED prolongation (&PT[stride_P] read as (degH+1)^3 x (degh_c+1)^3), which
+ * equals P_c^T for one child but interleaves rows of different children for eight; a d4est build therefore holds THAT block on
+ * h-coarsened levels (non-symmetric).  The chain form above is the exact product by construction. */
+long long d4est_hip_transfer_fine_matrix_nodes(const d4est_hip_transfer_t* t);
+long long d4est_hip_transfer_coarse_matrix_nodes(const d4est_hip_transfer_t* t);
+void d4est_hip_transfer_galerkin_blocks(d4est_hip_transfer_t* t, const double* fine_blocks_dev, double* coarse_blocks_dev, int literal_window);
 
 /* ---- additive Schwarz smoother ------------------------------------------------------------
  * Replaces d4est_solver_schwarz_iterate (src/Solver/d4est_solver_schwarz.c:172-285) with its CG subdomain solver

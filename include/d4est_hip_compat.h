@@ -86,9 +86,12 @@ void d4est_quadrature_apply_inverse_mass_matrix(d4est_operators_t *d4est_ops,dou
 /* the mass terms of the nonlinear problems with their user callbacks (d4est_quadrature.h:135, :138; d4est_quadrature.c:776-936, :593-774),
  * called directly by the Problem files (src/Problems/ConstantDensityStar/constant_density_star_fcns.h:407, :575): the callbacks are host
  * function pointers, evaluated on the host at the quadrature nodes (or, interpolate_f, at the Lobatto nodes), the integrals run through
- * the shims above.  QUAD_COMPUTE_MATRIX (the dense element matrix) aborts.  interpolate / apply_mass_matrix / apply_galerkin_integral
+ * the shims above.  QUAD_COMPUTE_MATRIX (the dense element matrix the multigrid matrix operator asks for,
+ * src/Solver/d4est_solver_multigrid_matrix_operator.c:215-238) is d4est_quadrature_compute_mass_matrix (:1143-1186) with jac * f(u) f(v): all
+ * columns in one device call.  interpolate / apply_mass_matrix / apply_galerkin_integral
  * and these two also serve QUAD_OBJECT_MORTAR objects (dim - 1, on the host), as the reference's estimators and mesh update need. */
 void d4est_quadrature_apply_fofufofvlj(d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,void *object,d4est_quadrature_object_type_t object_type,d4est_quadrature_integrand_type_t integrand_type,double *u,double *v,int deg_lobatto,double *jac_quad,double *xyz_quad[3],int deg_quad,double *out,d4est_xyzu_fcn_t fofu_fcn,void *fofu_ctx,d4est_xyzu_fcn_t fofv_fcn,void *fofv_ctx,int interpolate_f,double *xyz_lobatto[3]);
+void d4est_quadrature_compute_mass_matrix(d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geometry,d4est_quadrature_t *d4est_quadrature,void *object,d4est_quadrature_object_type_t object_type,d4est_quadrature_integrand_type_t integrand_type,int deg_lobatto,double *jac_quad,int deg_quad,double *out);
 void d4est_quadrature_apply_fofufofvlilj(d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,void *object,d4est_quadrature_object_type_t object_type,d4est_quadrature_integrand_type_t integrand_type,double *vec,double *u,double *v,int deg_lobatto,double *xyz_quad[3],double *jac_quad,int deg_quad,double *out,d4est_xyzu_fcn_t fofu_fcn,void *fofu_ctx,d4est_xyzu_fcn_t fofv_fcn,void *fofv_ctx,d4est_quadrature_apply_or_compute_matrix_t apply_or_compute_matrix,int interpolate_f,double *xyz_lobatto[3]);
 
 /* ---- element level: src/dGMath/d4est_operators.h:69-126 -------------------------------------------------------------------- */
@@ -102,6 +105,12 @@ void d4est_operators_apply_p_prolong(d4est_operators_t *d4est_ops,double *D4EST_
 void d4est_operators_apply_hp_prolong(d4est_operators_t *d4est_ops,double *D4EST_RESTRICT in,int degH,int dim,int *degh,double *D4EST_RESTRICT out);
 void d4est_operators_apply_p_restrict(d4est_operators_t *d4est_ops,double *D4EST_RESTRICT in,int degh,int dim,int degH,double *D4EST_RESTRICT out);
 void d4est_operators_apply_hp_restrict(d4est_operators_t *d4est_ops,double *D4EST_RESTRICT in,int *degh,int dim,int degH,double *D4EST_RESTRICT out);
+/* src/dGMath/d4est_operators.h:104, :107: the dense prolongation and the Galerkin product of the multigrid matrix operator's restriction
+ * callback (src/Solver/d4est_solver_multigrid_matrix_operator.c:29).  compute_PT_mat_P forms sum_i P_i^T mat_i P_i; with eight children
+ * the reference's own code reads a window of the transposed STACKED prolongation as the left factor (d4est_operators.c:651), which is not
+ * P_i^T -- D4EST_HIP_REFERENCE_PT_WINDOW=1 reproduces that arithmetic to the letter (see DESIGN.md "MG matrix operator") */
+void d4est_operators_compute_prolong_matrix(d4est_operators_t *d4est_ops,int degH,int dim,int *degh,int children,double *D4EST_RESTRICT prolong_mat);
+void d4est_operators_compute_PT_mat_P(d4est_operators_t *d4est_ops,double *D4EST_RESTRICT mat,int degH,int dim,int *degh,int children,double *D4EST_RESTRICT PT_mat_P);
 void d4est_operators_apply_p_prolong_transpose(d4est_operators_t *d4est_ops,double *D4EST_RESTRICT in,int degh,int dim,int degH,double *D4EST_RESTRICT out);
 void d4est_operators_apply_hp_prolong_transpose(d4est_operators_t *d4est_ops,double *D4EST_RESTRICT in,int *degh,int dim,int degH,double *D4EST_RESTRICT out);
 

@@ -173,6 +173,26 @@ void oracle_apply_lhs(const double* u, double* Au);   /* the registered operator
 void oracle_set_lhs_coefficient(const double* coeff_quad);   /* + weighted mass term of a linearised nonlinear problem; NULL = off */
 void oracle_operator_info(int* n_elements, const int** deg, const int** nodal_stride, int* local_nodes);
 
+/* ---- multigrid matrix operator (oracle/d4est_oracle_mgmatrix.c): the zeroth-order term as dense element blocks, Galerkin-restricted ---- */
+void oracle_quadrature_compute_mass_matrix(int quad_type, int deg_lobatto, const double* jac_quad, int deg_quad, double* out);   /* Quadrature/d4est_quadrature.c:1143-1186 */
+void oracle_quadrature_compute_fofufofvlilj_matrix(int quad_type, int deg_lobatto, const double* coeff_quad, const double* jac_quad,
+                                                   int deg_quad, double* out);                                               /* :593-774, QUAD_COMPUTE_MATRIX */
+long long oracle_mg_matrix_setup_fofufofvlilj_operator(int quad_type, int n_elements, const int* deg, const int* deg_quad,
+                                                       const int* quad_stride, const double* J_quad, const double* coeff_quad,
+                                                       double* matrix_at0);                    /* Solver/d4est_solver_multigrid_matrix_operator.c:160-245 */
+void oracle_compute_prolong_matrix(int degH, int dim, const int* degh, int children, double* prolong_mat);   /* dGMath/d4est_operators.c:572-605 */
+/* literal_window != 0: the reference's arithmetic to the letter (:651 reads a window of the transposed STACKED prolongation, which is
+ * P_i^T only for one child); 0: sum_i P_i^T mat_i P_i */
+void oracle_compute_PT_mat_P(const double* mat, int degH, int dim, const int* degh, int children, int literal_window, double* PT_mat_P); /* :608-667 */
+void oracle_PT_window(int degH, const int* degh, int children, int child, double* window);
+void oracle_mg_matrix_restriction(int n_items, const int* hrefine, const int* degH, const int* degh, int literal_window,
+                                  const double* fine_matrix, double* coarse_matrix);           /* Solver/d4est_solver_multigrid_matrix_operator.c:6-48 */
+void oracle_apply_element_blocks_add(int n_elements, const int* deg, const int* nodal_stride, int local_nodes, const double* matrix,
+                                     const double* u, double* Au);      /* Problems/ConstantDensityStar/constant_density_star_fcns.h:485-527 */
+/* the registered operator's zeroth-order term as dense element blocks (apply_jac on a coarse multigrid level,
+ * constant_density_star_fcns.h:806-850); NULL = off */
+void oracle_set_lhs_element_blocks(const double* matrix);
+
 /* ---- additive Schwarz smoother (oracle/d4est_oracle_schwarz.c) ----
  * Subdomain metadata in flat form (Solver/d4est_solver_schwarz_metadata.h:19-62): subdomain i owns the entries
  * [sub_first[i], sub_first[i+1]) of sub_elem (local element ids, sorted by (tree, quadid) as :447-455 does), sub_faces[3*k..] (faces of

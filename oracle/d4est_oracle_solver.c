@@ -53,6 +53,10 @@ void oracle_apply_lhs(const double* u, double* Au) { apply_lhs(u, Au); }
  * (Problems/ConstantDensityStar/constant_density_star_fcns.h:528-603, :777-850); NULL = pure Laplacian */
 static const double* g_lhs_coeff = NULL;
 void oracle_set_lhs_coefficient(const double* coeff_quad) { g_lhs_coeff = coeff_quad; }
+/* the same term on a coarse multigrid level, where the reference holds it as Galerkin-restricted dense element blocks
+ * (constant_density_star_apply_jac, constant_density_star_fcns.h:806-850 with :485-527) */
+static const double* g_lhs_blocks = NULL;
+void oracle_set_lhs_element_blocks(const double* matrix) { g_lhs_blocks = matrix; }
 void oracle_operator_info(int* n_elements, const int** deg, const int** nodal_stride, int* local_nodes) {
   if (!g_op.set) { fprintf(stderr, "[ORACLE_ABORT] operator not set\n"); abort(); }
   *n_elements = g_op.n_elements; *deg = g_op.deg; *nodal_stride = g_op.nodal_stride; *local_nodes = g_op.local_nodes;
@@ -72,6 +76,7 @@ static void apply_lhs(const double* u, double* Au) {
     oracle_linalg_vec_axpy(1.0, Mu, Au, g_op.local_nodes);
     free(Mu);
   }
+  if (g_lhs_blocks) oracle_apply_element_blocks_add(g_op.n_elements, g_op.deg, g_op.nodal_stride, g_op.local_nodes, g_lhs_blocks, u, Au);
 }
 
 /* Solver/d4est_solver_multigrid_smoother_cheby.c:81-176 */

@@ -153,6 +153,72 @@ static void element_level(int p, int pq, int quad_type) {
       snprintf(nm, sizeof nm, "apply_galerkin_integral MORTAR q%d dq%d", quad_type, pq - p); check(nm, p, g2, r2, n2, 1e-13);
       free(I1); free(w1); free(q2); free(r2); free(g2);
     }
+    /* QUAD_COMPUTE_MATRIX: the dense element matrix the multigrid matrix operator asks for per element
+     * (Solver/d4est_solver_multigrid_matrix_operator.c:215-238), with both callbacks; and d4est_quadrature_compute_mass_matrix itself */
+    if (p <= 3) {
+      double *gotM = vec(n3 * n3), *refM = vec(n3 * n3), *cq = vec(q3);
+      for (int i = 0; i < q3; i++) cq[i] = probe_f(xyzq[0][i], xyzq[1][i], xyzq[2][i], uq[i], ctx) * probe_g(xyzq[0][i], xyzq[1][i], xyzq[2][i], vq[i], ctx + 1);
+      oracle_quadrature_compute_fofufofvlilj_matrix(quad_type, p, cq, J, pq, refM);
+      d4est_quadrature_apply_fofufofvlilj(NULL, NULL, quad, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, NULL, u, v, p, xyzq, J, pq, gotM, probe_f, ctx,
+                                          probe_g, ctx + 1, QUAD_COMPUTE_MATRIX, 0, NULL);
+      snprintf(nm, sizeof nm, "fofufofvlilj COMPUTE_MATRIX q%d dq%d", quad_type, pq - p); check(nm, p, gotM, refM, n3 * n3, 1e-12);
+      oracle_quadrature_compute_mass_matrix(quad_type, p, J, pq, refM);
+      d4est_quadrature_compute_mass_matrix(NULL, NULL, quad, NULL, QUAD_OBJECT_VOLUME, QUAD_INTEGRAND_UNKNOWN, p, J, pq, gotM);
+      snprintf(nm, sizeof nm, "compute_mass_matrix q%d dq%d", quad_type, pq - p); check(nm, p, gotM, refM, n3 * n3, 1e-12);
+      free(gotM); free(refM); free(cq);
+    }
+    /* the callback entries on QUAD_OBJECT_MORTAR objects: a face embedded in 3-D, so the callbacks still see z (d4est_quadrature.c:660-690
+     * under #if P4EST_DIM==3); probe_f / probe_g depend on z.  Expected values from the oracle's 1-D tables, sums written out */
+    {
+      const int nq2 = NQ * NQ;
+      double *I1 = vec(NQ * N), *w1 = vec(NQ), *uq2 = vec(nq2), *vq2 = vec(nq2), *c2 = vec(nq2), *r2 = vec(n2 * n2 > nq2 ? n2 * n2 : nq2), *g2 = vec(n2 * n2 > nq2 ? n2 * n2 : nq2);
+      oracle_quad_interp(quad_type, p, pq, I1);
+      oracle_quad_weights(quad_type, pq, w1);
+      for (int bq = 0; bq < NQ; bq++)
+        for (int aq = 0; aq < NQ; aq++) {
+          double su = 0, sv = 0;
+          for (int b = 0; b < N; b++)
+            for (int a = 0; a < N; a++) { su += I1[bq * N + b] * I1[aq * N + a] * u[a + N * b]; sv += I1[bq * N + b] * I1[aq * N + a] * v[a + N * b]; }
+          uq2[aq + NQ * bq] = su; vq2[aq + NQ * bq] = sv;
+        }
+      for (int i = 0; i < nq2; i++) c2[i] = probe_f(xyzq[0][i], xyzq[1][i], xyzq[2][i], uq2[i], ctx) * probe_g(xyzq[0][i], xyzq[1][i], xyzq[2][i], vq2[i], ctx + 1);
+      /* lilj applied to u */
+      for (int b = 0; b < N; b++)
+        for (int a = 0; a < N; a++) {
+          double s = 0;
+          for (int bq = 0; bq < NQ; bq++)
+            for (int aq = 0; aq < NQ; aq++) s += I1[bq * N + b] * I1[aq * N + a] * w1[aq] * w1[bq] * J[aq + NQ * bq] * c2[aq + NQ * bq] * uq2[aq + NQ * bq];
+          r2[a + N * b] = s;
+        }
+      d4est_quadrature_apply_fofufofvlilj(NULL, NULL, quad, NULL, QUAD_OBJECT_MORTAR, QUAD_INTEGRAND_UNKNOWN, u, u, v, p, xyzq, J, pq, g2, probe_f, ctx,
+                                          probe_g, ctx + 1, QUAD_APPLY_MATRIX, 0, NULL);
+      snprintf(nm, sizeof nm, "fofufofvlilj MORTAR z q%d dq%d", quad_type, pq - p); check(nm, p, g2, r2, n2, 1e-13);
+      /* lj */
+      for (int b = 0; b < N; b++)
+        for (int a = 0; a < N; a++) {
+          double s = 0;
+          for (int bq = 0; bq < NQ; bq++)
+            for (int aq = 0; aq < NQ; aq++) s += I1[bq * N + b] * I1[aq * N + a] * w1[aq] * w1[bq] * J[aq + NQ * bq] * c2[aq + NQ * bq];
+          r2[a + N * b] = s;
+        }
+      d4est_quadrature_apply_fofufofvlj(NULL, NULL, quad, NULL, QUAD_OBJECT_MORTAR, QUAD_INTEGRAND_UNKNOWN, u, v, p, J, xyzq, pq, g2, probe_f, ctx, probe_g,
+                                        ctx + 1, 0, NULL);
+      snprintf(nm, sizeof nm, "fofufofvlj MORTAR z q%d dq%d", quad_type, pq - p); check(nm, p, g2, r2, n2, 1e-13);
+      /* the dense mortar mass matrix (QUAD_COMPUTE_MATRIX on a mortar object) */
+      if (p <= 7) {
+        for (int i = 0; i < n2; i++)
+          for (int j = 0; j < n2; j++) {
+            double s = 0;
+            for (int bq = 0; bq < NQ; bq++)
+              for (int aq = 0; aq < NQ; aq++)
+                s += I1[bq * N + i / N] * I1[aq * N + i % N] * w1[aq] * w1[bq] * J[aq + NQ * bq] * I1[bq * N + j / N] * I1[aq * N + j % N];
+            r2[i * n2 + j] = s;
+          }
+        d4est_quadrature_compute_mass_matrix(NULL, NULL, quad, NULL, QUAD_OBJECT_MORTAR, QUAD_INTEGRAND_UNKNOWN, p, J, pq, g2);
+        snprintf(nm, sizeof nm, "compute_mass_matrix MORTAR q%d dq%d", quad_type, pq - p); check(nm, p, g2, r2, n2 * n2, 1e-13);
+      }
+      free(I1); free(w1); free(uq2); free(vq2); free(c2); free(r2); free(g2);
+    }
     for (int d = 0; d < 3; d++) { free(xyzq[d]); free(xyzl[d]); }
     free(v); free(uq); free(vq); free(fj); free(fl);
   }
@@ -188,6 +254,23 @@ static void element_level(int p, int pq, int quad_type) {
     d4est_operators_apply_hp_restrict(NULL, fine, degh, 3, p, got); oracle_apply_hp_restrict(fine, degh, 3, p, ref); check("apply_hp_restrict", p, got, ref, n3, 1e-11);
     d4est_operators_apply_hp_prolong_transpose(NULL, fine, degh, 3, p, got); oracle_apply_hp_prolong_transpose(fine, degh, 3, p, ref);
     check("apply_hp_prolong_transpose", p, got, ref, n3, 1e-12);
+    /* the multigrid matrix operator's restriction: the dense prolongation and P^T mat P (dGMath/d4est_operators.h:104, :107) */
+    if (p <= 3) {
+      for (int children = 1; children <= 8; children += 7) {
+        int dh[8], toth = 0;
+        long long totm = 0;
+        for (int c = 0; c < children; c++) { dh[c] = (children == 1) ? ph : degh[c]; const int n = (dh[c] + 1) * (dh[c] + 1) * (dh[c] + 1); toth += n; totm += (long long)n * n; }
+        double *Pg = vec(toth * n3), *Pr = vec(toth * n3), *mat = vec((int)totm), *Mg = vec(n3 * n3), *Mr = vec(n3 * n3);
+        for (long long i = 0; i < totm; i++) mat[i] = lcg(&seed) - 0.5;
+        d4est_operators_compute_prolong_matrix(NULL, p, 3, dh, children, Pg);
+        oracle_compute_prolong_matrix(p, 3, dh, children, Pr);
+        snprintf(nm, sizeof nm, "compute_prolong_matrix children %d", children); check(nm, p, Pg, Pr, toth * n3, 1e-13);
+        d4est_operators_compute_PT_mat_P(NULL, mat, p, 3, dh, children, Mg);
+        oracle_compute_PT_mat_P(mat, p, 3, dh, children, 0, Mr);
+        snprintf(nm, sizeof nm, "compute_PT_mat_P children %d", children); check(nm, p, Mg, Mr, n3 * n3, 1e-12);
+        free(Pg); free(Pr); free(mat); free(Mg); free(Mr);
+      }
+    }
     free(fine); free(gotf); free(reff);
   }
   for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) free(rst[a][b]);

@@ -244,6 +244,35 @@ class Oracle:
         self._lhs_coeff = None if coeff_quad is None else np.ascontiguousarray(coeff_quad, dtype=np.float64)
         self.lib.oracle_set_lhs_coefficient(None if self._lhs_coeff is None else P(self._lhs_coeff))
 
+    # ---- multigrid matrix operator (oracle/d4est_oracle_mgmatrix.c)
+    def mg_matrix_setup(self, mesh, J, coeff_q):
+        """d4est_solver_multigrid_matrix_setup_fofufofvlilj_operator: one dense block per element (QUAD_COMPUTE_MATRIX), consecutive"""
+        f = self.lib.oracle_mg_matrix_setup_fofufofvlilj_operator
+        f.restype = ctypes.c_longlong
+        f.argtypes = [ctypes.c_int, ctypes.c_int, ip, ip, ip, dp, dp, dp]
+        cq = None if coeff_q is None else np.ascontiguousarray(coeff_q, dtype=np.float64)
+        n = f(mesh.quad_type, mesh.n_elements, I(mesh.deg), I(mesh.deg_quad), I(mesh.quad_stride), P(J), None if cq is None else P(cq), None)
+        out = np.zeros(n)
+        f(mesh.quad_type, mesh.n_elements, I(mesh.deg), I(mesh.deg_quad), I(mesh.quad_stride), P(J), None if cq is None else P(cq), P(out))
+        return out
+
+    def mg_matrix_restriction(self, hrefine, degH, degh, fine_matrix, literal_window=False):
+        """the restriction callback of the matrix operator over a transfer's item list: coarse blocks = sum_c P_c^T M_c P_c
+        (literal_window: the reference's :651 window instead of P_c^T)"""
+        hrefine, degH, degh = (np.ascontiguousarray(a, dtype=np.int32) for a in (hrefine, degH, degh))
+        n = int(sum((int(d) + 1) ** 6 for d in degH))
+        out = np.zeros(n)
+        f = self.lib.oracle_mg_matrix_restriction
+        f.argtypes = [ctypes.c_int, ip, ip, ip, ctypes.c_int, dp, dp]
+        f(len(hrefine), I(hrefine), I(degH), I(degh), int(bool(literal_window)), P(np.ascontiguousarray(fine_matrix)), P(out))
+        return out
+
+    def set_lhs_element_blocks(self, matrix):
+        """zeroth-order term of the registered operator as dense element blocks (None switches it off); kept alive here"""
+        self.lib.oracle_set_lhs_element_blocks.argtypes = [dp]
+        self._lhs_blocks = None if matrix is None else np.ascontiguousarray(matrix, dtype=np.float64)
+        self.lib.oracle_set_lhs_element_blocks(None if self._lhs_blocks is None else P(self._lhs_blocks))
+
     def apply_lhs(self, u):
         out = np.zeros_like(u)
         self.lib.oracle_apply_lhs.argtypes = [dp, dp]

@@ -29,7 +29,8 @@ def test_compat_header_is_c99_and_every_declared_symbol_is_exported(hiplib, orac
     assert {"d4est_quadrature_apply_stiffness_matrix", "d4est_operators_apply_hp_restrict", "d4est_laplacian_apply_aij", "cg_eigs",
             "d4est_laplacian_with_opt_apply_aij", "d4est_laplacian_with_opt_apply_stiffness_matrix",
             "d4est_solver_multigrid_smoother_cheby_iterate_aux", "d4est_hip_compat_bind_mesh", "d4est_quadrature_apply_fofufofvlilj",
-            "d4est_quadrature_apply_fofufofvlj", "d4est_hip_compat_bind_operator", "d4est_hip_compat_build_rhs_with_strong_bc"} <= names and len(names) >= 30
+            "d4est_quadrature_apply_fofufofvlj", "d4est_hip_compat_bind_operator", "d4est_hip_compat_build_rhs_with_strong_bc",
+            "d4est_quadrature_compute_mass_matrix", "d4est_operators_compute_PT_mat_P", "d4est_operators_compute_prolong_matrix"} <= names and len(names) >= 30
     lib = ctypes.CDLL(os.path.join(LIBDIR, "libd4est_hip_compat.so"))
     for n in names:
         getattr(lib, n)
@@ -54,7 +55,9 @@ def test_reference_prototypes_from_plain_c_match_oracle(gpu, hiplib, oracle, tmp
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert out.stdout.strip().endswith("ok")
     assert out.stdout.count("rel-inf") >= 370
-    for what in ("apply_fofufofvlilj", "apply_fofufofvlj", "MORTAR", "build_rhs_with_strong_bc", "registered apply_lhs accepted"):
+    for what in ("apply_fofufofvlilj", "apply_fofufofvlj", "MORTAR", "build_rhs_with_strong_bc", "registered apply_lhs accepted",
+                 "fofufofvlilj COMPUTE_MATRIX", "compute_mass_matrix MORTAR", "fofufofvlilj MORTAR z", "fofufofvlj MORTAR z",
+                 "compute_PT_mat_P children 8", "compute_prolong_matrix children 1"):
         assert what in out.stdout
 
 
