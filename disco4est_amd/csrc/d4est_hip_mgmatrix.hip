@@ -38,10 +38,9 @@ struct LhsChain {
 // One workgroup per (element, chunk of rows); a wavefront owns rows r, r + 4, ...: its lanes stride along the row (512 contiguous bytes
 // per wave load, non-temporal: every block entry is read exactly once per apply), u_e sits in the LDS, the 64 partial sums are folded
 // with cross-lane adds.  Row sums are complete in one wave in a fixed order: deterministic.
-constexpr int kBlockRowsPerWG = 64;
 __global__ __launch_bounds__(256) void block_matvec_add_kernel(const int* __restrict__ elem_ids, const int* __restrict__ ns_list, int N3,
                                                                const double* __restrict__ blocks, const long long* __restrict__ block_off,
-                                                               const double* __restrict__ u, double* __restrict__ Au) {
+                                                               const double* __restrict__ u, double* __restrict__ Au, int rows_per_wg) {
   extern __shared__ __attribute__((aligned(16))) double su[];
   const int i = blockIdx.x;
   const int e = elem_ids[i];
@@ -50,8 +49,8 @@ __global__ __launch_bounds__(256) void block_matvec_add_kernel(const int* __rest
   for (int k = threadIdx.x; k < N3; k += blockDim.x) su[k] = u[ns + k];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r0 = blockIdx.y * kBlockRowsPerWG;
-  const int r1 = min(N3, r0 + kBlockRowsPerWG);
+  const int r0 = blockIdx.y * rows_per_wg;
+  const int r1 = min(N3, r0 + rows_per_wg);
   // two rows per trip: twice the loads in flight per wavefront
   for (int r = r0 + wave; r < r1; r += 8) {
     const int rb = r + 4;
@@ -79,9 +78,13 @@ void add_lhs_blocks_term(d4est_hip_plan* plan, const double* u, double* Au) {
   for (const Bucket& bk : plan->buckets) {
     if (bk.n_elem == 0) continue;
     const int N3 = bk.N * bk.N * bk.N;
-    const dim3 grid(bk.n_elem, (N3 + kBlockRowsPerWG - 1) / kBlockRowsPerWG);
+    // 64 rows per workgroup on large buckets; fewer (down to one trip of the four wavefronts, 8 rows) where that is needed to put
+    // ~16 workgroups on every CU: coarse multigrid levels have few elements
+    int rows = 64;
+    while (rows > 8 && (long long)bk.n_elem * ((N3 + rows - 1) / rows) < 4096) rows >>= 1;
+    const dim3 grid(bk.n_elem, (N3 + rows - 1) / rows);
     hipLaunchKernelGGL(block_matvec_add_kernel, grid, dim3(256), (size_t)N3 * sizeof(double), plan->stream, plan->d_elem_ids + bk.elem_offset,
-                       plan->d_ns_list + bk.elem_offset, N3, plan->d_lhs_blocks, plan->d_lhs_block_off, u, Au);
+                       plan->d_ns_list + bk.elem_offset, N3, plan->d_lhs_blocks, plan->d_lhs_block_off, u, Au, rows);
   }
   HIP_CHECK(hipGetLastError());
 }

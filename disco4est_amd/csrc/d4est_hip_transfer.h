@@ -11,6 +11,13 @@ struct d4est_hip_transfer {
   int* d_item_first = nullptr; // per item: index of its first child record (n_items + 1)
   double* d_ops = nullptr;
   double* d_rops = nullptr;    // the L2-projection operators (p_restrict / hp_restrict) at the same offsets as the prolongations
+  double* d_opsT = nullptr;    // every prolongation transposed (NH x Nh), same offsets: the operand form of the compile-time kernels
+  double* d_ropsT = nullptr;   // every projection operator transposed (Nh x NH)
+  // work lists (d4est_hip_transfer.hip): fine elements (prolongation) / coarse elements (restriction) by coarse size NH for the
+  // compile-time kernels, dmax = the largest Nh - NH in the list; NH = 0: the generic runtime-size kernels
+  struct List { int NH, dmax, first, n, nc; };   // nc: children per coarse element of a restriction list (1 or 8)
+  std::vector<List> prolong_lists, restrict_lists;
+  int* d_lists = nullptr;
   hipStream_t stream = nullptr;
   // multigrid matrix operator (d4est_hip_mgmatrix.hip): where every child's / item's dense block sits (doubles), and the workspace of
   // the triple product  sum_c P_c^T M_c P_c  (T_c = M_c P_c, allocated on first use)

@@ -16,17 +16,19 @@
 #include "d4est_hip_internal.h"
 #include "d4est_hip_tables.h"
 #include "d4est_hip_transfer.h"
+#include "d4est_hip_wave.h"
 
 namespace d4est_hip {
 
 // one workgroup per fine element
 __global__ __launch_bounds__(256) void prolong_kernel(const double* __restrict__ xc, double* __restrict__ xf,
                                                       const int* __restrict__ child, const long long* __restrict__ off,
-                                                      const double* __restrict__ ops, int n_children, int max_n3) {
+                                                      const double* __restrict__ ops, const int* __restrict__ list, int n_children, int max_n3) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* a = smem;
   double* b = smem + max_n3;
-  for (int c = blockIdx.x; c < n_children; c += gridDim.x) {
+  for (int ci = blockIdx.x; ci < n_children; ci += gridDim.x) {
+    const int c = list[ci];
     const int* d = child + 8 * c;
     const int NH = d[1], Nh = d[2];
     const long long co = off[2 * c], fo = off[2 * c + 1];
@@ -43,11 +45,12 @@ template <bool TRANS>
 __global__ __launch_bounds__(256) void restrict_kernel(const double* __restrict__ xf, double* __restrict__ xc,
                                                        const int* __restrict__ child, const long long* __restrict__ off,
                                                        const int* __restrict__ item_first, const double* __restrict__ ops,
-                                                       int n_items, int max_n3, int acc_in_lds) {
+                                                       const int* __restrict__ list, int n_items, int max_n3, int acc_in_lds) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* a = smem;
   double* b = smem + max_n3;
-  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+  for (int ii = blockIdx.x; ii < n_items; ii += gridDim.x) {
+    const int it = list[ii];
     const int c0 = item_first[it], c1 = item_first[it + 1];
     const int NH = child[8 * c0 + 1];
     // the sum over the children: a third LDS field, or -- p = 18, 19: three fields of 19^3 / 20^3 doubles exceed the 160 KB -- the coarse
@@ -72,6 +75,236 @@ __global__ __launch_bounds__(256) void restrict_kernel(const double* __restrict_
   }
 }
 
+
+// ---- the MI355X-shaped transfer kernels: degree pairs as compile-time constants ---------------------------------------------------
+// One workgroup per fine element (prolongation) or per coarse element (restriction / projection: its children in a loop, summed in
+// registers in child order).  A thread owns a LINE of the element along the contracted direction in registers; the 1-D operator rows are
+// wave-uniform and come through scalar loads (contract_n, d4est_hip_wave.h) -- no operand traffic in the FMA loops, no index division in
+// them.  Pass order x, y, z: the element arrives with one coalesced copy into a padded LDS image (odd row length: the x-lines are read
+// thread-strided without bank conflicts), the hand-offs between passes are conflict-free by construction, and the LAST pass (z) leaves
+// each thread with a z-line whose stores are coalesced over the whole (x, y) plane.  NH = coarse nodes per direction; the fine size
+// Nh = NH + d, d <= DMAX, is looked up per fine element (a wave-uniform switch), so mixed-degree children share one launch.
+constexpr int kFastMaxNH = 16;
+constexpr int kFastMaxD = 3;
+
+template <int NH, int DMAX>
+struct TransferCfg {
+  static constexpr int NHM = NH + DMAX;                                      // largest fine size
+  static constexpr int THREADS = ((NHM * NHM + 63) / 64) * 64;
+  // prolongation: B [NH][NH][Nh|1], C [NH][Nh][Nh];  restriction (per child group): B [Nh][Nh][NH|1], C [Nh][NH][NH]
+  static constexpr int LDS_PROLONG = NH * NH * (NHM | 1) + NH * NHM * NHM;
+  static constexpr int LDS_RESTRICT = NHM * NHM * (NH | 1) + NHM * NH * NH;
+  // child groups of the restriction: as many of an item's eight children at once as the LDS and 1024 threads hold
+  static constexpr int cg_max() {
+    int cg = 8;
+    while (cg > 1 && ((long long)cg * LDS_RESTRICT * 8 > 150 * 1024 || cg * THREADS > 1024)) cg >>= 1;
+    return cg;
+  }
+  static constexpr int CGMAX = cg_max();
+};
+
+// t: the thread's index in its group of TransferCfg::THREADS threads (the whole workgroup for the prolongation)
+template <int NH, int Nh>
+__device__ __forceinline__ void prolong_body(const double* __restrict__ xc_e, double* __restrict__ xf_e, const double* PxT,
+                                             const double* PyT, const double* PzT, double* lds, int t) {
+  constexpr int RSB = Nh | 1;
+  double* B = lds;
+  double* C = B + NH * NH * RSB;
+  if (t < NH * NH) {                       // thread (b, k): its x-line straight from memory (the element is one contiguous run)
+    double x[NH], y[Nh];
+#pragma unroll
+    for (int a = 0; a < NH; ++a) x[a] = xc_e[t * NH + a];
+    contract_n<NH, Nh>(PxT, x, y);
+#pragma unroll
+    for (int a = 0; a < Nh; ++a) B[t * RSB + a] = y[a];
+  }
+  __syncthreads();
+  if (t < Nh * NH) {                       // thread (aq, k): the y-line
+    const int aq = t % Nh, k = t / Nh;
+    double x[NH], y[Nh];
+#pragma unroll
+    for (int b = 0; b < NH; ++b) x[b] = B[(k * NH + b) * RSB + aq];
+    contract_n<NH, Nh>(PyT, x, y);
+#pragma unroll
+    for (int b = 0; b < Nh; ++b) C[(k * Nh + b) * Nh + aq] = y[b];
+  }
+  __syncthreads();
+  if (t < Nh * Nh) {                       // thread (aq, bq): the z-line, stored coalesced
+    double x[NH], y[Nh];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) x[k] = C[k * Nh * Nh + t];
+    contract_n<NH, Nh>(PzT, x, y);
+#pragma unroll
+    for (int k = 0; k < Nh; ++k) xf_e[k * Nh * Nh + t] = y[k];
+  }
+}
+
+template <int NH, int DMAX>
+__global__ __launch_bounds__((TransferCfg<NH, DMAX>::THREADS)) void prolong_fast_kernel(const double* __restrict__ xc, double* __restrict__ xf,
+                                                                                      const int* __restrict__ child,
+                                                                                      const long long* __restrict__ off,
+                                                                                      const double* __restrict__ opsT,
+                                                                                      const int* __restrict__ list) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int c = list[blockIdx.x];
+  const int* d = child + 8 * c;
+  const int dN = d[2] - NH;
+  const double* xc_e = xc + off[2 * c];
+  double* xf_e = xf + off[2 * c + 1];
+  const double *px = opsT + d[3], *py = opsT + d[4], *pz = opsT + d[5];
+  const int t = threadIdx.x;
+  if (dN == 0) prolong_body<NH, NH>(xc_e, xf_e, px, py, pz, smem, t);
+  if constexpr (DMAX >= 1) { if (dN == 1) prolong_body<NH, NH + 1>(xc_e, xf_e, px, py, pz, smem, t); }
+  if constexpr (DMAX >= 2) { if (dN == 2) prolong_body<NH, NH + 2>(xc_e, xf_e, px, py, pz, smem, t); }
+  if constexpr (DMAX >= 3) { if (dN == 3) prolong_body<NH, NH + 3>(xc_e, xf_e, px, py, pz, smem, t); }
+}
+
+// acc (the thread's z-line of the coarse element) += its part of  op_z (x) op_y (x) op_x  applied to one fine element; op* are Nh x NH
+// row-major (the prolongation itself for P^T, the transposed projection operator for the L2 projection)
+template <int NH, int Nh>
+__device__ __forceinline__ void restrict_body(const double* __restrict__ xf_e, const double* Ox, const double* Oy, const double* Oz,
+                                              double* lds, double (&acc)[NH], int t) {
+  constexpr int RSB = NH | 1;
+  double* B = lds;
+  double* C = B + Nh * Nh * RSB;
+  if (t < Nh * Nh) {
+    double x[Nh], y[NH];
+#pragma unroll
+    for (int a = 0; a < Nh; ++a) x[a] = xf_e[t * Nh + a];
+    contract_n<Nh, NH>(Ox, x, y);
+#pragma unroll
+    for (int a = 0; a < NH; ++a) B[t * RSB + a] = y[a];
+  }
+  __syncthreads();
+  if (t < NH * Nh) {
+    const int a = t % NH, k = t / NH;
+    double x[Nh], y[NH];
+#pragma unroll
+    for (int b = 0; b < Nh; ++b) x[b] = B[(k * Nh + b) * RSB + a];
+    contract_n<Nh, NH>(Oy, x, y);
+#pragma unroll
+    for (int b = 0; b < NH; ++b) C[(k * NH + b) * NH + a] = y[b];
+  }
+  __syncthreads();
+  if (t < NH * NH) {
+    double x[Nh], y[NH];
+#pragma unroll
+    for (int k = 0; k < Nh; ++k) x[k] = C[k * NH * NH + t];
+    contract_n<Nh, NH>(Oz, x, y);
+#pragma unroll
+    for (int k = 0; k < NH; ++k) acc[k] += y[k];
+  }
+}
+
+// blockDim = THREADS * CG: CG groups of threads work on different children of the coarse element at once (a coarse multigrid level has
+// few elements: without this an h-restriction runs one wavefront per EIGHT fine elements); group g takes children g, g + CG, ...; the
+// partial sums meet in the LDS and are added in group order by group 0 -- a fixed order, so the result is deterministic
+template <int NH, int DMAX>
+__global__ __launch_bounds__((TransferCfg<NH, DMAX>::THREADS * TransferCfg<NH, DMAX>::CGMAX)) void restrict_fast_kernel(const double* __restrict__ xf, double* __restrict__ xc,
+                                                             const int* __restrict__ child, const long long* __restrict__ off,
+                                                             const int* __restrict__ item_first, const double* __restrict__ ops,
+                                                             const int* __restrict__ list, int CG) {
+  using Cfg = TransferCfg<NH, DMAX>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int it = list[blockIdx.x];
+  const int c0 = item_first[it], c1 = item_first[it + 1];
+  // a group is whole wavefronts (THREADS is a multiple of 64): its index is wave-uniform, and with it the child and its operator tables
+  const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / Cfg::THREADS)), t = threadIdx.x % Cfg::THREADS;
+  double* lds = smem + (size_t)g * Cfg::LDS_RESTRICT;
+  double acc[NH];
+#pragma unroll
+  for (int k = 0; k < NH; ++k) acc[k] = 0.0;
+  // every group runs the same number of trips (and so of barriers); a trip without a child only keeps step
+  for (int c = c0 + g; c - g < c1; c += CG) {
+    if (c < c1) {
+      const int* d = child + 8 * c;
+      const int dN = d[2] - NH;
+      const double* xf_e = xf + off[2 * c + 1];
+      const double *ox = ops + d[3], *oy = ops + d[4], *oz = ops + d[5];
+      if (dN == 0) restrict_body<NH, NH>(xf_e, ox, oy, oz, lds, acc, t);
+      if constexpr (DMAX >= 1) { if (dN == 1) restrict_body<NH, NH + 1>(xf_e, ox, oy, oz, lds, acc, t); }
+      if constexpr (DMAX >= 2) { if (dN == 2) restrict_body<NH, NH + 2>(xf_e, ox, oy, oz, lds, acc, t); }
+      if constexpr (DMAX >= 3) { if (dN == 3) restrict_body<NH, NH + 3>(xf_e, ox, oy, oz, lds, acc, t); }
+    } else {
+      __syncthreads();
+      __syncthreads();
+    }
+    __syncthreads();   // the group's image is rewritten by its next child / by the partial sums below
+  }
+  if (CG > 1) {
+    if (t < NH * NH) {
+#pragma unroll
+      for (int k = 0; k < NH; ++k) lds[k * NH * NH + t] = acc[k];
+    }
+    __syncthreads();
+    if (g == 0 && t < NH * NH) {
+      for (int gg = 1; gg < CG; ++gg) {
+        const double* o = smem + (size_t)gg * Cfg::LDS_RESTRICT;
+#pragma unroll
+        for (int k = 0; k < NH; ++k) acc[k] += o[k * NH * NH + t];
+      }
+    }
+  }
+  if (g == 0 && t < NH * NH) {
+    double* xc_e = xc + off[2 * c0];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) xc_e[k * NH * NH + t] = acc[k];
+  }
+}
+
+template <typename K>
+static void fast_lds_limit(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+// launches of one (NH, DMAX) list
+template <int NH, int DMAX>
+static void go_prolong(d4est_hip_transfer* t, const double* xc, double* xf, const int* list, int n) {
+  using C = TransferCfg<NH, DMAX>;
+  const size_t lds = (size_t)C::LDS_PROLONG * sizeof(double);
+  fast_lds_limit(prolong_fast_kernel<NH, DMAX>, lds);
+  hipLaunchKernelGGL((prolong_fast_kernel<NH, DMAX>), dim3(n), dim3(C::THREADS), lds, t->stream, xc, xf, t->d_child, t->d_off, t->d_opsT, list);
+}
+template <int NH, int DMAX>
+static void go_restrict(d4est_hip_transfer* t, const double* xf, double* xc, const double* ops, const int* list, int n, int n_children) {
+  using C = TransferCfg<NH, DMAX>;
+  // child groups: as many of the item's children at once as the LDS (and 1024 threads) hold
+  // child groups where the list alone does not fill the chip (coarse levels); with thousands of coarse elements one group per element
+  // keeps more elements in flight (level 5, p = 3: 61 us against 113 us with groups)
+  const int cg = (n_children == 8 && n < 8192) ? C::CGMAX : 1;
+  const size_t lds = (size_t)cg * C::LDS_RESTRICT * sizeof(double);
+  fast_lds_limit(restrict_fast_kernel<NH, DMAX>, lds);
+  hipLaunchKernelGGL((restrict_fast_kernel<NH, DMAX>), dim3(n), dim3(C::THREADS * cg), lds, t->stream, xf, xc, t->d_child, t->d_off,
+                     t->d_item_first, ops, list, cg);
+}
+
+#define D4EST_HIP_TRANSFER_NH(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+
+static void launch_fast_prolong(d4est_hip_transfer* t, const double* xc, double* xf, int NH, int dmax, const int* list, int n) {
+#define X(N_)                                                         \
+  if (NH == N_) {                                                     \
+    if (dmax == 0) go_prolong<N_, 0>(t, xc, xf, list, n);             \
+    else if (dmax == 1) go_prolong<N_, 1>(t, xc, xf, list, n);        \
+    else go_prolong<N_, 3>(t, xc, xf, list, n);                       \
+    return;                                                           \
+  }
+  D4EST_HIP_TRANSFER_NH(X)
+#undef X
+  D4EST_HIP_ABORT("transfer: no fast prolongation kernel for %d coarse nodes per direction", NH);
+}
+static void launch_fast_restrict(d4est_hip_transfer* t, const double* xf, double* xc, const double* ops, int NH, int dmax, const int* list, int n, int nc) {
+#define X(N_)                                                         \
+  if (NH == N_) {                                                     \
+    if (dmax == 0) go_restrict<N_, 0>(t, xf, xc, ops, list, n, nc);       \
+    else if (dmax == 1) go_restrict<N_, 1>(t, xf, xc, ops, list, n, nc);  \
+    else go_restrict<N_, 3>(t, xf, xc, ops, list, n, nc);                 \
+    return;                                                           \
+  }
+  D4EST_HIP_TRANSFER_NH(X)
+#undef X
+  D4EST_HIP_ABORT("transfer: no fast restriction kernel for %d coarse nodes per direction", NH);
+}
+
 }  // namespace d4est_hip
 
 using d4est_hip::Tables1D;
@@ -82,7 +315,7 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
   if (n_items < 0 || (n_items > 0 && (!hrefine || !degH || !degh))) D4EST_HIP_ABORT("transfer_create: bad arguments");
   d4est_hip_transfer* t = new d4est_hip_transfer();
   t->n_items = n_items;
-  std::vector<double> ops, rops;
+  std::vector<double> ops, rops, opsT, ropsT;   // P (Nh x NH), R (NH x Nh) and their transposes at the same offsets
   std::map<std::pair<int, int>, int> p_index, hp_index;
   auto get_p = [&](int dH, int dh) {
     auto key = std::make_pair(dH, dh);
@@ -93,6 +326,9 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
     ops.insert(ops.end(), P.begin(), P.end());
     std::vector<double> R = Tables1D::p_restrict(dH, dh);  // (dH+1) x (dh+1), d4est_operators.c:1165-1185
     rops.insert(rops.end(), R.begin(), R.end());
+    const std::vector<double> PT = Tables1D::transpose(P, dh + 1, dH + 1), RT = Tables1D::transpose(R, dH + 1, dh + 1);
+    opsT.insert(opsT.end(), PT.begin(), PT.end());
+    ropsT.insert(ropsT.end(), RT.begin(), RT.end());
     p_index[key] = o;
     return o;
   };
@@ -105,6 +341,13 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
     ops.insert(ops.end(), P.begin(), P.end());
     std::vector<double> R = Tables1D::hp_restrict(dH, dh); // 2 x (dH+1) x (dh+1), d4est_operators.c:1232-1259
     rops.insert(rops.end(), R.begin(), R.end());
+    const size_t half = (size_t)(dh + 1) * (dH + 1);
+    for (int h = 0; h < 2; ++h) {   // each half transposed on its own: the offsets of the halves stay
+      const std::vector<double> PT = Tables1D::transpose(std::vector<double>(P.begin() + h * half, P.begin() + (h + 1) * half), dh + 1, dH + 1);
+      const std::vector<double> RT = Tables1D::transpose(std::vector<double>(R.begin() + h * half, R.begin() + (h + 1) * half), dH + 1, dh + 1);
+      opsT.insert(opsT.end(), PT.begin(), PT.end());
+      ropsT.insert(ropsT.end(), RT.begin(), RT.end());
+    }
     hp_index[key] = o;
     return o;
   };
@@ -174,12 +417,55 @@ d4est_hip_transfer_t* d4est_hip_transfer_create(int n_items, const int* hrefine,
   if (!ops.empty()) HIP_CHECK(hipMemcpy(t->d_ops, ops.data(), ops.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_CHECK(hipMalloc(&t->d_rops, std::max<size_t>(rops.size(), 1) * sizeof(double)));
   if (!rops.empty()) HIP_CHECK(hipMemcpy(t->d_rops, rops.data(), rops.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMalloc(&t->d_opsT, std::max<size_t>(opsT.size(), 1) * sizeof(double)));
+  if (!opsT.empty()) HIP_CHECK(hipMemcpy(t->d_opsT, opsT.data(), opsT.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMalloc(&t->d_ropsT, std::max<size_t>(ropsT.size(), 1) * sizeof(double)));
+  if (!ropsT.empty()) HIP_CHECK(hipMemcpy(t->d_ropsT, ropsT.data(), ropsT.size() * sizeof(double), hipMemcpyHostToDevice));
+  // work lists: fine elements / coarse elements by coarse size NH for the compile-time kernels (NH <= 16, every fine size of the item
+  // within NH .. NH + 3), everything else through the generic runtime-size kernels
+  {
+    const bool no_fast = std::getenv("D4EST_HIP_TRANSFER_GENERIC") != nullptr;
+    std::map<int, std::vector<int>> pl;
+    std::map<std::pair<int, int>, std::vector<int>> rl;   // restriction: coarse elements with eight children (worked on by child groups) apart
+    std::map<int, int> pd;
+    std::map<std::pair<int, int>, int> rd;
+    std::vector<int> pg, rg;
+    for (int it = 0; it < n_items; ++it) {
+      const int c0 = item_first[it], c1 = item_first[it + 1];
+      const int NH = child[8 * c0 + 1];
+      int dmax = 0;
+      for (int c = c0; c < c1; ++c) dmax = std::max(dmax, child[8 * c + 2] - NH);
+      const bool fast = !no_fast && NH >= 2 && NH <= d4est_hip::kFastMaxNH && dmax <= d4est_hip::kFastMaxD;
+      if (fast) {
+        const auto rk = std::make_pair(NH, c1 - c0);
+        rl[rk].push_back(it);
+        rd[rk] = std::max(rd[rk], dmax);
+        for (int c = c0; c < c1; ++c) pl[NH].push_back(c);
+        pd[NH] = std::max(pd[NH], dmax);
+      } else {
+        rg.push_back(it);
+        for (int c = c0; c < c1; ++c) pg.push_back(c);
+      }
+    }
+    std::vector<int> all;
+    auto add = [&](std::vector<d4est_hip_transfer::List>& dst, int NH, int dmax, const std::vector<int>& v, int nc = 1) {
+      if (v.empty()) return;
+      dst.push_back({NH, dmax, (int)all.size(), (int)v.size(), nc});
+      all.insert(all.end(), v.begin(), v.end());
+    };
+    for (auto& kv : pl) add(t->prolong_lists, kv.first, pd[kv.first], kv.second);
+    add(t->prolong_lists, 0, 0, pg);
+    for (auto& kv : rl) add(t->restrict_lists, kv.first.first, rd[kv.first], kv.second, kv.first.second);
+    add(t->restrict_lists, 0, 0, rg);
+    t->d_lists = up_i(all);
+  }
   return t;
 }
 
 void d4est_hip_transfer_destroy(d4est_hip_transfer_t* t) {
   if (!t) return;
   (void)hipFree(t->d_child); (void)hipFree(t->d_off); (void)hipFree(t->d_item_first); (void)hipFree(t->d_ops); (void)hipFree(t->d_rops);
+  (void)hipFree(t->d_opsT); (void)hipFree(t->d_ropsT); (void)hipFree(t->d_lists);
   (void)hipFree(t->d_moff); (void)hipFree(t->d_coff); (void)hipFree(t->d_work); (void)hipFree(t->d_window); (void)hipFree(t->d_woff);
   delete t;
 }
@@ -195,29 +481,38 @@ long long d4est_hip_transfer_fine_nodes(const d4est_hip_transfer_t* t) { return 
 void d4est_hip_transfer_prolong(d4est_hip_transfer_t* t, const double* x_coarse_dev, double* x_fine_dev) {
   if (!t) D4EST_HIP_ABORT("transfer_prolong: NULL transfer");
   if (t->n_children == 0) return;
-  const int n3 = t->max_n * t->max_n * t->max_n;
-  const size_t lds = (size_t)2 * n3 * sizeof(double);
-  if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(d4est_hip::prolong_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(d4est_hip::prolong_kernel, dim3(std::min(t->n_children, 65536)), dim3(256), lds, t->stream, x_coarse_dev, x_fine_dev,
-                     t->d_child, t->d_off, t->d_ops, t->n_children, n3);
+  for (const d4est_hip_transfer::List& L : t->prolong_lists) {
+    if (L.NH > 0) { d4est_hip::launch_fast_prolong(t, x_coarse_dev, x_fine_dev, L.NH, L.dmax, t->d_lists + L.first, L.n); continue; }
+    const int n3 = t->max_n * t->max_n * t->max_n;
+    const size_t lds = (size_t)2 * n3 * sizeof(double);
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(d4est_hip::prolong_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(d4est_hip::prolong_kernel, dim3(std::min(L.n, 65536)), dim3(256), lds, t->stream, x_coarse_dev, x_fine_dev,
+                       t->d_child, t->d_off, t->d_ops, t->d_lists + L.first, L.n, n3);
+  }
   HIP_CHECK(hipGetLastError());
 }
 
 static void launch_restrict(d4est_hip_transfer_t* t, const double* x_fine_dev, double* x_coarse_dev, bool project, const char* who) {
   if (!t) D4EST_HIP_ABORT("%s: NULL transfer", who);
   if (t->n_items == 0) return;
-  const int n3 = t->max_n * t->max_n * t->max_n;
-  const int acc_in_lds = ((size_t)3 * n3 * sizeof(double) <= 160 * 1024) ? 1 : 0;
-  const size_t lds = (size_t)(acc_in_lds ? 3 : 2) * n3 * sizeof(double);
-  if (lds > 160 * 1024) D4EST_HIP_ABORT("%s: degree too high for the LDS-resident kernel", who);
-  const void* fn = project ? reinterpret_cast<const void*>(d4est_hip::restrict_kernel<false>) : reinterpret_cast<const void*>(d4est_hip::restrict_kernel<true>);
-  if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (project)
-    hipLaunchKernelGGL(d4est_hip::restrict_kernel<false>, dim3(std::min(t->n_items, 65536)), dim3(256), lds, t->stream, x_fine_dev, x_coarse_dev,
-                       t->d_child, t->d_off, t->d_item_first, t->d_rops, t->n_items, n3, acc_in_lds);
-  else
-    hipLaunchKernelGGL(d4est_hip::restrict_kernel<true>, dim3(std::min(t->n_items, 65536)), dim3(256), lds, t->stream, x_fine_dev, x_coarse_dev,
-                       t->d_child, t->d_off, t->d_item_first, t->d_ops, t->n_items, n3, acc_in_lds);
+  for (const d4est_hip_transfer::List& L : t->restrict_lists) {
+    if (L.NH > 0) {   // P^T: the prolongation itself is the (Nh x NH) operand; the projection: its operator transposed
+      d4est_hip::launch_fast_restrict(t, x_fine_dev, x_coarse_dev, project ? t->d_ropsT : t->d_ops, L.NH, L.dmax, t->d_lists + L.first, L.n, L.nc);
+      continue;
+    }
+    const int n3 = t->max_n * t->max_n * t->max_n;
+    const int acc_in_lds = ((size_t)3 * n3 * sizeof(double) <= 160 * 1024) ? 1 : 0;
+    const size_t lds = (size_t)(acc_in_lds ? 3 : 2) * n3 * sizeof(double);
+    if (lds > 160 * 1024) D4EST_HIP_ABORT("%s: degree too high for the LDS-resident kernel", who);
+    const void* fn = project ? reinterpret_cast<const void*>(d4est_hip::restrict_kernel<false>) : reinterpret_cast<const void*>(d4est_hip::restrict_kernel<true>);
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (project)
+      hipLaunchKernelGGL(d4est_hip::restrict_kernel<false>, dim3(std::min(L.n, 65536)), dim3(256), lds, t->stream, x_fine_dev, x_coarse_dev,
+                         t->d_child, t->d_off, t->d_item_first, t->d_rops, t->d_lists + L.first, L.n, n3, acc_in_lds);
+    else
+      hipLaunchKernelGGL(d4est_hip::restrict_kernel<true>, dim3(std::min(L.n, 65536)), dim3(256), lds, t->stream, x_fine_dev, x_coarse_dev,
+                         t->d_child, t->d_off, t->d_item_first, t->d_ops, t->d_lists + L.first, L.n, n3, acc_in_lds);
+  }
   HIP_CHECK(hipGetLastError());
 }
 

@@ -19,6 +19,15 @@ def _items(seed, n_items, pmax):
         degh[8:16] = [17, 18, 19, 19, 18, 17, 19, 18]
         degh[16] = 19
         return hrefine, degH, degh
+    if pmax == "p15d3":   # the edge of the compile-time kernels: coarse p = 15 (16 nodes), fine sizes up to + 3; and one step beyond each
+        hrefine = np.array([1, 0, 0, 1], dtype=np.int32)
+        degH = np.array([15, 15, 16, 3], dtype=np.int32)
+        degh = np.zeros(32, dtype=np.int32)
+        degh[0:8] = [15, 16, 17, 18, 18, 17, 16, 15]
+        degh[8] = 18
+        degh[16] = 17
+        degh[24:32] = [3, 4, 5, 6, 7, 3, 4, 7]     # + 4: beyond the fast kernels' range, the whole item takes the generic path
+        return hrefine, degH, degh
     rng = np.random.RandomState(seed)
     hrefine = rng.randint(0, 2, size=n_items).astype(np.int32)
     degH = rng.randint(1, pmax, size=n_items).astype(np.int32)
@@ -68,10 +77,17 @@ def _oracle_transfer(oracle, hrefine, degH, degh, x, prolong):
     return out
 
 
-@pytest.mark.parametrize("seed,n_items,pmax", [(1, 7, 4), (2, 40, 6), (3, 9, 9), (4, 3, 13), (7, 3, "p19")])
-def test_prolong_restrict_parity(gpu, hiplib, oracle, seed, n_items, pmax):
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("seed,n_items,pmax", [(1, 7, 4), (2, 40, 6), (3, 9, 9), (4, 3, 13), (7, 3, "p19"), (9, 4, "p15d3")])
+def test_prolong_restrict_parity(gpu, hiplib, oracle, seed, n_items, pmax, generic, monkeypatch):
+    """generic = True forces every item through the runtime-size kernels (D4EST_HIP_TRANSFER_GENERIC), False takes the compile-time
+    kernels wherever they apply (coarse size <= 16 nodes, fine sizes within + 3)"""
     import torch
     from disco4est_amd import Transfer, mesh as M
+    if generic:
+        monkeypatch.setenv("D4EST_HIP_TRANSFER_GENERIC", "1")
+    else:
+        monkeypatch.delenv("D4EST_HIP_TRANSFER_GENERIC", raising=False)
     hrefine, degH, degh = _items(seed, n_items, pmax)
     t = Transfer(hrefine, degH, degh)
     xc = M.splitmix64_uniform(seed, t.coarse_nodes) - 0.5
@@ -105,7 +121,7 @@ def test_empty_transfer(gpu, hiplib):
     t.destroy()
 
 
-@pytest.mark.parametrize("seed,n_items,pmax", [(5, 12, 5), (6, 6, 9), (8, 3, "p19")])
+@pytest.mark.parametrize("seed,n_items,pmax", [(5, 12, 5), (6, 6, 9), (8, 3, "p19"), (10, 4, "p15d3")])
 def test_projection_parity(gpu, hiplib, oracle, seed, n_items, pmax):
     """d4est_hip_transfer_project = d4est_operators_apply_p_restrict / _hp_restrict per item (the L2 projection of a field onto the
     coarse space): parity with the oracle, and project(prolong(x)) = x"""
