@@ -138,20 +138,21 @@ def brick_operator_plan(level, deg, stream, torch, dev):
     return m, plan, x, y
 
 
-def gate_operator(name, plan, level, deg, x, y, shards=3):
+def gate_operator(name, plan, level, deg, x, y, shards=3, factory=None, n_total=None, cnt=64):
     """parity gate of a timed full-operator secondary: A u of the plan's default kernel path against the oracle on 64-element shards cut
-    from the mesh (whole-element ghost data gathered from the global vector); raises if the worst shard exceeds 1e-12"""
+    from the mesh (whole-element ghost data gathered from the global vector); raises if the worst shard exceeds 1e-12.
+    factory(first, count) -> the shard's mesh (default: the uniform brick of `level`, `deg`); n_total: elements of the whole mesh"""
     from disco4est_amd import mesh as M
     from tests import oracle_lib
     oracle = oracle_lib.load()
     plan.apply_aij(x, y)
     u, got = x.cpu().numpy(), y.cpu().numpy()
-    n = 8 ** level
-    cnt = min(64, n)
+    n = 8 ** level if n_total is None else n_total
+    cnt = min(cnt, n)
     firsts = sorted({0, ((n // 2 + n // 16) // cnt) * cnt, n - cnt})
     worst = 0.0
     for first in firsts[:shards]:
-        sub = M.BrickMesh(level, deg, first=first, count=cnt)
+        sub = M.BrickMesh(level, deg, first=first, count=cnt) if factory is None else factory(first, cnt)
         Js, rsts = sub.geometry(None); ss = sub.build_sides(None)
         s0 = sub.global_nodal_offset
         ref = oracle.apply_aij(sub, Js, rsts, ss, np.ascontiguousarray(u[s0:s0 + sub.local_nodes]),
@@ -161,6 +162,22 @@ def gate_operator(name, plan, level, deg, x, y, shards=3):
     if not worst <= 1e-12:
         raise RuntimeError("parity gate of %s failed: %.3e" % (name, worst))
     return worst
+
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X dense FP64 vector = matrix peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def stiffness_flops_per_dof(N, NQ):
+    """fused sum-factorisation, forward 2 (2 N^3 NQ + 3 N^2 NQ^2 + 3 N NQ^3), backward the same, metric 15 NQ^3
+    (= 32 N + 15 per DoF at NQ = N)"""
+    return (4.0 * (2 * N ** 3 * NQ + 3 * N * N * NQ * NQ + 3 * N * NQ ** 3) + 15.0 * NQ ** 3) / N ** 3
+
+
+def mixed_operator_bytes(m, sides):
+    """algorithmic bytes of one full operator apply on any mesh: u 8 + A u 8 per node, metric 48 per quadrature node, the 7 pre-combined
+    face factors per mortar quadrature node (total_mortar_nodes counts every side's block once; the four small sides of a hanging face
+    share theirs)"""
+    return 16.0 * m.local_nodes + 48.0 * m.local_nodes_quad + 56.0 * float(sides["total_mortar_nodes"])
 
 
 def eig_window(plan, x, torch, its=12):
@@ -585,14 +602,20 @@ def main():
                 plan.set_tuning(7, -1)
                 ms = time_region(lambda: plan.apply_stiffness_matrix(du, dAu), 100, stream, torch, warm=20)
                 sec["stiffness_p%d_affine_path" % args.deg] = {"ms": ms, "GDoF_per_s": dofs_per_rank / (ms * 1e-3) / 1e9,
-                                                                "algorithmic_bytes_per_dof": 16.0, "kernel": plan.last_kernel()}
+                                                                "algorithmic_bytes_per_dof": 16.0, "kernel": plan.last_kernel(),
+                                                                "flops_per_dof": stiffness_flops_per_dof(N, NQ),
+                                                                "roofline_frac_fp64": stiffness_flops_per_dof(N, NQ) * dofs_per_rank / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
                 # ... and the full operator / the smoother iteration with the affine volume metric (the face factors are still streamed):
                 # what a brick gets when tuning key 7 is left alone; labelled separately like the entry above
                 for name, fn, applies in (("apply_aij_affine_path", lambda: plan.apply_aij(du, dAu), 1),
                                           ("cheby_5_iterations_affine_path", lambda: plan.cheby_iterate(du, rhs, dAu, r, 5, lmin, lmax, 0), 5)):
                     ms = time_region(fn, 50, stream, torch, warm=10)
+                    bpd_af = 16.0 + 6.0 * 7.0 * 8.0 * NQ * NQ / N ** 3 + (CHEBY_VECTOR_BYTES_PER_DOF if applies > 1 else 0.0)
                     sec[name] = {"ms": ms, "GDoF_per_s": dofs_per_rank * applies / (ms * 1e-3) / 1e9, "face_path": plan.face_path(),
-                                 "algorithmic_bytes_per_dof": 16.0 + 6.0 * 7.0 * 8.0 * NQ * NQ / N ** 3 + (CHEBY_VECTOR_BYTES_PER_DOF if applies > 1 else 0.0)}
+                                 "algorithmic_bytes_per_dof": bpd_af,
+                                 "roofline_frac_hbm": bpd_af * dofs_per_rank * applies / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 # the volume term's flops alone (the face terms add to them): a lower bound of the FP64 fraction
+                                 "roofline_frac_fp64_volume_flops_only": stiffness_flops_per_dof(N, NQ) * dofs_per_rank * applies / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
                 plan.set_tuning(7, 0)
             # stiffness apply at the other degrees SURVEY.md section 8d names (same general path, ~2-8 MDoF each)
             for deg, level, count in ((3, 5, None), (11, 4, None), (15, 4, 2048)):
@@ -610,7 +633,9 @@ def main():
                     p2.set_tuning(7, -1)
                     ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 40, stream, torch, warm=20)
                     sec["stiffness_p15_affine_path"] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes,
-                                                        "kernel": p2.last_kernel(), "algorithmic_bytes_per_dof": 16.0}
+                                                        "kernel": p2.last_kernel(), "algorithmic_bytes_per_dof": 16.0,
+                                                        "flops_per_dof": stiffness_flops_per_dof(16, 16),
+                                                        "roofline_frac_fp64": stiffness_flops_per_dof(16, 16) * m2.local_nodes / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
                 p2.destroy()
                 del x2, y2
             # off-cache points (the config-2 working set, 134 MB, sits in the 256 MB Infinity Cache): level 5 at p = 7 (1.07 GB per
@@ -630,7 +655,9 @@ def main():
                     p2.set_tuning(7, -1)
                     ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 10, stream, torch)
                     sec[name + "_affine_path"] = {"ms": ms, "GDoF_per_s": m2.local_nodes / (ms * 1e-3) / 1e9, "dofs": m2.local_nodes,
-                                                  "kernel": p2.last_kernel(), "algorithmic_bytes_per_dof": 16.0}
+                                                  "kernel": p2.last_kernel(), "algorithmic_bytes_per_dof": 16.0,
+                                                  "flops_per_dof": stiffness_flops_per_dof(deg + 1, deg + 1),
+                                                  "roofline_frac_fp64": stiffness_flops_per_dof(deg + 1, deg + 1) * m2.local_nodes / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
                 p2.destroy()
                 del x2, y2
             # the FULL operator at the degrees of BASELINE configs 3 and 5: one kernel per apply
@@ -698,12 +725,24 @@ def main():
                 p4.set_faces(m4.build_sides(None))
                 x4 = torch.from_numpy(m4.field()).to(dev)
                 y4 = torch.empty_like(x4)
+                s4 = m4.build_sides(None)
+                try:
+                    g4 = None if args.no_check else gate_operator("mixed_p3_to_9_level4", p4, 4, None, x4, y4, shards=3,
+                                                                  factory=lambda first, cnt: M.BrickMesh(4, degs, first=first, count=cnt))
+                except Exception as exc:   # recorded in the entry (and on stderr), the other secondaries still run
+                    log("parity gate mixed_p3_to_9_level4 FAILED: %r" % (exc,))
+                    g4 = "FAILED: " + repr(exc)
                 ms_s = time_region(lambda: p4.apply_stiffness_matrix(x4, y4), 50, stream, torch, warm=10)
                 ms_a = time_region(lambda: p4.apply_aij(x4, y4), 50, stream, torch, warm=10)
+                by4 = mixed_operator_bytes(m4, s4)
                 sec["mixed_p3_to_9_level4"] = {"dofs": m4.local_nodes, "elements": m4.n_elements, "stiffness_ms": ms_s,
                                                "stiffness_GDoF_per_s": m4.local_nodes / (ms_s * 1e-3) / 1e9, "apply_aij_ms": ms_a,
                                                "apply_aij_GDoF_per_s": m4.local_nodes / (ms_a * 1e-3) / 1e9,
-                                               "face_path": p4.face_path()}
+                                               "algorithmic_bytes_per_dof": by4 / m4.local_nodes,
+                                               "roofline_frac_hbm": by4 / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "stiffness_roofline_frac_hbm": 64.0 * m4.local_nodes / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "traffic": (json.load(open(tf)) if os.path.exists(tf) else {}).get("mixed_p3_to_9_level4", {}).get("hbm_bytes_per_launch"),
+                                               "face_path": p4.face_path(), "parity_gate_rel_inf": g4}
                 p4.destroy()
                 del x4, y4
             # a locally refined (hanging-face) brick, the mesh class of BASELINE config 4: level 4 with every 64th octant refined
@@ -733,12 +772,170 @@ def main():
                 print("parity gate hanging_level4_p7: split face kernels against the mortar-record kernels: rel-inf = %.3e" % g5, file=sys.stderr)
                 if not args.no_check and not g5 <= 1e-12:
                     raise RuntimeError("hanging_level4_p7: the split face path deviates from the record kernels by %.3e" % g5)
+                g5o = None
+                if not args.no_check:   # the default path against the ORACLE on shards of the hanging mesh (ghost elements gathered from the global vector)
+                    p5 = Plan(m5.deg, m5.deg_quad, m5.nodal_stride, m5.quad_stride, 0, stream=stream)
+                    p5.set_geometry(J5, rst5); p5.set_tuning(7, 0); p5.set_faces(s5)
+                    y5 = torch.empty_like(x5)
+                    try:
+                        g5o = gate_operator("hanging_level4_p7", p5, 4, None, x5, y5, shards=3, n_total=m5.n_elements, cnt=71,
+                                            factory=lambda first, cnt: M.HangingBrickMesh(4, refine, 7, first=first, count=cnt))
+                    except Exception as exc:
+                        log("parity gate hanging_level4_p7 FAILED: %r" % (exc,))
+                        g5o = "FAILED: " + repr(exc)
+                    p5.destroy()
+                by5 = mixed_operator_bytes(m5, s5)
                 sec["hanging_level4_p7"] = {"dofs": m5.local_nodes, "elements": m5.n_elements,
                                             "hanging_faces": int((np.asarray(s5["side_hang"]) == 1).sum()),
                                             "apply_aij_ms": res5[-1][0], "apply_aij_GDoF_per_s": m5.local_nodes / (res5[-1][0] * 1e-3) / 1e9,
+                                            "algorithmic_bytes_per_dof": by5 / m5.local_nodes,
+                                            "roofline_frac_hbm": by5 / (res5[-1][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "traffic": (json.load(open(tf)) if os.path.exists(tf) else {}).get("hanging_level4_p7", {}).get("hbm_bytes_per_launch"),
                                             "apply_aij_ms_record_kernels_only": res5[0][0], "face_path": "two-phase, conforming sides / hanging sides split",
-                                            "parity_gate_rel_inf_vs_record_kernels": g5}
+                                            "parity_gate_rel_inf": g5o, "parity_gate_rel_inf_vs_record_kernels": g5}
                 del x5, res5
+            # BASELINE config 5's mesh class AT SIZE: the reference's 7-tree cubed sphere, level 2 (448 curved elements), p = 15, every
+            # geometric factor (volume metric and mortar factors through the oriented tree faces) generated on the device from the analytic
+            # map; side list from d4est_hip_build_sides.  Gate: the oracle on shards of 4 elements with host-computed factors.
+            def sec_cubed_sphere():
+                from disco4est_amd import forest as F
+                conn = F.cubed_sphere_7tree_connectivity()
+                cmap = F.CubedSphere7Map(1.0, 2.0)
+                m6 = F.ForestMesh(conn, 2, 15, cmap)
+                tree6, q6, dq6 = m6.cells()
+                par6 = (1.0, 2.0, 0.0)
+                p6 = Plan(m6.deg, m6.deg_quad, m6.nodal_stride, m6.quad_stride, 0, stream=stream)
+                p6.set_geometry_analytic(1, par6, tree6, q6, dq6, m6.nf)
+                p6.set_tuning(7, 0)
+                s6 = m6.build_sides_c()
+                p6.set_faces(s6, 10.0, 0, analytic=(1, par6, tree6, q6, dq6, m6.nf, None))
+                u6 = m6.field()
+                x6 = torch.from_numpy(u6).to(dev); y6 = torch.empty_like(x6)
+                g6 = None
+                if not args.no_check:
+                    from tests import oracle_lib
+                    orc = oracle_lib.load()
+                    p6.apply_aij(x6, y6)
+                    got6 = y6.cpu().numpy(); g6 = 0.0
+                    for first in (6 * 64, 2 * 64 + 20):
+                        sub = F.ForestMesh(conn, 2, 15, cmap, first=first, count=4)
+                        Js, rsts = sub.geometry(); ss = sub.build_sides()
+                        s0 = sub.global_nodal_offset
+                        ref = orc.apply_aij(sub, Js, rsts, ss, np.ascontiguousarray(u6[s0:s0 + sub.local_nodes]), u_ghost=sub.gather_ghost(ss, u6),
+                                            nthreads=min(os.cpu_count() or 1, 16))
+                        g6 = max(g6, float(np.abs(got6[s0:s0 + sub.local_nodes] - ref).max() / np.abs(ref).max()))
+                    log("parity gate apply_aij_cubed_sphere_p15: A u against the oracle on 2 shards of 4 curved elements: rel-inf = %.3e  [%s]" % (g6, p6.face_path()))
+                    if not g6 <= 1e-12:
+                        raise RuntimeError("parity gate of apply_aij_cubed_sphere_p15 failed: %.3e" % g6)
+                ms = time_region(lambda: p6.apply_aij(x6, y6), 30, stream, torch, warm=20)
+                by6 = 16.0 * m6.local_nodes + 48.0 * m6.local_nodes_quad + 56.0 * float(s6["total_mortar_nodes"])
+                sec["apply_aij_cubed_sphere_p15"] = {"ms": ms, "GDoF_per_s": m6.local_nodes / (ms * 1e-3) / 1e9, "dofs": m6.local_nodes,
+                                                     "elements": m6.n_elements, "trees": 7, "algorithmic_bytes_per_dof": by6 / m6.local_nodes,
+                                                     "roofline_frac_hbm": by6 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "face_path": p6.face_path(),
+                                                     "kernel": p6.last_kernel(), "parity_gate_rel_inf": g6, "stream_mode": p6.stream_mode(),
+                                                     "geometry": "cubed_sphere_7tree R0 = 1, R1 = 2, factors generated on the device"}
+                p6.destroy()
+                del x6, y6
+            if args.geometry != "sine":
+                try:
+                    sec_cubed_sphere()
+                except Exception as exc:   # this block's failure (a parity gate included) is recorded in its own entry
+                    log("secondary apply_aij_cubed_sphere_p15 failed: %r" % (exc,))
+                    sec["apply_aij_cubed_sphere_p15"] = {"error": repr(exc)}
+            # The multigrid MATRIX OPERATOR (verdict row a14): apply_lhs on a COARSE level, whose zeroth-order term the reference holds as
+            # Galerkin-restricted dense element blocks (Solver/d4est_solver_multigrid_matrix_operator.c).  Coarse = level 3, p = 7 (512
+            # elements), fine = level 4, p = 7 (config 2): blocks built on the device (QUAD_COMPUTE_MATRIX for every fine element, P^T M P),
+            # then the term (a) as the dense-block stream (1.07 GB per apply: HBM-bound) and (b) as the matrix-free Galerkin chain
+            # (prolong, fine weighted mass, prolong-transpose).  Gate: (a) against a torch bmm of the same blocks, (b) against (a).
+            def sec_multigrid():
+                from disco4est_amd import Transfer
+                mcz, pcz, xz, yz = brick_operator_plan(3, 7, stream, torch, dev)
+                mfz, pfz, _, _ = brick_plan(4, 7, stream, torch, dev)
+                cz = 1.0 + torch.rand(mfz.local_nodes_quad, dtype=torch.float64, device=dev)
+                pfz.set_lhs_coefficient(cz)
+                Tz = Transfer(np.ones(mcz.n_elements, np.int32), np.full(mcz.n_elements, 7, np.int32), np.full(8 * mcz.n_elements, 7, np.int32), stream=stream)
+                fb = torch.empty(pfz.matrix_nodes(), dtype=torch.float64, device=dev)
+                cb = torch.empty(pcz.matrix_nodes(), dtype=torch.float64, device=dev)
+                t0 = time.perf_counter()
+                pfz.compute_weighted_mass_blocks(cz, fb); Tz.galerkin_blocks(fb, cb); torch.cuda.synchronize()
+                setup_ms = (time.perf_counter() - t0) * 1e3
+                del fb
+                ms_lap = time_region(lambda: pcz.apply_aij(xz, yz), 30, stream, torch, warm=10)
+                lapz = yz.clone()
+                pcz.set_lhs_element_blocks(cb)
+                pcz.apply_lhs(xz, yz)
+                refz = lapz + torch.bmm(cb.view(mcz.n_elements, 512, 512), xz.view(mcz.n_elements, 512, 1)).view(-1)
+                gb_ = float((yz - refz).abs().max() / refz.abs().max())
+                ya_ = yz.clone()
+                ms_blk = time_region(lambda: pcz.apply_lhs(xz, yz), 20, stream, torch, warm=5)
+                pcz.set_lhs_galerkin_chain([Tz], pfz)
+                pcz.apply_lhs(xz, yz)
+                gc_ = float((yz - ya_).abs().max() / ya_.abs().max())
+                log("parity gate mg_matrix_operator_level3_p7: block term against torch.bmm rel-inf = %.3e, Galerkin chain against the blocks %.3e" % (gb_, gc_))
+                if not args.no_check and not (gb_ <= 1e-12 and gc_ <= 1e-12):
+                    raise RuntimeError("parity gate of mg_matrix_operator_level3_p7 failed: %.3e %.3e" % (gb_, gc_))
+                ms_chn = time_region(lambda: pcz.apply_lhs(xz, yz), 20, stream, torch, warm=5)
+                blk_bytes = 8.0 * cb.numel()
+                sec["mg_matrix_operator_level3_p7"] = {
+                    "coarse_elements": mcz.n_elements, "coarse_dofs": mcz.local_nodes, "fine_dofs": mfz.local_nodes, "apply_aij_ms": ms_lap,
+                    "apply_lhs_blocks_ms": ms_blk, "block_term_ms": ms_blk - ms_lap, "block_bytes": blk_bytes,
+                    "block_term_GB_per_s": blk_bytes / ((ms_blk - ms_lap) * 1e-3) / 1e9,
+                    "block_term_roofline_frac_hbm": blk_bytes / ((ms_blk - ms_lap) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "apply_lhs_chain_ms": ms_chn, "chain_term_ms": ms_chn - ms_lap,
+                    # the chain's algorithmic bytes: fine coefficient 8 per fine quadrature node + the coarse vector in and out
+                    "chain_algorithmic_bytes": 8.0 * mfz.local_nodes_quad + 16.0 * mcz.local_nodes,
+                    "setup_blocks_ms": setup_ms, "parity_gate_rel_inf_blocks_vs_bmm": gb_, "parity_gate_rel_inf_chain_vs_blocks": gc_}
+                pcz.set_lhs_galerkin_chain([], None)
+                # hp-multigrid transfers at config-2 size (verdict item 8): p-coarsening 7 -> 6 on the level-4 brick and h-coarsening level 4 ->
+                # level 3 at p = 7; algorithmic bytes = one vector in + one out.  Then a two-grid cycle on config 2 (3 Chebyshev iterations,
+                # residual, restriction, 3 iterations on the level-3 re-discretisation, prolongation + correction, 3 iterations).
+                hp = {}
+                for tname, Tt in (("p7_to_p6_level4", Transfer(np.zeros(4096, np.int32), np.full(4096, 6, np.int32),
+                                                                np.ascontiguousarray(np.stack([np.full(4096, 7, np.int32)] + [np.zeros(4096, np.int32)] * 7, axis=1).reshape(-1)), stream=stream)),
+                                  ("level4_to_level3_p7", Tz)):
+                    xc_ = torch.rand(Tt.coarse_nodes, dtype=torch.float64, device=dev); xf_ = torch.rand(Tt.fine_nodes, dtype=torch.float64, device=dev)
+                    oc_, of_ = torch.empty_like(xc_), torch.empty_like(xf_)
+                    byt = 8.0 * (Tt.coarse_nodes + Tt.fine_nodes)
+                    ent = {"coarse_dofs": Tt.coarse_nodes, "fine_dofs": Tt.fine_nodes, "algorithmic_bytes": byt}
+                    for op, fn in (("prolong", lambda: Tt.prolong(xc_, of_)), ("restrict", lambda: Tt.restrict(xf_, oc_)), ("project", lambda: Tt.project(xf_, oc_))):
+                        ms_ = time_region(fn, 50, stream, torch, warm=10)
+                        ent[op + "_us"] = ms_ * 1e3
+                        ent[op + "_roofline_frac_hbm"] = byt / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    # adjointness <P xc, xf> = <xc, P^T xf> as the gate of the pair (each is held to the oracle by tests/test_transfer_gpu.py)
+                    Tt.prolong(xc_, of_); Tt.restrict(xf_, oc_)
+                    a_, b_ = float(of_ @ xf_), float(xc_ @ oc_)
+                    ent["adjointness_rel"] = abs(a_ - b_) / max(abs(a_), abs(b_))
+                    hp[tname] = ent
+                    if Tt is not Tz:
+                        Tt.destroy()
+                sec["hp_transfer_level4_p7"] = hp
+                l0f, l1f = lmin, lmax
+                l0c, l1c = eig_window(pcz, xz, torch)
+                rf = torch.empty_like(du); ef = torch.empty_like(du)
+                rc = torch.empty_like(xz); ec = torch.empty_like(xz); Ac = torch.empty_like(xz); rr = torch.empty_like(xz)
+                uu = torch.zeros_like(du)
+
+                def two_grid():
+                    plan.cheby_iterate(uu, du, dAu, rf, 3, l0f, l1f, 1)      # pre-smoothing, rf = rhs - A u on exit (rhs = du)
+                    Tz.restrict(rf, rc)
+                    ec.zero_()
+                    pcz.cheby_iterate(ec, rc, Ac, rr, 3, l0c, l1c, 0)
+                    Tz.prolong(ec, ef)
+                    uu.add_(ef)
+                    plan.cheby_iterate(uu, du, dAu, rf, 3, l0f, l1f, 0)
+                ms_tg = time_region(two_grid, 20, stream, torch, warm=5)
+                ms_sm = time_region(lambda: plan.cheby_iterate(uu, du, dAu, rf, 3, l0f, l1f, 1), 20, stream, torch, warm=5)
+                sec["two_grid_cycle_level4_p7"] = {"ms": ms_tg, "fine_smoother_3_iterations_with_residual_ms": ms_sm,
+                                                   "transfer_us": hp["level4_to_level3_p7"]["restrict_us"] + hp["level4_to_level3_p7"]["prolong_us"],
+                                                   "fine_dofs": mesh.local_nodes, "coarse_dofs": mcz.local_nodes}
+                pcz.destroy(); pfz.destroy(); Tz.destroy()
+                del cb, cz, xz, yz
+            if args.geometry != "sine":
+                try:
+                    sec_multigrid()
+                except Exception as exc:   # this block's failure (a parity gate included) is recorded in its own entry
+                    log("secondary mg_matrix_operator_level3_p7 failed: %r" % (exc,))
+                    sec["mg_matrix_operator_level3_p7"] = {"error": repr(exc)}
             out["secondary"] = sec
         except Exception as exc:  # secondary numbers must never break the headline line
             out["secondary"] = {"error": repr(exc)}

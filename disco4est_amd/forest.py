@@ -692,6 +692,36 @@ class ForestMesh:
             out.update(side_hang=side_hang, side_sub=side_sub, side_nbr4=side_nbr4, side_orientation=side_orientation)
         return out
 
+    def build_sides_c(self):
+        """The side arrays of Plan.set_faces from d4est_hip_build_sides (csrc/d4est_hip_sides.cpp: connectivity + quadrant list, the
+        host-side replacement of the p4est_iterate face walk) WITHOUT any geometric factor -- for plans whose mortar factors are
+        generated on the device (Plan.set_faces(..., analytic=...) / brick=...).  Whole meshes only (no ghost quadrants)."""
+        import ctypes
+        if self.n_elements != self.global_elements:
+            raise ValueError("build_sides_c: whole meshes only (a shard's ghost quadrants come from build_sides)")
+        lib = capi.load_library()
+        ne = self.n_elements
+        tree, q, dq = self.cells()
+        I = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        ins = [I(self.conn.tree_to_tree), I(self.conn.tree_to_face), I(tree), I(q), I(dq), I(self.deg), I(self.deg_quad)]
+        z = np.zeros(1, dtype=np.int32)
+        out = {k: np.zeros(6 * ne, dtype=np.int32) for k in ("side_nbr", "side_nbr_face", "side_reorder", "side_orientation", "side_hang",
+                                                             "side_sub", "side_mortar_stride", "side_bndry_stride")}
+        out["side_nbr4"] = np.zeros(24 * ne, dtype=np.int32)
+        tm, tb = ctypes.c_int(0), ctypes.c_int(0)
+        hang = lib.d4est_hip_build_sides(self.conn.num_trees, vp(ins[0]), vp(ins[1]), self.nf, ne, vp(ins[2]), vp(ins[3]), vp(ins[4]), vp(ins[5]),
+                                         vp(ins[6]), 0, vp(z), vp(z), vp(z), vp(z), vp(out["side_nbr"]), vp(out["side_nbr_face"]),
+                                         vp(out["side_reorder"]), vp(out["side_orientation"]), vp(out["side_hang"]), vp(out["side_sub"]),
+                                         vp(out["side_nbr4"]), vp(out["side_mortar_stride"]), vp(out["side_bndry_stride"]),
+                                         ctypes.byref(tm), ctypes.byref(tb))
+        out.update(total_mortar_nodes=tm.value, total_bndry_nodes=tb.value, ghost_deg=np.zeros(0, np.int32), ghost_deg_quad=np.zeros(0, np.int32),
+                   ghost_global_ids=np.zeros(0, np.int64), ghost_nodes=0)
+        if not hang:
+            for k in ("side_hang", "side_sub", "side_nbr4", "side_orientation"):
+                out.pop(k)
+        return out
+
     def cells(self, global_ids=None):
         """(tree, q[n,3], dq) of the local elements (or of the given global ids, e.g. sides["ghost_global_ids"]) in units of the fine
         grid, root length = self.nf: d4est_element_data_t::tree, ::q, ::dq for d4est_hip_plan_set_geometry_analytic"""

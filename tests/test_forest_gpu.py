@@ -145,6 +145,63 @@ def test_cubed_sphere_consistency_at_size(gpu, hiplib):
     plan.destroy()
 
 
+def test_cubed_sphere_p15_at_size(gpu, hiplib, oracle, monkeypatch):
+    """Config 5 at size: the 7-tree cubed sphere at level 2 (448 curved elements), p = 15, 1.84 MDoF, every geometric factor generated on the
+    device from the analytic map, on the DEFAULT kernel path (the whole operator in operator_mw_kernel<16>: asserted).  The oracle runs
+    on shards cut from the mesh (whole-element ghost data gathered from the global vector, host-computed factors of the shard) --
+    through faces between trees with orientation != 0 --; around it the size-independent identities: symmetry, positivity, constants
+    annihilated with matching Dirichlet data, determinism."""
+    import torch
+    from disco4est_amd import Plan
+    monkeypatch.delenv("D4EST_HIP_FACE_DIRECT", raising=False)
+    conn = F.cubed_sphere_7tree_connectivity()
+    R0, R1 = 1.0, 2.0
+    mp = F.CubedSphere7Map(R0, R1)
+    m = F.ForestMesh(conn, 2, 15, mp)
+    assert m.n_elements == 448
+    tree, q, dq = m.cells()
+    params = (R0, R1, 0.0)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, m.quad_type)
+    plan.set_geometry_analytic(1, params, tree, q, dq, m.nf)
+    s = m.build_sides_c()      # topology only (d4est_hip_build_sides): no host-side geometric factor anywhere in this plan
+    plan.set_faces(s, 10.0, 0, analytic=(1, params, tree, q, dq, m.nf, None))
+    assert plan.face_path() == "direct+volume"
+    u = m.field()
+    du = _t(u, gpu)
+    Au = torch.full_like(du, float("nan"))
+    plan.apply_aij(du, Au)
+    assert "operator_mw_kernel<16" in plan.last_kernel(), plan.last_kernel()
+    got = Au.cpu().numpy()
+    assert np.isfinite(got).all()
+    Au2 = torch.full_like(du, float("nan"))
+    plan.apply_aij(du, Au2)
+    assert torch.equal(Au, Au2)
+    # oracle on three shards of 4 elements: inside the centre cube's neighbourhood (tree 6 against the wedges: orientation != 0), in a
+    # wedge, and the last elements (outer boundary)
+    n_oriented = 0
+    for first in (6 * 64, 2 * 64 + 20, m.n_elements - 4):
+        sub = F.ForestMesh(conn, 2, 15, mp, first=first, count=4)
+        Js, rsts = sub.geometry(); ss = sub.build_sides()
+        n_oriented += int(((ss["side_nbr"] <= -2) & (ss["side_reorder"] != 0)).sum())
+        s0 = sub.global_nodal_offset
+        ref = oracle.apply_aij(sub, Js, rsts, ss, np.ascontiguousarray(u[s0:s0 + sub.local_nodes]), u_ghost=sub.gather_ghost(ss, u), nthreads=8)
+        assert _rel(got[s0:s0 + sub.local_nodes], ref) <= RTOL
+    assert n_oriented > 0
+    v = _t(M.splitmix64_uniform(1, m.local_nodes), gpu)
+    w = _t(M.splitmix64_uniform(2, m.local_nodes), gpu)
+    Av, Aw = torch.empty_like(v), torch.empty_like(w)
+    plan.apply_aij(v, Av)
+    plan.apply_aij(w, Aw)
+    a, b = float(w @ Av), float(v @ Aw)
+    assert abs(a - b) <= 1e-11 * abs(a)
+    assert float(v @ Av) > 0
+    plan.set_dirichlet_values(np.full(int(s["total_bndry_nodes"]), 3.0))
+    c = torch.full_like(v, 3.0)
+    plan.apply_aij(c, Av)
+    assert float(Av.abs().max()) <= 1e-8 * float(Aw.abs().max())
+    plan.destroy()
+
+
 @pytest.mark.parametrize("deg,refine", [(3, None), (9, None), (4, [0, 0, 1, 0, 0, 0, 1])])
 def test_cubed_sphere_smoothers(gpu, hiplib, oracle, deg, refine):
     """Chebyshev iteration and cg_eigs on the multi-tree operator (d4est_solver_multigrid_smoother_cheby_iterate_aux, cg_eigs)."""
