@@ -180,6 +180,16 @@ def mixed_operator_bytes(m, sides):
     return 16.0 * m.local_nodes + 48.0 * m.local_nodes_quad + 56.0 * float(sides["total_mortar_nodes"])
 
 
+def graded_degrees(level):
+    """config 4's degree field: p = 3 ... 9 over the level-`level` brick, SMOOTHLY graded (what smooth_pred hp-adaptation leaves behind:
+    high degree where the solution is smooth, i.e. away from a corner here), neighbours differ by at most one"""
+    from disco4est_amd import mesh as M
+    ijk = M.morton_order(level).astype(np.float64)
+    n = float(1 << level)
+    r = np.sqrt(((ijk + 0.5) ** 2).sum(axis=1)) / (np.sqrt(3.0) * n)      # distance from the corner, 0 .. 1
+    return np.clip(np.rint(3.0 + 6.0 * r), 3, 9).astype(np.int32)
+
+
 def eig_window(plan, x, torch, its=12):
     """(lmin, lmax) for the Chebyshev secondaries: 1.1 x a power-iteration estimate of the largest eigenvalue, and 1/30 of it (the
     reference's smoother window, d4est_solver_multigrid_smoother_cheby.c:60-76) -- so that the timed iterations contract"""
@@ -306,8 +316,12 @@ def sharded_secondary(args, rank, world, dev, stream, dist, torch):
         invariance = float(np.abs(got - ref).max() / np.abs(ref).max())
         pf.destroy()
     res = {"transport": "host-side torch.distributed (one-GPU rehearsal)" if rehearsal else "RCCL in C (csrc/d4est_hip_comm.hip)",
-           "rccl_ranks": world, "elements_per_rank": [int(c) for _, c in parts], "exchange_doubles_sent_by_rank0": int(x.send_doubles),
+           "ranks": world, "elements_per_rank": [int(c) for _, c in parts], "exchange_doubles_sent_by_rank0": int(x.send_doubles),
            "peers_of_rank0": [int(p_) for p_ in sched.peers], "rank_count_invariance_rel_inf": invariance}
+    if not rehearsal:   # what RCCL itself says (ncclCommCount) -- absent on the host-transport rehearsal, where RCCL saw no ranks at all
+        res["rccl_ranks"] = int(comm.lib.d4est_hip_comm_nccl_count(comm.handle))
+        if res["rccl_ranks"] != world:
+            return {"error": "ncclCommCount = %d but WORLD_SIZE = %d" % (res["rccl_ranks"], world)}
 
     def timed(fn, reps):
         for _ in range(3):
@@ -333,6 +347,31 @@ def sharded_secondary(args, rank, world, dev, stream, dist, torch):
                                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_dof": bpd_aij}
     res["apply_aij_config2_strong"]["roofline"]["frac"] = res["apply_aij_config2_strong"]["roofline"]["achieved"] / HBM_PEAK_GBS
     x.destroy(); plan.destroy()
+    # ---- config 4's shape: degrees p = 3 ... 9 graded smoothly across the level-4 brick, split N ways BY DoF COUNT (p4est_partition with
+    # weights, SURVEY.md section 8e: the shards hold very different element counts); full operator, strong scaling
+    try:
+        degs = graded_degrees(args.level)
+        fullm = M.BrickMesh(args.level, degs)
+        mparts = P.partition_by_dofs(fullm.deg_global, world)
+        mm = M.BrickMesh(args.level, degs, first=mparts[rank][0], count=mparts[rank][1])
+        Jm, rstm = mm.geometry(None)
+        sm = mm.build_sides(None)
+        pm = Plan(mm.deg, mm.deg_quad, mm.nodal_stride, mm.quad_stride, 0, stream=stream)
+        pm.set_geometry(Jm, rstm)
+        pm.set_tuning(7, 0)
+        pm.set_faces(sm, 10.0, 0)
+        xm = wire(pm, mm, sm, mparts)
+        um = torch.from_numpy(mm.field(None)).to(dev)
+        Aum = torch.empty_like(um)
+        ms = timed(lambda: pm.apply_lhs(um, Aum), 30)
+        dofs_r = [int(sum((int(d) + 1) ** 3 for d in degs[f:f + c])) for f, c in mparts]
+        res["apply_aij_mixed_p3_to_9_strong"] = {"ms": ms, "GDoF_per_s": fullm.local_nodes / (ms * 1e-3) / 1e9, "dofs": fullm.local_nodes,
+                                                 "elements_per_rank": [int(c) for _, c in mparts], "dofs_per_rank": dofs_r,
+                                                 "dof_imbalance": max(dofs_r) / (sum(dofs_r) / float(world)), "face_path": pm.face_path(),
+                                                 "exchange_doubles_sent_by_rank0": int(xm.send_doubles)}
+        xm.destroy(); pm.destroy()
+    except Exception as exc:
+        res["apply_aij_mixed_p3_to_9_strong"] = {"error": repr(exc)}
     # ---- WEAK scaling of the full operator: one config-2 brick's worth of elements per rank, WITH neighbours -- the domain is the box of
     # the first `world` level-`level` sub-cubes of the level + 1 Morton sequence (world = 8: the whole level + 1 cube), every rank
     # owns one sub-cube and exchanges face traces with up to three others
@@ -794,14 +833,14 @@ def main():
                                             "apply_aij_ms_record_kernels_only": res5[0][0], "face_path": "two-phase, conforming sides / hanging sides split",
                                             "parity_gate_rel_inf": g5o, "parity_gate_rel_inf_vs_record_kernels": g5}
                 del x5, res5
-            # BASELINE config 5's mesh class AT SIZE: the reference's 7-tree cubed sphere, level 2 (448 curved elements), p = 15, every
+            # BASELINE config 5's mesh class AT SIZE: the reference's 7-tree cubed sphere, level 3 (3584 curved elements, 14.7 MDoF), p = 15, every
             # geometric factor (volume metric and mortar factors through the oriented tree faces) generated on the device from the analytic
             # map; side list from d4est_hip_build_sides.  Gate: the oracle on shards of 4 elements with host-computed factors.
             def sec_cubed_sphere():
                 from disco4est_amd import forest as F
                 conn = F.cubed_sphere_7tree_connectivity()
                 cmap = F.CubedSphere7Map(1.0, 2.0)
-                m6 = F.ForestMesh(conn, 2, 15, cmap)
+                m6 = F.ForestMesh(conn, 3, 15, cmap)
                 tree6, q6, dq6 = m6.cells()
                 par6 = (1.0, 2.0, 0.0)
                 p6 = Plan(m6.deg, m6.deg_quad, m6.nodal_stride, m6.quad_stride, 0, stream=stream)
@@ -809,16 +848,16 @@ def main():
                 p6.set_tuning(7, 0)
                 s6 = m6.build_sides_c()
                 p6.set_faces(s6, 10.0, 0, analytic=(1, par6, tree6, q6, dq6, m6.nf, None))
-                u6 = m6.field()
-                x6 = torch.from_numpy(u6).to(dev); y6 = torch.empty_like(x6)
+                x6 = torch.rand(m6.local_nodes, dtype=torch.float64, device=dev); y6 = torch.empty_like(x6)
+                u6 = x6.cpu().numpy()
                 g6 = None
                 if not args.no_check:
                     from tests import oracle_lib
                     orc = oracle_lib.load()
                     p6.apply_aij(x6, y6)
                     got6 = y6.cpu().numpy(); g6 = 0.0
-                    for first in (6 * 64, 2 * 64 + 20):
-                        sub = F.ForestMesh(conn, 2, 15, cmap, first=first, count=4)
+                    for first in (6 * 512, 2 * 512 + 200):   # in the centre cube (faces towards the wedges: orientation != 0) and in a wedge
+                        sub = F.ForestMesh(conn, 3, 15, cmap, first=first, count=4)
                         Js, rsts = sub.geometry(); ss = sub.build_sides()
                         s0 = sub.global_nodal_offset
                         ref = orc.apply_aij(sub, Js, rsts, ss, np.ascontiguousarray(u6[s0:s0 + sub.local_nodes]), u_ghost=sub.gather_ghost(ss, u6),
@@ -827,7 +866,7 @@ def main():
                     log("parity gate apply_aij_cubed_sphere_p15: A u against the oracle on 2 shards of 4 curved elements: rel-inf = %.3e  [%s]" % (g6, p6.face_path()))
                     if not g6 <= 1e-12:
                         raise RuntimeError("parity gate of apply_aij_cubed_sphere_p15 failed: %.3e" % g6)
-                ms = time_region(lambda: p6.apply_aij(x6, y6), 30, stream, torch, warm=20)
+                ms = time_region(lambda: p6.apply_aij(x6, y6), 10, stream, torch, warm=10)
                 by6 = 16.0 * m6.local_nodes + 48.0 * m6.local_nodes_quad + 56.0 * float(s6["total_mortar_nodes"])
                 sec["apply_aij_cubed_sphere_p15"] = {"ms": ms, "GDoF_per_s": m6.local_nodes / (ms * 1e-3) / 1e9, "dofs": m6.local_nodes,
                                                      "elements": m6.n_elements, "trees": 7, "algorithmic_bytes_per_dof": by6 / m6.local_nodes,

@@ -123,6 +123,7 @@ SIGNATURES = {
     "d4est_hip_comm_destroy": (None, [_vp]),
     "d4est_hip_comm_rank": (ctypes.c_int, [_vp]),
     "d4est_hip_comm_size": (ctypes.c_int, [_vp]),
+    "d4est_hip_comm_nccl_count": (ctypes.c_int, [_vp]),
     "d4est_hip_plan_set_rccl_exchange": (_vp, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "d4est_hip_rccl_exchange_destroy": (None, [_vp]),
     "d4est_hip_rccl_exchange_count": (ctypes.c_longlong, [_vp]),

@@ -4,7 +4,10 @@
 // mirror elements) by: ONE pack kernel (face-trace blocks of all peers into one send buffer) -> ncclGroupStart; ncclRecv / ncclSend
 // per neighbouring rank; ncclGroupEnd on a communication stream -> ONE unpack kernel into the ghost trace buffer.  Posted right after
 // the trace kernel, completed right before the flux kernel, so the transfers run beside the volume kernel (which needs no ghost data).
-// sc_allreduce of the CG / Lanczos scalars (src/Solver/d4est_solver_cg_eigs.c:181-243) becomes ncclAllReduce on the plan's stream.
+// sc_allreduce of the CG / Lanczos scalars (src/Solver/d4est_solver_cg_eigs.c:181-243) becomes ncclAllReduce.
+// EVERY operation of a communicator -- the grouped send / receive rounds, the all-reduces, the stand-alone entries -- is issued on the
+// communicator's OWN stream, with an event in from and an event out to the caller's stream: one communicator, one stream, so the order
+// in which RCCL sees the operations is the host's issue order on every rank, whatever streams the plans run on.
 // No Python, no host synchronisation in the per-apply path.
 //
 // librccl is opened at run time (dlopen), so the library loads -- and every single-GPU entry point works -- on a box without RCCL.
@@ -24,6 +27,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -52,6 +56,7 @@ RcclApi& rccl() {
   LOAD(GetUniqueId, "ncclGetUniqueId");
   LOAD(CommInitRank, "ncclCommInitRank");
   LOAD(CommDestroy, "ncclCommDestroy");
+  LOAD(CommCount, "ncclCommCount");
   LOAD(GroupStart, "ncclGroupStart");
   LOAD(GroupEnd, "ncclGroupEnd");
   LOAD(Send, "ncclSend");
@@ -73,6 +78,8 @@ RcclApi& rccl() {
 struct d4est_hip_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  hipStream_t stream = nullptr;               // the one stream this communicator's operations run on
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;   // hand-over from / to a caller's stream (stand-alone entries, all-reduce)
 };
 
 // per plan: the exchange lists and buffers
@@ -86,8 +93,7 @@ struct d4est_hip_rccl_exchange {
   double *d_send = nullptr, *d_recv = nullptr;
   long long *d_s_src = nullptr, *d_s_dst = nullptr, *d_r_src = nullptr, *d_r_dst = nullptr;
   int *d_s_len = nullptr, *d_r_len = nullptr;
-  hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;   // the exchange's own hand-over events (the stream is the communicator's)
   long long n_exchanges = 0;
 };
 
@@ -108,16 +114,17 @@ void exchange_hook(void* ctx, int phase, const double* trace_dev, double* ghost_
   if (phase == 0) {
     // pack on the plan's stream (behind the trace kernel), transfers on the communication stream
     d4est_hip::launch_copy_blocks(s, x->n_send_blocks, trace_dev, x->d_s_src, x->d_send, x->d_s_dst, x->d_s_len);
+    hipStream_t cs = x->comm->stream;
     HIP_CHECK(hipEventRecord(x->ev_packed, s));
-    HIP_CHECK(hipStreamWaitEvent(x->comm_stream, x->ev_packed, 0));
+    HIP_CHECK(hipStreamWaitEvent(cs, x->ev_packed, 0));
     RCCL_CHECK(api.GroupStart());
     for (size_t p = 0; p < x->peer.size(); ++p) {
       const long long nr = x->recv_first[p + 1] - x->recv_first[p], ns = x->send_first[p + 1] - x->send_first[p];
-      if (nr > 0) RCCL_CHECK(api.Recv(x->d_recv + x->recv_first[p], (size_t)nr, ncclDouble, x->peer[p], x->comm->comm, x->comm_stream));
-      if (ns > 0) RCCL_CHECK(api.Send(x->d_send + x->send_first[p], (size_t)ns, ncclDouble, x->peer[p], x->comm->comm, x->comm_stream));
+      if (nr > 0) RCCL_CHECK(api.Recv(x->d_recv + x->recv_first[p], (size_t)nr, ncclDouble, x->peer[p], x->comm->comm, cs));
+      if (ns > 0) RCCL_CHECK(api.Send(x->d_send + x->send_first[p], (size_t)ns, ncclDouble, x->peer[p], x->comm->comm, cs));
     }
     RCCL_CHECK(api.GroupEnd());
-    HIP_CHECK(hipEventRecord(x->ev_arrived, x->comm_stream));
+    HIP_CHECK(hipEventRecord(x->ev_arrived, cs));
     x->n_exchanges++;
   } else {
     HIP_CHECK(hipStreamWaitEvent(s, x->ev_arrived, 0));
@@ -125,10 +132,28 @@ void exchange_hook(void* ctx, int phase, const double* trace_dev, double* ghost_
   }
 }
 
+// run fn(communicator stream) ordered after what `user` has queued, and make `user` wait for it
+template <typename F>
+void on_comm_stream(d4est_hip_comm* c, hipStream_t user, F fn) {
+  HIP_CHECK(hipEventRecord(c->ev_in, user));
+  HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+  fn(c->stream);
+  HIP_CHECK(hipEventRecord(c->ev_out, c->stream));
+  HIP_CHECK(hipStreamWaitEvent(user, c->ev_out, 0));
+}
+
 void allreduce_hook(void* ctx, double* scalars_dev, int n) {
   auto* x = static_cast<d4est_hip_rccl_exchange*>(ctx);
   if (x->comm->world == 1) return;
-  RCCL_CHECK(rccl().AllReduce(scalars_dev, scalars_dev, (size_t)n, ncclDouble, ncclSum, x->comm->comm, x->plan->stream));
+  on_comm_stream(x->comm, x->plan->stream, [&](hipStream_t cs) {
+    RCCL_CHECK(rccl().AllReduce(scalars_dev, scalars_dev, (size_t)n, ncclDouble, ncclSum, x->comm->comm, cs));
+  });
+}
+
+void comm_streams_create(d4est_hip_comm* c) {
+  HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
 }
 
 }  // namespace
@@ -152,6 +177,7 @@ d4est_hip_comm_t* d4est_hip_comm_create(const void* unique_id, int rank, int wor
   ncclUniqueId id;
   std::memcpy(&id, unique_id, sizeof(id));
   RCCL_CHECK(rccl().CommInitRank(&c->comm, world, id, rank));
+  comm_streams_create(c);
   return c;
 }
 
@@ -169,16 +195,26 @@ d4est_hip_comm_t* d4est_hip_comm_try_create(const void* unique_id, int rank, int
     delete c;
     return nullptr;
   }
+  comm_streams_create(c);
   return c;
 }
 
 void d4est_hip_comm_destroy(d4est_hip_comm_t* c) {
   if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)rccl().CommDestroy(c->comm);
+  if (c->stream) { (void)hipStreamDestroy(c->stream); (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); }
   delete c;
 }
 
 int d4est_hip_comm_rank(const d4est_hip_comm_t* c) { return c ? c->rank : -1; }
+// the number of ranks RCCL itself reports for the communicator (ncclCommCount), not what the host passed in
+int d4est_hip_comm_nccl_count(const d4est_hip_comm_t* c) {
+  if (!c || !c->comm) return 0;
+  int n = 0;
+  RCCL_CHECK(rccl().CommCount(c->comm, &n));
+  return n;
+}
 int d4est_hip_comm_size(const d4est_hip_comm_t* c) { return c ? c->world : 0; }
 
 d4est_hip_rccl_exchange_t* d4est_hip_plan_set_rccl_exchange(d4est_hip_plan_t* plan, d4est_hip_comm_t* comm, int n_peers, const int* peer_rank,
@@ -218,7 +254,6 @@ d4est_hip_rccl_exchange_t* d4est_hip_plan_set_rccl_exchange(d4est_hip_plan_t* pl
   HIP_CHECK(hipMalloc(&x->d_recv, std::max<size_t>((size_t)x->recv_total, 1) * sizeof(double)));
   x->d_s_src = to_device(s_src); x->d_s_dst = to_device(s_dst); x->d_s_len = to_device(s_len);
   x->d_r_src = to_device(r_src); x->d_r_dst = to_device(r_dst); x->d_r_len = to_device(r_len);
-  HIP_CHECK(hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&x->ev_packed, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&x->ev_arrived, hipEventDisableTiming));
   d4est_hip_plan_set_comm(plan, plan->ghost_trace_doubles > 0 ? exchange_hook : nullptr, allreduce_hook, x);
@@ -229,11 +264,10 @@ void d4est_hip_rccl_exchange_destroy(d4est_hip_rccl_exchange_t* x) {
   if (!x) return;
   // (a plan destroyed before its exchange clears this back-pointer: d4est_hip_rccl_exchange_detach_plan, called by plan_destroy)
   if (x->plan && x->plan->comm_ctx == x) d4est_hip_plan_set_comm(x->plan, nullptr, nullptr, nullptr);
-  (void)hipStreamSynchronize(x->comm_stream);
+  if (x->comm && x->comm->stream) (void)hipStreamSynchronize(x->comm->stream);
   (void)hipFree(x->d_send); (void)hipFree(x->d_recv);
   (void)hipFree(x->d_s_src); (void)hipFree(x->d_s_dst); (void)hipFree(x->d_s_len);
   (void)hipFree(x->d_r_src); (void)hipFree(x->d_r_dst); (void)hipFree(x->d_r_len);
-  (void)hipStreamDestroy(x->comm_stream);
   (void)hipEventDestroy(x->ev_packed); (void)hipEventDestroy(x->ev_arrived);
   delete x;
 }
@@ -257,18 +291,22 @@ void d4est_hip_comm_sendrecv(d4est_hip_comm_t* comm, d4est_hip_plan_t* plan, int
   for (int p = 0; p < n_peers; ++p)
     if (peer_rank[p] < 0 || peer_rank[p] >= comm->world) D4EST_HIP_ABORT("comm_sendrecv: peer %d outside the communicator of %d ranks", peer_rank[p], comm->world);
   RcclApi& api = rccl();
-  RCCL_CHECK(api.GroupStart());
-  for (int p = 0; p < n_peers; ++p) {
-    const long long nr = recv_first[p + 1] - recv_first[p], ns = send_first[p + 1] - send_first[p];
-    if (nr > 0) RCCL_CHECK(api.Recv(recv_dev + recv_first[p], (size_t)nr, ncclDouble, peer_rank[p], comm->comm, plan->stream));
-    if (ns > 0) RCCL_CHECK(api.Send(send_dev + send_first[p], (size_t)ns, ncclDouble, peer_rank[p], comm->comm, plan->stream));
-  }
-  RCCL_CHECK(api.GroupEnd());
+  on_comm_stream(comm, plan->stream, [&](hipStream_t cs) {
+    RCCL_CHECK(api.GroupStart());
+    for (int p = 0; p < n_peers; ++p) {
+      const long long nr = recv_first[p + 1] - recv_first[p], ns = send_first[p + 1] - send_first[p];
+      if (nr > 0) RCCL_CHECK(api.Recv(recv_dev + recv_first[p], (size_t)nr, ncclDouble, peer_rank[p], comm->comm, cs));
+      if (ns > 0) RCCL_CHECK(api.Send(send_dev + send_first[p], (size_t)ns, ncclDouble, peer_rank[p], comm->comm, cs));
+    }
+    RCCL_CHECK(api.GroupEnd());
+  });
 }
 
 void d4est_hip_comm_allreduce_sum(d4est_hip_comm_t* comm, d4est_hip_plan_t* plan, double* scalars_dev, int n) {
   if (!comm || !plan) D4EST_HIP_ABORT("comm_allreduce_sum: NULL argument");
-  RCCL_CHECK(rccl().AllReduce(scalars_dev, scalars_dev, (size_t)n, ncclDouble, ncclSum, comm->comm, plan->stream));
+  on_comm_stream(comm, plan->stream, [&](hipStream_t cs) {
+    RCCL_CHECK(rccl().AllReduce(scalars_dev, scalars_dev, (size_t)n, ncclDouble, ncclSum, comm->comm, cs));
+  });
 }
 
 }  // extern "C"

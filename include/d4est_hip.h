@@ -384,7 +384,10 @@ void d4est_hip_vec_dot(d4est_hip_plan_t* plan, int n, const double* x_dev, const
  * (src/Solver/d4est_solver_cg_eigs.c:181-243), one process per GPU, RCCL over xGMI.  librccl is opened at run time.
  * Communicator: rank 0 calls d4est_hip_comm_get_unique_id, the host broadcasts the d4est_hip_comm_unique_id_bytes() bytes by whatever
  * it has (MPI_Bcast in a d4est build, torch.distributed in the tests), every rank calls d4est_hip_comm_create (ncclCommInitRank;
- * collective; the calling thread's current HIP device is the rank's GPU). */
+ * collective; the calling thread's current HIP device is the rank's GPU).
+ * One communicator, ONE stream: every RCCL operation of a communicator (the grouped send / receive of the trace exchange, the all-reduce
+ * of the CG scalars, d4est_hip_comm_sendrecv / _allreduce_sum) is issued on a stream the communicator owns, with an event in from and an
+ * event out to the calling plan's stream -- the order RCCL sees is the host's issue order on every rank, whatever streams the plans use. */
 typedef struct d4est_hip_comm d4est_hip_comm_t;
 typedef struct d4est_hip_rccl_exchange d4est_hip_rccl_exchange_t;
 int d4est_hip_comm_unique_id_bytes(void);
@@ -395,6 +398,8 @@ d4est_hip_comm_t* d4est_hip_comm_try_create(const void* unique_id, int rank, int
 void d4est_hip_comm_destroy(d4est_hip_comm_t* comm);
 int d4est_hip_comm_rank(const d4est_hip_comm_t* comm);
 int d4est_hip_comm_size(const d4est_hip_comm_t* comm);
+/* ncclCommCount of the communicator: the rank count RCCL itself reports (reports / self-checks) */
+int d4est_hip_comm_nccl_count(const d4est_hip_comm_t* comm);
 /* Wire a plan (faces set) to the communicator: installs C exchange / allreduce hooks (no callback into the host language), so that
  * d4est_hip_apply_lhs, _cheby_iterate, _cg_eigs run on N ranks.  Per neighbouring rank p (peer_rank[p]) the blocks
  * [send_first[p], send_first[p+1]) of (send_off, send_len): offsets / lengths in doubles into the plan's LOCAL trace buffer

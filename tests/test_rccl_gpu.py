@@ -1,7 +1,9 @@
-"""The C RCCL transport (csrc/d4est_hip_comm.hip) on real hardware.  A GPU box has ONE GPU and RCCL refuses two ranks on one device,
-so what runs here is a one-rank communicator: the library's own ncclCommInitRank, and the whole per-apply path -- pack kernel, grouped
-ncclSend / ncclRecv on the communication stream, event hand-over, unpack kernel -- with the rank as its own peer.  The multi-rank
-schedules are covered over gloo (tests/test_parallel.py) and by bench.py --gpus N on the driver's 8-GPU node."""
+"""The C RCCL transport (csrc/d4est_hip_comm.hip) on real hardware.  A one-GPU box can only hold a one-rank communicator (RCCL refuses
+two ranks on one device): the library's own ncclCommInitRank, and the whole per-apply path -- pack kernel, grouped ncclSend / ncclRecv
+on the communicator's stream, event hand-over, unpack kernel -- with the rank as its own peer.  Wherever TWO OR MORE GPUs are visible
+test_two_ranks starts two fresh processes (one per GPU) and holds the sharded operator, Chebyshev loop and cg_eigs over real
+ncclSend / ncclRecv / ncclAllReduce to the one-rank results.  The multi-rank schedules are also covered over gloo (tests/test_parallel.py)
+and by bench.py --gpus N."""
 import numpy as np
 import pytest
 
@@ -90,3 +92,22 @@ def test_rccl_sendrecv_and_allreduce_single_rank(gpu, hiplib):
     assert torch.equal(a, b) and s.tolist() == [1.5, 2.5]
     plan.destroy()
     comm.destroy()
+
+
+def test_two_ranks(hiplib):
+    """two ranks on two GPUs through the real RCCL hooks (skipped on one-GPU boxes): tests/helpers/rccl_two_rank_child.py, started as
+    fresh child processes -- the children never inherit this process's GPU state, and nothing here replaces a running program"""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:          # (counting devices does not initialise the GPU)
+        pytest.skip("needs two GPUs; this box has %d" % torch.cuda.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", os.path.join(root, "tests", "helpers", "rccl_two_rank_child.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    print(out.stdout[-4000:], out.stderr[-3000:])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "two-rank RCCL check: ok" in out.stdout
