@@ -53,6 +53,7 @@ SIGNATURES = {
     "d4est_hip_compute_dudr": (None, [_vp, _vp, _vp, _vp, _vp]),
     "d4est_hip_build_sides": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp,
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "d4est_hip_topology_table": (ctypes.c_int, [ctypes.c_int, _vp]),
     "d4est_hip_plan_set_faces": (None, [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _c_int_p, _c_int_p]),
     "d4est_hip_plan_set_hanging": (None, [_vp, _vp, _vp, _vp, _vp]),

@@ -23,6 +23,7 @@
 #include <tuple>
 
 #include "d4est_hip_internal.h"
+#include "d4est_hip_topology.h"
 #include "d4est_hip_maps.h"
 #include "d4est_hip_tables.h"
 #include "d4est_hip_wave.h"
@@ -1699,12 +1700,8 @@ T* upload_vec(const std::vector<T>& v) {
 
 // dGMath/d4est_reference.c:3-12, :84-110: index, in the (+) side's own order, of the sub-face that is i in (-) order
 int reorient_face_order(int f_m, int f_p, int o, int i) {
-  static const int FToF_code[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
-                                      {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
-  static const int code_to_perm[3][4] = {{1, 2, 5, 6}, {0, 3, 4, 7}, {0, 4, 3, 7}};
-  static const int perm_to_order[8][4] = {{0, 1, 2, 3}, {0, 2, 1, 3}, {1, 0, 3, 2}, {1, 3, 0, 2},
-                                          {2, 0, 3, 1}, {2, 3, 0, 1}, {3, 1, 2, 0}, {3, 2, 1, 0}};
-  return perm_to_order[code_to_perm[FToF_code[f_m][f_p]][o]][i];
+  using namespace topo;   // d4est_hip_topology.h: the tables, pinned entry by entry to the reference's own by tests/test_topology_tables.py
+  return d4est_perm_to_order[d4est_code_to_perm[d4est_FToF_code[f_m][f_p]][o]][i];
 }
 
 // The (flip0, flip1, transpose) code d4est_operators_reorient_face_data derives from a tree-boundary face pair
@@ -1712,9 +1709,8 @@ int reorient_face_order(int f_m, int f_p, int o, int i) {
 // -- axes of the lower face's tangential directions, the axes they map to, and whether each is reversed
 // (p4est_expand_face_transform: my_axis = ft[0..2], target_axis = ft[3..5], edge_reverse = ft[6..8]).
 int face_reorder_code(int f_m, int f_p, int o) {
-  static const int ref0[6] = {0, 1, 1, 0, 0, 1};   // p8est_face_permutation_refs[0][.]
-  static const int refs[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
-                                 {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
+  const auto& refs = topo::face_permutation_refs;
+  const int* ref0 = refs[0];
   const int lo = f_m <= f_p ? f_m : f_p, hi = f_m <= f_p ? f_p : f_m;
   int my_axis[2], target_axis[2], edge_reverse[2];
   my_axis[0] = lo < 2 ? 1 : 0;

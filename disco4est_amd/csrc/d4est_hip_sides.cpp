@@ -16,14 +16,14 @@
 #include <vector>
 
 #include "d4est_hip_internal.h"
+#include "d4est_hip_topology.h"
 
 namespace {
 
 using Key = std::array<int, 5>;   // tree, x, y, z, size
 
 void expand_face_transform(int iface, int target_face, int o, int ft[9]) {
-  static const int refs[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
-                                 {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
+  const auto& refs = d4est_hip::topo::face_permutation_refs;
   ft[0] = iface < 2 ? 1 : 0;
   ft[1] = iface < 4 ? 2 : 1;
   ft[2] = iface / 2;
@@ -162,4 +162,27 @@ extern "C" int d4est_hip_build_sides(int n_trees, const int* tree_to_tree, const
   if (total_mortar_nodes) *total_mortar_nodes = total;
   if (total_bndry_nodes) *total_bndry_nodes = total_b;
   return any_hanging;
+}
+
+// the integer tables of d4est_hip_topology.h by id (out == NULL: only the entry count): 0 p8est_face_corners [6][4], 1 p8est_face_dual [6],
+// 2 p8est_face_permutations [8][4], 3 p8est_face_permutation_sets [3][4], 4 p8est_face_permutation_refs [6][6], 5 p8est_corner_faces
+// [8][3], 10 / 11 / 12 d4est_reference_p8est_FToF_code [6][6] / _code_to_perm [3][4] / _perm_to_order [8][4]
+extern "C" int d4est_hip_topology_table(int id, int* out) {
+  using namespace d4est_hip::topo;
+  const int* src = nullptr;
+  int n = 0;
+  switch (id) {
+    case 0: src = &face_corners[0][0]; n = 24; break;
+    case 1: src = &face_dual[0]; n = 6; break;
+    case 2: src = &face_permutations[0][0]; n = 32; break;
+    case 3: src = &face_permutation_sets[0][0]; n = 12; break;
+    case 4: src = &face_permutation_refs[0][0]; n = 36; break;
+    case 5: src = &corner_faces[0][0]; n = 24; break;
+    case 10: src = &d4est_FToF_code[0][0]; n = 36; break;
+    case 11: src = &d4est_code_to_perm[0][0]; n = 12; break;
+    case 12: src = &d4est_perm_to_order[0][0]; n = 32; break;
+    default: return -1;
+  }
+  if (out) for (int i = 0; i < n; ++i) out[i] = src[i];
+  return n;
 }

@@ -215,6 +215,13 @@ int d4est_hip_build_sides(int n_trees, const int* tree_to_tree, const int* tree_
                           const int* ghost_q, const int* ghost_dq, const int* ghost_deg_quad, int* side_nbr, int* side_nbr_face,
                           int* side_reorder, int* side_orientation, int* side_hang, int* side_sub, int* side_nbr4,
                           int* side_mortar_stride, int* side_bndry_stride, int* total_mortar_nodes, int* total_bndry_nodes);
+/* The integer topology tables the library works with (csrc/d4est_hip_topology.h), for hosts that want the same numbers and for the
+ * pin against the reference's own data (tests/test_topology_tables.py): id 0 p8est_face_corners [6][4], 1 p8est_face_dual [6],
+ * 2 p8est_face_permutations [8][4], 3 p8est_face_permutation_sets [3][4], 4 p8est_face_permutation_refs [6][6], 5 p8est_corner_faces [8][3]
+ * (p4est-2.8 src/p8est_connectivity.c:29-63, :145-152); 10 / 11 / 12 d4est_reference_p8est_FToF_code [6][6] / _code_to_perm [3][4] /
+ * _perm_to_order [8][4] (src/dGMath/d4est_reference.c:3-12).  Returns the entry count (row-major ints written to out; out == NULL: count
+ * only), -1 for an unknown id. */
+int d4est_hip_topology_table(int id, int* out);
 /* Non-conforming (hanging, 1 <-> 4) faces of a 2:1 balanced mesh; call BEFORE d4est_hip_plan_set_faces (conforming meshes skip it).
  * HOST int arrays over the sides s = 6*e + f, mirroring the two calls the reference's face iteration makes per hanging face
  * (src/Mesh/d4est_mortars.c:700-803: (e_m[4], faces_m = 4 | e_p[1]) and (e_m[1] | e_p[4], faces_p = 4)):

@@ -144,6 +144,7 @@ void oracle_flux_set_robin(const double* coeff_quad, const double* rhs_quad);
  * A hanging face's mortar block holds its 4 sub-mortars one after another (vector components strided by the block total), and the
  * 4 small sides share one block, as in Mesh/d4est_mesh.c:956-962. */
 void oracle_flux_set_hanging(const int* side_hang, const int* side_sub, const int* side_nbr4, const int* side_orientation);
+int oracle_topology_table(int id, int* out);                      /* the integer tables of d4est_oracle_flux.c (ids of d4est_hip_topology_table) */
 int oracle_reorient_face_order(int f_m, int f_p, int o, int i);   /* dGMath/d4est_reference.c:84-110 */
 void oracle_expand_face_transform(int iface, int nface, int ftransform[9]); /* p4est-2.8 src/p4est_connectivity.c:2877-2944 */
 int oracle_face_reorder_code(int f_m, int f_p, int o);             /* dGMath/d4est_operators.c:2031-2050 */

@@ -225,13 +225,30 @@ void oracle_flux_set_hanging(const int* side_hang, const int* side_sub, const in
   g_side_hang = side_hang; g_side_sub = side_sub; g_side_nbr4 = side_nbr4; g_side_orientation = side_orientation;
 }
 
+/* the integer tables this file works with, in one place so that tests/test_topology_tables.py can hold them to the reference's own data
+ * (oracle_topology_table): dGMath/d4est_reference.c:3-12 and p4est-2.8 src/p8est_connectivity.c:57-63 */
+static const int FToF_code[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
+                                    {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
+static const int code_to_perm[3][4] = {{1, 2, 5, 6}, {0, 3, 4, 7}, {0, 4, 3, 7}};
+static const int perm_to_order[8][4] = {{0, 1, 2, 3}, {0, 2, 1, 3}, {1, 0, 3, 2}, {1, 3, 0, 2},
+                                        {2, 0, 3, 1}, {2, 3, 0, 1}, {3, 1, 2, 0}, {3, 2, 1, 0}};
+static const int face_permutation_refs[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
+                                                {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
+/* ids as d4est_hip_topology_table: 4 p8est_face_permutation_refs, 10 / 11 / 12 the d4est_reference.c tables */
+int oracle_topology_table(int id, int* out) {
+  const int* src = NULL;
+  int n = 0;
+  if (id == 4) { src = &face_permutation_refs[0][0]; n = 36; }
+  else if (id == 10) { src = &FToF_code[0][0]; n = 36; }
+  else if (id == 11) { src = &code_to_perm[0][0]; n = 12; }
+  else if (id == 12) { src = &perm_to_order[0][0]; n = 32; }
+  else return -1;
+  for (int i = 0; out && i < n; i++) out[i] = src[i];
+  return n;
+}
+
 /* dGMath/d4est_reference.c:3-12 (tables), :84-110 (face_dim == 2 branch) */
 int oracle_reorient_face_order(int f_m, int f_p, int o, int i) {
-  static const int FToF_code[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
-                                      {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
-  static const int code_to_perm[3][4] = {{1, 2, 5, 6}, {0, 3, 4, 7}, {0, 4, 3, 7}};
-  static const int perm_to_order[8][4] = {{0, 1, 2, 3}, {0, 2, 1, 3}, {1, 0, 3, 2}, {1, 3, 0, 2},
-                                          {2, 0, 3, 1}, {2, 3, 0, 1}, {3, 1, 2, 0}, {3, 2, 1, 0}};
   int perm = code_to_perm[FToF_code[f_m][f_p]][o];
   return perm_to_order[perm][i];
 }
@@ -240,8 +257,6 @@ int oracle_reorient_face_order(int f_m, int f_p, int o, int i) {
  * reference (third_party/p4est-2.8.tar.gz, un-vendored); restated from its published algorithm:
  * ftransform[0..2] = my_axis, [3..5] = target_axis, [6..8] = edge_reverse. */
 void oracle_expand_face_transform(int iface, int nface, int ftransform[9]) {
-  static const int face_permutation_refs[6][6] = {{0, 1, 1, 0, 0, 1}, {2, 0, 0, 1, 1, 0}, {2, 0, 0, 1, 1, 0},
-                                                  {0, 2, 2, 0, 0, 1}, {0, 2, 2, 0, 0, 1}, {2, 0, 0, 2, 2, 0}};
   const int target_face = nface % 6, orientation = nface / 6;
   int reverse;
   ftransform[0] = iface < 2 ? 1 : 0;

@@ -7,6 +7,12 @@
   cubed_sphere_7tree_connectivity.json tree_to_tree / tree_to_face of d4est_connectivity_new_sphere_7tree
                                        (src/Geometry/d4est_connectivity_cubed_sphere.c:41-58).
 
+  p8est_tables.json                    the integer face / corner tables of p4est 2.8 (third_party/p4est-2.8.tar.gz,
+                                       src/p8est_connectivity.c:29-63, :145-152: p8est_face_corners, _face_dual, _face_permutations,
+                                       _face_permutation_sets, _face_permutation_refs, _corner_faces) and the reference's own copies
+                                       (src/dGMath/d4est_reference.c:3-12: d4est_reference_p8est_FToF_code, _code_to_perm,
+                                       _perm_to_order), read out of the initialisers as integers.
+
 Run from the repo root:  python tests/golden/make_reference_tables.py   (needs /root/reference; the fixtures are committed).
 """
 import json
@@ -84,6 +90,35 @@ def main():
     with open(os.path.join(HERE, "cubed_sphere_7tree_connectivity.json"), "w") as fh:
         json.dump({"source": "src/Geometry/d4est_connectivity_cubed_sphere.c:41-58 (d4est_connectivity_new_sphere_7tree)",
                    "num_trees": 7, "tree_to_tree": ttt, "tree_to_face": ttf}, fh)
+    # ---- integer topology tables: the initialisers' integers, in order
+    import tarfile
+
+    def int_table(text, name):
+        m = re.search(r"\b" + re.escape(name) + r"\s*((?:\[\s*\d*\s*\])+)\s*=\s*\{(.*?)\}\s*;", text, flags=re.S)
+        if not m:
+            raise ValueError("table %s not found" % name)
+        dims = [int(d) for d in re.findall(r"\[\s*(\d+)\s*\]", m.group(1))]
+        body = re.sub(r"/\*.*?\*/", "", m.group(2), flags=re.S)
+        vals = [int(v) for v in re.findall(r"-?\d+", body)]
+        n = 1
+        for d in dims:
+            n *= d
+        assert len(vals) == n, (name, dims, len(vals))
+        return {"shape": dims, "values": vals}
+
+    with tarfile.open("/root/reference/third_party/p4est-2.8.tar.gz") as tf:
+        member = [m for m in tf.getmembers() if m.name.endswith("/src/p8est_connectivity.c")][0]
+        p8 = tf.extractfile(member).read().decode()
+    dref = open(os.path.join(REF, "dGMath", "d4est_reference.c")).read()
+    tables = {"source": "third_party/p4est-2.8.tar.gz: src/p8est_connectivity.c:29-63, :145-152; src/dGMath/d4est_reference.c:3-12 (integers only)"}
+    for name in ("p8est_face_corners", "p8est_face_dual", "p8est_face_permutations", "p8est_face_permutation_sets",
+                 "p8est_face_permutation_refs", "p8est_corner_faces"):
+        tables[name] = int_table(p8, name)
+    for name in ("d4est_reference_p8est_FToF_code", "d4est_reference_p8est_code_to_perm", "d4est_reference_p8est_perm_to_order"):
+        tables[name] = int_table(dref, name)
+    with open(os.path.join(HERE, "p8est_tables.json"), "w") as fh:
+        json.dump(tables, fh)
+    print("wrote p8est_tables.json")
     print("wrote reference_nodes_weights.json (n = 1..20) and cubed_sphere_7tree_connectivity.json")
 
 
