@@ -3,6 +3,7 @@
 //
 // Element-level shims: a cached one-element plan per (deg, deg_quad, quadrature type) with persistent pinned staging and device
 // buffers (allocated on first use, never per call); operator-level shims: the whole-mesh plan bound to the p4est pointer.
+#include <algorithm>
 #include <array>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +36,14 @@ struct ElemCtx {
 std::map<std::tuple<int, int, int>, ElemCtx> g_elem;
 std::map<std::array<int, 10>, d4est_hip_transfer_t*> g_transfer;
 std::map<const void*, d4est_hip_plan_t*> g_bound;
+// what the bound plan stands for and needs from the mesh data the shims cannot read: the SIPG parameters / boundary-condition type the
+// plan was set up with (checked against the caller's flux data), the node coordinates (source terms), the Schwarz smoother handle
+struct FluxReg { double prefactor; int bc_type; };
+std::map<const void*, FluxReg> g_flux;
+struct CoordReg { const double* lob[3]; const double* quad[3]; };
+std::map<const void*, CoordReg> g_coord;
+struct SchwarzReg { d4est_hip_schwarz_t* sz; int iter; double atol, rtol; };
+std::map<const void*, SchwarzReg> g_schwarz;
 double* g_tr_h = nullptr;   // pinned staging of the transfer shims
 double* g_tr_d = nullptr;
 size_t g_tr_cap = 0;
@@ -195,6 +204,80 @@ void transfer_run(d4est_hip_transfer_t* t, int mode, const double* in, double* o
     d4est_hip_memcpy_d2h(hc, dc, sizeof(double) * nc);
     std::memcpy(out, hc, sizeof(double) * nc);
   }
+}
+
+
+// ---- (dim - 1)-dimensional transfers on the host: what d4est_mortars_project_side_onto_mortar_space / _mass_mortar_onto_side and the
+// estimators ask of apply_p_prolong & co. with dim = 2 (src/Mesh/d4est_mortars.c:510-598).  ops: per direction a row-major (n_out x n_in)
+// matrix; out[a + n_out b] = sum op_y[b][B] op_x[a][A] in[A + n_in B]
+void tensor2(const double* opx, const double* opy, int n_in, int n_out, const double* in, double* out, bool accumulate) {
+  std::vector<double> tmp((size_t)n_out * n_in);
+  for (int B = 0; B < n_in; ++B)
+    for (int a = 0; a < n_out; ++a) {
+      double s = 0.0;
+      for (int A = 0; A < n_in; ++A) s += opx[(size_t)a * n_in + A] * in[A + (size_t)n_in * B];
+      tmp[a + (size_t)n_out * B] = s;
+    }
+  for (int b = 0; b < n_out; ++b)
+    for (int a = 0; a < n_out; ++a) {
+      double s = 0.0;
+      for (int B = 0; B < n_in; ++B) s += opy[(size_t)b * n_in + B] * tmp[a + (size_t)n_out * B];
+      if (accumulate) out[a + (size_t)n_out * b] += s;
+      else out[a + (size_t)n_out * b] = s;
+    }
+}
+std::vector<double> table_of(int id, int deg_a, int deg_b) {
+  std::vector<double> t((size_t)d4est_hip_table(id, deg_a, deg_b, nullptr));
+  d4est_hip_table(id, deg_a, deg_b, t.data());
+  return t;
+}
+std::vector<double> transposed(const double* m, int rows, int cols) {
+  std::vector<double> t((size_t)rows * cols);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = m[(size_t)r * cols + c];
+  return t;
+}
+// mode 0 prolong (coarse -> fine), 1 prolong-transpose, 2 L2 projection (fine -> coarse); children = 1 or 4
+void transfer2(int mode, int children, int degH, const int* degh, const double* in, double* out) {
+  const int nH = degH + 1;
+  size_t stride = 0;
+  if (mode != 0) std::fill(out, out + (size_t)nH * nH, 0.0);
+  for (int c = 0; c < children; ++c) {
+    const int nh = degh[c] + 1;
+    if (nh < nH) COMPAT_ABORT("transfer (dim 2): degh %d < degH %d (d4est_operators.c:379)", degh[c], degH);
+    const size_t half = (size_t)nh * nH;
+    const int hx = children == 1 ? 0 : (c & 1), hy = children == 1 ? 0 : ((c >> 1) & 1);
+    if (mode == 2) {
+      const std::vector<double> R = table_of(children == 1 ? D4EST_HIP_TABLE_P_RESTRICT : D4EST_HIP_TABLE_HP_RESTRICT, degH, degh[c]);   // (nH x nh) per half
+      tensor2(R.data() + hx * half, R.data() + hy * half, nh, nH, in + stride, out, true);
+    } else {
+      const std::vector<double> P = table_of(children == 1 ? D4EST_HIP_TABLE_P_PROLONG : D4EST_HIP_TABLE_HP_PROLONG, degH, degh[c]);    // (nh x nH) per half
+      if (mode == 0) tensor2(P.data() + hx * half, P.data() + hy * half, nH, nh, in, out + stride, false);
+      else {
+        const std::vector<double> Tx = transposed(P.data() + hx * half, nh, nH), Ty = transposed(P.data() + hy * half, nh, nH);
+        tensor2(Tx.data(), Ty.data(), nh, nH, in + stride, out, true);
+      }
+    }
+    stride += (size_t)nh * nh;
+  }
+}
+void need_dim23(int dim, const char* who) {
+  if (dim != 3 && dim != 2) COMPAT_ABORT("%s: dim = %d; volume (3) and face (2) objects of the d8est build only", who, dim);
+}
+
+// the caller's flux data against what the bound plan was set up with (d4est_hip_compat_bind_flux): a plan that stands in for a
+// DIFFERENT operator must not answer silently.  prefactor: first member of d4est_laplacian_flux_sipg_params_t.
+void check_flux(const void* p4est, int flux_type, const void* sipg_params, int bc_type, const char* who) {
+  auto it = g_flux.find(p4est);
+  if (it == g_flux.end()) return;
+  if (flux_type != 0) COMPAT_ABORT("%s: flux_type %d; the plan applies FLUX_SIPG", who, flux_type);
+  double pre = 0.0;
+  if (!sipg_params) COMPAT_ABORT("%s: flux_fcn_data->flux_data is NULL", who);
+  std::memcpy(&pre, sipg_params, sizeof(double));
+  if (pre != it->second.prefactor)
+    COMPAT_ABORT("%s: flux_fcn_data carries sipg_penalty_prefactor %.17g, the bound plan was set up with %.17g (d4est_hip_compat_bind_flux)", who, pre, it->second.prefactor);
+  if (bc_type != it->second.bc_type)
+    COMPAT_ABORT("%s: flux_fcn_data carries bc_type %d, the bound plan was set up with %d (BC_ROBIN 0 / BC_DIRICHLET 1)", who, bc_type, it->second.bc_type);
 }
 
 d4est_hip_plan_t* bound(const void* p4est, const char* who) {
@@ -435,19 +518,23 @@ void d4est_operators_apply_invmij(d4est_operators_t*, double* in, int dim, int d
   download(c, out, c.N3);
 }
 void d4est_operators_apply_p_prolong(d4est_operators_t*, double* in, int degH, int dim, int degh, double* out) {   // :1107-1132
-  need_dim3(dim, "d4est_operators_apply_p_prolong");
+  need_dim23(dim, "d4est_operators_apply_p_prolong");
+  if (dim == 2) { transfer2(0, 1, degH, &degh, in, out); return; }
   transfer_run(transfer_of(0, degH, &degh), 0, in, out);
 }
 void d4est_operators_apply_hp_prolong(d4est_operators_t*, double* in, int degH, int dim, int* degh, double* out) {   // :1091-1105
-  need_dim3(dim, "d4est_operators_apply_hp_prolong");
+  need_dim23(dim, "d4est_operators_apply_hp_prolong");
+  if (dim == 2) { transfer2(0, 4, degH, degh, in, out); return; }
   transfer_run(transfer_of(1, degH, degh), 0, in, out);
 }
 void d4est_operators_apply_p_restrict(d4est_operators_t*, double* in, int degh, int dim, int degH, double* out) {   // :1205-1230
-  need_dim3(dim, "d4est_operators_apply_p_restrict");
+  need_dim23(dim, "d4est_operators_apply_p_restrict");
+  if (dim == 2) { transfer2(2, 1, degH, &degh, in, out); return; }
   transfer_run(transfer_of(0, degH, &degh), 2, in, out);
 }
 void d4est_operators_apply_hp_restrict(d4est_operators_t*, double* in, int* degh, int dim, int degH, double* out) {   // :1275-1297
-  need_dim3(dim, "d4est_operators_apply_hp_restrict");
+  need_dim23(dim, "d4est_operators_apply_hp_restrict");
+  if (dim == 2) { transfer2(2, 4, degH, degh, in, out); return; }
   transfer_run(transfer_of(1, degH, degh), 2, in, out);
 }
 // :572-605: the dense prolongation (sum_i (degh_i+1)^3) x (degH+1)^3, column i = P e_i
@@ -485,11 +572,13 @@ void d4est_operators_compute_PT_mat_P(d4est_operators_t*, double* mat, int degH,
   d4est_hip_free(d_c);
 }
 void d4est_operators_apply_p_prolong_transpose(d4est_operators_t*, double* in, int degh, int dim, int degH, double* out) {   // :1719-1749
-  need_dim3(dim, "d4est_operators_apply_p_prolong_transpose");
+  need_dim23(dim, "d4est_operators_apply_p_prolong_transpose");
+  if (dim == 2) { transfer2(1, 1, degH, &degh, in, out); return; }
   transfer_run(transfer_of(0, degH, &degh), 1, in, out);
 }
 void d4est_operators_apply_hp_prolong_transpose(d4est_operators_t*, double* in, int* degh, int dim, int degH, double* out) {   // :1689-1717
-  need_dim3(dim, "d4est_operators_apply_hp_prolong_transpose");
+  need_dim23(dim, "d4est_operators_apply_hp_prolong_transpose");
+  if (dim == 2) { transfer2(1, 4, degH, degh, in, out); return; }
   transfer_run(transfer_of(1, degH, degh), 1, in, out);
 }
 
@@ -501,9 +590,10 @@ void d4est_laplacian_apply_stiffness_matrix(p4est_t* p4est, d4est_operators_t*, 
   d4est_hip_apply_stiffness_matrix_host(plan, u + (size_t)which_field * local_nodes, Au + (size_t)which_field * local_nodes);
 }
 
-void d4est_laplacian_apply_aij(p4est_t* p4est, d4est_ghost_t*, d4est_ghost_data_t*, d4est_elliptic_data_t* d, d4est_laplacian_flux_data_t*,
+void d4est_laplacian_apply_aij(p4est_t* p4est, d4est_ghost_t*, d4est_ghost_data_t*, d4est_elliptic_data_t* d, d4est_laplacian_flux_data_t* fd,
                                d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t*, d4est_mesh_data_t*, int which_field) {   // :318-417
   d4est_hip_plan_t* plan = bound(p4est, "d4est_laplacian_apply_aij");
+  if (fd) check_flux(p4est, fd->flux_type, fd->flux_data, fd->bc_type, "d4est_laplacian_apply_aij");
   if (!d || d->local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("d4est_laplacian_apply_aij: elliptic data does not match the bound plan");
   const size_t off = (size_t)which_field * d->local_nodes;   // :364-366: which_field * local_nodes
   d4est_hip_apply_aij_host(plan, d->u + off, d->Au + off);
@@ -516,9 +606,10 @@ void d4est_laplacian_with_opt_apply_stiffness_matrix(p4est_t* p4est, d4est_opera
 }
 
 void d4est_laplacian_with_opt_apply_aij(p4est_t* p4est, d4est_ghost_t*, d4est_ghost_data_t*, d4est_elliptic_data_t* d,
-                                        d4est_laplacian_with_opt_flux_data_t*, d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t*,
+                                        d4est_laplacian_with_opt_flux_data_t* fd, d4est_operators_t*, d4est_geometry_t*, d4est_quadrature_t*,
                                         d4est_mesh_data_t*, int which_field) {   // d4est_laplacian_with_opt.c
   d4est_hip_plan_t* plan = bound(p4est, "d4est_laplacian_with_opt_apply_aij");
+  if (fd) check_flux(p4est, fd->flux_type, fd->flux_data, fd->bc_type, "d4est_laplacian_with_opt_apply_aij");
   if (!d || d->local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("d4est_laplacian_with_opt_apply_aij: elliptic data does not match the bound plan");
   const size_t off = (size_t)which_field * d->local_nodes;
   d4est_hip_apply_aij_host(plan, d->u + off, d->Au + off);
@@ -546,7 +637,7 @@ void cg_eigs(p4est_t* p4est, d4est_elliptic_data_t* vecs, d4est_elliptic_eqns_t*
 
 void d4est_hip_compat_bind_mesh(const void* p4est, d4est_hip_plan_t* plan) {
   if (plan) g_bound[p4est] = plan;
-  else { g_bound.erase(p4est); g_bound_lhs.erase(p4est); }
+  else { g_bound.erase(p4est); g_bound_lhs.erase(p4est); g_flux.erase(p4est); g_coord.erase(p4est); g_schwarz.erase(p4est); }
 }
 void d4est_hip_compat_bind_operator(const void* p4est, d4est_apply_operator_fcn_t apply_lhs) {
   if (apply_lhs) g_bound_lhs[p4est] = apply_lhs;
@@ -563,6 +654,154 @@ void d4est_hip_compat_build_rhs_with_strong_bc(const void* p4est, d4est_elliptic
   if (init_option != 1 && init_option != 2) COMPAT_ABORT("build_rhs_with_strong_bc: init_option %d is not a supported init option (INIT_FIELD_ON_LOBATTO = 1 / INIT_FIELD_ON_QUAD = 2)", init_option);
   d4est_hip_build_rhs_with_strong_bc_host(plan, f, init_option == 2, rhs + (size_t)which_field * prob_vecs->local_nodes);
 }
+
+// ---- registrations that let the reference-named entries below work without reading the reference's mesh structs ----------------
+void d4est_hip_compat_bind_flux(const void* p4est, double sipg_penalty_prefactor, int bc_type) {
+  g_flux[p4est] = FluxReg{sipg_penalty_prefactor, bc_type};
+}
+void d4est_hip_compat_bind_coordinates(const void* p4est, double* xyz_lobatto[3], double* xyz_quad[3]) {
+  CoordReg c{};
+  for (int d = 0; d < 3; ++d) { c.lob[d] = xyz_lobatto ? xyz_lobatto[d] : nullptr; c.quad[d] = xyz_quad ? xyz_quad[d] : nullptr; }
+  g_coord[p4est] = c;
+}
+void d4est_hip_compat_bind_schwarz(const void* p4est, d4est_hip_schwarz_t* sz, int subdomain_iter, double subdomain_atol, double subdomain_rtol) {
+  if (sz) g_schwarz[p4est] = SchwarzReg{sz, subdomain_iter, subdomain_atol, subdomain_rtol};
+  else g_schwarz.erase(p4est);
+}
+
+// src/dGMath/d4est_laplacian.c:16-140 with the reference's own argument list.  The source callback is evaluated here, on the host, at the
+// node coordinates registered for this p4est (d4est_factors->xyz / ->xyz_quad: d4est_mesh_init_field, src/Mesh/d4est_mesh.c:2200-2260,
+// walks the same arrays), then rhs = M f (or V^T W J f) - A(0) on the bound plan with the boundary data currently set on it.
+void d4est_laplacian_build_rhs_with_strong_bc(p4est_t* p4est, d4est_ghost_t*, d4est_ghost_data_t*, d4est_operators_t*, d4est_geometry_t*,
+                                              d4est_quadrature_t*, d4est_mesh_data_t*, d4est_elliptic_data_t* prob_vecs,
+                                              d4est_laplacian_flux_data_t* flux_fcn_data_for_build_rhs, double* rhs, d4est_xyz_fcn_t problem_rhs_fcn,
+                                              d4est_mesh_init_field_option_t init_option, void* ctx, int which_field) {
+  d4est_hip_plan_t* plan = bound(p4est, "d4est_laplacian_build_rhs_with_strong_bc");
+  if (!prob_vecs || prob_vecs->local_nodes != d4est_hip_plan_local_nodes(plan)) COMPAT_ABORT("d4est_laplacian_build_rhs_with_strong_bc: elliptic data does not match the bound plan");
+  if (init_option != INIT_FIELD_ON_LOBATTO && init_option != INIT_FIELD_ON_QUAD) COMPAT_ABORT("d4est_laplacian_build_rhs_with_strong_bc: Not a support init option");   // :46-48
+  if (!problem_rhs_fcn) COMPAT_ABORT("d4est_laplacian_build_rhs_with_strong_bc: problem_rhs_fcn == NULL");
+  if (flux_fcn_data_for_build_rhs)
+    check_flux(p4est, flux_fcn_data_for_build_rhs->flux_type, flux_fcn_data_for_build_rhs->flux_data, flux_fcn_data_for_build_rhs->bc_type,
+               "d4est_laplacian_build_rhs_with_strong_bc");
+  auto it = g_coord.find(p4est);
+  const bool on_quad = init_option == INIT_FIELD_ON_QUAD;
+  if (it == g_coord.end() || !(on_quad ? it->second.quad[0] : it->second.lob[0]))
+    COMPAT_ABORT("d4est_laplacian_build_rhs_with_strong_bc: no %s node coordinates registered for this p4est (d4est_hip_compat_bind_coordinates)", on_quad ? "quadrature" : "Lobatto");
+  const double* const* X = on_quad ? it->second.quad : it->second.lob;
+  const int n = on_quad ? d4est_hip_plan_local_nodes_quad(plan) : d4est_hip_plan_local_nodes(plan);
+  std::vector<double> f((size_t)n);
+  for (int i = 0; i < n; ++i) f[i] = problem_rhs_fcn(X[0][i], X[1][i], X[2][i], ctx);
+  d4est_hip_build_rhs_with_strong_bc_host(plan, f.data(), on_quad ? 1 : 0, rhs + (size_t)which_field * prob_vecs->local_nodes);
+}
+
+// src/dGMath/d4est_operators.c:1951-1991: reverse the node order of a face array along direction dir (0: the fast index, 1: the slow
+// one, 2: both); dim = 1: a line.  Pure index work, done on the host.
+void d4est_operators_apply_flip(d4est_operators_t*, double* in, int dim, int deg, int dir, double* out) {
+  const int n = deg + 1;
+  if (dim == 1) { for (int a = 0; a < n; ++a) out[a] = in[deg - a]; return; }
+  if (dim != 2) COMPAT_ABORT("d4est_operators_apply_flip: flip not supported in this dimension atm.");   // :1988
+  if (dir < 0 || dir > 2) return;   // (the reference does nothing for another dir)
+  for (int b = 0; b < n; ++b)
+    for (int a = 0; a < n; ++a)
+      out[a + (size_t)n * b] = in[((dir == 0 || dir == 2) ? deg - a : a) + (size_t)n * ((dir == 1 || dir == 2) ? deg - b : b)];
+}
+// :1993-2087: bring a face array from the (+) side's order into the (-) side's: flip0 / flip1 / transpose from p4est's face transform of
+// the pair (lower face, higher face, orientation)
+void d4est_operators_reorient_face_data(d4est_operators_t* ops, double* in, int face_dim, int deg, int o, int f_m, int f_p, double* out) {
+  const int n = deg + 1;
+  if (face_dim == 1) {
+    if (o == 1) d4est_operators_apply_flip(ops, in, 1, deg, 0, out);
+    else std::memcpy(out, in, sizeof(double) * n);
+    return;
+  }
+  if (face_dim != 2 || o < 0 || o > 3) COMPAT_ABORT("d4est_operators_reorient_face_data: face_dim %d, orientation %d", face_dim, o);
+  const int code = d4est_hip_face_reorder_code(f_m, f_p, o);
+  for (int b = 0; b < n; ++b)
+    for (int a = 0; a < n; ++a) {
+      // out = transpose?(flip1?(flip0?(in))): undo in reverse order to find the source entry
+      int sa = (code & 4) ? b : a, sb = (code & 4) ? a : b;
+      if (code & 2) sb = deg - sb;
+      if (code & 1) sa = deg - sa;
+      out[a + (size_t)n * b] = in[sa + (size_t)n * sb];
+    }
+}
+
+// src/Mesh/d4est_mortars.c:550-598 / :510-547: a side's face data onto its mortar space (1 -> 1 p-prolongation, 1 -> 4 hp-prolongation,
+// 4 -> 4 face by face) and the mass-weighted way back (the transposes).  (P4EST_DIM) - 1 = 2: the face transfers above.
+static void project_faces(bool to_mortar, d4est_operators_t* ops, double* in, int faces_in, int* deg_in, double* out, int faces_out, int* deg_out,
+                          const char* who) {
+  // to_mortar: in = side, out = mortar; else in = mortar, out = side
+  int faces_side = to_mortar ? faces_in : faces_out, faces_mortar = to_mortar ? faces_out : faces_in;
+  int* deg_side = to_mortar ? deg_in : deg_out;
+  int* deg_mortar = to_mortar ? deg_out : deg_in;
+  if (faces_side == 1 && faces_mortar == 1) {
+    if (to_mortar) d4est_operators_apply_p_prolong(ops, in, deg_side[0], 2, deg_mortar[0], out);
+    else d4est_operators_apply_p_prolong_transpose(ops, in, deg_mortar[0], 2, deg_side[0], out);
+  } else if (faces_side == 1 && faces_mortar == 4) {
+    if (to_mortar) d4est_operators_apply_hp_prolong(ops, in, deg_side[0], 2, deg_mortar, out);
+    else d4est_operators_apply_hp_prolong_transpose(ops, in, deg_mortar, 2, deg_side[0], out);
+  } else if (faces_side == 4 && faces_mortar == 4) {
+    size_t ss = 0, sm = 0;
+    for (int i = 0; i < 4; ++i) {
+      if (to_mortar) d4est_operators_apply_p_prolong(ops, in + ss, deg_side[i], 2, deg_mortar[i], out + sm);
+      else d4est_operators_apply_p_prolong_transpose(ops, in + sm, deg_mortar[i], 2, deg_side[i], out + ss);
+      ss += (size_t)(deg_side[i] + 1) * (deg_side[i] + 1);
+      sm += (size_t)(deg_mortar[i] + 1) * (deg_mortar[i] + 1);
+    }
+  } else COMPAT_ABORT("ERROR: %s", who);
+}
+void d4est_mortars_project_side_onto_mortar_space(d4est_operators_t* d4est_ops, double* in_side, int faces_side, int* deg_side, double* out_mortar,
+                                                  int faces_mortar, int* deg_mortar) {
+  project_faces(true, d4est_ops, in_side, faces_side, deg_side, out_mortar, faces_mortar, deg_mortar, "d4est_mortars_project_side_onto_mortar_space");
+}
+void d4est_mortars_project_mass_mortar_onto_side(d4est_operators_t* dgmath, double* in_mortar, int faces_mortar, int* deg_mortar, double* out_side,
+                                                 int faces_side, int* deg_side) {
+  project_faces(false, dgmath, in_mortar, faces_mortar, deg_mortar, out_side, faces_side, deg_side, "d4est_mortars_project_mass_mortar_onto_side_space");
+}
+
+// ---- additive Schwarz: the reference's metadata (src/Solver/d4est_solver_schwarz_metadata.h:19-90) flattened into the arrays
+// d4est_hip_schwarz_create takes -- INTEGRATION.md section 2e as code.  Outputs are caller-allocated: sub_first[num_subdomains + 1],
+// sub_elem[num_elements], sub_faces / sub_core_faces[3 num_elements].  Subdomain elements keep the reference's order (sorted by
+// (tree, quadid), d4est_solver_schwarz_metadata.c:447-455); `id` must be a LOCAL element id (one rank; on several ranks hand over the
+// rank's extended mesh and map ghost ids into it first).
+void d4est_hip_compat_flatten_schwarz_metadata(const d4est_solver_schwarz_metadata_t* md, int* sub_first, int* sub_elem, int* sub_faces,
+                                               int* sub_core_faces) {
+  if (!md || !sub_first || !sub_elem || !sub_faces || !sub_core_faces) COMPAT_ABORT("flatten_schwarz_metadata: NULL argument");
+  int k = 0;
+  for (int i = 0; i < md->num_subdomains; ++i) {
+    const d4est_solver_schwarz_subdomain_metadata_t& sd = md->subdomain_metadata[i];
+    sub_first[i] = k;
+    for (int j = 0; j < sd.num_elements; ++j, ++k) {
+      const d4est_solver_schwarz_element_metadata_t& ed = sd.element_metadata[j];
+      if (ed.id < 0) COMPAT_ABORT("flatten_schwarz_metadata: subdomain %d element %d has id %d (a second-layer ghost?)", i, j, ed.id);
+      sub_elem[k] = ed.id;
+      for (int f = 0; f < 3; ++f) { sub_faces[3 * k + f] = ed.faces[f]; sub_core_faces[3 * k + f] = ed.core_faces[f]; }
+    }
+  }
+  sub_first[md->num_subdomains] = k;
+  if (k != md->num_elements) COMPAT_ABORT("flatten_schwarz_metadata: %d subdomain elements counted, metadata says %d", k, md->num_elements);
+}
+
+// src/Solver/d4est_solver_schwarz.c:172-285 with the reference's argument list: vecs->u += the Schwarz correction of the residual r, on
+// the smoother handle bound to this p4est (d4est_hip_compat_bind_schwarz; the three CG options were given there).  Host vectors in and
+// out (one upload of u and r, one download of u); `schwarz` is not read.
+void d4est_solver_schwarz_iterate(p4est_t* p4est, d4est_geometry_t*, d4est_quadrature_t*, d4est_mesh_data_t*, d4est_ghost_t*,
+                                  d4est_solver_schwarz_t*, d4est_elliptic_data_t* vecs, double* r) {
+  auto it = g_schwarz.find(p4est);
+  if (it == g_schwarz.end()) COMPAT_ABORT("d4est_solver_schwarz_iterate: no Schwarz smoother bound to p4est %p (d4est_hip_compat_bind_schwarz)", (const void*)p4est);
+  if (!vecs || !vecs->u || !r) COMPAT_ABORT("d4est_solver_schwarz_iterate: NULL vector");
+  const size_t bytes = sizeof(double) * (size_t)vecs->local_nodes;
+  double* d_u = (double*)d4est_hip_malloc(bytes);
+  double* d_r = (double*)d4est_hip_malloc(bytes);
+  d4est_hip_memcpy_h2d(d_u, vecs->u, bytes);
+  d4est_hip_memcpy_h2d(d_r, r, bytes);
+  d4est_hip_schwarz_iterate(it->second.sz, d_u, d_r, it->second.iter, it->second.atol, it->second.rtol);
+  d4est_hip_device_synchronize();
+  d4est_hip_memcpy_d2h(vecs->u, d_u, bytes);
+  d4est_hip_free(d_u);
+  d4est_hip_free(d_r);
+}
+
 d4est_hip_plan_t* d4est_hip_compat_bound_plan(const void* p4est) {
   auto it = g_bound.find(p4est);
   return it == g_bound.end() ? nullptr : it->second;

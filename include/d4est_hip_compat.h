@@ -41,8 +41,66 @@ typedef struct d4est_quadrature_opaque d4est_quadrature_t;      /* Quadrature/d4
 typedef struct d4est_mesh_data_opaque d4est_mesh_data_t;        /* Mesh/d4est_mesh.h:123-169 */
 typedef struct d4est_ghost_opaque d4est_ghost_t;                /* Mesh/d4est_ghost.h */
 typedef struct d4est_ghost_data_opaque d4est_ghost_data_t;      /* Mesh/d4est_ghost_data.h */
-typedef struct d4est_laplacian_flux_data_opaque d4est_laplacian_flux_data_t; /* dGMath/d4est_laplacian_flux.h */
-typedef struct d4est_laplacian_with_opt_flux_data_opaque d4est_laplacian_with_opt_flux_data_t; /* dGMath/d4est_laplacian_with_opt_flux.h */
+typedef struct d4est_solver_schwarz_opaque d4est_solver_schwarz_t;   /* Solver/d4est_solver_schwarz.h:14-38 (not read by the shims) */
+/* The CALLER-SET head of the two flux-data structs, mirrored member for member (dGMath/d4est_laplacian_flux.h:113-128,
+ * dGMath/d4est_laplacian_with_opt_flux.h:125-139); the "internally set" tails are never touched here.  The operator-level shims read
+ * flux_type, the SIPG prefactor (first member of d4est_laplacian_flux_sipg_params_t, dGMath/d4est_laplacian_flux_sipg.h:18-19) and
+ * bc_type, and abort when they differ from what the bound plan was set up with (d4est_hip_compat_bind_flux). */
+typedef struct d4est_laplacian_flux_data {
+  int flux_type;                                   /* d4est_laplacian_flux_type_t: FLUX_SIPG 0, FLUX_NIPG 1, FLUX_IIPG 2, FLUX_NOT_SET 3 (d4est_laplacian_aux.h:6) */
+  void (*interface_fcn)(void);                     /* d4est_laplacian_flux_interface_fcn_t */
+  void (*boundary_fcn)(void);                      /* d4est_laplacian_flux_boundary_fcn_t */
+  void* flux_data;                                 /* FLUX_SIPG: d4est_laplacian_flux_sipg_params_t* */
+  int (*get_deg_mortar_quad)(void*, void*);
+  void* get_deg_mortar_quad_ctx;
+  int bc_type;                                     /* d4est_laplacian_bc_t: BC_ROBIN 0, BC_DIRICHLET 1, BC_NOT_SET 2 (d4est_laplacian_aux.h:7) */
+  void* bc_data;
+} d4est_laplacian_flux_data_t;
+typedef struct d4est_laplacian_with_opt_flux_data {
+  int flux_type;
+  void (*interface_fcn)(void);
+  void (*boundary_fcn)(void);
+  void* flux_data;
+  int (*get_deg_mortar_quad)(void*, void*);
+  void* get_deg_mortar_quad_ctx;
+  int skip_p_side;
+  int last_mortar_side_id_m;
+  int bc_type;
+  void* bc_data;
+} d4est_laplacian_with_opt_flux_data_t;
+#define FLUX_SIPG 0
+#define BC_ROBIN 0
+#define BC_DIRICHLET 1
+/* src/Mesh/d4est_xyz_functions.h:14-25 (DIM = 3): f(x, y, z, user); src/Mesh/d4est_mesh.h:19 */
+typedef double (*d4est_xyz_fcn_t)(double, double, double, void*);
+typedef int d4est_mesh_init_field_option_t;
+#define INIT_FIELD_NOT_SET 0
+#define INIT_FIELD_ON_LOBATTO 1
+#define INIT_FIELD_ON_QUAD 2
+/* the additive Schwarz metadata, mirrored member for member (src/Solver/d4est_solver_schwarz_metadata.h:19-90; p4est_qcoord_t = int32_t):
+ * what d4est_hip_compat_flatten_schwarz_metadata walks */
+typedef struct {
+  int mpirank, tree, tree_quadid, id, deg;
+  int faces[3];
+  int core_faces[3];
+  int is_core;
+  int nodal_size, nodal_stride, restricted_nodal_size, restricted_nodal_stride;
+} d4est_solver_schwarz_element_metadata_t;
+typedef struct {
+  int mpirank, subdomain_id, core_id;
+  d4est_solver_schwarz_element_metadata_t* element_metadata;
+  int core_deg, core_tree, num_elements, restricted_nodal_size, restricted_nodal_stride, nodal_size, nodal_stride, element_stride;
+} d4est_solver_schwarz_subdomain_metadata_t;
+typedef struct {
+  int num_nodes_overlap;
+  int restricted_nodal_size, nodal_size, num_subdomains, num_elements;
+  d4est_solver_schwarz_subdomain_metadata_t* subdomain_metadata;
+  d4est_solver_schwarz_element_metadata_t* element_metadata;
+  void* subdomain_ghostdata;   /* d4est_ghost_data_ext_t* */
+  void* element_ghostdata;
+  d4est_ghost_t* d4est_ghost;
+  const char* input_section;
+} d4est_solver_schwarz_metadata_t;
 typedef int d4est_quadrature_object_type_t;                     /* enum {QUAD_OBJECT_MORTAR, QUAD_OBJECT_VOLUME}, d4est_quadrature.h:16-17 */
 typedef int d4est_quadrature_integrand_type_t;                  /* enum, d4est_quadrature.h:21-29 */
 typedef int d4est_field_type_t;                                 /* enum, Mesh/d4est_field.h */
@@ -128,6 +186,19 @@ void d4est_operators_apply_hp_prolong_transpose(d4est_operators_t *d4est_ops,dou
  *                                              the callback the plan stands for with d4est_hip_compat_bind_operator: the two shims
  *                                              then abort when fcns->apply_lhs is another function
  *   cg_eigs                                    src/Solver/d4est_solver_cg_eigs.h:9 */
+/* also with the reference's own names and argument lists (registrations below supply what the opaque mesh structs would):
+ *   d4est_laplacian_build_rhs_with_strong_bc   src/dGMath/d4est_laplacian.h:25  the source callback is evaluated on the host at the
+ *                                              coordinates of d4est_hip_compat_bind_coordinates; boundary data as set on the plan
+ *   d4est_solver_schwarz_iterate               src/Solver/d4est_solver_schwarz.h:42  on the handle of d4est_hip_compat_bind_schwarz
+ *   d4est_operators_apply_flip, _reorient_face_data   src/dGMath/d4est_operators.h (index work, host)
+ *   d4est_mortars_project_side_onto_mortar_space, _mass_mortar_onto_side   src/Mesh/d4est_mortars.h (face transfers, dim - 1, host)
+ * apply_p_prolong & co. accept dim = 2 (faces: host) besides dim = 3 (device). */
+void d4est_laplacian_build_rhs_with_strong_bc(p4est_t *p4est,d4est_ghost_t *ghost,d4est_ghost_data_t *ghost_data,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,d4est_elliptic_data_t *prob_vecs,d4est_laplacian_flux_data_t *flux_fcn_data_for_build_rhs,double *D4EST_RESTRICT rhs,d4est_xyz_fcn_t problem_rhs_fcn,d4est_mesh_init_field_option_t init_option,void *ctx,int which_field);
+void d4est_solver_schwarz_iterate(p4est_t *p4est,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,d4est_ghost_t *ghost,d4est_solver_schwarz_t *schwarz,d4est_elliptic_data_t *vecs,double *r);
+void d4est_operators_apply_flip(d4est_operators_t *d4est_ops,double *D4EST_RESTRICT in,int dim,int deg,int dir,double *out);
+void d4est_operators_reorient_face_data(d4est_operators_t *d4est_ops,double *D4EST_RESTRICT in,int face_dim,int deg,int o,int f_m,int f_p,double *D4EST_RESTRICT out);
+void d4est_mortars_project_side_onto_mortar_space(d4est_operators_t *d4est_ops,double *in_side,int faces_side,int *deg_side,double *out_mortar,int faces_mortar,int *deg_mortar);
+void d4est_mortars_project_mass_mortar_onto_side(d4est_operators_t *dgmath,double *in_mortar,int faces_mortar,int *deg_mortar,double *out_side,int faces_side,int *deg_side);
 void d4est_laplacian_apply_stiffness_matrix(p4est_t *p4est,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,double *D4EST_RESTRICT u,double *D4EST_RESTRICT Au,int local_nodes,int which_field);
 void d4est_laplacian_apply_aij(p4est_t *p4est,d4est_ghost_t *d4est_ghost,d4est_ghost_data_t *d4est_ghost_data,d4est_elliptic_data_t *d4est_elliptic_data,d4est_laplacian_flux_data_t *flux_fcn_data,d4est_operators_t *d4est_ops,d4est_geometry_t *d4est_geom,d4est_quadrature_t *d4est_quad,d4est_mesh_data_t *d4est_factors,int which_field);
 /* the "_with_opt" twins (src/dGMath/d4est_laplacian_with_opt.h:22-23): the reference's second implementation of the SAME operator,
@@ -148,7 +219,19 @@ d4est_hip_plan_t* d4est_hip_compat_bound_plan(const void* p4est);
 /* the apply_lhs callback whose operator the bound plan applies (e.g. constant_density_star_apply_jac): cheby_iterate_aux / cg_eigs abort
  * on any other fcns->apply_lhs; NULL removes the registration (then fcns is not looked at) */
 void d4est_hip_compat_bind_operator(const void* p4est, d4est_apply_operator_fcn_t apply_lhs);
-/* d4est_laplacian_build_rhs_with_strong_bc (src/dGMath/d4est_laplacian.c:16-140) on the bound plan: rhs[which_field] = M f - A(0).
+/* what the bound plan was set up with: [flux] sipg_penalty_prefactor and the boundary-condition type (BC_ROBIN 0 / BC_DIRICHLET 1).  Once
+ * registered, d4est_laplacian_apply_aij, its _with_opt twin and d4est_laplacian_build_rhs_with_strong_bc ABORT when the flux data the
+ * caller passes says otherwise (other flux type, other prefactor, other bc_type) instead of silently applying the plan's operator */
+void d4est_hip_compat_bind_flux(const void* p4est, double sipg_penalty_prefactor, int bc_type);
+/* the node coordinates of the mesh (d4est_factors->xyz[d] at the Lobatto nodes, ->xyz_quad[d] at the quadrature nodes; host arrays that
+ * stay the caller's; either may be NULL): where d4est_laplacian_build_rhs_with_strong_bc evaluates the source callback */
+void d4est_hip_compat_bind_coordinates(const void* p4est, double* xyz_lobatto[3], double* xyz_quad[3]);
+/* the Schwarz smoother of this mesh and its three [d4est_solver_schwarz] CG options, for d4est_solver_schwarz_iterate; NULL unbinds */
+void d4est_hip_compat_bind_schwarz(const void* p4est, d4est_hip_schwarz_t* sz, int subdomain_iter, double subdomain_atol, double subdomain_rtol);
+/* the reference's Schwarz metadata as the flat arrays d4est_hip_schwarz_create takes; outputs caller-allocated:
+ * sub_first[num_subdomains + 1], sub_elem[num_elements], sub_faces / sub_core_faces[3 num_elements] */
+void d4est_hip_compat_flatten_schwarz_metadata(const d4est_solver_schwarz_metadata_t* md, int* sub_first, int* sub_elem, int* sub_faces, int* sub_core_faces);
+/* d4est_laplacian_build_rhs_with_strong_bc (src/dGMath/d4est_laplacian.c:16-140) on the bound plan, with the source values handed over: rhs[which_field] = M f - A(0).
  * The reference's function evaluates the source callback through d4est_mesh_init_field (it needs the p4est and the mesh data, which
  * the shims cannot read), so the caller does that step -- one call it already has -- and passes the values: f at the Lobatto nodes
  * (init_option 1 = INIT_FIELD_ON_LOBATTO) or at the quadrature nodes (2 = INIT_FIELD_ON_QUAD; the values of d4est_mesh_init_field_option_t).  Boundary data: set the inhomogeneous

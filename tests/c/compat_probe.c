@@ -36,6 +36,8 @@ static double* vec(int n) { return (double*)calloc((size_t)(n > 0 ? n : 1), size
 /* user callbacks of the d4est_xyzu_fcn_t form (src/Mesh/d4est_xyz_functions.h:27-37) */
 static double probe_f(double x, double y, double z, double u, void* ctx) { return 1.0 + x - 0.5 * y + *(double*)ctx * z + u * u; }
 static double probe_g(double x, double y, double z, double v, void* ctx) { return *(double*)ctx + 0.3 * x * y - z + 0.7 * v; }
+static double probe_src(double x, double y, double z, void* ctx) { return 1.0 + 2.0 * x - y * z + *(double*)ctx * z; }   /* d4est_xyz_fcn_t */
+static int flux_mismatch = 0;
 /* two apply_lhs callbacks of the d4est_apply_operator_fcn_t form: the registered one and another */
 static void probe_lhs_a(p4est_t* a, d4est_ghost_t* b, d4est_ghost_data_t* c, d4est_elliptic_data_t* d, d4est_operators_t* e, d4est_geometry_t* f,
                         d4est_quadrature_t* g, d4est_mesh_data_t* h, void* i) { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; }
@@ -382,6 +384,39 @@ static void operator_level(int p) {
     for (int e = 0; e < ne; e++) oracle_quadrature_apply_galerkin_integral(0, f + qs[e], p, J + qs[e], p, Mf + ns[e]);
     for (int i = 0; i < ln; i++) ref[i] = Mf[i] - A0[i];
     check("build_rhs_with_strong_bc (quad)", p, got, ref, ln, 1e-12);
+    /* the reference's own prototype (src/dGMath/d4est_laplacian.h:25): the source CALLBACK is evaluated by the shim at the registered node
+     * coordinates; the flux data the caller passes is checked against what the plan was set up with */
+    {
+      double *xl[3], *fx = vec(ln);
+      for (int d = 0; d < 3; d++) { xl[d] = vec(ln); for (int i = 0; i < ln; i++) xl[d][i] = lcg(&seed); }
+      double cz = 0.75, sipg_params[8] = {10.0, 0, 0, 0, 0, 0, 0, 0};   /* d4est_laplacian_flux_sipg_params_t begins with the prefactor */
+      d4est_laplacian_flux_data_t fd;
+      memset(&fd, 0, sizeof fd);
+      fd.flux_type = FLUX_SIPG; fd.flux_data = sipg_params; fd.bc_type = BC_DIRICHLET;
+      d4est_hip_compat_bind_flux(p4est, 10.0, BC_DIRICHLET);
+      d4est_hip_compat_bind_coordinates(p4est, xl, xl);     /* deg_quad = deg here: as many quadrature as Lobatto nodes */
+      for (int i = 0; i < ln; i++) fx[i] = probe_src(xl[0][i], xl[1][i], xl[2][i], &cz);
+      d4est_laplacian_build_rhs_with_strong_bc(p4est, NULL, NULL, NULL, NULL, NULL, NULL, &vecs, &fd, got, probe_src, INIT_FIELD_ON_LOBATTO, &cz, 0);
+      oracle_laplacian_apply_mass_matrix(0, ne, deg, degq, ns, qs, J, fx, Mf, 1);
+      for (int i = 0; i < ln; i++) ref[i] = Mf[i] - A0[i];
+      check("d4est_laplacian_build_rhs_with_strong_bc", p, got, ref, ln, 1e-12);
+      d4est_laplacian_build_rhs_with_strong_bc(p4est, NULL, NULL, NULL, NULL, NULL, NULL, &vecs, &fd, got, probe_src, INIT_FIELD_ON_QUAD, &cz, 0);
+      for (int e = 0; e < ne; e++) oracle_quadrature_apply_galerkin_integral(0, fx + qs[e], p, J + qs[e], p, Mf + ns[e]);
+      for (int i = 0; i < ln; i++) ref[i] = Mf[i] - A0[i];
+      check("d4est_laplacian_build_rhs (quad)", p, got, ref, ln, 1e-12);
+      /* apply_aij with flux data that agrees with the registration is served */
+      d4est_hip_plan_set_dirichlet_values(plan, NULL, 0);
+      d4est_laplacian_apply_aij(p4est, NULL, NULL, &vecs, &fd, NULL, NULL, NULL, NULL, 0);
+      oracle_apply_lhs(u, ref);
+      check("apply_aij with matching flux data", p, Au, ref, ln, 1e-12);
+      if (flux_mismatch) {   /* ... and one that does not is refused (the caller of this mode expects the abort) */
+        sipg_params[0] = 20.0;
+        d4est_laplacian_apply_aij(p4est, NULL, NULL, &vecs, &fd, NULL, NULL, NULL, NULL, 0);
+        printf("NOT ABORTED\n");
+      }
+      for (int d = 0; d < 3; d++) free(xl[d]);
+      free(fx);
+    }
     d4est_hip_plan_set_dirichlet_values(plan, NULL, 0);
     free(g); free(f); free(zero); free(A0); free(Mf); free(got);
   }
@@ -389,6 +424,76 @@ static void operator_level(int p) {
   d4est_hip_plan_destroy(plan);
   free(J); free(rst); free(sj); free(nrm); free(dm); free(hm);
   free(u); free(rhs); free(Au); free(r); free(ref); free(ur); free(Aur); free(rr);
+}
+
+/* face-level entries (index work and (dim - 1) transfers, host side): d4est_operators_apply_flip / _reorient_face_data for all 144
+ * (f_m, f_p, orientation) triples, the dim = 2 transfers, and d4est_mortars_project_* in their three shapes */
+static void face_level(int p) {
+  const int N = p + 1, n2 = N * N;
+  unsigned long long seed = 4242ULL + p;
+  double *a = vec(4 * (N + 2) * (N + 2)), *got = vec(4 * (N + 2) * (N + 2)), *ref = vec(4 * (N + 2) * (N + 2));
+  for (int i = 0; i < 4 * (N + 2) * (N + 2); i++) a[i] = lcg(&seed) - 0.5;
+  char nm[64];
+  int bad = 0;
+  for (int f_m = 0; f_m < 6; f_m++)
+    for (int f_p = 0; f_p < 6; f_p++)
+      for (int o = 0; o < 4; o++) {
+        d4est_operators_reorient_face_data(NULL, a, 2, p, o, f_m, f_p, got);
+        oracle_reorient_face_data(a, p, oracle_face_reorder_code(f_m, f_p, o), ref);
+        for (int i = 0; i < n2; i++) bad += (got[i] != ref[i]);
+      }
+  printf("%-34s p=%2d  144 triples, %d entries differ %s\n", "reorient_face_data", p, bad, bad ? "FAIL" : "");
+  if (bad) n_fail++;
+  for (int dir = 0; dir < 3; dir++) {
+    d4est_operators_apply_flip(NULL, a, 2, p, dir, got);
+    for (int b = 0; b < N; b++)
+      for (int c = 0; c < N; c++) ref[c + N * b] = a[((dir == 0 || dir == 2) ? p - c : c) + N * ((dir == 1 || dir == 2) ? p - b : b)];
+    snprintf(nm, sizeof nm, "apply_flip dim 2 dir %d", dir); check(nm, p, got, ref, n2, 0.0);
+  }
+  d4est_operators_apply_flip(NULL, a, 1, p, 0, got);
+  for (int c = 0; c < N; c++) ref[c] = a[p - c];
+  check("apply_flip dim 1", p, got, ref, N, 0.0);
+  /* dim = 2 transfers against the oracle's dim = 2 branch */
+  int degm[4] = {p, p + 1, p + 2, p + 1}, tot = 0;
+  for (int c = 0; c < 4; c++) tot += (degm[c] + 1) * (degm[c] + 1);
+  d4est_operators_apply_p_prolong(NULL, a, p, 2, p + 2, got); oracle_apply_p_prolong(a, p, 2, p + 2, ref);
+  check("apply_p_prolong dim 2", p, got, ref, (N + 2) * (N + 2), 1e-13);
+  d4est_operators_apply_hp_prolong(NULL, a, p, 2, degm, got); oracle_apply_hp_prolong(a, p, 2, degm, ref);
+  check("apply_hp_prolong dim 2", p, got, ref, tot, 1e-13);
+  d4est_operators_apply_p_prolong_transpose(NULL, a, p + 2, 2, p, got); oracle_apply_p_prolong_transpose(a, p + 2, 2, p, ref);
+  check("apply_p_prolong_transpose dim 2", p, got, ref, n2, 1e-13);
+  d4est_operators_apply_hp_prolong_transpose(NULL, a, degm, 2, p, got); oracle_apply_hp_prolong_transpose(a, degm, 2, p, ref);
+  check("apply_hp_prolong_transpose dim 2", p, got, ref, n2, 1e-13);
+  d4est_operators_apply_p_restrict(NULL, a, p + 2, 2, p, got); oracle_apply_p_restrict(a, p + 2, 2, p, ref);
+  check("apply_p_restrict dim 2", p, got, ref, n2, 1e-11);
+  d4est_operators_apply_hp_restrict(NULL, a, degm, 2, p, got); oracle_apply_hp_restrict(a, degm, 2, p, ref);
+  check("apply_hp_restrict dim 2", p, got, ref, n2, 1e-11);
+  /* d4est_mortars_project_side_onto_mortar_space / _mass_mortar_onto_side (src/Mesh/d4est_mortars.c:510-598): 1 -> 1, 1 -> 4, 4 -> 4 */
+  int ds1[1] = {p}, dm1[1] = {p + 1}, ds4[4] = {p, p, p + 1, p};
+  d4est_mortars_project_side_onto_mortar_space(NULL, a, 1, ds1, got, 1, dm1); oracle_apply_p_prolong(a, p, 2, p + 1, ref);
+  check("mortars_project side->mortar 1-1", p, got, ref, (N + 1) * (N + 1), 1e-13);
+  d4est_mortars_project_side_onto_mortar_space(NULL, a, 1, ds1, got, 4, degm); oracle_apply_hp_prolong(a, p, 2, degm, ref);
+  check("mortars_project side->mortar 1-4", p, got, ref, tot, 1e-13);
+  d4est_mortars_project_mass_mortar_onto_side(NULL, a, 4, degm, got, 1, ds1); oracle_apply_hp_prolong_transpose(a, degm, 2, p, ref);
+  check("mortars_project mortar->side 4-1", p, got, ref, n2, 1e-13);
+  {
+    int ss = 0, sm = 0, tots = 0;
+    d4est_mortars_project_side_onto_mortar_space(NULL, a, 4, ds4, got, 4, degm);
+    for (int i = 0; i < 4; i++) {
+      oracle_apply_p_prolong(a + ss, ds4[i], 2, degm[i], ref + sm);
+      ss += (ds4[i] + 1) * (ds4[i] + 1); sm += (degm[i] + 1) * (degm[i] + 1);
+    }
+    check("mortars_project side->mortar 4-4", p, got, ref, sm, 1e-13);
+    d4est_mortars_project_mass_mortar_onto_side(NULL, a, 4, degm, got, 4, ds4);
+    ss = sm = 0;
+    for (int i = 0; i < 4; i++) {
+      oracle_apply_p_prolong_transpose(a + sm, degm[i], 2, ds4[i], ref + ss);
+      ss += (ds4[i] + 1) * (ds4[i] + 1); sm += (degm[i] + 1) * (degm[i] + 1);
+    }
+    tots = ss;
+    check("mortars_project mortar->side 4-4", p, got, ref, tots, 1e-13);
+  }
+  free(a); free(got); free(ref);
 }
 
 static void probe_lhs_b(p4est_t* a, d4est_ghost_t* b, d4est_ghost_data_t* c, d4est_elliptic_data_t* d, d4est_operators_t* e, d4est_geometry_t* f,
@@ -414,6 +519,8 @@ int main(int argc, char** argv) {
     printf("NOT ABORTED\n");
     return 0;
   }
+  if (argc > 1 && strcmp(argv[1], "fluxmismatch") == 0) { flux_mismatch = 1; operator_level(3); return 0; }
+  face_level(2); face_level(7); face_level(11);
   const int ps[] = {2, 3, 7, 8, 11};
   for (int i = 0; i < 5; i++) {
     element_level(ps[i], ps[i], 0);
