@@ -273,6 +273,7 @@ const char* d4est_hip_plan_last_kernel(const d4est_hip_plan_t* plan) { check_pla
 const char* d4est_hip_plan_face_path(const d4est_hip_plan_t* plan) {
   check_plan(plan, "plan_face_path");
   if (!plan->has_faces) D4EST_HIP_ABORT("plan_face_path: call plan_set_faces first");
+  if (d4est_hip::hybrid_active(plan)) return d4est_hip::hybrid_path(plan);
   return d4est_hip::direct_active(plan) ? (d4est_hip::direct_fused_ok(plan) ? "direct+volume" : "direct") : "two-phase";
 }
 int d4est_hip_plan_local_nodes(const d4est_hip_plan_t* plan) { check_plan(plan, "plan_local_nodes"); return plan->local_nodes; }

@@ -161,7 +161,9 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
   if (slot >= n_elem) return;
   // an element list leaves out elements whose rows the caller forms another way (condensed Schwarz copies); they are still READ as neighbours
   const int e = elem_list ? __builtin_amdgcn_readfirstlane(elem_list[slot]) : slot;
-  const int ns = __builtin_amdgcn_readfirstlane(ns0 + e * ns_stride);
+  // (ns_stride < 0: a mixed-degree or locally refined plan, whose clean elements this kernel serves through a list -- the element's
+  // nodal offset then sits in the otherwise unused fourth word of its first side descriptor: one more scalar load)
+  const int ns = __builtin_amdgcn_readfirstlane(ns_stride >= 0 ? ns0 + e * ns_stride : direct_kargs()->sides[6 * (size_t)e].pad);
 
   // ---- the element's u -> LDS (odd padded line length: conflict-free line reads in all three directions); all loads first
   {
@@ -677,11 +679,12 @@ bool direct_fused_ok(const d4est_hip_plan* plan) {
 }
 
 // vol_term: 0 the face terms only (Au += ...), 1 the whole operator (Au = volume + faces; direct_fused_ok), 2 the whole operator
-// with the plan's zeroth-order term (plan_set_lhs_coefficient) in its volume stage
-void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
-                         const double* robin_c, const double* robin_r, int vol_term) {
-  DirectHost* dh = host_of(plan);
-  if (!dh) D4EST_HIP_ABORT("direct face kernel: the plan has no direct tables");
+// with the plan's zeroth-order term (plan_set_lhs_coefficient) in its volume stage.
+// dh / bk: the direct tables and the bucket they belong to -- the plan's own (uniform conforming plans) or one clean-element bucket of
+// the hybrid operator (hybrid = true: offsets by element id from the side table / d_qs_by_elem, streamed metric).
+static void launch_direct_core(d4est_hip_plan* plan, DirectHost* dh, const Bucket& bk, bool hybrid, const int* d_qs_by_elem, const double* u,
+                               const double* ghost_trace, double* Au, const DirectFuse* cf, const double* robin_c, const double* robin_r,
+                               int vol_term) {
   if (!plan->has_face_geometry) D4EST_HIP_ABORT("apply flux: plan_set_mortar_geometry was not called");
   const int n = dh->d_list ? dh->n_list : plan->n_elements;
   if (n == 0) return;
@@ -693,14 +696,14 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
   DirectVol vol;
   int vmode = 0;
   if (vol_term) {
-    if (!direct_fused_ok(plan)) D4EST_HIP_ABORT("direct face kernel: the fused volume term was requested on a plan that cannot take it");
-    const Bucket& bk = plan->buckets[0];
+    if (!hybrid && !direct_fused_ok(plan)) D4EST_HIP_ABORT("direct face kernel: the fused volume term was requested on a plan that cannot take it");
     vol.metric = plan->d_metric;
     vol.EBf = bk.d_EBf; vol.EGf = bk.d_EGf; vol.EBb = bk.d_EBb; vol.EGb = bk.d_EGb;
     vol.EDq = bk.d_EDq; vol.EDqT = bk.d_EDqT;
     vol.stream = plan->stream_mode;
-    vol.qs0 = bk.qs0; vol.qs_stride = bk.ns_stride >= 0 ? bk.qs_stride : -1; vol.qs_list = plan->d_qs_list + bk.elem_offset;
-    const bool aff = bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine;
+    if (hybrid) { vol.qs0 = 0; vol.qs_stride = -1; vol.qs_list = d_qs_by_elem; }
+    else { vol.qs0 = bk.qs0; vol.qs_stride = bk.ns_stride >= 0 ? bk.qs_stride : -1; vol.qs_list = plan->d_qs_list + bk.elem_offset; }
+    const bool aff = !hybrid && bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine;
     if (aff) { vol.affine = plan->d_metric_affine; vol.wq = bk.d_w; }
     vmode = aff ? 2 : 1;
     if (vol_term == 2) {
@@ -751,6 +754,183 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
                  nb, kDirectWPB, at.numRegs, at.sharedSizeBytes, at.localSizeBytes, nv, av.numRegs, av.sharedSizeBytes, av.localSizeBytes);
   }
   HIP_CHECK(hipGetLastError());
+}
+
+void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf,
+                         const double* robin_c, const double* robin_r, int vol_term) {
+  DirectHost* dh = host_of(plan);
+  if (!dh) D4EST_HIP_ABORT("direct face kernel: the plan has no direct tables");
+  launch_direct_core(plan, dh, plan->buckets[0], false, nullptr, u, ghost_trace, Au, cf, robin_c, robin_r, vol_term);
+}
+
+// ---------------------------------------------------------------------------
+// The hybrid operator: mixed-degree and locally refined plans (BASELINE config 4's mesh class).
+// Most elements of an hp-adaptive mesh sit inside a region of one degree and one refinement level: all six of their sides are
+// conforming, against a local element of the same degree (or the domain boundary).  Those CLEAN elements get the whole operator from
+// the trace-free one-kernel path -- faces_direct_kernel / operator_mw_kernel of their degree bucket over an element list, u in, A u out,
+// no trace arrays -- and only the DIRTY rest (a mixed-degree, hanging or ghost side) runs traces + volume + flux through the two-phase
+// kernels, on lists: traces of the dirty elements and of their neighbours (the ring), the volume term and the flux of the dirty ones.
+// Every element's A u is written by exactly one path.  Reference: d4est_laplacian_apply_aij (src/dGMath/d4est_laplacian.c:318-417) is
+// one path for every mesh; this is the same operator, split by where each element's data comes from.
+// ---------------------------------------------------------------------------
+struct HybridHost {
+  std::vector<DirectHost*> dh;        // per plan bucket (nullptr: no clean elements there)
+  std::vector<int*> d_clean;          // per plan bucket: its clean elements
+  std::vector<int> n_clean;
+  DirectSide* d_sides = nullptr;      // shared by the buckets' tables (the element's nodal offset in sides[6 e].pad)
+  DirectGhostOff* d_ghost_off = nullptr;
+  int* d_qs_by_elem = nullptr;
+  int *d_dirty = nullptr, *d_ring = nullptr;
+  int n_dirty = 0, n_ring = 0, n_clean_total = 0;
+  int *d_ns_dirty = nullptr, *d_qs_dirty = nullptr;   // bucket-ordered lists of the dirty elements (the volume kernels' view)
+  std::vector<int> dirty_off, dirty_cnt;
+  char path[96] = "";
+};
+static HybridHost* hybrid_of(const d4est_hip_plan* plan) { return static_cast<HybridHost*>(plan->hybrid); }
+
+void hybrid_destroy(d4est_hip_plan* plan) {
+  HybridHost* hh = hybrid_of(plan);
+  if (!hh) return;
+  for (DirectHost* d : hh->dh)
+    if (d) { (void)hipFree(d->d_ops); delete d; }
+  for (int* p : hh->d_clean) (void)hipFree(p);
+  (void)hipFree(hh->d_sides); (void)hipFree(hh->d_ghost_off); (void)hipFree(hh->d_qs_by_elem); (void)hipFree(hh->d_dirty); (void)hipFree(hh->d_ring);
+  (void)hipFree(hh->d_ns_dirty); (void)hipFree(hh->d_qs_dirty);
+  delete hh;
+  plan->hybrid = nullptr;
+}
+
+bool hybrid_pair_built(int N, int NQ) { return N == NQ && direct_pair_built(N, NQ); }
+
+template <typename T>
+static T* hy_upload(const std::vector<T>& v) {
+  T* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+// clean[e]: 1 = the element takes the one-kernel path.  tables(bucket) -> {C, CD, E} of the bucket's degree (host pointers, NQ x N / N x NQ)
+void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const std::vector<const double*>& C, const std::vector<const double*>& CD,
+                  const std::vector<const double*>& E) {
+  hybrid_destroy(plan);
+  const int ne = plan->n_elements;
+  HybridHost* hh = new HybridHost;
+  const size_t nb = plan->buckets.size();
+  hh->dh.assign(nb, nullptr); hh->d_clean.assign(nb, nullptr); hh->n_clean.assign(nb, 0);
+  hh->dirty_off.assign(nb, 0); hh->dirty_cnt.assign(nb, 0);
+  // side table of every element (only clean elements are worked on, everybody is read as a neighbour)
+  std::vector<DirectSide> sd(6 * (size_t)ne);
+  std::vector<DirectGhostOff> goff(6 * (size_t)ne, 0);
+  for (int e = 0; e < ne; ++e)
+    for (int f = 0; f < 6; ++f) {
+      const size_t s = 6 * (size_t)e + f;
+      DirectSide d{};
+      const int nbr = plan->side_nbr[s];
+      const int kind = (nbr == -1) ? 0 : (nbr >= 0 ? 1 : 2);
+      const int fp = (kind == 0) ? 0 : plan->side_nbr_face[s];
+      d.kcf = kind | ((plan->side_reorder[s] & 7) << 2) | (fp << 5);
+      d.nbr_ns = (kind == 1) ? plan->nodal_stride[nbr] : 0;
+      d.geom = plan->side_mortar_stride[s];
+      d.pad = (f == 0) ? plan->nodal_stride[e] : 0;
+      sd[s] = d;
+    }
+  hh->d_sides = hy_upload(sd);
+  hh->d_ghost_off = hy_upload(goff);
+  hh->d_qs_by_elem = hy_upload(plan->quad_stride);
+  // bucket-ordered walk: clean lists per bucket, dirty lists for the volume kernels' view
+  std::vector<int> dirty, ns_dirty, qs_dirty;
+  for (size_t b = 0; b < nb; ++b) {
+    const Bucket& bk = plan->buckets[b];
+    std::vector<int> cl;
+    hh->dirty_off[b] = (int)ns_dirty.size();
+    for (int i = 0; i < bk.n_elem; ++i) {
+      const int e = plan->elem_ids[bk.elem_offset + i];
+      if (clean[e]) cl.push_back(e);
+      else { ns_dirty.push_back(plan->nodal_stride[e]); qs_dirty.push_back(plan->quad_stride[e]); }
+    }
+    hh->dirty_cnt[b] = (int)ns_dirty.size() - hh->dirty_off[b];
+    if (cl.empty()) continue;
+    std::sort(cl.begin(), cl.end());   // element (Morton) order: neighbours' u close in the caches
+    DirectHost* dh = new DirectHost;
+    const int N = bk.N, NQ = bk.NQ;
+    dh->N = N; dh->NQ = NQ; dh->ns0 = 0; dh->ns_stride = -1;
+    dh->mw = direct_mw_built(N, NQ);
+    dh->eo = true;
+    std::vector<double> Cv(C[b], C[b] + (size_t)NQ * N), CDv(CD[b], CD[b] + (size_t)NQ * N), Ev(E[b], E[b] + (size_t)N * NQ);
+    std::vector<double> D = Tables1D::dij(N - 1);
+    std::vector<double> DtE = Tables1D::matmul(Tables1D::transpose(D, N, N), Ev, N, N, NQ);
+    std::vector<double> ops;
+    auto put = [&](const std::vector<double>& Mx, int R, int Cc, bool anti) {
+      std::vector<double> t = Tables1D::eo_table(Mx, R, Cc, anti);
+      t.resize((size_t)R * Cc, 0.0);
+      ops.insert(ops.end(), t.begin(), t.end());
+    };
+    put(Cv, NQ, N, false);
+    put(CDv, NQ, N, true);
+    put(Ev, N, NQ, false);
+    put(DtE, N, NQ, true);
+    for (int i = 0; i < N; ++i) ops.push_back(D[i]);
+    for (int i = 0; i < N; ++i) ops.push_back(D[(size_t)(N - 1) * N + i]);
+    ops.resize(ops.size() + 16, 0.0);
+    dh->d_ops = hy_upload(ops);
+    dh->d_sides = hh->d_sides;
+    dh->d_ghost_off = hh->d_ghost_off;
+    hh->d_clean[b] = hy_upload(cl);
+    hh->n_clean[b] = (int)cl.size();
+    dh->d_list = hh->d_clean[b];
+    dh->n_list = hh->n_clean[b];
+    hh->dh[b] = dh;
+    hh->n_clean_total += (int)cl.size();
+  }
+  // dirty elements in element order, and the ring: the dirty elements plus every local element across one of their sides (whose traces the
+  // dirty flux reads; hanging neighbours through side_nbr4)
+  std::vector<char> in_ring(ne, 0);
+  for (int e = 0; e < ne; ++e) {
+    if (clean[e]) continue;
+    dirty.push_back(e);
+    in_ring[e] = 1;
+    for (int f = 0; f < 6; ++f) {
+      const size_t s = 6 * (size_t)e + f;
+      if (plan->side_nbr[s] >= 0) in_ring[plan->side_nbr[s]] = 1;
+      if (!plan->side_nbr4.empty())
+        for (int k = 0; k < 4; ++k)
+          if (plan->side_nbr4[4 * s + k] >= 0) in_ring[plan->side_nbr4[4 * s + k]] = 1;
+    }
+  }
+  std::vector<int> ring;
+  for (int e = 0; e < ne; ++e)
+    if (in_ring[e]) ring.push_back(e);
+  hh->d_dirty = hy_upload(dirty); hh->n_dirty = (int)dirty.size();
+  hh->d_ring = hy_upload(ring); hh->n_ring = (int)ring.size();
+  hh->d_ns_dirty = hy_upload(ns_dirty);
+  hh->d_qs_dirty = hy_upload(qs_dirty);
+  std::snprintf(hh->path, sizeof(hh->path), "hybrid: direct+volume on %d clean elements, two-phase on %d", hh->n_clean_total, hh->n_dirty);
+  plan->hybrid = hh;
+}
+
+bool hybrid_active(const d4est_hip_plan* plan) {
+  const HybridHost* hh = hybrid_of(plan);
+  return hh != nullptr && plan->tuning[D4EST_HIP_TUNE_HYBRID] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
+         plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT] != 0 && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0 && plan->has_geometry;
+}
+const char* hybrid_path(const d4est_hip_plan* plan) { return hybrid_of(plan)->path; }
+void hybrid_lists(const d4est_hip_plan* plan, const int** dirty, int* n_dirty, const int** ring, int* n_ring) {
+  const HybridHost* hh = hybrid_of(plan);
+  *dirty = hh->d_dirty; *n_dirty = hh->n_dirty; *ring = hh->d_ring; *n_ring = hh->n_ring;
+}
+
+// the clean elements: one whole-operator launch per degree bucket (u in, A u out)
+void launch_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const double* robin_c, const double* robin_r) {
+  HybridHost* hh = hybrid_of(plan);
+  for (size_t b = 0; b < hh->dh.size(); ++b)
+    if (hh->dh[b]) launch_direct_core(plan, hh->dh[b], plan->buckets[b], true, hh->d_qs_by_elem, u, ghost_trace, Au, nullptr, robin_c, robin_r, 1);
+}
+// the dirty elements' volume term
+void launch_hybrid_dirty_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
+  HybridHost* hh = hybrid_of(plan);
+  if (hh->n_dirty == 0) return;
+  launch_stiffness_view(plan, u, Au, hh->d_ns_dirty, hh->d_qs_dirty, hh->dirty_off.data(), hh->dirty_cnt.data());
 }
 
 }  // namespace d4est_hip

@@ -175,7 +175,7 @@ __global__ __launch_bounds__((MwCfg<N>::THREADS), (N <= 13 ? D4EST_HIP_MWD_WAVES
   const int slot = xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v;
   if (slot >= n_elem) return;
   const int e = elem_list ? __builtin_amdgcn_readfirstlane(elem_list[slot]) : slot;
-  const int ns = __builtin_amdgcn_readfirstlane(ns0 + e * ns_stride);
+  const int ns = __builtin_amdgcn_readfirstlane(ns_stride >= 0 ? ns0 + e * ns_stride : sides[6 * (size_t)e].pad);   // (see faces_direct_kernel)
   MW_STAMP(0);
 
   // the six side descriptors now (scalar loads; two dependent round trips -- kernel-argument segment, then the array -- that would
@@ -571,9 +571,14 @@ bool launch_direct_mw_hi(d4est_hip_plan* plan, DirectHost* dh, const double* u, 
 #define D4EST_HIP_MW_LAUNCHER bool launch_direct_mw_hi
 #endif
 
-template <typename K>
-static void mw_set_lds_limit(K kernel, size_t bytes) {
-  if (bytes > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+// the dynamic-LDS attribute of a kernel instance is set ONCE (a static flag per instantiation of this template), not at every launch:
+// the launch sits in the hot path of a Chebyshev iteration / a Schwarz CG sweep, and inside hipGraph capture regions
+template <typename K, K Kernel>
+static void mw_set_lds_limit_once(size_t bytes) {
+  static bool done = false;
+  if (done) return;
+  if (bytes > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done = true;
 }
 
 // vmode: VOL of operator_mw_kernel; + 8 (stream mode, plan->stream_mode) exists for the whole operator with the streamed metric (1 -> 9)
@@ -584,7 +589,7 @@ D4EST_HIP_MW_LAUNCHER(d4est_hip_plan* plan, DirectHost* dh, const double* u, con
   if (vmode == 1 && vol.stream) vmode = 9;
 #define D4EST_HIP_MW_GO(N_, FUSE_, VOL_)                                                                                          \
   do {                                                                                                                             \
-    mw_set_lds_limit(operator_mw_kernel<N_, FUSE_, VOL_>, MwCfg<N_>::LDS_BYTES);                                                  \
+    mw_set_lds_limit_once<decltype(&operator_mw_kernel<N_, FUSE_, VOL_>), &operator_mw_kernel<N_, FUSE_, VOL_>>(MwCfg<N_>::LDS_BYTES);  \
     hipLaunchKernelGGL((operator_mw_kernel<N_, FUSE_, VOL_>), dim3(n), dim3(MwCfg<N_>::THREADS), MwCfg<N_>::LDS_BYTES, plan->stream, \
                        u, ghost_trace, Au, dh->d_sides, dh->d_ghost_off, dh->d_ops, plan->d_face_geom, plan->d_bndry, robin_c,     \
                        robin_r, n, dh->ns0, dh->ns_stride, chunk, cfv, vol, dh->d_list);                                           \

@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
                                                         const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                         const double* __restrict__ geom, const double* __restrict__ bndry_q,
                                                         const double* __restrict__ robin_c, const double* __restrict__ robin_r,
-                                                        int n_elem, int xcd_chunk, ChebyFuse cf) {
+                                                        int n_elem, int xcd_chunk, ChebyFuse cf, const int* __restrict__ elist) {
   __shared__ double s_in[6][4][64];   // per wave: 4 term fields on the 8 x 8 grid
   __shared__ double s_tmp[INPLACE ? 1 : 6][INPLACE ? 1 : 4][64];
   __shared__ double s_E[6][64];       // per wave: E of its side, zero-padded to 8 x 8
@@ -1054,7 +1054,8 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
   // XCD-aware element order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the virtual index v is
   // mapped to element (v % 8) * chunk + v / 8: every XCD walks one contiguous (Morton-local) eighth of the elements and finds
   // its neighbours' traces in its own L2 more often.  xcd_chunk = 0: identity.
-  auto elem_of = [&](int v) { return xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v; };
+  // elist: the kernel works on the listed elements only (the hybrid operator's dirty elements; n_elem = the list's length)
+  auto elem_of = [&](int v) { return elist ? elist[v] : (xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v); };
   int e = blockIdx.x;
   ElemDesc edn = ed[e < n_elem ? elem_of(e) : 0];
   SideDesc dn = sd[6 * (e < n_elem ? elem_of(e) : 0) + f];
@@ -1185,7 +1186,7 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
                                                           const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                           const double* __restrict__ geom, const double* __restrict__ bndry_q,
                                                           const double* __restrict__ robin_c, const double* __restrict__ robin_r,
-                                                          int n_elem, int xcd_chunk, ChebyFuse cf) {
+                                                          int n_elem, int xcd_chunk, ChebyFuse cf, const int* __restrict__ elist) {
   constexpr int LT = 17;                    // padded row length of a 16 x 16 tile in LDS
   constexpr int TPB = 192;
   __shared__ double s_tile[6][2][16 * LT];  // per face: val, normal field   (rows a, columns b)
@@ -1200,7 +1201,7 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
 #pragma unroll
   for (int i = 0; i < 4; ++i) opE[0][i] = opE[1][i] = opD[i] = 0.0;
   for (int v = blockIdx.x; v < n_elem; v += gridDim.x) {
-    const int e = xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v;   // XCD-aware element order, see flux_wave_kernel
+    const int e = elist ? elist[v] : (xcd_chunk > 0 ? (v & 7) * xcd_chunk + (v >> 3) : v);   // XCD-aware element order / element list, see flux_wave_kernel
     const ElemDesc el = ed[e];
     const int N = el.N, N2 = N * N, N3 = N2 * N;
     if (el.offD != cur_offD || N != cur_N) {
@@ -2257,6 +2258,49 @@ void faces_setup(d4est_hip_plan* plan) {
       if (!rec.empty()) HIP_CHECK(hipMemcpy(fh.d_rec, rec.data(), rec.size() * sizeof(HpMortar), hipMemcpyHostToDevice));
     }
   }
+  // ---- the hybrid operator (d4est_hip_direct.hip): on mixed-degree / locally refined plans the CLEAN elements -- deg_quad = deg with a
+  // one-kernel instance, all six sides conforming against a local element of the same degree or the boundary -- take the trace-free
+  // whole-operator kernels of their degree bucket; one rank, plans whose two-phase kernels have list forms
+  hybrid_destroy(plan);
+  if (!plan->direct && ne > 0 && plan->n_ghost == 0 && plan->tuning[D4EST_HIP_TUNE_HYBRID] != 0 && plan->tuning[D4EST_HIP_TUNE_GHOST_ALIAS] <= 0 &&
+      plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1 && (hp ? (fh.hp_split || (fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16)) : (fast || (fh.max_N <= 16 && fh.max_NQ <= 16)))) {
+    std::vector<char> bucket_ok(plan->buckets.size(), 0), clean(ne, 0);
+    std::vector<int> bucket_of(ne, -1);
+    for (size_t b = 0; b < plan->buckets.size(); ++b) {
+      const Bucket& bk = plan->buckets[b];
+      bucket_ok[b] = bk.N == bk.NQ && bk.d_EBf && hybrid_pair_built(bk.N, bk.NQ);
+      for (int i = 0; i < bk.n_elem; ++i) bucket_of[plan->elem_ids[bk.elem_offset + i]] = (int)b;
+    }
+    int n_clean = 0;
+    for (int e = 0; e < ne; ++e) {
+      if (bucket_of[e] < 0 || !bucket_ok[bucket_of[e]]) continue;
+      bool ok = true;
+      for (int f = 0; f < 6 && ok; ++f) {
+        const size_t s_ = 6 * (size_t)e + f;
+        if (hp && plan->side_hang[s_] != 0) { ok = false; break; }
+        const int nbr = plan->side_nbr[s_];
+        if (nbr == -1) continue;                                   // domain boundary
+        if (nbr < 0) { ok = false; break; }                        // (ghost: not on one-rank plans)
+        const size_t sp = 6 * (size_t)nbr + plan->side_nbr_face[s_];
+        ok = plan->deg[nbr] == plan->deg[e] && plan->deg_quad[nbr] == plan->deg_quad[e] && deg_mq_of[s_] == plan->deg_quad[e] &&
+             !(hp && plan->side_hang[sp] != 0);
+      }
+      clean[e] = ok;
+      n_clean += ok;
+    }
+    if (n_clean > 0 && (plan->tuning[D4EST_HIP_TUNE_HYBRID] > 0 || 4 * (size_t)n_clean >= (size_t)ne)) {
+      std::vector<int> oC(plan->buckets.size(), -1), oCD(plan->buckets.size(), -1), oE(plan->buckets.size(), -1);
+      for (size_t b = 0; b < plan->buckets.size(); ++b) {
+        if (!bucket_ok[b]) continue;
+        const int d = plan->buckets[b].deg, dq = plan->buckets[b].deg_quad;
+        oC[b] = get_C(d, dq); oCD[b] = get_CD(d, dq); oE[b] = get_E(d, d, dq);
+      }
+      std::vector<const double*> pC(plan->buckets.size(), nullptr), pCD(plan->buckets.size(), nullptr), pE(plan->buckets.size(), nullptr);
+      for (size_t b = 0; b < plan->buckets.size(); ++b)
+        if (oC[b] >= 0) { pC[b] = ops.data() + oC[b]; pCD[b] = ops.data() + oCD[b]; pE[b] = ops.data() + oE[b]; }
+      hybrid_setup(plan, clean, pC, pCD, pE);
+    }
+  }
   const size_t tm = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
   HIP_CHECK(hipMalloc(&plan->d_trace, std::max<size_t>((size_t)plan->local_trace_doubles, 1) * sizeof(double)));
   HIP_CHECK(hipMalloc(&plan->d_bndry, tm * sizeof(double)));  // Dirichlet data at the mortar quadrature nodes, by geom stride
@@ -2662,8 +2706,9 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     return;
   }
   // elist: only these elements' traces are needed (the tiled MFMA kernels take the list; the other families compute every element)
-  const bool listed = elist && !fh.hp && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
-                      ((plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1) || (!plan->face_fast && fh.max_N <= 16 && fh.max_NQ <= 16));
+  const bool listed = elist && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
+                      ((fh.hp && (fh.hp_split || (fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16))) ||
+                       (!fh.hp && ((plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1) || (!plan->face_fast && fh.max_N <= 16 && fh.max_NQ <= 16))));
   if (!listed) elist = nullptr;
   const int n = listed ? n_list : plan->n_elements;
   if (n == 0) return;
@@ -2675,7 +2720,7 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
-                       (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, (const int*)nullptr);
+                       (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, elist);
     if (fh.n_hang_elems > 0) {
       const size_t lds = (size_t)(fh.hp_max_N * 272 + 3 * 2 * 16 * 34) * sizeof(double);
       if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2687,7 +2732,7 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     const size_t lds = (size_t)(fh.hp_max_N * 272 + 3 * 2 * 16 * 34) * sizeof(double);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(trace_hp_mfma16_kernel, dim3(std::min(n, 4 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), lds, plan->stream, u, trace,
-                       fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, n, fh.hp_max_N);
+                       fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, n, fh.hp_max_N, elist, 0);
   } else if (fh.hp) {
     const size_t lds = fh.hp_lds_doubles * sizeof(double);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2730,17 +2775,20 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
 // true when launch_flux runs the kernel that can carry the Chebyshev update in its epilogue
 bool flux_can_fuse_update(d4est_hip_plan* plan) {
   FaceHost& fh = g_face_host[plan];
-  return plan->has_faces && plan->n_elements > 0 && !fh.hp && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
+  return plan->has_faces && plan->n_elements > 0 && !fh.hp && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && !hybrid_active(plan) &&
          (plan->face_fast || (fh.max_N <= 16 && fh.max_NQ <= 16));
 }
 
-void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf) {
+void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf, const int* elist,
+                 int n_list) {
   FaceHost& fh = g_face_host[plan];
   if (cf && !flux_can_fuse_update(plan)) D4EST_HIP_ABORT("launch_flux: fused update requested on a plan whose flux kernel cannot carry it");
   if (!plan->has_faces || !plan->has_face_geometry) D4EST_HIP_ABORT("apply flux: plan_set_faces / plan_set_mortar_geometry were not called");
   if (plan->n_elements == 0) return;
   if (fh.n_ghost_sides > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost sides but no ghost trace buffer was given", fh.n_ghost_sides);
-  const int n = plan->n_elements;
+  const int n = elist ? n_list : plan->n_elements;
+  if (n == 0) return;
+  if (elist && cf) D4EST_HIP_ABORT("launch_flux: a fused update cannot ride on an element list");
   if (fh.hp && fh.hp_split) {
     // hp split (see launch_traces): the conforming sides' terms from the fast kernel, then the hanging sides' from the record kernel
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
@@ -2748,19 +2796,22 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     static const bool no_remap_s = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
-    const int chunk_s = (n % 8 == 0 && grid % 8 == 0 && !no_remap_s) ? n / 8 : 0;   // XCD-aware element order, as on conforming plans
+    const int chunk_s = (!elist && n % 8 == 0 && grid % 8 == 0 && !no_remap_s) ? n / 8 : 0;   // XCD-aware element order, as on conforming plans
     hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
                        (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom,
-                       plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk_s, ChebyFuse{});
+                       plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk_s, ChebyFuse{}, elist);
     if (fh.n_hang_elems > 0)
       hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(fh.n_hang_elems, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
                          fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
                          plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems,
                          (const int*)fh.d_hang_elems, 1);
+  } else if (elist && ((fh.hp && !(fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0)) ||
+                       (!fh.hp && !(plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && (plan->face_fast || (fh.max_N <= 16 && fh.max_NQ <= 16)))))) {
+    D4EST_HIP_ABORT("launch_flux: no list form of this plan's flux kernels (the hybrid operator is not set up for such plans)");
   } else if (fh.hp && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256))), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
                        fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
-                       plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n);
+                       plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, elist, 0);
   } else if (fh.hp) {
     const size_t lds = fh.hp_lds_doubles * sizeof(double);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_hp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2774,12 +2825,12 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     const int rounds = (n + resident - 1) / resident;
     const int grid = (n + rounds - 1) / rounds;
     static const bool no_remap = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
-    const int chunk = (n % 8 == 0 && grid % 8 == 0 && !no_remap) ? n / 8 : 0;
+    const int chunk = (!elist && n % 8 == 0 && grid % 8 == 0 && !no_remap) ? n / 8 : 0;
     const bool subdomain_plan = plan->tuning[D4EST_HIP_TUNE_GHOST_ALIAS] > 0;   // see flux_wave_kernel: INPLACE
 #define D4EST_HIP_LAUNCH_FLUX_WAVE(FUSE_, INPLACE_, CF_)                                                                                 \
   hipLaunchKernelGGL((flux_wave_kernel<FUSE_, INPLACE_>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,               \
                      (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom,        \
-                     plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk, CF_)
+                     plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk, CF_, elist)
     if (cf && subdomain_plan) D4EST_HIP_LAUNCH_FLUX_WAVE(true, false, *cf);
     else if (cf) D4EST_HIP_LAUNCH_FLUX_WAVE(true, true, *cf);
     else if (subdomain_plan) D4EST_HIP_LAUNCH_FLUX_WAVE(false, false, ChebyFuse{});
@@ -2788,16 +2839,16 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int grid16 = std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256));
     static const bool no_remap16 = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
-    const int chunk16 = (n % 8 == 0 && grid16 % 8 == 0 && !no_remap16) ? n / 8 : 0;
+    const int chunk16 = (!elist && n % 8 == 0 && grid16 % 8 == 0 && !no_remap16) ? n / 8 : 0;
     if (cf)
       hipLaunchKernelGGL(flux_mfma16_kernel<true>, dim3(grid16), dim3(192), 0, plan->stream, trace,
                          ghost_trace, Au, (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
-                         plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk16, *cf);
+                         plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk16, *cf, elist);
     else
       hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(grid16), dim3(192), 0, plan->stream, trace,
                          ghost_trace, Au, (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops,
                          plan->d_face_geom, plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk16,
-                         ChebyFuse{});
+                         ChebyFuse{}, elist);
   } else {
     const size_t lds = generic_lds_bytes(plan);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(flux_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2814,8 +2865,14 @@ void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* gho
   launch_direct_faces(plan, u, ghost_trace, Au, cf, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, vol_term);
 }
 
+void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au) {
+  FaceHost& fh = g_face_host[plan];
+  launch_hybrid_clean(plan, u, ghost_trace, Au, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr);
+}
+
 void faces_destroy(d4est_hip_plan* plan) {
   direct_destroy(plan);
+  hybrid_destroy(plan);
   auto it = g_face_host.find(plan);
   if (it != g_face_host.end()) {
     FaceHost& fh = it->second;

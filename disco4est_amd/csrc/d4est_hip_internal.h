@@ -112,6 +112,7 @@ struct d4est_hip_plan {
   int max_face_lds_doubles = 0;
   bool face_fast = false;  // all sides have N, Np, NQ <= 8: flux_wave_kernel applies
   void* direct = nullptr;  // DirectHost (d4est_hip_direct.hip): conforming uniform-degree plans, deg_quad <= 7
+  void* hybrid = nullptr;  // HybridHost (d4est_hip_direct.hip): mixed-degree / locally refined plans -- clean elements through the direct kernels
 
   // ---- solver workspace / communication hooks (d4est_hip_solver.hip) ----
   double *d_work_p = nullptr, *d_work_d = nullptr, *d_work_r = nullptr, *d_reduce = nullptr, *d_ghost_trace = nullptr;
@@ -141,7 +142,7 @@ struct d4est_hip_plan {
   int stream_mode = 0;            // 1: non-temporal metric / factor loads and A u stores (capi: update_stream_mode; kernels: with_ld)
   bool bc_inhomogeneous = false;   // non-zero Dirichlet data or Robin data is set (an affine, not linear, operator)
 
-  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
+  int tuning[D4EST_HIP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1 = auto  // see d4est_hip_plan_set_tuning
 
   // generic-path scratch (allocated lazily)
   double* d_scratch = nullptr;
@@ -163,6 +164,8 @@ void faces_set_geometry_analytic(d4est_hip_plan* plan, const TreeMapParams& P, c
 // d4est_hip_volume.hip
 void launch_metric_precombine(d4est_hip_plan* plan, const double* d_J, const double* d_rst);
 void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
+void launch_stiffness_view(d4est_hip_plan* plan, const double* u, double* Au, int* ns_list_view, int* qs_list_view, const int* view_offset,
+                           const int* view_count);
 // mode: 0 mass, 1 galerkin, 2 interpolate / square tensor apply, 3 weighted mass, 4 inverse mass;
 // which: 0 quadrature interpolation, 1 inverse Gauss interpolation, 2 M (1-D mass), 3 M^-1
 void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* out, const double* coeff = nullptr, int which = 0);
@@ -221,7 +224,21 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
 // the same through the plan's face data (Robin arrays): vol_term = 0: Au += face terms of u; 1: Au = (volume + face terms) of u
 void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf = nullptr,
                         int vol_term = 0);
-void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf = nullptr);
+// elist / n_list: only these elements' face terms (the hybrid operator's dirty elements); the hanging-side record kernels keep their own list
+void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf = nullptr,
+                 const int* elist = nullptr, int n_list = 0);
+// the hybrid operator (d4est_hip_direct.hip): clean elements (all six sides conforming against a local element of the same degree, or
+// the boundary) through the one-kernel path of their degree bucket, the rest through the two-phase kernels on lists
+bool hybrid_pair_built(int N, int NQ);
+void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const std::vector<const double*>& C, const std::vector<const double*>& CD,
+                  const std::vector<const double*>& E);
+void hybrid_destroy(d4est_hip_plan* plan);
+bool hybrid_active(const d4est_hip_plan* plan);
+const char* hybrid_path(const d4est_hip_plan* plan);
+void hybrid_lists(const d4est_hip_plan* plan, const int** dirty, int* n_dirty, const int** ring, int* n_ring);
+void launch_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const double* robin_c, const double* robin_r);
+void launch_hybrid_dirty_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
+void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au);   // (faces.hip: supplies the Robin arrays)
 void faces_destroy(d4est_hip_plan* plan);
 
 // d4est_hip_solver.hip

@@ -154,6 +154,23 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
   if (has_ghost && !plan->exchange_fn) D4EST_HIP_ABORT("apply_lhs: plan has ghost sides but no exchange callback (plan_set_comm)");
   // measured: the two cross-stream event waits cost more than the overlap buys (config 2: 119 -> 129 us; 512 elements:
   // 16 -> 44 us), so the fork is opt-in (tuning value 1) and the default is one stream
+  if (hybrid_active(plan)) {
+    // mixed-degree / locally refined plan (d4est_hip_direct.hip, "the hybrid operator"): the clean elements' A u from the one-kernel path of
+    // their degree bucket, the dirty elements' from traces (dirty elements + their neighbours) + volume + flux on lists.  Disjoint
+    // rows, so the order of the launches is free; the small dirty-path kernels go first.
+    if (cf) D4EST_HIP_ABORT("apply_operator: the hybrid operator does not carry a fused update (flux_can_fuse_update is false for it)");
+    const int *dirty, *ring;
+    int n_dirty, n_ring;
+    hybrid_lists(plan, &dirty, &n_dirty, &ring, &n_ring);
+    if (n_dirty > 0) {
+      launch_traces(plan, u, plan->d_trace, false, ring, n_ring);
+      launch_hybrid_dirty_stiffness(plan, u, Au);
+      launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, nullptr, dirty, n_dirty);
+    }
+    launch_flux_hybrid_clean(plan, u, plan->d_ghost_trace, Au);
+    if (lhs_term) add_lhs_mass_term(plan, u, Au);
+    return;
+  }
   if (direct_active(plan)) {
     // one-kernel face terms (d4est_hip_direct.hip): both sides' traces come from u inside the kernel; with ghost sides the trace
     // kernel still runs, to feed the exchange

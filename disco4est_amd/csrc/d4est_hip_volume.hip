@@ -18,6 +18,7 @@
 // element is the algorithmic minimum: u once, the 6-entry symmetric metric once,
 // Au once (64 B/DoF at Nq = N).
 #include <algorithm>
+#include <cstring>
 
 #include "d4est_hip_internal.h"
 #include "d4est_hip_maps.h"
@@ -699,8 +700,8 @@ __global__ __launch_bounds__(64, 4) void stiffness_wave_eo_multi_kernel(const do
 #undef D4EST_CASE
 }
 
-// Mixed-degree plans, p = 8 ... 12: the buckets whose multi-wave kernels have the same workgroup size (N = 9, 10: 128 threads; N = 11,
-// 12, 13: 192) in ONE launch, like stiffness_wave_eo_multi_kernel for p <= 7 -- a workgroup looks its bucket up and runs that degree's
+// Mixed-degree plans, p = 8 ... 12: the buckets whose multi-wave kernels have the same workgroup size (N = 9, 10, 11: 128 threads -- N = 11
+// is 121 lines --; N = 12, 13: 192) in ONE launch, like stiffness_wave_eo_multi_kernel for p <= 7 -- a workgroup looks its bucket up and runs that degree's
 // body (stiffness_wave_kernel's: collocated-gradient form, streamed metric).  Small buckets (585 elements each on the p = 3 ... 9 mesh of
 // the bench) no longer queue behind each other: 13 + 15 us -> one launch.  WaveEoMulti: EGb / EGf carry the tables of Dq / Dq^T.
 template <int N, bool NT>
@@ -1748,6 +1749,35 @@ void launch_mass_like(d4est_hip_plan* plan, int mode, const double* in, double* 
   else if (mode == 3) launch_mass_like_mode<3>(plan, in, out, coeff, which);
   else if (mode == 4) launch_mass_like_mode<4>(plan, in, out, coeff, which);
   else D4EST_HIP_ABORT("launch_mass_like: bad mode %d", mode);
+}
+
+// The volume term on a sub-list of every bucket (the hybrid operator's dirty elements, d4est_hip_direct.hip): the bucket-ordered lists and
+// counts are swapped for the view's while launch_stiffness runs.  Offsets come from the lists (no affine strides), the metric is
+// streamed (the per-bucket affine constants are indexed by bucket position).
+void launch_stiffness_view(d4est_hip_plan* plan, const double* u, double* Au, int* ns_list_view, int* qs_list_view, const int* view_offset,
+                           const int* view_count) {
+  struct Saved { int elem_offset, n_elem, ns_stride, qs_stride; bool affine; };
+  std::vector<Saved> saved(plan->buckets.size());
+  int* ns_saved = plan->d_ns_list;
+  int* qs_saved = plan->d_qs_list;
+  for (size_t i = 0; i < plan->buckets.size(); ++i) {
+    Bucket& bk = plan->buckets[i];
+    saved[i] = Saved{bk.elem_offset, bk.n_elem, bk.ns_stride, bk.qs_stride, bk.affine};
+    bk.elem_offset = view_offset[i]; bk.n_elem = view_count[i]; bk.ns_stride = -1; bk.qs_stride = -1; bk.affine = false;
+  }
+  plan->d_ns_list = ns_list_view;
+  plan->d_qs_list = qs_list_view;
+  char kept[sizeof(plan->last_kernel)];
+  std::memcpy(kept, plan->last_kernel, sizeof(kept));
+  launch_stiffness(plan, u, Au);
+  std::memcpy(plan->last_kernel, kept, sizeof(kept));
+  plan->d_ns_list = ns_saved;
+  plan->d_qs_list = qs_saved;
+  for (size_t i = 0; i < plan->buckets.size(); ++i) {
+    Bucket& bk = plan->buckets[i];
+    bk.elem_offset = saved[i].elem_offset; bk.n_elem = saved[i].n_elem; bk.ns_stride = saved[i].ns_stride; bk.qs_stride = saved[i].qs_stride;
+    bk.affine = saved[i].affine;
+  }
 }
 
 void launch_dudr(d4est_hip_plan* plan, const double* u, double* d0, double* d1, double* d2) {
