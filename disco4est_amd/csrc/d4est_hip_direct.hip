@@ -785,6 +785,12 @@ struct HybridHost {
   int *d_ns_dirty = nullptr, *d_qs_dirty = nullptr;   // bucket-ordered lists of the dirty elements (the volume kernels' view)
   std::vector<int> dirty_off, dirty_cnt;
   char path[96] = "";
+  // the clean buckets' launches are short, latency-structured kernels (one wavefront / workgroup per element, a few hundred elements
+  // each): back to back on one stream they cost their serial chains one after another (p = 3 ... 9 graded: 7 launches, 175 us), so each
+  // bucket gets its own stream, forked from and joined to the plan's stream by events, beside the dirty path on the plan's stream
+  std::vector<hipStream_t> side;
+  std::vector<hipEvent_t> done;
+  hipEvent_t fork = nullptr;
 };
 static HybridHost* hybrid_of(const d4est_hip_plan* plan) { return static_cast<HybridHost*>(plan->hybrid); }
 
@@ -794,6 +800,9 @@ void hybrid_destroy(d4est_hip_plan* plan) {
   for (DirectHost* d : hh->dh)
     if (d) { (void)hipFree(d->d_ops); delete d; }
   for (int* p : hh->d_clean) (void)hipFree(p);
+  for (hipStream_t st : hh->side) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : hh->done) (void)hipEventDestroy(ev);
+  if (hh->fork) (void)hipEventDestroy(hh->fork);
   (void)hipFree(hh->d_sides); (void)hipFree(hh->d_ghost_off); (void)hipFree(hh->d_qs_by_elem); (void)hipFree(hh->d_dirty); (void)hipFree(hh->d_ring);
   (void)hipFree(hh->d_ns_dirty); (void)hipFree(hh->d_qs_dirty);
   delete hh;
@@ -920,11 +929,47 @@ void hybrid_lists(const d4est_hip_plan* plan, const int** dirty, int* n_dirty, c
   *dirty = hh->d_dirty; *n_dirty = hh->n_dirty; *ring = hh->d_ring; *n_ring = hh->n_ring;
 }
 
-// the clean elements: one whole-operator launch per degree bucket (u in, A u out)
-void launch_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const double* robin_c, const double* robin_r) {
+// the clean elements: one whole-operator launch per degree bucket (u in, A u out), every bucket on its own stream between a fork event
+// on the plan's stream (phase 0, before the dirty path is queued there) and the join (phase 1, after it)
+void launch_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const double* robin_c, const double* robin_r,
+                         int phase) {
   HybridHost* hh = hybrid_of(plan);
-  for (size_t b = 0; b < hh->dh.size(); ++b)
-    if (hh->dh[b]) launch_direct_core(plan, hh->dh[b], plan->buckets[b], true, hh->d_qs_by_elem, u, ghost_trace, Au, nullptr, robin_c, robin_r, 1);
+  static const bool serial = std::getenv("D4EST_HIP_HYBRID_SERIAL") != nullptr;
+  int n_launch = 0;
+  for (DirectHost* d : hh->dh) n_launch += d != nullptr;
+  const bool forked = !serial && n_launch > 1;
+  if (!forked) {   // one bucket: nothing to overlap
+    if (phase == 0) return;
+    for (size_t b = 0; b < hh->dh.size(); ++b)
+      if (hh->dh[b]) launch_direct_core(plan, hh->dh[b], plan->buckets[b], true, hh->d_qs_by_elem, u, ghost_trace, Au, nullptr, robin_c, robin_r, 1);
+    return;
+  }
+  hipStream_t main = plan->stream;
+  if (phase == 0) {
+    if (!hh->fork) {
+      HIP_CHECK(hipEventCreateWithFlags(&hh->fork, hipEventDisableTiming));
+      for (int i = 0; i < n_launch; ++i) {
+        hipStream_t st; hipEvent_t ev;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hh->side.push_back(st); hh->done.push_back(ev);
+      }
+    }
+    if (plan->d_lhs_coeff == nullptr) {}   // (the zeroth-order term is added after the join, on the plan's stream)
+    HIP_CHECK(hipEventRecord(hh->fork, main));
+    int i = 0;
+    for (size_t b = 0; b < hh->dh.size(); ++b) {
+      if (!hh->dh[b]) continue;
+      HIP_CHECK(hipStreamWaitEvent(hh->side[i], hh->fork, 0));
+      plan->stream = hh->side[i];
+      launch_direct_core(plan, hh->dh[b], plan->buckets[b], true, hh->d_qs_by_elem, u, ghost_trace, Au, nullptr, robin_c, robin_r, 1);
+      plan->stream = main;
+      HIP_CHECK(hipEventRecord(hh->done[i], hh->side[i]));
+      ++i;
+    }
+    return;
+  }
+  for (int i = 0; i < n_launch; ++i) HIP_CHECK(hipStreamWaitEvent(main, hh->done[i], 0));
 }
 // the dirty elements' volume term
 void launch_hybrid_dirty_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {

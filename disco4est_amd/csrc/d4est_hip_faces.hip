@@ -2865,9 +2865,9 @@ void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* gho
   launch_direct_faces(plan, u, ghost_trace, Au, cf, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, vol_term);
 }
 
-void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au) {
+void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, int phase) {
   FaceHost& fh = g_face_host[plan];
-  launch_hybrid_clean(plan, u, ghost_trace, Au, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr);
+  launch_hybrid_clean(plan, u, ghost_trace, Au, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, phase);
 }
 
 void faces_destroy(d4est_hip_plan* plan) {

@@ -236,9 +236,10 @@ void hybrid_destroy(d4est_hip_plan* plan);
 bool hybrid_active(const d4est_hip_plan* plan);
 const char* hybrid_path(const d4est_hip_plan* plan);
 void hybrid_lists(const d4est_hip_plan* plan, const int** dirty, int* n_dirty, const int** ring, int* n_ring);
-void launch_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const double* robin_c, const double* robin_r);
+void launch_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const double* robin_c, const double* robin_r,
+                         int phase);
 void launch_hybrid_dirty_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
-void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au);   // (faces.hip: supplies the Robin arrays)
+void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, int phase);   // (faces.hip: supplies the Robin arrays; phase 0 fork + launches, 1 join)
 void faces_destroy(d4est_hip_plan* plan);
 
 // d4est_hip_solver.hip

@@ -162,12 +162,13 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
     const int *dirty, *ring;
     int n_dirty, n_ring;
     hybrid_lists(plan, &dirty, &n_dirty, &ring, &n_ring);
-    if (n_dirty > 0) {
+    launch_flux_hybrid_clean(plan, u, plan->d_ghost_trace, Au, 0);   // the clean buckets, each on its own stream beside ...
+    if (n_dirty > 0) {                                                // ... the dirty path on the plan's stream
       launch_traces(plan, u, plan->d_trace, false, ring, n_ring);
       launch_hybrid_dirty_stiffness(plan, u, Au);
       launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, nullptr, dirty, n_dirty);
     }
-    launch_flux_hybrid_clean(plan, u, plan->d_ghost_trace, Au);
+    launch_flux_hybrid_clean(plan, u, plan->d_ghost_trace, Au, 1);   // join
     if (lhs_term) add_lhs_mass_term(plan, u, Au);
     return;
   }

@@ -1,0 +1,37 @@
+"""The hybrid operator against the all-two-phase form on config 4's mesh class: tools/time_hybrid.py <mesh>
+  graded   : level-4 brick, p = 3 ... 9 graded smoothly (bench.graded_degrees)
+  plateau  : level-4 brick, p = 3, 5, 7, 9 in slabs four elements thick
+  hanging  : level-4 brick, every 64th octant refined, p = 7
+  combined : hanging + plateau degrees"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from disco4est_amd import Plan, mesh as M
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+kind = sys.argv[1]
+dev = torch.device("cuda:0"); st = torch.cuda.current_stream()
+ijk = M.morton_order(4)
+plateau = np.asarray([3, 5, 7, 9], np.int32)[(ijk[:, 0] * 4) // 16]
+refine = np.zeros(4096, dtype=bool); refine[::64] = True
+if kind == "graded": m = M.BrickMesh(4, bench.graded_degrees(4))
+elif kind == "plateau": m = M.BrickMesh(4, plateau)
+elif kind == "hanging": m = M.HangingBrickMesh(4, refine, 7)
+else: m = M.HangingBrickMesh(4, refine, np.concatenate([np.full(8 if refine[b] else 1, plateau[b]) for b in range(4096)]).astype(np.int32))
+J, rst = m.geometry(None); sides = m.build_sides(None)
+x = torch.from_numpy(m.field()).to(dev); y = torch.empty_like(x)
+by = bench.mixed_operator_bytes(m, sides)
+out = {}
+for hyb in (0, -1):
+    p = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=st)
+    p.set_tuning(14, hyb); p.set_geometry(J, rst); p.set_tuning(7, 0); p.set_faces(sides)
+    ms = bench.time_region(lambda: p.apply_aij(x, y), 50, st, torch, warm=10)
+    out[hyb] = (ms, y.clone(), p.face_path())
+    p.destroy()
+err = float((out[0][1] - out[-1][1]).abs().max() / out[0][1].abs().max())
+for hyb in (0, -1):
+    ms = out[hyb][0]
+    print("%-9s %4d elements %.2f MDoF  [%s]: apply_aij %.1f us = %.1f GDoF/s, %.2f of the HBM roof (%.0f B/DoF)" %
+          (kind, m.n_elements, m.local_nodes * 1e-6, out[hyb][2], ms * 1e3, m.local_nodes / ms * 1e-6, by / (ms * 1e-3) / 8e12, by / m.local_nodes))
+print("  hybrid vs two-phase rel-inf %.2e" % err)
