@@ -2288,7 +2288,18 @@ void faces_setup(d4est_hip_plan* plan) {
       clean[e] = ok;
       n_clean += ok;
     }
-    if (n_clean > 0 && (plan->tuning[D4EST_HIP_TUNE_HYBRID] > 0 || 4 * (size_t)n_clean >= (size_t)ne)) {
+    // default: only where it was measured to pay -- ONE clean degree bucket holding at least half of the elements (a locally refined mesh of
+    // one degree: level 4, p = 7, every 64th octant refined 144 -> 125 us).  With several clean buckets every bucket is its own launch of
+    // a latency-structured kernel (25 - 40 us for a few hundred elements each, whatever their number): back to back they cost more than
+    // the two-phase kernels save, and on side streams the cross-queue event waits (about 50 us per fork / join on this runtime) eat the
+    // overlap (graded p = 3 ... 9, 4096 elements: 144 us two-phase, 275 us serial, 250 us forked) -- tuning value 1 still forces it
+    int clean_buckets = 0;
+    {
+      std::vector<char> seen(plan->buckets.size(), 0);
+      for (int e = 0; e < ne; ++e)
+        if (clean[e] && !seen[bucket_of[e]]) { seen[bucket_of[e]] = 1; ++clean_buckets; }
+    }
+    if (n_clean > 0 && (plan->tuning[D4EST_HIP_TUNE_HYBRID] > 0 || (clean_buckets == 1 && 2 * (size_t)n_clean >= (size_t)ne))) {
       std::vector<int> oC(plan->buckets.size(), -1), oCD(plan->buckets.size(), -1), oE(plan->buckets.size(), -1);
       for (size_t b = 0; b < plan->buckets.size(); ++b) {
         if (!bucket_ok[b]) continue;

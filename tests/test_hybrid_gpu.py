@@ -142,9 +142,11 @@ def test_hybrid_robin_boundary(gpu, hiplib, oracle):
     plan.destroy()
 
 
-def test_config4_mesh_class_at_size(gpu, hiplib, oracle):
+@pytest.mark.parametrize("hybrid", [1, -1])
+def test_config4_mesh_class_at_size(gpu, hiplib, oracle, hybrid):
     """At size: the level-4 brick with every 64th octant refined (hanging faces) AND degrees p = 3, 5, 7, 9 in plateaus four elements thick (mixed-degree sides
-    between them), 4544 elements, on the default path (the hybrid operator: asserted): the oracle on 71-element shards with ghost
+    between them), 4544 elements, on the hybrid operator (forced: tuning 1) and on the default path (two-phase here: several clean
+    degree buckets): the oracle on 71-element shards with ghost
     elements, A(x^2 + y^2 + z^2) = M(-6) with exact Dirichlet data, symmetry, positivity, determinism"""
     import torch
     from disco4est_amd import Plan, mesh as M
@@ -155,6 +157,7 @@ def test_config4_mesh_class_at_size(gpu, hiplib, oracle):
     m = mk()
     J, rst = m.geometry(None); sides = m.build_sides(None)
     plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan.set_tuning(14, hybrid)
     plan.set_geometry(J, rst)
     plan.set_faces(sides, 10.0, 0)
     path = plan.face_path()
@@ -185,5 +188,30 @@ def test_config4_mesh_class_at_size(gpu, hiplib, oracle):
     s1, s2 = torch.dot(b, Aa).item(), torch.dot(a, Ab).item()
     assert abs(s1 - s2) <= 1e-11 * max(abs(s1), abs(s2))
     assert torch.dot(a, Aa).item() > 0
-    assert path.startswith("hybrid"), path
+    assert path.startswith("hybrid") == (hybrid == 1), path
+    plan.destroy()
+
+
+def test_default_path_on_a_one_degree_refined_mesh_is_hybrid(gpu, hiplib, oracle):
+    """the bench's hanging_level4_p7 mesh class: one degree, local refinement -- the default is the hybrid operator (one clean bucket)"""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    refine = np.zeros(512, dtype=bool); refine[::32] = True
+    m = M.HangingBrickMesh(3, refine, 7)
+    J, rst = m.geometry(None); sides = m.build_sides(None)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan.set_geometry(J, rst)
+    plan.set_faces(sides, 10.0, 0)
+    assert plan.face_path().startswith("hybrid"), plan.face_path()
+    u = m.field(None)
+    du = _t(u, gpu); Au = torch.empty_like(du)
+    plan.apply_aij(du, Au)
+    got = Au.cpu().numpy()
+    n = m.n_elements
+    for first in (0, n - 64):
+        sub = M.HangingBrickMesh(3, refine, 7, first=first, count=64)
+        Js, rsts = sub.geometry(None); ss = sub.build_sides(None)
+        s0 = sub.global_nodal_offset
+        ref = oracle.apply_aij(sub, Js, rsts, ss, np.ascontiguousarray(u[s0:s0 + sub.local_nodes]), u_ghost=sub.gather_ghost(ss, u), nthreads=8)
+        assert _rel(got[s0:s0 + sub.local_nodes], ref) <= RTOL
     plan.destroy()
