@@ -1676,6 +1676,7 @@ struct FaceHost {
   double* d_robin_c = nullptr;  // sj * coeff, sj * rhs at the mortar nodes of the boundary sides
   double* d_robin_r = nullptr;
   bool robin = false;
+  bool dirichlet_nonzero = false;   // non-zero Dirichlet data sits in d_bndry (it survives a Robin on / off cycle)
   std::vector<int> side_deg_m, side_deg_p;
   int* d_side_deg_m = nullptr;
   int* d_side_deg_p = nullptr;
@@ -2363,7 +2364,8 @@ void faces_set_geometry(d4est_hip_plan* plan, const double* sj, const double* n,
 void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_device) {
   FaceHost& fh = g_face_host[plan];
   const size_t tm = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
-  plan->bc_inhomogeneous = (g_lobatto != nullptr) || fh.robin;
+  fh.dirichlet_nonzero = (g_lobatto != nullptr);
+  plan->bc_inhomogeneous = fh.dirichlet_nonzero || fh.robin;
   if (!g_lobatto) {
     HIP_CHECK(hipMemsetAsync(plan->d_bndry, 0, tm * sizeof(double), plan->stream));
     return;
@@ -2645,7 +2647,7 @@ void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const doubl
   if (!plan->has_face_geometry) D4EST_HIP_ABORT("plan_set_robin_values: call d4est_hip_plan_set_mortar_geometry first (needs sj)");
   if (!coeff_quad) {
     fh.robin = false;
-    plan->bc_inhomogeneous = false;   // (back to Dirichlet; plan_set_dirichlet_values decides from here on)
+    plan->bc_inhomogeneous = fh.dirichlet_nonzero;   // back to Dirichlet: the values set earlier are still in d_bndry
     return;
   }
   if (!rhs_quad) D4EST_HIP_ABORT("plan_set_robin_values: rhs_quad is NULL");

@@ -411,6 +411,7 @@ static void operator_level(int p) {
       check("apply_aij with matching flux data", p, Au, ref, ln, 1e-12);
       if (flux_mismatch) {   /* ... and one that does not is refused (the caller of this mode expects the abort) */
         sipg_params[0] = 20.0;
+        fflush(stdout);
         d4est_laplacian_apply_aij(p4est, NULL, NULL, &vecs, &fd, NULL, NULL, NULL, NULL, 0);
         printf("NOT ABORTED\n");
       }

@@ -83,3 +83,36 @@ def test_newton_on_cubic_reaction_diffusion(gpu, hiplib, oracle):
     assert len(hist) <= 7 and hist[2] < 0.05 * hist[1]                    # Newton, not a crawl
     err = float((u - T(u_star)).abs().max())
     assert err < 2e-3, err                                                 # p = 4 on 8 elements
+
+
+@pytest.mark.parametrize("deg,level,direct", [(7, 2, 2), (3, 1, 0), (9, 1, 2)])
+def test_lhs_term_follows_a_later_change_of_the_jacobian(gpu, hiplib, deg, level, direct):
+    """The fused operator kernels read w J c pre-combined at plan_set_lhs_coefficient; d4est_hip_plan_set_jacobian overwrites J afterwards
+    (advisor, round 3): the cached stream must be rebuilt, so that apply_lhs = apply_aij + the weighted mass term with the NEW J on the
+    whole-operator path (direct = 2) exactly as on the separate-kernel path (direct = 0)"""
+    import ctypes
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    m = M.BrickMesh(level, deg)
+    mp = M.SineMap(0.03)
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0)
+    plan.set_tuning(11, direct)
+    plan.set_geometry(J, rst)
+    plan.set_faces(sides, 10.0, 0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    c = T(0.5 + M.splitmix64_uniform(1, m.local_nodes_quad))
+    u = T(m.field(mp))
+    plan.set_lhs_coefficient(c)
+    a0 = torch.empty_like(u)
+    plan.apply_lhs(u, a0)                      # builds w J c with the first J
+    J2 = T(J * (1.0 + 0.5 * M.splitmix64_uniform(2, m.local_nodes_quad)))
+    plan.lib.d4est_hip_plan_set_jacobian(plan.handle, ctypes.c_void_p(J2.data_ptr()), 1)
+    a1, lap, wm = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+    plan.apply_lhs(u, a1)
+    plan.apply_aij(u, lap)
+    plan.apply_weighted_mass_matrix(u, c, wm)   # reads the plan's (new) J
+    ref = lap + wm
+    assert float((a1 - ref).abs().max()) <= 1e-12 * float(ref.abs().max())
+    assert float((a1 - a0).abs().max()) > 1e-6 * float(ref.abs().max())     # the change of J is visible in the term
+    plan.destroy()
