@@ -839,6 +839,49 @@ def main():
                                             "face_path": res5[-1][2],
                                             "parity_gate_rel_inf": g5o, "parity_gate_rel_inf_vs_record_kernels": g5}
                 del x5, res5
+            # BASELINE config 4's mesh class proper: hanging faces AND mixed degrees, smoothly graded -- the level-4 brick with every 64th octant
+            # refined and p = 3 ... 9 rising with the distance from a corner (4544 elements); the full operator and a Chebyshev iteration on it,
+            # algorithmic bytes, oracle shard gate.  Also the graded mesh without the refinement (the mesh of profiles/r04_mixed_p_graded_*).
+            def sec_config4():
+                refine = np.zeros(8 ** 4, dtype=bool)
+                refine[::64] = True
+                gd = graded_degrees(4)
+                for name, mk in (("mixed_p3_to_9_graded_level4", lambda **kw: M.BrickMesh(4, gd, **kw)),
+                                 ("config4_mesh_class_level4", lambda **kw: M.HangingBrickMesh(4, refine, np.concatenate([np.full(8 if refine[b] else 1, gd[b]) for b in range(8 ** 4)]).astype(np.int32), **kw))):
+                    m7 = mk()
+                    J7, rst7 = m7.geometry(None); s7 = m7.build_sides(None)
+                    p7 = Plan(m7.deg, m7.deg_quad, m7.nodal_stride, m7.quad_stride, 0, stream=stream)
+                    p7.set_geometry(J7, rst7); p7.set_tuning(7, 0); p7.set_faces(s7)
+                    x7 = torch.from_numpy(m7.field()).to(dev); y7 = torch.empty_like(x7)
+                    cnt7 = 64 if name.startswith("mixed") else 71
+                    try:
+                        g7 = None if args.no_check else gate_operator(name, p7, 4, None, x7, y7, shards=3, n_total=m7.n_elements, cnt=cnt7,
+                                                                      factory=lambda first, cnt: mk(first=first, count=cnt))
+                    except Exception as exc:
+                        log("parity gate %s FAILED: %r" % (name, exc))
+                        g7 = "FAILED: " + repr(exc)
+                    ms_a = time_region(lambda: p7.apply_aij(x7, y7), 50, stream, torch, warm=10)
+                    l0, l1 = eig_window(p7, x7, torch)
+                    rhs7 = torch.zeros_like(x7); r7 = torch.empty_like(x7)
+                    gc7 = None if args.no_check else gate_cheby(name + " cheby", p7, x7, rhs7, torch, 5, l0, l1)
+                    ms_c = time_region(lambda: p7.cheby_iterate(x7, rhs7, y7, r7, 5, l0, l1, 0), 20, stream, torch, warm=5)
+                    by7 = mixed_operator_bytes(m7, s7)
+                    sec[name] = {"dofs": m7.local_nodes, "elements": m7.n_elements, "degrees": "p = 3 ... 9 graded (neighbours differ by at most one)",
+                                 "hanging_faces": int((np.asarray(s7["side_hang"]) == 1).sum()) if "side_hang" in s7 else 0,
+                                 "apply_aij_ms": ms_a, "apply_aij_GDoF_per_s": m7.local_nodes / (ms_a * 1e-3) / 1e9,
+                                 "algorithmic_bytes_per_dof": by7 / m7.local_nodes, "roofline_frac_hbm": by7 / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "cheby_5_iterations_ms": ms_c, "cheby_GDoF_per_s": 5 * m7.local_nodes / (ms_c * 1e-3) / 1e9,
+                                 "cheby_roofline_frac_hbm": 5 * (by7 + CHEBY_VECTOR_BYTES_PER_DOF * m7.local_nodes) / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": (json.load(open(tf)) if os.path.exists(tf) else {}).get(name, {}).get("hbm_bytes_per_launch"),
+                                 "face_path": p7.face_path(), "parity_gate_rel_inf": g7, "parity_gate_cheby_rel_inf": gc7}
+                    p7.destroy()
+                    del x7, y7, rhs7, r7
+            if args.geometry != "sine":
+                try:
+                    sec_config4()
+                except Exception as exc:
+                    log("secondary config4_mesh_class_level4 failed: %r" % (exc,))
+                    sec["config4_mesh_class_level4"] = {"error": repr(exc)}
             # BASELINE config 5's mesh class AT SIZE: the reference's 7-tree cubed sphere, level 3 (3584 curved elements, 14.7 MDoF), p = 15, every
             # geometric factor (volume metric and mortar factors through the oriented tree faces) generated on the device from the analytic
             # map; side list from d4est_hip_build_sides.  Gate: the oracle on shards of 4 elements with host-computed factors.

@@ -32,6 +32,7 @@ struct LhsChain {
   std::vector<d4est_hip_transfer*> t;   // t[0]: this plan's level <-> the next finer one, ..., t.back(): <-> the fine plan's level
   d4est_hip_plan* fine = nullptr;
   std::vector<double*> x, y;            // per finer level: the prolonged vector and the term on its way back
+  bool fused = false;                   // one transfer, every item within the compile-time sizes: galerkin_fast_kernel (d4est_hip_transfer.hip)
 };
 
 // ---- (1) Au_e += M_e u_e --------------------------------------------------------------------------------------------------------
@@ -92,6 +93,15 @@ void add_lhs_blocks_term(d4est_hip_plan* plan, const double* u, double* Au) {
 // ---- (2) the Galerkin chain -----------------------------------------------------------------------------------------------------
 static LhsChain* chain_of(d4est_hip_plan* plan) { return static_cast<LhsChain*>(plan->lhs_chain); }
 
+// the fine plan's w J c, (re)built on the given stream if its inputs changed
+static const double* ensure_lhs_wjc_on(d4est_hip_plan* fine, hipStream_t st) {
+  hipStream_t saved = fine->stream;
+  fine->stream = st;
+  const double* w = ensure_lhs_wjc(fine);
+  fine->stream = saved;
+  return w;
+}
+
 void lhs_chain_destroy(d4est_hip_plan* plan) {
   LhsChain* ch = chain_of(plan);
   if (!ch) return;
@@ -111,6 +121,10 @@ void add_lhs_chain_term(d4est_hip_plan* plan, const double* u, double* Au) {
   d4est_hip_plan* fine = ch->fine;
   if (!fine->d_lhs_coeff) D4EST_HIP_ABORT("Galerkin chain: the fine plan has no coefficient (d4est_hip_plan_set_lhs_coefficient on the fine plan)");
   const int k = (int)ch->t.size();
+  if (ch->fused) {   // prolong, interpolate, weigh, and back in ONE kernel: only the fine level's w J c is streamed
+    galerkin_fused_apply(ch->t[0], ensure_lhs_wjc_on(fine, plan->stream), u, Au, plan->stream);
+    return;
+  }
   // everything runs on THIS plan's stream (the transfer objects and the fine plan may have been given other streams by their owner)
   hipStream_t st = plan->stream;
   std::vector<hipStream_t> saved(k);
@@ -462,6 +476,8 @@ void d4est_hip_plan_set_lhs_galerkin_chain(d4est_hip_plan_t* plan, int n_transfe
   if (expect != fine_plan->local_nodes)
     D4EST_HIP_ABORT("plan_set_lhs_galerkin_chain: the last transfer ends at %lld nodes, the fine plan has %d", expect, fine_plan->local_nodes);
   if (!plan->d_work_m) HIP_CHECK(hipMalloc(&plan->d_work_m, std::max<size_t>((size_t)plan->local_nodes, 1) * sizeof(double)));
+  const bool no_fused = std::getenv("D4EST_HIP_CHAIN_UNFUSED") != nullptr;   // (read at every call: the tests switch it)
+  ch->fused = !no_fused && n_transfers == 1 && galerkin_fused_setup(ch->t[0], fine_plan);
   plan->lhs_chain = ch;
 }
 

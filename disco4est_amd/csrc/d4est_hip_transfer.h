@@ -18,6 +18,16 @@ struct d4est_hip_transfer {
   struct List { int NH, dmax, first, n, nc; };   // nc: children per coarse element of a restriction list (1 or 8)
   std::vector<List> prolong_lists, restrict_lists;
   int* d_lists = nullptr;
+  // fused Galerkin term (galerkin_fused_*, d4est_hip_transfer.hip): coarse u -> [prolong, interpolate to the fine quadrature nodes] as ONE
+  // composite 1-D operator per direction, times w J c of the fine level, and back -- the multigrid matrix operator's coarse term in one
+  // kernel that streams only the fine coefficient.  Built for one fine plan at a time (gal_fine).
+  const void* gal_fine = nullptr;
+  double* d_gal_T = nullptr;     // composite operators T = B P (NQ x NH) ...
+  double* d_gal_TT = nullptr;    // ... and their transposes (NH x NQ), same offsets
+  int* d_gal_child = nullptr;    // per (item, child): {NQ, off_x, off_y, off_z}
+  int* d_gal_qs = nullptr;       // per (item, child): offset of the fine element's quadrature block
+  int* d_gal_lists = nullptr;
+  std::vector<List> gal_lists;   // coarse elements by (NH, largest NQ - NH, children)
   hipStream_t stream = nullptr;
   // multigrid matrix operator (d4est_hip_mgmatrix.hip): where every child's / item's dense block sits (doubles), and the workspace of
   // the triple product  sum_c P_c^T M_c P_c  (T_c = M_c P_c, allocated on first use)
@@ -62,5 +72,9 @@ __device__ inline void tensor3(const double* __restrict__ Ax, const double* __re
   }
   __syncthreads();
 }
+
+// the multigrid matrix operator's coarse term in one kernel (one transfer between the plan's level and the fine plan's)
+bool galerkin_fused_setup(d4est_hip_transfer* t, d4est_hip_plan* fine);
+void galerkin_fused_apply(d4est_hip_transfer* t, const double* wjc, const double* u, double* Au, hipStream_t st);
 
 }  // namespace d4est_hip

@@ -252,6 +252,139 @@ __global__ __launch_bounds__((TransferCfg<NH, DMAX>::THREADS * TransferCfg<NH, D
   }
 }
 
+// ---- the fused Galerkin term: Au_H += sum_c (B_c P_c)^T (w J c)_c (B_c P_c) u_H per coarse element, the coarse-level zeroth-order term of
+// the multigrid matrix operator (d4est_hip_mgmatrix.hip) without a fine-level vector: the prolongation to child c and the interpolation to
+// its quadrature nodes are ONE composite operator T = B P per direction (NQ x NH, built on the host), so a child costs three passes up,
+// the pointwise product with the fine level's w J c (the only stream: 8 B per fine quadrature node, coalesced over the (x, y) plane),
+// three passes down; the children's contributions are summed in registers (child groups as in restrict_fast_kernel).
+template <int NH, int DMAX>
+struct GalerkinCfg {
+  static constexpr int NQM = NH + DMAX;
+  static constexpr int THREADS = ((NQM * NQM + 63) / 64) * 64;
+  static constexpr int LDS = NH * NH * (NQM | 1) + NH * NQM * NQM;
+  static constexpr int cg_max() {
+    int cg = 8;
+    while (cg > 1 && ((long long)cg * LDS * 8 > 150 * 1024 || cg * THREADS > 1024)) cg >>= 1;
+    return cg;
+  }
+  static constexpr int CGMAX = cg_max();
+};
+
+template <int NH, int NQ>
+__device__ __forceinline__ void galerkin_body(const double* __restrict__ u_e, const double* __restrict__ wjc, const double* TTx, const double* TTy,
+                                              const double* TTz, const double* Tx, const double* Ty, const double* Tz, double* lds,
+                                              double (&acc)[NH], int t) {
+  constexpr int RSB = NQ | 1;
+  double* B = lds;                    // [NH][NH][NQ | 1]
+  double* C = B + NH * NH * RSB;      // [NH][NQ][NQ]
+  if (t < NH * NH) {                  // up, x: the coarse element's x-lines straight from memory
+    double x[NH], y[NQ];
+#pragma unroll
+    for (int a = 0; a < NH; ++a) x[a] = u_e[t * NH + a];
+    contract_n<NH, NQ>(TTx, x, y);
+#pragma unroll
+    for (int a = 0; a < NQ; ++a) B[t * RSB + a] = y[a];
+  }
+  __syncthreads();
+  if (t < NQ * NH) {                  // up, y
+    const int aq = t % NQ, k = t / NQ;
+    double x[NH], y[NQ];
+#pragma unroll
+    for (int b = 0; b < NH; ++b) x[b] = B[(k * NH + b) * RSB + aq];
+    contract_n<NH, NQ>(TTy, x, y);
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) C[(k * NQ + b) * NQ + aq] = y[b];
+  }
+  __syncthreads();
+  double w[NQ];
+  if (t < NQ * NQ) {                  // up, z; then the coefficient at the thread's quadrature column
+    double x[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) x[k] = C[k * NQ * NQ + t];
+    contract_n<NH, NQ>(TTz, x, w);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) w[k] *= __builtin_nontemporal_load(wjc + k * NQ * NQ + t);
+  }
+  __syncthreads();
+  if (t < NQ * NQ) {                  // down, z
+    double y[NH];
+    contract_n<NQ, NH>(Tz, w, y);
+#pragma unroll
+    for (int k = 0; k < NH; ++k) C[k * NQ * NQ + t] = y[k];
+  }
+  __syncthreads();
+  if (t < NQ * NH) {                  // down, y
+    const int aq = t % NQ, k = t / NQ;
+    double x[NQ], y[NH];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) x[b] = C[k * NQ * NQ + b * NQ + aq];
+    contract_n<NQ, NH>(Ty, x, y);
+#pragma unroll
+    for (int b = 0; b < NH; ++b) B[(k * NH + b) * RSB + aq] = y[b];
+  }
+  __syncthreads();
+  if (t < NH * NH) {                  // down, x: into the thread's x-line of the coarse element
+    double x[NQ], y[NH];
+#pragma unroll
+    for (int a = 0; a < NQ; ++a) x[a] = B[t * RSB + a];
+    contract_n<NQ, NH>(Tx, x, y);
+#pragma unroll
+    for (int a = 0; a < NH; ++a) acc[a] += y[a];
+  }
+}
+
+template <int NH, int DMAX>
+__global__ __launch_bounds__((GalerkinCfg<NH, DMAX>::THREADS * GalerkinCfg<NH, DMAX>::CGMAX)) void galerkin_fast_kernel(
+    const double* __restrict__ u, double* __restrict__ Au, const double* __restrict__ wjc, const int* __restrict__ child,
+    const long long* __restrict__ off, const int* __restrict__ item_first, const int* __restrict__ gchild, const int* __restrict__ gqs,
+    const double* __restrict__ T, const double* __restrict__ TT, const int* __restrict__ list, int CG) {
+  using Cfg = GalerkinCfg<NH, DMAX>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int it = list[blockIdx.x];
+  const int c0 = item_first[it], c1 = item_first[it + 1];
+  const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / Cfg::THREADS)), t = threadIdx.x % Cfg::THREADS;
+  double* lds = smem + (size_t)g * Cfg::LDS;
+  const double* u_e = u + off[2 * c0];
+  double acc[NH];
+#pragma unroll
+  for (int a = 0; a < NH; ++a) acc[a] = 0.0;
+  for (int c = c0 + g; c - g < c1; c += CG) {
+    if (c < c1) {
+      const int* d = gchild + 4 * c;
+      const int dQ = d[0] - NH;
+      const double* wj = wjc + gqs[c];
+      const double *ttx = TT + d[1], *tty = TT + d[2], *ttz = TT + d[3], *tx = T + d[1], *ty = T + d[2], *tz = T + d[3];
+      if (dQ == 0) galerkin_body<NH, NH>(u_e, wj, ttx, tty, ttz, tx, ty, tz, lds, acc, t);
+      if constexpr (DMAX >= 1) { if (dQ == 1) galerkin_body<NH, NH + 1>(u_e, wj, ttx, tty, ttz, tx, ty, tz, lds, acc, t); }
+      if constexpr (DMAX >= 2) { if (dQ == 2) galerkin_body<NH, NH + 2>(u_e, wj, ttx, tty, ttz, tx, ty, tz, lds, acc, t); }
+      if constexpr (DMAX >= 3) { if (dQ == 3) galerkin_body<NH, NH + 3>(u_e, wj, ttx, tty, ttz, tx, ty, tz, lds, acc, t); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) __syncthreads();
+    }
+    __syncthreads();
+  }
+  if (CG > 1) {
+    if (t < NH * NH) {
+#pragma unroll
+      for (int a = 0; a < NH; ++a) lds[t * NH + a] = acc[a];
+    }
+    __syncthreads();
+    if (g == 0 && t < NH * NH) {
+      for (int gg = 1; gg < CG; ++gg) {
+        const double* o = smem + (size_t)gg * Cfg::LDS;
+#pragma unroll
+        for (int a = 0; a < NH; ++a) acc[a] += o[t * NH + a];
+      }
+    }
+  }
+  if (g == 0 && t < NH * NH) {
+    double* Au_e = Au + off[2 * c0];
+#pragma unroll
+    for (int a = 0; a < NH; ++a) Au_e[t * NH + a] = __dadd_rn(Au_e[t * NH + a], acc[a]);
+  }
+}
+
 template <typename K>
 static void fast_lds_limit(K kernel, size_t bytes) {
   if (bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -303,6 +436,101 @@ static void launch_fast_restrict(d4est_hip_transfer* t, const double* xf, double
   D4EST_HIP_TRANSFER_NH(X)
 #undef X
   D4EST_HIP_ABORT("transfer: no fast restriction kernel for %d coarse nodes per direction", NH);
+}
+
+
+template <int NH, int DMAX>
+static void go_galerkin(d4est_hip_transfer* t, const double* u, double* Au, const double* wjc, const int* list, int n, int n_children, hipStream_t st) {
+  using C = GalerkinCfg<NH, DMAX>;
+  const int cg = (n_children == 8 && n < 8192) ? C::CGMAX : 1;
+  const size_t lds = (size_t)cg * C::LDS * sizeof(double);
+  fast_lds_limit(galerkin_fast_kernel<NH, DMAX>, lds);
+  hipLaunchKernelGGL((galerkin_fast_kernel<NH, DMAX>), dim3(n), dim3(C::THREADS * cg), lds, st, u, Au, wjc, t->d_child, t->d_off, t->d_item_first,
+                     t->d_gal_child, t->d_gal_qs, t->d_gal_T, t->d_gal_TT, list, cg);
+}
+
+// true: the fused kernel serves this transfer with this fine plan (every item within the compile-time sizes); tables and lists are built
+bool galerkin_fused_setup(d4est_hip_transfer* t, d4est_hip_plan* fine) {
+  if (t->gal_fine == fine && t->d_gal_T) return !t->gal_lists.empty() || t->n_items == 0;
+  (void)hipFree(t->d_gal_T); (void)hipFree(t->d_gal_TT); (void)hipFree(t->d_gal_child); (void)hipFree(t->d_gal_qs); (void)hipFree(t->d_gal_lists);
+  t->d_gal_T = t->d_gal_TT = nullptr; t->d_gal_child = t->d_gal_qs = t->d_gal_lists = nullptr;
+  t->gal_lists.clear();
+  t->gal_fine = fine;
+  if (std::getenv("D4EST_HIP_TRANSFER_GENERIC") || fine->n_elements != t->n_children || fine->quad_aliased) return false;
+  std::vector<double> T, TT;
+  std::map<std::tuple<int, int, int, int>, int> index;   // (hp, degH, degh, deg_quad) -> offset of the (two) composite operators
+  auto get = [&](int hp, int dH, int dh, int dq) {
+    auto key = std::make_tuple(hp, dH, dh, dq);
+    auto f = index.find(key);
+    if (f != index.end()) return f->second;
+    const std::vector<double> B = Tables1D::quad_interp(fine->quad_type, dh, dq);   // (dq+1) x (dh+1)
+    const std::vector<double> P = hp ? Tables1D::hp_prolong(dH, dh) : Tables1D::p_prolong(dH, dh);
+    const int o = (int)T.size();
+    for (int h = 0; h < (hp ? 2 : 1); ++h) {
+      const std::vector<double> Ph(P.begin() + (size_t)h * (dh + 1) * (dH + 1), P.begin() + (size_t)(h + 1) * (dh + 1) * (dH + 1));
+      const std::vector<double> C = Tables1D::matmul(B, Ph, dq + 1, dh + 1, dH + 1);   // (dq+1) x (dH+1)
+      const std::vector<double> Ct = Tables1D::transpose(C, dq + 1, dH + 1);
+      T.insert(T.end(), C.begin(), C.end());
+      TT.insert(TT.end(), Ct.begin(), Ct.end());
+    }
+    index[key] = o;
+    return o;
+  };
+  std::vector<int> gchild((size_t)4 * std::max(t->n_children, 1), 0), gqs((size_t)std::max(t->n_children, 1), 0);
+  std::map<std::pair<int, int>, std::vector<int>> lists;
+  std::map<std::pair<int, int>, int> dmax_of;
+  long long fo = 0;
+  int rec = 0;
+  for (int it = 0; it < t->n_items; ++it) {
+    const int nc = t->h_hrefine[it] == 1 ? 8 : 1, dH = t->h_degH[it], NH = dH + 1;
+    int dmax = 0;
+    for (int c = 0; c < nc; ++c, ++rec) {
+      const int dh = t->h_degh[8 * (size_t)it + c], dq = fine->deg_quad[rec];
+      if (fine->deg[rec] != dh || fine->nodal_stride[rec] != fo) return false;   // the fine plan is not this transfer's fine level
+      fo += (long long)(dh + 1) * (dh + 1) * (dh + 1);
+      const int base = get(nc == 8, dH, dh, dq);
+      const int half = (dq + 1) * NH;
+      gchild[4 * (size_t)rec + 0] = dq + 1;
+      gchild[4 * (size_t)rec + 1] = base + (nc == 8 ? (c & 1) * half : 0);
+      gchild[4 * (size_t)rec + 2] = base + (nc == 8 ? ((c >> 1) & 1) * half : 0);
+      gchild[4 * (size_t)rec + 3] = base + (nc == 8 ? ((c >> 2) & 1) * half : 0);
+      gqs[rec] = fine->quad_stride[rec];
+      dmax = std::max(dmax, dq + 1 - NH);
+      if (dq + 1 < NH) return false;
+    }
+    if (NH < 2 || NH > kFastMaxNH || dmax > kFastMaxD) return false;
+    const auto key = std::make_pair(NH, nc);
+    lists[key].push_back(it);
+    dmax_of[key] = std::max(dmax_of[key], dmax);
+  }
+  std::vector<int> all;
+  for (auto& kv : lists) {
+    t->gal_lists.push_back({kv.first.first, dmax_of[kv.first], (int)all.size(), (int)kv.second.size(), kv.first.second});
+    all.insert(all.end(), kv.second.begin(), kv.second.end());
+  }
+  auto up_i = [](const std::vector<int>& v) { int* d = nullptr; HIP_CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(int))); if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice)); return d; };
+  auto up_d = [](const std::vector<double>& v) { double* d = nullptr; HIP_CHECK(hipMalloc(&d, (v.size() + 16) * sizeof(double))); HIP_CHECK(hipMemset(d, 0, (v.size() + 16) * sizeof(double))); if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice)); return d; };
+  t->d_gal_T = up_d(T); t->d_gal_TT = up_d(TT);
+  t->d_gal_child = up_i(gchild); t->d_gal_qs = up_i(gqs); t->d_gal_lists = up_i(all);
+  return true;
+}
+
+void galerkin_fused_apply(d4est_hip_transfer* t, const double* wjc, const double* u, double* Au, hipStream_t st) {
+  for (const d4est_hip_transfer::List& L : t->gal_lists) {
+    const int* list = t->d_gal_lists + L.first;
+    bool done = false;
+#define X(N_)                                                                             \
+  if (!done && L.NH == N_) {                                                              \
+    if (L.dmax == 0) go_galerkin<N_, 0>(t, u, Au, wjc, list, L.n, L.nc, st);              \
+    else if (L.dmax == 1) go_galerkin<N_, 1>(t, u, Au, wjc, list, L.n, L.nc, st);         \
+    else go_galerkin<N_, 3>(t, u, Au, wjc, list, L.n, L.nc, st);                          \
+    done = true;                                                                          \
+  }
+    D4EST_HIP_TRANSFER_NH(X)
+#undef X
+    if (!done) D4EST_HIP_ABORT("fused Galerkin term: no kernel for %d coarse nodes per direction", L.NH);
+  }
+  HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace d4est_hip
@@ -466,6 +694,7 @@ void d4est_hip_transfer_destroy(d4est_hip_transfer_t* t) {
   if (!t) return;
   (void)hipFree(t->d_child); (void)hipFree(t->d_off); (void)hipFree(t->d_item_first); (void)hipFree(t->d_ops); (void)hipFree(t->d_rops);
   (void)hipFree(t->d_opsT); (void)hipFree(t->d_ropsT); (void)hipFree(t->d_lists);
+  (void)hipFree(t->d_gal_T); (void)hipFree(t->d_gal_TT); (void)hipFree(t->d_gal_child); (void)hipFree(t->d_gal_qs); (void)hipFree(t->d_gal_lists);
   (void)hipFree(t->d_moff); (void)hipFree(t->d_coff); (void)hipFree(t->d_work); (void)hipFree(t->d_window); (void)hipFree(t->d_woff);
   delete t;
 }

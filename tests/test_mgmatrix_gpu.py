@@ -61,10 +61,18 @@ def _hierarchy(kind):
     raise ValueError(kind)
 
 
+@pytest.mark.parametrize("unfused", [False, True])
 @pytest.mark.parametrize("kind", ["hp3", "hanging2"])
-def test_coarse_level_operator_blocks_and_chain(gpu, hiplib, oracle, kind):
+def test_coarse_level_operator_blocks_and_chain(gpu, hiplib, oracle, kind, unfused, monkeypatch):
+    """unfused = False: a chain of ONE transfer runs the fused kernel (galerkin_fast_kernel: composite prolong-and-interpolate operators,
+    only the fine coefficient streamed); True (D4EST_HIP_CHAIN_UNFUSED): prolong, fine weighted mass, prolong-transpose as separate kernels
+    -- what longer chains always do"""
     import torch
     from disco4est_amd import Transfer, mesh as M
+    if unfused:
+        monkeypatch.setenv("D4EST_HIP_CHAIN_UNFUSED", "1")
+    else:
+        monkeypatch.delenv("D4EST_HIP_CHAIN_UNFUSED", raising=False)
     mp = M.SineMap(0.04)
     meshes, items = _hierarchy(kind)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
