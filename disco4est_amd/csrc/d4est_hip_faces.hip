@@ -1687,6 +1687,12 @@ struct FaceHost {
   int max_N = 1, max_NQ = 1;
   int max_local_N = 1;   // largest deg + 1 among the plan's own elements (sizes the LDS copy of u in trace_mfma16_kernel)
   ElemDesc* d_elem_desc_generic = nullptr;  // offD -> unpadded N x N matrices
+  // family split (conforming mixed-degree plans with degrees above 7): the elements whose own degree and six mortars all fit 8 x 8 go
+  // through the p <= 7 kernels (trace_mfma_kernel / flux_wave_kernel, 2 - 3 x faster per element than the tiled 16 x 16 kernels), the
+  // rest through the tiled ones; both families write the same trace array and add into the same A u
+  bool family_split = false;
+  int *d_fam_small = nullptr, *d_fam_big = nullptr;
+  int n_fam_small = 0, n_fam_big = 0;
 };
 std::map<d4est_hip_plan*, FaceHost> g_face_host;
 
@@ -2161,7 +2167,7 @@ void faces_setup(d4est_hip_plan* plan) {
     edv[e].N = edg[e].N = plan->deg[e] + 1;
     edv[e].ns = edg[e].ns = plan->nodal_stride[e];
     edg[e].offD = get_D(plan->deg[e], false);
-    edv[e].offD = fast ? get_D(plan->deg[e], true) : edg[e].offD;
+    edv[e].offD = (fast || plan->deg[e] + 1 <= 8) ? get_D(plan->deg[e], true) : edg[e].offD;
     edv[e].pad = edg[e].pad = 0;
   }
   // uniform plan? (one degree, one mortar degree, contiguous element and trace strides)
@@ -2257,6 +2263,27 @@ void faces_setup(d4est_hip_plan* plan) {
       fh.d_hang_elems = upload_vec(hang_elems);
       if (!sd.empty()) HIP_CHECK(hipMemcpy(plan->d_side_desc, sd.data(), sd.size() * sizeof(SideDesc), hipMemcpyHostToDevice));
       if (!rec.empty()) HIP_CHECK(hipMemcpy(fh.d_rec, rec.data(), rec.size() * sizeof(HpMortar), hipMemcpyHostToDevice));
+    }
+  }
+  // ---- family split of a conforming mixed-degree plan whose largest degree is above 7 (see FaceHost)
+  fh.family_split = false;
+  (void)hipFree(fh.d_fam_small); (void)hipFree(fh.d_fam_big);
+  fh.d_fam_small = fh.d_fam_big = nullptr; fh.n_fam_small = fh.n_fam_big = 0;
+  if (!hp && !fast && ne > 0 && fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
+      plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1 && plan->tuning[D4EST_HIP_TUNE_GHOST_ALIAS] <= 0 && !std::getenv("D4EST_HIP_NO_FAMILY_SPLIT")) {
+    std::vector<int> small_e, big_e;
+    for (int e = 0; e < ne; ++e) {
+      bool sm = plan->deg[e] + 1 <= 8;
+      for (int f = 0; f < 6 && sm; ++f) {
+        const size_t s_ = 6 * (size_t)e + f;
+        sm = deg_mq_of[s_] + 1 <= 8 && deg_p_of[s_] + 1 <= 8;
+      }
+      (sm ? small_e : big_e).push_back(e);
+    }
+    if (!big_e.empty() && 2 * small_e.size() >= (size_t)ne) {
+      fh.family_split = true;
+      fh.d_fam_small = upload_vec(small_e); fh.n_fam_small = (int)small_e.size();
+      fh.d_fam_big = upload_vec(big_e); fh.n_fam_big = (int)big_e.size();
     }
   }
   // ---- the hybrid operator (d4est_hip_direct.hip): on mixed-degree / locally refined plans the CLEAN elements -- deg_quad = deg with a
@@ -2766,6 +2793,20 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     else
       hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
                          (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, fh.uni);
+  } else if (fh.family_split && !elist && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+    const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
+    {
+      const int ns_ = fh.n_fam_small, resident = 8 * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
+      hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
+                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, ns_, (const int*)fh.d_fam_small);
+    }
+    const int max_local_n = fh.max_local_N;
+    const size_t lds = (size_t)(max_local_n * 272 + 3 * 2 * 16 * 34) * sizeof(double);
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+    hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(fh.n_fam_big, per_cu * cus)), dim3(192), lds, plan->stream, u, trace,
+                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.n_fam_big, max_local_n,
+                       (const int*)fh.d_fam_big);
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     // p = 8 .. 15: tiled MFMA trace kernel (descriptors with unpadded N x N derivative matrices)
     // only local elements are copied to LDS: size the copy of u by the largest LOCAL degree
@@ -2788,7 +2829,7 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
 // true when launch_flux runs the kernel that can carry the Chebyshev update in its epilogue
 bool flux_can_fuse_update(d4est_hip_plan* plan) {
   FaceHost& fh = g_face_host[plan];
-  return plan->has_faces && plan->n_elements > 0 && !fh.hp && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && !hybrid_active(plan) &&
+  return plan->has_faces && plan->n_elements > 0 && !fh.hp && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && !hybrid_active(plan) && !fh.family_split &&
          (plan->face_fast || (fh.max_N <= 16 && fh.max_NQ <= 16));
 }
 
@@ -2849,6 +2890,17 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     else if (subdomain_plan) D4EST_HIP_LAUNCH_FLUX_WAVE(false, false, ChebyFuse{});
     else D4EST_HIP_LAUNCH_FLUX_WAVE(false, true, ChebyFuse{});
 #undef D4EST_HIP_LAUNCH_FLUX_WAVE
+  } else if (fh.family_split && !elist && !cf && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+    const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
+    {
+      const int ns_ = fh.n_fam_small, resident = face_wg_per_cu() * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
+      hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
+                         (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
+                         fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, ns_, 0, ChebyFuse{}, (const int*)fh.d_fam_small);
+    }
+    hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(std::min(fh.n_fam_big, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
+                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
+                       fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_fam_big, 0, ChebyFuse{}, (const int*)fh.d_fam_big);
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int grid16 = std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256));
     static const bool no_remap16 = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
@@ -2892,6 +2944,7 @@ void faces_destroy(d4est_hip_plan* plan) {
     (void)hipFree(fh.d_side_deg_m); (void)hipFree(fh.d_side_deg_p); (void)hipFree(fh.d_side_bndry_stride);
     (void)hipFree(fh.d_ghost_sides); (void)hipFree(fh.d_elem_desc_generic);
     (void)hipFree(fh.d_sj); (void)hipFree(fh.d_robin_c); (void)hipFree(fh.d_robin_r);
+    (void)hipFree(fh.d_fam_small); (void)hipFree(fh.d_fam_big);
     (void)hipFree(fh.d_rec); (void)hipFree(fh.d_gsrc); (void)hipFree(fh.d_elem_first); (void)hipFree(fh.d_side_first); (void)hipFree(fh.d_hp_ops); (void)hipFree(fh.d_hang_elems);
     g_face_host.erase(it);
   }

@@ -10,7 +10,9 @@ m = M.BrickMesh(level, deg)
 J, rst = m.geometry(None); sides = m.build_sides(None); u = m.field()
 dev = torch.device("cuda:0")
 plan = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=torch.cuda.current_stream())
-plan.set_geometry(J, rst); plan.set_tuning(7, 0); plan.set_tuning(11, key11); plan.set_faces(sides)
+plan.set_geometry(J, rst); plan.set_tuning(7, 0); plan.set_tuning(11, key11)
+if os.environ.get('D4EST_STREAM'): plan.set_tuning(12, int(os.environ['D4EST_STREAM']))   # stream mode forced off / on
+plan.set_faces(sides)
 du = torch.from_numpy(u).to(dev); Au = torch.empty_like(du)
 for _ in range(5): plan.apply_aij(du, Au)
 torch.cuda.synchronize()
