@@ -701,13 +701,10 @@ static void launch_direct_core(d4est_hip_plan* plan, DirectHost* dh, const Bucke
     vol.EBf = bk.d_EBf; vol.EGf = bk.d_EGf; vol.EBb = bk.d_EBb; vol.EGb = bk.d_EGb;
     vol.EDq = bk.d_EDq; vol.EDqT = bk.d_EDqT;
     vol.stream = plan->stream_mode;
-    // the one-wavefront whole-operator kernel: the once-touched streams (metric 48 B, face factors 56 B per mortar node, A u) carry the
-    // non-temporal hint already from 160 MB per apply -- below the plan-wide 320 MB threshold -- because what they evict from the 4 MB
-    // L2 slices here is the NEIGHBOURS' u, which every element reads six times (config 2: HBM traffic 275 -> 242 MB = 1.24 -> 1.09 x
-    // algorithmic, 49.1-50.3 -> 48.3-49.2 us; profiles/r04_aij_l4p7_stream_traffic.txt)
-    if (!dh->mw && plan->tuning[D4EST_HIP_TUNE_STREAM] < 0 &&
-        48.0 * (double)plan->local_nodes_quad + 16.0 * (double)plan->local_nodes + 56.0 * (double)plan->total_mortar_nodes > 160e6)
-      vol.stream = 1;
+    // (measured, round 4: forcing the non-temporal hints on at config 2 -- 222 MB per apply, below the 320 MB threshold -- takes the HBM
+    // traffic of this kernel from 275 to 242 MB = 1.24 -> 1.09 x algorithmic, the neighbours' u stays in the L2, but the kernel does not
+    // get faster: 50.4 - 50.7 us without, 51.9 - 52.4 us with the hints in alternating runs; the threshold stays.
+    // profiles/r04_aij_l4p7_stream_traffic.txt)
     if (hybrid) { vol.qs0 = 0; vol.qs_stride = -1; vol.qs_list = d_qs_by_elem; }
     else { vol.qs0 = bk.qs0; vol.qs_stride = bk.ns_stride >= 0 ? bk.qs_stride : -1; vol.qs_list = plan->d_qs_list + bk.elem_offset; }
     const bool aff = !hybrid && bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine;
