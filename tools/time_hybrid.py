@@ -11,14 +11,15 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
 bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 kind = sys.argv[1]
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 4   # refinement level of the base brick
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream()
-ijk = M.morton_order(4)
-plateau = np.asarray([3, 5, 7, 9], np.int32)[(ijk[:, 0] * 4) // 16]
-refine = np.zeros(4096, dtype=bool); refine[::64] = True
-if kind == "graded": m = M.BrickMesh(4, bench.graded_degrees(4))
-elif kind == "plateau": m = M.BrickMesh(4, plateau)
-elif kind == "hanging": m = M.HangingBrickMesh(4, refine, 7)
-else: m = M.HangingBrickMesh(4, refine, np.concatenate([np.full(8 if refine[b] else 1, plateau[b]) for b in range(4096)]).astype(np.int32))
+ijk = M.morton_order(L)
+plateau = np.asarray([3, 5, 7, 9], np.int32)[(ijk[:, 0] * 4) // (1 << L)]
+refine = np.zeros(8 ** L, dtype=bool); refine[::64] = True
+if kind == "graded": m = M.BrickMesh(L, bench.graded_degrees(L))
+elif kind == "plateau": m = M.BrickMesh(L, plateau)
+elif kind == "hanging": m = M.HangingBrickMesh(L, refine, 7)
+else: m = M.HangingBrickMesh(L, refine, np.concatenate([np.full(8 if refine[b] else 1, plateau[b]) for b in range(8 ** L)]).astype(np.int32))
 J, rst = m.geometry(None); sides = m.build_sides(None)
 x = torch.from_numpy(m.field()).to(dev); y = torch.empty_like(x)
 by = bench.mixed_operator_bytes(m, sides)
