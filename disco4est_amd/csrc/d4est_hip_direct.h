@@ -6,9 +6,11 @@
 namespace d4est_hip {
 
 struct DirectSide {
-  int kcf;             // kind | code << 2 | fp << 5:  kind 0 boundary, 1 interface with a local (+) element, 2 with a ghost (+) element;
+  int kcf;             // kind | code << 2 | fp << 5:  kind 0 boundary, 1 interface with a local (+) element, 2 with a ghost (+) element
+                       // (or, hanging-aware form, a small hanging side: the (+) block in the trace array), 3 (hanging-aware form) served elsewhere;
                        // code = flip0 | flip1<<1 | transpose<<2 applied when reading the (+) side; fp = face of the (+) element
-  int nbr_ns;          // nodal offset of the (+) element (kind 1)
+  int nbr_ns;          // nodal offset of the (+) element (kind 1); hanging-aware form, kind 2: where the side's own mortar-node block is
+                       // exported to in the trace array
   int geom;            // scalar offset of the side's mortar data (7 combined factors at 7*geom; Dirichlet / Robin data at geom)
   int pad;
 };
@@ -26,6 +28,7 @@ struct DirectHost {
   const int* d_list = nullptr;   // optional list of the elements the kernel works on (not owned; direct_set_element_list)
   int n_list = 0;
   mutable int order_ok = -1;     // 1: the plan's single bucket lists the elements in order (cached by direct_fused_ok)
+  bool hang = false;             // hybrid operator on a locally refined plan: sides of kind 3 / exports exist (VOL & 16 instances)
   bool mw = false;               // N > 8: the multi-wave kernel of d4est_hip_direct_mw.hip serves the plan
   int* d_bnd_list = nullptr;     // elements with a ghost (+) side, and the others (multi-rank plans; direct_ghost_split)
   int* d_int_list = nullptr;

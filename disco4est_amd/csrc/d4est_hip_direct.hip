@@ -111,12 +111,12 @@ constexpr int kDirectWPB = 4;
 #define D4EST_HIP_DIRECT_GEOM_EARLY 1   /* both faces' geometric factors requested: 0 at their use, 1 before the SIPG loop, 2 with the neighbour lines */
 #endif
 // the seven geometric-factor fields of a side at mortar node k (sj n_l / 2-weighted rows 0..5, penalty row 6), or the Robin coefficient
-template <int T, bool NT = false /* stream mode, d4est_hip_wave.h */>
+template <int T, bool NT = false /* stream mode, d4est_hip_wave.h */, bool HANG = false /* kind 3 exists: a side another kernel serves */>
 __device__ __forceinline__ void direct_load_geom(double* gq, int kind, bool on, int k, int sgeom, const double* __restrict__ geom,
                                                  const double* __restrict__ robin_c) {
 #pragma unroll
   for (int c = 0; c < 7; ++c) gq[c] = 0.0;
-  if (on) {
+  if (on && !(HANG && kind == 3)) {
     if (kind == 0 && robin_c) {
       gq[6] = robin_c[sgeom + k];   // am = ap = 0: no term 1 / term 2 on a Robin side
     } else {
@@ -127,7 +127,12 @@ __device__ __forceinline__ void direct_load_geom(double* gq, int kind, bool on, 
   }
 }
 
-template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 streamed metric, 2 affine metric; + 4: and the zeroth-order term; + 8: stream mode (non-temporal metric / factor loads and A u stores) */>
+// VOL & 16 (the hybrid operator on a locally refined plan, "hanging-aware"): side kind 3 = a side the mortar-record kernels serve (a big
+// hanging side, or a small one they keep): no contribution here; kind 2 also stands for a SMALL hanging side whose (+) block -- the big
+// element's sub-mortar trace, written by trace_hp_mfma16_kernel before this kernel -- sits in the plan's trace array (passed as
+// ghost_qtrace), and the side's own mortar-node block (u, du/dr_0..2: what the trace kernels would write) is exported to that
+// array at nbr_ns, for the record flux kernel of the big element across it, which runs after this kernel.
+template <int N, int NQ, bool EO, bool FUSE, int VOL = 0 /* 0 faces only; + volume term: 1 streamed metric, 2 affine metric; + 4: and the zeroth-order term; + 8: stream mode (non-temporal metric / factor loads and A u stores); + 16: hanging-aware */>
 __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const double* __restrict__ u, const double* __restrict__ ghost_qtrace,
                                                              double* __restrict__ Au, const DirectSide* __restrict__ sides,
                                                              const DirectGhostOff* __restrict__ ghost_off,
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 2
     double gqa[2][7];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) direct_load_geom<T, (VOL & 8) != 0>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], direct_kargs()->geom, direct_kargs()->robin_c);
+    for (int h = 0; h < 2; ++h) direct_load_geom<T, (VOL & 8) != 0, (VOL & 16) != 0>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], direct_kargs()->geom, direct_kargs()->robin_c);
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 1
     double gqa[2][7];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) direct_load_geom<T, (VOL & 8) != 0>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], geom, robin_c);
+    for (int h = 0; h < 2; ++h) direct_load_geom<T, (VOL & 8) != 0, (VOL & 16) != 0>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], geom, robin_c);
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -332,14 +337,22 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
           const double* __restrict__ p = K->ghost_qtrace + K->ghost_off[6 * (size_t)e + 2 * d + h] + reorder_index(code, NQ - 1, a, b);
 #pragma unroll
           for (int c = 0; c < 4; ++c) qp[c] = p[c * T];
+        } else if ((VOL & 16) != 0 && kind == 3) {
         } else if (robin_c) {
           qp[0] = K->robin_r[sgeom[h] + k];
         } else {
           qp[0] = K->bndry_q[sgeom[h] + k];
         }
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 0
-        direct_load_geom<T, (VOL & 8) != 0>(gq, kind, true, k, sgeom[h], geom, robin_c);
+        direct_load_geom<T, (VOL & 8) != 0, (VOL & 16) != 0>(gq, kind, true, k, sgeom[h], geom, robin_c);
 #endif
+        if constexpr ((VOL & 16) != 0) {
+          if (kind == 2) {   // export the side's own mortar-node block (wave-uniform branch)
+            double* __restrict__ tp = const_cast<double*>((const double*)K->ghost_qtrace) + sd[2 * d + h].nbr_ns;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) tp[c * T + k] = qm[c];
+          }
+        }
       }
 #if D4EST_HIP_DIRECT_GEOM_EARLY != 0
 #pragma unroll
@@ -726,6 +739,10 @@ static void launch_direct_core(d4est_hip_plan* plan, DirectHost* dh, const Bucke
   const DirectFuse cfv = cf ? *cf : DirectFuse{};
   bool done = false;
   if (vmode == 1 && vol.stream) vmode = 9;   // stream mode (plan->stream_mode): the twin with non-temporal metric / factor loads and A u stores
+  if (dh->hang) {
+    if (!(vmode == 1 || vmode == 9) || cf) D4EST_HIP_ABORT("direct face kernel: the hanging-aware form exists for the plain whole operator only (vmode %d)", vmode);
+    vmode |= 16;
+  }
 #define D4EST_HIP_DIRECT_GO(N_, NQ_, FUSE_, VOL_)                                                                             \
   hipLaunchKernelGGL((faces_direct_kernel<N_, NQ_, true, FUSE_, VOL_>), dim3(n_wg), dim3(64 * kDirectWPB), 0,     \
                      plan->stream, u, ghost_trace, Au, dh->d_sides, dh->d_ghost_off, dh->d_ops, plan->d_face_geom, plan->d_bndry,            \
@@ -735,6 +752,8 @@ static void launch_direct_core(d4est_hip_plan* plan, DirectHost* dh, const Bucke
     if constexpr (N_ == NQ_) {                                                     \
       if (vmode == 1) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 1); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 1); done = true; } \
       if (vmode == 9) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 9); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 9); done = true; } \
+      if (vmode == 17 && !cf) { D4EST_HIP_DIRECT_GO(N_, NQ_, false, 17); done = true; } \
+      if (vmode == 25 && !cf) { D4EST_HIP_DIRECT_GO(N_, NQ_, false, 25); done = true; } \
       if (vmode == 2) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 2); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 2); done = true; } \
       if (vmode == 5) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 5); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 5); done = true; } \
       if (vmode == 6) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 6); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 6); done = true; } \
@@ -789,6 +808,7 @@ struct HybridHost {
   int *d_ns_dirty = nullptr, *d_qs_dirty = nullptr;   // bucket-ordered lists of the dirty elements (the volume kernels' view)
   std::vector<int> dirty_off, dirty_cnt;
   char path[96] = "";
+  bool hang = false;                  // hanging-aware form: the clean kernels read record traces and export small sides' blocks
   // the clean buckets' launches are short, latency-structured kernels (one wavefront / workgroup per element, a few hundred elements
   // each): back to back on one stream they cost their serial chains one after another (p = 3 ... 9 graded: 7 launches, 175 us), so each
   // bucket gets its own stream, forked from and joined to the plan's stream by events, beside the dirty path on the plan's stream
@@ -825,7 +845,7 @@ static T* hy_upload(const std::vector<T>& v) {
 
 // clean[e]: 1 = the element takes the one-kernel path.  tables(bucket) -> {C, CD, E} of the bucket's degree (host pointers, NQ x N / N x NQ)
 void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const std::vector<const double*>& C, const std::vector<const double*>& CD,
-                  const std::vector<const double*>& E) {
+                  const std::vector<const double*>& E, const std::vector<HybridSideOverride>* ov) {
   hybrid_destroy(plan);
   const int ne = plan->n_elements;
   HybridHost* hh = new HybridHost;
@@ -846,6 +866,12 @@ void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const st
       d.nbr_ns = (kind == 1) ? plan->nodal_stride[nbr] : 0;
       d.geom = plan->side_mortar_stride[s];
       d.pad = (f == 0) ? plan->nodal_stride[e] : 0;
+      if (ov && clean[e] && (*ov)[s].kind >= 0) {
+        const HybridSideOverride& o = (*ov)[s];
+        d.kcf = o.kind | ((plan->side_reorder[s] & 7) << 2);
+        if (o.kind == 2) { d.nbr_ns = o.export_off; d.geom = o.geom; goff[s] = o.goff; }
+        hh->hang = true;
+      }
       sd[s] = d;
     }
   hh->d_sides = hy_upload(sd);
@@ -870,6 +896,7 @@ void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const st
     dh->N = N; dh->NQ = NQ; dh->ns0 = 0; dh->ns_stride = -1;
     dh->mw = direct_mw_built(N, NQ);
     dh->eo = true;
+    dh->hang = hh->hang;
     std::vector<double> Cv(C[b], C[b] + (size_t)NQ * N), CDv(CD[b], CD[b] + (size_t)NQ * N), Ev(E[b], E[b] + (size_t)N * NQ);
     std::vector<double> D = Tables1D::dij(N - 1);
     std::vector<double> DtE = Tables1D::matmul(Tables1D::transpose(D, N, N), Ev, N, N, NQ);
@@ -918,7 +945,7 @@ void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const st
   hh->d_ring = hy_upload(ring); hh->n_ring = (int)ring.size();
   hh->d_ns_dirty = hy_upload(ns_dirty);
   hh->d_qs_dirty = hy_upload(qs_dirty);
-  std::snprintf(hh->path, sizeof(hh->path), "hybrid: direct+volume on %d clean elements, two-phase on %d", hh->n_clean_total, hh->n_dirty);
+  std::snprintf(hh->path, sizeof(hh->path), "hybrid%s: direct+volume on %d clean elements, two-phase on %d", hh->hang ? " (hanging-aware)" : "", hh->n_clean_total, hh->n_dirty);
   plan->hybrid = hh;
 }
 
@@ -928,6 +955,7 @@ bool hybrid_active(const d4est_hip_plan* plan) {
          plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT] != 0 && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0 && plan->has_geometry;
 }
 const char* hybrid_path(const d4est_hip_plan* plan) { return hybrid_of(plan)->path; }
+bool hybrid_hanging(const d4est_hip_plan* plan) { return hybrid_of(plan)->hang; }
 void hybrid_lists(const d4est_hip_plan* plan, const int** dirty, int* n_dirty, const int** ring, int* n_ring) {
   const HybridHost* hh = hybrid_of(plan);
   *dirty = hh->d_dirty; *n_dirty = hh->n_dirty; *ring = hh->d_ring; *n_ring = hh->n_ring;

@@ -1648,6 +1648,290 @@ __global__ __launch_bounds__(192) void flux_hp_mfma16_kernel(const double* __res
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// hp split, the record kernels' work in its parallel form: a UNIT is one side that stays with the mortar records (a big hanging side: 4
+// records; a small side the conforming kernels cannot take: 1), and its records go to the 4 wavefronts of a workgroup side by side
+// instead of one after the other.  The two kernels above walk an element's sides in three direction-waves and a side's records in
+// a loop: on a locally refined mesh (one hanging side per listed element, a few hundred listed elements) two of the three waves find
+// nothing to do and the third runs four dependent chains of descriptor load -> operator / trace loads -> MFMA one after another
+// (13.8 + 22.7 us per apply at level 4, p = 7, 350 listed elements: pure latency).  Same arithmetic per record; the four sub-mortar
+// contributions of a big side meet in LDS and are summed in record order (deterministic).
+// ---------------------------------------------------------------------------
+struct HangUnit { int e, f, r0, nrec; };
+
+__global__ __launch_bounds__(256) void trace_unit_kernel(const double* __restrict__ u, double* __restrict__ qtrace,
+                                                         const HpMortar* __restrict__ md, const HangUnit* __restrict__ units,
+                                                         const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
+                                                         const double* __restrict__ hp_ops, int n_units, int max_n) {
+  constexpr int LDM = 34;
+  constexpr int UJ = 17, UK = 272;
+  constexpr int TPB = 256;
+  extern __shared__ __attribute__((aligned(16))) double smem16[];
+  double* s_u = smem16;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* stage = smem16 + max_n * UK + wv * (16 * LDM);   // per wave: the side's nodal trace (columns 0..15) and normal derivative (16..31)
+  const int lane = threadIdx.x & 63;
+  const int mi = lane & 15, mk = lane >> 4;
+  for (int i = lane; i < 16 * LDM; i += 64) stage[i] = 0.0;
+  for (int ui = blockIdx.x; ui < n_units; ui += gridDim.x) {
+    const HangUnit un = units[ui];
+    const ElemDesc el = ed[un.e];
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
+    const int dir = un.f >> 1, hi = un.f & 1;
+    const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;
+    // this wave's record, requested with the element's data (its operator offsets are needed two round trips later)
+    const bool have = wv < un.nrec;
+    const HpMortar m = md[un.r0 + (have ? wv : 0)];
+    for (int tb = threadIdx.x; tb < N3; tb += 8 * TPB) {
+      double uv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) uv[c] = (tb + c * TPB < N3) ? u[el.ns + tb + c * TPB] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int t = tb + c * TPB;
+        if (t < N3) s_u[(t % N) + UJ * ((t / N) % N) + UK * (t / N2)] = uv[c];
+      }
+    }
+    double drow[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) drow[i] = (i < N) ? face_ops[el.offD + (hi ? (N - 1) * N : 0) + i] : 0.0;
+    const int NQ = m.NQ, T = NQ * NQ;
+    double oa[2][4], ob[2][4];   // along a: C, CD ; along b: C, CD   -- OP[row mi][col 4 ks + mk]
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int col = 4 * ks + mk;
+      const bool in = have && mi < NQ && col < N;
+      oa[0][ks] = in ? hp_ops[m.offCa + mi * N + col] : 0.0;
+      oa[1][ks] = in ? hp_ops[m.offCDa + mi * N + col] : 0.0;
+      ob[0][ks] = in ? hp_ops[m.offCb + mi * N + col] : 0.0;
+      ob[1][ks] = in ? hp_ops[m.offCDb + mi * N + col] : 0.0;
+    }
+    __syncthreads();
+    if (have) {
+      const int sn = (dir == 0) ? 1 : (dir == 1 ? UJ : UK);
+      const int sa = (dir == 0) ? UJ : 1, sb = (dir == 2) ? UJ : UK;
+      const int fixo = hi ? (N - 1) * sn : 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (4 * c >= N) continue;
+        const int idx = 64 * c + lane, a = idx & 15, b = idx >> 4;
+        if (a < N && b < N) {
+          double nd = 0.0;
+          const int base = a * sa + b * sb;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (i >= N) continue;
+            nd = fma(drow[i], s_u[base + i * sn], nd);
+          }
+          stage[a * LDM + b] = s_u[base + fixo];
+          stage[a * LDM + 16 + b] = nd;
+        }
+      }
+      wave_lds_fence();
+      const int KN = (N + 3) >> 2;
+      double aval[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        aval[0][ks] = stage[(4 * ks + mk) * LDM + mi];
+        aval[1][ks] = stage[(4 * ks + mk) * LDM + 16 + mi];
+      }
+      mfma_d4 ytc = {0.0, 0.0, 0.0, 0.0}, ytd = {0.0, 0.0, 0.0, 0.0}, ync = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks >= KN) continue;
+        ytc = __builtin_amdgcn_mfma_f64_16x16x4f64(aval[0][ks], oa[0][ks], ytc, 0, 0, 0);
+        ytd = __builtin_amdgcn_mfma_f64_16x16x4f64(aval[0][ks], oa[1][ks], ytd, 0, 0, 0);
+        ync = __builtin_amdgcn_mfma_f64_16x16x4f64(aval[1][ks], oa[0][ks], ync, 0, 0, 0);
+      }
+      mfma_d4 qu = {0.0, 0.0, 0.0, 0.0}, qta = {0.0, 0.0, 0.0, 0.0}, qtb = {0.0, 0.0, 0.0, 0.0}, qn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r >= KN) continue;
+        qu = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[0][r], ytc[r], qu, 0, 0, 0);
+        qta = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[0][r], ytd[r], qta, 0, 0, 0);
+        qtb = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[1][r], ytc[r], qtb, 0, 0, 0);
+        qn = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[0][r], ync[r], qn, 0, 0, 0);
+      }
+      double* out = qtrace + m.qoff;
+      if (mi < NQ) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int bq = mk + 4 * r;
+          if (bq < NQ) {
+            out[mi + NQ * bq] = qu[r];
+            out[(1 + t0) * T + mi + NQ * bq] = qta[r];
+            out[(1 + t1d) * T + mi + NQ * bq] = qtb[r];
+            out[(1 + dir) * T + mi + NQ * bq] = qn[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// one workgroup per listed element; its units one after the other, a unit's records on the 4 wavefronts
+__global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
+                                                        double* __restrict__ Au, const HpMortar* __restrict__ md,
+                                                        const HangUnit* __restrict__ units, const int* __restrict__ unit_first,
+                                                        const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
+                                                        const double* __restrict__ hp_ops, const double* __restrict__ geom,
+                                                        const double* __restrict__ bndry_q, const double* __restrict__ robin_c,
+                                                        const double* __restrict__ robin_r, int n_elem) {
+  constexpr int LT = 17;
+  constexpr int TPB = 256;
+  __shared__ double s_tile[6][2][16 * LT];
+  __shared__ double s_part[3][4][16 * LT];   // waves 1..3: their record's four lifted fields
+  __shared__ double s_tr[16 * LT];
+  __shared__ double s_Dfix[6][16];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int mi = lane & 15, mk = lane >> 4;
+  for (int ei = blockIdx.x; ei < n_elem; ei += gridDim.x) {
+    const int u0 = unit_first[ei], u1 = unit_first[ei + 1];
+    if (u0 == u1) continue;
+    const HangUnit first = units[u0];
+    const ElemDesc el = ed[first.e];
+    const int N = el.N, N2 = N * N, N3 = N2 * N;
+    const int KN = (N + 3) >> 2;
+    // A u of the element, requested before anything else: it is added to at the very end
+    double au_[8];
+    {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) au_[c] = (threadIdx.x + c * TPB < N3) ? Au[el.ns + threadIdx.x + c * TPB] : 0.0;
+    }
+    double opD[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) opD[ks] = (4 * ks + mk < N && mi < N) ? face_ops[el.offD + (4 * ks + mk) * N + mi] : 0.0;
+    int mask = 0;
+    for (int ui = u0; ui < u1; ++ui) {
+      const HangUnit un = (ui == u0) ? first : units[ui];
+      const int f = un.f, dir = f >> 1;
+      const int t0 = (dir == 0) ? 1 : 0, t1d = (dir == 2) ? 1 : 2;
+      mask |= 1 << f;
+      if (wv == 0 && lane < 16) s_Dfix[f][lane] = (lane < N) ? face_ops[el.offD + face_fix(f, N) * N + lane] : 0.0;
+      mfma_d4 R[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) R[c] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+      if (wv < un.nrec) {
+        const HpMortar m = md[un.r0 + wv];
+        const int NQ = m.NQ, T = NQ * NQ, KQ = (NQ + 3) >> 2;
+        double oea[4], oeb[4];   // E along a / b: E[mi][4 ks + mk]  (N x NQ)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bool in = mi < N && 4 * ks + mk < NQ;
+          oea[ks] = in ? hp_ops[m.offEa + mi * NQ + 4 * ks + mk] : 0.0;
+          oeb[ks] = in ? hp_ops[m.offEb + mi * NQ + 4 * ks + mk] : 0.0;
+        }
+        double A[4][4];
+        const bool robin = (m.kind == 0) && robin_c;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int bq = 4 * ks + mk;
+          A[0][ks] = A[1][ks] = A[2][ks] = A[3][ks] = 0.0;
+          if (mi < NQ && bq < NQ) {
+            const int k = mi + NQ * bq;
+            const double* qm = qtrace + m.qoff + k;
+            const double um = qm[0];
+            if (robin) {
+              A[0][ks] = robin_c[m.gidx + k] * um - robin_r[m.gidx + k];
+            } else {
+              const double* g = geom + (size_t)7 * m.gidx + k;
+              double up, tm = 0.0, tp = 0.0, am[3];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                am[i] = g[i * T];
+                tm += am[i] * qm[(1 + i) * T];
+              }
+              if (m.kind != 0) {
+                const double* pp = ((m.kind == 2) ? ghost_qtrace : qtrace) + m.nbr_qoff + reorder_index(m.code, NQ - 1, mi, bq);
+                up = pp[m.u_shift];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) tp += g[(3 + i) * T] * pp[(1 + i) * T];
+              } else {
+                up = bndry_q[m.gidx + k];
+              }
+              const double jump = um - up;
+              const double w1 = (m.kind != 0) ? -0.5 : -1.0;
+              A[0][ks] = w1 * (tm + tp) + g[6 * T] * jump;   // (fm, fp, w2: folded into the factors by face_geom_hp_kernel)
+              A[1][ks] = w1 * am[t0] * jump;
+              A[2][ks] = w1 * am[t1d] * jump;
+              A[3][ks] = w1 * am[dir] * jump;
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          mfma_d4 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            if (ks < KQ) y = __builtin_amdgcn_mfma_f64_16x16x4f64(A[c][ks], oeb[ks], y, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < KQ) R[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(oea[r], y[r], R[c], 0, 0, 0);
+        }
+        if (wv > 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_part[wv - 1][c][(mk + 4 * r) * LT + mi] = R[c][r];
+        }
+      }
+      __syncthreads();
+      if (wv == 0) {
+        for (int w = 1; w < un.nrec; ++w) {   // the side's mortars, summed in record order
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[c][r] += s_part[w - 1][c][(mk + 4 * r) * LT + mi];
+        }
+        mfma_d4 val = R[0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < KN) val = __builtin_amdgcn_mfma_f64_16x16x4f64(opD[r], R[1][r], val, 0, 0, 0);
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_tr[(mk + 4 * r) * LT + mi] = R[2][r];
+        wave_lds_fence();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks >= KN) continue;
+          const double a_ = s_tr[mi * LT + 4 * ks + mk];
+          val = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, opD[ks], val, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s_tile[f][0][(mk + 4 * r) * LT + mi] = val[r];
+          s_tile[f][1][(mk + 4 * r) * LT + mi] = R[3][r];
+        }
+      }
+      __syncthreads();
+    }
+    for (int idx0 = threadIdx.x; idx0 < N3; idx0 += 8 * TPB) {
+      if (idx0 != (int)threadIdx.x) {   // (N > 12: a second sweep)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) au_[c] = (idx0 + c * TPB < N3) ? Au[el.ns + idx0 + c * TPB] : 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int idx = idx0 + c * TPB;
+        if (idx >= N3) continue;
+        const int i = idx % N, j = (idx / N) % N, k = idx / N2;
+        double v = 0.0;
+        if (mask & 1) { v = fma(s_Dfix[0][i], s_tile[0][1][j * LT + k], v); if (i == 0) v += s_tile[0][0][j * LT + k]; }
+        if (mask & 2) { v = fma(s_Dfix[1][i], s_tile[1][1][j * LT + k], v); if (i == N - 1) v += s_tile[1][0][j * LT + k]; }
+        if (mask & 4) { v = fma(s_Dfix[2][j], s_tile[2][1][i * LT + k], v); if (j == 0) v += s_tile[2][0][i * LT + k]; }
+        if (mask & 8) { v = fma(s_Dfix[3][j], s_tile[3][1][i * LT + k], v); if (j == N - 1) v += s_tile[3][0][i * LT + k]; }
+        if (mask & 16) { v = fma(s_Dfix[4][k], s_tile[4][1][i * LT + j], v); if (k == 0) v += s_tile[4][0][i * LT + j]; }
+        if (mask & 32) { v = fma(s_Dfix[5][k], s_tile[5][1][i * LT + j], v); if (k == N - 1) v += s_tile[5][0][i * LT + j]; }
+        Au[el.ns + idx] = au_[c] + v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1668,6 +1952,9 @@ struct FaceHost {
   bool hp_split = false;
   int* d_hang_elems = nullptr;
   int n_hang_elems = 0;
+  HangUnit* d_units = nullptr;   // the sides of the listed elements that stay with the records, element by element (trace_unit_kernel / flux_unit_kernel)
+  int* d_unit_first = nullptr;   // per listed element: its first unit (n_hang_elems + 1 entries)
+  int n_units = 0;
   std::vector<HpMortar> rec_host;   // host copy of the records (set-up of the split)
   double* d_hp_ops = nullptr;
   int hp_fld_stride = 0;
@@ -2214,6 +2501,7 @@ void faces_setup(d4est_hip_plan* plan) {
   // record kernel, launched after it, overwrites (the block is at least as long), the fast flux kernel reads zeros for it.
   fh.hp_split = false;
   (void)hipFree(fh.d_hang_elems); fh.d_hang_elems = nullptr; fh.n_hang_elems = 0;
+  (void)hipFree(fh.d_units); (void)hipFree(fh.d_unit_first); fh.d_units = nullptr; fh.d_unit_first = nullptr; fh.n_units = 0;
   if (hp && fast && fh.hp_max_N <= 8 && fh.hp_max_NQ <= 8 && plan->tuning[D4EST_HIP_TUNE_HP_SPLIT] != 0 &&
       plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1) {
     std::vector<int> hang_elems;
@@ -2261,6 +2549,29 @@ void faces_setup(d4est_hip_plan* plan) {
       fh.hp_split = true;
       fh.n_hang_elems = (int)hang_elems.size();
       fh.d_hang_elems = upload_vec(hang_elems);
+      // the units: per listed element its sides with a live record (D4EST_HIP_NO_HANG_UNITS=1 keeps the serial record kernels)
+      if (!std::getenv("D4EST_HIP_NO_HANG_UNITS")) {
+        std::vector<HangUnit> units;
+        std::vector<int> unit_first(1, 0);
+        bool units_ok = true;
+        for (int e : hang_elems) {
+          for (int f = 0; f < 6; ++f) {
+            const size_t s_ = 6 * (size_t)e + f;
+            const int r0 = plan->side_first_rec[s_], r1 = plan->side_first_rec[s_ + 1];
+            int live = 0;
+            for (int r = r0; r < r1; ++r) live += rec[r].hang != 0.0;
+            if (live == 0) continue;
+            if (live != r1 - r0 || r1 - r0 > 4) { units_ok = false; break; }
+            units.push_back(HangUnit{e, f, r0, r1 - r0});
+          }
+          unit_first.push_back((int)units.size());
+        }
+        if (units_ok && !units.empty()) {
+          fh.n_units = (int)units.size();
+          fh.d_units = upload_vec(units);
+          fh.d_unit_first = upload_vec(unit_first);
+        }
+      }
       if (!sd.empty()) HIP_CHECK(hipMemcpy(plan->d_side_desc, sd.data(), sd.size() * sizeof(SideDesc), hipMemcpyHostToDevice));
       if (!rec.empty()) HIP_CHECK(hipMemcpy(fh.d_rec, rec.data(), rec.size() * sizeof(HpMortar), hipMemcpyHostToDevice));
     }
@@ -2294,6 +2605,13 @@ void faces_setup(d4est_hip_plan* plan) {
       plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1 && (hp ? (fh.hp_split || (fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16)) : (fast || (fh.max_N <= 16 && fh.max_NQ <= 16)))) {
     std::vector<char> bucket_ok(plan->buckets.size(), 0), clean(ne, 0);
     std::vector<int> bucket_of(ne, -1);
+    // hanging-aware form (hp split active): a hanging side does not make an element dirty -- the record kernels serve it (kind 3) or,
+    // a small side the split handed to the conforming kernels, the direct kernel reads the big element's sub-mortar block from the trace
+    // array and exports its own (kind 2); D4EST_HIP_HYBRID_NO_HANGING=1 keeps every element with a hanging side dirty
+    const bool hang_aware = hp && fh.hp_split && !std::getenv("D4EST_HIP_HYBRID_NO_HANGING") && plan->local_trace_doubles < (1LL << 31);
+    std::vector<HybridSideOverride> ov;
+    if (hang_aware) ov.assign(ns, HybridSideOverride{-1, 0, 0, 0});
+    bool any_ov = false;
     for (size_t b = 0; b < plan->buckets.size(); ++b) {
       const Bucket& bk = plan->buckets[b];
       bucket_ok[b] = bk.N == bk.NQ && bk.d_EBf && hybrid_pair_built(bk.N, bk.NQ);
@@ -2305,7 +2623,17 @@ void faces_setup(d4est_hip_plan* plan) {
       bool ok = true;
       for (int f = 0; f < 6 && ok; ++f) {
         const size_t s_ = 6 * (size_t)e + f;
-        if (hp && plan->side_hang[s_] != 0) { ok = false; break; }
+        if (hp && plan->side_hang[s_] != 0) {
+          if (!hang_aware) { ok = false; break; }
+          const SideDesc& d = sd[s_];
+          if (d.kind == 3) { ov[s_] = HybridSideOverride{3, 0, 0, 0}; continue; }   // (the element is on the record kernels' list)
+          if (d.kind == 1 && plan->side_hang[s_] == 2 && d.NQ == plan->buckets[bucket_of[e]].NQ && deg_p_of[s_] == plan->deg[e]) {
+            ov[s_] = HybridSideOverride{2, d.nbr_qoff, (int)d.qoff, d.geom};
+            continue;
+          }
+          ok = false;
+          break;
+        }
         const int nbr = plan->side_nbr[s_];
         if (nbr == -1) continue;                                   // domain boundary
         if (nbr < 0) { ok = false; break; }                        // (ghost: not on one-rank plans)
@@ -2315,6 +2643,8 @@ void faces_setup(d4est_hip_plan* plan) {
       }
       clean[e] = ok;
       n_clean += ok;
+      if (ok && hang_aware)
+        for (int f = 0; f < 6; ++f) any_ov = any_ov || ov[6 * (size_t)e + f].kind >= 0;
     }
     // default: only where it was measured to pay -- ONE clean degree bucket holding at least half of the elements (a locally refined mesh of
     // one degree: level 4, p = 7, every 64th octant refined 144 -> 125 us).  With several clean buckets every bucket is its own launch of
@@ -2337,7 +2667,7 @@ void faces_setup(d4est_hip_plan* plan) {
       std::vector<const double*> pC(plan->buckets.size(), nullptr), pCD(plan->buckets.size(), nullptr), pE(plan->buckets.size(), nullptr);
       for (size_t b = 0; b < plan->buckets.size(); ++b)
         if (oC[b] >= 0) { pC[b] = ops.data() + oC[b]; pCD[b] = ops.data() + oCD[b]; pE[b] = ops.data() + oE[b]; }
-      hybrid_setup(plan, clean, pC, pCD, pE);
+      hybrid_setup(plan, clean, pC, pCD, pE, any_ov ? &ov : nullptr);
     }
   }
   const size_t tm = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
@@ -2733,7 +3063,7 @@ static void debug_occupancy_once() {
 
 static size_t generic_lds_bytes(const d4est_hip_plan* plan) { return (size_t)plan->max_face_lds_doubles * sizeof(double); }
 
-void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost, const int* elist, int n_list) {
+void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost, const int* elist, int n_list, int parts) {
   FaceHost& fh = g_face_host[plan];
   if (ghost) {
     if (fh.hp) D4EST_HIP_ABORT("compute_ghost_traces: plans with hanging faces take their ghost traces from the trace exchange (d4est_hip_plan_*_sub offsets), not from whole ghost elements");
@@ -2751,17 +3081,24 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
                        (!fh.hp && ((plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1) || (!plan->face_fast && fh.max_N <= 16 && fh.max_NQ <= 16))));
   if (!listed) elist = nullptr;
   const int n = listed ? n_list : plan->n_elements;
-  if (n == 0) return;
+  if (parts != 3 && !(fh.hp && fh.hp_split)) D4EST_HIP_ABORT("launch_traces: parts = %d on a plan without the hp split", parts);
+  if (n == 0 && !(fh.hp && fh.hp_split && (parts & 2))) return;
   if (fh.hp && fh.hp_split) {
     // hp split: every conforming side from the fast conforming kernel, then the hanging sides of the elements that have one (the
     // record kernel overwrites the blocks the first kernel filled for those sides)
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-    const int resident = 8 * cus;
-    const int rounds = (n + resident - 1) / resident;
-    const int grid = (n + rounds - 1) / rounds;
-    hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
-                       (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, elist);
-    if (fh.n_hang_elems > 0) {
+    if (n > 0 && (parts & 1)) {
+      const int resident = 8 * cus;
+      const int rounds = (n + resident - 1) / resident;
+      const int grid = (n + rounds - 1) / rounds;
+      hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
+                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, elist);
+    }
+    if (fh.n_units > 0 && (parts & 2)) {
+      const size_t lds = (size_t)(fh.hp_max_N * 272 + 4 * 16 * 34) * sizeof(double);
+      hipLaunchKernelGGL(trace_unit_kernel, dim3(std::min(fh.n_units, 4 * cus)), dim3(256), lds, plan->stream, u, trace, fh.d_rec, fh.d_units,
+                         (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, fh.n_units, fh.hp_max_N);
+    } else if (fh.n_hang_elems > 0 && (parts & 2)) {
       const size_t lds = (size_t)(fh.hp_max_N * 272 + 3 * 2 * 16 * 34) * sizeof(double);
       if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_hp_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(trace_hp_mfma16_kernel, dim3(std::min(fh.n_hang_elems, 4 * cus)), dim3(192), lds, plan->stream, u, trace, fh.d_rec,
@@ -2834,27 +3171,34 @@ bool flux_can_fuse_update(d4est_hip_plan* plan) {
 }
 
 void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf, const int* elist,
-                 int n_list) {
+                 int n_list, int parts) {
   FaceHost& fh = g_face_host[plan];
   if (cf && !flux_can_fuse_update(plan)) D4EST_HIP_ABORT("launch_flux: fused update requested on a plan whose flux kernel cannot carry it");
   if (!plan->has_faces || !plan->has_face_geometry) D4EST_HIP_ABORT("apply flux: plan_set_faces / plan_set_mortar_geometry were not called");
   if (plan->n_elements == 0) return;
   if (fh.n_ghost_sides > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost sides but no ghost trace buffer was given", fh.n_ghost_sides);
   const int n = elist ? n_list : plan->n_elements;
-  if (n == 0) return;
+  if (parts != 3 && !(fh.hp && fh.hp_split)) D4EST_HIP_ABORT("launch_flux: parts = %d on a plan without the hp split", parts);
+  if (n == 0 && !(fh.hp && fh.hp_split && (parts & 2))) return;
   if (elist && cf) D4EST_HIP_ABORT("launch_flux: a fused update cannot ride on an element list");
   if (fh.hp && fh.hp_split) {
     // hp split (see launch_traces): the conforming sides' terms from the fast kernel, then the hanging sides' from the record kernel
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-    const int resident = face_wg_per_cu() * cus;
-    const int rounds = (n + resident - 1) / resident;
-    const int grid = (n + rounds - 1) / rounds;
-    static const bool no_remap_s = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
-    const int chunk_s = (!elist && n % 8 == 0 && grid % 8 == 0 && !no_remap_s) ? n / 8 : 0;   // XCD-aware element order, as on conforming plans
-    hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
-                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom,
-                       plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk_s, ChebyFuse{}, elist);
-    if (fh.n_hang_elems > 0)
+    if (n > 0 && (parts & 1)) {
+      const int resident = face_wg_per_cu() * cus;
+      const int rounds = (n + resident - 1) / resident;
+      const int grid = (n + rounds - 1) / rounds;
+      static const bool no_remap_s = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
+      const int chunk_s = (!elist && n % 8 == 0 && grid % 8 == 0 && !no_remap_s) ? n / 8 : 0;   // XCD-aware element order, as on conforming plans
+      hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
+                         (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom,
+                         plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk_s, ChebyFuse{}, elist);
+    }
+    if (fh.n_units > 0 && (parts & 2))
+      hipLaunchKernelGGL(flux_unit_kernel, dim3(std::min(fh.n_hang_elems, 4 * cus)), dim3(256), 0, plan->stream, trace, ghost_trace, Au, fh.d_rec,
+                         fh.d_units, fh.d_unit_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
+                         plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems);
+    else if (fh.n_hang_elems > 0 && (parts & 2))
       hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(fh.n_hang_elems, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
                          fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
                          plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems,
@@ -2946,6 +3290,7 @@ void faces_destroy(d4est_hip_plan* plan) {
     (void)hipFree(fh.d_sj); (void)hipFree(fh.d_robin_c); (void)hipFree(fh.d_robin_r);
     (void)hipFree(fh.d_fam_small); (void)hipFree(fh.d_fam_big);
     (void)hipFree(fh.d_rec); (void)hipFree(fh.d_gsrc); (void)hipFree(fh.d_elem_first); (void)hipFree(fh.d_side_first); (void)hipFree(fh.d_hp_ops); (void)hipFree(fh.d_hang_elems);
+    (void)hipFree(fh.d_units); (void)hipFree(fh.d_unit_first);
     g_face_host.erase(it);
   }
   (void)hipFree(plan->d_elem_desc);

@@ -184,7 +184,7 @@ int reorient_face_order(int f_m, int f_p, int o, int i);  // dGMath/d4est_refere
 int face_reorder_code(int f_m, int f_p, int o);            // dGMath/d4est_operators.c:2031-2050
 void faces_set_dirichlet(d4est_hip_plan* plan, const double* g_lobatto, int on_device);
 void faces_set_robin(d4est_hip_plan* plan, const double* coeff_quad, const double* rhs_quad, int on_device);
-void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost, const int* elist = nullptr, int n_list = 0);
+void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool ghost, const int* elist = nullptr, int n_list = 0, int parts = 3 /* see launch_flux */);
 // Chebyshev update carried by the flux kernel's epilogue (flux_wave_kernel<true>): r = alpha (rhs - Au), p = r + beta p, u += p
 struct ChebyFuse {
   const double* rhs = nullptr;
@@ -225,13 +225,19 @@ void launch_direct_faces(d4est_hip_plan* plan, const double* u, const double* gh
 void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const DirectFuse* cf = nullptr,
                         int vol_term = 0);
 // elist / n_list: only these elements' face terms (the hybrid operator's dirty elements); the hanging-side record kernels keep their own list
+// parts (locally refined plans under the hp split): 1 the conforming kernel only, 2 the record kernel only, 3 both
 void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf = nullptr,
-                 const int* elist = nullptr, int n_list = 0);
+                 const int* elist = nullptr, int n_list = 0, int parts = 3);
 // the hybrid operator (d4est_hip_direct.hip): clean elements (all six sides conforming against a local element of the same degree, or
 // the boundary) through the one-kernel path of their degree bucket, the rest through the two-phase kernels on lists
 bool hybrid_pair_built(int N, int NQ);
+// hanging-aware form (locally refined plans under the hp split): what a clean element's hanging side is to the direct kernel --
+// kind 3: served by the mortar-record kernels (no contribution); kind 2: a small side, (+) block at goff in the plan's trace array, own
+// block exported to export_off, combined factors at geom; kind < 0: an ordinary side
+struct HybridSideOverride { int kind; long long goff; int export_off; int geom; };
 void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const std::vector<const double*>& C, const std::vector<const double*>& CD,
-                  const std::vector<const double*>& E);
+                  const std::vector<const double*>& E, const std::vector<HybridSideOverride>* ov = nullptr);
+bool hybrid_hanging(const d4est_hip_plan* plan);   // the clean kernels read / write the trace array: record traces before, record flux after them
 void hybrid_destroy(d4est_hip_plan* plan);
 bool hybrid_active(const d4est_hip_plan* plan);
 const char* hybrid_path(const d4est_hip_plan* plan);

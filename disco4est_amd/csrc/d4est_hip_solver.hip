@@ -162,6 +162,21 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
     const int *dirty, *ring;
     int n_dirty, n_ring;
     hybrid_lists(plan, &dirty, &n_dirty, &ring, &n_ring);
+    if (hybrid_hanging(plan)) {
+      // hanging-aware form (a locally refined plan under the hp split): elements with hanging sides are clean too.  The record trace
+      // kernel goes first (the clean kernel reads the big elements' sub-mortar blocks for its small sides), the record flux kernel last
+      // (it adds the big sides' terms to rows the clean kernel writes, from small-side blocks that kernel exports).
+      launch_traces(plan, u, plan->d_trace, false, ring, n_ring, n_dirty > 0 ? 3 : 2);
+      launch_flux_hybrid_clean(plan, u, plan->d_trace, Au, 0);
+      if (n_dirty > 0) {
+        launch_hybrid_dirty_stiffness(plan, u, Au);
+        launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, nullptr, dirty, n_dirty, 1);
+      }
+      launch_flux_hybrid_clean(plan, u, plan->d_trace, Au, 1);
+      launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, nullptr, dirty, n_dirty, 2);
+      if (lhs_term) add_lhs_mass_term(plan, u, Au);
+      return;
+    }
     launch_flux_hybrid_clean(plan, u, plan->d_ghost_trace, Au, 0);   // the clean buckets, each on its own stream beside ...
     if (n_dirty > 0) {                                                // ... the dirty path on the plan's stream
       launch_traces(plan, u, plan->d_trace, false, ring, n_ring);

@@ -34,7 +34,8 @@ def _mesh(kind):
         return M.BrickMesh(2, _plateau_degrees(2, [2, 5]))
     if kind == "mixed_p_3_8_9":          # degrees above 7: operator_mw_kernel on the clean p = 8 / 9 elements, tiled MFMA kernels on the dirty ones
         return M.BrickMesh(2, _plateau_degrees(2, [3, 8, 9, 9]))
-    if kind == "hanging_p4":             # one degree, one refined octant: hanging sides stay with the record kernels
+    if kind == "hanging_p4":             # one degree, one refined octant: every element is clean (hanging-aware form: big sides skipped and
+                                         # left to the record kernels, small sides read the big element's sub-mortar block and export their own)
         refine = np.zeros(64, dtype=bool); refine[[21]] = True
         return M.HangingBrickMesh(2, refine, 4)
     if kind == "hanging_mixed":          # both: refined octants and two degree plateaus
@@ -85,9 +86,33 @@ def test_hybrid_operator_parity(gpu, hiplib, oracle, kind, curved):
         res[hybrid] = got
         if hybrid:
             n_clean = int(path.split(" on ")[1].split()[0])
-            assert 0 < n_clean < m.n_elements, path
+            if kind == "hanging_p4":
+                assert n_clean == m.n_elements and "hanging-aware" in path, path
+            else:
+                assert 0 < n_clean < m.n_elements, path
         plan.destroy()
     assert _rel(res[1], res[0]) <= RTOL
+
+
+@pytest.mark.parametrize("kind", ["hanging_p4", "hanging_mixed"])
+def test_hybrid_without_the_hanging_aware_form(gpu, hiplib, oracle, kind, monkeypatch):
+    """D4EST_HIP_HYBRID_NO_HANGING=1: every element with a hanging side stays with the two-phase kernels (round 4's first form)"""
+    import torch
+    from disco4est_amd import mesh as M
+    monkeypatch.setenv("D4EST_HIP_HYBRID_NO_HANGING", "1")
+    m = _mesh(kind)
+    mp = M.SineMap(0.04)
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    u = m.field(mp)
+    ref = oracle.apply_aij(m, J, rst, sides, u, nthreads=8)
+    plan = _plan(m, J, rst, sides, 1)
+    path = plan.face_path()
+    assert path.startswith("hybrid") and "hanging-aware" not in path, path
+    assert int(path.split(" on ")[1].split()[0]) < m.n_elements
+    du = _t(u, gpu); Au = torch.full_like(du, float("nan"))
+    plan.apply_aij(du, Au)
+    assert _rel(Au.cpu().numpy(), ref) <= RTOL
+    plan.destroy()
 
 
 @pytest.mark.parametrize("kind", ["mixed_p_2_5", "hanging_mixed"])
