@@ -798,8 +798,9 @@ def main():
                 x5 = torch.from_numpy(m5.field()).to(dev)
                 res5 = {}
                 # three forms of the same operator: every side through the mortar-record kernels (0) / conforming sides through the fast
-                # conforming kernels, hanging sides through the record kernels ("split") / the default: the hybrid operator -- elements
-                # without a hanging side get the whole operator from the one-kernel path, the rest the split two-phase kernels on lists
+                # conforming kernels, hanging sides through the record kernels ("split") / the default: the hybrid operator in its
+                # hanging-aware form -- EVERY element gets the whole operator from the one-kernel path (small hanging sides read the big
+                # element's sub-mortar block and export their own), only the big sides' terms come from the record kernels, before / after it
                 for key, (k13, k14) in (("records", (0, 0)), ("split", (-1, 0)), (-1, (-1, -1))):
                     p5 = Plan(m5.deg, m5.deg_quad, m5.nodal_stride, m5.quad_stride, 0, stream=stream)
                     p5.set_tuning(13, k13)

@@ -28,6 +28,7 @@ struct DirectHost {
   const int* d_list = nullptr;   // optional list of the elements the kernel works on (not owned; direct_set_element_list)
   int n_list = 0;
   mutable int order_ok = -1;     // 1: the plan's single bucket lists the elements in order (cached by direct_fused_ok)
+  int hy_qs0 = 0, hy_qs_stride = -1;   // hybrid operator, one bucket = the whole plan in order: affine quadrature offsets (else by element id)
   bool hang = false;             // hybrid operator on a locally refined plan: sides of kind 3 / exports exist (VOL & 16 instances)
   bool mw = false;               // N > 8: the multi-wave kernel of d4est_hip_direct_mw.hip serves the plan
   int* d_bnd_list = nullptr;     // elements with a ghost (+) side, and the others (multi-rank plans; direct_ghost_split)

@@ -718,7 +718,8 @@ static void launch_direct_core(d4est_hip_plan* plan, DirectHost* dh, const Bucke
     // traffic of this kernel from 275 to 242 MB = 1.24 -> 1.09 x algorithmic, the neighbours' u stays in the L2, but the kernel does not
     // get faster: 50.4 - 50.7 us without, 51.9 - 52.4 us with the hints in alternating runs; the threshold stays.
     // profiles/r04_aij_l4p7_stream_traffic.txt)
-    if (hybrid) { vol.qs0 = 0; vol.qs_stride = -1; vol.qs_list = d_qs_by_elem; }
+    if (hybrid && dh->hy_qs_stride > 0) { vol.qs0 = dh->hy_qs0; vol.qs_stride = dh->hy_qs_stride; vol.qs_list = nullptr; }
+    else if (hybrid) { vol.qs0 = 0; vol.qs_stride = -1; vol.qs_list = d_qs_by_elem; }
     else { vol.qs0 = bk.qs0; vol.qs_stride = bk.ns_stride >= 0 ? bk.qs_stride : -1; vol.qs_list = plan->d_qs_list + bk.elem_offset; }
     const bool aff = !hybrid && bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine;
     if (aff) { vol.affine = plan->d_metric_affine; vol.wq = bk.d_w; }
@@ -920,6 +921,19 @@ void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const st
     hh->n_clean[b] = (int)cl.size();
     dh->d_list = hh->d_clean[b];
     dh->n_list = hh->n_clean[b];
+    // every element of the plan, in order, at affine offsets (a locally refined mesh of one degree in the hanging-aware form): the
+    // arithmetic addressing of a uniform plan -- no list, no per-element offset loads in front of the element's first memory request
+    if ((int)cl.size() == ne && ne > 0) {
+      bool affine = true;
+      const int n3 = N * N * N, q3 = NQ * NQ * NQ;
+      for (int e = 0; e < ne && affine; ++e)
+        affine = plan->nodal_stride[e] == plan->nodal_stride[0] + e * n3 && plan->quad_stride[e] == plan->quad_stride[0] + e * q3;
+      if (affine) {
+        dh->d_list = nullptr; dh->n_list = 0;
+        dh->ns0 = plan->nodal_stride[0]; dh->ns_stride = n3;
+        dh->hy_qs0 = plan->quad_stride[0]; dh->hy_qs_stride = q3;
+      }
+    }
     hh->dh[b] = dh;
     hh->n_clean_total += (int)cl.size();
   }
