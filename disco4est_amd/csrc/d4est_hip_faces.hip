@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
       for (int ks = 0; ks < 4; ++ks) {
         const int bq = 4 * ks + mk;
         A[0][ks] = A[1][ks] = A[2][ks] = A[3][ks] = 0.0;
-        if (mi < NQ && bq < NQ) {
+        if (mi < NQ && bq < NQ && d.kind != 3) {   // kind 3: a hanging side of an hp-split plan -- its terms come from the mortar-record kernels
           const int k = mi + NQ * bq;
           const double* m = qtrace + d.qoff + k;
           const double um = m[0];
@@ -1950,6 +1950,8 @@ struct FaceHost {
   // hp split (deg, deg_quad <= 7): the fast conforming kernels serve every conforming (and small hanging) side of the mesh, the mortar-record
   // kernels only the hanging sides of the elements that have one (d_hang_elems)
   bool hp_split = false;
+  bool hp_split_fast = false;    // ... and every degree <= 7: the p <= 7 kernels take every conforming side; else the tiled 16 x 16 kernels (or both
+                                 // families on lists: family_split) do
   int* d_hang_elems = nullptr;
   int n_hang_elems = 0;
   HangUnit* d_units = nullptr;   // the sides of the listed elements that stay with the records, element by element (trace_unit_kernel / flux_unit_kernel)
@@ -2502,7 +2504,12 @@ void faces_setup(d4est_hip_plan* plan) {
   fh.hp_split = false;
   (void)hipFree(fh.d_hang_elems); fh.d_hang_elems = nullptr; fh.n_hang_elems = 0;
   (void)hipFree(fh.d_units); (void)hipFree(fh.d_unit_first); fh.d_units = nullptr; fh.d_unit_first = nullptr; fh.n_units = 0;
-  if (hp && fast && fh.hp_max_N <= 8 && fh.hp_max_NQ <= 8 && plan->tuning[D4EST_HIP_TUNE_HP_SPLIT] != 0 &&
+  // (degrees above 7 -- round 4: the conforming sides then go through the tiled 16 x 16 conforming kernels, or, family split below, through
+  // both conforming families on lists; D4EST_HIP_HP_SPLIT_FAST_ONLY=1 keeps such plans on the record kernels throughout)
+  const bool split_fast = fast && fh.hp_max_N <= 8 && fh.hp_max_NQ <= 8;
+  const bool split_tiled = !split_fast && fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16 && fh.max_N <= 16 && fh.max_NQ <= 16 && !std::getenv("D4EST_HIP_HP_SPLIT_FAST_ONLY");
+  fh.hp_split_fast = false;
+  if (hp && (split_fast || split_tiled) && plan->tuning[D4EST_HIP_TUNE_HP_SPLIT] != 0 &&
       plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1) {
     std::vector<int> hang_elems;
     std::vector<HpMortar> rec = fh.rec_host;
@@ -2547,6 +2554,7 @@ void faces_setup(d4est_hip_plan* plan) {
     if (ok && plan->tuning[D4EST_HIP_TUNE_HP_SPLIT] < 0 && 2 * hang_elems.size() > (size_t)ne) ok = false;
     if (ok) {
       fh.hp_split = true;
+      fh.hp_split_fast = split_fast;
       fh.n_hang_elems = (int)hang_elems.size();
       fh.d_hang_elems = upload_vec(hang_elems);
       // the units: per listed element its sides with a live record (D4EST_HIP_NO_HANG_UNITS=1 keeps the serial record kernels)
@@ -2580,7 +2588,7 @@ void faces_setup(d4est_hip_plan* plan) {
   fh.family_split = false;
   (void)hipFree(fh.d_fam_small); (void)hipFree(fh.d_fam_big);
   fh.d_fam_small = fh.d_fam_big = nullptr; fh.n_fam_small = fh.n_fam_big = 0;
-  if (!hp && !fast && ne > 0 && fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
+  if ((!hp || (fh.hp_split && !fh.hp_split_fast)) && !fast && ne > 0 && fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 &&
       plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1 && plan->tuning[D4EST_HIP_TUNE_GHOST_ALIAS] <= 0 && !std::getenv("D4EST_HIP_NO_FAMILY_SPLIT")) {
     std::vector<int> small_e, big_e;
     for (int e = 0; e < ne; ++e) {
@@ -2608,7 +2616,7 @@ void faces_setup(d4est_hip_plan* plan) {
     // hanging-aware form (hp split active): a hanging side does not make an element dirty -- the record kernels serve it (kind 3) or,
     // a small side the split handed to the conforming kernels, the direct kernel reads the big element's sub-mortar block from the trace
     // array and exports its own (kind 2); D4EST_HIP_HYBRID_NO_HANGING=1 keeps every element with a hanging side dirty
-    const bool hang_aware = hp && fh.hp_split && !std::getenv("D4EST_HIP_HYBRID_NO_HANGING") && plan->local_trace_doubles < (1LL << 31);
+    const bool hang_aware = hp && fh.hp_split && fh.hp_split_fast && !std::getenv("D4EST_HIP_HYBRID_NO_HANGING") && plan->local_trace_doubles < (1LL << 31);
     std::vector<HybridSideOverride> ov;
     if (hang_aware) ov.assign(ns, HybridSideOverride{-1, 0, 0, 0});
     bool any_ov = false;
@@ -3087,12 +3095,29 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     // hp split: every conforming side from the fast conforming kernel, then the hanging sides of the elements that have one (the
     // record kernel overwrites the blocks the first kernel filled for those sides)
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-    if (n > 0 && (parts & 1)) {
+    if (n > 0 && (parts & 1) && fh.hp_split_fast) {
       const int resident = 8 * cus;
       const int rounds = (n + resident - 1) / resident;
       const int grid = (n + rounds - 1) / rounds;
       hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
                          (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, elist);
+    } else if (n > 0 && (parts & 1)) {
+      // degrees above 7: the conforming sides through the tiled kernels -- both conforming families on their lists where the plan has them
+      const int max_local_n = fh.max_local_N;
+      const size_t lds = (size_t)(max_local_n * 272 + 3 * 2 * 16 * 34) * sizeof(double);
+      if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+      if (fh.family_split && !elist) {
+        const int ns_ = fh.n_fam_small, resident = 8 * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
+        hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
+                           (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, ns_, (const int*)fh.d_fam_small);
+        hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(fh.n_fam_big, per_cu * cus)), dim3(192), lds, plan->stream, u, trace,
+                           (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.n_fam_big, max_local_n,
+                           (const int*)fh.d_fam_big);
+      } else {
+        hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(n, per_cu * cus)), dim3(192), lds, plan->stream, u, trace,
+                           (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n, max_local_n, elist);
+      }
     }
     if (fh.n_units > 0 && (parts & 2)) {
       const size_t lds = (size_t)(fh.hp_max_N * 272 + 4 * 16 * 34) * sizeof(double);
@@ -3184,7 +3209,7 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   if (fh.hp && fh.hp_split) {
     // hp split (see launch_traces): the conforming sides' terms from the fast kernel, then the hanging sides' from the record kernel
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-    if (n > 0 && (parts & 1)) {
+    if (n > 0 && (parts & 1) && fh.hp_split_fast) {
       const int resident = face_wg_per_cu() * cus;
       const int rounds = (n + resident - 1) / resident;
       const int grid = (n + rounds - 1) / rounds;
@@ -3193,6 +3218,20 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
       hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
                          (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom,
                          plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk_s, ChebyFuse{}, elist);
+    } else if (n > 0 && (parts & 1)) {
+      if (fh.family_split && !elist) {
+        const int ns_ = fh.n_fam_small, resident = face_wg_per_cu() * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
+        hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
+                           (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
+                           fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, ns_, 0, ChebyFuse{}, (const int*)fh.d_fam_small);
+        hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(std::min(fh.n_fam_big, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
+                           (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
+                           fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_fam_big, 0, ChebyFuse{}, (const int*)fh.d_fam_big);
+      } else {
+        hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(std::min(n, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
+                           (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
+                           fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, 0, ChebyFuse{}, elist);
+      }
     }
     if (fh.n_units > 0 && (parts & 2))
       hipLaunchKernelGGL(flux_unit_kernel, dim3(std::min(fh.n_hang_elems, 4 * cus)), dim3(256), 0, plan->stream, trace, ghost_trace, Au, fh.d_rec,
