@@ -2,6 +2,7 @@
   graded   : level-4 brick, p = 3 ... 9 graded smoothly (bench.graded_degrees)
   plateau  : level-4 brick, p = 3, 5, 7, 9 in slabs four elements thick
   hanging  : level-4 brick, every 64th octant refined, p = 7
+  hanging1 : the same brick with ONE refined octant
   combined : hanging + plateau degrees"""
 import os, sys
 import numpy as np, torch
@@ -19,6 +20,9 @@ refine = np.zeros(8 ** L, dtype=bool); refine[::64] = True
 if kind == "graded": m = M.BrickMesh(L, bench.graded_degrees(L))
 elif kind == "plateau": m = M.BrickMesh(L, plateau)
 elif kind == "hanging": m = M.HangingBrickMesh(L, refine, 7)
+elif kind == "hanging1":   # ONE refined octant: a hanging plan that is uniform but for eight elements (what the hybrid machinery itself costs)
+    refine[:] = False; refine[8 ** L // 2 + 5] = True
+    m = M.HangingBrickMesh(L, refine, 7)
 else: m = M.HangingBrickMesh(L, refine, np.concatenate([np.full(8 if refine[b] else 1, plateau[b]) for b in range(8 ** L)]).astype(np.int32))
 J, rst = m.geometry(None); sides = m.build_sides(None)
 x = torch.from_numpy(m.field()).to(dev); y = torch.empty_like(x)
