@@ -680,7 +680,9 @@ def main():
             # off-cache points (the config-2 working set, 134 MB, sits in the 256 MB Infinity Cache): level 5 at p = 7 (1.07 GB per
             # apply) and BASELINE config 3 at full size (level 5, p = 11, 56.6 MDoF, 3.6 GB per apply); factors generated on the device
             # ... and config 5's degree at a size past the ramp (8192 elements, 33.6 MDoF, 2.1 GB per apply)
-            for name, level, deg, count in (("stiffness_p7_level5", 5, 7, None), ("stiffness_p11_level5_config3", 5, 11, None),
+            # ... and the top of SURVEY.md section 8d's level sweep: level 6 at p = 7 (262 144 elements, 134 MDoF, 8.6 GB per apply)
+            for name, level, deg, count in (("stiffness_p7_level5", 5, 7, None), ("stiffness_p7_level6", 6, 7, None),
+                                            ("stiffness_p11_level5_config3", 5, 11, None),
                                             ("stiffness_p15_8192_elements", 5, 15, 8192)):
                 m2, p2, x2, y2 = brick_plan(level, deg, stream, torch, dev, count=count)
                 ms = time_region(lambda: p2.apply_stiffness_matrix(x2, y2), 10 if count is None else 30, stream, torch, warm=10 if count is None else 30)
@@ -829,6 +831,25 @@ def main():
                         log("parity gate hanging_level4_p7 FAILED: %r" % (exc,))
                         g5o = "FAILED: " + repr(exc)
                     p5.destroy()
+                # the smoother on that mesh: 5 Chebyshev iterations on the default path (update in the operator kernel and the record flux
+                # kernel), gated against the written-out recurrence, and with the update as a separate kernel (tuning key 10 = 0)
+                cheb5 = {}
+                try:
+                    p5 = Plan(m5.deg, m5.deg_quad, m5.nodal_stride, m5.quad_stride, 0, stream=stream)
+                    p5.set_geometry(J5, rst5); p5.set_tuning(7, 0); p5.set_faces(s5)
+                    y5 = torch.empty_like(x5); rhs5 = torch.zeros_like(x5); r5 = torch.empty_like(x5)
+                    l0, l1 = eig_window(p5, x5, torch)
+                    gc5 = None if args.no_check else gate_cheby("hanging_level4_p7 cheby", p5, x5, rhs5, torch, 5, l0, l1)
+                    xc5 = x5.clone()
+                    ms_f = time_region(lambda: p5.cheby_iterate(xc5, rhs5, y5, r5, 5, l0, l1, 0), 20, stream, torch, warm=5)
+                    p5.set_tuning(10, 0)
+                    ms_s = time_region(lambda: p5.cheby_iterate(xc5, rhs5, y5, r5, 5, l0, l1, 0), 20, stream, torch, warm=5)
+                    p5.destroy()
+                    cheb5 = {"cheby_5_iterations_ms": ms_f, "cheby_GDoF_per_s": 5 * m5.local_nodes / (ms_f * 1e-3) / 1e9,
+                             "cheby_5_iterations_ms_separate_update_kernel": ms_s, "parity_gate_cheby_rel_inf": gc5}
+                except Exception as exc:
+                    log("hanging_level4_p7 cheby FAILED: %r" % (exc,))
+                    cheb5 = {"cheby": "FAILED: " + repr(exc)}
                 by5 = mixed_operator_bytes(m5, s5)
                 sec["hanging_level4_p7"] = {"dofs": m5.local_nodes, "elements": m5.n_elements,
                                             "hanging_faces": int((np.asarray(s5["side_hang"]) == 1).sum()),
@@ -839,6 +860,9 @@ def main():
                                             "apply_aij_ms_record_kernels_only": res5[0][0], "apply_aij_ms_two_phase_split": res5["split"][0],
                                             "face_path": res5[-1][2],
                                             "parity_gate_rel_inf": g5o, "parity_gate_rel_inf_vs_record_kernels": g5}
+                sec["hanging_level4_p7"].update(cheb5)
+                if "cheby_5_iterations_ms" in cheb5:
+                    sec["hanging_level4_p7"]["cheby_roofline_frac_hbm"] = 5 * (by5 + CHEBY_VECTOR_BYTES_PER_DOF * m5.local_nodes) / (cheb5["cheby_5_iterations_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                 del x5, res5
             # BASELINE config 4's mesh class proper: hanging faces AND mixed degrees, smoothly graded -- the level-4 brick with every 64th octant
             # refined and p = 3 ... 9 rising with the distance from a corner (4544 elements); the full operator and a Chebyshev iteration on it,

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
   double facc[N];   // VOL: the element's face terms at (i = a, j = b, k = 0 .. N-1)
 #pragma unroll
   for (int i = 0; i < N; ++i) facc[i] = 0.0;
+  int any3 = 0;     // hanging-aware form: the element has a side the record kernels serve -- its A u is not final here (wave-uniform)
 
   auto dir_body = [&](auto dc) {
     constexpr int d = decltype(dc)::value;
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
     const sside_ptr sd = (sside_ptr)(unsigned long long)(direct_kargs()->sides + 6 * (size_t)e);
     const int kcf[2] = {sd[2 * d].kcf, sd[2 * d + 1].kcf};
     const int sgeom[2] = {sd[2 * d].geom, sd[2 * d + 1].geom};
+    if constexpr ((VOL & 16) != 0 && FUSE) any3 |= ((kcf[0] & 3) == 3) | ((kcf[1] & 3) == 3);
     // ---- nodal fields of the two faces: c = 0..3 trace (own 2d, own 2d+1, nbr 2d, nbr 2d+1), c = 4..7 normal derivative
     double fld[8] = {own_tr[2 * d], own_tr[2 * d + 1], 0.0, 0.0, own_nd[2 * d], own_nd[2 * d + 1], 0.0, 0.0};
     // the normal lines of the two (+) elements' faces at THEIR face node (a, b): both faces' lines (and, below, both faces' geometric
@@ -497,12 +499,16 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
       DirectFuse cfl;
       if constexpr (FUSE) cfl = direct_load_fuse(direct_kargs());
       double* __restrict__ Au_ = direct_kargs()->Au;
+      // hanging-aware form: an element with a side of kind 3 gets the rest of its A u -- and then its update -- from the record flux kernel
+      const bool upd = !((VOL & 16) != 0 && any3 != 0);
       double rh[FUSE ? N : 1], pp[FUSE ? N : 1], uu[FUSE ? N : 1];   // the smoother's loads first, all of them: see the faces-only form above
       if constexpr (FUSE) {
+        if (upd) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-          const size_t o = (size_t)ns + a + N * b + N2 * i;
-          rh[i] = cfl.rhs[o]; pp[i] = cfl.p[o]; uu[i] = u[o];
+          for (int i = 0; i < N; ++i) {
+            const size_t o = (size_t)ns + a + N * b + N2 * i;
+            rh[i] = cfl.rhs[o]; pp[i] = cfl.p[o]; uu[i] = u[o];
+          }
         }
       }
 #pragma unroll
@@ -510,8 +516,8 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
         const size_t o = (size_t)ns + a + N * b + N2 * i;
         const double au = s_U[a + PN * (b + N * i)] + facc[i];
         if constexpr (!FUSE && (VOL & 8) != 0) __builtin_nontemporal_store(au, &Au_[o]);   // stream mode
-        else if (!FUSE || !cfl.skip_Au_store) Au_[o] = au;
-        if constexpr (FUSE) {   // the Chebyshev update of the node, as in the faces-only form
+        else if (!FUSE || !cfl.skip_Au_store || !upd) Au_[o] = au;
+        if (FUSE && upd) {   // the Chebyshev update of the node, as in the faces-only form
           const double res = __dadd_rn(rh[i], __dmul_rn(-1.0, au));
           const double ri = __dmul_rn(cfl.alpha, res);
           const double pi = __dadd_rn(__dmul_rn(cfl.beta, pp[i]), ri);
@@ -741,7 +747,7 @@ static void launch_direct_core(d4est_hip_plan* plan, DirectHost* dh, const Bucke
   bool done = false;
   if (vmode == 1 && vol.stream) vmode = 9;   // stream mode (plan->stream_mode): the twin with non-temporal metric / factor loads and A u stores
   if (dh->hang) {
-    if (!(vmode == 1 || vmode == 9) || cf) D4EST_HIP_ABORT("direct face kernel: the hanging-aware form exists for the plain whole operator only (vmode %d)", vmode);
+    if (!(vmode == 1 || vmode == 9)) D4EST_HIP_ABORT("direct face kernel: the hanging-aware form exists for the plain whole operator only (vmode %d)", vmode);
     vmode |= 16;
   }
 #define D4EST_HIP_DIRECT_GO(N_, NQ_, FUSE_, VOL_)                                                                             \
@@ -753,8 +759,8 @@ static void launch_direct_core(d4est_hip_plan* plan, DirectHost* dh, const Bucke
     if constexpr (N_ == NQ_) {                                                     \
       if (vmode == 1) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 1); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 1); done = true; } \
       if (vmode == 9) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 9); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 9); done = true; } \
-      if (vmode == 17 && !cf) { D4EST_HIP_DIRECT_GO(N_, NQ_, false, 17); done = true; } \
-      if (vmode == 25 && !cf) { D4EST_HIP_DIRECT_GO(N_, NQ_, false, 25); done = true; } \
+      if (vmode == 17) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 17); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 17); done = true; } \
+      if (vmode == 25) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 25); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 25); done = true; } \
       if (vmode == 2) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 2); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 2); done = true; } \
       if (vmode == 5) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 5); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 5); done = true; } \
       if (vmode == 6) { if (cf) D4EST_HIP_DIRECT_GO(N_, NQ_, true, 6); else D4EST_HIP_DIRECT_GO(N_, NQ_, false, 6); done = true; } \
@@ -809,6 +815,7 @@ struct HybridHost {
   int *d_ns_dirty = nullptr, *d_qs_dirty = nullptr;   // bucket-ordered lists of the dirty elements (the volume kernels' view)
   std::vector<int> dirty_off, dirty_cnt;
   char path[96] = "";
+  double* d_u2 = nullptr;             // second iterate vector of the fused Chebyshev update (hybrid_second_vector)
   bool hang = false;                  // hanging-aware form: the clean kernels read record traces and export small sides' blocks
   // the clean buckets' launches are short, latency-structured kernels (one wavefront / workgroup per element, a few hundred elements
   // each): back to back on one stream they cost their serial chains one after another (p = 3 ... 9 graded: 7 launches, 175 us), so each
@@ -829,7 +836,7 @@ void hybrid_destroy(d4est_hip_plan* plan) {
   for (hipEvent_t ev : hh->done) (void)hipEventDestroy(ev);
   if (hh->fork) (void)hipEventDestroy(hh->fork);
   (void)hipFree(hh->d_sides); (void)hipFree(hh->d_ghost_off); (void)hipFree(hh->d_qs_by_elem); (void)hipFree(hh->d_dirty); (void)hipFree(hh->d_ring);
-  (void)hipFree(hh->d_ns_dirty); (void)hipFree(hh->d_qs_dirty);
+  (void)hipFree(hh->d_ns_dirty); (void)hipFree(hh->d_qs_dirty); (void)hipFree(hh->d_u2);
   delete hh;
   plan->hybrid = nullptr;
 }
@@ -969,6 +976,24 @@ bool hybrid_active(const d4est_hip_plan* plan) {
          plan->tuning[D4EST_HIP_TUNE_FACE_DIRECT] != 0 && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] != 0 && plan->has_geometry;
 }
 const char* hybrid_path(const d4est_hip_plan* plan) { return hybrid_of(plan)->path; }
+// The Chebyshev update can ride in the hybrid operator's kernels where ONE clean launch writes every element's A u and the record flux
+// kernel finishes the elements it serves (hanging-aware form, no dirty elements, one single-wave bucket, no zeroth-order term: that
+// term is added after the kernels on this path)
+bool hybrid_can_fuse_update(const d4est_hip_plan* plan) {
+  const HybridHost* hh = hybrid_of(plan);
+  if (!hh || !hybrid_active(plan) || !hh->hang || hh->n_dirty != 0) return false;
+  if (plan->d_lhs_coeff || lhs_extra_term(plan)) return false;
+  if (!faces_have_units(const_cast<d4est_hip_plan*>(plan))) return false;
+  int n_launch = 0;
+  for (const DirectHost* d : hh->dh)
+    if (d) { ++n_launch; if (d->mw) return false; }
+  return n_launch == 1;
+}
+double* hybrid_second_vector(d4est_hip_plan* plan) {
+  HybridHost* hh = hybrid_of(plan);
+  if (!hh->d_u2) HIP_CHECK(hipMalloc(&hh->d_u2, std::max<size_t>((size_t)plan->local_nodes, 1) * sizeof(double)));
+  return hh->d_u2;
+}
 bool hybrid_hanging(const d4est_hip_plan* plan) { return hybrid_of(plan)->hang; }
 void hybrid_lists(const d4est_hip_plan* plan, const int** dirty, int* n_dirty, const int** ring, int* n_ring) {
   const HybridHost* hh = hybrid_of(plan);
@@ -978,8 +1003,9 @@ void hybrid_lists(const d4est_hip_plan* plan, const int** dirty, int* n_dirty, c
 // the clean elements: one whole-operator launch per degree bucket (u in, A u out), every bucket on its own stream between a fork event
 // on the plan's stream (phase 0, before the dirty path is queued there) and the join (phase 1, after it)
 void launch_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const double* robin_c, const double* robin_r,
-                         int phase) {
+                         int phase, const DirectFuse* cf) {
   HybridHost* hh = hybrid_of(plan);
+  if (cf && !hybrid_can_fuse_update(plan)) D4EST_HIP_ABORT("hybrid operator: a fused update was requested on a plan that cannot carry it");
   static const bool serial = std::getenv("D4EST_HIP_HYBRID_SERIAL") != nullptr;
   int n_launch = 0;
   for (DirectHost* d : hh->dh) n_launch += d != nullptr;
@@ -987,7 +1013,7 @@ void launch_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* gh
   if (!forked) {   // one bucket: nothing to overlap
     if (phase == 0) return;
     for (size_t b = 0; b < hh->dh.size(); ++b)
-      if (hh->dh[b]) launch_direct_core(plan, hh->dh[b], plan->buckets[b], true, hh->d_qs_by_elem, u, ghost_trace, Au, nullptr, robin_c, robin_r, 1);
+      if (hh->dh[b]) launch_direct_core(plan, hh->dh[b], plan->buckets[b], true, hh->d_qs_by_elem, u, ghost_trace, Au, cf, robin_c, robin_r, 1);
     return;
   }
   hipStream_t main = plan->stream;

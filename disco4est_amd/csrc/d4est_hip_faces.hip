@@ -1771,14 +1771,17 @@ __global__ __launch_bounds__(256) void trace_unit_kernel(const double* __restric
   }
 }
 
-// one workgroup per listed element; its units one after the other, a unit's records on the 4 wavefronts
+// one workgroup per listed element; its units one after the other, a unit's records on the 4 wavefronts.
+// FUSE: the Chebyshev update of the listed elements in the epilogue (their A u is final only here: hybrid operator, hanging-aware form;
+// roundings of cheby_update_kernel; the new iterate goes to cf.u_out -- the operator kernel reads the neighbours' u)
+template <bool FUSE>
 __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
                                                         double* __restrict__ Au, const HpMortar* __restrict__ md,
                                                         const HangUnit* __restrict__ units, const int* __restrict__ unit_first,
                                                         const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                         const double* __restrict__ hp_ops, const double* __restrict__ geom,
                                                         const double* __restrict__ bndry_q, const double* __restrict__ robin_c,
-                                                        const double* __restrict__ robin_r, int n_elem) {
+                                                        const double* __restrict__ robin_r, int n_elem, ChebyFuse cf) {
   constexpr int LT = 17;
   constexpr int TPB = 256;
   __shared__ double s_tile[6][2][16 * LT];
@@ -1796,10 +1799,15 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
     const int N = el.N, N2 = N * N, N3 = N2 * N;
     const int KN = (N + 3) >> 2;
     // A u of the element, requested before anything else: it is added to at the very end
-    double au_[8];
+    double au_[8], rh_[FUSE ? 8 : 1], pp_[FUSE ? 8 : 1], uu_[FUSE ? 8 : 1];
     {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) au_[c] = (threadIdx.x + c * TPB < N3) ? Au[el.ns + threadIdx.x + c * TPB] : 0.0;
+      for (int c = 0; c < 8; ++c) {
+        const bool in = threadIdx.x + c * TPB < N3;
+        const size_t o = (size_t)el.ns + threadIdx.x + c * TPB;
+        au_[c] = in ? Au[o] : 0.0;
+        if constexpr (FUSE) { rh_[c] = in ? cf.rhs[o] : 0.0; pp_[c] = in ? cf.p[o] : 0.0; uu_[c] = in ? cf.u[o] : 0.0; }
+      }
     }
     double opD[4];
 #pragma unroll
@@ -1911,7 +1919,12 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
     for (int idx0 = threadIdx.x; idx0 < N3; idx0 += 8 * TPB) {
       if (idx0 != (int)threadIdx.x) {   // (N > 12: a second sweep)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) au_[c] = (idx0 + c * TPB < N3) ? Au[el.ns + idx0 + c * TPB] : 0.0;
+        for (int c = 0; c < 8; ++c) {
+          const bool in = idx0 + c * TPB < N3;
+          const size_t o = (size_t)el.ns + idx0 + c * TPB;
+          au_[c] = in ? Au[o] : 0.0;
+          if constexpr (FUSE) { rh_[c] = in ? cf.rhs[o] : 0.0; pp_[c] = in ? cf.p[o] : 0.0; uu_[c] = in ? cf.u[o] : 0.0; }
+        }
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -1925,7 +1938,17 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
         if (mask & 8) { v = fma(s_Dfix[3][j], s_tile[3][1][i * LT + k], v); if (j == N - 1) v += s_tile[3][0][i * LT + k]; }
         if (mask & 16) { v = fma(s_Dfix[4][k], s_tile[4][1][i * LT + j], v); if (k == 0) v += s_tile[4][0][i * LT + j]; }
         if (mask & 32) { v = fma(s_Dfix[5][k], s_tile[5][1][i * LT + j], v); if (k == N - 1) v += s_tile[5][0][i * LT + j]; }
-        Au[el.ns + idx] = au_[c] + v;
+        const double a_ = au_[c] + v;
+        if (!FUSE || !cf.skip_Au_store) Au[el.ns + idx] = a_;
+        if constexpr (FUSE) {
+          const size_t o = (size_t)el.ns + idx;
+          const double res = __dadd_rn(rh_[c], __dmul_rn(-1.0, a_));
+          const double ri = __dmul_rn(cf.alpha, res);
+          const double pi = __dadd_rn(__dmul_rn(cf.beta, pp_[c]), ri);
+          if (cf.r) cf.r[o] = ri;
+          cf.p[o] = pi;
+          cf.u_out[o] = __dadd_rn(uu_[c], pi);
+        }
       }
     }
     __syncthreads();
@@ -3234,9 +3257,9 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
       }
     }
     if (fh.n_units > 0 && (parts & 2))
-      hipLaunchKernelGGL(flux_unit_kernel, dim3(std::min(fh.n_hang_elems, 4 * cus)), dim3(256), 0, plan->stream, trace, ghost_trace, Au, fh.d_rec,
+      hipLaunchKernelGGL(flux_unit_kernel<false>, dim3(std::min(fh.n_hang_elems, 4 * cus)), dim3(256), 0, plan->stream, trace, ghost_trace, Au, fh.d_rec,
                          fh.d_units, fh.d_unit_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
-                         plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems);
+                         plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems, ChebyFuse{});
     else if (fh.n_hang_elems > 0 && (parts & 2))
       hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(fh.n_hang_elems, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
                          fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
@@ -3313,9 +3336,27 @@ void launch_flux_direct(d4est_hip_plan* plan, const double* u, const double* gho
   launch_direct_faces(plan, u, ghost_trace, Au, cf, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, vol_term);
 }
 
-void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, int phase) {
+void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, int phase, const DirectFuse* cf) {
   FaceHost& fh = g_face_host[plan];
-  launch_hybrid_clean(plan, u, ghost_trace, Au, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, phase);
+  launch_hybrid_clean(plan, u, ghost_trace, Au, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, phase, cf);
+}
+
+void launch_flux_units(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf) {
+  FaceHost& fh = g_face_host[plan];
+  if (!(fh.hp && fh.hp_split)) D4EST_HIP_ABORT("launch_flux_units: the plan has no hp split");
+  if (!cf) { launch_flux(plan, trace, ghost_trace, Au, nullptr, nullptr, 0, 2); return; }
+  if (fh.n_hang_elems == 0) return;
+  if (fh.n_units == 0) D4EST_HIP_ABORT("launch_flux_units: a fused update needs the unit form of the record kernels");
+  if (!cf->u_out || cf->u_out == cf->u) D4EST_HIP_ABORT("launch_flux_units: the fused update needs a second vector");
+  const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
+  hipLaunchKernelGGL(flux_unit_kernel<true>, dim3(std::min(fh.n_hang_elems, 4 * cus)), dim3(256), 0, plan->stream, trace, ghost_trace, Au, fh.d_rec,
+                     fh.d_units, fh.d_unit_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
+                     plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems, *cf);
+  HIP_CHECK(hipGetLastError());
+}
+bool faces_have_units(d4est_hip_plan* plan) {
+  FaceHost& fh = g_face_host[plan];
+  return fh.hp && fh.hp_split && (fh.n_hang_elems == 0 || fh.n_units > 0);
 }
 
 void faces_destroy(d4est_hip_plan* plan) {

@@ -243,9 +243,14 @@ bool hybrid_active(const d4est_hip_plan* plan);
 const char* hybrid_path(const d4est_hip_plan* plan);
 void hybrid_lists(const d4est_hip_plan* plan, const int** dirty, int* n_dirty, const int** ring, int* n_ring);
 void launch_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, const double* robin_c, const double* robin_r,
-                         int phase);
+                         int phase, const DirectFuse* cf = nullptr);
+bool hybrid_can_fuse_update(const d4est_hip_plan* plan);   // the Chebyshev update can ride in the hybrid operator's kernels (hanging-aware form, all clean)
+double* hybrid_second_vector(d4est_hip_plan* plan);
+// the record flux kernel of an hp-split plan alone, optionally with the Chebyshev update of the elements it serves in its epilogue
+void launch_flux_units(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf);
+bool faces_have_units(d4est_hip_plan* plan);   // hp split with the unit record kernels (the form that can carry the update)
 void launch_hybrid_dirty_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
-void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, int phase);   // (faces.hip: supplies the Robin arrays; phase 0 fork + launches, 1 join)
+void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, int phase, const DirectFuse* cf = nullptr);   // (faces.hip: supplies the Robin arrays; phase 0 fork + launches, 1 join)
 void faces_destroy(d4est_hip_plan* plan);
 
 // d4est_hip_solver.hip

@@ -158,10 +158,25 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
     // mixed-degree / locally refined plan (d4est_hip_direct.hip, "the hybrid operator"): the clean elements' A u from the one-kernel path of
     // their degree bucket, the dirty elements' from traces (dirty elements + their neighbours) + volume + flux on lists.  Disjoint
     // rows, so the order of the launches is free; the small dirty-path kernels go first.
-    if (cf) D4EST_HIP_ABORT("apply_operator: the hybrid operator does not carry a fused update (flux_can_fuse_update is false for it)");
     const int *dirty, *ring;
     int n_dirty, n_ring;
     hybrid_lists(plan, &dirty, &n_dirty, &ring, &n_ring);
+    if (cf && !(hybrid_hanging(plan) && hybrid_can_fuse_update(plan)))
+      D4EST_HIP_ABORT("apply_operator: the hybrid operator of this plan does not carry a fused update");
+    if (hybrid_hanging(plan) && cf) {
+      // the Chebyshev update in the kernels' epilogues: the operator kernel updates every element it finishes, the record flux kernel
+      // the elements with a record side (disjoint sets; both read u and write the new iterate to cf->u_out)
+      if (!cf->u_out || cf->u_out == u) D4EST_HIP_ABORT("apply_operator: the hybrid operator needs a second vector for the fused update");
+      DirectFuse df;
+      df.rhs = cf->rhs; df.p = cf->p; df.u_out = cf->u_out; df.r = cf->r; df.alpha = cf->alpha; df.beta = cf->beta;
+      df.skip_Au_store = cf->skip_Au_store ? 1 : 0;
+      launch_traces(plan, u, plan->d_trace, false, ring, n_ring, 2);
+      launch_flux_hybrid_clean(plan, u, plan->d_trace, Au, 1, &df);
+      ChebyFuse cu = *cf;
+      cu.u = const_cast<double*>(u);
+      launch_flux_units(plan, plan->d_trace, plan->d_ghost_trace, Au, &cu);
+      return;
+    }
     if (hybrid_hanging(plan)) {
       // hanging-aware form (a locally refined plan under the hp split): elements with hanging sides are clean too.  The record trace
       // kernel goes first (the clean kernel reads the big elements' sub-mortar blocks for its small sides), the record flux kernel last
@@ -359,6 +374,7 @@ void cheby_iterate(d4est_hip_plan* plan, double* u, const double* rhs, double* A
     HIP_CHECK(hipMemsetAsync(plan->d_work_d, 0, std::max<size_t>((size_t)plan->local_nodes, 1) * sizeof(double), plan->stream));
     apply_operator(plan, plan->d_work_d, plan->d_work_r);
     if (direct_active(plan)) (void)direct_second_vector(plan);   // the second iterate vector of the fused update
+    if (hybrid_active(plan) && hybrid_hanging(plan) && hybrid_can_fuse_update(plan)) (void)hybrid_second_vector(plan);
     HIP_CHECK(hipStreamSynchronize(plan->stream));
     hipGraph_t g = nullptr;
     HIP_CHECK(hipStreamBeginCapture(plan->stream, hipStreamCaptureModeThreadLocal));
@@ -378,11 +394,13 @@ static void cheby_iterate_body(d4est_hip_plan* plan, double* u, const double* rh
   const double d = (lmax + lmin) * .5, c = (lmax - lmin) * .5;
   double alpha = 0.0, beta = 0.0;
   HIP_CHECK(hipMemsetAsync(plan->d_work_p, 0, std::max<size_t>((size_t)n, 1) * sizeof(double), plan->stream));
-  const bool fuse = plan->tuning[D4EST_HIP_TUNE_FUSE_UPDATE] != 0 && flux_can_fuse_update(plan);
+  // (the hybrid operator in its hanging-aware form carries the update in the operator kernel and the record flux kernel: hybrid_can_fuse_update)
+  const bool fuse_hy = plan->tuning[D4EST_HIP_TUNE_FUSE_UPDATE] != 0 && hybrid_active(plan) && hybrid_hanging(plan) && hybrid_can_fuse_update(plan);
+  const bool fuse = fuse_hy || (plan->tuning[D4EST_HIP_TUNE_FUSE_UPDATE] != 0 && flux_can_fuse_update(plan));
   // the direct face kernel reads the neighbours' u, so its fused update writes the new iterate to a second vector: the iterates
   // alternate between the caller's u and a plan-owned one (copied back after an odd number of iterations)
-  const bool pingpong = fuse && direct_active(plan);
-  double* ub = pingpong ? direct_second_vector(plan) : u;
+  const bool pingpong = fuse && (fuse_hy || direct_active(plan));
+  double* ub = pingpong ? (fuse_hy ? hybrid_second_vector(plan) : direct_second_vector(plan)) : u;
   double* const u_caller = u;
   for (int i = 0; i < iter; ++i) {
     if (i == 0) alpha = 1. / d;

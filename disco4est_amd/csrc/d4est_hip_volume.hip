@@ -18,6 +18,8 @@
 // element is the algorithmic minimum: u once, the 6-entry symmetric metric once,
 // Au once (64 B/DoF at Nq = N).
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 #include <cstring>
 
 #include "d4est_hip_internal.h"
@@ -1374,9 +1376,19 @@ __global__ __launch_bounds__(256) void metric_precombine_kernel(const double* __
 // p = 16 .. 19 (the reference's tables stop at 20 Lobatto points): only the two-field multi-wave kernels fit the 160 KB LDS
 #define D4EST_HIP_BIG_PAIRS(X) X(17, 17) X(18, 18) X(19, 19) X(20, 20)
 
+// (once per kernel instance and size: a driver call per launch would sit in the hot path of every smoother iteration, and inside a
+// hipGraph capture region)
 template <typename K>
 static void set_lds_limit(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (bytes <= 64 * 1024) return;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> done;
+  const void* key = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find(key);
+  if (it != done.end() && it->second >= bytes) return;
+  HIP_CHECK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done[key] = bytes;
 }
 
 static void ensure_scratch(d4est_hip_plan* plan, size_t doubles) {

@@ -240,3 +240,42 @@ def test_default_path_on_a_one_degree_refined_mesh_is_hybrid(gpu, hiplib, oracle
         ref = oracle.apply_aij(sub, Js, rsts, ss, np.ascontiguousarray(u[s0:s0 + sub.local_nodes]), u_ghost=sub.gather_ghost(ss, u), nthreads=8)
         assert _rel(got[s0:s0 + sub.local_nodes], ref) <= RTOL
     plan.destroy()
+
+
+@pytest.mark.parametrize("iters", [4, 5])
+@pytest.mark.parametrize("curved", [False, True])
+def test_hanging_aware_chebyshev_fused_update(gpu, hiplib, oracle, iters, curved):
+    """cheby_iterate on the hanging-aware hybrid operator: the update rides in the whole-operator kernel (elements it finishes) and in the
+    record flux kernel (elements with a record side), iterates alternating between two vectors -- against the oracle's recurrence
+    (Solver/d4est_solver_multigrid_smoother_cheby.c:81-176) and against the separate update kernel (tuning key 10 = 0: same roundings)"""
+    import torch
+    from disco4est_amd import mesh as M
+    refine = np.zeros(64, dtype=bool); refine[[21, 40]] = True
+    m = M.HangingBrickMesh(2, refine, 4)
+    mp = M.SineMap(0.03) if curved else None
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    oracle.set_operator(m, J, rst, sides, 10.0, 0, threads=8)
+    oracle.set_hanging(sides)
+    oracle.set_lhs_coefficient(None); oracle.set_lhs_element_blocks(None)
+    rhs = M.splitmix64_uniform(5, m.local_nodes) - 0.5
+    u0 = M.splitmix64_uniform(6, m.local_nodes) - 0.5
+    lmax = 1.1 * oracle.cg_eigs(np.zeros(m.local_nodes), rhs, 8)[0]
+    lmin = lmax / 30.0
+    out = {}
+    for fuse in (-1, 0):
+        plan = _plan(m, J, rst, sides, -1)
+        assert "hanging-aware" in plan.face_path(), plan.face_path()
+        plan.set_tuning(10, fuse)
+        for flag in (0, 1):
+            ref_u, ref_r = oracle.cheby_iterate(u0.copy(), rhs, iters, lmin, lmax, flag)
+            x = _t(u0, gpu); Au = torch.full_like(x, float("nan")); r = torch.full_like(x, float("nan"))
+            plan.cheby_iterate(x, _t(rhs, gpu), Au, r, iters, lmin, lmax, flag)
+            assert _rel(x.cpu().numpy(), ref_u) <= 1e-11
+            assert np.abs(r.cpu().numpy() - ref_r).max() <= 1e-11 * np.abs(rhs).max()
+            assert np.isfinite(Au.cpu().numpy()).all()
+            out[(fuse, flag)] = (x.cpu().numpy(), r.cpu().numpy(), Au.cpu().numpy())
+        plan.destroy()
+    oracle.set_hanging(None)
+    for flag in (0, 1):
+        for a, b in zip(out[(-1, flag)], out[(0, flag)]):
+            assert _rel(a, b) <= 1e-13
