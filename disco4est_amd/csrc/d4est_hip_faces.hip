@@ -1665,12 +1665,14 @@ __global__ __launch_bounds__(256) void trace_unit_kernel(const double* __restric
                                                          const ElemDesc* __restrict__ ed, const double* __restrict__ face_ops,
                                                          const double* __restrict__ hp_ops, int n_units, int max_n) {
   constexpr int LDM = 34;
-  constexpr int UJ = 17, UK = 272;
   constexpr int TPB = 256;
+  // the element's u as [i + UJ (j + ...)] with odd row and slab strides sized by the plan's largest degree (a p = 7 plan: 5.3 KB instead of
+  // the 17.4 KB of the 16-wide image: workgroups per CU are what bounds this kernel on densely refined meshes)
+  const int UJ = max_n | 1, UK = (max_n * UJ) | 1;
   extern __shared__ __attribute__((aligned(16))) double smem16[];
   double* s_u = smem16;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* stage = smem16 + max_n * UK + wv * (16 * LDM);   // per wave: the side's nodal trace (columns 0..15) and normal derivative (16..31)
+  double* stage = smem16 + ((max_n * UK + 1) & ~1) + wv * (16 * LDM);   // per wave: the side's nodal trace (columns 0..15) and normal derivative (16..31)
   const int lane = threadIdx.x & 63;
   const int mi = lane & 15, mk = lane >> 4;
   for (int i = lane; i < 16 * LDM; i += 64) stage[i] = 0.0;
@@ -1774,7 +1776,9 @@ __global__ __launch_bounds__(256) void trace_unit_kernel(const double* __restric
 // one workgroup per listed element; its units one after the other, a unit's records on the 4 wavefronts.
 // FUSE: the Chebyshev update of the listed elements in the epilogue (their A u is final only here: hybrid operator, hanging-aware form;
 // roundings of cheby_update_kernel; the new iterate goes to cf.u_out -- the operator kernel reads the neighbours' u)
-template <bool FUSE>
+// TS: tile size of the LDS images (8 where every degree of the plan is <= 7: 15 KB instead of 55 KB per workgroup -- on densely refined
+// meshes the workgroups per CU bound this kernel --, else 16)
+template <bool FUSE, int TS>
 __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict__ qtrace, const double* __restrict__ ghost_qtrace,
                                                         double* __restrict__ Au, const HpMortar* __restrict__ md,
                                                         const HangUnit* __restrict__ units, const int* __restrict__ unit_first,
@@ -1782,11 +1786,11 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
                                                         const double* __restrict__ hp_ops, const double* __restrict__ geom,
                                                         const double* __restrict__ bndry_q, const double* __restrict__ robin_c,
                                                         const double* __restrict__ robin_r, int n_elem, ChebyFuse cf) {
-  constexpr int LT = 17;
+  constexpr int LT = TS + 1;
   constexpr int TPB = 256;
-  __shared__ double s_tile[6][2][16 * LT];
-  __shared__ double s_part[3][4][16 * LT];   // waves 1..3: their record's four lifted fields
-  __shared__ double s_tr[16 * LT];
+  __shared__ double s_tile[6][2][TS * LT];
+  __shared__ double s_part[3][4][TS * LT];   // waves 1..3: their record's four lifted fields
+  __shared__ double s_tr[TS * LT];
   __shared__ double s_Dfix[6][16];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1879,11 +1883,12 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
           for (int r = 0; r < 4; ++r)
             if (r < KQ) R[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(oea[r], y[r], R[c], 0, 0, 0);
         }
-        if (wv > 0) {
+        if (wv > 0 && mi < TS) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_part[wv - 1][c][(mk + 4 * r) * LT + mi] = R[c][r];
+            for (int r = 0; r < 4; ++r)
+              if (mk + 4 * r < TS) s_part[wv - 1][c][(mk + 4 * r) * LT + mi] = R[c][r];
         }
       }
       __syncthreads();
@@ -1892,7 +1897,8 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
 #pragma unroll
           for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) R[c][r] += s_part[w - 1][c][(mk + 4 * r) * LT + mi];
+            for (int r = 0; r < 4; ++r)
+              if (mi < TS && mk + 4 * r < TS) R[c][r] += s_part[w - 1][c][(mk + 4 * r) * LT + mi];
         }
         mfma_d4 val = R[0];
 #pragma unroll
@@ -1900,18 +1906,21 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
           if (r < KN) val = __builtin_amdgcn_mfma_f64_16x16x4f64(opD[r], R[1][r], val, 0, 0, 0);
         wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_tr[(mk + 4 * r) * LT + mi] = R[2][r];
+        for (int r = 0; r < 4; ++r)
+          if (mi < TS && mk + 4 * r < TS) s_tr[(mk + 4 * r) * LT + mi] = R[2][r];
         wave_lds_fence();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           if (ks >= KN) continue;
-          const double a_ = s_tr[mi * LT + 4 * ks + mk];
+          const double a_ = (mi < TS && 4 * ks + mk < TS) ? s_tr[mi * LT + 4 * ks + mk] : 0.0;
           val = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, opD[ks], val, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s_tile[f][0][(mk + 4 * r) * LT + mi] = val[r];
-          s_tile[f][1][(mk + 4 * r) * LT + mi] = R[3][r];
+          if (mi < TS && mk + 4 * r < TS) {
+            s_tile[f][0][(mk + 4 * r) * LT + mi] = val[r];
+            s_tile[f][1][(mk + 4 * r) * LT + mi] = R[3][r];
+          }
         }
       }
       __syncthreads();
@@ -3143,8 +3152,10 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
       }
     }
     if (fh.n_units > 0 && (parts & 2)) {
-      const size_t lds = (size_t)(fh.hp_max_N * 272 + 4 * 16 * 34) * sizeof(double);
-      hipLaunchKernelGGL(trace_unit_kernel, dim3(std::min(fh.n_units, 4 * cus)), dim3(256), lds, plan->stream, u, trace, fh.d_rec, fh.d_units,
+      const int uj = fh.hp_max_N | 1, uk = (fh.hp_max_N * uj) | 1;
+      const size_t lds = (size_t)(((fh.hp_max_N * uk + 1) & ~1) + 4 * 16 * 34) * sizeof(double);
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+      hipLaunchKernelGGL(trace_unit_kernel, dim3(std::min(fh.n_units, per_cu * cus)), dim3(256), lds, plan->stream, u, trace, fh.d_rec, fh.d_units,
                          (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, fh.n_units, fh.hp_max_N);
     } else if (fh.n_hang_elems > 0 && (parts & 2)) {
       const size_t lds = (size_t)(fh.hp_max_N * 272 + 3 * 2 * 16 * 34) * sizeof(double);
@@ -3257,9 +3268,15 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
       }
     }
     if (fh.n_units > 0 && (parts & 2))
-      hipLaunchKernelGGL(flux_unit_kernel<false>, dim3(std::min(fh.n_hang_elems, 4 * cus)), dim3(256), 0, plan->stream, trace, ghost_trace, Au, fh.d_rec,
-                         fh.d_units, fh.d_unit_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
-                         plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems, ChebyFuse{});
+    {
+      auto go = [&](auto kern, int per_cu) {
+        hipLaunchKernelGGL(kern, dim3(std::min(fh.n_hang_elems, per_cu * cus)), dim3(256), 0, plan->stream, trace, ghost_trace, Au, fh.d_rec,
+                           fh.d_units, fh.d_unit_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
+                           plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems, ChebyFuse{});
+      };
+      if (fh.hp_max_N <= 8) go(flux_unit_kernel<false, 8>, 8);
+      else go(flux_unit_kernel<false, 16>, 2);
+    }
     else if (fh.n_hang_elems > 0 && (parts & 2))
       hipLaunchKernelGGL(flux_hp_mfma16_kernel, dim3(std::min(fh.n_hang_elems, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
                          fh.d_rec, fh.d_side_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
@@ -3349,9 +3366,13 @@ void launch_flux_units(d4est_hip_plan* plan, const double* trace, const double* 
   if (fh.n_units == 0) D4EST_HIP_ABORT("launch_flux_units: a fused update needs the unit form of the record kernels");
   if (!cf->u_out || cf->u_out == cf->u) D4EST_HIP_ABORT("launch_flux_units: the fused update needs a second vector");
   const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-  hipLaunchKernelGGL(flux_unit_kernel<true>, dim3(std::min(fh.n_hang_elems, 4 * cus)), dim3(256), 0, plan->stream, trace, ghost_trace, Au, fh.d_rec,
-                     fh.d_units, fh.d_unit_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
-                     plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems, *cf);
+  auto go = [&](auto kern, int per_cu) {
+    hipLaunchKernelGGL(kern, dim3(std::min(fh.n_hang_elems, per_cu * cus)), dim3(256), 0, plan->stream, trace, ghost_trace, Au, fh.d_rec,
+                       fh.d_units, fh.d_unit_first, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.d_hp_ops, plan->d_face_geom,
+                       plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_hang_elems, *cf);
+  };
+  if (fh.hp_max_N <= 8) go(flux_unit_kernel<true, 8>, 8);
+  else go(flux_unit_kernel<true, 16>, 2);
   HIP_CHECK(hipGetLastError());
 }
 bool faces_have_units(d4est_hip_plan* plan) {
