@@ -2691,11 +2691,24 @@ void faces_setup(d4est_hip_plan* plan) {
     // a latency-structured kernel (25 - 40 us for a few hundred elements each, whatever their number): back to back they cost more than
     // the two-phase kernels save, and on side streams the cross-queue event waits (about 50 us per fork / join on this runtime) eat the
     // overlap (graded p = 3 ... 9, 4096 elements: 144 us two-phase, 275 us serial, 250 us forked) -- tuning value 1 still forces it
+    // (round 4: with several clean buckets the default keeps the LARGEST one where it holds at least half of the mesh -- a mesh with one
+    // dominant degree -- and leaves the other buckets' elements to the two-phase lists)
     int clean_buckets = 0;
     {
-      std::vector<char> seen(plan->buckets.size(), 0);
+      std::vector<int> cnt(plan->buckets.size(), 0);
       for (int e = 0; e < ne; ++e)
-        if (clean[e] && !seen[bucket_of[e]]) { seen[bucket_of[e]] = 1; ++clean_buckets; }
+        if (clean[e]) ++cnt[bucket_of[e]];
+      int best = -1;
+      for (size_t b = 0; b < cnt.size(); ++b) {
+        if (cnt[b] > 0) ++clean_buckets;
+        if (best < 0 || cnt[b] > cnt[best]) best = (int)b;
+      }
+      if (plan->tuning[D4EST_HIP_TUNE_HYBRID] < 0 && clean_buckets > 1 && best >= 0 && 2 * (size_t)cnt[best] >= (size_t)ne &&
+          !std::getenv("D4EST_HIP_HYBRID_ONE_BUCKET_ONLY")) {
+        for (int e = 0; e < ne; ++e)
+          if (clean[e] && bucket_of[e] != best) { clean[e] = 0; --n_clean; }
+        clean_buckets = 1;
+      }
     }
     if (n_clean > 0 && (plan->tuning[D4EST_HIP_TUNE_HYBRID] > 0 || (clean_buckets == 1 && 2 * (size_t)n_clean >= (size_t)ne))) {
       std::vector<int> oC(plan->buckets.size(), -1), oCD(plan->buckets.size(), -1), oE(plan->buckets.size(), -1);

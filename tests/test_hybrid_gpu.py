@@ -279,3 +279,40 @@ def test_hanging_aware_chebyshev_fused_update(gpu, hiplib, oracle, iters, curved
     for flag in (0, 1):
         for a, b in zip(out[(-1, flag)], out[(0, flag)]):
             assert _rel(a, b) <= 1e-13
+
+
+def test_default_path_with_one_dominant_degree(gpu, hiplib, oracle):
+    """a locally refined mesh with ONE dominant degree (p = 4 but for a column of p = 3 octants): the default keeps the largest clean bucket
+    (hanging-aware one-kernel path) and leaves the other degrees' elements to the two-phase lists; D4EST_HIP_HYBRID_ONE_BUCKET_ONLY=1 is
+    round 4's first rule (several clean buckets: no hybrid operator)"""
+    import os
+    import torch
+    from disco4est_amd import mesh as M
+    ijk = M.morton_order(3)
+    refine = np.zeros(512, dtype=bool); refine[[77, 300]] = True
+    base = np.where(ijk[:, 0] < 2, 3, 4)      # a slab of p = 3 two octants thick (its outer layer is clean too: two clean buckets)
+    deg = np.concatenate([np.full(8 if refine[b] else 1, base[b]) for b in range(512)]).astype(np.int32)
+    m = M.HangingBrickMesh(3, refine, deg)
+    mp = M.SineMap(0.04)
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    u = m.field(mp)
+    ref = oracle.apply_aij(m, J, rst, sides, u, nthreads=8)
+    plan = _plan(m, J, rst, sides, -1)
+    path = plan.face_path()
+    assert path.startswith("hybrid") and "hanging-aware" in path, path
+    n_clean = int(path.split(" on ")[1].split()[0]); n_dirty = int(path.split(" on ")[2].split()[0])
+    assert 2 * n_clean >= m.n_elements and n_dirty > 0 and n_clean + n_dirty == m.n_elements, path
+    du = _t(u, gpu); Au = torch.full_like(du, float("nan"))
+    plan.apply_aij(du, Au)
+    assert _rel(Au.cpu().numpy(), ref) <= RTOL
+    plan.destroy()
+    os.environ["D4EST_HIP_HYBRID_ONE_BUCKET_ONLY"] = "1"
+    try:
+        plan = _plan(m, J, rst, sides, -1)
+        assert plan.face_path() == "two-phase", plan.face_path()
+        Au2 = torch.full_like(du, float("nan"))
+        plan.apply_aij(du, Au2)
+        assert _rel(Au2.cpu().numpy(), ref) <= RTOL
+        plan.destroy()
+    finally:
+        del os.environ["D4EST_HIP_HYBRID_ONE_BUCKET_ONLY"]

@@ -3,6 +3,7 @@
   plateau  : level-4 brick, p = 3, 5, 7, 9 in slabs four elements thick
   hanging  : level-4 brick, every 64th octant refined, p = 7
   hanging1 : the same brick with ONE refined octant
+  dominant : hanging, p = 7 but for a slab of p = 5 (12.5 % of the mesh)
   combined : hanging + plateau degrees"""
 import os, sys
 import numpy as np, torch
@@ -20,6 +21,9 @@ refine = np.zeros(8 ** L, dtype=bool); refine[::64] = True
 if kind == "graded": m = M.BrickMesh(L, bench.graded_degrees(L))
 elif kind == "plateau": m = M.BrickMesh(L, plateau)
 elif kind == "hanging": m = M.HangingBrickMesh(L, refine, 7)
+elif kind == "dominant":   # hanging + one dominant degree: p = 7 but for a slab of p = 5 two elements thick (12.5 % of the mesh)
+    dd = np.where(ijk[:, 0] < (1 << L) // 8, 5, 7).astype(np.int32)
+    m = M.HangingBrickMesh(L, refine, np.concatenate([np.full(8 if refine[b] else 1, dd[b]) for b in range(8 ** L)]).astype(np.int32))
 elif kind == "hanging1":   # ONE refined octant: a hanging plan that is uniform but for eight elements (what the hybrid machinery itself costs)
     refine[:] = False; refine[8 ** L // 2 + 5] = True
     m = M.HangingBrickMesh(L, refine, 7)
