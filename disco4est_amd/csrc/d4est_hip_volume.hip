@@ -755,6 +755,60 @@ __global__ __launch_bounds__(THREADS, D4EST_HIP_MW_WAVES) void stiffness_mw_mult
 #undef D4EST_CASE
 }
 
+
+// Mixed-degree plans, the two launches above in ONE: the p <= 7 buckets (one wavefront per work unit, two independent units per
+// 128-thread workgroup, wave-level hand-offs) and the 128-thread multi-wave buckets (N = 9, 10, 11) -- on config 4's degree range p = 3 ... 9
+// every bucket of the plan.  Both kinds are short, latency-structured kernels at these sizes (13 - 18 us each for 585-element buckets): side by
+// side in one launch they cost the longer of the two (general path; D4EST_HIP_STIFFNESS_SPLIT_LAUNCH=1 keeps the two launches).
+template <bool NT>
+__global__ __launch_bounds__(128, D4EST_HIP_MW_WAVES) void stiffness_all_multi_kernel(const double* __restrict__ u, double* __restrict__ Au,
+                                                                                    const double* __restrict__ metric,
+                                                                                    const int* __restrict__ ns_list_all,
+                                                                                    const int* __restrict__ qs_list_all, WaveEoMulti A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int blk = blockIdx.x;
+  int bi = 0;
+  while (bi + 1 < A.n && blk >= A.wg_end[bi]) ++bi;   // wave-uniform
+  const int wgb = blk - (bi > 0 ? A.wg_end[bi - 1] : 0);
+  const int off = A.elem_offset[bi], nb = A.n_elem[bi];
+  const double* EBf = A.EBf[bi];
+  const double* EGf = A.EGf[bi];   // (multi-wave buckets: Dq^T)
+  const double* EBb = A.EBb[bi];
+  const double* EGb = A.EGb[bi];   // (multi-wave buckets: Dq)
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#define D4EST_CASE_EO(N_)                                                                                                              \
+  case N_: {                                                                                                                           \
+    using C = WaveCfg<N_, N_>;                                                                                                         \
+    constexpr int PL = C::PL, PN = C::PN, FS = C::FS;                                                                                  \
+    const int tid = threadIdx.x & 63, slot = tid / PL, te = tid - slot * PL;                                                           \
+    const int ei = (2 * wgb + wv) * C::EPB + slot;                                                                                     \
+    const bool active = (slot < C::EPB) && (ei < nb);                                                                                  \
+    double* R0 = smem + wv * (C::EPB * C::LDS_PER_ELEM) + (active ? slot : 0) * C::LDS_PER_ELEM;                                       \
+    double* R1 = R0 + FS;                                                                                                              \
+    int ns = 0, qs = 0;                                                                                                                \
+    if (active) {                                                                                                                      \
+      ns = ns_list_all[off + ei];                                                                                                      \
+      qs = qs_list_all[off + ei];                                                                                                      \
+      if (C::EPB == 1) { ns = __builtin_amdgcn_readfirstlane(ns); qs = __builtin_amdgcn_readfirstlane(qs); }                           \
+      load_element_image<N_, PL, PN>(R0, u + ns, te);                                                                                  \
+    }                                                                                                                                  \
+    wave_lds_fence();                                                                                                                  \
+    stiffness_wave_eo_element<N_, N_, false, false>(R0, R1, metric, qs, ei, active, te % N_, te / N_, EBf, EGf, EBb, EGb, nullptr, nullptr); \
+    if (active) store_element_image<N_, PL, PN>(Au + ns, R0, te);                                                                      \
+  } break;
+#define D4EST_CASE_MW(N_)                                                                                                              \
+  case N_:                                                                                                                             \
+    mw_multi_body<N_, NT>(smem, wgb, u, Au, metric, ns_list_all + off, qs_list_all + off, nb, EBb, EBf, EGb, EGf);                     \
+    break;
+  switch (A.N[bi]) {
+    D4EST_CASE_EO(2) D4EST_CASE_EO(3) D4EST_CASE_EO(4) D4EST_CASE_EO(5) D4EST_CASE_EO(6) D4EST_CASE_EO(7) D4EST_CASE_EO(8)
+    D4EST_CASE_MW(9) D4EST_CASE_MW(10) D4EST_CASE_MW(11)
+    default: break;
+  }
+#undef D4EST_CASE_EO
+#undef D4EST_CASE_MW
+}
+
 // ---------------------------------------------------------------------------
 // N = NQ = 16 (p = 15) on the FP64 matrix cores (N = 13 ... 15 run too, operators zero-padded to 16, but the padding and the idle
 // waves eat the gain -- measured 32 / 47 / 36 GDoF/s against 41 / 46 / 34 of the vector-ALU kernel -- so only p = 15 selects it by itself): the whole sum-factorised apply as chains of v_mfma_f64_16x16x4
@@ -1559,9 +1613,61 @@ static unsigned launch_stiffness_multi_mw(d4est_hip_plan* plan, const double* u,
   return covered;
 }
 
+
+// ... and both kinds in one launch where a plan has p <= 7 buckets AND 128-thread multi-wave buckets (stiffness_all_multi_kernel)
+static unsigned launch_stiffness_all_multi(d4est_hip_plan* plan, const double* u, double* Au) {
+  const int tw = plan->tuning[D4EST_HIP_TUNE_STIFFNESS_WAVE];
+  if (!(tw < 0 || tw == 11) || plan->tuning[D4EST_HIP_TUNE_STIFFNESS_PREFETCH] > 0) return 0u;
+  if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] >= 0 && plan->tuning[D4EST_HIP_TUNE_STIFFNESS_BIGP] != 1) return 0u;
+  if (plan->tuning[D4EST_HIP_TUNE_STIFFNESS_EO] == 0) return 0u;
+  static const bool split = std::getenv("D4EST_HIP_STIFFNESS_SPLIT_LAUNCH") != nullptr;
+  if (split) return 0u;
+  WaveEoMulti A;
+  size_t lds = 0;
+  unsigned mine = 0u;
+  int wgs = 0, n_eo = 0, n_mw = 0;
+  for (size_t i = 0; i < plan->buckets.size() && i < 32; ++i) {
+    const Bucket& bk = plan->buckets[i];
+    if (bk.n_elem == 0 || bk.N != bk.NQ || A.n == WaveEoMulti::MAXB) continue;
+    if (bk.affine && plan->tuning[D4EST_HIP_TUNE_AFFINE] != 0 && plan->d_metric_affine) continue;   // (affine buckets keep their kernels)
+    const int j = A.n;
+    if (bk.N >= 2 && bk.N <= 8 && bk.d_EBf && bk.n_elem <= 8192) {
+      size_t l = 0;
+      int epb = 1;
+#define X(N_) if (bk.N == N_) { l = WaveCfg<N_, N_>::LDS_BYTES; epb = WaveCfg<N_, N_>::EPB; }
+      X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#undef X
+      lds = std::max(lds, 2 * l);
+      const int units = (bk.n_elem + epb - 1) / epb;
+      wgs += (units + 1) / 2;
+      A.EBf[j] = bk.d_EBf; A.EGf[j] = bk.d_EGf; A.EBb[j] = bk.d_EBb; A.EGb[j] = bk.d_EGb;
+      ++n_eo;
+    } else if (bk.N >= 9 && bk.N <= 11 && bk.d_EDq) {
+      lds = std::max(lds, (size_t)2 * bk.N * bk.N * (bk.N | 1) * sizeof(double));
+      wgs += bk.n_elem;
+      A.EBf[j] = bk.d_EBf; A.EGf[j] = bk.d_EDqT; A.EBb[j] = bk.d_EBb; A.EGb[j] = bk.d_EDq;
+      ++n_mw;
+    } else {
+      continue;
+    }
+    A.n = j + 1;
+    A.wg_end[j] = wgs; A.N[j] = bk.N; A.n_elem[j] = bk.n_elem; A.elem_offset[j] = bk.elem_offset; A.wq[j] = bk.d_w;
+    mine |= 1u << i;
+  }
+  if (n_eo == 0 || n_mw == 0) return 0u;   // one kind only: the launches above
+  std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::stiffness_all_multi_kernel (%d + %d buckets)", n_eo, n_mw);
+  auto go = [&](auto kern) {
+    set_lds_limit(kern, lds);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(128), lds, plan->stream, u, Au, plan->d_metric, plan->d_ns_list, plan->d_qs_list, A);
+  };
+  if (plan->stream_mode) go(stiffness_all_multi_kernel<true>); else go(stiffness_all_multi_kernel<false>);
+  return mine;
+}
+
 void launch_stiffness(d4est_hip_plan* plan, const double* u, double* Au) {
   if (!plan->has_geometry) D4EST_HIP_ABORT("apply_stiffness_matrix: d4est_hip_plan_set_geometry was not called");
-  const unsigned covered = launch_stiffness_multi(plan, u, Au) | launch_stiffness_multi_mw(plan, u, Au);
+  unsigned covered = launch_stiffness_all_multi(plan, u, Au);
+  if (covered == 0u) covered = launch_stiffness_multi(plan, u, Au) | launch_stiffness_multi_mw(plan, u, Au);
   size_t bucket_index = 0;
   for (const Bucket& bk : plan->buckets) {
     const size_t this_bucket = bucket_index++;
