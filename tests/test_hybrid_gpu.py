@@ -150,10 +150,11 @@ def test_hybrid_smoothers_and_lhs_term(gpu, hiplib, oracle, kind):
     plan.destroy()
 
 
-def test_hybrid_robin_boundary(gpu, hiplib, oracle):
+@pytest.mark.parametrize("kind", ["mixed_p_2_5", "hanging_p4"])
+def test_hybrid_robin_boundary(gpu, hiplib, oracle, kind):
     import torch
     from disco4est_amd import mesh as M
-    m = _mesh("mixed_p_2_5")
+    m = _mesh(kind)
     J, rst = m.geometry(None); sides = m.build_sides(None)
     rc = 0.5 + M.splitmix64_uniform(7, int(sides["total_mortar_nodes"]))
     rr = M.splitmix64_uniform(8, int(sides["total_mortar_nodes"])) - 0.5
