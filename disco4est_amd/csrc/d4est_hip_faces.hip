@@ -1788,6 +1788,7 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
                                                         const double* __restrict__ robin_r, int n_elem, ChebyFuse cf) {
   constexpr int LT = TS + 1;
   constexpr int TPB = 256;
+  constexpr int NAU = (TS <= 8) ? 2 : 8;   // nodes of the element per thread and sweep (N <= 8: 512 nodes = two per thread)
   __shared__ double s_tile[6][2][TS * LT];
   __shared__ double s_part[3][4][TS * LT];   // waves 1..3: their record's four lifted fields
   __shared__ double s_tr[TS * LT];
@@ -1803,10 +1804,10 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
     const int N = el.N, N2 = N * N, N3 = N2 * N;
     const int KN = (N + 3) >> 2;
     // A u of the element, requested before anything else: it is added to at the very end
-    double au_[8], rh_[FUSE ? 8 : 1], pp_[FUSE ? 8 : 1], uu_[FUSE ? 8 : 1];
+    double au_[NAU], rh_[FUSE ? NAU : 1], pp_[FUSE ? NAU : 1], uu_[FUSE ? NAU : 1];
     {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < NAU; ++c) {
         const bool in = threadIdx.x + c * TPB < N3;
         const size_t o = (size_t)el.ns + threadIdx.x + c * TPB;
         au_[c] = in ? Au[o] : 0.0;
@@ -1925,10 +1926,10 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
       }
       __syncthreads();
     }
-    for (int idx0 = threadIdx.x; idx0 < N3; idx0 += 8 * TPB) {
+    for (int idx0 = threadIdx.x; idx0 < N3; idx0 += NAU * TPB) {
       if (idx0 != (int)threadIdx.x) {   // (N > 12: a second sweep)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < NAU; ++c) {
           const bool in = idx0 + c * TPB < N3;
           const size_t o = (size_t)el.ns + idx0 + c * TPB;
           au_[c] = in ? Au[o] : 0.0;
@@ -1936,7 +1937,7 @@ __global__ __launch_bounds__(256) void flux_unit_kernel(const double* __restrict
         }
       }
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < NAU; ++c) {
         const int idx = idx0 + c * TPB;
         if (idx >= N3) continue;
         const int i = idx % N, j = (idx / N) % N, k = idx / N2;
