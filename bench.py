@@ -907,6 +907,48 @@ def main():
                 except Exception as exc:
                     log("secondary config4_mesh_class_level4 failed: %r" % (exc,))
                     sec["config4_mesh_class_level4"] = {"error": repr(exc)}
+            # config 4's mesh class AT SIZE (level 5: the throughput regime; at level 4 every kernel of these paths sits on its latency floor):
+            # the locally refined p = 7 brick (36 352 elements, 18.6 MDoF) and the graded p = 3 ... 9 brick (32 768 elements, 13.6 MDoF), default
+            # paths (at this size the hybrid operator on both: thousands of clean elements per degree bucket); gate: the same operator through
+            # the two-phase kernels (hybrid off) -- both forms are held to the oracle at level 4 above
+            def sec_config4_level5():
+                refine5 = np.zeros(8 ** 5, dtype=bool)
+                refine5[::64] = True
+                for name, mk, alt in (("hanging_level5_p7", lambda: M.HangingBrickMesh(5, refine5, 7), 0),
+                                      ("mixed_p3_to_9_graded_level5", lambda: M.BrickMesh(5, graded_degrees(5)), 0)):
+                    m8 = mk()
+                    J8, rst8 = m8.geometry(None); s8 = m8.build_sides(None)
+                    x8 = torch.from_numpy(m8.field()).to(dev)
+                    res8 = {}
+                    for key, k14 in (("default", -1), ("other", alt)):
+                        if key == "other" and args.no_check:
+                            continue
+                        p8 = Plan(m8.deg, m8.deg_quad, m8.nodal_stride, m8.quad_stride, 0, stream=stream)
+                        p8.set_tuning(14, k14); p8.set_geometry(J8, rst8); p8.set_tuning(7, 0); p8.set_faces(s8)
+                        y8 = torch.empty_like(x8)
+                        ms8 = time_region(lambda: p8.apply_aij(x8, y8), 10, stream, torch, warm=3)
+                        res8[key] = (ms8, y8, p8.face_path())
+                        p8.destroy()
+                    g8 = None
+                    if "other" in res8:
+                        g8 = float((res8["default"][1] - res8["other"][1]).abs().max() / res8["other"][1].abs().max())
+                        log("parity gate %s: default path [%s] against [%s]: rel-inf = %.3e" % (name, res8["default"][2][:40], res8["other"][2][:40], g8))
+                        if not g8 <= 1e-12:
+                            raise RuntimeError("%s: the two operator paths differ by %.3e" % (name, g8))
+                    by8 = mixed_operator_bytes(m8, s8)
+                    ms8 = res8["default"][0]
+                    sec[name] = {"dofs": m8.local_nodes, "elements": m8.n_elements, "apply_aij_ms": ms8,
+                                 "apply_aij_GDoF_per_s": m8.local_nodes / (ms8 * 1e-3) / 1e9, "algorithmic_bytes_per_dof": by8 / m8.local_nodes,
+                                 "roofline_frac_hbm": by8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "face_path": res8["default"][2],
+                                 "parity_gate_rel_inf_vs_other_path": g8,
+                                 "apply_aij_ms_other_path": res8["other"][0] if "other" in res8 else None}
+                    del x8, res8
+            if args.geometry != "sine":
+                try:
+                    sec_config4_level5()
+                except Exception as exc:
+                    log("secondary config4 level 5 failed: %r" % (exc,))
+                    sec["hanging_level5_p7"] = sec.get("hanging_level5_p7", {"error": repr(exc)})
             # BASELINE config 5's mesh class AT SIZE: the reference's 7-tree cubed sphere, level 3 (3584 curved elements, 14.7 MDoF), p = 15, every
             # geometric factor (volume metric and mortar factors through the oriented tree faces) generated on the device from the analytic
             # map; side list from d4est_hip_build_sides.  Gate: the oracle on shards of 4 elements with host-computed factors.

@@ -2695,6 +2695,7 @@ void faces_setup(d4est_hip_plan* plan) {
     // (round 4: with several clean buckets the default keeps the LARGEST one where it holds at least half of the mesh -- a mesh with one
     // dominant degree -- and leaves the other buckets' elements to the two-phase lists)
     int clean_buckets = 0;
+    bool all_buckets = false;
     {
       std::vector<int> cnt(plan->buckets.size(), 0);
       for (int e = 0; e < ne; ++e)
@@ -2704,14 +2705,20 @@ void faces_setup(d4est_hip_plan* plan) {
         if (cnt[b] > 0) ++clean_buckets;
         if (best < 0 || cnt[b] > cnt[best]) best = (int)b;
       }
-      if (plan->tuning[D4EST_HIP_TUNE_HYBRID] < 0 && clean_buckets > 1 && best >= 0 && 2 * (size_t)cnt[best] >= (size_t)ne &&
-          !std::getenv("D4EST_HIP_HYBRID_ONE_BUCKET_ONLY")) {
+      // ... and, at size, every clean bucket: with thousands of clean elements per bucket the buckets' launches fill the chip and their
+      // latency no longer matters (level 5, 32 768 elements, graded p = 3 ... 9: two-phase 756 us, hybrid 691 us; hanging + plateaus 1033 -> 894 us;
+      // at level 4, 385 clean elements per bucket: 275 against 126 us)
+      const bool one_only = std::getenv("D4EST_HIP_HYBRID_ONE_BUCKET_ONLY") != nullptr;
+      if (plan->tuning[D4EST_HIP_TUNE_HYBRID] < 0 && clean_buckets > 1 && !one_only && 2 * (size_t)n_clean >= (size_t)ne &&
+          (size_t)n_clean >= (size_t)2048 * clean_buckets) {
+        all_buckets = true;
+      } else if (plan->tuning[D4EST_HIP_TUNE_HYBRID] < 0 && clean_buckets > 1 && best >= 0 && 2 * (size_t)cnt[best] >= (size_t)ne && !one_only) {
         for (int e = 0; e < ne; ++e)
           if (clean[e] && bucket_of[e] != best) { clean[e] = 0; --n_clean; }
         clean_buckets = 1;
       }
     }
-    if (n_clean > 0 && (plan->tuning[D4EST_HIP_TUNE_HYBRID] > 0 || (clean_buckets == 1 && 2 * (size_t)n_clean >= (size_t)ne))) {
+    if (n_clean > 0 && (plan->tuning[D4EST_HIP_TUNE_HYBRID] > 0 || all_buckets || (clean_buckets == 1 && 2 * (size_t)n_clean >= (size_t)ne))) {
       std::vector<int> oC(plan->buckets.size(), -1), oCD(plan->buckets.size(), -1), oE(plan->buckets.size(), -1);
       for (size_t b = 0; b < plan->buckets.size(); ++b) {
         if (!bucket_ok[b]) continue;
