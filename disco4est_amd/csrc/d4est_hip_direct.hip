@@ -812,6 +812,7 @@ struct HybridHost {
   int* d_qs_by_elem = nullptr;
   int *d_dirty = nullptr, *d_ring = nullptr;
   int n_dirty = 0, n_ring = 0, n_clean_total = 0;
+  std::vector<int> h_dirty, h_ring;   // host copies (the face set-up splits them by kernel family, hybrid_host_lists)
   int *d_ns_dirty = nullptr, *d_qs_dirty = nullptr;   // bucket-ordered lists of the dirty elements (the volume kernels' view)
   std::vector<int> dirty_off, dirty_cnt;
   char path[96] = "";
@@ -964,6 +965,7 @@ void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const st
     if (in_ring[e]) ring.push_back(e);
   hh->d_dirty = hy_upload(dirty); hh->n_dirty = (int)dirty.size();
   hh->d_ring = hy_upload(ring); hh->n_ring = (int)ring.size();
+  hh->h_dirty = dirty; hh->h_ring = ring;
   hh->d_ns_dirty = hy_upload(ns_dirty);
   hh->d_qs_dirty = hy_upload(qs_dirty);
   std::snprintf(hh->path, sizeof(hh->path), "hybrid%s: direct+volume on %d clean elements, two-phase on %d", hh->hang ? " (hanging-aware)" : "", hh->n_clean_total, hh->n_dirty);
@@ -995,6 +997,10 @@ double* hybrid_second_vector(d4est_hip_plan* plan) {
   return hh->d_u2;
 }
 bool hybrid_hanging(const d4est_hip_plan* plan) { return hybrid_of(plan)->hang; }
+void hybrid_host_lists(const d4est_hip_plan* plan, const std::vector<int>** dirty, const std::vector<int>** ring) {
+  const HybridHost* hh = hybrid_of(plan);
+  *dirty = &hh->h_dirty; *ring = &hh->h_ring;
+}
 void hybrid_lists(const d4est_hip_plan* plan, const int** dirty, int* n_dirty, const int** ring, int* n_ring) {
   const HybridHost* hh = hybrid_of(plan);
   *dirty = hh->d_dirty; *n_dirty = hh->n_dirty; *ring = hh->d_ring; *n_ring = hh->n_ring;

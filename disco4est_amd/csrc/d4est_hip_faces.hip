@@ -2015,6 +2015,11 @@ struct FaceHost {
   bool family_split = false;
   int *d_fam_small = nullptr, *d_fam_big = nullptr;
   int n_fam_small = 0, n_fam_big = 0;
+  // ... and the hybrid operator's ring / dirty lists of such a plan, split the same way (the list launches of the two families; without them
+  // a listed launch sends every listed element through the tiled kernels: level 5, graded p = 3 ... 9, ring traces 396 us)
+  const int *hy_ring = nullptr, *hy_dirty = nullptr;   // the hybrid operator's device lists these belong to (matched by pointer)
+  int *d_ring_small = nullptr, *d_ring_big = nullptr, *d_dirty_small = nullptr, *d_dirty_big = nullptr;
+  int n_ring_small = 0, n_ring_big = 0, n_dirty_small = 0, n_dirty_big = 0;
 };
 std::map<d4est_hip_plan*, FaceHost> g_face_host;
 
@@ -2642,6 +2647,10 @@ void faces_setup(d4est_hip_plan* plan) {
   // one-kernel instance, all six sides conforming against a local element of the same degree or the boundary -- take the trace-free
   // whole-operator kernels of their degree bucket; one rank, plans whose two-phase kernels have list forms
   hybrid_destroy(plan);
+  (void)hipFree(fh.d_ring_small); (void)hipFree(fh.d_ring_big); (void)hipFree(fh.d_dirty_small); (void)hipFree(fh.d_dirty_big);
+  fh.d_ring_small = fh.d_ring_big = fh.d_dirty_small = fh.d_dirty_big = nullptr;
+  fh.n_ring_small = fh.n_ring_big = fh.n_dirty_small = fh.n_dirty_big = 0;
+  fh.hy_ring = fh.hy_dirty = nullptr;
   if (!plan->direct && ne > 0 && plan->n_ghost == 0 && plan->tuning[D4EST_HIP_TUNE_HYBRID] != 0 && plan->tuning[D4EST_HIP_TUNE_GHOST_ALIAS] <= 0 &&
       plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1 && (hp ? (fh.hp_split || (fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16)) : (fast || (fh.max_N <= 16 && fh.max_NQ <= 16)))) {
     std::vector<char> bucket_ok(plan->buckets.size(), 0), clean(ne, 0);
@@ -2729,6 +2738,30 @@ void faces_setup(d4est_hip_plan* plan) {
       for (size_t b = 0; b < plan->buckets.size(); ++b)
         if (oC[b] >= 0) { pC[b] = ops.data() + oC[b]; pCD[b] = ops.data() + oCD[b]; pE[b] = ops.data() + oE[b]; }
       hybrid_setup(plan, clean, pC, pCD, pE, any_ov ? &ov : nullptr);
+      if (fh.family_split) {
+        std::vector<char> is_small(ne, 0);
+        for (int e = 0; e < ne; ++e) {
+          bool sm = plan->deg[e] + 1 <= 8;
+          for (int f = 0; f < 6 && sm; ++f) {
+            const size_t s_ = 6 * (size_t)e + f;
+            sm = deg_mq_of[s_] + 1 <= 8 && deg_p_of[s_] + 1 <= 8;
+          }
+          is_small[e] = sm;
+        }
+        const std::vector<int>*hd, *hr;
+        hybrid_host_lists(plan, &hd, &hr);
+        std::vector<int> rs, rb, ds, db;
+        for (int e : *hr) (is_small[e] ? rs : rb).push_back(e);
+        for (int e : *hd) (is_small[e] ? ds : db).push_back(e);
+        fh.d_ring_small = upload_vec(rs); fh.n_ring_small = (int)rs.size();
+        fh.d_ring_big = upload_vec(rb); fh.n_ring_big = (int)rb.size();
+        fh.d_dirty_small = upload_vec(ds); fh.n_dirty_small = (int)ds.size();
+        fh.d_dirty_big = upload_vec(db); fh.n_dirty_big = (int)db.size();
+        const int *dd, *dr;
+        int nd_, nr_;
+        hybrid_lists(plan, &dd, &nd_, &dr, &nr_);
+        fh.hy_dirty = dd; fh.hy_ring = dr;
+      }
     }
   }
   const size_t tm = std::max<size_t>((size_t)plan->total_mortar_nodes, 1);
@@ -3142,6 +3175,11 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
                        (!fh.hp && ((plan->face_fast && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1) || (!plan->face_fast && fh.max_N <= 16 && fh.max_NQ <= 16))));
   if (!listed) elist = nullptr;
   const int n = listed ? n_list : plan->n_elements;
+  // the two conforming families' lists of this launch: the whole plan's, or the hybrid operator's ring list split the same way
+  const bool fam = fh.family_split && (!elist || (elist == fh.hy_ring && fh.d_ring_small));
+  const int* fam_small = elist ? fh.d_ring_small : fh.d_fam_small;
+  const int* fam_big = elist ? fh.d_ring_big : fh.d_fam_big;
+  const int n_fam_small = elist ? fh.n_ring_small : fh.n_fam_small, n_fam_big = elist ? fh.n_ring_big : fh.n_fam_big;
   if (parts != 3 && !(fh.hp && fh.hp_split)) D4EST_HIP_ABORT("launch_traces: parts = %d on a plan without the hp split", parts);
   if (n == 0 && !(fh.hp && fh.hp_split && (parts & 2))) return;
   if (fh.hp && fh.hp_split) {
@@ -3160,13 +3198,16 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
       const size_t lds = (size_t)(max_local_n * 272 + 3 * 2 * 16 * 34) * sizeof(double);
       if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
-      if (fh.family_split && !elist) {
-        const int ns_ = fh.n_fam_small, resident = 8 * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
-        hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
-                           (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, ns_, (const int*)fh.d_fam_small);
-        hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(fh.n_fam_big, per_cu * cus)), dim3(192), lds, plan->stream, u, trace,
-                           (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.n_fam_big, max_local_n,
-                           (const int*)fh.d_fam_big);
+      if (fam) {
+        if (n_fam_small > 0) {
+          const int ns_ = n_fam_small, resident = 8 * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
+          hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
+                             (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, ns_, fam_small);
+        }
+        if (n_fam_big > 0)
+          hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(n_fam_big, per_cu * cus)), dim3(192), lds, plan->stream, u, trace,
+                             (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n_fam_big, max_local_n,
+                             fam_big);
       } else {
         hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(n, per_cu * cus)), dim3(192), lds, plan->stream, u, trace,
                            (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n, max_local_n, elist);
@@ -3210,20 +3251,21 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
     else
       hipLaunchKernelGGL(trace_wave_kernel, dim3(grid), dim3(384), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
                          (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, n, fh.uni);
-  } else if (fh.family_split && !elist && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+  } else if (fam && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-    {
-      const int ns_ = fh.n_fam_small, resident = 8 * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
+    if (n_fam_small > 0) {
+      const int ns_ = n_fam_small, resident = 8 * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
       hipLaunchKernelGGL(trace_mfma_kernel, dim3(grid), dim3(192), 0, plan->stream, u, trace, (const SideDesc*)plan->d_side_desc,
-                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, ns_, (const int*)fh.d_fam_small);
+                         (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, ns_, fam_small);
     }
     const int max_local_n = fh.max_local_N;
     const size_t lds = (size_t)(max_local_n * 272 + 3 * 2 * 16 * 34) * sizeof(double);
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trace_mfma16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
-    hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(fh.n_fam_big, per_cu * cus)), dim3(192), lds, plan->stream, u, trace,
-                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, fh.n_fam_big, max_local_n,
-                       (const int*)fh.d_fam_big);
+    if (n_fam_big > 0)
+      hipLaunchKernelGGL(trace_mfma16_kernel, dim3(std::min(n_fam_big, per_cu * cus)), dim3(192), lds, plan->stream, u, trace,
+                         (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, n_fam_big, max_local_n,
+                         fam_big);
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     // p = 8 .. 15: tiled MFMA trace kernel (descriptors with unpadded N x N derivative matrices)
     // only local elements are copied to LDS: size the copy of u by the largest LOCAL degree
@@ -3261,6 +3303,11 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
   if (parts != 3 && !(fh.hp && fh.hp_split)) D4EST_HIP_ABORT("launch_flux: parts = %d on a plan without the hp split", parts);
   if (n == 0 && !(fh.hp && fh.hp_split && (parts & 2))) return;
   if (elist && cf) D4EST_HIP_ABORT("launch_flux: a fused update cannot ride on an element list");
+  // the two conforming families' lists of this launch: the whole plan's, or the hybrid operator's dirty list split the same way
+  const bool fam = fh.family_split && (!elist || (elist == fh.hy_dirty && fh.d_dirty_small));
+  const int* fam_small = elist ? fh.d_dirty_small : fh.d_fam_small;
+  const int* fam_big = elist ? fh.d_dirty_big : fh.d_fam_big;
+  const int n_fam_small = elist ? fh.n_dirty_small : fh.n_fam_small, n_fam_big = elist ? fh.n_dirty_big : fh.n_fam_big;
   if (fh.hp && fh.hp_split) {
     // hp split (see launch_traces): the conforming sides' terms from the fast kernel, then the hanging sides' from the record kernel
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
@@ -3274,14 +3321,17 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
                          (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom,
                          plan->d_bndry, fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n, chunk_s, ChebyFuse{}, elist);
     } else if (n > 0 && (parts & 1)) {
-      if (fh.family_split && !elist) {
-        const int ns_ = fh.n_fam_small, resident = face_wg_per_cu() * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
-        hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
-                           (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
-                           fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, ns_, 0, ChebyFuse{}, (const int*)fh.d_fam_small);
-        hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(std::min(fh.n_fam_big, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
-                           (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
-                           fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_fam_big, 0, ChebyFuse{}, (const int*)fh.d_fam_big);
+      if (fam) {
+        if (n_fam_small > 0) {
+          const int ns_ = n_fam_small, resident = face_wg_per_cu() * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
+          hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
+                             (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
+                             fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, ns_, 0, ChebyFuse{}, fam_small);
+        }
+        if (n_fam_big > 0)
+          hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(std::min(n_fam_big, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
+                             (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
+                             fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n_fam_big, 0, ChebyFuse{}, fam_big);
       } else {
         hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(std::min(n, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
                            (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
@@ -3334,17 +3384,18 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     else if (subdomain_plan) D4EST_HIP_LAUNCH_FLUX_WAVE(false, false, ChebyFuse{});
     else D4EST_HIP_LAUNCH_FLUX_WAVE(false, true, ChebyFuse{});
 #undef D4EST_HIP_LAUNCH_FLUX_WAVE
-  } else if (fh.family_split && !elist && !cf && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+  } else if (fam && !cf && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
-    {
-      const int ns_ = fh.n_fam_small, resident = face_wg_per_cu() * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
+    if (n_fam_small > 0) {
+      const int ns_ = n_fam_small, resident = face_wg_per_cu() * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
       hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
                          (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
-                         fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, ns_, 0, ChebyFuse{}, (const int*)fh.d_fam_small);
+                         fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, ns_, 0, ChebyFuse{}, fam_small);
     }
-    hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(std::min(fh.n_fam_big, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
-                       (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
-                       fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, fh.n_fam_big, 0, ChebyFuse{}, (const int*)fh.d_fam_big);
+    if (n_fam_big > 0)
+      hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(std::min(n_fam_big, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
+                         (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
+                         fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n_fam_big, 0, ChebyFuse{}, fam_big);
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int grid16 = std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256));
     static const bool no_remap16 = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
@@ -3413,6 +3464,7 @@ void faces_destroy(d4est_hip_plan* plan) {
     (void)hipFree(fh.d_fam_small); (void)hipFree(fh.d_fam_big);
     (void)hipFree(fh.d_rec); (void)hipFree(fh.d_gsrc); (void)hipFree(fh.d_elem_first); (void)hipFree(fh.d_side_first); (void)hipFree(fh.d_hp_ops); (void)hipFree(fh.d_hang_elems);
     (void)hipFree(fh.d_units); (void)hipFree(fh.d_unit_first);
+    (void)hipFree(fh.d_ring_small); (void)hipFree(fh.d_ring_big); (void)hipFree(fh.d_dirty_small); (void)hipFree(fh.d_dirty_big);
     g_face_host.erase(it);
   }
   (void)hipFree(plan->d_elem_desc);

@@ -237,7 +237,8 @@ bool hybrid_pair_built(int N, int NQ);
 struct HybridSideOverride { int kind; long long goff; int export_off; int geom; };
 void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const std::vector<const double*>& C, const std::vector<const double*>& CD,
                   const std::vector<const double*>& E, const std::vector<HybridSideOverride>* ov = nullptr);
-bool hybrid_hanging(const d4est_hip_plan* plan);   // the clean kernels read / write the trace array: record traces before, record flux after them
+bool hybrid_hanging(const d4est_hip_plan* plan);
+void hybrid_host_lists(const d4est_hip_plan* plan, const std::vector<int>** dirty, const std::vector<int>** ring);   // host copies of hybrid_lists   // the clean kernels read / write the trace array: record traces before, record flux after them
 void hybrid_destroy(d4est_hip_plan* plan);
 bool hybrid_active(const d4est_hip_plan* plan);
 const char* hybrid_path(const d4est_hip_plan* plan);
