@@ -10,7 +10,7 @@ struct DirectSide {
                        // (or, hanging-aware form, a small hanging side: the (+) block in the trace array), 3 (hanging-aware form) served elsewhere;
                        // code = flip0 | flip1<<1 | transpose<<2 applied when reading the (+) side; fp = face of the (+) element
   int nbr_ns;          // nodal offset of the (+) element (kind 1); hanging-aware form, kind 2: where the side's own mortar-node block is
-                       // exported to in the trace array
+                       // exported to in the trace array (-1: no export -- mixed-aware sides, whose block the ring's trace kernel writes)
   int geom;            // scalar offset of the side's mortar data (7 combined factors at 7*geom; Dirichlet / Robin data at geom)
   int pad;
 };

@@ -349,8 +349,9 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
         direct_load_geom<T, (VOL & 8) != 0, (VOL & 16) != 0>(gq, kind, true, k, sgeom[h], geom, robin_c);
 #endif
         if constexpr ((VOL & 16) != 0) {
-          if (kind == 2) {   // export the side's own mortar-node block (wave-uniform branch)
-            double* __restrict__ tp = const_cast<double*>((const double*)K->ghost_qtrace) + sd[2 * d + h].nbr_ns;
+          const int xoff = sd[2 * d + h].nbr_ns;
+          if (kind == 2 && xoff >= 0) {   // export the side's own mortar-node block (wave-uniform branch)
+            double* __restrict__ tp = const_cast<double*>((const double*)K->ghost_qtrace) + xoff;
 #pragma unroll
             for (int c = 0; c < 4; ++c) tp[c * T + k] = qm[c];
           }
@@ -854,7 +855,7 @@ static T* hy_upload(const std::vector<T>& v) {
 
 // clean[e]: 1 = the element takes the one-kernel path.  tables(bucket) -> {C, CD, E} of the bucket's degree (host pointers, NQ x N / N x NQ)
 void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const std::vector<const double*>& C, const std::vector<const double*>& CD,
-                  const std::vector<const double*>& E, const std::vector<HybridSideOverride>* ov) {
+                  const std::vector<const double*>& E, const std::vector<HybridSideOverride>* ov, const char* form) {
   hybrid_destroy(plan);
   const int ne = plan->n_elements;
   HybridHost* hh = new HybridHost;
@@ -968,7 +969,9 @@ void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const st
   hh->h_dirty = dirty; hh->h_ring = ring;
   hh->d_ns_dirty = hy_upload(ns_dirty);
   hh->d_qs_dirty = hy_upload(qs_dirty);
-  std::snprintf(hh->path, sizeof(hh->path), "hybrid%s: direct+volume on %d clean elements, two-phase on %d", hh->hang ? " (hanging-aware)" : "", hh->n_clean_total, hh->n_dirty);
+  char tag[32] = "";
+  if (hh->hang) std::snprintf(tag, sizeof(tag), " (%s)", form);
+  std::snprintf(hh->path, sizeof(hh->path), "hybrid%s: direct+volume on %d clean elements, two-phase on %d", tag, hh->n_clean_total, hh->n_dirty);
   plan->hybrid = hh;
 }
 

@@ -2659,9 +2659,14 @@ void faces_setup(d4est_hip_plan* plan) {
     // a small side the split handed to the conforming kernels, the direct kernel reads the big element's sub-mortar block from the trace
     // array and exports its own (kind 2); D4EST_HIP_HYBRID_NO_HANGING=1 keeps every element with a hanging side dirty
     const bool hang_aware = hp && fh.hp_split && fh.hp_split_fast && !std::getenv("D4EST_HIP_HYBRID_NO_HANGING") && plan->local_trace_doubles < (1LL << 31);
+    // mixed-aware form: a conforming side against a local element of LOWER degree does not make the (one-wavefront) element dirty either --
+    // the mortar is the element's own (d4est's rule: the larger degree), its operators are the same-degree ones, and the (+) block, which the
+    // lower-degree neighbour's trace kernel interpolates up to that mortar, is read from the trace array like a ghost block (kind 2; the
+    // neighbour itself stays dirty: ITS side sees a mortar above its own degree).  D4EST_HIP_HYBRID_NO_MIXED=1 switches it off
+    const bool mixed_aware = (!hp || fh.hp_split) && !std::getenv("D4EST_HIP_HYBRID_NO_MIXED") && plan->local_trace_doubles < (1LL << 31);
     std::vector<HybridSideOverride> ov;
-    if (hang_aware) ov.assign(ns, HybridSideOverride{-1, 0, 0, 0});
-    bool any_ov = false;
+    if (hang_aware || mixed_aware) ov.assign(ns, HybridSideOverride{-1, 0, 0, 0});
+    bool any_ov = false, any_hang_ov = false, any_mixed_ov = false;
     for (size_t b = 0; b < plan->buckets.size(); ++b) {
       const Bucket& bk = plan->buckets[b];
       bucket_ok[b] = bk.N == bk.NQ && bk.d_EBf && hybrid_pair_built(bk.N, bk.NQ);
@@ -2688,13 +2693,26 @@ void faces_setup(d4est_hip_plan* plan) {
         if (nbr == -1) continue;                                   // domain boundary
         if (nbr < 0) { ok = false; break; }                        // (ghost: not on one-rank plans)
         const size_t sp = 6 * (size_t)nbr + plan->side_nbr_face[s_];
+        if (mixed_aware && plan->buckets[bucket_of[e]].N <= 8 && plan->deg[nbr] < plan->deg[e] && plan->deg_quad[nbr] <= plan->deg_quad[e] &&
+            deg_mq_of[s_] == plan->deg_quad[e] && !(hp && plan->side_hang[sp] != 0) && sd[s_].kind == 1 && sd[s_].NQ == plan->buckets[bucket_of[e]].NQ) {
+          // (no export: the neighbour is dirty, so this element is in the ring and the trace kernel writes its block -- an export from the
+          // clean kernel could race with the dirty flux kernel reading that block on another stream)
+          ov[s_] = HybridSideOverride{2, sd[s_].nbr_qoff, -1, sd[s_].geom};
+          continue;
+        }
         ok = plan->deg[nbr] == plan->deg[e] && plan->deg_quad[nbr] == plan->deg_quad[e] && deg_mq_of[s_] == plan->deg_quad[e] &&
              !(hp && plan->side_hang[sp] != 0);
       }
       clean[e] = ok;
       n_clean += ok;
-      if (ok && hang_aware)
-        for (int f = 0; f < 6; ++f) any_ov = any_ov || ov[6 * (size_t)e + f].kind >= 0;
+      if (ok && (hang_aware || mixed_aware))
+        for (int f = 0; f < 6; ++f) {
+          const size_t s_ = 6 * (size_t)e + f;
+          if (ov[s_].kind < 0) continue;
+          any_ov = true;
+          if (hp && plan->side_hang[s_] != 0) any_hang_ov = true;
+          else any_mixed_ov = true;
+        }
     }
     // default: only where it was measured to pay -- ONE clean degree bucket holding at least half of the elements (a locally refined mesh of
     // one degree: level 4, p = 7, every 64th octant refined 144 -> 125 us).  With several clean buckets every bucket is its own launch of
@@ -2714,12 +2732,14 @@ void faces_setup(d4est_hip_plan* plan) {
         if (cnt[b] > 0) ++clean_buckets;
         if (best < 0 || cnt[b] > cnt[best]) best = (int)b;
       }
-      // ... and, at size, every clean bucket: with thousands of clean elements per bucket the buckets' launches fill the chip and their
+      // ... and, at size (every clean bucket holds at least 2048 clean elements), every clean bucket: with thousands of clean elements per bucket the buckets' launches fill the chip and their
       // latency no longer matters (level 5, 32 768 elements, graded p = 3 ... 9: two-phase 756 us, hybrid 691 us; hanging + plateaus 1033 -> 894 us;
       // at level 4, 385 clean elements per bucket: 275 against 126 us)
       const bool one_only = std::getenv("D4EST_HIP_HYBRID_ONE_BUCKET_ONLY") != nullptr;
-      if (plan->tuning[D4EST_HIP_TUNE_HYBRID] < 0 && clean_buckets > 1 && !one_only && 2 * (size_t)n_clean >= (size_t)ne &&
-          (size_t)n_clean >= (size_t)2048 * clean_buckets) {
+      int min_cnt = ne;
+      for (size_t b = 0; b < cnt.size(); ++b)
+        if (cnt[b] > 0) min_cnt = std::min(min_cnt, cnt[b]);
+      if (plan->tuning[D4EST_HIP_TUNE_HYBRID] < 0 && clean_buckets > 1 && !one_only && 2 * (size_t)n_clean >= (size_t)ne && min_cnt >= 2048) {
         all_buckets = true;
       } else if (plan->tuning[D4EST_HIP_TUNE_HYBRID] < 0 && clean_buckets > 1 && best >= 0 && 2 * (size_t)cnt[best] >= (size_t)ne && !one_only) {
         for (int e = 0; e < ne; ++e)
@@ -2737,7 +2757,9 @@ void faces_setup(d4est_hip_plan* plan) {
       std::vector<const double*> pC(plan->buckets.size(), nullptr), pCD(plan->buckets.size(), nullptr), pE(plan->buckets.size(), nullptr);
       for (size_t b = 0; b < plan->buckets.size(); ++b)
         if (oC[b] >= 0) { pC[b] = ops.data() + oC[b]; pCD[b] = ops.data() + oCD[b]; pE[b] = ops.data() + oE[b]; }
-      hybrid_setup(plan, clean, pC, pCD, pE, any_ov ? &ov : nullptr);
+      // (the flags describe the classification before the dominant-bucket rule demoted anybody: a label, not a contract)
+      hybrid_setup(plan, clean, pC, pCD, pE, any_ov ? &ov : nullptr,
+                   any_hang_ov ? (any_mixed_ov ? "hanging-aware, mixed-aware" : "hanging-aware") : "mixed-aware");
       if (fh.family_split) {
         std::vector<char> is_small(ne, 0);
         for (int e = 0; e < ne; ++e) {
@@ -3446,6 +3468,10 @@ void launch_flux_units(d4est_hip_plan* plan, const double* trace, const double* 
   if (fh.hp_max_N <= 8) go(flux_unit_kernel<true, 8>, 8);
   else go(flux_unit_kernel<true, 16>, 2);
   HIP_CHECK(hipGetLastError());
+}
+bool faces_hp_split(d4est_hip_plan* plan) {
+  FaceHost& fh = g_face_host[plan];
+  return fh.hp && fh.hp_split;
 }
 bool faces_have_units(d4est_hip_plan* plan) {
   FaceHost& fh = g_face_host[plan];

@@ -236,7 +236,7 @@ bool hybrid_pair_built(int N, int NQ);
 // block exported to export_off, combined factors at geom; kind < 0: an ordinary side
 struct HybridSideOverride { int kind; long long goff; int export_off; int geom; };
 void hybrid_setup(d4est_hip_plan* plan, const std::vector<char>& clean, const std::vector<const double*>& C, const std::vector<const double*>& CD,
-                  const std::vector<const double*>& E, const std::vector<HybridSideOverride>* ov = nullptr);
+                  const std::vector<const double*>& E, const std::vector<HybridSideOverride>* ov = nullptr, const char* form = "hanging-aware");
 bool hybrid_hanging(const d4est_hip_plan* plan);
 void hybrid_host_lists(const d4est_hip_plan* plan, const std::vector<int>** dirty, const std::vector<int>** ring);   // host copies of hybrid_lists   // the clean kernels read / write the trace array: record traces before, record flux after them
 void hybrid_destroy(d4est_hip_plan* plan);
@@ -249,7 +249,8 @@ bool hybrid_can_fuse_update(const d4est_hip_plan* plan);   // the Chebyshev upda
 double* hybrid_second_vector(d4est_hip_plan* plan);
 // the record flux kernel of an hp-split plan alone, optionally with the Chebyshev update of the elements it serves in its epilogue
 void launch_flux_units(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf);
-bool faces_have_units(d4est_hip_plan* plan);   // hp split with the unit record kernels (the form that can carry the update)
+bool faces_have_units(d4est_hip_plan* plan);
+bool faces_hp_split(d4est_hip_plan* plan);   // the plan has record kernels beside the conforming ones (launch_traces / launch_flux take `parts`)   // hp split with the unit record kernels (the form that can carry the update)
 void launch_hybrid_dirty_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
 void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, int phase, const DirectFuse* cf = nullptr);   // (faces.hip: supplies the Robin arrays; phase 0 fork + launches, 1 join)
 void faces_destroy(d4est_hip_plan* plan);

@@ -181,14 +181,17 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
       // hanging-aware form (a locally refined plan under the hp split): elements with hanging sides are clean too.  The record trace
       // kernel goes first (the clean kernel reads the big elements' sub-mortar blocks for its small sides), the record flux kernel last
       // (it adds the big sides' terms to rows the clean kernel writes, from small-side blocks that kernel exports).
-      launch_traces(plan, u, plan->d_trace, false, ring, n_ring, n_dirty > 0 ? 3 : 2);
+      // (mixed-aware form on a plan without hanging faces: no record kernels, the two-phase kernels whole)
+      const bool rec = faces_hp_split(plan);
+      if (rec) launch_traces(plan, u, plan->d_trace, false, ring, n_ring, n_dirty > 0 ? 3 : 2);
+      else if (n_dirty > 0) launch_traces(plan, u, plan->d_trace, false, ring, n_ring);
       launch_flux_hybrid_clean(plan, u, plan->d_trace, Au, 0);
       if (n_dirty > 0) {
         launch_hybrid_dirty_stiffness(plan, u, Au);
-        launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, nullptr, dirty, n_dirty, 1);
+        launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, nullptr, dirty, n_dirty, rec ? 1 : 3);
       }
       launch_flux_hybrid_clean(plan, u, plan->d_trace, Au, 1);
-      launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, nullptr, dirty, n_dirty, 2);
+      if (rec) launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, nullptr, dirty, n_dirty, 2);
       if (lhs_term) add_lhs_mass_term(plan, u, Au);
       return;
     }
