@@ -2732,14 +2732,23 @@ void faces_setup(d4est_hip_plan* plan) {
         if (cnt[b] > 0) ++clean_buckets;
         if (best < 0 || cnt[b] > cnt[best]) best = (int)b;
       }
-      // ... and, at size (every clean bucket holds at least 2048 clean elements), every clean bucket: with thousands of clean elements per bucket the buckets' launches fill the chip and their
+      // ... and, at size, every clean bucket of at least 2048 clean elements (the smaller buckets' elements stay two-phase): with thousands of clean elements per bucket the buckets' launches fill the chip and their
       // latency no longer matters (level 5, 32 768 elements, graded p = 3 ... 9: two-phase 756 us, hybrid 691 us; hanging + plateaus 1033 -> 894 us;
       // at level 4, 385 clean elements per bucket: 275 against 126 us)
       const bool one_only = std::getenv("D4EST_HIP_HYBRID_ONE_BUCKET_ONLY") != nullptr;
-      int min_cnt = ne;
+      if (std::getenv("D4EST_HIP_DEBUG_HYBRID")) {
+        std::fprintf(stderr, "[d4est_hip] hybrid classification: %d of %d elements clean, per bucket:", n_clean, ne);
+        for (size_t b = 0; b < cnt.size(); ++b) std::fprintf(stderr, " N=%d:%d/%d", plan->buckets[b].N, cnt[b], plan->buckets[b].n_elem);
+        std::fprintf(stderr, "\n");
+      }
+      // the buckets that are worth a launch of their own at size: at least 2048 clean elements each
+      int n_kept = 0;
+      size_t kept_sum = 0;
       for (size_t b = 0; b < cnt.size(); ++b)
-        if (cnt[b] > 0) min_cnt = std::min(min_cnt, cnt[b]);
-      if (plan->tuning[D4EST_HIP_TUNE_HYBRID] < 0 && clean_buckets > 1 && !one_only && 2 * (size_t)n_clean >= (size_t)ne && min_cnt >= 2048) {
+        if (cnt[b] >= 2048) { ++n_kept; kept_sum += (size_t)cnt[b]; }
+      if (plan->tuning[D4EST_HIP_TUNE_HYBRID] < 0 && clean_buckets > 1 && !one_only && n_kept >= 2 && 2 * kept_sum >= (size_t)ne) {
+        for (int e = 0; e < ne; ++e)
+          if (clean[e] && cnt[bucket_of[e]] < 2048) { clean[e] = 0; --n_clean; }   // (small buckets' elements: two-phase)
         all_buckets = true;
       } else if (plan->tuning[D4EST_HIP_TUNE_HYBRID] < 0 && clean_buckets > 1 && best >= 0 && 2 * (size_t)cnt[best] >= (size_t)ne && !one_only) {
         for (int e = 0; e < ne; ++e)
