@@ -908,14 +908,17 @@ def main():
                     log("secondary config4_mesh_class_level4 failed: %r" % (exc,))
                     sec["config4_mesh_class_level4"] = {"error": repr(exc)}
             # config 4's mesh class AT SIZE (level 5: the throughput regime; at level 4 every kernel of these paths sits on its latency floor):
-            # the locally refined p = 7 brick (36 352 elements, 18.6 MDoF) and the graded p = 3 ... 9 brick (32 768 elements, 13.6 MDoF), default
+            # the locally refined p = 7 brick (36 352 elements, 18.6 MDoF), the graded p = 3 ... 9 brick (32 768 elements, 13.6 MDoF) and both at once
+            # (graded degrees AND every 64th octant refined: the class proper), default
             # paths (at this size the hybrid operator on both: thousands of clean elements per degree bucket); gate: the same operator through
             # the two-phase kernels (hybrid off) -- both forms are held to the oracle at level 4 above
             def sec_config4_level5():
                 refine5 = np.zeros(8 ** 5, dtype=bool)
                 refine5[::64] = True
+                gd5 = graded_degrees(5)
                 for name, mk, alt in (("hanging_level5_p7", lambda: M.HangingBrickMesh(5, refine5, 7), 0),
-                                      ("mixed_p3_to_9_graded_level5", lambda: M.BrickMesh(5, graded_degrees(5)), 0)):
+                                      ("mixed_p3_to_9_graded_level5", lambda: M.BrickMesh(5, gd5), 0),
+                                      ("config4_mesh_class_level5", lambda: M.HangingBrickMesh(5, refine5, np.concatenate([np.full(8 if refine5[b] else 1, gd5[b]) for b in range(8 ** 5)]).astype(np.int32)), 0)):
                     m8 = mk()
                     J8, rst8 = m8.geometry(None); s8 = m8.build_sides(None)
                     x8 = torch.from_numpy(m8.field()).to(dev)

@@ -2658,7 +2658,9 @@ void faces_setup(d4est_hip_plan* plan) {
     // hanging-aware form (hp split active): a hanging side does not make an element dirty -- the record kernels serve it (kind 3) or,
     // a small side the split handed to the conforming kernels, the direct kernel reads the big element's sub-mortar block from the trace
     // array and exports its own (kind 2); D4EST_HIP_HYBRID_NO_HANGING=1 keeps every element with a hanging side dirty
-    const bool hang_aware = hp && fh.hp_split && fh.hp_split_fast && !std::getenv("D4EST_HIP_HYBRID_NO_HANGING") && plan->local_trace_doubles < (1LL << 31);
+    // (plans with degrees above 7 under the generalised hp split: the elements of the one-wavefront buckets, N <= 8, only -- the multi-wave
+    // whole-operator kernel has no hanging-aware instance)
+    const bool hang_aware = hp && fh.hp_split && !std::getenv("D4EST_HIP_HYBRID_NO_HANGING") && plan->local_trace_doubles < (1LL << 31);
     // mixed-aware form: a conforming side against a local element of LOWER degree does not make the (one-wavefront) element dirty either --
     // the mortar is the element's own (d4est's rule: the larger degree), its operators are the same-degree ones, and the (+) block, which the
     // lower-degree neighbour's trace kernel interpolates up to that mortar, is read from the trace array like a ghost block (kind 2; the
@@ -2679,7 +2681,7 @@ void faces_setup(d4est_hip_plan* plan) {
       for (int f = 0; f < 6 && ok; ++f) {
         const size_t s_ = 6 * (size_t)e + f;
         if (hp && plan->side_hang[s_] != 0) {
-          if (!hang_aware) { ok = false; break; }
+          if (!hang_aware || plan->buckets[bucket_of[e]].N > 8) { ok = false; break; }
           const SideDesc& d = sd[s_];
           if (d.kind == 3) { ov[s_] = HybridSideOverride{3, 0, 0, 0}; continue; }   // (the element is on the record kernels' list)
           if (d.kind == 1 && plan->side_hang[s_] == 2 && d.NQ == plan->buckets[bucket_of[e]].NQ && deg_p_of[s_] == plan->deg[e]) {
