@@ -317,3 +317,28 @@ def test_default_path_with_one_dominant_degree(gpu, hiplib, oracle):
         plan.destroy()
     finally:
         del os.environ["D4EST_HIP_HYBRID_ONE_BUCKET_ONLY"]
+
+
+@pytest.mark.parametrize("kind", ["hanging_mixed", "hanging_p4"])
+def test_hybrid_chebyshev_graph_replay(gpu, hiplib, kind):
+    """tuning key 9 = 1 (cheby_iterate captured into a hipGraph and replayed) on the hybrid operator: the clean buckets' side streams join
+    the capture through their fork / join events, the hanging-aware form carries the fused update -- bit-identical to the plain stream"""
+    import torch
+    from disco4est_amd import Plan, mesh as M
+    m = _mesh(kind)
+    J, rst = m.geometry(None); sides = m.build_sides(None)
+    st = torch.cuda.current_stream()
+    rhs = _t(M.splitmix64_uniform(5, m.local_nodes) - 0.5, gpu)
+    out = {}
+    for graph in (0, 1):
+        p = Plan(m.deg, m.deg_quad, m.nodal_stride, m.quad_stride, 0, stream=st)
+        p.set_tuning(14, 1); p.set_tuning(9, graph)
+        p.set_geometry(J, rst); p.set_faces(sides, 10.0, 0)
+        assert p.face_path().startswith("hybrid")
+        x = torch.zeros_like(rhs); Au = torch.empty_like(rhs); r = torch.empty_like(rhs)
+        for _ in range(3):      # (the second and third call replay the captured graph)
+            x.zero_(); p.cheby_iterate(x, rhs, Au, r, 5, 1.0, 40.0, 0)
+        torch.cuda.synchronize()
+        out[graph] = (x.clone(), r.clone())
+        p.destroy()
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
