@@ -3321,7 +3321,7 @@ void launch_traces(d4est_hip_plan* plan, const double* u, double* trace, bool gh
 // true when launch_flux runs the kernel that can carry the Chebyshev update in its epilogue
 bool flux_can_fuse_update(d4est_hip_plan* plan) {
   FaceHost& fh = g_face_host[plan];
-  return plan->has_faces && plan->n_elements > 0 && !fh.hp && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && !hybrid_active(plan) && !fh.family_split &&
+  return plan->has_faces && plan->n_elements > 0 && !fh.hp && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && !hybrid_active(plan) &&
          (plan->face_fast || (fh.max_N <= 16 && fh.max_NQ <= 16));
 }
 
@@ -3417,18 +3417,27 @@ void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_
     else if (subdomain_plan) D4EST_HIP_LAUNCH_FLUX_WAVE(false, false, ChebyFuse{});
     else D4EST_HIP_LAUNCH_FLUX_WAVE(false, true, ChebyFuse{});
 #undef D4EST_HIP_LAUNCH_FLUX_WAVE
-  } else if (fam && !cf && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+  } else if (fam && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
+    // (cf: the Chebyshev update in both families' epilogues -- every element is on exactly one of the two lists)
     const int cus = plan->n_cus > 0 ? plan->n_cus : 256;
+    const ChebyFuse cfv = cf ? *cf : ChebyFuse{};
     if (n_fam_small > 0) {
       const int ns_ = n_fam_small, resident = face_wg_per_cu() * cus, rounds = (ns_ + resident - 1) / resident, grid = (ns_ + rounds - 1) / rounds;
-      hipLaunchKernelGGL((flux_wave_kernel<false, true>), dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
-                         (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
-                         fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, ns_, 0, ChebyFuse{}, fam_small);
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(384), 0, plan->stream, trace, ghost_trace, Au,
+                           (const SideDesc*)plan->d_side_desc, (const ElemDesc*)plan->d_elem_desc, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
+                           fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, ns_, 0, cfv, fam_small);
+      };
+      if (cf) go(flux_wave_kernel<true, true>); else go(flux_wave_kernel<false, true>);
     }
-    if (n_fam_big > 0)
-      hipLaunchKernelGGL(flux_mfma16_kernel<false>, dim3(std::min(n_fam_big, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
-                         (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
-                         fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n_fam_big, 0, ChebyFuse{}, fam_big);
+    if (n_fam_big > 0) {
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(std::min(n_fam_big, 8 * cus)), dim3(192), 0, plan->stream, trace, ghost_trace, Au,
+                           (const SideDesc*)plan->d_side_desc, (const ElemDesc*)fh.d_elem_desc_generic, plan->d_face_ops, plan->d_face_geom, plan->d_bndry,
+                           fh.robin ? fh.d_robin_c : nullptr, fh.robin ? fh.d_robin_r : nullptr, n_fam_big, 0, cfv, fam_big);
+      };
+      if (cf) go(flux_mfma16_kernel<true>); else go(flux_mfma16_kernel<false>);
+    }
   } else if (fh.max_N <= 16 && fh.max_NQ <= 16 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0) {
     const int grid16 = std::min(n, 8 * (plan->n_cus > 0 ? plan->n_cus : 256));
     static const bool no_remap16 = std::getenv("D4EST_HIP_NO_XCD_REMAP") != nullptr;
