@@ -943,6 +943,7 @@ def main():
                     sec[name] = {"dofs": m8.local_nodes, "elements": m8.n_elements, "apply_aij_ms": ms8,
                                  "apply_aij_GDoF_per_s": m8.local_nodes / (ms8 * 1e-3) / 1e9, "algorithmic_bytes_per_dof": by8 / m8.local_nodes,
                                  "roofline_frac_hbm": by8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "face_path": res8["default"][2],
+                                 "traffic": (json.load(open(tf)) if os.path.exists(tf) else {}).get(name, {}).get("hbm_bytes_per_launch"),
                                  "parity_gate_rel_inf_vs_other_path": g8,
                                  "apply_aij_ms_other_path": res8["other"][0] if "other" in res8 else None}
                     del x8, res8
