@@ -107,13 +107,19 @@ struct DirectCfg {
 // one-wave workgroups take ~10 us to get going at config 2)
 constexpr int kDirectWPB = 4;
 
+#ifndef D4EST_HIP_DIRECT_NT_MASK
+#define D4EST_HIP_DIRECT_NT_MASK 7   /* stream mode (VOL & 8) of the one-wavefront kernel: which streams carry the non-temporal hint -- 1 the mortar factors, 2 the volume metric, 4 the A u stores (kernel experiments: tools/build_variant.sh) */
+#endif
 #ifndef D4EST_HIP_DIRECT_GEOM_EARLY
 #define D4EST_HIP_DIRECT_GEOM_EARLY 1   /* both faces' geometric factors requested: 0 at their use, 1 before the SIPG loop, 2 with the neighbour lines */
 #endif
 // the seven geometric-factor fields of a side at mortar node k (sj n_l / 2-weighted rows 0..5, penalty row 6), or the Robin coefficient
+#ifndef D4EST_HIP_DIRECT_GEOM_NT_RT
+#define D4EST_HIP_DIRECT_GEOM_NT_RT 1   /* 1: outside stream mode the mortar factors still take the non-temporal hint where the launch asks for it (DirectVol::stream bit 1, a wave-uniform branch around the batch of loads) */
+#endif
 template <int T, bool NT = false /* stream mode, d4est_hip_wave.h */, bool HANG = false /* kind 3 exists: a side another kernel serves */>
 __device__ __forceinline__ void direct_load_geom(double* gq, int kind, bool on, int k, int sgeom, const double* __restrict__ geom,
-                                                 const double* __restrict__ robin_c) {
+                                                 const double* __restrict__ robin_c, bool nt_rt = false) {
 #pragma unroll
   for (int c = 0; c < 7; ++c) gq[c] = 0.0;
   if (on && !(HANG && kind == 3)) {
@@ -121,8 +127,17 @@ __device__ __forceinline__ void direct_load_geom(double* gq, int kind, bool on, 
       gq[6] = robin_c[sgeom + k];   // am = ap = 0: no term 1 / term 2 on a Robin side
     } else {
       const double* __restrict__ g = geom + (size_t)7 * sgeom + k;
+      if (!NT && D4EST_HIP_DIRECT_GEOM_NT_RT && nt_rt) {
+        // (the pointer goes through an opaque copy: the two arms load the same addresses, and the compiler otherwise hoists ONE load out of
+        // them, dropping the hint)
+        const double* gn = g;
+        asm volatile("" : "+v"(gn));
 #pragma unroll
-      for (int c = 0; c < 7; ++c) gq[c] = ld_sel<NT>(&g[c * T]);
+        for (int c = 0; c < 7; ++c) gq[c] = __builtin_nontemporal_load(&gn[c * T]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) gq[c] = ld_sel<NT>(&g[c * T]);
+      }
     }
   }
 }
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 2
     double gqa[2][7];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) direct_load_geom<T, (VOL & 8) != 0, (VOL & 16) != 0>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], direct_kargs()->geom, direct_kargs()->robin_c);
+    for (int h = 0; h < 2; ++h) direct_load_geom<T, (VOL & 8) != 0 && (D4EST_HIP_DIRECT_NT_MASK & 1) != 0, (VOL & 16) != 0>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], direct_kargs()->geom, direct_kargs()->robin_c);
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -307,8 +322,9 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
     const double* __restrict__ robin_c = K->robin_c;
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 1
     double gqa[2][7];
+    const bool geom_nt = (VOL != 0) && (K->vol.stream & 2) != 0;   // (wave-uniform, see D4EST_HIP_DIRECT_GEOM_NT_RT)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) direct_load_geom<T, (VOL & 8) != 0, (VOL & 16) != 0>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], geom, robin_c);
+    for (int h = 0; h < 2; ++h) direct_load_geom<T, (VOL & 8) != 0 && (D4EST_HIP_DIRECT_NT_MASK & 1) != 0, (VOL & 16) != 0>(gqa[h], kcf[h] & 3, on_q, lane, sgeom[h], geom, robin_c, geom_nt);
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
           qp[0] = K->bndry_q[sgeom[h] + k];
         }
 #if D4EST_HIP_DIRECT_GEOM_EARLY == 0
-        direct_load_geom<T, (VOL & 8) != 0, (VOL & 16) != 0>(gq, kind, true, k, sgeom[h], geom, robin_c);
+        direct_load_geom<T, (VOL & 8) != 0 && (D4EST_HIP_DIRECT_NT_MASK & 1) != 0, (VOL & 16) != 0>(gq, kind, true, k, sgeom[h], geom, robin_c);
 #endif
         if constexpr ((VOL & 16) != 0) {
           const int xoff = sd[2 * d + h].nbr_ns;
@@ -493,7 +509,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
     {
       const DirectVol vl = direct_load_vol(direct_kargs());
       const int qs = __builtin_amdgcn_readfirstlane(vl.qs_stride >= 0 ? vl.qs0 + e * vl.qs_stride : vl.qs_list[e]);
-      stiffness_wave_eo_element<N, NQ, (VOL & 3) == 2, false, (VOL & 4) != 0, (VOL & 8) != 0>(s_U, s_S, vl.metric, qs, e, on_q, a, b, vl.EBf, vl.EGf, vl.EBb,
+      stiffness_wave_eo_element<N, NQ, (VOL & 3) == 2, false, (VOL & 4) != 0, (VOL & 8) != 0 && (D4EST_HIP_DIRECT_NT_MASK & 2) != 0>(s_U, s_S, vl.metric, qs, e, on_q, a, b, vl.EBf, vl.EGf, vl.EBb,
                                                                               vl.EGb, vl.affine, vl.wq, vl.cq);
     }
     if (on_m) {
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(64 * kDirectWPB, 4) void faces_direct_kernel(const 
       for (int i = 0; i < N; ++i) {
         const size_t o = (size_t)ns + a + N * b + N2 * i;
         const double au = s_U[a + PN * (b + N * i)] + facc[i];
-        if constexpr (!FUSE && (VOL & 8) != 0) __builtin_nontemporal_store(au, &Au_[o]);   // stream mode
+        if constexpr (!FUSE && (VOL & 8) != 0 && (D4EST_HIP_DIRECT_NT_MASK & 4) != 0) __builtin_nontemporal_store(au, &Au_[o]);   // stream mode
         else if (!FUSE || !cfl.skip_Au_store || !upd) Au_[o] = au;
         if (FUSE && upd) {   // the Chebyshev update of the node, as in the faces-only form
           const double res = __dadd_rn(rh[i], __dmul_rn(-1.0, au));
@@ -721,6 +737,15 @@ static void launch_direct_core(d4est_hip_plan* plan, DirectHost* dh, const Bucke
     vol.EBf = bk.d_EBf; vol.EGf = bk.d_EGf; vol.EBb = bk.d_EBb; vol.EGb = bk.d_EGb;
     vol.EDq = bk.d_EDq; vol.EDqT = bk.d_EDqT;
     vol.stream = plan->stream_mode;
+    {
+      // one-wavefront kernel outside stream mode: the mortar factors -- read once per apply, 42 B/DoF at p = 7 -- with the non-temporal hint
+      // (bit 1), so that the neighbours' u stays in the XCD's L2.  Measured (alternating runs): config 2 (222 MB per apply, fits the Infinity
+      // Cache) HBM traffic 275 -> 243 MB = 1.24 -> 1.09 x algorithmic but 51.6 -> 53.2 us; the hybrid operator on the locally refined
+      // p = 7 brick (306 MB with its trace array) 82.2 -> 79.4 us.  So: on for the hybrid operator's launches, off on uniform plans
+      // (D4EST_HIP_GEOM_NT = 0 never, 2 always; the hint on the metric or on A u alone changes neither traffic nor time)
+      static const int geom_nt = [] { const char* e = std::getenv("D4EST_HIP_GEOM_NT"); return e ? std::atoi(e) : 1; }();
+      if (!dh->mw && !vol.stream && (geom_nt == 2 || (geom_nt == 1 && hybrid))) vol.stream |= 2;
+    }
     // (measured, round 4: forcing the non-temporal hints on at config 2 -- 222 MB per apply, below the 320 MB threshold -- takes the HBM
     // traffic of this kernel from 275 to 242 MB = 1.24 -> 1.09 x algorithmic, the neighbours' u stays in the L2, but the kernel does not
     // get faster: 50.4 - 50.7 us without, 51.9 - 52.4 us with the hints in alternating runs; the threshold stays.
@@ -736,7 +761,7 @@ static void launch_direct_core(d4est_hip_plan* plan, DirectHost* dh, const Bucke
       vol.cq = ensure_lhs_wjc(plan);
       vmode |= 4;
     }
-    const char* sm = (!aff && vol_term != 2 && vol.stream) ? ",stream" : "";
+    const char* sm = (!aff && vol_term != 2 && (vol.stream & 1)) ? ",stream" : "";
     if (dh->mw) std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::operator_mw_kernel<%d,vol%s%s> (stiffness_wave_kernel body + faces)", dh->N, aff ? ",affine" : "", sm);
     else std::snprintf(plan->last_kernel, sizeof(plan->last_kernel), "d4est_hip::faces_direct_kernel<%d,%d,vol%s%s> (faces + stiffness_wave_eo body)", dh->N, dh->NQ, aff ? ",affine" : "", sm);
   }
@@ -746,7 +771,7 @@ static void launch_direct_core(d4est_hip_plan* plan, DirectHost* dh, const Bucke
   }
   const DirectFuse cfv = cf ? *cf : DirectFuse{};
   bool done = false;
-  if (vmode == 1 && vol.stream) vmode = 9;   // stream mode (plan->stream_mode): the twin with non-temporal metric / factor loads and A u stores
+  if (vmode == 1 && (vol.stream & 1)) vmode = 9;   // stream mode (plan->stream_mode): the twin with non-temporal metric / factor loads and A u stores
   if (dh->hang) {
     if (!(vmode == 1 || vmode == 9)) D4EST_HIP_ABORT("direct face kernel: the hanging-aware form exists for the plain whole operator only (vmode %d)", vmode);
     vmode |= 16;
