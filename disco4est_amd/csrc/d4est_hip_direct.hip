@@ -1011,9 +1011,14 @@ const char* hybrid_path(const d4est_hip_plan* plan) { return hybrid_of(plan)->pa
 // term is added after the kernels on this path)
 bool hybrid_can_fuse_update(const d4est_hip_plan* plan) {
   const HybridHost* hh = hybrid_of(plan);
-  if (!hh || !hybrid_active(plan) || !hh->hang || hh->n_dirty != 0) return false;
+  if (!hh || !hybrid_active(plan)) return false;
   if (plan->d_lhs_coeff || lhs_extra_term(plan)) return false;
-  if (!faces_have_units(const_cast<d4est_hip_plan*>(plan))) return false;
+  d4est_hip_plan* p = const_cast<d4est_hip_plan*>(plan);
+  // ... or, on a plan WITHOUT hanging faces (mixed degrees), in every clean bucket's kernel and in the flux kernels of the dirty list: each
+  // element's A u is final in exactly one of them (with hanging faces a dirty element's rows are finished by the record flux kernel)
+  if (!faces_hp(p)) return true;
+  if (!hh->hang || hh->n_dirty != 0) return false;
+  if (!faces_have_units(p)) return false;
   int n_launch = 0;
   for (const DirectHost* d : hh->dh)
     if (d) { ++n_launch; if (d->mw) return false; }
@@ -1068,7 +1073,7 @@ void launch_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* gh
       if (!hh->dh[b]) continue;
       HIP_CHECK(hipStreamWaitEvent(hh->side[i], hh->fork, 0));
       plan->stream = hh->side[i];
-      launch_direct_core(plan, hh->dh[b], plan->buckets[b], true, hh->d_qs_by_elem, u, ghost_trace, Au, nullptr, robin_c, robin_r, 1);
+      launch_direct_core(plan, hh->dh[b], plan->buckets[b], true, hh->d_qs_by_elem, u, ghost_trace, Au, cf, robin_c, robin_r, 1);
       plan->stream = main;
       HIP_CHECK(hipEventRecord(hh->done[i], hh->side[i]));
       ++i;

@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(384, 6) void flux_wave_kernel(const double* __restr
           const double pi = __dadd_rn(__dmul_rn(cf.beta, cf.p[o]), ri);
           if (cf.r) cf.r[o] = ri;
           cf.p[o] = pi;
-          cf.u[o] = __dadd_rn(cf.u[o], pi);
+          (cf.u_out ? cf.u_out : cf.u)[o] = __dadd_rn(cf.u[o], pi);   // (u_out: the hybrid operator's second vector -- its clean kernels read the neighbours' u)
         }
       }
     }
@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(192) void flux_mfma16_kernel(const double* __restri
         const double pi = __dadd_rn(__dmul_rn(cf.beta, pp_[c]), ri);
         if (cf.r) cf.r[o] = ri;
         cf.p[o] = pi;
-        cf.u[o] = __dadd_rn(uu_[c], pi);
+        (cf.u_out ? cf.u_out : cf.u)[o] = __dadd_rn(uu_[c], pi);
       }
       }
     }
@@ -2018,6 +2018,7 @@ struct FaceHost {
   // ... and the hybrid operator's ring / dirty lists of such a plan, split the same way (the list launches of the two families; without them
   // a listed launch sends every listed element through the tiled kernels: level 5, graded p = 3 ... 9, ring traces 396 us)
   const int *hy_ring = nullptr, *hy_dirty = nullptr;   // the hybrid operator's device lists these belong to (matched by pointer)
+  const int* hy_dirty_any = nullptr;                   // the hybrid operator's dirty list, family split or not (a fused update may ride on it)
   int *d_ring_small = nullptr, *d_ring_big = nullptr, *d_dirty_small = nullptr, *d_dirty_big = nullptr;
   int n_ring_small = 0, n_ring_big = 0, n_dirty_small = 0, n_dirty_big = 0;
 };
@@ -2650,7 +2651,7 @@ void faces_setup(d4est_hip_plan* plan) {
   (void)hipFree(fh.d_ring_small); (void)hipFree(fh.d_ring_big); (void)hipFree(fh.d_dirty_small); (void)hipFree(fh.d_dirty_big);
   fh.d_ring_small = fh.d_ring_big = fh.d_dirty_small = fh.d_dirty_big = nullptr;
   fh.n_ring_small = fh.n_ring_big = fh.n_dirty_small = fh.n_dirty_big = 0;
-  fh.hy_ring = fh.hy_dirty = nullptr;
+  fh.hy_ring = fh.hy_dirty = fh.hy_dirty_any = nullptr;
   if (!plan->direct && ne > 0 && plan->n_ghost == 0 && plan->tuning[D4EST_HIP_TUNE_HYBRID] != 0 && plan->tuning[D4EST_HIP_TUNE_GHOST_ALIAS] <= 0 &&
       plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 0 && plan->tuning[D4EST_HIP_TUNE_FLUX_FAST] != 1 && (hp ? (fh.hp_split || (fh.hp_max_N <= 16 && fh.hp_max_NQ <= 16)) : (fast || (fh.max_N <= 16 && fh.max_NQ <= 16)))) {
     std::vector<char> bucket_ok(plan->buckets.size(), 0), clean(ne, 0);
@@ -2771,6 +2772,12 @@ void faces_setup(d4est_hip_plan* plan) {
       // (the flags describe the classification before the dominant-bucket rule demoted anybody: a label, not a contract)
       hybrid_setup(plan, clean, pC, pCD, pE, any_ov ? &ov : nullptr,
                    any_hang_ov ? (any_mixed_ov ? "hanging-aware, mixed-aware" : "hanging-aware") : "mixed-aware");
+      {
+        const int *dd0, *dr0;
+        int nd0, nr0;
+        hybrid_lists(plan, &dd0, &nd0, &dr0, &nr0);
+        fh.hy_dirty_any = dd0;
+      }
       if (fh.family_split) {
         std::vector<char> is_small(ne, 0);
         for (int e = 0; e < ne; ++e) {
@@ -3328,14 +3335,15 @@ bool flux_can_fuse_update(d4est_hip_plan* plan) {
 void launch_flux(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf, const int* elist,
                  int n_list, int parts) {
   FaceHost& fh = g_face_host[plan];
-  if (cf && !flux_can_fuse_update(plan)) D4EST_HIP_ABORT("launch_flux: fused update requested on a plan whose flux kernel cannot carry it");
+  if (cf && !(flux_can_fuse_update(plan) || (elist && hybrid_active(plan) && !fh.hp))) D4EST_HIP_ABORT("launch_flux: fused update requested on a plan whose flux kernel cannot carry it");
   if (!plan->has_faces || !plan->has_face_geometry) D4EST_HIP_ABORT("apply flux: plan_set_faces / plan_set_mortar_geometry were not called");
   if (plan->n_elements == 0) return;
   if (fh.n_ghost_sides > 0 && !ghost_trace) D4EST_HIP_ABORT("apply flux: plan has %d ghost sides but no ghost trace buffer was given", fh.n_ghost_sides);
   const int n = elist ? n_list : plan->n_elements;
   if (parts != 3 && !(fh.hp && fh.hp_split)) D4EST_HIP_ABORT("launch_flux: parts = %d on a plan without the hp split", parts);
   if (n == 0 && !(fh.hp && fh.hp_split && (parts & 2))) return;
-  if (elist && cf) D4EST_HIP_ABORT("launch_flux: a fused update cannot ride on an element list");
+  // (a fused update on a list: the hybrid operator's dirty elements only -- cf->u_out set, see apply_operator)
+  if (elist && cf && !(elist == fh.hy_dirty_any && cf->u_out)) D4EST_HIP_ABORT("launch_flux: a fused update cannot ride on this element list");
   // the two conforming families' lists of this launch: the whole plan's, or the hybrid operator's dirty list split the same way
   const bool fam = fh.family_split && (!elist || (elist == fh.hy_dirty && fh.d_dirty_small));
   const int* fam_small = elist ? fh.d_dirty_small : fh.d_fam_small;
@@ -3489,6 +3497,7 @@ void launch_flux_units(d4est_hip_plan* plan, const double* trace, const double* 
   else go(flux_unit_kernel<true, 16>, 2);
   HIP_CHECK(hipGetLastError());
 }
+bool faces_hp(d4est_hip_plan* plan) { return g_face_host[plan].hp; }
 bool faces_hp_split(d4est_hip_plan* plan) {
   FaceHost& fh = g_face_host[plan];
   return fh.hp && fh.hp_split;

@@ -250,6 +250,7 @@ double* hybrid_second_vector(d4est_hip_plan* plan);
 // the record flux kernel of an hp-split plan alone, optionally with the Chebyshev update of the elements it serves in its epilogue
 void launch_flux_units(d4est_hip_plan* plan, const double* trace, const double* ghost_trace, double* Au, const ChebyFuse* cf);
 bool faces_have_units(d4est_hip_plan* plan);
+bool faces_hp(d4est_hip_plan* plan);         // the plan has hanging faces (mortar records)
 bool faces_hp_split(d4est_hip_plan* plan);   // the plan has record kernels beside the conforming ones (launch_traces / launch_flux take `parts`)   // hp split with the unit record kernels (the form that can carry the update)
 void launch_hybrid_dirty_stiffness(d4est_hip_plan* plan, const double* u, double* Au);
 void launch_flux_hybrid_clean(d4est_hip_plan* plan, const double* u, const double* ghost_trace, double* Au, int phase, const DirectFuse* cf = nullptr);   // (faces.hip: supplies the Robin arrays; phase 0 fork + launches, 1 join)

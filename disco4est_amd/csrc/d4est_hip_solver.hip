@@ -161,8 +161,27 @@ void apply_operator(d4est_hip_plan* plan, const double* u, double* Au, const Che
     const int *dirty, *ring;
     int n_dirty, n_ring;
     hybrid_lists(plan, &dirty, &n_dirty, &ring, &n_ring);
-    if (cf && !(hybrid_hanging(plan) && hybrid_can_fuse_update(plan)))
+    if (cf && !hybrid_can_fuse_update(plan))
       D4EST_HIP_ABORT("apply_operator: the hybrid operator of this plan does not carry a fused update");
+    if (cf && !faces_hp(plan)) {
+      // conforming mixed-degree plan: the update in every clean bucket's kernel and in the flux kernels of the dirty list (each element's
+      // A u is final in exactly one of them); all of them read u and write the new iterate to cf->u_out
+      if (!cf->u_out || cf->u_out == u) D4EST_HIP_ABORT("apply_operator: the hybrid operator needs a second vector for the fused update");
+      DirectFuse df;
+      df.rhs = cf->rhs; df.p = cf->p; df.u_out = cf->u_out; df.r = cf->r; df.alpha = cf->alpha; df.beta = cf->beta;
+      df.skip_Au_store = cf->skip_Au_store ? 1 : 0;
+      const double* gt = hybrid_hanging(plan) ? plan->d_trace : plan->d_ghost_trace;   // (mixed-aware sides read the trace array)
+      if (n_dirty > 0) launch_traces(plan, u, plan->d_trace, false, ring, n_ring);
+      launch_flux_hybrid_clean(plan, u, gt, Au, 0, &df);
+      if (n_dirty > 0) {
+        launch_hybrid_dirty_stiffness(plan, u, Au);
+        ChebyFuse cu = *cf;
+        cu.u = const_cast<double*>(u);
+        launch_flux(plan, plan->d_trace, plan->d_ghost_trace, Au, &cu, dirty, n_dirty);
+      }
+      launch_flux_hybrid_clean(plan, u, gt, Au, 1, &df);
+      return;
+    }
     if (hybrid_hanging(plan) && cf) {
       // the Chebyshev update in the kernels' epilogues: the operator kernel updates every element it finishes, the record flux kernel
       // the elements with a record side (disjoint sets; both read u and write the new iterate to cf->u_out)
@@ -377,7 +396,7 @@ void cheby_iterate(d4est_hip_plan* plan, double* u, const double* rhs, double* A
     HIP_CHECK(hipMemsetAsync(plan->d_work_d, 0, std::max<size_t>((size_t)plan->local_nodes, 1) * sizeof(double), plan->stream));
     apply_operator(plan, plan->d_work_d, plan->d_work_r);
     if (direct_active(plan)) (void)direct_second_vector(plan);   // the second iterate vector of the fused update
-    if (hybrid_active(plan) && hybrid_hanging(plan) && hybrid_can_fuse_update(plan)) (void)hybrid_second_vector(plan);
+    if (hybrid_active(plan) && hybrid_can_fuse_update(plan)) (void)hybrid_second_vector(plan);
     HIP_CHECK(hipStreamSynchronize(plan->stream));
     hipGraph_t g = nullptr;
     HIP_CHECK(hipStreamBeginCapture(plan->stream, hipStreamCaptureModeThreadLocal));
@@ -398,7 +417,7 @@ static void cheby_iterate_body(d4est_hip_plan* plan, double* u, const double* rh
   double alpha = 0.0, beta = 0.0;
   HIP_CHECK(hipMemsetAsync(plan->d_work_p, 0, std::max<size_t>((size_t)n, 1) * sizeof(double), plan->stream));
   // (the hybrid operator in its hanging-aware form carries the update in the operator kernel and the record flux kernel: hybrid_can_fuse_update)
-  const bool fuse_hy = plan->tuning[D4EST_HIP_TUNE_FUSE_UPDATE] != 0 && hybrid_active(plan) && hybrid_hanging(plan) && hybrid_can_fuse_update(plan);
+  const bool fuse_hy = plan->tuning[D4EST_HIP_TUNE_FUSE_UPDATE] != 0 && hybrid_active(plan) && hybrid_can_fuse_update(plan);
   const bool fuse = fuse_hy || (plan->tuning[D4EST_HIP_TUNE_FUSE_UPDATE] != 0 && flux_can_fuse_update(plan));
   // the direct face kernel reads the neighbours' u, so its fused update writes the new iterate to a second vector: the iterates
   // alternate between the caller's u and a plan-owned one (copied back after an odd number of iterations)

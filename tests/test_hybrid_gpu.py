@@ -342,3 +342,39 @@ def test_hybrid_chebyshev_graph_replay(gpu, hiplib, kind):
         out[graph] = (x.clone(), r.clone())
         p.destroy()
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("kind", ["mixed_p_2_5", "mixed_p_3_8_9"])
+@pytest.mark.parametrize("iters", [4, 5])
+def test_hybrid_chebyshev_fused_update_on_mixed_degrees(gpu, hiplib, oracle, kind, iters):
+    """cheby_iterate on the hybrid operator of a conforming mixed-degree plan: the update rides in every clean bucket's whole-operator
+    kernel (single-wave and multi-wave instances, side streams) and in the flux kernels of the dirty list, iterates alternating between
+    two vectors -- against the oracle's recurrence and against the separate update kernel (tuning key 10 = 0)"""
+    import torch
+    from disco4est_amd import mesh as M
+    m = _mesh(kind)
+    mp = M.SineMap(0.03)
+    J, rst = m.geometry(mp); sides = m.build_sides(mp)
+    oracle.set_operator(m, J, rst, sides, 10.0, 0, threads=8)
+    oracle.set_lhs_coefficient(None); oracle.set_lhs_element_blocks(None)
+    rhs = M.splitmix64_uniform(5, m.local_nodes) - 0.5
+    u0 = M.splitmix64_uniform(6, m.local_nodes) - 0.5
+    lmax = 1.1 * oracle.cg_eigs(np.zeros(m.local_nodes), rhs, 8)[0]
+    lmin = lmax / 30.0
+    out = {}
+    for fuse in (-1, 0):
+        plan = _plan(m, J, rst, sides, 1)
+        assert plan.face_path().startswith("hybrid"), plan.face_path()
+        plan.set_tuning(10, fuse)
+        for flag in (0, 1):
+            ref_u, ref_r = oracle.cheby_iterate(u0.copy(), rhs, iters, lmin, lmax, flag)
+            x = _t(u0, gpu); Au = torch.full_like(x, float("nan")); r = torch.full_like(x, float("nan"))
+            plan.cheby_iterate(x, _t(rhs, gpu), Au, r, iters, lmin, lmax, flag)
+            assert _rel(x.cpu().numpy(), ref_u) <= 1e-11
+            assert np.abs(r.cpu().numpy() - ref_r).max() <= 1e-11 * np.abs(rhs).max()
+            assert np.isfinite(Au.cpu().numpy()).all()
+            out[(fuse, flag)] = (x.cpu().numpy(), r.cpu().numpy(), Au.cpu().numpy())
+        plan.destroy()
+    for flag in (0, 1):
+        for a, b in zip(out[(-1, flag)], out[(0, flag)]):
+            assert _rel(a, b) <= 1e-13
