@@ -90,7 +90,7 @@ enum d4est_hip_tuning_key {
   D4EST_HIP_TUNE_FACE_DIRECT = 11,       /* 0: apply_aij / apply_lhs / the smoothers always run the two-phase face kernels (traces, then flux); default: conforming plans with one degree, deg_quad <= 7 and at least 768 elements (below that the two-phase kernels, with several wavefronts per element, are faster on the mostly empty chip) run the single-wavefront kernel that forms both sides' traces from u itself (no trace arrays; with ghost sides the trace kernel still feeds the exchange); 1: that kernel for the face terms only, the volume kernel separately, whatever the size; 2: the whole operator in that one kernel where deg_quad = deg (else as 1), whatever the size -- the default picks this form too.  Conforming plans with one degree deg = deg_quad = 8 ... 15 have the multi-wave form of that kernel (one workgroup per element: volume term, then the trace-free face terms; d4est_hip_direct_mw.hip), which is the default at EVERY size; values 0 / 1 / 2 select as above */
   D4EST_HIP_TUNE_STREAM = 12,            /* stream mode of the volume kernels with more than 8192 elements or deg >= 8, and of the p = 8 ... 15 whole-operator kernel: the data an apply reads or writes exactly once (metric, mortar factors, A u) moves with the non-temporal hint. default (-1): on when metric + u + A u of one apply exceed 320 MB (they then do not fit the 256 MB Infinity Cache, and keeping them out of the caches leaves those to u: level 5, p = 7 stiffness 191 -> 156 us); 0 / 1 force it off / on.  Same numbers either way */
   D4EST_HIP_TUNE_HP_SPLIT = 13,          /* set before plan_set_faces.  Plans with hanging faces, every deg and deg_quad <= 7 (any number of ranks): 0 every side through the tiled mortar-record kernels; 1 the conforming sides of the whole mesh AND the small sides of the hanging faces (one mortar each, the hanging factor folded into the geometric factors) through the fast conforming face kernels, only the big sides (four mortars) through the record kernels; default (-1): that split unless more than half of the elements would stay with the record kernels (level-4 brick, p = 7, every 64th ... every 3rd octant refined: apply_aij 203 -> 139 ... 661 -> 448 us).  Round 4: plans with degrees up to 15 take the split too (their conforming sides through the tiled conforming kernels, on the two family lists where the plan has them), and the record kernels run in their unit form (a side's sub-mortar records on four wavefronts); environment D4EST_HIP_HP_SPLIT_FAST_ONLY=1 / D4EST_HIP_NO_HANG_UNITS=1 restore round 3's forms */
-  D4EST_HIP_TUNE_HYBRID = 14,            /* set before plan_set_faces.  Mixed-degree and locally refined plans (one rank): 0 every element through the two-phase kernels; CLEAN elements -- deg_quad = deg <= 15 and all six sides conforming against a local element of the same degree or the domain boundary -- get the whole operator from the trace-free one-kernel path of their degree (faces_direct_kernel / operator_mw_kernel over an element list), only the rest runs traces + volume + flux, on lists.  default (-1): where that was measured to pay -- the clean elements are one degree bucket and at least half of the mesh (locally refined meshes of one degree: level 4, p = 7, every 64th octant refined, apply_aij 144 -> 125 us); with several clean buckets the largest one is kept where it holds at least half of the mesh (one dominant degree; the others' elements stay two-phase) -- or, at size (at least 2048 clean elements per clean bucket), every bucket --, else every bucket would be its own latency-structured launch and the two-phase kernels win at these sizes; 1: whenever there is a clean element.  Same operator either way (tests/test_hybrid_gpu.py).  Hanging-aware form (plans under the hp split with every degree <= 7; environment D4EST_HIP_HYBRID_NO_HANGING=1 switches it off): a hanging side does not make an element dirty -- big sides stay with the record kernels, small sides read the big element's sub-mortar block from the trace array and export their own; on a locally refined mesh of one degree EVERY element then takes the one-kernel path (level 4, p = 7, every 64th octant refined: 125 -> 81 us) and cheby_iterate carries its update in the operator kernel and the record flux kernel */
+  D4EST_HIP_TUNE_HYBRID = 14,            /* set before plan_set_faces.  Mixed-degree and locally refined plans (one rank): 0 every element through the two-phase kernels; CLEAN elements -- deg_quad = deg <= 15 and all six sides conforming against a local element of the same degree or the domain boundary -- get the whole operator from the trace-free one-kernel path of their degree (faces_direct_kernel / operator_mw_kernel over an element list), only the rest runs traces + volume + flux, on lists.  default (-1): where that was measured to pay -- the clean elements are one degree bucket and at least half of the mesh (locally refined meshes of one degree: level 4, p = 7, every 64th octant refined, apply_aij 144 -> 125 us); with several clean buckets the largest one is kept where it holds at least half of the mesh (one dominant degree; the others' elements stay two-phase) -- or, at size (at least 2048 clean elements per clean bucket), every bucket --, else every bucket would be its own latency-structured launch and the two-phase kernels win at these sizes; 1: whenever there is a clean element.  Same operator either way (tests/test_hybrid_gpu.py).  Hanging-aware form (plans under the hp split, elements with deg <= 7; environment D4EST_HIP_HYBRID_NO_HANGING=1 switches it off; mixed-aware form likewise for a conforming side against a lower-degree neighbour, D4EST_HIP_HYBRID_NO_MIXED=1): a hanging side does not make an element dirty -- big sides stay with the record kernels, small sides read the big element's sub-mortar block from the trace array and export their own; on a locally refined mesh of one degree EVERY element then takes the one-kernel path (level 4, p = 7, every 64th octant refined: 125 -> 81 us) and cheby_iterate carries its update in the operator kernel and the record flux kernel */
   D4EST_HIP_TUNE_COUNT = 15
 };
 void d4est_hip_plan_set_tuning(d4est_hip_plan_t* plan, int key, int value);
