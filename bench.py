@@ -930,7 +930,19 @@ def main():
                         p8.set_tuning(14, k14); p8.set_geometry(J8, rst8); p8.set_tuning(7, 0); p8.set_faces(s8)
                         y8 = torch.empty_like(x8)
                         ms8 = time_region(lambda: p8.apply_aij(x8, y8), 10, stream, torch, warm=3)
-                        res8[key] = (ms8, y8, p8.face_path())
+                        ch8 = None
+                        if key == "default":   # the smoother at size: 5 Chebyshev iterations (update fused where the path carries it), gated
+                            try:
+                                rhs8 = torch.zeros_like(x8); r8 = torch.empty_like(x8); yc8 = torch.empty_like(x8)
+                                gc8 = None if args.no_check else gate_cheby(name + " cheby", p8, x8, rhs8, torch, 5, 1.0, 40.0)
+                                xc8 = x8.clone()
+                                ms_c8 = time_region(lambda: p8.cheby_iterate(xc8, rhs8, yc8, r8, 5, 1.0, 40.0, 0), 4, stream, torch, warm=1)
+                                ch8 = (ms_c8, gc8)
+                                del rhs8, r8, yc8, xc8
+                            except Exception as exc:
+                                log("%s cheby FAILED: %r" % (name, exc))
+                                ch8 = (None, "FAILED: " + repr(exc))
+                        res8[key] = (ms8, y8, p8.face_path(), ch8)
                         p8.destroy()
                     g8 = None
                     if "other" in res8:
@@ -946,6 +958,13 @@ def main():
                                  "traffic": (json.load(open(tf)) if os.path.exists(tf) else {}).get(name, {}).get("hbm_bytes_per_launch"),
                                  "parity_gate_rel_inf_vs_other_path": g8,
                                  "apply_aij_ms_other_path": res8["other"][0] if "other" in res8 else None}
+                    ch8 = res8["default"][3]
+                    if ch8 is not None:
+                        sec[name]["parity_gate_cheby_rel_inf"] = ch8[1]
+                        if ch8[0] is not None:
+                            sec[name]["cheby_5_iterations_ms"] = ch8[0]
+                            sec[name]["cheby_GDoF_per_s"] = 5 * m8.local_nodes / (ch8[0] * 1e-3) / 1e9
+                            sec[name]["cheby_roofline_frac_hbm"] = 5 * (by8 + CHEBY_VECTOR_BYTES_PER_DOF * m8.local_nodes) / (ch8[0] * 1e-3) / 1e9 / HBM_PEAK_GBS
                     del x8, res8
             if args.geometry != "sine":
                 try:
